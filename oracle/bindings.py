@@ -1,0 +1,258 @@
+"""TEST INFRASTRUCTURE ONLY: ctypes bindings of the two CPU checkers.
+
+* ``Oracle``  -- oracle/libme_oracle.so, this repository's plain-C restatement
+  (me_oracle.c); travels to the GPU box.
+* ``Ref``     -- oracle/_ref/libx265ref{8,10}.so, the reference's own sources
+  compiled by oracle/Makefile; exists only where /root/reference does.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+PARTITIONS = [(4, 4), (8, 8), (8, 4), (4, 8), (16, 16), (16, 8), (8, 16), (16, 12), (12, 16), (16, 4), (4, 16),
+              (32, 32), (32, 16), (16, 32), (32, 24), (24, 32), (32, 8), (8, 32),
+              (64, 64), (64, 32), (32, 64), (64, 48), (48, 64), (64, 16), (16, 64)]
+METHODS = {"dia": 0, "hex": 1, "umh": 2, "star": 3, "full": 4}
+
+
+def dtype_for(depth):
+    return np.uint8 if depth <= 8 else np.uint16
+
+
+def _p(arr, offset_elems=0):
+    """void* to element ``offset_elems`` of a numpy array (flat index)."""
+    return C.c_void_p(arr.ctypes.data + offset_elems * arr.itemsize)
+
+
+class MV(C.Structure):
+    _fields_ = [("x", C.c_int16), ("y", C.c_int16)]
+
+
+class MECtx(C.Structure):
+    _fields_ = [("depth", C.c_int), ("fenc_plane", C.c_void_p), ("fenc_stride", C.c_ssize_t),
+                ("ref_planes", C.c_void_p * 4), ("ref_stride", C.c_ssize_t), ("is_lowres", C.c_int),
+                ("cost", C.c_void_p), ("method", C.c_int), ("subme", C.c_int)]
+
+
+class MEStats(C.Structure):
+    _fields_ = [("sad_pixels", C.c_uint64), ("subpel_pixels", C.c_uint64),
+                ("sad_calls", C.c_uint32), ("subpel_calls", C.c_uint32)]
+
+
+def build_oracle():
+    import subprocess
+    subprocess.check_call(["make", "-C", HERE, "libme_oracle.so"], stdout=subprocess.DEVNULL)
+
+
+class Oracle:
+    """Plain-C restatement (oracle/me_oracle.c)."""
+
+    def __init__(self):
+        path = os.path.join(HERE, "libme_oracle.so")
+        if not os.path.exists(path):
+            build_oracle()
+        L = self.L = C.CDLL(path)
+        L.orc_me_search.restype = C.c_int
+        L.orc_me_search.argtypes = [C.POINTER(MECtx), C.c_ssize_t, C.c_int, C.c_int, MV, MV, MV, C.c_int,
+                                    C.c_void_p, C.c_int, C.POINTER(MV), C.c_void_p]
+        L.orc_subpel_compare.argtypes = [C.POINTER(MECtx), C.c_ssize_t, C.c_int, C.c_int, MV, C.c_int]
+        L.orc_lookahead_field.argtypes = [C.POINTER(MECtx), C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+        for n in ("orc_sad", "orc_satd", "orc_sa8d_inter"):
+            getattr(L, n).argtypes = [C.c_int, C.c_void_p, C.c_ssize_t, C.c_void_p, C.c_ssize_t, C.c_int, C.c_int]
+        self._tables = {}
+
+    def cost_table(self, qp):
+        if qp not in self._tables:
+            t = np.zeros(65535, np.uint16)
+            self.L.orc_cost_table(C.c_int(qp), _p(t))
+            self._tables[qp] = t
+        return self._tables[qp]
+
+    def sad(self, depth, a, ao, sa, b, bo, sb, w, h):
+        return self.L.orc_sad(depth, _p(a, ao), sa, _p(b, bo), sb, w, h)
+
+    def satd(self, depth, a, ao, sa, b, bo, sb, w, h):
+        return self.L.orc_satd(depth, _p(a, ao), sa, _p(b, bo), sb, w, h)
+
+    def sa8d_inter(self, depth, a, ao, sa, b, bo, sb, w, h):
+        return self.L.orc_sa8d_inter(depth, _p(a, ao), sa, _p(b, bo), sb, w, h)
+
+    def sad_x3(self, depth, fenc, r, offs, rs, w, h):
+        res = (C.c_int32 * 3)()
+        self.L.orc_sad_x3(depth, _p(fenc), _p(r, offs[0]), _p(r, offs[1]), _p(r, offs[2]), C.c_ssize_t(rs), w, h, res)
+        return list(res)
+
+    def sad_x4(self, depth, fenc, r, offs, rs, w, h):
+        res = (C.c_int32 * 4)()
+        self.L.orc_sad_x4(depth, _p(fenc), _p(r, offs[0]), _p(r, offs[1]), _p(r, offs[2]), _p(r, offs[3]),
+                          C.c_ssize_t(rs), w, h, res)
+        return list(res)
+
+    def pixelavg(self, depth, a, ao, sa, b, bo, sb, w, h):
+        dst = np.zeros((h, w), dtype_for(depth))
+        self.L.orc_pixelavg_pp(depth, _p(dst), C.c_ssize_t(w), _p(a, ao), C.c_ssize_t(sa), _p(b, bo), C.c_ssize_t(sb), w, h)
+        return dst
+
+    def luma_hpp(self, depth, src, so, ss, ci, w, h):
+        dst = np.zeros((h, w), dtype_for(depth))
+        self.L.orc_luma_hpp(depth, _p(src, so), C.c_ssize_t(ss), _p(dst), C.c_ssize_t(w), ci, w, h)
+        return dst
+
+    def luma_vpp(self, depth, src, so, ss, ci, w, h):
+        dst = np.zeros((h, w), dtype_for(depth))
+        self.L.orc_luma_vpp(depth, _p(src, so), C.c_ssize_t(ss), _p(dst), C.c_ssize_t(w), ci, w, h)
+        return dst
+
+    def luma_hps(self, depth, src, so, ss, ci, ext, w, h):
+        dst = np.zeros((h + (7 if ext else 0), w), np.int16)
+        self.L.orc_luma_hps(depth, _p(src, so), C.c_ssize_t(ss), _p(dst), C.c_ssize_t(w), ci, ext, w, h)
+        return dst
+
+    def luma_vsp(self, depth, src16, so, ss, ci, w, h):
+        dst = np.zeros((h, w), dtype_for(depth))
+        self.L.orc_luma_vsp(depth, _p(src16, so), C.c_ssize_t(ss), _p(dst), C.c_ssize_t(w), ci, w, h)
+        return dst
+
+    def lowres_core(self, depth, src, so, ss, w, h):
+        outs = [np.zeros((h, w), dtype_for(depth)) for _ in range(4)]
+        self.L.orc_lowres_core(depth, _p(src, so), _p(outs[0]), _p(outs[1]), _p(outs[2]), _p(outs[3]),
+                               C.c_ssize_t(ss), C.c_ssize_t(w), w, h)
+        return outs
+
+    def make_ctx(self, depth, fenc, fenc_origin, fenc_stride, refs, ref_origin, ref_stride, is_lowres, qp, method, subme):
+        ctx = MECtx()
+        ctx.depth = depth
+        ctx.fenc_plane = fenc.ctypes.data + fenc_origin * fenc.itemsize
+        ctx.fenc_stride = fenc_stride
+        for i in range(4):
+            r = refs[i] if i < len(refs) else refs[0]
+            ctx.ref_planes[i] = r.ctypes.data + ref_origin * r.itemsize
+        ctx.ref_stride = ref_stride
+        ctx.is_lowres = int(is_lowres)
+        ctx.cost = self.cost_table(qp).ctypes.data
+        ctx.method = method
+        ctx.subme = subme
+        ctx._keep = (fenc, refs)
+        return ctx
+
+    def me_search(self, ctx, off, w, h, mvmin, mvmax, qmvp, mvc, merange, stats=None):
+        out = MV()
+        cand = (MV * max(1, len(mvc)))(*[MV(*m) for m in mvc])
+        cost = self.L.orc_me_search(C.byref(ctx), off, w, h, MV(*mvmin), MV(*mvmax), MV(*qmvp), len(mvc),
+                                    C.cast(cand, C.c_void_p), merange, C.byref(out),
+                                    C.cast(C.pointer(stats), C.c_void_p) if stats is not None else None)
+        return (out.x, out.y), cost
+
+    def subpel_compare(self, ctx, off, w, h, qmv, cmp):
+        return self.L.orc_subpel_compare(C.byref(ctx), off, w, h, MV(*qmv), cmp)
+
+    def lookahead_field(self, ctx, wcu, hcu, merange, stats=None):
+        mvs = np.zeros((hcu * wcu, 2), np.int16)
+        costs = np.zeros(hcu * wcu, np.int32)
+        self.L.orc_lookahead_field(C.byref(ctx), wcu, hcu, merange, _p(mvs), _p(costs),
+                                   C.cast(C.pointer(stats), C.c_void_p) if stats is not None else None)
+        return mvs, costs
+
+
+def ref_available(depth=8):
+    return os.path.exists(os.path.join(HERE, "_ref", "libx265ref%d.so" % (8 if depth <= 8 else 10)))
+
+
+class Ref:
+    """The reference's own code (oracle/_ref), one instance per bit depth."""
+
+    def __init__(self, depth):
+        self.depth = depth
+        L = self.L = C.CDLL(os.path.join(HERE, "_ref", "libx265ref%d.so" % (8 if depth <= 8 else 10)))
+        L.ref_setup(depth)
+        L.ref_me_create.restype = C.c_void_p
+        self.h = C.c_void_p(L.ref_me_create())
+
+    def part(self, w, h):
+        return PARTITIONS.index((w, h))
+
+    def cost_table(self, qp):
+        t = np.zeros(65535, np.uint16)
+        self.L.ref_cost_table(qp, _p(t))
+        return t
+
+    def _cmp(self, name, a, ao, sa, b, bo, sb, w, h):
+        return getattr(self.L, name)(self.part(w, h), _p(a, ao), C.c_ssize_t(sa), _p(b, bo), C.c_ssize_t(sb))
+
+    def sad(self, a, ao, sa, b, bo, sb, w, h):
+        return self._cmp("ref_sad", a, ao, sa, b, bo, sb, w, h)
+
+    def satd(self, a, ao, sa, b, bo, sb, w, h):
+        return self._cmp("ref_satd", a, ao, sa, b, bo, sb, w, h)
+
+    def sa8d_inter(self, a, ao, sa, b, bo, sb, w, h):
+        return self._cmp("ref_sa8d_inter", a, ao, sa, b, bo, sb, w, h)
+
+    def sad_x3(self, fenc, r, offs, rs, w, h):
+        res = (C.c_int32 * 3)()
+        self.L.ref_sad_x3(self.part(w, h), _p(fenc), _p(r, offs[0]), _p(r, offs[1]), _p(r, offs[2]), C.c_ssize_t(rs), res)
+        return list(res)
+
+    def sad_x4(self, fenc, r, offs, rs, w, h):
+        res = (C.c_int32 * 4)()
+        self.L.ref_sad_x4(self.part(w, h), _p(fenc), _p(r, offs[0]), _p(r, offs[1]), _p(r, offs[2]), _p(r, offs[3]),
+                          C.c_ssize_t(rs), res)
+        return list(res)
+
+    def pixelavg(self, a, ao, sa, b, bo, sb, w, h):
+        dst = np.zeros((h, w), dtype_for(self.depth))
+        self.L.ref_pixelavg_pp(self.part(w, h), _p(dst), C.c_ssize_t(w), _p(a, ao), C.c_ssize_t(sa), _p(b, bo), C.c_ssize_t(sb))
+        return dst
+
+    def luma_hpp(self, src, so, ss, ci, w, h):
+        dst = np.zeros((h, w), dtype_for(self.depth))
+        self.L.ref_luma_hpp(self.part(w, h), _p(src, so), C.c_ssize_t(ss), _p(dst), C.c_ssize_t(w), ci)
+        return dst
+
+    def luma_vpp(self, src, so, ss, ci, w, h):
+        dst = np.zeros((h, w), dtype_for(self.depth))
+        self.L.ref_luma_vpp(self.part(w, h), _p(src, so), C.c_ssize_t(ss), _p(dst), C.c_ssize_t(w), ci)
+        return dst
+
+    def luma_hps(self, src, so, ss, ci, ext, w, h):
+        dst = np.zeros((h + (7 if ext else 0), w), np.int16)
+        self.L.ref_luma_hps(self.part(w, h), _p(src, so), C.c_ssize_t(ss), _p(dst), C.c_ssize_t(w), ci, ext)
+        return dst
+
+    def luma_vsp(self, src16, so, ss, ci, w, h):
+        dst = np.zeros((h, w), dtype_for(self.depth))
+        self.L.ref_luma_vsp(self.part(w, h), _p(src16, so), C.c_ssize_t(ss), _p(dst), C.c_ssize_t(w), ci)
+        return dst
+
+    def lowres_core(self, src, so, ss, w, h):
+        outs = [np.zeros((h, w), dtype_for(self.depth)) for _ in range(4)]
+        self.L.ref_lowres_core(_p(src, so), _p(outs[0]), _p(outs[1]), _p(outs[2]), _p(outs[3]),
+                               C.c_ssize_t(ss), C.c_ssize_t(w), w, h)
+        return outs
+
+    def me_config(self, fenc, fenc_origin, fenc_stride, qp, method, subme):
+        self._keep = fenc
+        self.L.ref_me_config(self.h, _p(fenc, fenc_origin), C.c_ssize_t(fenc_stride), qp, method, subme)
+
+    def me_search(self, off, w, h, refs, ref_origin, ref_stride, is_lowres, mvmin, mvmax, qmvp, mvc, merange):
+        planes = (C.c_void_p * 4)(*[refs[i if i < len(refs) else 0].ctypes.data + ref_origin * refs[0].itemsize
+                                    for i in range(4)])
+        i16 = lambda v: (C.c_int16 * 2)(*v)
+        cand = (C.c_int16 * max(2, 2 * len(mvc)))(*[c for m in mvc for c in m])
+        out = (C.c_int16 * 2)()
+        cost = self.L.ref_me_search(self.h, off, w, h, planes, ref_stride, int(is_lowres), i16(mvmin), i16(mvmax),
+                                    i16(qmvp), len(mvc), cand, merange, out)
+        return (out[0], out[1]), cost
+
+    def subpel_compare(self, off, w, h, plane, origin, stride, qmv, cmp):
+        return self.L.ref_me_subpel_compare(self.h, off, w, h, _p(plane, origin), stride, qmv[0], qmv[1], cmp)
+
+    def lookahead_field(self, fenc, refs, origin, stride, wcu, hcu, qp, method, subme, merange):
+        planes = (C.c_void_p * 4)(*[r.ctypes.data + origin * r.itemsize for r in refs])
+        mvs = np.zeros((hcu * wcu, 2), np.int16)
+        costs = np.zeros(hcu * wcu, np.int32)
+        self.L.ref_lookahead_field(_p(fenc, origin), planes, stride, wcu, hcu, qp, method, subme, merange, _p(mvs), _p(costs))
+        return mvs, costs

@@ -1,0 +1,225 @@
+/* TEST INFRASTRUCTURE ONLY -- see me_oracle.h. Plain-C restatement of the
+ * reference's ME path; the shipped HIP engine never links or calls this file. */
+#include "me_oracle.h"
+
+#include <stdlib.h>
+#include <string.h>
+#include <math.h>
+
+/* HEVC 8-tap luma interpolation taps; source/Lib/TLibCommon/TComRom.cpp:175-181 */
+static const int16_t orc_luma_filter[4][8] = {
+    {  0, 0,   0, 64,  0,   0, 0,  0 },
+    { -1, 4, -10, 58, 17,  -5, 1,  0 },
+    { -1, 4, -11, 40, 40, -11, 4, -1 },
+    {  0, 1,  -5, 17, 58, -10, 4, -1 },
+};
+
+/* lambda^2 for non-I slices per QP; source/Lib/TLibCommon/TComRom.cpp:529-541 */
+static const double orc_lambda2_non_I[70] = {
+    0.05231, 0.060686, 0.07646, 0.096333333, 0.151715667, 0.15292, 0.192666667, 0.242745, 0.382299,
+    0.385333333, 0.485489333, 0.611678333, 0.963333333, 0.970979, 1.223356667, 1.541333333, 2.427447667,
+    2.446714, 3.082666667, 3.883916667, 6.116785, 6.165333333, 7.767833333, 9.786856667, 15.41333333,
+    16.57137733, 22.183542, 29.5936, 39.357022, 52.19656867, 69.05173333, 91.14257667, 150.0651347,
+    157.8325333, 207.1422197, 271.4221573, 443.904, 447.4271947, 563.722941, 710.2464, 1118.567987,
+    1127.445883, 1420.4928, 1789.70878, 2818.614706, 2840.9856, 3579.41756, 4509.78353, 7102.464,
+    7158.83512, 9019.56706, 11363.9424, 14317.66967, 18039.13269, 22727.8821, 28635.33594, 36078.2611,
+    45455.7588, 57270.66508, 72156.51362, 90911.5068, 114541.3166, 144313.0101, 181822.992, 229082.6059,
+    288625.9859, 363645.9408, 458165.1574, 577251.9032, 727291.7952
+};
+
+/* optional trace of every full-pel SAD position (debugging aid for the tests) */
+static int64_t *orc_trace_buf; static int orc_trace_n, orc_trace_cap;
+void orc_trace_begin(int64_t *buf, int cap) { orc_trace_buf = buf; orc_trace_cap = cap; orc_trace_n = 0; }
+int orc_trace_end(void) { orc_trace_buf = 0; return orc_trace_n; }
+static inline void orc_trace(int64_t v) { if (orc_trace_buf) { if (orc_trace_n < orc_trace_cap) orc_trace_buf[orc_trace_n] = v; orc_trace_n++; } }
+
+#define PIXEL uint8_t
+#define FN(n) n##_8
+#include "me_oracle_impl.h"
+#undef PIXEL
+#undef FN
+
+#define PIXEL uint16_t
+#define FN(n) n##_16
+#include "me_oracle_impl.h"
+#undef PIXEL
+#undef FN
+
+/* partition enum order of source/common/primitives.h:65-73 */
+static const uint8_t orc_part_wh[25][2] = {
+    {4,4}, {8,8}, {8,4}, {4,8}, {16,16}, {16,8}, {8,16}, {16,12}, {12,16}, {16,4}, {4,16},
+    {32,32}, {32,16}, {16,32}, {32,24}, {24,32}, {32,8}, {8,32},
+    {64,64}, {64,32}, {32,64}, {64,48}, {48,64}, {64,16}, {16,64}
+};
+
+int orc_partition(int w, int h)
+{
+    for (int i = 0; i < 25; i++)
+        if (orc_part_wh[i][0] == w && orc_part_wh[i][1] == h)
+            return i;
+    return -1;
+}
+
+#define DISPATCH(depth, call8, call16) do { if ((depth) <= 8) { call8; } else { call16; } } while (0)
+
+int orc_sad(int depth, const void *a, intptr_t sa, const void *b, intptr_t sb, int w, int h)
+{
+    if (depth <= 8) return sad_8((const uint8_t*)a, sa, (const uint8_t*)b, sb, w, h);
+    return sad_16((const uint16_t*)a, sa, (const uint16_t*)b, sb, w, h);
+}
+
+int orc_satd(int depth, const void *a, intptr_t sa, const void *b, intptr_t sb, int w, int h)
+{
+    if (depth <= 8) return satd_8((const uint8_t*)a, sa, (const uint8_t*)b, sb, w, h);
+    return satd_16((const uint16_t*)a, sa, (const uint16_t*)b, sb, w, h);
+}
+
+int orc_sa8d_inter(int depth, const void *a, intptr_t sa, const void *b, intptr_t sb, int w, int h)
+{
+    if (depth <= 8) return sa8d_inter_8((const uint8_t*)a, sa, (const uint8_t*)b, sb, w, h);
+    return sa8d_inter_16((const uint16_t*)a, sa, (const uint16_t*)b, sb, w, h);
+}
+
+/* sad_x3 / sad_x4 share one 64-stride fenc block; pixel.cpp:111-156 */
+void orc_sad_x3(int depth, const void *fenc, const void *r0, const void *r1, const void *r2,
+                intptr_t rs, int w, int h, int32_t *res)
+{
+    res[0] = orc_sad(depth, fenc, 64, r0, rs, w, h);
+    res[1] = orc_sad(depth, fenc, 64, r1, rs, w, h);
+    res[2] = orc_sad(depth, fenc, 64, r2, rs, w, h);
+}
+
+void orc_sad_x4(int depth, const void *fenc, const void *r0, const void *r1, const void *r2, const void *r3,
+                intptr_t rs, int w, int h, int32_t *res)
+{
+    orc_sad_x3(depth, fenc, r0, r1, r2, rs, w, h, res);
+    res[3] = orc_sad(depth, fenc, 64, r3, rs, w, h);
+}
+
+void orc_pixelavg_pp(int depth, void *dst, intptr_t ds, const void *a, intptr_t sa, const void *b, intptr_t sb, int w, int h)
+{
+    DISPATCH(depth, pixelavg_8((uint8_t*)dst, ds, (const uint8_t*)a, sa, (const uint8_t*)b, sb, w, h),
+             pixelavg_16((uint16_t*)dst, ds, (const uint16_t*)a, sa, (const uint16_t*)b, sb, w, h));
+}
+
+void orc_luma_hpp(int depth, const void *src, intptr_t ss, void *dst, intptr_t ds, int ci, int w, int h)
+{
+    DISPATCH(depth, luma_hpp_8((const uint8_t*)src, ss, (uint8_t*)dst, ds, ci, w, h, depth),
+             luma_hpp_16((const uint16_t*)src, ss, (uint16_t*)dst, ds, ci, w, h, depth));
+}
+
+void orc_luma_vpp(int depth, const void *src, intptr_t ss, void *dst, intptr_t ds, int ci, int w, int h)
+{
+    DISPATCH(depth, luma_vpp_8((const uint8_t*)src, ss, (uint8_t*)dst, ds, ci, w, h, depth),
+             luma_vpp_16((const uint16_t*)src, ss, (uint16_t*)dst, ds, ci, w, h, depth));
+}
+
+void orc_luma_hps(int depth, const void *src, intptr_t ss, int16_t *dst, intptr_t ds, int ci, int ext, int w, int h)
+{
+    DISPATCH(depth, luma_hps_8((const uint8_t*)src, ss, dst, ds, ci, ext, w, h, depth),
+             luma_hps_16((const uint16_t*)src, ss, dst, ds, ci, ext, w, h, depth));
+}
+
+void orc_luma_vsp(int depth, const int16_t *src, intptr_t ss, void *dst, intptr_t ds, int ci, int w, int h)
+{
+    DISPATCH(depth, luma_vsp_8(src, ss, (uint8_t*)dst, ds, ci, w, h, depth),
+             luma_vsp_16(src, ss, (uint16_t*)dst, ds, ci, w, h, depth));
+}
+
+void orc_lowres_core(int depth, const void *src, void *d0, void *dh, void *dv, void *dc,
+                     intptr_t ss, intptr_t ds, int w, int h)
+{
+    DISPATCH(depth, lowres_core_8((const uint8_t*)src, (uint8_t*)d0, (uint8_t*)dh, (uint8_t*)dv, (uint8_t*)dc, ss, ds, w, h),
+             lowres_core_16((const uint16_t*)src, (uint16_t*)d0, (uint16_t*)dh, (uint16_t*)dv, (uint16_t*)dc, ss, ds, w, h));
+}
+
+/* bitcost.cpp:71-83 (bit-size estimate, float) and :47-54 (scale by
+ * sqrt(lambda2) in double, +0.5f, clamp to 65535, truncate) */
+void orc_cost_table(int qp, uint16_t *out)
+{
+    double lambda = sqrt(orc_lambda2_non_I[qp]);
+    float log2_2 = 2.0f / logf(2.0f);
+    for (int i = 0; i < 32768; i++)
+    {
+        float bits = (i == 0) ? 0.718f : logf((float)(i + 1)) * log2_2 + 1.718f;
+        double v = bits * lambda + 0.5f;
+        if (v > 65535.0) v = 65535.0;
+        uint16_t c = (uint16_t)v;
+        if (i < 32768 && 32767 + i < 65535) out[32767 + i] = c;
+        out[32767 - i] = c;
+    }
+}
+
+int orc_me_search(const orc_me_ctx *c, intptr_t off, int w, int h, orc_mv mvmin, orc_mv mvmax, orc_mv qmvp,
+                  int numc, const orc_mv *mvc, int merange, orc_mv *out, orc_me_stats *st)
+{
+    if (c->depth <= 8)
+        return me_search_8(c, off, w, h, mvmin, mvmax, qmvp, numc, mvc, merange, out, st);
+    return me_search_16(c, off, w, h, mvmin, mvmax, qmvp, numc, mvc, merange, out, st);
+}
+
+int orc_subpel_compare(const orc_me_ctx *c, intptr_t off, int w, int h, orc_mv qmv, int cmp)
+{
+    if (c->depth <= 8)
+    {
+        me_t_8 m;
+        memset(&m, 0, sizeof(m));
+        m.c = c; m.w = w; m.h = h; m.off = off; m.stride = c->ref_stride;
+        for (int y = 0; y < h; y++)
+            memcpy(m.fenc + 64 * y, (const uint8_t*)c->fenc_plane + off + y * c->fenc_stride, w);
+        return subpel_cmp_8(&m, qmv.x, qmv.y, cmp ? satd_8 : sad_8);
+    }
+    else
+    {
+        me_t_16 m;
+        memset(&m, 0, sizeof(m));
+        m.c = c; m.w = w; m.h = h; m.off = off; m.stride = c->ref_stride;
+        for (int y = 0; y < h; y++)
+            memcpy(m.fenc + 64 * y, (const uint16_t*)c->fenc_plane + off + y * c->fenc_stride, w * 2);
+        return subpel_cmp_16(&m, qmv.x, qmv.y, cmp ? satd_16 : sad_16);
+    }
+}
+
+static int16_t median3(int16_t a, int16_t b, int16_t c)
+{
+    /* slicetype.cpp:42-57 evaluates to the median of the three values */
+    int16_t lo = a < b ? a : b, hi = a < b ? b : a;
+    int16_t m = lo > c ? lo : c;
+    return m < hi ? m : hi;
+}
+
+/* slicetype.cpp:1401-1470 (ME part), visiting order of slicetype.cpp:1344,1356 */
+void orc_lookahead_field(const orc_me_ctx *c, int widthInCU, int heightInCU, int merange,
+                         orc_mv *mvs, int32_t *costs, orc_me_stats *st)
+{
+    for (int cuy = heightInCU - 1; cuy >= 0; cuy--)
+    {
+        for (int cux = widthInCU - 1; cux >= 0; cux--)
+        {
+            const int cuXY = cux + cuy * widthInCU;
+            const intptr_t pelOffset = 8 * cux + 8 * cuy * c->fenc_stride;
+            orc_mv mvmin, mvmax, mvc[4], mvp;
+            /* bounds pass through uint16 and land in int16 (slicetype.cpp:1427-1430) */
+            mvmin.x = (int16_t)(uint16_t)(-cux * 8 - 8);
+            mvmin.y = (int16_t)(uint16_t)(-cuy * 8 - 8);
+            mvmax.x = (int16_t)(uint16_t)((widthInCU - cux - 1) * 8 + 8);
+            mvmax.y = (int16_t)(uint16_t)((heightInCU - cuy - 1) * 8 + 8);
+            int numc = 0;
+            memset(mvc, 0, sizeof(mvc));
+            if (cux < widthInCU - 1) mvc[numc++] = mvs[cuXY + 1];
+            if (cuy < heightInCU - 1)
+            {
+                mvc[numc++] = mvs[cuXY + widthInCU];
+                if (cux > 0) mvc[numc++] = mvs[cuXY + widthInCU - 1];
+                if (cux < widthInCU - 1) mvc[numc++] = mvs[cuXY + widthInCU + 1];
+            }
+            if (numc <= 1) mvp = mvc[0];
+            else
+            {
+                mvp.x = median3(mvc[0].x, mvc[1].x, mvc[2].x);
+                mvp.y = median3(mvc[0].y, mvc[1].y, mvc[2].y);
+            }
+            costs[cuXY] = orc_me_search(c, pelOffset, 8, 8, mvmin, mvmax, mvp, numc, mvc, merange, &mvs[cuXY], st);
+        }
+    }
+}

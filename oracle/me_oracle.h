@@ -1,0 +1,90 @@
+/* TEST INFRASTRUCTURE ONLY -- CPU restatement of the reference's motion-estimation
+ * path in plain C. It is the checker for the HIP engine (tests/, smoke(), and the
+ * cpu_baseline leg of bench.py); the shipped library never links or calls it.
+ *
+ * Parity status: PINNED -- every function here is checked bit-for-bit against
+ * the reference's own code compiled in oracle/_ref (tests/test_oracle_vs_ref.py,
+ * when /root/reference is present) and against the golden vectors generated from
+ * that build and committed under tests/golden/ (tests/test_oracle_golden.py).
+ *
+ * All pixel pointers are to samples of `bytes_per_pixel` = 1 (8-bit) or 2
+ * (>8-bit, little-endian uint16); strides are in samples.
+ */
+#ifndef ME_ORACLE_H
+#define ME_ORACLE_H
+
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct { int16_t x, y; } orc_mv;
+
+enum { ORC_DIA = 0, ORC_HEX = 1, ORC_UMH = 2, ORC_STAR = 3, ORC_FULL = 4 };
+
+/* luma partition enum, same order as source/common/primitives.h:65-73 */
+int orc_partition(int w, int h); /* -1 when (w,h) is not an HEVC luma partition */
+
+/* ---- primitives (source/common/pixel.cpp, ipfilter.cpp) ---- */
+int  orc_sad(int depth, const void *a, intptr_t sa, const void *b, intptr_t sb, int w, int h);
+int  orc_satd(int depth, const void *a, intptr_t sa, const void *b, intptr_t sb, int w, int h);
+int  orc_sa8d_inter(int depth, const void *a, intptr_t sa, const void *b, intptr_t sb, int w, int h);
+void orc_sad_x3(int depth, const void *fenc, const void *r0, const void *r1, const void *r2,
+                intptr_t rs, int w, int h, int32_t *res);
+void orc_sad_x4(int depth, const void *fenc, const void *r0, const void *r1, const void *r2, const void *r3,
+                intptr_t rs, int w, int h, int32_t *res);
+void orc_pixelavg_pp(int depth, void *dst, intptr_t ds, const void *a, intptr_t sa, const void *b, intptr_t sb,
+                     int w, int h);
+void orc_luma_hpp(int depth, const void *src, intptr_t ss, void *dst, intptr_t ds, int coeffIdx, int w, int h);
+void orc_luma_vpp(int depth, const void *src, intptr_t ss, void *dst, intptr_t ds, int coeffIdx, int w, int h);
+void orc_luma_hps(int depth, const void *src, intptr_t ss, int16_t *dst, intptr_t ds, int coeffIdx, int isRowExt,
+                  int w, int h);
+void orc_luma_vsp(int depth, const int16_t *src, intptr_t ss, void *dst, intptr_t ds, int coeffIdx, int w, int h);
+void orc_lowres_core(int depth, const void *src, void *d0, void *dh, void *dv, void *dc,
+                     intptr_t ss, intptr_t ds, int w, int h);
+
+/* ---- BitCost (source/encoder/bitcost.cpp:34-83) ----
+ * out[i + 32767] = cost of MVD component i, i in [-32767, 32767] */
+void orc_cost_table(int qp, uint16_t *out);
+
+/* ---- classic MotionEstimate::motionEstimate (source/encoder/motion.cpp:549-1146) ---- */
+typedef struct
+{
+    int depth;                 /* bit depth: 8 or 10/12 */
+    const void *fenc_plane;    /* origin (pixel 0,0) of the padded source plane */
+    intptr_t fenc_stride;
+    const void *ref_planes[4]; /* [0] = full-pel plane origin; lowres: the 4 hpel planes */
+    intptr_t ref_stride;
+    int is_lowres;
+    const uint16_t *cost;      /* orc_cost_table output (65535 entries) */
+    int method;                /* ORC_* */
+    int subme;                 /* 0..7 */
+} orc_me_ctx;
+
+typedef struct
+{
+    uint64_t sad_pixels;    /* pixel-SADs evaluated at full-pel candidates */
+    uint64_t subpel_pixels; /* pixels compared at interpolated / satd positions */
+    uint32_t sad_calls;
+    uint32_t subpel_calls;
+} orc_me_stats;
+
+int orc_me_search(const orc_me_ctx *c, intptr_t pu_offset, int w, int h,
+                  orc_mv mvmin, orc_mv mvmax, orc_mv qmvp, int numc, const orc_mv *mvc,
+                  int merange, orc_mv *out, orc_me_stats *stats /* may be NULL, accumulated */);
+
+/* subpelCompare (motion.cpp:1651-1689): cmp 0 = sad, 1 = satd */
+int orc_subpel_compare(const orc_me_ctx *c, intptr_t pu_offset, int w, int h, orc_mv qmv, int cmp);
+
+/* ---- lookahead lowres MV field, ME part of EstimateRow::estimateCUCost
+ * (source/encoder/slicetype.cpp:1401-1470), 8x8 CUs visited bottom-right to
+ * top-left. mvs: 2*ncu int16, costs: ncu int32. */
+void orc_lookahead_field(const orc_me_ctx *c, int widthInCU, int heightInCU, int merange,
+                         orc_mv *mvs, int32_t *costs, orc_me_stats *stats);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,873 @@
+/* TEST INFRASTRUCTURE ONLY -- body of the CPU restatement, instantiated twice by
+ * me_oracle.c: once with PIXEL = uint8_t (8-bit) and once with uint16_t (>8-bit).
+ * Required macros: PIXEL, FN(name), SUM2_T (packed accumulator type is not used:
+ * the Hadamard transforms below are computed in plain int32, which is what the
+ * reference's SWAR arithmetic evaluates to -- source/common/pixel.cpp:181-252).
+ */
+
+/* ---------------- pixel primitives: source/common/pixel.cpp ---------------- */
+
+/* pixel.cpp:92-109 */
+static int FN(sad)(const PIXEL *a, intptr_t sa, const PIXEL *b, intptr_t sb, int w, int h)
+{
+    int sum = 0;
+    for (int y = 0; y < h; y++, a += sa, b += sb)
+        for (int x = 0; x < w; x++)
+            sum += abs((int)a[x] - (int)b[x]);
+    return sum;
+}
+
+/* 4x4 Hadamard of the difference block, sum of |coeff| (before the >>1);
+ * pixel.cpp:201-227 */
+static int FN(had4x4)(const PIXEL *a, intptr_t sa, const PIXEL *b, intptr_t sb)
+{
+    int d[4][4], t[4][4];
+    for (int i = 0; i < 4; i++)
+        for (int j = 0; j < 4; j++)
+            d[i][j] = (int)a[i * sa + j] - (int)b[i * sb + j];
+    for (int i = 0; i < 4; i++)
+    {
+        int s01 = d[i][0] + d[i][1], d01 = d[i][0] - d[i][1];
+        int s23 = d[i][2] + d[i][3], d23 = d[i][2] - d[i][3];
+        t[i][0] = s01 + s23; t[i][1] = s01 - s23;
+        t[i][2] = d01 + d23; t[i][3] = d01 - d23;
+    }
+    int sum = 0;
+    for (int j = 0; j < 4; j++)
+    {
+        int s01 = t[0][j] + t[1][j], d01 = t[0][j] - t[1][j];
+        int s23 = t[2][j] + t[3][j], d23 = t[2][j] - t[3][j];
+        sum += abs(s01 + s23) + abs(s01 - s23) + abs(d01 + d23) + abs(d01 - d23);
+    }
+    return sum;
+}
+
+/* satd table of pixel.cpp:817-841: widths that are multiples of 8 use 8x4 tiles
+ * (two 4x4 transforms summed, then >>1, pixel.cpp:230-252), widths 4 and 12 use
+ * 4x4 tiles (>>1 each, pixel.cpp:256-270). */
+static int FN(satd)(const PIXEL *a, intptr_t sa, const PIXEL *b, intptr_t sb, int w, int h)
+{
+    int total = 0;
+    if ((w & 7) == 0)
+    {
+        for (int r = 0; r < h; r += 4)
+            for (int c = 0; c < w; c += 8)
+                total += (FN(had4x4)(a + r * sa + c, sa, b + r * sb + c, sb) +
+                          FN(had4x4)(a + r * sa + c + 4, sa, b + r * sb + c + 4, sb)) >> 1;
+    }
+    else
+    {
+        for (int r = 0; r < h; r += 4)
+            for (int c = 0; c < w; c += 4)
+                total += FN(had4x4)(a + r * sa + c, sa, b + r * sb + c, sb) >> 1;
+    }
+    return total;
+}
+
+/* 8x8 Hadamard abs-sum without rounding; pixel.cpp:290-325 */
+static int FN(had8x8)(const PIXEL *a, intptr_t sa, const PIXEL *b, intptr_t sb)
+{
+    int m[8][8];
+    for (int i = 0; i < 8; i++)
+        for (int j = 0; j < 8; j++)
+            m[i][j] = (int)a[i * sa + j] - (int)b[i * sb + j];
+    for (int pass = 0; pass < 2; pass++)
+    {
+        for (int i = 0; i < 8; i++)
+        {
+            int v[8];
+            for (int j = 0; j < 8; j++) v[j] = pass ? m[j][i] : m[i][j];
+            for (int s = 1; s < 8; s <<= 1)
+                for (int j = 0; j < 8; j++)
+                    if (!(j & s)) { int p = v[j], q = v[j + s]; v[j] = p + q; v[j + s] = p - q; }
+            for (int j = 0; j < 8; j++) { if (pass) m[j][i] = v[j]; else m[i][j] = v[j]; }
+        }
+    }
+    int sum = 0;
+    for (int i = 0; i < 8; i++)
+        for (int j = 0; j < 8; j++)
+            sum += abs(m[i][j]);
+    return sum;
+}
+
+/* sa8d_inter table, pixel.cpp:929-953 with the satd aliases of primitives.cpp:138-144 */
+static int FN(sa8d_inter)(const PIXEL *a, intptr_t sa, const PIXEL *b, intptr_t sb, int w, int h)
+{
+    if ((w & 7) || (h & 7))
+        return FN(satd)(a, sa, b, sb, w, h);
+    int use16 = !(w & 15) && !(h & 15);
+    int cost = 0;
+    if (use16)
+    {
+        /* sa8d_16x16 rounds once per 16x16 (pixel.cpp:332-342) */
+        for (int y = 0; y < h; y += 16)
+            for (int x = 0; x < w; x += 16)
+            {
+                int s = 0;
+                for (int k = 0; k < 4; k++)
+                    s += FN(had8x8)(a + (y + (k >> 1) * 8) * sa + x + (k & 1) * 8, sa,
+                                    b + (y + (k >> 1) * 8) * sb + x + (k & 1) * 8, sb);
+                cost += (s + 2) >> 2;
+            }
+    }
+    else
+    {
+        for (int y = 0; y < h; y += 8)
+            for (int x = 0; x < w; x += 8)
+                cost += (FN(had8x8)(a + y * sa + x, sa, b + y * sb + x, sb) + 2) >> 2;
+    }
+    return cost;
+}
+
+/* pixel.cpp:546-560 */
+static void FN(pixelavg)(PIXEL *dst, intptr_t ds, const PIXEL *a, intptr_t sa, const PIXEL *b, intptr_t sb, int w, int h)
+{
+    for (int y = 0; y < h; y++, dst += ds, a += sa, b += sb)
+        for (int x = 0; x < w; x++)
+            dst[x] = (PIXEL)(((int)a[x] + (int)b[x] + 1) >> 1);
+}
+
+/* pixel.cpp:595-618: 2x downscale into the full-pel and the H / V / centre
+ * half-pel planes, nested rounding averages */
+static void FN(lowres_core)(const PIXEL *src0, PIXEL *d0, PIXEL *dh, PIXEL *dv, PIXEL *dc,
+                            intptr_t ss, intptr_t ds, int w, int h)
+{
+#define AVG4(a, b, c, d) (PIXEL)((((((int)(a) + (int)(b) + 1) >> 1) + (((int)(c) + (int)(d) + 1) >> 1) + 1) >> 1))
+    for (int y = 0; y < h; y++)
+    {
+        const PIXEL *s0 = src0 + 2 * y * ss, *s1 = s0 + ss, *s2 = s1 + ss;
+        for (int x = 0; x < w; x++)
+        {
+            d0[y * ds + x] = AVG4(s0[2 * x], s1[2 * x], s0[2 * x + 1], s1[2 * x + 1]);
+            dh[y * ds + x] = AVG4(s0[2 * x + 1], s1[2 * x + 1], s0[2 * x + 2], s1[2 * x + 2]);
+            dv[y * ds + x] = AVG4(s1[2 * x], s2[2 * x], s1[2 * x + 1], s2[2 * x + 1]);
+            dc[y * ds + x] = AVG4(s1[2 * x + 1], s2[2 * x + 1], s1[2 * x + 2], s2[2 * x + 2]);
+        }
+    }
+#undef AVG4
+}
+
+/* ---------------- interpolation: source/common/ipfilter.cpp ---------------- */
+
+static inline PIXEL FN(clip_pix)(int16_t v, int depth)
+{
+    int maxv = (1 << depth) - 1;
+    if (v < 0) v = 0;
+    if (v > maxv) v = (int16_t)maxv;
+    return (PIXEL)v;
+}
+
+/* ipfilter.cpp:194-233; note the int16 cast BEFORE the clip (ipfilter.cpp:223) */
+static void FN(luma_hpp)(const PIXEL *src, intptr_t ss, PIXEL *dst, intptr_t ds, int ci, int w, int h, int depth)
+{
+    const int16_t *c = orc_luma_filter[ci];
+    src -= 3;
+    for (int r = 0; r < h; r++, src += ss, dst += ds)
+        for (int x = 0; x < w; x++)
+        {
+            int sum = 0;
+            for (int k = 0; k < 8; k++) sum += (int)src[x + k] * c[k];
+            dst[x] = FN(clip_pix)((int16_t)((sum + 32) >> 6), depth);
+        }
+}
+
+/* ipfilter.cpp:280-319 */
+static void FN(luma_vpp)(const PIXEL *src, intptr_t ss, PIXEL *dst, intptr_t ds, int ci, int w, int h, int depth)
+{
+    const int16_t *c = orc_luma_filter[ci];
+    src -= 3 * ss;
+    for (int r = 0; r < h; r++, src += ss, dst += ds)
+        for (int x = 0; x < w; x++)
+        {
+            int sum = 0;
+            for (int k = 0; k < 8; k++) sum += (int)src[x + k * ss] * c[k];
+            dst[x] = FN(clip_pix)((int16_t)((sum + 32) >> 6), depth);
+        }
+}
+
+/* ipfilter.cpp:235-278 */
+static void FN(luma_hps)(const PIXEL *src, intptr_t ss, int16_t *dst, intptr_t ds, int ci, int isRowExt,
+                         int w, int h, int depth)
+{
+    const int16_t *c = orc_luma_filter[ci];
+    int headRoom = 14 - depth;
+    int shift = 6 - headRoom;
+    int offset = -(8192 << shift);
+    int rows = h;
+    src -= 3;
+    if (isRowExt) { src -= 3 * ss; rows += 7; }
+    for (int r = 0; r < rows; r++, src += ss, dst += ds)
+        for (int x = 0; x < w; x++)
+        {
+            int sum = 0;
+            for (int k = 0; k < 8; k++) sum += (int)src[x + k] * c[k];
+            dst[x] = (int16_t)((sum + offset) >> shift);
+        }
+}
+
+/* ipfilter.cpp:359-400 */
+static void FN(luma_vsp)(const int16_t *src, intptr_t ss, PIXEL *dst, intptr_t ds, int ci, int w, int h, int depth)
+{
+    const int16_t *c = orc_luma_filter[ci];
+    int headRoom = 14 - depth;
+    int shift = 6 + headRoom;
+    int offset = (1 << (shift - 1)) + (8192 << 6);
+    src -= 3 * ss;
+    for (int r = 0; r < h; r++, src += ss, dst += ds)
+        for (int x = 0; x < w; x++)
+        {
+            int sum = 0;
+            for (int k = 0; k < 8; k++) sum += (int)src[x + k * ss] * c[k];
+            dst[x] = FN(clip_pix)((int16_t)((sum + offset) >> shift), depth);
+        }
+}
+
+/* ---------------- motion search: source/encoder/motion.cpp ---------------- */
+
+typedef struct
+{
+    const orc_me_ctx *c;
+    PIXEL fenc[64 * 64];      /* FENC_STRIDE 64 cache, motion.cpp:116-142 */
+    int w, h, part;
+    intptr_t off;
+    const PIXEL *fref;        /* ref_planes[0] + off */
+    intptr_t stride;
+    const uint16_t *cost;     /* centred */
+    int mvpx, mvpy;
+    orc_me_stats *st;
+} FN(me_t);
+
+static inline int FN(mvcost)(const FN(me_t) *m, int x, int y)
+{
+    /* bitcost.h:46: the sum of the two table entries is truncated to uint16 */
+    return (uint16_t)(m->cost[x - m->mvpx] + m->cost[y - m->mvpy]);
+}
+
+static inline int FN(fpsad)(FN(me_t) *m, int mx, int my)
+{
+    if (m->st) { m->st->sad_pixels += (uint64_t)m->w * m->h; m->st->sad_calls++; }
+    orc_trace((int64_t)(m->off + mx + my * m->stride));
+    return FN(sad)(m->fenc, 64, m->fref + mx + my * m->stride, m->stride, m->w, m->h);
+}
+
+typedef int (*FN(cmp_t))(const PIXEL *, intptr_t, const PIXEL *, intptr_t, int, int);
+
+/* motion.cpp:1651-1689 */
+static int FN(subpel_cmp)(FN(me_t) *m, int qx, int qy, FN(cmp_t) cmp)
+{
+    int xFrac = qx & 3, yFrac = qy & 3;
+    int mvX = qx >> 2, mvY = qy >> 2;
+    int depth = m->c->depth;
+    const PIXEL *fref = (const PIXEL*)m->c->ref_planes[0] + m->off + mvX + mvY * m->stride;
+    if (m->st) { m->st->subpel_pixels += (uint64_t)m->w * m->h; m->st->subpel_calls++; }
+    if (cmp == FN(sad))
+        orc_trace((xFrac | yFrac) ? -1 : (int64_t)(m->off + mvX + mvY * m->stride));
+    if ((xFrac | yFrac) == 0)
+        return cmp(m->fenc, 64, fref, m->stride, m->w, m->h);
+    PIXEL buf[64 * 64];
+    if (yFrac == 0)
+        FN(luma_hpp)(fref, m->stride, buf, 64, xFrac, m->w, m->h, depth);
+    else if (xFrac == 0)
+        FN(luma_vpp)(fref, m->stride, buf, 64, yFrac, m->w, m->h, depth);
+    else
+    {
+        int16_t immed[64 * (64 + 8)];
+        FN(luma_hps)(fref, m->stride, immed, m->w, xFrac, 1, m->w, m->h, depth);
+        FN(luma_vsp)(immed + 3 * m->w, m->w, buf, 64, yFrac, m->w, m->h, depth);
+    }
+    return cmp(m->fenc, 64, buf, 64, m->w, m->h);
+}
+
+/* lowres.h:78-97: half-pel planes are precomputed, quarter-pel = rounding average
+ * of the two nearest half-pel planes, always on an 8x8 block */
+static int FN(lowres_cost)(FN(me_t) *m, int qx, int qy, FN(cmp_t) cmp)
+{
+    const orc_me_ctx *c = m->c;
+    if (m->st) { m->st->subpel_pixels += (uint64_t)m->w * m->h; m->st->subpel_calls++; }
+    int hpelA = (qy & 2) | ((qx & 2) >> 1);
+    const PIXEL *frefA = (const PIXEL*)c->ref_planes[hpelA] + m->off + (qx >> 2) + (qy >> 2) * m->stride;
+    if ((qx | qy) & 1)
+    {
+        PIXEL buf[8 * 8];
+        int16_t bx = (int16_t)(qx + (qx & 1) * 2), by = (int16_t)(qy + (qy & 1) * 2);
+        int hpelB = (by & 2) | ((bx & 2) >> 1);
+        const PIXEL *frefB = (const PIXEL*)c->ref_planes[hpelB] + m->off + (bx >> 2) + (by >> 2) * m->stride;
+        FN(pixelavg)(buf, 8, frefA, m->stride, frefB, m->stride, 8, 8);
+        return cmp(m->fenc, 64, buf, 8, m->w, m->h);
+    }
+    return cmp(m->fenc, 64, frefA, m->stride, m->w, m->h);
+}
+
+static inline int FN(qcost)(FN(me_t) *m, int qx, int qy, FN(cmp_t) cmp)
+{
+    return m->c->is_lowres ? FN(lowres_cost)(m, qx, qy, cmp) : FN(subpel_cmp)(m, qx, qy, cmp);
+}
+
+#define S16(v) ((int16_t)(v))
+#define IN_RANGE(x, y) ((x) >= mnx && (x) <= mxx && (y) >= mny && (y) <= mxy)
+/* COST_MV (motion.cpp:196-202): full-pel candidate with strict-less update */
+#define TRY_MV_AT(sx, sy, mx, my) do { int _x = (mx), _y = (my); \
+        int _c = FN(fpsad)(m, (sx), (sy)) + FN(mvcost)(m, S16(_x << 2), S16(_y << 2)); \
+        if (_c < bcost) { bcost = _c; bmx = S16(_x); bmy = S16(_y); } } while (0)
+#define TRY_MV(mx, my) TRY_MV_AT(mx, my, mx, my)
+
+/* StarPatternSearch, motion.cpp:307-547. Returns through the pointers. */
+static void FN(star_pattern)(FN(me_t) *m, int mnx, int mny, int mxx, int mxy,
+                             int16_t *pbmx, int16_t *pbmy, int *pbcost, int *pPointNr, int *pDistance,
+                             int earlyExitIters, int merange)
+{
+    int16_t bmx = *pbmx, bmy = *pbmy;
+    int bcost = *pbcost, bPointNr = *pPointNr, bDistance = *pDistance;
+    const int16_t ox = bmx, oy = bmy;
+    int saved = bcost, rounds = 0;
+
+#define PT(mx, my, point, dist) do { int _x = S16(mx), _y = S16(my); \
+        int _c = FN(fpsad)(m, _x, _y) + FN(mvcost)(m, S16(_x << 2), S16(_y << 2)); \
+        if (_c < bcost) { bcost = _c; bmx = S16(_x); bmy = S16(_y); bPointNr = (point); bDistance = (dist); } } while (0)
+#define ROUND_END() do { if (bcost < saved) rounds = 0; else if (++rounds >= earlyExitIters) goto done; } while (0)
+
+    {
+        const int16_t dist = 1;
+        const int16_t top = S16(oy - dist), bottom = S16(oy + dist), left = S16(ox - dist), right = S16(ox + dist);
+        /* the all-inside branch visits the same 4 points in the same order (motion.cpp:338-363) */
+        if (top >= mny) PT(ox, top, 2, dist);
+        if (left >= mnx) PT(left, oy, 4, dist);
+        if (right <= mxx) PT(right, oy, 5, dist);
+        if (bottom <= mxy) PT(ox, bottom, 7, dist);
+        ROUND_END();
+    }
+
+    for (int16_t dist = 2; dist <= 8; dist <<= 1)
+    {
+        const int16_t top = S16(oy - dist), bottom = S16(oy + dist), left = S16(ox - dist), right = S16(ox + dist);
+        const int16_t top2 = S16(oy - (dist >> 1)), bottom2 = S16(oy + (dist >> 1));
+        const int16_t left2 = S16(ox - (dist >> 1)), right2 = S16(ox + (dist >> 1));
+        saved = bcost;
+        if (top >= mny && left >= mnx && right <= mxx && bottom <= mxy)
+        {
+            /* visit order of the two sad_x4 groups, motion.cpp:394-401 */
+            PT(ox, top, 2, dist);
+            PT(left2, top2, 1, dist >> 1);
+            PT(right2, top2, 3, dist >> 1);
+            PT(left, oy, 4, dist);
+            PT(right, oy, 5, dist);
+            PT(left2, bottom2, 6, dist >> 1);
+            PT(right2, bottom2, 8, dist >> 1);
+            PT(ox, bottom, 7, dist);
+        }
+        else
+        {
+            /* motion.cpp:405-442 */
+            if (top >= mny) PT(ox, top, 2, dist);
+            if (top2 >= mny)
+            {
+                if (left2 >= mnx) PT(left2, top2, 1, dist >> 1);
+                if (right2 <= mxx) PT(right2, top2, 3, dist >> 1);
+            }
+            if (left >= mnx) PT(left, oy, 4, dist);
+            if (right <= mxx) PT(right, oy, 5, dist);
+            if (bottom2 <= mxy)
+            {
+                if (left2 >= mnx) PT(left2, bottom2, 6, dist >> 1);
+                if (right2 <= mxx) PT(right2, bottom2, 8, dist >> 1);
+            }
+            if (bottom <= mxy) PT(ox, bottom, 7, dist);
+        }
+        ROUND_END();
+    }
+
+    for (int16_t dist = 16; dist <= (int16_t)merange; dist <<= 1)
+    {
+        const int16_t top = S16(oy - dist), bottom = S16(oy + dist), left = S16(ox - dist), right = S16(ox + dist);
+        saved = bcost;
+        if (top >= mny && left >= mnx && right <= mxx && bottom <= mxy)
+        {
+            PT(ox, top, 0, dist);
+            PT(left, oy, 0, dist);
+            PT(right, oy, 0, dist);
+            PT(ox, bottom, 0, dist);
+            for (int16_t index = 1; index < 4; index++)
+            {
+                int16_t posYT = S16(top + ((dist >> 2) * index)), posYB = S16(bottom - ((dist >> 2) * index));
+                int16_t posXL = S16(ox - ((dist >> 2) * index)), posXR = S16(ox + ((dist >> 2) * index));
+                PT(posXL, posYT, 0, dist);
+                PT(posXR, posYT, 0, dist);
+                PT(posXL, posYB, 0, dist);
+                PT(posXR, posYB, 0, dist);
+            }
+        }
+        else
+        {
+            if (top >= mny) PT(ox, top, 0, dist);
+            if (left >= mnx) PT(left, oy, 0, dist);
+            if (right <= mxx) PT(right, oy, 0, dist);
+            if (bottom <= mxy) PT(ox, bottom, 0, dist);
+            for (int16_t index = 1; index < 4; index++)
+            {
+                int16_t posYT = S16(top + ((dist >> 2) * index)), posYB = S16(bottom - ((dist >> 2) * index));
+                int16_t posXL = S16(ox - ((dist >> 2) * index)), posXR = S16(ox + ((dist >> 2) * index));
+                if (posYT >= mny)
+                {
+                    if (posXL >= mnx) PT(posXL, posYT, 0, dist);
+                    if (posXR <= mxx) PT(posXR, posYT, 0, dist);
+                }
+                if (posYB <= mxy)
+                {
+                    if (posXL >= mnx) PT(posXL, posYB, 0, dist);
+                    if (posXR <= mxx) PT(posXR, posYB, 0, dist);
+                }
+            }
+        }
+        ROUND_END();
+    }
+done:
+#undef PT
+#undef ROUND_END
+    *pbmx = bmx; *pbmy = bmy; *pbcost = bcost; *pPointNr = bPointNr; *pDistance = bDistance;
+}
+
+/* motion.cpp:549-1146 */
+static int FN(me_search)(const orc_me_ctx *c, intptr_t off, int w, int h, orc_mv mvmin, orc_mv mvmax, orc_mv qmvp,
+                         int numc, const orc_mv *mvc, int merange, orc_mv *out, orc_me_stats *st)
+{
+    static const int8_t hex2[8][2] = { {-1,-2}, {-2,0}, {-1,2}, {1,2}, {2,0}, {1,-2}, {-1,-2}, {-2,0} };
+    static const uint8_t mod6m1[8] = { 5, 0, 1, 2, 3, 4, 5, 0 };
+    static const int8_t square1[9][2] = { {0,0}, {0,-1}, {0,1}, {-1,0}, {1,0}, {-1,-1}, {-1,1}, {1,-1}, {1,1} };
+    static const int8_t hex4[16][2] = { {0,-4}, {0,4}, {-2,-3}, {2,-3}, {-4,-2}, {4,-2}, {-4,-1}, {4,-1},
+                                        {-4,0}, {4,0}, {-4,1}, {4,1}, {-4,2}, {4,2}, {-2,3}, {2,3} };
+    static const int8_t twopt[16][2] = { {-1,0}, {0,-1}, {-1,-1}, {1,-1}, {-1,0}, {1,0}, {-1,1}, {-1,-1},
+                                         {1,-1}, {1,1}, {-1,0}, {0,1}, {-1,1}, {1,1}, {1,0}, {0,1} };
+    /* SubpelWorkload, motion.cpp:53-63: hpel_iters, hpel_dirs, qpel_iters, qpel_dirs, hpel_satd */
+    static const int8_t workload[8][5] = { {1,4,0,4,0}, {1,4,1,4,0}, {1,4,1,4,1}, {2,4,1,4,1},
+                                           {2,4,2,4,1}, {1,8,1,8,1}, {2,8,1,8,1}, {2,8,2,8,1} };
+
+    FN(me_t) mm, *m = &mm;
+    m->c = c; m->w = w; m->h = h; m->off = off; m->st = st;
+    m->stride = c->ref_stride;
+    m->fref = (const PIXEL*)c->ref_planes[0] + off;
+    m->cost = c->cost + 32767;
+    m->mvpx = qmvp.x; m->mvpy = qmvp.y; /* setMVP, bitcost.h:43 */
+    {
+        const PIXEL *src = (const PIXEL*)c->fenc_plane + off;
+        for (int y = 0; y < h; y++)
+            memcpy(m->fenc + 64 * y, src + y * c->fenc_stride, w * sizeof(PIXEL));
+    }
+    const int mnx = mvmin.x, mny = mvmin.y, mxx = mvmax.x, mxy = mvmax.y;
+    const int16_t qmnx = S16(mnx << 2), qmny = S16(mny << 2), qmxx = S16(mxx << 2), qmxy = S16(mxy << 2);
+    int costs[16];
+
+#define CLIPQ_X(v) ((v) > qmxx ? qmxx : ((v) < qmnx ? qmnx : (v)))
+#define CLIPQ_Y(v) ((v) > qmxy ? qmxy : ((v) < qmny ? qmny : (v)))
+    /* clipped qpel predictor, motion.cpp:575-582 (no mvcost on the predictor itself) */
+    int16_t pmx = CLIPQ_X(qmvp.x), pmy = CLIPQ_Y(qmvp.y);
+    int16_t bpx = pmx, bpy = pmy;
+    int bprecost = FN(qcost)(m, pmx, pmy, FN(sad));
+
+    int16_t bmx = S16((pmx + 2) >> 2), bmy = S16((pmy + 2) >> 2);
+    int bcost = bprecost;
+    if ((pmx & 3) | (pmy & 3))
+        bcost = FN(fpsad)(m, bmx, bmy) + FN(mvcost)(m, S16(bmx << 2), S16(bmy << 2));
+
+    if (pmx | pmy)
+    {
+        int cost = FN(fpsad)(m, 0, 0) + FN(mvcost)(m, 0, 0);
+        if (cost < bcost) { bcost = cost; bmx = 0; bmy = 0; }
+    }
+
+    for (int i = 0; i < numc; i++)
+    {
+        int16_t cx = CLIPQ_X(mvc[i].x), cy = CLIPQ_Y(mvc[i].y);
+        if ((cx | cy) && !(cx == pmx && cy == pmy) && !(cx == bpx && cy == bpy))
+        {
+            int cost = FN(qcost)(m, cx, cy, FN(sad)) + FN(mvcost)(m, cx, cy);
+            if (cost < bprecost) { bprecost = cost; bpx = cx; bpy = cy; }
+        }
+    }
+
+    pmx = S16((pmx + 2) >> 2); pmy = S16((pmy + 2) >> 2);
+    int16_t omx = bmx, omy = bmy;
+
+    /* sad at (base + d) for a group, costs include mvcost of (cm + d) << 2 */
+#define GROUP_COST(k, basex, basey, cmx, cmy, dx, dy) \
+    costs[k] = FN(fpsad)(m, (basex) + (dx), (basey) + (dy)) + \
+               FN(mvcost)(m, S16(S16((cmx) + (dx)) << 2), S16(S16((cmy) + (dy)) << 2))
+#define LT1(a, b) do { if ((b) < (a)) (a) = (b); } while (0)
+
+    switch (c->method)
+    {
+    case ORC_DIA:
+    {
+        /* motion.cpp:628-649 */
+        bcost <<= 4;
+        int i = merange;
+        do
+        {
+            GROUP_COST(0, bmx, bmy, bmx, bmy, 0, -1);
+            GROUP_COST(1, bmx, bmy, bmx, bmy, 0, 1);
+            GROUP_COST(2, bmx, bmy, bmx, bmy, -1, 0);
+            GROUP_COST(3, bmx, bmy, bmx, bmy, 1, 0);
+            LT1(bcost, (costs[0] << 4) + 1);
+            LT1(bcost, (costs[1] << 4) + 3);
+            LT1(bcost, (costs[2] << 4) + 4);
+            LT1(bcost, (costs[3] << 4) + 12);
+            if (!(bcost & 15))
+                break;
+            bmx = S16(bmx - (((int32_t)((uint32_t)bcost << 28)) >> 30));
+            bmy = S16(bmy - (((int32_t)((uint32_t)bcost << 30)) >> 30));
+            bcost &= ~15;
+        }
+        while (--i && IN_RANGE(bmx, bmy));
+        bcost >>= 4;
+        break;
+    }
+
+    case ORC_HEX:
+    {
+me_hex2:
+        /* motion.cpp:673-706: the six hexagon points are evaluated without a range check */
+        GROUP_COST(0, bmx, bmy, bmx, bmy, -2, 0);
+        GROUP_COST(1, bmx, bmy, bmx, bmy, -1, 2);
+        GROUP_COST(2, bmx, bmy, bmx, bmy, 1, 2);
+        bcost <<= 3;
+        LT1(bcost, (costs[0] << 3) + 2);
+        LT1(bcost, (costs[1] << 3) + 3);
+        LT1(bcost, (costs[2] << 3) + 4);
+        GROUP_COST(0, bmx, bmy, bmx, bmy, 2, 0);
+        GROUP_COST(1, bmx, bmy, bmx, bmy, 1, -2);
+        GROUP_COST(2, bmx, bmy, bmx, bmy, -1, -2);
+        LT1(bcost, (costs[0] << 3) + 5);
+        LT1(bcost, (costs[1] << 3) + 6);
+        LT1(bcost, (costs[2] << 3) + 7);
+
+        if (bcost & 7)
+        {
+            int dir = (bcost & 7) - 2;
+            bmx = S16(bmx + hex2[dir + 1][0]); bmy = S16(bmy + hex2[dir + 1][1]);
+            for (int i = (merange >> 1) - 1; i > 0 && IN_RANGE(bmx, bmy); i--)
+            {
+                GROUP_COST(0, bmx, bmy, bmx, bmy, hex2[dir + 0][0], hex2[dir + 0][1]);
+                GROUP_COST(1, bmx, bmy, bmx, bmy, hex2[dir + 1][0], hex2[dir + 1][1]);
+                GROUP_COST(2, bmx, bmy, bmx, bmy, hex2[dir + 2][0], hex2[dir + 2][1]);
+                bcost &= ~7;
+                LT1(bcost, (costs[0] << 3) + 1);
+                LT1(bcost, (costs[1] << 3) + 2);
+                LT1(bcost, (costs[2] << 3) + 3);
+                if (!(bcost & 7))
+                    break;
+                dir += (bcost & 7) - 2;
+                dir = mod6m1[dir + 1];
+                bmx = S16(bmx + hex2[dir + 1][0]); bmy = S16(bmy + hex2[dir + 1][1]);
+            }
+        }
+        bcost >>= 3;
+
+        /* square refine, motion.cpp:709-722, also unchecked */
+        int dir = 0;
+        for (int k = 1; k <= 8; k++)
+        {
+            /* order of the two sad_x4 groups: (0,-1)(0,1)(-1,0)(1,0) then (-1,-1)(-1,1)(1,-1)(1,1) == square1[1..8] */
+            GROUP_COST(0, bmx, bmy, bmx, bmy, square1[k][0], square1[k][1]);
+            if (costs[0] < bcost) { bcost = costs[0]; dir = k; }
+        }
+        bmx = S16(bmx + square1[dir][0]); bmy = S16(bmy + square1[dir][1]);
+        break;
+    }
+
+    case ORC_UMH:
+    {
+        /* motion.cpp:725-909. The SAD base of the X4 groups stays at the bmv the
+         * case was entered with (pix_base is computed once, motion.cpp:732) while
+         * the MV bookkeeping follows omv. */
+        static const uint8_t range_mul[4][4] = { {3,3,4,4}, {3,4,4,4}, {4,4,4,5}, {4,4,5,6} };
+        const int size_scale = (h * h) >> 4; /* motion.cpp:71-72 */
+#define SAD_THRESH(v) (bcost < (((v) >> 4) * size_scale))
+        const int16_t pbx = bmx, pby = bmy; /* pix_base */
+        int ucost1, ucost2;
+        int16_t cross_start = 1;
+#define X4(d0x, d0y, d1x, d1y, d2x, d2y, d3x, d3y) do { \
+            const int _dx[4] = { d0x, d1x, d2x, d3x }, _dy[4] = { d0y, d1y, d2y, d3y }; \
+            for (int _k = 0; _k < 4; _k++) GROUP_COST(_k, pbx, pby, omx, omy, _dx[_k], _dy[_k]); \
+            for (int _k = 0; _k < 4; _k++) \
+                if (costs[_k] < bcost) { bcost = costs[_k]; bmx = S16(omx + _dx[_k]); bmy = S16(omy + _dy[_k]); } \
+        } while (0)
+#define DIA1(mx, my) do { omx = (mx); omy = (my); X4(0, -1, 0, 1, -1, 0, 1, 0); } while (0)
+#define CROSS(start, x_max, y_max) do { \
+            int16_t _i = (start); \
+            if ((x_max) <= (mxx - omx < omx - mnx ? mxx - omx : omx - mnx)) \
+                for (; _i < (x_max) - 2; _i += 4) X4(_i, 0, -_i, 0, _i + 2, 0, -_i - 2, 0); \
+            for (; _i < (x_max); _i += 2) { \
+                if (omx + _i <= mxx) TRY_MV(omx + _i, omy); \
+                if (omx - _i >= mnx) TRY_MV(omx - _i, omy); } \
+            _i = (start); \
+            if ((y_max) <= (mxy - omy < omy - mny ? mxy - omy : omy - mny)) \
+                for (; _i < (y_max) - 2; _i += 4) X4(0, _i, 0, -_i, 0, _i + 2, 0, -_i - 2); \
+            for (; _i < (y_max); _i += 2) { \
+                /* COST_MV(omv.x, omv.y + i) expands to fref + omv.x + omv.y + i * stride \
+                 * (motion.cpp:199,301,303): the SAD is taken at (omv.x + omv.y, +-i) while \
+                 * the MV bookkeeping uses (omv.x, omv.y +- i) */ \
+                if (omy + _i <= mxy) TRY_MV_AT(omx + omy, _i, omx, omy + _i); \
+                if (omy - _i >= mny) TRY_MV_AT(omx + omy, -_i, omx, omy - _i); } \
+        } while (0)
+
+        omx = bmx; omy = bmy;
+        ucost1 = bcost;
+        DIA1(pmx, pmy);
+        if (pmx | pmy)
+            DIA1(0, 0);
+
+        ucost2 = bcost;
+        if ((bmx | bmy) && !(bmx == pmx && bmy == pmy))
+            DIA1(bmx, bmy);
+        if (bcost == ucost2)
+            cross_start = 3;
+
+        omx = bmx; omy = bmy;
+        if (bcost == ucost2 && SAD_THRESH(2000))
+        {
+            X4(0, -2, -1, -1, 1, -1, -2, 0);
+            X4(2, 0, -1, 1, 1, 1, 0, 2);
+            if (bcost == ucost1 && SAD_THRESH(500))
+                break;
+            if (bcost == ucost2)
+            {
+                int16_t range = (int16_t)((merange >> 1) | 1);
+                CROSS(3, range, range);
+                X4(-1, -2, 1, -2, -2, -1, 2, -1);
+                X4(-2, 1, 2, 1, -1, 2, 1, 2);
+                if (bcost == ucost2)
+                    break;
+                cross_start = S16(range + 2);
+            }
+        }
+
+        if (numc)
+        {
+            int mvd, denom = 1;
+            if (numc == 1)
+            {
+                if (w == 64 && h == 64) mvd = 25;
+                else mvd = abs(qmvp.x - mvc[0].x) + abs(qmvp.y - mvc[0].y);
+            }
+            else
+            {
+                denom = numc - 1;
+                mvd = 0;
+                if (!(w == 64 && h == 64))
+                {
+                    mvd = abs(qmvp.x - mvc[0].x) + abs(qmvp.y - mvc[0].y);
+                    denom++;
+                }
+                for (int i = 0; i < numc - 1; i++)
+                    mvd += abs(mvc[i].x - mvc[i + 1].x) + abs(mvc[i].y - mvc[i + 1].y);
+            }
+            int sad_ctx = SAD_THRESH(1000) ? 0 : SAD_THRESH(2000) ? 1 : SAD_THRESH(4000) ? 2 : 3;
+            int mvd_ctx = mvd < 10 * denom ? 0 : mvd < 20 * denom ? 1 : mvd < 40 * denom ? 2 : 3;
+            merange = (merange * range_mul[mvd_ctx][sad_ctx]) >> 2;
+        }
+
+        CROSS(cross_start, merange, merange >> 1);
+        X4(-2, -2, -2, 2, 2, -2, 2, 2);
+
+        /* hexagon grid, motion.cpp:826-905 */
+        omx = bmx; omy = bmy;
+        uint16_t i = 1;
+        do
+        {
+            int lim = mxx - omx;
+            if (omx - mnx < lim) lim = omx - mnx;
+            if (mxy - omy < lim) lim = mxy - omy;
+            if (omy - mny < lim) lim = omy - mny;
+            if (4 * i > lim)
+            {
+                for (int j = 0; j < 16; j++)
+                {
+                    int16_t mx = S16(omx + S16(hex4[j][0] * (int16_t)i)), my = S16(omy + S16(hex4[j][1] * (int16_t)i));
+                    if (IN_RANGE(mx, my))
+                        TRY_MV(mx, my);
+                }
+            }
+            else
+            {
+                /* all 16 points measured first, then compared in table order */
+                int dirx = 0, diry = 0, found = 0;
+                for (int j = 0; j < 16; j++)
+                {
+                    int px = omx + hex4[j][0] * i, py = omy + hex4[j][1] * i;
+                    /* p_cost_omvx[x*4*i] == m_cost_mvx[(omv.x + x*i) * 4] without the int16 wrap of MV << 2 */
+                    costs[j] = FN(fpsad)(m, px, py) +
+                               (int)m->cost[px * 4 - m->mvpx] + (int)m->cost[py * 4 - m->mvpy];
+                }
+                for (int j = 0; j < 16; j++)
+                    if (costs[j] < bcost) { bcost = costs[j]; dirx = hex4[j][0]; diry = hex4[j][1]; found = 1; }
+                if (found)
+                {
+                    bmx = S16(omx + i * dirx);
+                    bmy = S16(omy + i * diry);
+                }
+            }
+        }
+        while (++i <= merange >> 2);
+        if (IN_RANGE(bmx, bmy))
+            goto me_hex2;
+        break;
+#undef SAD_THRESH
+#undef X4
+#undef DIA1
+#undef CROSS
+    }
+
+    case ORC_STAR:
+    {
+        /* motion.cpp:911-1019 */
+        int bPointNr = 0, bDistance = 0;
+        FN(star_pattern)(m, mnx, mny, mxx, mxy, &bmx, &bmy, &bcost, &bPointNr, &bDistance, 3, merange);
+        if (bDistance == 1)
+        {
+            if (bPointNr)
+            {
+                int saved = bcost;
+                int16_t x1 = S16(bmx + twopt[(bPointNr - 1) * 2][0]), y1 = S16(bmy + twopt[(bPointNr - 1) * 2][1]);
+                int16_t x2 = S16(bmx + twopt[(bPointNr - 1) * 2 + 1][0]), y2 = S16(bmy + twopt[(bPointNr - 1) * 2 + 1][1]);
+                if (IN_RANGE(x1, y1)) TRY_MV(x1, y1);
+                if (IN_RANGE(x2, y2)) TRY_MV(x2, y2);
+                if (bcost == saved)
+                    break;
+            }
+            else
+                break;
+        }
+
+        if (bDistance > 5)
+        {
+            /* raster refinement, step 5; the 4th point of each full group of four is
+             * costed with tmv << 3 instead of << 2 (motion.cpp:975) */
+            for (int16_t ty = S16(mny); ty <= mxy; ty = S16(ty + 5))
+            {
+                for (int16_t tx = S16(mnx); tx <= mxx; tx = S16(tx + 5))
+                {
+                    if (tx + 15 <= mxx)
+                    {
+                        for (int k = 0; k < 4; k++)
+                            costs[k] = FN(fpsad)(m, tx + 5 * k, ty);
+                        for (int k = 0; k < 4; k++)
+                        {
+                            int sh = (k == 3) ? 3 : 2;
+                            int cst = costs[k] + FN(mvcost)(m, S16(tx << sh), S16(ty << sh));
+                            if (cst < bcost) { bcost = cst; bmx = tx; bmy = ty; }
+                            if (k < 3) tx = S16(tx + 5);
+                        }
+                    }
+                    else
+                        TRY_MV(tx, ty);
+                }
+            }
+        }
+
+        while (bDistance > 0)
+        {
+            bDistance = 0;
+            bPointNr = 0;
+            FN(star_pattern)(m, mnx, mny, mxx, mxy, &bmx, &bmy, &bcost, &bPointNr, &bDistance, 32, merange);
+            if (bDistance == 1)
+            {
+                if (!bPointNr)
+                    break;
+                int16_t x1 = S16(bmx + twopt[(bPointNr - 1) * 2][0]), y1 = S16(bmy + twopt[(bPointNr - 1) * 2][1]);
+                int16_t x2 = S16(bmx + twopt[(bPointNr - 1) * 2 + 1][0]), y2 = S16(bmy + twopt[(bPointNr - 1) * 2 + 1][1]);
+                if (IN_RANGE(x1, y1)) TRY_MV(x1, y1);
+                if (IN_RANGE(x2, y2)) TRY_MV(x2, y2);
+                break;
+            }
+        }
+        break;
+    }
+
+    case ORC_FULL:
+    {
+        /* motion.cpp:1021-1056: raster order y then x, strict-less update */
+        for (int ty = mny; ty <= mxy; ty++)
+            for (int tx = mnx; tx <= mxx; tx++)
+                TRY_MV(tx, ty);
+        break;
+    }
+    default:
+        return -1;
+    }
+
+    (void)omx; (void)omy;
+    int16_t qx, qy;
+    if (bprecost < bcost) { qx = bpx; qy = bpy; bcost = bprecost; }
+    else { qx = S16(bmx << 2); qy = S16(bmy << 2); }
+
+    const int8_t *wl = workload[c->subme];
+    if (!bcost)
+    {
+        /* motion.cpp:1073-1076 */
+    }
+    else if (c->is_lowres)
+    {
+        /* motion.cpp:1077-1099 */
+        int bdir = 0;
+        for (int i = 1; i <= wl[1]; i++)
+        {
+            int16_t tx = S16(qx + square1[i][0] * 2), ty = S16(qy + square1[i][1] * 2);
+            int cost = FN(lowres_cost)(m, tx, ty, FN(sad)) + FN(mvcost)(m, tx, ty);
+            if (cost < bcost) { bcost = cost; bdir = i; }
+        }
+        qx = S16(qx + square1[bdir][0] * 2); qy = S16(qy + square1[bdir][1] * 2);
+        bcost = FN(lowres_cost)(m, qx, qy, FN(satd)) + FN(mvcost)(m, qx, qy);
+        bdir = 0;
+        for (int i = 1; i <= wl[3]; i++)
+        {
+            int16_t tx = S16(qx + square1[i][0]), ty = S16(qy + square1[i][1]);
+            int cost = FN(lowres_cost)(m, tx, ty, FN(satd)) + FN(mvcost)(m, tx, ty);
+            if (cost < bcost) { bcost = cost; bdir = i; }
+        }
+        qx = S16(qx + square1[bdir][0]); qy = S16(qy + square1[bdir][1]);
+    }
+    else
+    {
+        /* motion.cpp:1100-1141 */
+        FN(cmp_t) hpelcomp = FN(sad);
+        if (wl[4])
+        {
+            bcost = FN(subpel_cmp)(m, qx, qy, FN(satd)) + FN(mvcost)(m, qx, qy);
+            hpelcomp = FN(satd);
+        }
+        for (int iter = 0; iter < wl[0]; iter++)
+        {
+            int bdir = 0;
+            for (int i = 1; i <= wl[1]; i++)
+            {
+                int16_t tx = S16(qx + square1[i][0] * 2), ty = S16(qy + square1[i][1] * 2);
+                int cost = FN(subpel_cmp)(m, tx, ty, hpelcomp) + FN(mvcost)(m, tx, ty);
+                if (cost < bcost) { bcost = cost; bdir = i; }
+            }
+            qx = S16(qx + square1[bdir][0] * 2); qy = S16(qy + square1[bdir][1] * 2);
+        }
+        if (!wl[4])
+            bcost = FN(subpel_cmp)(m, qx, qy, FN(satd)) + FN(mvcost)(m, qx, qy);
+        for (int iter = 0; iter < wl[2]; iter++)
+        {
+            int bdir = 0;
+            for (int i = 1; i <= wl[3]; i++)
+            {
+                int16_t tx = S16(qx + square1[i][0]), ty = S16(qy + square1[i][1]);
+                int cost = FN(subpel_cmp)(m, tx, ty, FN(satd)) + FN(mvcost)(m, tx, ty);
+                if (cost < bcost) { bcost = cost; bdir = i; }
+            }
+            qx = S16(qx + square1[bdir][0]); qy = S16(qy + square1[bdir][1]);
+        }
+    }
+    out->x = qx; out->y = qy;
+    return bcost;
+#undef GROUP_COST
+#undef LT1
+#undef CLIPQ_X
+#undef CLIPQ_Y
+}
+
+#undef S16
+#undef IN_RANGE
+#undef TRY_MV
+#undef TRY_MV_AT

@@ -1,0 +1,251 @@
+/* TEST INFRASTRUCTURE ONLY -- not part of the shipped engine.
+ *
+ * Thin extern "C" wrapper around the REFERENCE's own classes, compiled together
+ * with the reference's source files (where they lie under /root/reference) by
+ * oracle/Makefile into oracle/_ref/libx265ref{8,10}.so.  Nothing from the
+ * reference is copied: this file only #includes its headers at build time and
+ * calls MotionEstimate / EncoderPrimitives / BitCost as the encoder does.
+ *
+ * Used to (1) validate the plain-C restatement in oracle/me_oracle.c and
+ * (2) generate the golden vectors committed under tests/golden/.
+ *
+ * Call sites mirrored:
+ *   primitives table setup      source/common/primitives.cpp:124-144
+ *   MotionEstimate API          source/encoder/motion.h:66-108
+ *   lookahead CU driver         source/encoder/slicetype.cpp:1401-1470
+ *   lowres plane generation     source/common/lowres.cpp:155-166
+ */
+#include "TLibCommon/TComRom.h"
+#include "primitives.h"
+#include "common.h"
+#include "lowres.h"
+#include "motion.h"
+#include "bitcost.h"
+#include "mv.h"
+
+#include <string.h>
+#include <stdlib.h>
+#include <stdint.h>
+
+namespace x265 {
+void Setup_C_PixelPrimitives(EncoderPrimitives &p);
+void Setup_C_IPFilterPrimitives(EncoderPrimitives &p);
+}
+
+using namespace x265;
+
+namespace {
+/* MotionEstimate keeps its cost pointers protected; a subclass lets the
+ * harness read the table the reference built. */
+struct ProbeME : public MotionEstimate
+{
+    const uint16_t *costTable() const { return m_cost; }
+};
+
+bool g_ready = false;
+}
+
+extern "C" {
+
+int ref_pixel_size(void) { return (int)sizeof(pixel); }
+
+/* Fill the global primitive table with the reference's C primitives and apply
+ * the sa8d_inter -> satd aliasing of primitives.cpp:138-144 (the full
+ * x265_setup_primitives additionally initialises DCT/intra/CABAC tables that
+ * this path never touches). */
+void ref_setup(int bitDepth)
+{
+#if HIGH_BIT_DEPTH
+    g_bitDepth = bitDepth;
+#else
+    (void)bitDepth;
+#endif
+    if (g_ready) return;
+    Setup_C_PixelPrimitives(primitives);
+    Setup_C_IPFilterPrimitives(primitives);
+    primitives.sa8d_inter[LUMA_4x4]   = primitives.satd[LUMA_4x4];
+    primitives.sa8d_inter[LUMA_4x8]   = primitives.satd[LUMA_4x8];
+    primitives.sa8d_inter[LUMA_4x16]  = primitives.satd[LUMA_4x16];
+    primitives.sa8d_inter[LUMA_8x4]   = primitives.satd[LUMA_8x4];
+    primitives.sa8d_inter[LUMA_16x4]  = primitives.satd[LUMA_16x4];
+    primitives.sa8d_inter[LUMA_16x12] = primitives.satd[LUMA_16x12];
+    primitives.sa8d_inter[LUMA_12x16] = primitives.satd[LUMA_12x16];
+    g_maxCUWidth = 64;
+    g_maxCUHeight = 64;
+    g_ready = true;
+}
+
+int ref_partition(int w, int h) { return partitionFromSizes(w, h); }
+
+int ref_sad(int part, pixel *a, intptr_t sa, pixel *b, intptr_t sb)  { return primitives.sad[part](a, sa, b, sb); }
+int ref_satd(int part, pixel *a, intptr_t sa, pixel *b, intptr_t sb) { return primitives.satd[part](a, sa, b, sb); }
+int ref_sa8d_inter(int part, pixel *a, intptr_t sa, pixel *b, intptr_t sb) { return primitives.sa8d_inter[part](a, sa, b, sb); }
+void ref_sad_x3(int part, pixel *fenc, pixel *r0, pixel *r1, pixel *r2, intptr_t s, int32_t *res)
+{ primitives.sad_x3[part](fenc, r0, r1, r2, s, res); }
+void ref_sad_x4(int part, pixel *fenc, pixel *r0, pixel *r1, pixel *r2, pixel *r3, intptr_t s, int32_t *res)
+{ primitives.sad_x4[part](fenc, r0, r1, r2, r3, s, res); }
+void ref_pixelavg_pp(int part, pixel *dst, intptr_t ds, pixel *a, intptr_t sa, pixel *b, intptr_t sb)
+{ primitives.pixelavg_pp[part](dst, ds, a, sa, b, sb, 32); }
+void ref_luma_hpp(int part, pixel *src, intptr_t ss, pixel *dst, intptr_t ds, int c) { primitives.luma_hpp[part](src, ss, dst, ds, c); }
+void ref_luma_vpp(int part, pixel *src, intptr_t ss, pixel *dst, intptr_t ds, int c) { primitives.luma_vpp[part](src, ss, dst, ds, c); }
+void ref_luma_hps(int part, pixel *src, intptr_t ss, int16_t *dst, intptr_t ds, int c, int ext) { primitives.luma_hps[part](src, ss, dst, ds, c, ext); }
+void ref_luma_vsp(int part, int16_t *src, intptr_t ss, pixel *dst, intptr_t ds, int c) { primitives.luma_vsp[part](src, ss, dst, ds, c); }
+void ref_lowres_core(pixel *src, pixel *d0, pixel *dh, pixel *dv, pixel *dc, intptr_t ss, intptr_t ds, int w, int h)
+{ primitives.frame_init_lowres_core(src, d0, dh, dv, dc, ss, ds, w, h); }
+
+/* lambda-scaled MVD cost table for one QP, entries [-32767, 32767] written to
+ * out[0..65534] (bitcost.cpp:34-59). */
+void ref_cost_table(int qp, uint16_t *out)
+{
+    ProbeME me;
+    me.setQP(qp);
+    const uint16_t *t = me.costTable();
+    for (int i = -32767; i <= 32767; i++)
+        out[i + 32767] = t[i];
+}
+
+/* ---- classic MotionEstimate::motionEstimate, one PU ---- */
+struct RefME
+{
+    MotionEstimate me;
+    ReferencePlanes ref;
+};
+
+void *ref_me_create(void) { return new RefME; }
+void ref_me_destroy(void *h) { delete (RefME*)h; }
+
+void ref_me_config(void *h, pixel *fencPlane, intptr_t fencStride, int qp, int method, int subme)
+{
+    RefME *r = (RefME*)h;
+    r->me.setSourcePlane(fencPlane, fencStride);
+    r->me.setQP(qp);
+    r->me.setSearchMethod(method);
+    r->me.setSubpelRefine(subme);
+}
+
+/* planes[0] = full-pel plane origin; for lowres planes[0..3] = the four hpel
+ * planes (lowres.h:44). mv arguments are {x,y} int16 pairs. */
+int ref_me_search(void *h, int offset, int w, int hgt,
+                  pixel **planes, int stride, int isLowres,
+                  const int16_t *mvmin, const int16_t *mvmax, const int16_t *qmvp,
+                  int numc, const int16_t *mvc, int merange, int16_t *outmv)
+{
+    RefME *r = (RefME*)h;
+    r->ref.fpelPlane = planes[0];
+    r->ref.lumaStride = stride;
+    r->ref.isLowres = !!isLowres;
+    if (isLowres)
+        for (int i = 0; i < 4; i++) r->ref.lowresPlane[i] = planes[i];
+    r->me.setSourcePU(offset, w, hgt);
+    MV cand[8];
+    for (int i = 0; i < numc && i < 8; i++) cand[i] = MV(mvc[2 * i], mvc[2 * i + 1]);
+    MV out;
+    int cost = r->me.motionEstimate(&r->ref, MV(mvmin[0], mvmin[1]), MV(mvmax[0], mvmax[1]),
+                                    MV(qmvp[0], qmvp[1]), numc, cand, merange, out);
+    outmv[0] = out.x;
+    outmv[1] = out.y;
+    return cost;
+}
+
+/* subpelCompare at one qpel MV with sad (cmp=0) or satd (cmp=1); motion.cpp:1651 */
+int ref_me_subpel_compare(void *h, int offset, int w, int hgt, pixel *plane, int stride,
+                          int qx, int qy, int cmp)
+{
+    RefME *r = (RefME*)h;
+    r->ref.fpelPlane = plane;
+    r->ref.lumaStride = stride;
+    r->ref.isLowres = false;
+    r->me.setSourcePU(offset, w, hgt);
+    int part = partitionFromSizes(w, hgt);
+    return r->me.subpelCompare(&r->ref, MV(qx, qy), cmp ? primitives.satd[part] : primitives.sad[part]);
+}
+
+/* ---- lookahead: one lowres MV field (one list), ME part of
+ * EstimateRow::estimateCUCost, slicetype.cpp:1401-1470, visited in the
+ * reference's order (rows bottom->top, CUs right->left, slicetype.cpp:1344,1356).
+ * The MotionEstimate and ReferencePlanes objects are the reference's. */
+static inline int16_t med3(int16_t a, int16_t b, int16_t c)
+{
+    /* median of three (slicetype.cpp:42-51 computes the same value branch-free) */
+    int16_t lo = a < b ? a : b, hi = a < b ? b : a;
+    int16_t m = lo > c ? lo : c;
+    return m < hi ? m : hi;
+}
+
+void ref_lookahead_field(pixel *fencLowres, pixel **refPlanes, int stride,
+                         int widthInCU, int heightInCU, int qp, int method, int subme, int merange,
+                         int16_t *outMvs /* 2*ncu */, int32_t *outCosts /* ncu */)
+{
+    MotionEstimate me;
+    ReferencePlanes ref;
+    me.setQP(qp);
+    me.setSearchMethod(method);
+    me.setSubpelRefine(subme);
+    me.setSourcePlane(fencLowres, stride);
+    ref.fpelPlane = refPlanes[0];
+    ref.lumaStride = stride;
+    ref.isLowres = true;
+    for (int i = 0; i < 4; i++) ref.lowresPlane[i] = refPlanes[i];
+    MV *mvs = (MV*)outMvs;
+    const int cuSize = 8;
+    for (int cuy = heightInCU - 1; cuy >= 0; cuy--)
+    {
+        for (int cux = widthInCU - 1; cux >= 0; cux--)
+        {
+            const int cuXY = cux + cuy * widthInCU;
+            const int pelOffset = cuSize * cux + cuSize * cuy * stride;
+            me.setSourcePU(pelOffset, cuSize, cuSize);
+            MV mvmin, mvmax;
+            mvmin.x = (uint16_t)(-cux * cuSize - 8);
+            mvmin.y = (uint16_t)(-cuy * cuSize - 8);
+            mvmax.x = (uint16_t)((widthInCU - cux - 1) * cuSize + 8);
+            mvmax.y = (uint16_t)((heightInCU - cuy - 1) * cuSize + 8);
+            int numc = 0;
+            MV mvc[4], mvp;
+            MV *fenc_mv = &mvs[cuXY];
+            mvc[0] = 0;
+            mvc[2] = 0;
+            if (cux < widthInCU - 1) mvc[numc++] = fenc_mv[1];
+            if (cuy < heightInCU - 1)
+            {
+                mvc[numc++] = fenc_mv[widthInCU];
+                if (cux > 0) mvc[numc++] = fenc_mv[widthInCU - 1];
+                if (cux < widthInCU - 1) mvc[numc++] = fenc_mv[widthInCU + 1];
+            }
+            if (numc <= 1) mvp = mvc[0];
+            else { mvp.x = med3(mvc[0].x, mvc[1].x, mvc[2].x); mvp.y = med3(mvc[0].y, mvc[1].y, mvc[2].y); }
+            outCosts[cuXY] = me.motionEstimate(&ref, mvmin, mvmax, mvp, numc, mvc, merange, mvs[cuXY]);
+        }
+    }
+}
+
+/* ---- optional call trace: records the reference-plane address of every
+ * full-pel sad / sad_x3 / sad_x4 call of one partition, so visit order and
+ * candidate counts can be compared with the restatement ---- */
+static pixelcmp_t    t_sad0;
+static pixelcmp_x3_t t_x30;
+static pixelcmp_x4_t t_x40;
+static int64_t *t_buf; static int t_n, t_cap, t_part = -1; static pixel *t_base;
+static inline void t_log(pixel *p) { if (t_n < t_cap) t_buf[t_n] = (int64_t)(p - t_base); t_n++; }
+static int t_sad(pixel *a, intptr_t sa, pixel *b, intptr_t sb) { t_log(b); return t_sad0(a, sa, b, sb); }
+static void t_x3(pixel *f, pixel *a, pixel *b, pixel *c, intptr_t s, int32_t *r) { t_log(a); t_log(b); t_log(c); t_x30(f, a, b, c, s, r); }
+static void t_x4(pixel *f, pixel *a, pixel *b, pixel *c, pixel *d, intptr_t s, int32_t *r) { t_log(a); t_log(b); t_log(c); t_log(d); t_x40(f, a, b, c, d, s, r); }
+
+void ref_trace_begin(int part, pixel *base, int64_t *buf, int cap)
+{
+    t_part = part; t_base = base; t_buf = buf; t_cap = cap; t_n = 0;
+    t_sad0 = primitives.sad[part]; t_x30 = primitives.sad_x3[part]; t_x40 = primitives.sad_x4[part];
+    primitives.sad[part] = t_sad; primitives.sad_x3[part] = t_x3; primitives.sad_x4[part] = t_x4;
+}
+
+int ref_trace_end(void)
+{
+    if (t_part >= 0)
+    {
+        primitives.sad[t_part] = t_sad0; primitives.sad_x3[t_part] = t_x30; primitives.sad_x4[t_part] = t_x40;
+        t_part = -1;
+    }
+    return t_n;
+}
+
+} // extern "C"
