@@ -1,0 +1,190 @@
+/* x265_amd_me.h -- C ABI of the MI355X motion-estimation engine.
+ *
+ * Drop-in boundary for the hot path behind x265's MotionEstimate class and the
+ * EncoderPrimitives function table. Plain C, plain pointers and sizes; every entry
+ * point returns 0 on success or a negative X265AMD_E* code (the reference path has
+ * no error returns -- motion.cpp only asserts -- so errors are new and only cover
+ * bad arguments and HIP failures; x265amd_last_error() gives the text).
+ *
+ * Each declaration cites the reference interface it replaces
+ * (paths relative to the reference's source/ directory).
+ */
+#ifndef X265_AMD_ME_H
+#define X265_AMD_ME_H
+
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define X265AMD_OK          0
+#define X265AMD_EINVAL     -1   /* bad argument */
+#define X265AMD_EHIP       -2   /* HIP runtime error */
+#define X265AMD_ENOMEM     -3
+
+/* search methods: X265_DIA_SEARCH .. X265_FULL_SEARCH, x265.h (searchMethod) */
+enum { X265AMD_DIA = 0, X265AMD_HEX = 1, X265AMD_UMH = 2, X265AMD_STAR = 3, X265AMD_FULL = 4 };
+
+typedef struct x265amd_ctx x265amd_ctx;
+
+/* A padded picture plane resident in device memory. Replaces the
+ * (pixel* fpelPlane, int lumaStride) pair of struct ReferencePlanes
+ * (common/lowres.h:37-52) and MotionEstimate::setSourcePlane (encoder/motion.h:76).
+ * `origin` is the DEVICE address of pixel (0,0); `margin_*` replicated border
+ * pixels exist on every side (TComPicYuv.cpp:69-131). Samples are uint8_t for
+ * bit depth 8 and uint16_t above. */
+typedef struct
+{
+    void   *origin;
+    int32_t stride;            /* in samples */
+    int32_t width, height;
+    int32_t margin_x, margin_y;
+} x265amd_plane;
+
+/* One PU search = one call of MotionEstimate::setSourcePU + motionEstimate
+ * (encoder/motion.cpp:116, :549). MVs are {x, y}; mvmin/mvmax full-pel inclusive,
+ * qmvp and mvc quarter-pel, as in the reference signature (encoder/motion.h:93). */
+typedef struct
+{
+    int16_t pu_x, pu_y;        /* PU position in the picture: blockOffset = pu_y * stride + pu_x */
+    uint8_t w, h;              /* an HEVC luma partition (common/primitives.h:65-73), not 4x4 */
+    uint8_t numc;              /* numCandidates, 0..4 */
+    uint8_t reserved;
+    int16_t mvmin[2], mvmax[2];
+    int16_t qmvp[2];
+    int16_t mvc[4][2];
+    int32_t merange;
+} x265amd_job;
+
+typedef struct
+{
+    int16_t  mv[2];            /* outQMv */
+    int32_t  cost;             /* return value of motionEstimate */
+    uint32_t sad_calls;        /* full-pel SAD evaluations made (x3/x4 groups count 3/4) */
+    uint32_t subpel_calls;     /* subpelCompare / lowresQPelCost evaluations made */
+} x265amd_result;
+
+/* ---- context ---- */
+
+/* Creates an engine bound to HIP device `device` for `bit_depth` 8, 10 or 12
+ * (the reference fixes this at build time through HIGH_BIT_DEPTH / g_bitDepth). */
+int x265amd_create(int device, int bit_depth, x265amd_ctx **out);
+void x265amd_destroy(x265amd_ctx *ctx);
+const char *x265amd_last_error(const x265amd_ctx *ctx);
+/* HIP stream (hipStream_t) the engine launches on; for event timing by callers */
+void *x265amd_stream(x265amd_ctx *ctx);
+
+/* BitCost::setQP (encoder/bitcost.cpp:34-59): builds (once) and selects the
+ * lambda-scaled MVD cost table of `qp`; x265amd_cost_table copies the 65535
+ * entries [-32767, 32767] of that table to `out` (host). */
+int x265amd_set_qp(x265amd_ctx *ctx, int qp);
+int x265amd_cost_table(x265amd_ctx *ctx, int qp, uint16_t *out);
+
+/* ---- planes ---- */
+
+/* Uploads a padded host plane (`buf` holds (height + 2*margin_y) rows of `stride`
+ * samples, pixel (0,0) at margin_y * stride + margin_x) and returns its descriptor.
+ * Stands for the pictures the encoder already owns (TComPicYuv, Lowres::buffer). */
+int x265amd_plane_upload(x265amd_ctx *ctx, const void *buf, int width, int height,
+                         int margin_x, int margin_y, int stride, x265amd_plane *out);
+int x265amd_plane_free(x265amd_ctx *ctx, x265amd_plane *plane);
+/* Lowres::init (common/lowres.cpp:121-166): frame_init_lowres_core + border
+ * extension, on device. `src` is a full-resolution padded plane; produces the four
+ * half-resolution planes (full-pel, H, V, centre half-pel) with `src`'s margins. */
+int x265amd_lowres_init(x265amd_ctx *ctx, const x265amd_plane *src, x265amd_plane out[4]);
+/* copies a whole padded plane (all rows incl. margins) back to the host */
+int x265amd_plane_download(x265amd_ctx *ctx, const x265amd_plane *plane, void *buf);
+
+/* ---- motion search ---- */
+
+/* MotionEstimate::motionEstimate for `njobs` PUs of one (source, reference) pair
+ * (encoder/motion.cpp:549-1146; callers TEncSearch.cpp:4303, slicetype.cpp:1468).
+ * `ref` points to 1 plane, or to the 4 lowres hpel planes when is_lowres
+ * (ReferencePlanes::lowresPlane, lowres.h:44; lowres searches are 8x8 PUs only).
+ * method / subme are setSearchMethod / setSubpelRefine (motion.h:70-72).
+ * jobs and results are HOST arrays. */
+int x265amd_search_batch(x265amd_ctx *ctx, const x265amd_plane *fenc, const x265amd_plane *ref, int is_lowres,
+                         int qp, int method, int subme,
+                         const x265amd_job *jobs, int njobs, x265amd_result *results);
+/* Same, with jobs and results already in DEVICE memory; asynchronous on the
+ * engine's stream (x265amd_sync waits). */
+int x265amd_search_batch_dev(x265amd_ctx *ctx, const x265amd_plane *fenc, const x265amd_plane *ref, int is_lowres,
+                             int qp, int method, int subme,
+                             const x265amd_job *d_jobs, int njobs, x265amd_result *d_results);
+int x265amd_sync(x265amd_ctx *ctx);
+
+/* MotionEstimate::subpelCompare (encoder/motion.cpp:1651-1689) for njobs PUs:
+ * job.qmvp is the qpel MV to evaluate, cmp 0 = sad, 1 = satd; results[i].cost. */
+int x265amd_subpel_compare_batch(x265amd_ctx *ctx, const x265amd_plane *fenc, const x265amd_plane *ref,
+                                 int cmp, const x265amd_job *jobs, int njobs, x265amd_result *results);
+
+/* ---- lookahead ---- */
+
+/* The motion-search part of EstimateRow::estimateCUCost over a whole lowres frame
+ * for one reference list (encoder/slicetype.cpp:1401-1470 driven by
+ * CostEstimate::processRow :1342): 8x8 CUs in reverse raster order, each predicted
+ * from its right / below / below-left / below-right neighbours' final MVs.
+ * Fills Lowres::lowresMvs[list][dist] and lowresMvCosts[list][dist]
+ * (common/lowres.h:124-125). nfields independent fields run in one launch.
+ * out_mvs: nfields * ncu * 2 int16, out_costs: nfields * ncu int32 (HOST). */
+typedef struct
+{
+    x265amd_plane fenc;        /* lowresPlane[0] of the frame being searched */
+    x265amd_plane ref[4];      /* the four hpel planes of the reference frame */
+} x265amd_field;
+int x265amd_lookahead_fields(x265amd_ctx *ctx, const x265amd_field *fields, int nfields,
+                             int width_in_cu, int height_in_cu, int qp, int method, int subme, int merange,
+                             int16_t *out_mvs, int32_t *out_costs, x265amd_result *out_stats /* nfields*ncu or NULL */);
+
+/* ---- primitives table ---- */
+
+/* Mirror of the ME-relevant slice of struct EncoderPrimitives
+ * (common/primitives.h:209-288) with the reference's typedefs (:145-204). All
+ * pointers are HOST pointers; every call stages its operands on the device, runs
+ * the HIP kernel and returns the result, so the table can be checked call by call
+ * against the C primitives the way test/pixelharness.cpp and
+ * test/ipfilterharness.cpp do. Indexed by the LumaPartitions enum (:65-73).
+ * `pixel` is uint8_t or uint16_t according to the context's bit depth. */
+#define X265AMD_NUM_LUMA_PARTITIONS 25
+typedef int  (*x265amd_pixelcmp_t)(const void *fenc, intptr_t fencstride, const void *fref, intptr_t frefstride);
+typedef void (*x265amd_pixelcmp_x3_t)(const void *fenc, const void *fref0, const void *fref1, const void *fref2,
+                                      intptr_t frefstride, int32_t *res);
+typedef void (*x265amd_pixelcmp_x4_t)(const void *fenc, const void *fref0, const void *fref1, const void *fref2,
+                                      const void *fref3, intptr_t frefstride, int32_t *res);
+typedef void (*x265amd_filter_pp_t)(const void *src, intptr_t srcStride, void *dst, intptr_t dstStride, int coeffIdx);
+typedef void (*x265amd_filter_hps_t)(const void *src, intptr_t srcStride, int16_t *dst, intptr_t dstStride,
+                                     int coeffIdx, int isRowExt);
+typedef void (*x265amd_filter_sp_t)(const int16_t *src, intptr_t srcStride, void *dst, intptr_t dstStride, int coeffIdx);
+typedef void (*x265amd_pixelavg_pp_t)(void *dst, intptr_t dstride, const void *src0, intptr_t sstride0,
+                                      const void *src1, intptr_t sstride1, int weight);
+typedef void (*x265amd_downscale_t)(const void *src0, void *dstf, void *dsth, void *dstv, void *dstc,
+                                    intptr_t src_stride, intptr_t dst_stride, int width, int height);
+typedef struct
+{
+    x265amd_pixelcmp_t    sad[X265AMD_NUM_LUMA_PARTITIONS];
+    x265amd_pixelcmp_x3_t sad_x3[X265AMD_NUM_LUMA_PARTITIONS];
+    x265amd_pixelcmp_x4_t sad_x4[X265AMD_NUM_LUMA_PARTITIONS];
+    x265amd_pixelcmp_t    satd[X265AMD_NUM_LUMA_PARTITIONS];
+    x265amd_pixelcmp_t    sa8d_inter[X265AMD_NUM_LUMA_PARTITIONS];
+    x265amd_filter_pp_t   luma_hpp[X265AMD_NUM_LUMA_PARTITIONS];
+    x265amd_filter_hps_t  luma_hps[X265AMD_NUM_LUMA_PARTITIONS];
+    x265amd_filter_pp_t   luma_vpp[X265AMD_NUM_LUMA_PARTITIONS];
+    x265amd_filter_sp_t   luma_vsp[X265AMD_NUM_LUMA_PARTITIONS];
+    x265amd_pixelavg_pp_t pixelavg_pp[X265AMD_NUM_LUMA_PARTITIONS];
+    x265amd_downscale_t   frame_init_lowres_core;
+} x265amd_primitives;
+
+/* x265_setup_primitives (x265.h:665, common/primitives.cpp:82-149): fills `p` with
+ * entry points served by `ctx` (which becomes the process-wide engine for the
+ * table, as the reference's `primitives` global is process-wide). */
+int x265amd_setup_primitives(x265amd_ctx *ctx, x265amd_primitives *p);
+
+/* partitionFromSizes (common/primitives.h:134-143); -1 if not a luma partition */
+int x265amd_partition_from_sizes(int width, int height);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* X265_AMD_ME_H */

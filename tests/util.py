@@ -1,0 +1,77 @@
+"""Shared helpers for the parity tests: seeded job generators and oracle drivers."""
+import numpy as np
+
+from x265_amd.engine import JOB_DTYPE, PARTITIONS
+from x265_amd.synth import make_clip, pad_plane, lowres_dims
+
+MARGIN = 96
+
+
+def clip_planes(width, height, depth, kind="texture", seed=7, frames=(2, 0), margin=MARGIN):
+    """(fenc buffer, ref buffer, origin, stride): two frames of a synthetic clip, padded."""
+    clip = make_clip(width, height, max(frames) + 1, seed=seed, depth=depth, kind=kind)
+    fenc, org, stride = pad_plane(clip[frames[0]], margin)
+    ref, _, _ = pad_plane(clip[frames[1]], margin)
+    return fenc, ref, org, stride
+
+
+def random_jobs(rng, n, width, height, method, parts=None, meranges=(4, 16, 24, 57), slack=60, max_numc=3):
+    """Jobs shaped like the full-encode caller builds them: a window of +-merange around the
+    rounded predictor, clipped to the picture plus `slack` pixels (TEncSearch.cpp:4805-4822)."""
+    parts = parts or PARTITIONS[1:]
+    jobs = np.zeros(n, JOB_DTYPE)
+    for i in range(n):
+        w, h = parts[int(rng.integers(0, len(parts)))]
+        px = int(rng.integers(0, (width - w) // 4 + 1)) * 4
+        py = int(rng.integers(0, (height - h) // 4 + 1)) * 4
+        merange = int(rng.choice(meranges)) if method != 4 else int(rng.choice([3, 6, 9]))
+        qmvp = (int(rng.integers(-60, 61)), int(rng.integers(-60, 61)))
+        if i % 5 == 0:
+            qmvp = (0, 0)
+        elif i % 5 == 1:
+            qmvp = (qmvp[0] & ~3, qmvp[1] & ~3)
+        cx, cy = qmvp[0] >> 2, qmvp[1] >> 2
+        j = jobs[i]
+        j["pu_x"], j["pu_y"], j["w"], j["h"] = px, py, w, h
+        j["mvmin"] = (max(cx - merange, -px - slack), max(cy - merange, -py - slack))
+        j["mvmax"] = (min(cx + merange, width - px - w + slack), min(cy + merange, height - py - h + slack))
+        j["qmvp"] = qmvp
+        numc = int(rng.integers(0, max_numc + 1))
+        j["numc"] = numc
+        for k in range(numc):
+            j["mvc"][k] = (int(rng.integers(-80, 81)), int(rng.integers(-80, 81)))
+        j["merange"] = merange
+    return jobs
+
+
+def oracle_search(orc, depth, fenc, ref_planes, org, stride, jobs, qp, method, subme, is_lowres=False):
+    """Run the CPU oracle over a job array; returns (mv[n,2], cost[n], sad_calls[n], subpel_calls[n])."""
+    from oracle.bindings import MEStats
+    ctx = orc.make_ctx(depth, fenc, org, stride, ref_planes, org, stride, is_lowres, qp, method, subme)
+    n = len(jobs)
+    mv = np.zeros((n, 2), np.int16)
+    cost = np.zeros(n, np.int32)
+    sc = np.zeros(n, np.uint32)
+    qc = np.zeros(n, np.uint32)
+    for i, j in enumerate(jobs):
+        st = MEStats()
+        off = int(j["pu_y"]) * stride + int(j["pu_x"])
+        mvc = [tuple(int(v) for v in j["mvc"][k]) for k in range(int(j["numc"]))]
+        m, c = orc.me_search(ctx, off, int(j["w"]), int(j["h"]), tuple(int(v) for v in j["mvmin"]),
+                             tuple(int(v) for v in j["mvmax"]), tuple(int(v) for v in j["qmvp"]), mvc,
+                             int(j["merange"]), st)
+        mv[i] = m
+        cost[i] = c
+        sc[i] = st.sad_calls
+        qc[i] = st.subpel_calls
+    return mv, cost, sc, qc
+
+
+def host_lowres_planes(orc, depth, img, margin=64):
+    """Four padded lowres planes of `img` made with the oracle's downscaler (lowres.cpp:155-166)."""
+    h, w = img.shape
+    lw, lh, wcu, hcu = lowres_dims(w, h)
+    src, so, ss = pad_plane(img, 8)
+    outs = orc.lowres_core(depth, src, so, ss, lw, lh)
+    padded = [pad_plane(o, margin, stride_align=32) for o in outs]
+    return [p[0] for p in padded], padded[0][1], padded[0][2], wcu, hcu, lw, lh

@@ -1,0 +1,255 @@
+/* Device-side building blocks of the motion-estimation engine (gfx950, wave64).
+ *
+ * Work decomposition used by every kernel here: a PU is cut into 4x4-pixel tiles;
+ * one lane owns one (candidate, tile) pair, keeps the 16 source and 16 reference
+ * (or interpolated) pixels in VGPRs, and produces that tile's SAD or Hadamard
+ * cost without any cross-lane traffic. Per-candidate totals are then formed with a
+ * segmented butterfly over the lanes that share a candidate.
+ *
+ * Arithmetic follows the reference's C primitives exactly:
+ *   sad / satd            source/common/pixel.cpp:92-109, :201-288
+ *   8-tap interpolation   source/common/ipfilter.cpp:194-400
+ *   lowres qpel           source/common/lowres.h:78-97
+ */
+#ifndef X265AMD_ME_DEVICE_H
+#define X265AMD_ME_DEVICE_H
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace x265amd {
+
+/* HEVC luma taps, source/Lib/TLibCommon/TComRom.cpp:175-181 */
+__constant__ static const int16_t kLumaTaps[4][8] = {
+    {  0, 0,   0, 64,  0,   0, 0,  0 },
+    { -1, 4, -10, 58, 17,  -5, 1,  0 },
+    { -1, 4, -11, 40, 40, -11, 4, -1 },
+    {  0, 1,  -5, 17, 58, -10, 4, -1 },
+};
+
+/* the square of refinement offsets {0, N, S, W, E, NW, SW, NE, SE}; motion.cpp:147 */
+__constant__ static const int8_t kSquare1[9][2] = { {0,0}, {0,-1}, {0,1}, {-1,0}, {1,0}, {-1,-1}, {-1,1}, {1,-1}, {1,1} };
+
+__device__ __forceinline__ void wave_sync()
+{
+    /* LDS operations of one wave retire in order; this only stops the compiler
+     * from moving LDS accesses of different lanes across the hand-off point. */
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
+__device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
+
+/* ---- 4 horizontally adjacent pixels ---- */
+template<typename P> struct Px;
+
+template<> struct Px<uint8_t>
+{
+    typedef uint32_t quad;
+    static __device__ __forceinline__ quad load(const uint8_t *p)
+    {
+        typedef uint32_t __attribute__((aligned(1))) u32u;
+        return *(const u32u*)p;
+    }
+    static __device__ __forceinline__ quad load_aligned(const uint8_t *p) { return *(const uint32_t*)p; }
+    static __device__ __forceinline__ int sad(quad a, quad b, int acc) { return (int)__builtin_amdgcn_sad_u8(a, b, (uint32_t)acc); }
+    static __device__ __forceinline__ void unpack(quad q, int v[4])
+    {
+        v[0] = q & 0xff; v[1] = (q >> 8) & 0xff; v[2] = (q >> 16) & 0xff; v[3] = q >> 24;
+    }
+    /* rounding average of 4 packed pixels, (a + b + 1) >> 1 per byte */
+    static __device__ __forceinline__ quad avg(quad a, quad b) { return (a | b) - (((a ^ b) >> 1) & 0x7f7f7f7fu); }
+};
+
+template<> struct Px<uint16_t>
+{
+    typedef uint2 quad;
+    static __device__ __forceinline__ quad load(const uint16_t *p)
+    {
+        typedef uint32_t __attribute__((aligned(2))) u32u;
+        const u32u *q = (const u32u*)p;
+        return make_uint2(q[0], q[1]);
+    }
+    static __device__ __forceinline__ quad load_aligned(const uint16_t *p) { return *(const uint2*)p; }
+    static __device__ __forceinline__ int sad(quad a, quad b, int acc)
+    {
+        return (int)__builtin_amdgcn_sad_u16(a.y, b.y, __builtin_amdgcn_sad_u16(a.x, b.x, (uint32_t)acc));
+    }
+    static __device__ __forceinline__ void unpack(quad q, int v[4])
+    {
+        v[0] = q.x & 0xffff; v[1] = q.x >> 16; v[2] = q.y & 0xffff; v[3] = q.y >> 16;
+    }
+    static __device__ __forceinline__ quad avg(quad a, quad b)
+    {
+        return make_uint2((a.x | b.x) - (((a.x ^ b.x) >> 1) & 0x7fff7fffu), (a.y | b.y) - (((a.y ^ b.y) >> 1) & 0x7fff7fffu));
+    }
+};
+
+/* Sum of |Hadamard4x4(d)|, >> 1. The 16 coefficients all share the parity of the sum
+ * of d, so the abs-sum is even and halving per 4x4 tile equals the reference's
+ * halving per 8x4 pair (pixel.cpp:226, :251). */
+__device__ __forceinline__ int had4x4_half(const int d[4][4])
+{
+    int t[4][4];
+#pragma unroll
+    for (int r = 0; r < 4; r++)
+    {
+        int a0 = d[r][0] + d[r][1], a1 = d[r][0] - d[r][1];
+        int a2 = d[r][2] + d[r][3], a3 = d[r][2] - d[r][3];
+        t[r][0] = a0 + a2; t[r][1] = a1 + a3; t[r][2] = a0 - a2; t[r][3] = a1 - a3;
+    }
+    int s = 0;
+#pragma unroll
+    for (int c = 0; c < 4; c++)
+    {
+        int a0 = t[0][c] + t[1][c], a1 = t[0][c] - t[1][c];
+        int a2 = t[2][c] + t[3][c], a3 = t[2][c] - t[3][c];
+        s += abs(a0 + a2) + abs(a1 + a3) + abs(a0 - a2) + abs(a1 - a3);
+    }
+    return s >> 1;
+}
+
+__device__ __forceinline__ int clip_pixel(int v16, int maxv)
+{
+    /* v16 already passed through the reference's int16_t cast */
+    return v16 < 0 ? 0 : (v16 > maxv ? maxv : v16);
+}
+
+__device__ __forceinline__ int as_i16(int v) { return (int)(int16_t)v; }
+
+/* Interpolated 4x4 tile at integer position `r` (top-left of the tile in the
+ * reference plane) with fractional phase (xf, yf) != (0, 0).
+ *   yf == 0 : luma_hpp   (sum + 32) >> 6, int16 cast, clip      ipfilter.cpp:194-233
+ *   xf == 0 : luma_vpp                                           ipfilter.cpp:280-319
+ *   else    : luma_hps(isRowExt) into int16, then luma_vsp       ipfilter.cpp:235-278, :359-400
+ *             exactly as subpelCompare chains them (motion.cpp:1681-1685) */
+template<typename P>
+__device__ __forceinline__ void interp_tile(const P *r, int stride, int xf, int yf, int depth, int o[4][4])
+{
+    const int maxv = (1 << depth) - 1;
+    if (yf == 0)
+    {
+        int c[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) c[k] = kLumaTaps[xf][k];
+#pragma unroll
+        for (int y = 0; y < 4; y++)
+        {
+            int px[12];
+            const P *row = r + y * stride - 3;
+            Px<P>::unpack(Px<P>::load(row), px);
+            Px<P>::unpack(Px<P>::load(row + 4), px + 4);
+            Px<P>::unpack(Px<P>::load(row + 8), px + 8);
+#pragma unroll
+            for (int x = 0; x < 4; x++)
+            {
+                int sum = 0;
+#pragma unroll
+                for (int k = 0; k < 8; k++) sum += px[x + k] * c[k];
+                o[y][x] = clip_pixel(as_i16((sum + 32) >> 6), maxv);
+            }
+        }
+    }
+    else if (xf == 0)
+    {
+        int c[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) c[k] = kLumaTaps[yf][k];
+        int v[11][4];
+#pragma unroll
+        for (int y = 0; y < 11; y++)
+            Px<P>::unpack(Px<P>::load(r + (y - 3) * stride), v[y]);
+#pragma unroll
+        for (int y = 0; y < 4; y++)
+#pragma unroll
+            for (int x = 0; x < 4; x++)
+            {
+                int sum = 0;
+#pragma unroll
+                for (int k = 0; k < 8; k++) sum += v[y + k][x] * c[k];
+                o[y][x] = clip_pixel(as_i16((sum + 32) >> 6), maxv);
+            }
+    }
+    else
+    {
+        int ch[8], cv[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) { ch[k] = kLumaTaps[xf][k]; cv[k] = kLumaTaps[yf][k]; }
+        const int headRoom = 14 - depth;
+        const int shiftH = 6 - headRoom;
+        const int offH = -(8192 << shiftH);
+        const int shiftV = 6 + headRoom;
+        const int offV = (1 << (shiftV - 1)) + (8192 << 6);
+        int im[11][4];
+#pragma unroll
+        for (int y = 0; y < 11; y++)
+        {
+            int px[12];
+            const P *row = r + (y - 3) * stride - 3;
+            Px<P>::unpack(Px<P>::load(row), px);
+            Px<P>::unpack(Px<P>::load(row + 4), px + 4);
+            Px<P>::unpack(Px<P>::load(row + 8), px + 8);
+#pragma unroll
+            for (int x = 0; x < 4; x++)
+            {
+                int sum = 0;
+#pragma unroll
+                for (int k = 0; k < 8; k++) sum += px[x + k] * ch[k];
+                im[y][x] = as_i16((sum + offH) >> shiftH);
+            }
+        }
+#pragma unroll
+        for (int y = 0; y < 4; y++)
+#pragma unroll
+            for (int x = 0; x < 4; x++)
+            {
+                int sum = 0;
+#pragma unroll
+                for (int k = 0; k < 8; k++) sum += im[y + k][x] * cv[k];
+                o[y][x] = clip_pixel(as_i16((sum + offV) >> shiftV), maxv);
+            }
+    }
+}
+
+/* cost of one tile given the 4 packed source rows and 16 predicted pixels */
+template<typename P>
+__device__ __forceinline__ int tile_cost_px(const typename Px<P>::quad f[4], const int o[4][4], bool satd)
+{
+    int d[4][4];
+#pragma unroll
+    for (int y = 0; y < 4; y++)
+    {
+        int fv[4];
+        Px<P>::unpack(f[y], fv);
+#pragma unroll
+        for (int x = 0; x < 4; x++) d[y][x] = fv[x] - o[y][x];
+    }
+    if (satd)
+        return had4x4_half(d);
+    int s = 0;
+#pragma unroll
+    for (int y = 0; y < 4; y++)
+#pragma unroll
+        for (int x = 0; x < 4; x++) s += abs(d[y][x]);
+    return s;
+}
+
+/* cost of one tile against 4 packed reference rows */
+template<typename P>
+__device__ __forceinline__ int tile_cost_quads(const typename Px<P>::quad f[4], const typename Px<P>::quad q[4], bool satd)
+{
+    if (!satd)
+    {
+        int s = 0;
+#pragma unroll
+        for (int y = 0; y < 4; y++) s = Px<P>::sad(f[y], q[y], s);
+        return s;
+    }
+    int o[4][4];
+#pragma unroll
+    for (int y = 0; y < 4; y++) Px<P>::unpack(q[y], o[y]);
+    return tile_cost_px<P>(f, o, true);
+}
+
+} // namespace x265amd
+#endif

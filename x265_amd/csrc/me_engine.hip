@@ -1,0 +1,744 @@
+/* Host side of the C ABI (include/x265_amd_me.h) and the kernels it launches.
+ * Built for gfx950 only: hipcc --offload-arch=gfx950. */
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <math.h>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "me_search.h"
+
+using namespace x265amd;
+
+/* ------------------------------------------------------------------ kernels */
+
+/* XCD-aware job order: consecutive workgroup ids land on different XCDs (each with
+ * its own L2), so ids are remapped to give every XCD one contiguous run of jobs --
+ * neighbouring PUs read overlapping reference windows and then share an L2. */
+__device__ __forceinline__ int xcd_remap(int bid, int n)
+{
+    const int q = n >> 3, r = n & 7, x = bid & 7;
+    return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (bid >> 3);
+}
+
+struct SearchArgs
+{
+    PlaneDev fenc;
+    PlaneDev ref[4];
+    int nref, lowres, depth, method, subme;
+    const uint16_t *ctab;
+    const x265amd_job *jobs;
+    x265amd_result *results;
+    int njobs;
+};
+
+template<typename P, bool LOWRES>
+__global__ __launch_bounds__(64) void search_kernel(SearchArgs a)
+{
+    __shared__ WaveLds<P, LOWRES ? 8 : 64> lds;
+    const int j = xcd_remap(blockIdx.x, a.njobs);
+    if (j >= a.njobs) return;
+    const x265amd_job *job = a.jobs + j;
+    Searcher<P, LOWRES ? 8 : 64, LOWRES> S;
+    S.bind(&lds, a.fenc, a.ref, a.nref, a.ctab, a.depth, job->pu_x, job->pu_y, job->w, job->h);
+    S.search(job, a.method, a.subme, a.results + j);
+}
+
+/* subpelCompare for a batch of PUs (motion.cpp:1651-1689) */
+template<typename P>
+__global__ __launch_bounds__(64) void subpel_compare_kernel(SearchArgs a, int cmp)
+{
+    __shared__ WaveLds<P, 64> lds;
+    const int j = blockIdx.x;
+    if (j >= a.njobs) return;
+    const x265amd_job *job = a.jobs + j;
+    Searcher<P, 64> S;
+    S.bind(&lds, a.fenc, a.ref, a.nref, a.ctab, a.depth, job->pu_x, job->pu_y, job->w, job->h);
+    S.nsad = S.nsub = 0;
+    S.mvpx = S.mvpy = 0;
+    const int c = S.qdist(job->qmvp[0], job->qmvp[1], cmp ? 2 : 1);
+    if ((threadIdx.x & 63) == 0)
+    {
+        a.results[j].mv[0] = job->qmvp[0]; a.results[j].mv[1] = job->qmvp[1];
+        a.results[j].cost = c; a.results[j].sad_calls = 0; a.results[j].subpel_calls = 1;
+    }
+}
+
+/* Lookahead: one workgroup per lowres field, LA_WAVES waves walking the reverse-raster
+ * dependency wavefront. CU (x, y) needs the final MVs of (x+1, y) and of
+ * (x-1 .. x+1, y+1) (slicetype.cpp:1450-1459), so all CUs with equal
+ * (W-1-x) + 2 (H-1-y) are independent; one barrier separates the steps. */
+#define LA_WAVES 16
+struct FieldDev
+{
+    PlaneDev fenc;
+    PlaneDev ref[4];
+};
+
+struct LookaheadArgs
+{
+    const FieldDev *fields;
+    int wcu, hcu, depth, method, subme, merange;
+    const uint16_t *ctab;
+    int16_t *mvs;        /* nfields * ncu * 2 */
+    int32_t *costs;      /* nfields * ncu */
+    x265amd_result *stats; /* nfields * ncu or null */
+};
+
+__device__ __forceinline__ int median3(int a, int b, int c)
+{
+    const int lo = a < b ? a : b, hi = a < b ? b : a;
+    const int m = lo > c ? lo : c;
+    return m < hi ? m : hi;
+}
+
+template<typename P>
+__global__ __launch_bounds__(LA_WAVES * 64) void lookahead_kernel(LookaheadArgs a)
+{
+    __shared__ WaveLds<P, 8> lds[LA_WAVES];
+    __shared__ x265amd_job jobs[LA_WAVES];
+    __shared__ x265amd_result results[LA_WAVES];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int W = a.wcu, H = a.hcu, ncu = W * H;
+    const FieldDev &f = a.fields[blockIdx.x];
+    int16_t *mvs = a.mvs + (size_t)blockIdx.x * ncu * 2;
+    int32_t *costs = a.costs + (size_t)blockIdx.x * ncu;
+    const int nsteps = (W - 1) + 2 * (H - 1) + 1;
+    for (int s = 0; s < nsteps; s++)
+    {
+        /* CUs of this step: yy = H-1-y in [ylo, yhi], xx = s - 2 yy in [0, W-1] */
+        int ylo = (s - (W - 1) + 1) >> 1;
+        if (ylo < 0) ylo = 0;
+        int yhi = s >> 1;
+        if (yhi > H - 1) yhi = H - 1;
+        for (int yy = ylo + wave; yy <= yhi; yy += LA_WAVES)
+        {
+            const int xx = s - 2 * yy;
+            const int cux = W - 1 - xx, cuy = H - 1 - yy;
+            const int cuXY = cux + cuy * W;
+            x265amd_job *job = &jobs[wave];
+            if (lane == 0)
+            {
+                /* slicetype.cpp:1427-1466 */
+                job->pu_x = (int16_t)(cux * 8); job->pu_y = (int16_t)(cuy * 8);
+                job->w = 8; job->h = 8;
+                job->mvmin[0] = (int16_t)(uint16_t)(-cux * 8 - 8);
+                job->mvmin[1] = (int16_t)(uint16_t)(-cuy * 8 - 8);
+                job->mvmax[0] = (int16_t)(uint16_t)((W - cux - 1) * 8 + 8);
+                job->mvmax[1] = (int16_t)(uint16_t)((H - cuy - 1) * 8 + 8);
+                int numc = 0;
+                int16_t (*mvc)[2] = job->mvc;
+                for (int i = 0; i < 4; i++) { mvc[i][0] = 0; mvc[i][1] = 0; }
+                const int16_t *m = mvs + 2 * cuXY;
+#define MVC(idx) do { mvc[numc][0] = m[2 * (idx)]; mvc[numc][1] = m[2 * (idx) + 1]; numc++; } while (0)
+                if (cux < W - 1) MVC(1);
+                if (cuy < H - 1)
+                {
+                    MVC(W);
+                    if (cux > 0) MVC(W - 1);
+                    if (cux < W - 1) MVC(W + 1);
+                }
+#undef MVC
+                if (numc <= 1) { job->qmvp[0] = mvc[0][0]; job->qmvp[1] = mvc[0][1]; }
+                else
+                {
+                    job->qmvp[0] = (int16_t)median3(mvc[0][0], mvc[1][0], mvc[2][0]);
+                    job->qmvp[1] = (int16_t)median3(mvc[0][1], mvc[1][1], mvc[2][1]);
+                }
+                job->numc = (uint8_t)numc;
+                job->merange = a.merange;
+            }
+            wave_sync();
+            Searcher<P, 8, true> S;
+            S.bind(&lds[wave], f.fenc, f.ref, 4, a.ctab, a.depth, cux * 8, cuy * 8, 8, 8);
+            S.search(job, a.method, a.subme, &results[wave]);
+            wave_sync();
+            if (lane == 0)
+            {
+                mvs[2 * cuXY] = results[wave].mv[0];
+                mvs[2 * cuXY + 1] = results[wave].mv[1];
+                costs[cuXY] = results[wave].cost;
+                if (a.stats) a.stats[(size_t)blockIdx.x * ncu + cuXY] = results[wave];
+            }
+        }
+        __syncthreads();
+    }
+}
+
+/* frame_init_lowres_core (pixel.cpp:595-618): one thread per lowres pixel, four outputs */
+template<typename P>
+__global__ void lowres_core_kernel(const P *src, P *d0, P *dh, P *dv, P *dc, long ss, long ds, int w, int h)
+{
+    const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y * blockDim.y + threadIdx.y;
+    if (x >= w || y >= h) return;
+    const P *s0 = src + (long)2 * y * ss + 2 * x, *s1 = s0 + ss, *s2 = s1 + ss;
+    const int a0 = s0[0], a1 = s0[1], a2 = s0[2], b0 = s1[0], b1 = s1[1], b2 = s1[2], c0 = s2[0], c1 = s2[1], c2 = s2[2];
+#define F4(p, q, r, s) ((((((p) + (q) + 1) >> 1) + (((r) + (s) + 1) >> 1) + 1) >> 1))
+    d0[y * ds + x] = (P)F4(a0, b0, a1, b1);
+    dh[y * ds + x] = (P)F4(a1, b1, a2, b2);
+    dv[y * ds + x] = (P)F4(b0, c0, b1, c1);
+    dc[y * ds + x] = (P)F4(b1, c1, b2, c2);
+#undef F4
+}
+
+/* xExtendPicCompBorder (TComPicYuv.cpp:169-): replicate the picture edge into the
+ * margins; one thread per padded-plane sample outside the picture */
+template<typename P>
+__global__ void extend_border_kernel(P *origin, long stride, int w, int h, int mx, int my)
+{
+    const int x = (int)(blockIdx.x * blockDim.x + threadIdx.x) - mx, y = (int)(blockIdx.y * blockDim.y + threadIdx.y) - my;
+    if (x >= w + mx || y >= h + my) return;
+    if (x >= 0 && x < w && y >= 0 && y < h) return;
+    const int sx = x < 0 ? 0 : (x >= w ? w - 1 : x), sy = y < 0 ? 0 : (y >= h ? h - 1 : y);
+    origin[y * stride + x] = origin[sy * stride + sx];
+}
+
+/* ---- per-call primitives (EncoderPrimitives mirror); operands are staged copies ---- */
+
+/* sad / satd / sa8d of up to 4 reference blocks against one source block.
+ * mode 0 sad, 1 satd, 2 sa8d_inter. One wave; lane-per-tile (4x4, or 8x8 for sa8d). */
+template<typename P>
+__global__ __launch_bounds__(64) void prim_cmp_kernel(const P *fenc, long fs, const P *r0, const P *r1, const P *r2, const P *r3,
+                                                      long rs, int w, int h, int mode, int nref, int32_t *out)
+{
+    const int lane = threadIdx.x;
+    const P *refs[4] = { r0, r1, r2, r3 };
+    for (int n = 0; n < nref; n++)
+    {
+        const P *ref = refs[n];
+        int v = 0;
+        const bool use8 = mode == 2 && !(w & 7) && !(h & 7);
+        if (!use8)
+        {
+            const int wt = w >> 2, T = wt * (h >> 2);
+            for (int t = lane; t < T; t += 64)
+            {
+                const int ty = t / wt, tx = t - ty * wt;
+                typename Px<P>::quad f[4], q[4];
+                for (int y = 0; y < 4; y++)
+                {
+                    f[y] = Px<P>::load(fenc + (ty * 4 + y) * fs + tx * 4);
+                    q[y] = Px<P>::load(ref + (ty * 4 + y) * rs + tx * 4);
+                }
+                v += tile_cost_quads<P>(f, q, mode != 0);
+            }
+            for (int o = 1; o < 64; o <<= 1) v += __shfl_xor(v, o);
+        }
+        else
+        {
+            /* sa8d: 8x8 Hadamard per lane (pixel.cpp:290-325); 16-multiples round once per
+             * 16x16 (pixel.cpp:332-342, :361-376), others per 8x8 (:344-359) */
+            const int wb = w >> 3, B = wb * (h >> 3);
+            const bool per16 = !(w & 15) && !(h & 15);
+            for (int b0 = 0; b0 < B; b0 += 64)
+            {
+                const int b = b0 + lane;
+                int s = 0;
+                if (b < B)
+                {
+                    int bx, by;
+                    if (per16)
+                    {
+                        /* order blocks so that the 4 of one 16x16 sit in adjacent lanes */
+                        const int g = b >> 2, sub = b & 3, gw = w >> 4;
+                        by = (g / gw) * 2 + (sub >> 1); bx = (g % gw) * 2 + (sub & 1);
+                    }
+                    else { by = b / wb; bx = b - by * wb; }
+                    int m[8][8];
+                    for (int y = 0; y < 8; y++)
+                    {
+                        int fa[8], ra[8];
+                        Px<P>::unpack(Px<P>::load(fenc + (by * 8 + y) * fs + bx * 8), fa);
+                        Px<P>::unpack(Px<P>::load(fenc + (by * 8 + y) * fs + bx * 8 + 4), fa + 4);
+                        Px<P>::unpack(Px<P>::load(ref + (by * 8 + y) * rs + bx * 8), ra);
+                        Px<P>::unpack(Px<P>::load(ref + (by * 8 + y) * rs + bx * 8 + 4), ra + 4);
+                        for (int x = 0; x < 8; x++) m[y][x] = fa[x] - ra[x];
+                    }
+#pragma unroll
+                    for (int y = 0; y < 8; y++)
+#pragma unroll
+                        for (int st = 1; st < 8; st <<= 1)
+#pragma unroll
+                            for (int x = 0; x < 8; x++)
+                                if (!(x & st)) { int p = m[y][x], q = m[y][x + st]; m[y][x] = p + q; m[y][x + st] = p - q; }
+#pragma unroll
+                    for (int x = 0; x < 8; x++)
+#pragma unroll
+                        for (int st = 1; st < 8; st <<= 1)
+#pragma unroll
+                            for (int y = 0; y < 8; y++)
+                                if (!(y & st)) { int p = m[y][x], q = m[y + st][x]; m[y][x] = p + q; m[y + st][x] = p - q; }
+#pragma unroll
+                    for (int y = 0; y < 8; y++)
+#pragma unroll
+                        for (int x = 0; x < 8; x++) s += abs(m[y][x]);
+                }
+                if (per16)
+                {
+                    s += __shfl_xor(s, 1);
+                    s += __shfl_xor(s, 2);
+                    s = ((lane & 3) == 0 && b < B) ? ((s + 2) >> 2) : 0;
+                }
+                else
+                    s = b < B ? ((s + 2) >> 2) : 0;
+                for (int o = 1; o < 64; o <<= 1) s += __shfl_xor(s, o);
+                v += s;
+            }
+        }
+        if (lane == 0) out[n] = v;
+    }
+}
+
+/* mode 0 luma_hpp, 1 luma_vpp, 2 luma_hps, 3 luma_vsp; one thread per output sample */
+template<typename P>
+__global__ void prim_filter_kernel(const void *srcv, long ss, void *dstv, long ds, int ci, int w, int rows, int mode, int depth)
+{
+    const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y * blockDim.y + threadIdx.y;
+    if (x >= w || y >= rows) return;
+    const int maxv = (1 << depth) - 1;
+    int sum = 0;
+    if (mode == 0 || mode == 2)
+    {
+        const P *s = (const P*)srcv + y * ss + x - 3;
+        for (int k = 0; k < 8; k++) sum += (int)s[k] * kLumaTaps[ci][k];
+    }
+    else if (mode == 1)
+    {
+        const P *s = (const P*)srcv + (y - 3) * ss + x;
+        for (int k = 0; k < 8; k++) sum += (int)s[k * ss] * kLumaTaps[ci][k];
+    }
+    else
+    {
+        const int16_t *s = (const int16_t*)srcv + (y - 3) * ss + x;
+        for (int k = 0; k < 8; k++) sum += (int)s[k * ss] * kLumaTaps[ci][k];
+    }
+    const int headRoom = 14 - depth;
+    if (mode == 0 || mode == 1)
+        ((P*)dstv)[y * ds + x] = (P)clip_pixel(as_i16((sum + 32) >> 6), maxv);
+    else if (mode == 2)
+    {
+        const int shift = 6 - headRoom;
+        ((int16_t*)dstv)[y * ds + x] = (int16_t)((sum - (8192 << shift)) >> shift);
+    }
+    else
+    {
+        const int shift = 6 + headRoom;
+        ((P*)dstv)[y * ds + x] = (P)clip_pixel(as_i16((sum + (1 << (shift - 1)) + (8192 << 6)) >> shift), maxv);
+    }
+}
+
+template<typename P>
+__global__ void prim_avg_kernel(P *dst, long ds, const P *a, long sa, const P *b, long sb, int w, int h)
+{
+    const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y * blockDim.y + threadIdx.y;
+    if (x >= w || y >= h) return;
+    dst[y * ds + x] = (P)(((int)a[y * sa + x] + (int)b[y * sb + x] + 1) >> 1);
+}
+
+/* ------------------------------------------------------------------ host */
+
+/* lambda^2 for non-I slices, TComRom.cpp:529-541 (x265_lambda2_non_I) */
+static const double kLambda2NonI[70] = {
+    0.05231, 0.060686, 0.07646, 0.096333333, 0.151715667, 0.15292, 0.192666667, 0.242745, 0.382299,
+    0.385333333, 0.485489333, 0.611678333, 0.963333333, 0.970979, 1.223356667, 1.541333333, 2.427447667,
+    2.446714, 3.082666667, 3.883916667, 6.116785, 6.165333333, 7.767833333, 9.786856667, 15.41333333,
+    16.57137733, 22.183542, 29.5936, 39.357022, 52.19656867, 69.05173333, 91.14257667, 150.0651347,
+    157.8325333, 207.1422197, 271.4221573, 443.904, 447.4271947, 563.722941, 710.2464, 1118.567987,
+    1127.445883, 1420.4928, 1789.70878, 2818.614706, 2840.9856, 3579.41756, 4509.78353, 7102.464,
+    7158.83512, 9019.56706, 11363.9424, 14317.66967, 18039.13269, 22727.8821, 28635.33594, 36078.2611,
+    45455.7588, 57270.66508, 72156.51362, 90911.5068, 114541.3166, 144313.0101, 181822.992, 229082.6059,
+    288625.9859, 363645.9408, 458165.1574, 577251.9032, 727291.7952
+};
+
+static const uint8_t kPartWH[X265AMD_NUM_LUMA_PARTITIONS][2] = {
+    {4,4}, {8,8}, {8,4}, {4,8}, {16,16}, {16,8}, {8,16}, {16,12}, {12,16}, {16,4}, {4,16},
+    {32,32}, {32,16}, {16,32}, {32,24}, {24,32}, {32,8}, {8,32},
+    {64,64}, {64,32}, {32,64}, {64,48}, {48,64}, {64,16}, {16,64}
+};
+
+struct x265amd_ctx
+{
+    int device;
+    int depth;
+    hipStream_t stream;
+    std::map<int, uint16_t*> tables; /* qp -> device table, 65536 entries, index mvd + 32768 */
+    std::string err;
+    void *d_jobs; size_t jobs_cap;
+    void *d_results; size_t results_cap;
+    void *d_stage; size_t stage_cap;   /* staging for the per-call primitives */
+    int32_t *d_out;
+};
+
+static int fail(x265amd_ctx *c, int code, const std::string &msg)
+{
+    if (c) c->err = msg;
+    return code;
+}
+
+#define HIPCHK(c, call) do { hipError_t _e = (call); if (_e != hipSuccess) \
+        return fail((c), X265AMD_EHIP, std::string(#call) + ": " + hipGetErrorString(_e)); } while (0)
+
+static int ensure(x265amd_ctx *c, void **p, size_t *cap, size_t need)
+{
+    if (*cap >= need) return 0;
+    if (*p) { HIPCHK(c, hipFree(*p)); *p = 0; *cap = 0; }
+    size_t n = need + need / 2 + 4096;
+    HIPCHK(c, hipMalloc(p, n));
+    *cap = n;
+    return 0;
+}
+
+extern "C" {
+
+int x265amd_partition_from_sizes(int w, int h)
+{
+    for (int i = 0; i < X265AMD_NUM_LUMA_PARTITIONS; i++)
+        if (kPartWH[i][0] == w && kPartWH[i][1] == h) return i;
+    return -1;
+}
+
+int x265amd_create(int device, int bit_depth, x265amd_ctx **out)
+{
+    if (!out || !(bit_depth == 8 || bit_depth == 10 || bit_depth == 12)) return X265AMD_EINVAL;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || device < 0 || device >= n) return X265AMD_EHIP;
+    x265amd_ctx *c = new x265amd_ctx();
+    c->device = device; c->depth = bit_depth;
+    c->d_jobs = c->d_results = c->d_stage = 0; c->jobs_cap = c->results_cap = c->stage_cap = 0; c->d_out = 0;
+    if (hipSetDevice(device) != hipSuccess || hipStreamCreate(&c->stream) != hipSuccess ||
+        hipMalloc((void**)&c->d_out, 64) != hipSuccess)
+    {
+        delete c;
+        return X265AMD_EHIP;
+    }
+    *out = c;
+    return X265AMD_OK;
+}
+
+void x265amd_destroy(x265amd_ctx *c)
+{
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    for (std::map<int, uint16_t*>::iterator it = c->tables.begin(); it != c->tables.end(); ++it) (void)hipFree(it->second);
+    if (c->d_jobs) (void)hipFree(c->d_jobs);
+    if (c->d_results) (void)hipFree(c->d_results);
+    if (c->d_stage) (void)hipFree(c->d_stage);
+    if (c->d_out) (void)hipFree(c->d_out);
+    (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+const char *x265amd_last_error(const x265amd_ctx *c) { return c ? c->err.c_str() : "null context"; }
+void *x265amd_stream(x265amd_ctx *c) { return c ? (void*)c->stream : 0; }
+
+/* BitCost::CalculateLogs + setQP (bitcost.cpp:34-83): bit sizes in float,
+ * scaled by sqrt(lambda2) in double, +0.5f, clamped to 65535, truncated. */
+static void build_cost_table(int qp, uint16_t *tab /* 65536, index mvd + 32768 */)
+{
+    const double lambda = sqrt(kLambda2NonI[qp]);
+    const float log2_2 = 2.0f / logf(2.0f);
+    tab[0] = 0;
+    for (int i = 0; i < 32768; i++)
+    {
+        const float bits = i ? logf((float)(i + 1)) * log2_2 + 1.718f : 0.718f;
+        double v = bits * lambda + 0.5f;
+        if (v > 65535.0) v = 65535.0;
+        const uint16_t cst = (uint16_t)v;
+        tab[32768 + i] = cst;
+        tab[32768 - i] = cst;
+    }
+}
+
+int x265amd_set_qp(x265amd_ctx *c, int qp)
+{
+    if (!c || qp < 0 || qp >= 70) return fail(c, X265AMD_EINVAL, "qp out of range [0, 69]");
+    if (c->tables.count(qp)) return X265AMD_OK;
+    HIPCHK(c, hipSetDevice(c->device));
+    std::vector<uint16_t> tab(65536);
+    build_cost_table(qp, tab.data());
+    uint16_t *d = 0;
+    HIPCHK(c, hipMalloc((void**)&d, 65536 * sizeof(uint16_t)));
+    HIPCHK(c, hipMemcpy(d, tab.data(), 65536 * sizeof(uint16_t), hipMemcpyHostToDevice));
+    c->tables[qp] = d;
+    return X265AMD_OK;
+}
+
+int x265amd_cost_table(x265amd_ctx *c, int qp, uint16_t *out)
+{
+    if (!c || !out || qp < 0 || qp >= 70) return fail(c, X265AMD_EINVAL, "bad argument");
+    std::vector<uint16_t> tab(65536);
+    build_cost_table(qp, tab.data());
+    memcpy(out, tab.data() + 1, 65535 * sizeof(uint16_t));
+    return X265AMD_OK;
+}
+
+static size_t plane_bytes(const x265amd_ctx *c, int height, int margin_y, int stride)
+{
+    return (size_t)(height + 2 * margin_y) * stride * (c->depth > 8 ? 2 : 1);
+}
+
+static int plane_alloc(x265amd_ctx *c, int width, int height, int mx, int my, int stride, x265amd_plane *out)
+{
+    const int bpp = c->depth > 8 ? 2 : 1;
+    void *d = 0;
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipMalloc(&d, plane_bytes(c, height, my, stride)));
+    out->origin = (char*)d + ((size_t)my * stride + mx) * bpp;
+    out->stride = stride; out->width = width; out->height = height; out->margin_x = mx; out->margin_y = my;
+    return X265AMD_OK;
+}
+
+int x265amd_plane_upload(x265amd_ctx *c, const void *buf, int width, int height, int mx, int my, int stride,
+                         x265amd_plane *out)
+{
+    if (!c || !buf || !out || width <= 0 || height <= 0 || mx < 0 || my < 0 || stride < width + 2 * mx)
+        return fail(c, X265AMD_EINVAL, "bad plane geometry");
+    int rc = plane_alloc(c, width, height, mx, my, stride, out);
+    if (rc) return rc;
+    const int bpp = c->depth > 8 ? 2 : 1;
+    void *base = (char*)out->origin - ((size_t)my * stride + mx) * bpp;
+    HIPCHK(c, hipMemcpy(base, buf, plane_bytes(c, height, my, stride), hipMemcpyHostToDevice));
+    return X265AMD_OK;
+}
+
+int x265amd_plane_free(x265amd_ctx *c, x265amd_plane *p)
+{
+    if (!c || !p || !p->origin) return fail(c, X265AMD_EINVAL, "null plane");
+    const int bpp = c->depth > 8 ? 2 : 1;
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipFree((char*)p->origin - ((size_t)p->margin_y * p->stride + p->margin_x) * bpp));
+    p->origin = 0;
+    return X265AMD_OK;
+}
+
+int x265amd_plane_download(x265amd_ctx *c, const x265amd_plane *p, void *buf)
+{
+    if (!c || !p || !p->origin || !buf) return fail(c, X265AMD_EINVAL, "null plane");
+    const int bpp = c->depth > 8 ? 2 : 1;
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipMemcpy(buf, (char*)p->origin - ((size_t)p->margin_y * p->stride + p->margin_x) * bpp,
+                        plane_bytes(c, p->height, p->margin_y, p->stride), hipMemcpyDeviceToHost));
+    return X265AMD_OK;
+}
+
+int x265amd_lowres_init(x265amd_ctx *c, const x265amd_plane *src, x265amd_plane out[4])
+{
+    if (!c || !src || !src->origin || !out) return fail(c, X265AMD_EINVAL, "null plane");
+    /* lowres.cpp:33-44: half size rounded up to whole 8x8 CUs; stride rounded to 32 */
+    int w = src->width / 2, h = src->height / 2;
+    w = ((w + 7) >> 3) * 8; h = ((h + 7) >> 3) * 8;
+    if (2 * w + 2 > src->width + src->margin_x || 2 * h + 2 > src->height + src->margin_y)
+        return fail(c, X265AMD_EINVAL, "source margins too small for the lowres filter footprint");
+    int stride = w + 2 * src->margin_x;
+    if (stride & 31) stride += 32 - (stride & 31);
+    for (int i = 0; i < 4; i++)
+    {
+        int rc = plane_alloc(c, w, h, src->margin_x, src->margin_y, stride, &out[i]);
+        if (rc) return rc;
+    }
+    dim3 blk(64, 4), grd((w + 63) / 64, (h + 3) / 4);
+    dim3 grd2((w + 2 * src->margin_x + 63) / 64, (h + 2 * src->margin_y + 3) / 4);
+    if (c->depth <= 8)
+    {
+        hipLaunchKernelGGL(lowres_core_kernel<uint8_t>, grd, blk, 0, c->stream, (const uint8_t*)src->origin,
+                           (uint8_t*)out[0].origin, (uint8_t*)out[1].origin, (uint8_t*)out[2].origin, (uint8_t*)out[3].origin,
+                           (long)src->stride, (long)stride, w, h);
+        for (int i = 0; i < 4; i++)
+            hipLaunchKernelGGL(extend_border_kernel<uint8_t>, grd2, blk, 0, c->stream, (uint8_t*)out[i].origin, (long)stride,
+                               w, h, src->margin_x, src->margin_y);
+    }
+    else
+    {
+        hipLaunchKernelGGL(lowres_core_kernel<uint16_t>, grd, blk, 0, c->stream, (const uint16_t*)src->origin,
+                           (uint16_t*)out[0].origin, (uint16_t*)out[1].origin, (uint16_t*)out[2].origin, (uint16_t*)out[3].origin,
+                           (long)src->stride, (long)stride, w, h);
+        for (int i = 0; i < 4; i++)
+            hipLaunchKernelGGL(extend_border_kernel<uint16_t>, grd2, blk, 0, c->stream, (uint16_t*)out[i].origin, (long)stride,
+                               w, h, src->margin_x, src->margin_y);
+    }
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return X265AMD_OK;
+}
+
+/* Every address a job can touch must lie inside the padded planes: candidates in
+ * [mvmin-3, mvmax+3] (hexagon / square steps are unchecked), the 8-tap footprint of
+ * the sub-pel refinement around them, and MV (0,0). */
+static int validate_jobs(x265amd_ctx *c, const x265amd_plane *fenc, const x265amd_plane *ref, int is_lowres,
+                         int method, int subme, const x265amd_job *jobs, int njobs)
+{
+    if (method < 0 || method > X265AMD_FULL || subme < 0 || subme > 7) return fail(c, X265AMD_EINVAL, "bad method / subme");
+    if (method == X265AMD_UMH) return fail(c, X265AMD_EINVAL, "UMH search is not implemented on the device yet");
+    for (int i = 0; i < njobs; i++)
+    {
+        const x265amd_job &j = jobs[i];
+        if (x265amd_partition_from_sizes(j.w, j.h) <= 0) return fail(c, X265AMD_EINVAL, "job: not a searchable luma partition");
+        if (is_lowres && !(j.w == 8 && j.h == 8)) return fail(c, X265AMD_EINVAL, "lowres searches are 8x8 only");
+        if (j.numc > 4) return fail(c, X265AMD_EINVAL, "job: numc > 4");
+        if (j.mvmin[0] > j.mvmax[0] || j.mvmin[1] > j.mvmax[1]) return fail(c, X265AMD_EINVAL, "job: empty search range");
+        if (j.pu_x < 0 || j.pu_y < 0 || j.pu_x + j.w > fenc->width + fenc->margin_x || j.pu_y + j.h > fenc->height + fenc->margin_y)
+            return fail(c, X265AMD_EINVAL, "job: PU outside the source plane");
+        const int apron = 8;
+        const int x0 = j.pu_x + (j.mvmin[0] < 0 ? j.mvmin[0] : 0) - apron, x1 = j.pu_x + j.w + (j.mvmax[0] > 0 ? j.mvmax[0] : 0) + apron;
+        const int y0 = j.pu_y + (j.mvmin[1] < 0 ? j.mvmin[1] : 0) - apron, y1 = j.pu_y + j.h + (j.mvmax[1] > 0 ? j.mvmax[1] : 0) + apron;
+        if (x0 < -ref->margin_x || y0 < -ref->margin_y || x1 > ref->width + ref->margin_x || y1 > ref->height + ref->margin_y)
+            return fail(c, X265AMD_EINVAL, "job: search window leaves the padded reference plane");
+    }
+    return 0;
+}
+
+static void fill_args(x265amd_ctx *c, SearchArgs &a, const x265amd_plane *fenc, const x265amd_plane *ref, int is_lowres,
+                      int qp, int method, int subme)
+{
+    a.fenc.origin = fenc->origin; a.fenc.stride = fenc->stride;
+    a.nref = is_lowres ? 4 : 1;
+    for (int i = 0; i < 4; i++)
+    {
+        const x265amd_plane *r = &ref[i < a.nref ? i : 0];
+        a.ref[i].origin = r->origin; a.ref[i].stride = r->stride;
+    }
+    a.lowres = is_lowres; a.depth = c->depth; a.method = method; a.subme = subme;
+    a.ctab = c->tables[qp] + 32768;
+}
+
+int x265amd_search_batch_dev(x265amd_ctx *c, const x265amd_plane *fenc, const x265amd_plane *ref, int is_lowres,
+                             int qp, int method, int subme, const x265amd_job *d_jobs, int njobs, x265amd_result *d_results)
+{
+    if (!c || !fenc || !ref || !d_jobs || !d_results || njobs < 0) return fail(c, X265AMD_EINVAL, "null argument");
+    if (method < 0 || method > X265AMD_FULL || method == X265AMD_UMH || subme < 0 || subme > 7)
+        return fail(c, X265AMD_EINVAL, "bad method / subme");
+    int rc = x265amd_set_qp(c, qp);
+    if (rc) return rc;
+    if (!njobs) return X265AMD_OK;
+    HIPCHK(c, hipSetDevice(c->device));
+    SearchArgs a;
+    fill_args(c, a, fenc, ref, is_lowres, qp, method, subme);
+    a.jobs = d_jobs; a.results = d_results; a.njobs = njobs;
+    if (c->depth <= 8)
+    {
+        if (is_lowres) hipLaunchKernelGGL((search_kernel<uint8_t, true>), dim3(njobs), dim3(64), 0, c->stream, a);
+        else hipLaunchKernelGGL((search_kernel<uint8_t, false>), dim3(njobs), dim3(64), 0, c->stream, a);
+    }
+    else
+    {
+        if (is_lowres) hipLaunchKernelGGL((search_kernel<uint16_t, true>), dim3(njobs), dim3(64), 0, c->stream, a);
+        else hipLaunchKernelGGL((search_kernel<uint16_t, false>), dim3(njobs), dim3(64), 0, c->stream, a);
+    }
+    HIPCHK(c, hipGetLastError());
+    return X265AMD_OK;
+}
+
+int x265amd_sync(x265amd_ctx *c)
+{
+    if (!c) return X265AMD_EINVAL;
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return X265AMD_OK;
+}
+
+int x265amd_search_batch(x265amd_ctx *c, const x265amd_plane *fenc, const x265amd_plane *ref, int is_lowres,
+                         int qp, int method, int subme, const x265amd_job *jobs, int njobs, x265amd_result *results)
+{
+    if (!c || !fenc || !ref || !jobs || !results || njobs < 0) return fail(c, X265AMD_EINVAL, "null argument");
+    int rc = validate_jobs(c, fenc, ref, is_lowres, method, subme, jobs, njobs);
+    if (rc) return rc;
+    if (!njobs) return X265AMD_OK;
+    HIPCHK(c, hipSetDevice(c->device));
+    if ((rc = ensure(c, &c->d_jobs, &c->jobs_cap, (size_t)njobs * sizeof(x265amd_job)))) return rc;
+    if ((rc = ensure(c, &c->d_results, &c->results_cap, (size_t)njobs * sizeof(x265amd_result)))) return rc;
+    HIPCHK(c, hipMemcpyAsync(c->d_jobs, jobs, (size_t)njobs * sizeof(x265amd_job), hipMemcpyHostToDevice, c->stream));
+    rc = x265amd_search_batch_dev(c, fenc, ref, is_lowres, qp, method, subme, (const x265amd_job*)c->d_jobs, njobs,
+                                  (x265amd_result*)c->d_results);
+    if (rc) return rc;
+    HIPCHK(c, hipMemcpyAsync(results, c->d_results, (size_t)njobs * sizeof(x265amd_result), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return X265AMD_OK;
+}
+
+int x265amd_subpel_compare_batch(x265amd_ctx *c, const x265amd_plane *fenc, const x265amd_plane *ref, int cmp,
+                                 const x265amd_job *jobs, int njobs, x265amd_result *results)
+{
+    if (!c || !fenc || !ref || !jobs || !results || njobs < 0) return fail(c, X265AMD_EINVAL, "null argument");
+    if (!njobs) return X265AMD_OK;
+    int rc = x265amd_set_qp(c, 12);
+    if (rc) return rc;
+    for (int i = 0; i < njobs; i++)
+        if (x265amd_partition_from_sizes(jobs[i].w, jobs[i].h) < 0) return fail(c, X265AMD_EINVAL, "job: not a luma partition");
+    HIPCHK(c, hipSetDevice(c->device));
+    if ((rc = ensure(c, &c->d_jobs, &c->jobs_cap, (size_t)njobs * sizeof(x265amd_job)))) return rc;
+    if ((rc = ensure(c, &c->d_results, &c->results_cap, (size_t)njobs * sizeof(x265amd_result)))) return rc;
+    HIPCHK(c, hipMemcpyAsync(c->d_jobs, jobs, (size_t)njobs * sizeof(x265amd_job), hipMemcpyHostToDevice, c->stream));
+    SearchArgs a;
+    fill_args(c, a, fenc, ref, 0, 12, 0, 0);
+    a.jobs = (const x265amd_job*)c->d_jobs; a.results = (x265amd_result*)c->d_results; a.njobs = njobs;
+    if (c->depth <= 8)
+        hipLaunchKernelGGL(subpel_compare_kernel<uint8_t>, dim3(njobs), dim3(64), 0, c->stream, a, cmp);
+    else
+        hipLaunchKernelGGL(subpel_compare_kernel<uint16_t>, dim3(njobs), dim3(64), 0, c->stream, a, cmp);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipMemcpyAsync(results, c->d_results, (size_t)njobs * sizeof(x265amd_result), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return X265AMD_OK;
+}
+
+int x265amd_lookahead_fields(x265amd_ctx *c, const x265amd_field *fields, int nfields, int wcu, int hcu,
+                             int qp, int method, int subme, int merange,
+                             int16_t *out_mvs, int32_t *out_costs, x265amd_result *out_stats)
+{
+    if (!c || !fields || nfields < 0 || wcu <= 0 || hcu <= 0 || !out_mvs || !out_costs)
+        return fail(c, X265AMD_EINVAL, "null argument");
+    if (method < 0 || method > X265AMD_FULL || method == X265AMD_UMH || subme < 0 || subme > 7)
+        return fail(c, X265AMD_EINVAL, "bad method / subme");
+    if (!nfields) return X265AMD_OK;
+    for (int i = 0; i < nfields; i++)
+    {
+        const x265amd_plane &p = fields[i].ref[0];
+        /* slicetype.cpp:1427-1430: MVs may reach 8 px outside the frame, +3 unchecked
+         * hexagon steps, + the 8x8 block itself on the far side */
+        if (p.margin_x < 16 || p.margin_y < 16 || p.width < wcu * 8 || p.height < hcu * 8)
+            return fail(c, X265AMD_EINVAL, "lowres plane geometry does not cover the CU grid + 16 px");
+    }
+    int rc = x265amd_set_qp(c, qp);
+    if (rc) return rc;
+    HIPCHK(c, hipSetDevice(c->device));
+    const size_t ncu = (size_t)wcu * hcu;
+    std::vector<FieldDev> hf(nfields);
+    for (int i = 0; i < nfields; i++)
+    {
+        hf[i].fenc.origin = fields[i].fenc.origin; hf[i].fenc.stride = fields[i].fenc.stride;
+        for (int k = 0; k < 4; k++) { hf[i].ref[k].origin = fields[i].ref[k].origin; hf[i].ref[k].stride = fields[i].ref[k].stride; }
+    }
+    const size_t fbytes = nfields * sizeof(FieldDev), mvbytes = nfields * ncu * 4, cbytes = nfields * ncu * 4;
+    const size_t sbytes = out_stats ? nfields * ncu * sizeof(x265amd_result) : 0;
+    if ((rc = ensure(c, &c->d_jobs, &c->jobs_cap, fbytes))) return rc;
+    if ((rc = ensure(c, &c->d_results, &c->results_cap, mvbytes + cbytes + sbytes))) return rc;
+    HIPCHK(c, hipMemcpyAsync(c->d_jobs, hf.data(), fbytes, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemsetAsync(c->d_results, 0, mvbytes + cbytes + sbytes, c->stream));
+    LookaheadArgs a;
+    a.fields = (const FieldDev*)c->d_jobs;
+    a.wcu = wcu; a.hcu = hcu; a.depth = c->depth; a.method = method; a.subme = subme; a.merange = merange;
+    a.ctab = c->tables[qp] + 32768;
+    a.mvs = (int16_t*)c->d_results;
+    a.costs = (int32_t*)((char*)c->d_results + mvbytes);
+    a.stats = out_stats ? (x265amd_result*)((char*)c->d_results + mvbytes + cbytes) : 0;
+    if (c->depth <= 8)
+        hipLaunchKernelGGL(lookahead_kernel<uint8_t>, dim3(nfields), dim3(LA_WAVES * 64), 0, c->stream, a);
+    else
+        hipLaunchKernelGGL(lookahead_kernel<uint16_t>, dim3(nfields), dim3(LA_WAVES * 64), 0, c->stream, a);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipMemcpyAsync(out_mvs, a.mvs, mvbytes, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(out_costs, a.costs, cbytes, hipMemcpyDeviceToHost, c->stream));
+    if (out_stats) HIPCHK(c, hipMemcpyAsync(out_stats, a.stats, sbytes, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return X265AMD_OK;
+}
+
+} /* extern "C" */
+
+#include "me_primitives.inc"

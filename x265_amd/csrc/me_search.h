@@ -1,0 +1,624 @@
+/* One-wavefront motion search: MotionEstimate::motionEstimate re-designed for a
+ * 64-lane wave (reference: source/encoder/motion.cpp:549-1146).
+ *
+ * The search decisions are sequential and data dependent, so one wave owns one PU
+ * and walks the reference's decision sequence with wave-uniform control flow.
+ * What runs in parallel is every group of candidates the reference evaluates
+ * before it next looks at a cost: each (candidate, 4x4 tile) pair goes to one
+ * lane (me_device.h), per-candidate sums come from a segmented butterfly, and the
+ * candidates' lambda*bits terms are gathered by one lane each. Costs are then
+ * compared in the reference's visit order with its strict '<', which keeps every
+ * tie-break identical.
+ */
+#ifndef X265AMD_ME_SEARCH_H
+#define X265AMD_ME_SEARCH_H
+
+#include "me_device.h"
+#include "../../include/x265_amd_me.h"
+
+namespace x265amd {
+
+#define MAXC 16
+
+/* radius-2 hexagon with wrap-around entries, (x-1)%6, motion.cpp:145-146 */
+__constant__ static const int8_t kHex2[8][2] = { {-1,-2}, {-2,0}, {-1,2}, {1,2}, {2,0}, {1,-2}, {-1,-2}, {-2,0} };
+__constant__ static const uint8_t kMod6m1[8] = { 5, 0, 1, 2, 3, 4, 5, 0 };
+/* first hexagon ring in the order the reference measures it (motion.cpp:673-681) */
+__constant__ static const int8_t kHexRing[6][2] = { {-2,0}, {-1,2}, {1,2}, {2,0}, {1,-2}, {-1,-2} };
+/* offsets for the two-point search, motion.cpp:156-166 */
+__constant__ static const int8_t kTwoPoint[16][2] = { {-1,0}, {0,-1}, {-1,-1}, {1,-1}, {-1,0}, {1,0}, {-1,1}, {-1,-1},
+                                                      {1,-1}, {1,1}, {-1,0}, {0,1}, {-1,1}, {1,1}, {1,0}, {0,1} };
+/* SubpelWorkload {hpel_iters, hpel_dirs, qpel_iters, qpel_dirs, hpel_satd}, motion.cpp:53-63 */
+__constant__ static const int8_t kWorkload[8][5] = { {1,4,0,4,0}, {1,4,1,4,0}, {1,4,1,4,1}, {2,4,1,4,1},
+                                                     {2,4,2,4,1}, {1,8,1,8,1}, {2,8,1,8,1}, {2,8,2,8,1} };
+
+struct PlaneDev
+{
+    const void *origin;
+    int stride;
+};
+
+/* per-wave LDS working set */
+template<typename P, int ROWS = 64>
+struct WaveLds
+{
+    P   fenc[ROWS * 64];   /* source PU, stride 64 (FENC_STRIDE) */
+    int sx[MAXC], sy[MAXC];   /* where to measure: full-pel offset, or qpel MV */
+    int mvx[MAXC], mvy[MAXC]; /* MV charged for the candidate (same units) */
+    int sh[MAXC];             /* left shift applied to mv before the cost lookup */
+    int meta[MAXC];
+    int costs[MAXC];
+};
+
+/* LOWRES selects the lookahead flavour at compile time (half-pel planes instead of
+ * interpolation), which keeps the 8-tap code out of the lookahead kernel. */
+template<typename P, int ROWS = 64, bool LOWRES = false>
+struct Searcher
+{
+    WaveLds<P, ROWS> *L;
+    const P *ref[4];
+    long roff;          /* pu_y * rstride + pu_x */
+    int rstride;
+    const uint16_t *ctab; /* centred MVD cost table */
+    int mvpx, mvpy;
+    int w, h, T, Tp, lTp, wt, inv_wt;
+    int lane, depth;
+    static constexpr bool is_lowres = LOWRES;
+    unsigned nsad, nsub;
+
+    __device__ __forceinline__ int mvcost(int x, int y) const
+    {
+        /* bitcost.h:46 -- the sum is truncated to uint16 */
+        return ((int)ctab[x - mvpx] + (int)ctab[y - mvpy]) & 0xffff;
+    }
+
+    __device__ __forceinline__ void tile_xy(int t, int &tx, int &ty) const
+    {
+        ty = (t * inv_wt) >> 16;
+        tx = t - ty * wt;
+    }
+
+    __device__ __forceinline__ void load_fenc_tile(int tx, int ty, typename Px<P>::quad f[4]) const
+    {
+#pragma unroll
+        for (int y = 0; y < 4; y++) f[y] = Px<P>::load_aligned(L->fenc + (ty * 4 + y) * 64 + tx * 4);
+    }
+
+    /* cost of tile t of candidate k. mode 0: full-pel SAD at offset (sx, sy);
+     * mode 1/2: SAD / SATD at qpel MV (sx, sy) through subpelCompare or lowresQPelCost */
+    __device__ __forceinline__ int tile_cost(int k, int t, int mode) const
+    {
+        int tx, ty;
+        tile_xy(t, tx, ty);
+        typename Px<P>::quad f[4], q[4];
+        load_fenc_tile(tx, ty, f);
+        const int cx = L->sx[k], cy = L->sy[k];
+        if (mode == 0)
+        {
+            const P *r = ref[0] + roff + (long)(cy + ty * 4) * rstride + cx + tx * 4;
+#pragma unroll
+            for (int y = 0; y < 4; y++) q[y] = Px<P>::load(r + y * rstride);
+            return tile_cost_quads<P>(f, q, false);
+        }
+        const bool satd = mode == 2;
+        if constexpr (LOWRES)
+        {
+            /* lowres.h:78-97: pick the hpel plane; odd qpel = average with the next one */
+            const int hpelA = (cy & 2) | ((cx & 2) >> 1);
+            const P *ra = ref[hpelA] + roff + (long)((cy >> 2) + ty * 4) * rstride + (cx >> 2) + tx * 4;
+#pragma unroll
+            for (int y = 0; y < 4; y++) q[y] = Px<P>::load(ra + y * rstride);
+            if ((cx | cy) & 1)
+            {
+                const int bx = as_i16(cx + (cx & 1) * 2), by = as_i16(cy + (cy & 1) * 2);
+                const int hpelB = (by & 2) | ((bx & 2) >> 1);
+                const P *rb = ref[hpelB] + roff + (long)((by >> 2) + ty * 4) * rstride + (bx >> 2) + tx * 4;
+#pragma unroll
+                for (int y = 0; y < 4; y++) q[y] = Px<P>::avg(q[y], Px<P>::load(rb + y * rstride));
+            }
+            return tile_cost_quads<P>(f, q, satd);
+        }
+        else
+        {
+        const int xf = cx & 3, yf = cy & 3;
+        const P *r = ref[0] + roff + (long)((cy >> 2) + ty * 4) * rstride + (cx >> 2) + tx * 4;
+        if ((xf | yf) == 0)
+        {
+#pragma unroll
+            for (int y = 0; y < 4; y++) q[y] = Px<P>::load(r + y * rstride);
+            return tile_cost_quads<P>(f, q, satd);
+        }
+        int o[4][4];
+        interp_tile<P>(r, rstride, xf, yf, depth, o);
+        return tile_cost_px<P>(f, o, satd);
+        }
+    }
+
+    /* costs[k] = distortion(k) [+ mvcost(mv[k] << sh[k])] for k < K */
+    __device__ __noinline__ void eval(int K, int mode, bool addmv)
+    {
+        wave_sync();
+        if (Tp <= 64)
+        {
+            const int g = lane >> lTp, t = lane & (Tp - 1);
+            const int cpp = 64 >> lTp;
+            for (int k0 = 0; k0 < K; k0 += cpp)
+            {
+                const int k = k0 + g;
+                int v = 0;
+                if (k < K && t < T) v = tile_cost(k, t, mode);
+                for (int o = 1; o < Tp; o <<= 1) v += __shfl_xor(v, o);
+                if (t == 0 && k < K) L->costs[k] = v;
+            }
+        }
+        else
+        {
+            for (int k = 0; k < K; k++)
+            {
+                int v = 0;
+                for (int t = lane; t < T; t += 64) v += tile_cost(k, t, mode);
+                for (int o = 1; o < 64; o <<= 1) v += __shfl_xor(v, o);
+                if (lane == 0) L->costs[k] = v;
+            }
+        }
+        wave_sync();
+        if (addmv && lane < K)
+        {
+            const int s = L->sh[lane];
+            L->costs[lane] += mvcost(as_i16(L->mvx[lane] << s), as_i16(L->mvy[lane] << s));
+        }
+        wave_sync();
+        if (mode == 0) nsad += K; else nsub += K;
+    }
+
+    __device__ __forceinline__ void put(int k, int sx_, int sy_, int mx_, int my_, int sh_, int meta_)
+    {
+        L->sx[k] = sx_; L->sy[k] = sy_; L->mvx[k] = mx_; L->mvy[k] = my_; L->sh[k] = sh_; L->meta[k] = meta_;
+    }
+
+    __device__ __forceinline__ int cost_of(int k) const { return uni(L->costs[k]); }
+
+    /* single evaluations */
+    __device__ __forceinline__ int fpcost(int mx, int my)
+    {
+        put(0, mx, my, mx, my, 2, 0);
+        eval(1, 0, true);
+        return cost_of(0);
+    }
+    __device__ __forceinline__ int qdist(int qx, int qy, int mode)
+    {
+        put(0, qx, qy, qx, qy, 0, 0);
+        eval(1, mode, false);
+        return cost_of(0);
+    }
+
+    __device__ __forceinline__ bool in_range(int x, int y, int mnx, int mny, int mxx, int mxy) const
+    {
+        return x >= mnx && x <= mxx && y >= mny && y <= mxy;
+    }
+
+    /* Evaluate the K queued full-pel candidates (meta = point | dist << 8) and fold
+     * them into the running best in queue order; COST_MV_PT_DIST, motion.cpp:182-194 */
+    __device__ __forceinline__ void fold_pt(int K, int &bmx, int &bmy, int &bcost, int &bPointNr, int &bDistance)
+    {
+        if (!K) return;
+        eval(K, 0, true);
+        for (int k = 0; k < K; k++)
+        {
+            const int c = cost_of(k);
+            if (c < bcost)
+            {
+                bcost = c;
+                bmx = uni(L->mvx[k]); bmy = uni(L->mvy[k]);
+                const int m = uni(L->meta[k]);
+                bPointNr = m & 0xff; bDistance = m >> 8;
+            }
+        }
+    }
+
+    /* StarPatternSearch, motion.cpp:307-547. One diamond ring per round; every
+     * in-range point of a round is independent of the others, so a round is one
+     * batched evaluation folded in the reference's visit order. */
+    __device__ void star_pattern(int mnx, int mny, int mxx, int mxy, int &bmx, int &bmy, int &bcost,
+                                 int &bPointNr, int &bDistance, int earlyExitIters, int merange)
+    {
+        const int ox = bmx, oy = bmy;
+        int saved = bcost, rounds = 0;
+        int K;
+#define QPT(x_, y_, pt_, d_) do { put(K, (x_), (y_), (x_), (y_), 2, (pt_) | ((d_) << 8)); K++; } while (0)
+        {
+            const int top = as_i16(oy - 1), bottom = as_i16(oy + 1), left = as_i16(ox - 1), right = as_i16(ox + 1);
+            K = 0;
+            if (top >= mny) QPT(ox, top, 2, 1);
+            if (left >= mnx) QPT(left, oy, 4, 1);
+            if (right <= mxx) QPT(right, oy, 5, 1);
+            if (bottom <= mxy) QPT(ox, bottom, 7, 1);
+            fold_pt(K, bmx, bmy, bcost, bPointNr, bDistance);
+            if (bcost < saved) rounds = 0;
+            else if (++rounds >= earlyExitIters) return;
+        }
+        for (int dist = 2; dist <= 8; dist <<= 1)
+        {
+            const int hd = dist >> 1;
+            const int top = as_i16(oy - dist), bottom = as_i16(oy + dist), left = as_i16(ox - dist), right = as_i16(ox + dist);
+            const int top2 = as_i16(oy - hd), bottom2 = as_i16(oy + hd), left2 = as_i16(ox - hd), right2 = as_i16(ox + hd);
+            saved = bcost;
+            K = 0;
+            /* visit order 2,1,3,4,5,6,8,7 in both the all-inside and the clipped branch */
+            if (top >= mny) QPT(ox, top, 2, dist);
+            if (top2 >= mny)
+            {
+                if (left2 >= mnx) QPT(left2, top2, 1, hd);
+                if (right2 <= mxx) QPT(right2, top2, 3, hd);
+            }
+            if (left >= mnx) QPT(left, oy, 4, dist);
+            if (right <= mxx) QPT(right, oy, 5, dist);
+            if (bottom2 <= mxy)
+            {
+                if (left2 >= mnx) QPT(left2, bottom2, 6, hd);
+                if (right2 <= mxx) QPT(right2, bottom2, 8, hd);
+            }
+            if (bottom <= mxy) QPT(ox, bottom, 7, dist);
+            fold_pt(K, bmx, bmy, bcost, bPointNr, bDistance);
+            if (bcost < saved) rounds = 0;
+            else if (++rounds >= earlyExitIters) return;
+        }
+        for (int dist = 16; dist <= as_i16(merange) && dist > 0; dist = as_i16(dist << 1))
+        {
+            const int top = as_i16(oy - dist), bottom = as_i16(oy + dist), left = as_i16(ox - dist), right = as_i16(ox + dist);
+            saved = bcost;
+            K = 0;
+            if (top >= mny) QPT(ox, top, 0, dist);
+            if (left >= mnx) QPT(left, oy, 0, dist);
+            if (right <= mxx) QPT(right, oy, 0, dist);
+            if (bottom <= mxy) QPT(ox, bottom, 0, dist);
+            for (int index = 1; index < 4; index++)
+            {
+                const int q = (dist >> 2) * index;
+                const int posYT = as_i16(top + q), posYB = as_i16(bottom - q);
+                const int posXL = as_i16(ox - q), posXR = as_i16(ox + q);
+                if (posYT >= mny)
+                {
+                    if (posXL >= mnx) QPT(posXL, posYT, 0, dist);
+                    if (posXR <= mxx) QPT(posXR, posYT, 0, dist);
+                }
+                if (posYB <= mxy)
+                {
+                    if (posXL >= mnx) QPT(posXL, posYB, 0, dist);
+                    if (posXR <= mxx) QPT(posXR, posYB, 0, dist);
+                }
+            }
+            fold_pt(K, bmx, bmy, bcost, bPointNr, bDistance);
+            if (bcost < saved) rounds = 0;
+            else if (++rounds >= earlyExitIters) return;
+        }
+#undef QPT
+    }
+
+    /* Two extra points next to a distance-1 winner, motion.cpp:918-946 / :992-1015 */
+    __device__ __forceinline__ void two_point(int bPointNr, int mnx, int mny, int mxx, int mxy,
+                                              int &bmx, int &bmy, int &bcost)
+    {
+        const int i0 = (bPointNr - 1) * 2;
+        const int x1 = as_i16(bmx + kTwoPoint[i0][0]), y1 = as_i16(bmy + kTwoPoint[i0][1]);
+        const int x2 = as_i16(bmx + kTwoPoint[i0 + 1][0]), y2 = as_i16(bmy + kTwoPoint[i0 + 1][1]);
+        int K = 0;
+        /* the second point is measured relative to the ORIGINAL bmv and folded after
+         * the first, exactly as the two COST_MV calls do */
+        if (in_range(x1, y1, mnx, mny, mxx, mxy)) { put(K, x1, y1, x1, y1, 2, 0); K++; }
+        if (in_range(x2, y2, mnx, mny, mxx, mxy)) { put(K, x2, y2, x2, y2, 2, 0); K++; }
+        int pn = 0, pd = 0;
+        fold_pt(K, bmx, bmy, bcost, pn, pd);
+    }
+
+    /* the whole of motionEstimate for one PU */
+    __device__ void search(const x265amd_job *job, int method, int subme, x265amd_result *res)
+    {
+        const int mnx = job->mvmin[0], mny = job->mvmin[1], mxx = job->mvmax[0], mxy = job->mvmax[1];
+        const int qmnx = as_i16(mnx << 2), qmny = as_i16(mny << 2), qmxx = as_i16(mxx << 2), qmxy = as_i16(mxy << 2);
+        const int numc = job->numc;
+        int merange = job->merange;
+        mvpx = job->qmvp[0]; mvpy = job->qmvp[1]; /* setMVP, bitcost.h:43 */
+        nsad = 0; nsub = 0;
+
+#define CLIPX(v) ((v) > qmxx ? qmxx : ((v) < qmnx ? qmnx : (v)))
+#define CLIPY(v) ((v) > qmxy ? qmxy : ((v) < qmny ? qmny : (v)))
+        /* clipped qpel predictor, measured without its own mvcost (motion.cpp:575-582) */
+        int pmx = CLIPX(mvpx), pmy = CLIPY(mvpy);
+        int bpx = pmx, bpy = pmy;
+        int bprecost = qdist(pmx, pmy, 1);
+
+        int bmx = as_i16((pmx + 2) >> 2), bmy = as_i16((pmy + 2) >> 2);
+        int bcost = bprecost;
+        if ((pmx | pmy) & 3)
+            bcost = fpcost(bmx, bmy);
+        if (pmx | pmy)
+        {
+            const int c = fpcost(0, 0);
+            if (c < bcost) { bcost = c; bmx = 0; bmy = 0; }
+        }
+
+        /* qpel candidates, motion.cpp:603-621 (sequential: each test depends on bestpre) */
+        for (int i = 0; i < numc; i++)
+        {
+            const int cx = CLIPX((int)job->mvc[i][0]), cy = CLIPY((int)job->mvc[i][1]);
+            if ((cx | cy) && !(cx == pmx && cy == pmy) && !(cx == bpx && cy == bpy))
+            {
+                put(0, cx, cy, cx, cy, 0, 0);
+                eval(1, 1, true);
+                const int c = cost_of(0);
+                if (c < bprecost) { bprecost = c; bpx = cx; bpy = cy; }
+            }
+        }
+#undef CLIPX
+#undef CLIPY
+        pmx = as_i16((pmx + 2) >> 2); pmy = as_i16((pmy + 2) >> 2);
+
+        bool run_hex = false;
+        switch (method)
+        {
+        case X265AMD_DIA:
+        {
+            /* motion.cpp:628-649; the packed (cost << 4) + dir compare is a strict
+             * '<' scan in the order N, S, W, E */
+            int i = merange;
+            do
+            {
+                put(0, bmx, bmy - 1, as_i16(bmx), as_i16(bmy - 1), 2, 0);
+                put(1, bmx, bmy + 1, as_i16(bmx), as_i16(bmy + 1), 2, 0);
+                put(2, bmx - 1, bmy, as_i16(bmx - 1), as_i16(bmy), 2, 0);
+                put(3, bmx + 1, bmy, as_i16(bmx + 1), as_i16(bmy), 2, 0);
+                eval(4, 0, true);
+                int dir = -1;
+                for (int k = 0; k < 4; k++)
+                {
+                    const int c = cost_of(k);
+                    if (c < bcost) { bcost = c; dir = k; }
+                }
+                if (dir < 0) break;
+                bmx = uni(L->mvx[dir]); bmy = uni(L->mvy[dir]);
+            }
+            while (--i && in_range(bmx, bmy, mnx, mny, mxx, mxy));
+            break;
+        }
+        case X265AMD_HEX:
+            run_hex = true;
+            break;
+        case X265AMD_STAR:
+        {
+            /* motion.cpp:911-1019 */
+            int bPointNr = 0, bDistance = 0;
+            star_pattern(mnx, mny, mxx, mxy, bmx, bmy, bcost, bPointNr, bDistance, 3, merange);
+            bool done = false;
+            if (bDistance == 1)
+            {
+                if (bPointNr)
+                {
+                    const int saved = bcost;
+                    two_point(bPointNr, mnx, mny, mxx, mxy, bmx, bmy, bcost);
+                    if (bcost == saved) done = true;
+                }
+                else
+                    done = true;
+            }
+            if (done) break;
+
+            if (bDistance > 5)
+            {
+                /* raster refinement with step 5. Groups of four consecutive x positions are
+                 * costed together; the 4th one's MV bits use tmv << 3 (motion.cpp:975). */
+                for (int ty = as_i16(mny); ty <= mxy; ty = as_i16(ty + 5))
+                {
+                    int K = 0;
+                    for (int tx = as_i16(mnx); tx <= mxx; tx = as_i16(tx + 5))
+                    {
+                        if (tx + 15 <= mxx)
+                        {
+                            if (K + 4 > MAXC) { int pn, pd; fold_pt(K, bmx, bmy, bcost, pn, pd); K = 0; }
+                            for (int k = 0; k < 4; k++)
+                            {
+                                put(K, tx + 5 * k, ty, as_i16(tx + 5 * k), ty, k == 3 ? 3 : 2, 0);
+                                K++;
+                            }
+                            tx = as_i16(tx + 15);
+                        }
+                        else
+                        {
+                            if (K + 1 > MAXC) { int pn, pd; fold_pt(K, bmx, bmy, bcost, pn, pd); K = 0; }
+                            put(K, tx, ty, tx, ty, 2, 0);
+                            K++;
+                        }
+                    }
+                    int pn, pd;
+                    fold_pt(K, bmx, bmy, bcost, pn, pd);
+                }
+            }
+
+            while (bDistance > 0)
+            {
+                bDistance = 0;
+                bPointNr = 0;
+                star_pattern(mnx, mny, mxx, mxy, bmx, bmy, bcost, bPointNr, bDistance, 32, merange);
+                if (bDistance == 1)
+                {
+                    if (!bPointNr) break;
+                    two_point(bPointNr, mnx, mny, mxx, mxy, bmx, bmy, bcost);
+                    break;
+                }
+            }
+            break;
+        }
+        case X265AMD_FULL:
+        {
+            /* motion.cpp:1021-1056: raster scan, strict '<' keeps the first minimum */
+            int K = 0, pn, pd;
+            for (int ty = mny; ty <= mxy; ty++)
+                for (int tx = mnx; tx <= mxx; tx++)
+                {
+                    put(K, tx, ty, tx, ty, 2, 0);
+                    if (++K == MAXC) { fold_pt(K, bmx, bmy, bcost, pn, pd); K = 0; }
+                }
+            fold_pt(K, bmx, bmy, bcost, pn, pd);
+            break;
+        }
+        default:
+            break;
+        }
+
+        if (run_hex)
+        {
+            /* motion.cpp:651-723. Hexagon points and the closing square are evaluated
+             * without a range check, as in the reference. */
+            /* first ring: direction codes 2..7 in measuring order */
+            for (int k = 0; k < 6; k++)
+                put(k, bmx + kHexRing[k][0], bmy + kHexRing[k][1], as_i16(bmx + kHexRing[k][0]), as_i16(bmy + kHexRing[k][1]), 2, 0);
+            eval(6, 0, true);
+            int code = 0;
+            for (int k = 0; k < 6; k++)
+            {
+                const int c = cost_of(k);
+                if (c < bcost) { bcost = c; code = k + 2; }
+            }
+            if (code)
+            {
+                int dir = code - 2;
+                bmx = as_i16(bmx + kHex2[dir + 1][0]); bmy = as_i16(bmy + kHex2[dir + 1][1]);
+                for (int i = (merange >> 1) - 1; i > 0 && in_range(bmx, bmy, mnx, mny, mxx, mxy); i--)
+                {
+                    for (int k = 0; k < 3; k++)
+                        put(k, bmx + kHex2[dir + k][0], bmy + kHex2[dir + k][1],
+                            as_i16(bmx + kHex2[dir + k][0]), as_i16(bmy + kHex2[dir + k][1]), 2, 0);
+                    eval(3, 0, true);
+                    int step = 0;
+                    for (int k = 0; k < 3; k++)
+                    {
+                        const int c = cost_of(k);
+                        if (c < bcost) { bcost = c; step = k + 1; }
+                    }
+                    if (!step) break;
+                    dir += step - 2;
+                    dir = kMod6m1[dir + 1];
+                    bmx = as_i16(bmx + kHex2[dir + 1][0]); bmy = as_i16(bmy + kHex2[dir + 1][1]);
+                }
+            }
+            /* square refine */
+            for (int k = 1; k <= 8; k++)
+                put(k - 1, bmx + kSquare1[k][0], bmy + kSquare1[k][1],
+                    as_i16(bmx + kSquare1[k][0]), as_i16(bmy + kSquare1[k][1]), 2, 0);
+            eval(8, 0, true);
+            int dir = 0;
+            for (int k = 0; k < 8; k++)
+            {
+                const int c = cost_of(k);
+                if (c < bcost) { bcost = c; dir = k + 1; }
+            }
+            bmx = as_i16(bmx + kSquare1[dir][0]); bmy = as_i16(bmy + kSquare1[dir][1]);
+        }
+
+        /* motion.cpp:1063-1069 */
+        int qx, qy;
+        if (bprecost < bcost) { qx = bpx; qy = bpy; bcost = bprecost; }
+        else { qx = as_i16(bmx << 2); qy = as_i16(bmy << 2); }
+
+        const int hpel_iters = kWorkload[subme][0], hpel_dirs = kWorkload[subme][1];
+        const int qpel_iters = kWorkload[subme][2], qpel_dirs = kWorkload[subme][3], hpel_satd = kWorkload[subme][4];
+
+        if (bcost)
+        {
+            /* all directions of one refinement round share the same centre, so a
+             * round is one batched evaluation (motion.cpp:1077-1141) */
+            if (is_lowres)
+            {
+                refine_round(qx, qy, bcost, hpel_dirs, 2, 1);
+                put(0, qx, qy, qx, qy, 0, 0);
+                eval(1, 2, true);
+                bcost = cost_of(0);
+                refine_round(qx, qy, bcost, qpel_dirs, 1, 2);
+            }
+            else
+            {
+                int hmode = 1;
+                if (hpel_satd)
+                {
+                    put(0, qx, qy, qx, qy, 0, 0);
+                    eval(1, 2, true);
+                    bcost = cost_of(0);
+                    hmode = 2;
+                }
+                for (int it = 0; it < hpel_iters; it++)
+                    refine_round(qx, qy, bcost, hpel_dirs, 2, hmode);
+                if (!hpel_satd)
+                {
+                    put(0, qx, qy, qx, qy, 0, 0);
+                    eval(1, 2, true);
+                    bcost = cost_of(0);
+                }
+                for (int it = 0; it < qpel_iters; it++)
+                    refine_round(qx, qy, bcost, qpel_dirs, 1, 2);
+            }
+        }
+
+        if (lane == 0)
+        {
+            res->mv[0] = (int16_t)qx; res->mv[1] = (int16_t)qy;
+            res->cost = bcost;
+            res->sad_calls = nsad; res->subpel_calls = nsub;
+        }
+    }
+
+    __device__ __forceinline__ void refine_round(int &qx, int &qy, int &bcost, int dirs, int step, int mode)
+    {
+        for (int i = 1; i <= dirs; i++)
+        {
+            const int tx = as_i16(qx + kSquare1[i][0] * step), ty = as_i16(qy + kSquare1[i][1] * step);
+            put(i - 1, tx, ty, tx, ty, 0, 0);
+        }
+        eval(dirs, mode, true);
+        int bdir = 0;
+        for (int i = 1; i <= dirs; i++)
+        {
+            const int c = cost_of(i - 1);
+            if (c < bcost) { bcost = c; bdir = i; }
+        }
+        qx = as_i16(qx + kSquare1[bdir][0] * step); qy = as_i16(qy + kSquare1[bdir][1] * step);
+    }
+
+    /* bind to a PU: geometry, tile tables, and the source block copy
+     * (setSourcePU, motion.cpp:116-142) */
+    __device__ __forceinline__ void bind(WaveLds<P, ROWS> *lds, const PlaneDev &fencPl, const PlaneDev *refPl, int nref,
+                                         const uint16_t *costTab, int depth_,
+                                         int pu_x, int pu_y, int w_, int h_)
+    {
+        L = lds;
+        lane = threadIdx.x & 63;
+        depth = depth_;
+        ctab = costTab;
+        w = w_; h = h_;
+        wt = w >> 2;
+        T = wt * (h >> 2);
+        lTp = 0;
+        while ((1 << lTp) < T) lTp++;
+        Tp = 1 << lTp;
+        inv_wt = (65536 + wt - 1) / wt;
+        rstride = refPl[0].stride;
+        roff = (long)pu_y * rstride + pu_x;
+        for (int i = 0; i < 4; i++) ref[i] = (const P*)refPl[i < nref ? i : 0].origin;
+        const P *src = (const P*)fencPl.origin + (long)pu_y * fencPl.stride + pu_x;
+        wave_sync();
+        for (int t = lane; t < T; t += 64)
+        {
+            int tx, ty;
+            tile_xy(t, tx, ty);
+#pragma unroll
+            for (int y = 0; y < 4; y++)
+            {
+                typename Px<P>::quad q = Px<P>::load(src + (long)(ty * 4 + y) * fencPl.stride + tx * 4);
+                *(typename Px<P>::quad*)(L->fenc + (ty * 4 + y) * 64 + tx * 4) = q;
+            }
+        }
+        wave_sync();
+    }
+};
+
+} // namespace x265amd
+#endif
