@@ -1,0 +1,161 @@
+"""Generate the golden vectors under tests/golden/ from the REFERENCE's own code.
+
+Runs only where oracle/_ref/libx265ref{8,10}.so exist (built by oracle/Makefile from
+/root/reference). Inputs are seeded synthetic planes (x265_amd.synth) whose SHA-256
+is stored next to the expected outputs, so a drifting generator is detected instead
+of silently invalidating the vectors.
+
+    python tests/golden/make_golden.py
+"""
+import hashlib
+import json
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+from oracle.bindings import Ref, PARTITIONS, METHODS  # noqa: E402
+from util import clip_planes, random_jobs, host_lowres_planes, margin_for  # noqa: E402
+from oracle.bindings import Oracle  # noqa: E402
+from x265_amd.synth import make_clip  # noqa: E402
+
+ME_W, ME_H = 192, 128
+LA_W, LA_H = 416, 240
+QPS = [0, 12, 20, 24, 30, 37, 51, 69]
+
+
+def sha(a):
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+def me_cases():
+    """(depth, kind, method name, subme) combinations stored in me_golden.npz."""
+    cases = []
+    for depth in (8, 10):
+        for mname in ("dia", "hex", "umh", "star", "full"):
+            for subme in (0, 1, 2, 3, 5, 7):
+                cases.append((depth, "texture" if subme % 2 else "noise", mname, subme))
+    return cases
+
+
+def me_jobs_for(case):
+    depth, kind, mname, subme = case
+    seed = 1000 + depth * 100 + METHODS[mname] * 10 + subme
+    rng = np.random.default_rng(seed)
+    n = 60 if mname != "full" else 16
+    return random_jobs(rng, n, ME_W, ME_H, METHODS[mname])
+
+
+def prim_inputs(depth):
+    rng = np.random.default_rng(42 + depth)
+    maxv = (1 << depth) - 1
+    dt = np.uint8 if depth <= 8 else np.uint16
+    a = rng.integers(0, maxv + 1, size=(160, 256)).astype(dt)
+    b = rng.integers(0, maxv + 1, size=(160, 256)).astype(dt)
+    a[:70, :70] = 0
+    b[:70, :70] = maxv          # extreme differences (saturating SAD / Hadamard range)
+    a[0:70:2, 0:70:2] = maxv
+    return a.reshape(-1), b.reshape(-1)
+
+
+def prim_offsets(part_index):
+    """(fenc offset, ref offset) pairs used per partition: aligned and unaligned."""
+    return [(0, 0), (5 * 256 + 3 + part_index, 9 * 256 + 7 + 2 * part_index), (80 * 256 + 64, 75 * 256 + 33)]
+
+
+def main():
+    out = {}
+    # ---- cost tables
+    ref8 = Ref(8)
+    np.savez_compressed(os.path.join(HERE, "cost_tables.npz"), **{"qp%d" % qp: ref8.cost_table(qp) for qp in QPS})
+
+    # ---- primitives
+    prim = {}
+    for depth in (8, 10):
+        ref = Ref(depth)
+        a, b = prim_inputs(depth)
+        d = {"input_sha": [sha(a), sha(b)], "parts": {}}
+        for pi, (w, h) in enumerate(PARTITIONS):
+            rows = []
+            for (ao, bo) in prim_offsets(pi):
+                fenc = np.ascontiguousarray(a.reshape(160, 256)[:64, :64]).reshape(-1)
+                offs = [bo + k * 3 + k * 256 for k in range(4)]
+                so = bo + 10 * 256 + 10
+                e = {"sad": ref.sad(a, ao, 256, b, bo, 251, w, h), "satd": ref.satd(a, ao, 256, b, bo, 251, w, h),
+                     "sa8d": ref.sa8d_inter(a, ao, 256, b, bo, 251, w, h),
+                     "x3": ref.sad_x3(fenc, b, offs, 251, w, h), "x4": ref.sad_x4(fenc, b, offs, 251, w, h),
+                     "avg": sha(ref.pixelavg(a, ao, 256, b, bo, 251, w, h))}
+                for ci in (1, 2, 3):
+                    e["hpp%d" % ci] = sha(ref.luma_hpp(b, so, 256, ci, w, h))
+                    e["vpp%d" % ci] = sha(ref.luma_vpp(b, so, 256, ci, w, h))
+                    e["hps%d" % ci] = sha(ref.luma_hps(b, so, 256, ci, 0, w, h))
+                    im = ref.luma_hps(b, so, 256, ci, 1, w, h)
+                    e["hpsx%d" % ci] = sha(im)
+                    e["vsp%d" % ci] = sha(ref.luma_vsp(im.reshape(-1), 3 * w, w, ci, w, h))
+                rows.append(e)
+            d["parts"]["%dx%d" % (w, h)] = rows
+        d["lowres"] = [sha(o) for o in ref.lowres_core(a, 0, 256, 100, 70)]
+        prim[str(depth)] = d
+    json.dump(prim, open(os.path.join(HERE, "prim_golden.json"), "w"), indent=0, sort_keys=True)
+
+    # ---- motion search
+    me = {}
+    shas = {}
+    for case in me_cases():
+        depth, kind, mname, subme = case
+        ref = Ref(depth)
+        fenc, rpl, org, stride = clip_planes(ME_W, ME_H, depth, kind, margin=margin_for(METHODS[mname]))
+        shas["%d_%s_%d" % (depth, kind, margin_for(METHODS[mname]))] = [sha(fenc), sha(rpl)]
+        jobs = me_jobs_for(case)
+        qp = 20 + 6 * (depth - 8) + subme
+        ref.me_config(fenc, org, stride, qp, METHODS[mname], subme)
+        exp = np.zeros((len(jobs), 3), np.int32)
+        for i, j in enumerate(jobs):
+            off = int(j["pu_y"]) * stride + int(j["pu_x"])
+            mvc = [tuple(int(v) for v in j["mvc"][k]) for k in range(int(j["numc"]))]
+            mv, cost = ref.me_search(off, int(j["w"]), int(j["h"]), [rpl], org, stride, False,
+                                     tuple(int(v) for v in j["mvmin"]), tuple(int(v) for v in j["mvmax"]),
+                                     tuple(int(v) for v in j["qmvp"]), mvc, int(j["merange"]))
+            exp[i] = (mv[0], mv[1], cost)
+        key = "%d_%s_%s_%d" % case
+        me[key + "_jobs"] = jobs.view(np.uint8).reshape(len(jobs), -1)
+        me[key + "_exp"] = exp
+    np.savez_compressed(os.path.join(HERE, "me_golden.npz"), **me)
+
+    # ---- lookahead fields (config-1 geometry: 416x240 -> 26x15 lowres CUs)
+    la = {}
+    orc = Oracle()
+    for depth in (8, 10):
+        ref = Ref(depth)
+        clip = make_clip(LA_W, LA_H, 4, seed=3, depth=depth)
+        shas["la_%d" % depth] = [sha(clip[3]), sha(clip[1])]
+        # the lowres planes come from the reference's own downscaler
+        pa = host_lowres_planes(ref_as_orc(ref), depth, clip[3], 64)
+        pb = host_lowres_planes(ref_as_orc(ref), depth, clip[1], 64)
+        planes_a, org, stride, wcu, hcu = pa[0], pa[1], pa[2], pa[3], pa[4]
+        for (method, subme) in ((1, 1), (3, 2), (0, 0), (2, 5)):
+            mvs, costs = ref.lookahead_field(planes_a[0], pb[0], org, stride, wcu, hcu, 12 + 6 * (depth - 8), method, subme, 16)
+            la["%d_%d_%d_mvs" % (depth, method, subme)] = mvs
+            la["%d_%d_%d_costs" % (depth, method, subme)] = costs
+    np.savez_compressed(os.path.join(HERE, "lookahead_golden.npz"), **la)
+    json.dump(shas, open(os.path.join(HERE, "input_sha.json"), "w"), indent=0, sort_keys=True)
+    print("golden vectors written to", HERE)
+
+
+class ref_as_orc:
+    """Adapter so util.host_lowres_planes can drive the reference's downscaler."""
+
+    def __init__(self, ref):
+        self.ref = ref
+
+    def lowres_core(self, depth, src, so, ss, w, h):
+        return self.ref.lowres_core(src, so, ss, w, h)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,174 @@
+"""GPU: x265amd_search_batch (HIP) against the CPU oracle and the reference-generated
+golden vectors. Bit-exact bar: identical MV, cost, and evaluation counts."""
+import numpy as np
+import pytest
+
+from x265_amd.engine import METHODS, PARTITIONS, MotionEstimate, make_jobs, EngineError
+import golden_util as G
+from util import clip_planes, random_jobs, oracle_search, MARGIN, margin_for
+
+pytestmark = pytest.mark.gpu
+GPU_METHODS = {k: v for k, v in METHODS.items()}
+
+
+def _engine(request, depth):
+    return request.getfixturevalue("engine8" if depth == 8 else "engine10")
+
+
+@pytest.mark.parametrize("depth", [8, 10])
+def test_golden_vectors(request, depth):
+    e = _engine(request, depth)
+    planes = {}
+    for case, (jobs, exp) in G.me_golden().items():
+        d, kind, mname, subme = case
+        if d != depth:
+            continue
+        m = margin_for(METHODS[mname])
+        if (kind, m) not in planes:
+            fenc, ref, org, stride = clip_planes(G.ME_W, G.ME_H, depth, kind, margin=m)
+            planes[(kind, m)] = (e.upload_plane(fenc, G.ME_W, G.ME_H, m, m, stride),
+                                 e.upload_plane(ref, G.ME_W, G.ME_H, m, m, stride))
+        pf, pr = planes[(kind, m)]
+        r = e.search_batch(pf, pr, jobs, 20 + 6 * (depth - 8) + subme, METHODS[mname], subme)
+        assert np.array_equal(r["mv"], exp[:, :2]), case
+        assert np.array_equal(r["cost"], exp[:, 2]), case
+    for pf, pr in planes.values():
+        e.free_plane(pf)
+        e.free_plane(pr)
+
+
+@pytest.mark.parametrize("depth", [8, 10])
+@pytest.mark.parametrize("mname", sorted(GPU_METHODS))
+def test_random_jobs_vs_oracle(request, oracle, depth, mname):
+    e = _engine(request, depth)
+    method = METHODS[mname]
+    W, H = 320, 192
+    m = margin_for(method)
+    for kind in ("texture", "noise", "static"):
+        fenc, ref, org, stride = clip_planes(W, H, depth, kind, margin=m)
+        pf = e.upload_plane(fenc, W, H, m, m, stride)
+        pr = e.upload_plane(ref, W, H, m, m, stride)
+        for subme in range(8):
+            rng = np.random.default_rng(100 + method * 10 + subme)
+            jobs = random_jobs(rng, 96 if method != 4 else 24, W, H, method)
+            qp = int(rng.integers(10, 45))
+            r = e.search_batch(pf, pr, jobs, qp, method, subme)
+            mv, cost, sc, qc = oracle_search(oracle, depth, fenc, [ref], org, stride, jobs, qp, method, subme)
+            assert np.array_equal(r["mv"], mv), (kind, subme)
+            assert np.array_equal(r["cost"], cost), (kind, subme)
+            assert np.array_equal(r["sad_calls"], sc) and np.array_equal(r["subpel_calls"], qc), (kind, subme)
+        e.free_plane(pf)
+        e.free_plane(pr)
+
+
+def test_every_partition_every_method(engine8, oracle):
+    W, H = 256, 160
+    m = margin_for(2)
+    fenc, ref, org, stride = clip_planes(W, H, 8, "texture", seed=33, margin=m)
+    pf = engine8.upload_plane(fenc, W, H, m, m, stride)
+    pr = engine8.upload_plane(ref, W, H, m, m, stride)
+    for mname, method in GPU_METHODS.items():
+        for part in PARTITIONS[1:]:
+            rng = np.random.default_rng(hash((method,) + part) & 0xffff)
+            jobs = random_jobs(rng, 6 if method != 4 else 2, W, H, method, parts=[part])
+            r = engine8.search_batch(pf, pr, jobs, 26, method, 5)
+            mv, cost, _, _ = oracle_search(oracle, 8, fenc, [ref], org, stride, jobs, 26, method, 5)
+            assert np.array_equal(r["mv"], mv) and np.array_equal(r["cost"], cost), (mname, part)
+
+
+def test_edge_cases(engine8, oracle):
+    """Degenerate ranges, zero-cost blocks (sub-pel skipped, motion.cpp:1073), picture corners."""
+    W, H = 128, 96
+    m = margin_for(2)
+    fenc, _, org, stride = clip_planes(W, H, 8, "static", margin=m)
+    pf = engine8.upload_plane(fenc, W, H, m, m, stride)
+    jobs = make_jobs(6)
+    for i, (px, py, w, h, mn, mx, mvp) in enumerate([
+            (0, 0, 8, 8, (0, 0), (0, 0), (0, 0)),                 # single-point range
+            (W - 64, H - 64, 64, 64, (-8, -8), (8, 8), (3, -5)),  # bottom-right corner CTU
+            (0, 0, 64, 64, (-57, -57), (57, 57), (0, 0)),         # window reaches into the margins
+            (64, 32, 16, 16, (-3, 2), (5, 2), (40, 40)),          # predictor outside the range (gets clipped)
+            (32, 32, 4, 8, (-16, -16), (16, 16), (-7, 9)),
+            (32, 32, 12, 16, (-16, -16), (16, 16), (1, 1))]):
+        j = jobs[i]
+        j["pu_x"], j["pu_y"], j["w"], j["h"] = px, py, w, h
+        j["mvmin"], j["mvmax"], j["qmvp"], j["merange"] = mn, mx, mvp, 16
+        j["numc"] = 2
+        j["mvc"][0] = (0, 0)
+        j["mvc"][1] = (400, -400)
+    for method in GPU_METHODS.values():
+        # identical source and reference: the best cost is 0 wherever (0,0) is reachable
+        r = engine8.search_batch(pf, pf, jobs, 30, method, 5)
+        mv, cost, sc, qc = oracle_search(oracle, 8, fenc, [fenc], org, stride, jobs, 30, method, 5)
+        assert np.array_equal(r["mv"], mv) and np.array_equal(r["cost"], cost)
+        assert np.array_equal(r["sad_calls"], sc) and np.array_equal(r["subpel_calls"], qc)
+    assert len(engine8.search_batch(pf, pf, make_jobs(0), 30, 1, 5)) == 0   # empty batch
+
+
+def test_argument_errors(engine8):
+    W, H = 64, 64
+    fenc, _, org, stride = clip_planes(W, H, 8, "static", margin=32)
+    pf = engine8.upload_plane(fenc, W, H, 32, 32, stride)
+    j = make_jobs(1)
+    j["w"], j["h"] = 16, 16
+    j["mvmin"][0], j["mvmax"][0] = (-16, -16), (16, 16)
+    j["merange"] = 16
+    engine8.search_batch(pf, pf, j, 20, 1, 5)
+    bad = j.copy(); bad["w"] = 20
+    with pytest.raises(EngineError):
+        engine8.search_batch(pf, pf, bad, 20, 1, 5)            # not a partition
+    bad = j.copy(); bad["mvmax"][0] = (200, 16)
+    with pytest.raises(EngineError):
+        engine8.search_batch(pf, pf, bad, 20, 1, 5)            # window leaves the padded plane
+    with pytest.raises(EngineError):
+        engine8.search_batch(pf, pf, j, 20, 9, 5)              # unknown method
+    with pytest.raises(EngineError):
+        engine8.search_batch(pf, pf, j, 99, 1, 5)              # qp out of range
+
+
+def test_motion_estimate_class_mirror(engine8, oracle):
+    """The per-call class reads like the reference call site (TEncSearch.cpp:4266-4303)."""
+    W, H = 192, 128
+    fenc, ref, org, stride = clip_planes(W, H, 8, "texture")
+    pf = engine8.upload_plane(fenc, W, H, MARGIN, MARGIN, stride)
+    pr = engine8.upload_plane(ref, W, H, MARGIN, MARGIN, stride)
+    me = MotionEstimate(engine8)
+    me.setSourcePlane(pf)
+    me.setQP(28)
+    me.setSearchMethod(METHODS["star"])
+    me.setSubpelRefine(5)
+    me.setSourcePU(64, 32, 32, 32)
+    mvc = [(4, -8), (0, 0), (12, 9)]
+    cost, mv = me.motionEstimate(pr, (-57, -57), (57, 57), (5, 3), 3, mvc, 57)
+    ctx = oracle.make_ctx(8, fenc, org, stride, [ref], org, stride, False, 28, 3, 5)
+    assert oracle.me_search(ctx, 32 * stride + 64, 32, 32, (-57, -57), (57, 57), (5, 3), mvc, 57) == (mv, cost)
+    for q in ((0, 0), (2, 0), (0, 3), (1, 2), (-5, 7)):
+        for cmp in (0, 1):
+            assert me.subpelCompare(pr, q, cmp) == oracle.subpel_compare(ctx, 32 * stride + 64, 32, 32, q, cmp)
+
+
+def test_full_size_properties(engine8):
+    """1080p, every 16x16 PU: size-independent properties instead of a CPU replay.
+    (a) searching a frame against itself finds MV 0 with cost 0 everywhere;
+    (b) against a copy shifted by (+3, -2) pixels an exhaustive search recovers exactly that shift with SAD 0
+        (interior PUs), so bcost == mvcost of the shift."""
+    from x265_amd.synth import make_clip, pad_plane
+    W, H = 1920, 1080
+    img = make_clip(W, H, 1, seed=5, kind="noise")[0]
+    buf, org, stride = pad_plane(img, 80)
+    pf = engine8.upload_plane(buf, W, H, 80, 80, stride)
+    shifted = np.roll(img, (-2, 3), axis=(0, 1))      # ref(x + 3, y - 2) == cur(x, y)
+    bufs, _, _ = pad_plane(shifted, 80)
+    ps = engine8.upload_plane(bufs, W, H, 80, 80, stride)
+    xs, ys = np.meshgrid(np.arange(16, W - 32, 16), np.arange(16, H - 32, 16))
+    jobs = make_jobs(xs.size)
+    jobs["pu_x"], jobs["pu_y"] = xs.ravel(), ys.ravel()
+    jobs["w"] = 16; jobs["h"] = 16
+    jobs["mvmin"] = (-4, -4); jobs["mvmax"] = (4, 4); jobs["merange"] = 4
+    r = engine8.search_batch(pf, pf, jobs, 30, METHODS["hex"], 5)
+    assert (r["cost"] == 0).all() and (r["mv"] == 0).all()
+    r = engine8.search_batch(pf, ps, jobs, 30, METHODS["full"], 5)
+    assert (r["mv"] == (12, -8)).all()
+    t = engine8.cost_table(30).astype(np.int64)
+    assert (r["cost"] == t[32767 + 12] + t[32767 - 8]).all()
+    assert (r["sad_calls"] == 81).all()   # the 9x9 raster; the zero predictor itself is measured through subpelCompare

@@ -1,0 +1,68 @@
+"""CPU: the plain-C oracle (oracle/me_oracle.c) against the golden vectors that
+were generated from the reference's own code (tests/golden/make_golden.py)."""
+import numpy as np
+import pytest
+
+from oracle.bindings import PARTITIONS, METHODS
+from x265_amd.synth import make_clip
+import golden_util as G
+from util import clip_planes, oracle_search, host_lowres_planes, margin_for
+
+
+def test_cost_tables(oracle):
+    for qp, tab in G.cost_tables().items():
+        assert np.array_equal(oracle.cost_table(qp), tab), "BitCost table differs at qp %d" % qp
+
+
+@pytest.mark.parametrize("depth", [8, 10])
+def test_primitives(oracle, depth):
+    g = G.prim_golden()[str(depth)]
+    a, b = G.prim_inputs(depth)
+    assert [G.sha(a), G.sha(b)] == g["input_sha"], "synthetic input generator drifted"
+    for pi, (w, h) in enumerate(PARTITIONS):
+        rows = g["parts"]["%dx%d" % (w, h)]
+        for (ao, bo), e in zip(G.prim_offsets(pi), rows):
+            fenc = np.ascontiguousarray(a.reshape(160, 256)[:64, :64]).reshape(-1)
+            offs = [bo + k * 3 + k * 256 for k in range(4)]
+            so = bo + 10 * 256 + 10
+            assert oracle.sad(depth, a, ao, 256, b, bo, 251, w, h) == e["sad"]
+            assert oracle.satd(depth, a, ao, 256, b, bo, 251, w, h) == e["satd"]
+            assert oracle.sa8d_inter(depth, a, ao, 256, b, bo, 251, w, h) == e["sa8d"]
+            assert oracle.sad_x3(depth, fenc, b, offs, 251, w, h) == e["x3"]
+            assert oracle.sad_x4(depth, fenc, b, offs, 251, w, h) == e["x4"]
+            assert G.sha(oracle.pixelavg(depth, a, ao, 256, b, bo, 251, w, h)) == e["avg"]
+            for ci in (1, 2, 3):
+                assert G.sha(oracle.luma_hpp(depth, b, so, 256, ci, w, h)) == e["hpp%d" % ci]
+                assert G.sha(oracle.luma_vpp(depth, b, so, 256, ci, w, h)) == e["vpp%d" % ci]
+                assert G.sha(oracle.luma_hps(depth, b, so, 256, ci, 0, w, h)) == e["hps%d" % ci]
+                im = oracle.luma_hps(depth, b, so, 256, ci, 1, w, h)
+                assert G.sha(im) == e["hpsx%d" % ci]
+                assert G.sha(oracle.luma_vsp(depth, im.reshape(-1), 3 * w, w, ci, w, h)) == e["vsp%d" % ci]
+    assert [G.sha(o) for o in oracle.lowres_core(depth, a, 0, 256, 100, 70)] == g["lowres"]
+
+
+def test_motion_search(oracle):
+    shas = G.input_shas()
+    for case, (jobs, exp) in G.me_golden().items():
+        depth, kind, mname, subme = case
+        m = margin_for(METHODS[mname])
+        fenc, ref, org, stride = clip_planes(G.ME_W, G.ME_H, depth, kind, margin=m)
+        assert [G.sha(fenc), G.sha(ref)] == shas["%d_%s_%d" % (depth, kind, m)], "synthetic clip generator drifted"
+        qp = 20 + 6 * (depth - 8) + subme
+        mv, cost, _, _ = oracle_search(oracle, depth, fenc, [ref], org, stride, jobs, qp, METHODS[mname], subme)
+        assert np.array_equal(mv, exp[:, :2]), case
+        assert np.array_equal(cost, exp[:, 2]), case
+
+
+@pytest.mark.parametrize("depth", [8, 10])
+def test_lookahead_field(oracle, depth):
+    g = G.lookahead_golden()
+    clip = make_clip(G.LA_W, G.LA_H, 4, seed=3, depth=depth)
+    assert [G.sha(clip[3]), G.sha(clip[1])] == G.input_shas()["la_%d" % depth]
+    pa = host_lowres_planes(oracle, depth, clip[3], 64)
+    pb = host_lowres_planes(oracle, depth, clip[1], 64)
+    for (method, subme) in ((1, 1), (3, 2), (0, 0), (2, 5)):
+        ctx = oracle.make_ctx(depth, pa[0][0], pa[1], pa[2], pb[0], pa[1], pa[2], True, 12 + 6 * (depth - 8), method, subme)
+        mvs, costs = oracle.lookahead_field(ctx, pa[3], pa[4], 16)
+        assert np.array_equal(mvs, g["%d_%d_%d_mvs" % (depth, method, subme)])
+        assert np.array_equal(costs, g["%d_%d_%d_costs" % (depth, method, subme)])

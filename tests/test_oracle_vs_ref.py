@@ -1,0 +1,87 @@
+"""CPU: randomized differential check of the plain-C oracle against the reference's
+own code compiled into oracle/_ref (skipped where /root/reference is absent, e.g. on
+the GPU box; the golden-vector tests cover that case)."""
+import numpy as np
+import pytest
+
+from oracle.bindings import Ref, ref_available, PARTITIONS, METHODS, _p
+from util import clip_planes, random_jobs, margin_for
+
+pytestmark = pytest.mark.skipif(not ref_available(8), reason="oracle/_ref not built (reference sources absent)")
+
+
+@pytest.fixture(scope="module", params=[8, 10])
+def ref(request):
+    return Ref(request.param)
+
+
+def test_cost_tables_all_qp(oracle, ref):
+    for qp in range(70):
+        assert np.array_equal(oracle.cost_table(qp), ref.cost_table(qp)), qp
+
+
+def test_search_and_visit_order(oracle, ref):
+    """MV, cost and the exact sequence of full-pel SAD positions, every method."""
+    depth = ref.depth
+    W, H = 256, 160
+    for kind in ("texture", "noise"):
+        for mname, method in METHODS.items():
+            fenc, rpl, org, stride = clip_planes(W, H, depth, kind, margin=margin_for(method))
+            rng = np.random.default_rng(11 + method)
+            jobs = random_jobs(rng, 120 if method != 4 else 12, W, H, method)
+            for i, j in enumerate(jobs):
+                subme = int(rng.integers(2, 8))   # >= 2: no SAD on interpolated buffers, traces stay comparable
+                qp = int(rng.integers(12, 45))
+                w, h = int(j["w"]), int(j["h"])
+                off = int(j["pu_y"]) * stride + int(j["pu_x"])
+                mvc = [tuple(int(v) for v in j["mvc"][k]) for k in range(int(j["numc"]))]
+                args = (tuple(int(v) for v in j["mvmin"]), tuple(int(v) for v in j["mvmax"]),
+                        tuple(int(v) for v in j["qmvp"]), mvc, int(j["merange"]))
+                ctx = oracle.make_ctx(depth, fenc, org, stride, [rpl], org, stride, False, qp, method, subme)
+                ta = np.zeros(40000, np.int64)
+                tb = np.zeros(40000, np.int64)
+                oracle.L.orc_trace_begin(_p(ta), len(ta))
+                a = oracle.me_search(ctx, off, w, h, *args)
+                na = oracle.L.orc_trace_end()
+                ref.me_config(fenc, org, stride, qp, method, subme)
+                ref.L.ref_trace_begin(ref.part(w, h), _p(rpl, org), _p(tb), len(tb))
+                b = ref.me_search(off, w, h, [rpl], org, stride, False, *args)
+                nb = ref.L.ref_trace_end()
+                assert a == b, (mname, kind, i)
+                assert na == nb, (mname, kind, i)
+                tb[(tb < -org) | (tb >= len(rpl) - org)] = -1
+                assert np.array_equal(ta[:na], tb[:nb]), (mname, kind, i)
+
+
+def test_subme_levels(oracle, ref):
+    depth = ref.depth
+    W, H = 192, 128
+    fenc, rpl, org, stride = clip_planes(W, H, depth, "texture", seed=21)
+    rng = np.random.default_rng(5)
+    for subme in range(8):
+        jobs = random_jobs(rng, 40, W, H, 1)
+        ctx = oracle.make_ctx(depth, fenc, org, stride, [rpl], org, stride, False, 28, 1, subme)
+        ref.me_config(fenc, org, stride, 28, 1, subme)
+        for j in jobs:
+            off = int(j["pu_y"]) * stride + int(j["pu_x"])
+            mvc = [tuple(int(v) for v in j["mvc"][k]) for k in range(int(j["numc"]))]
+            args = (tuple(int(v) for v in j["mvmin"]), tuple(int(v) for v in j["mvmax"]),
+                    tuple(int(v) for v in j["qmvp"]), mvc, int(j["merange"]))
+            assert oracle.me_search(ctx, off, int(j["w"]), int(j["h"]), *args) == \
+                ref.me_search(off, int(j["w"]), int(j["h"]), [rpl], org, stride, False, *args)
+
+
+def test_subpel_compare(oracle, ref):
+    depth = ref.depth
+    W, H = 192, 128
+    fenc, rpl, org, stride = clip_planes(W, H, depth, "noise", seed=9)
+    ctx = oracle.make_ctx(depth, fenc, org, stride, [rpl], org, stride, False, 20, 1, 5)
+    ref.me_config(fenc, org, stride, 20, 1, 5)
+    rng = np.random.default_rng(3)
+    for (w, h) in PARTITIONS[1:]:
+        for _ in range(6):
+            px, py = int(rng.integers(0, W - w)), int(rng.integers(0, H - h))
+            q = (int(rng.integers(-40, 41)), int(rng.integers(-40, 41)))
+            for cmp in (0, 1):
+                assert oracle.subpel_compare(ctx, py * stride + px, w, h, q, cmp) == \
+                    ref.subpel_compare(py * stride + px, w, h, rpl, org, stride, q, cmp)

@@ -5,6 +5,11 @@ from x265_amd.engine import JOB_DTYPE, PARTITIONS
 from x265_amd.synth import make_clip, pad_plane, lowres_dims
 
 MARGIN = 96
+UMH_MARGIN = 320   # UMH reads far outside its window (pix_base / CROSS quirks of the reference)
+
+
+def margin_for(method):
+    return UMH_MARGIN if method == 2 else MARGIN
 
 
 def clip_planes(width, height, depth, kind="texture", seed=7, frames=(2, 0), margin=MARGIN):
@@ -71,7 +76,7 @@ def host_lowres_planes(orc, depth, img, margin=64):
     """Four padded lowres planes of `img` made with the oracle's downscaler (lowres.cpp:155-166)."""
     h, w = img.shape
     lw, lh, wcu, hcu = lowres_dims(w, h)
-    src, so, ss = pad_plane(img, 8)
+    src, so, ss = pad_plane(img, 24)   # the 2x filter of the CU-rounded size reads up to 18 px past the picture
     outs = orc.lowres_core(depth, src, so, ss, lw, lh)
     padded = [pad_plane(o, margin, stride_align=32) for o in outs]
     return [p[0] for p in padded], padded[0][1], padded[0][2], wcu, hcu, lw, lh

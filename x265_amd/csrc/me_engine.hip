@@ -574,7 +574,6 @@ static int validate_jobs(x265amd_ctx *c, const x265amd_plane *fenc, const x265am
                          int method, int subme, const x265amd_job *jobs, int njobs)
 {
     if (method < 0 || method > X265AMD_FULL || subme < 0 || subme > 7) return fail(c, X265AMD_EINVAL, "bad method / subme");
-    if (method == X265AMD_UMH) return fail(c, X265AMD_EINVAL, "UMH search is not implemented on the device yet");
     for (int i = 0; i < njobs; i++)
     {
         const x265amd_job &j = jobs[i];
@@ -585,8 +584,19 @@ static int validate_jobs(x265amd_ctx *c, const x265amd_plane *fenc, const x265am
         if (j.pu_x < 0 || j.pu_y < 0 || j.pu_x + j.w > fenc->width + fenc->margin_x || j.pu_y + j.h > fenc->height + fenc->margin_y)
             return fail(c, X265AMD_EINVAL, "job: PU outside the source plane");
         const int apron = 8;
-        const int x0 = j.pu_x + (j.mvmin[0] < 0 ? j.mvmin[0] : 0) - apron, x1 = j.pu_x + j.w + (j.mvmax[0] > 0 ? j.mvmax[0] : 0) + apron;
-        const int y0 = j.pu_y + (j.mvmin[1] < 0 ? j.mvmin[1] : 0) - apron, y1 = j.pu_y + j.h + (j.mvmax[1] > 0 ? j.mvmax[1] : 0) + apron;
+        const int lox = j.mvmin[0] < 0 ? j.mvmin[0] : 0, hix = j.mvmax[0] > 0 ? j.mvmax[0] : 0;
+        const int loy = j.mvmin[1] < 0 ? j.mvmin[1] : 0, hiy = j.mvmax[1] > 0 ? j.mvmax[1] : 0;
+        int x0 = j.pu_x + lox - apron, x1 = j.pu_x + j.w + hix + apron;
+        int y0 = j.pu_y + loy - apron, y1 = j.pu_y + j.h + hiy + apron;
+        if (method == X265AMD_UMH)
+        {
+            /* UMH measures its cross / diamond groups relative to the block it started from and
+             * its vertical cross at x = omv.x + omv.y (motion.cpp:732, :301-303), up to the
+             * rescaled range (x 6/4) away */
+            const int b = ((j.merange * 6) >> 2) + 6;
+            x0 = j.pu_x + lox + loy - b - apron; x1 = j.pu_x + j.w + hix + hiy + b + apron;
+            y0 = j.pu_y + loy - b - apron; y1 = j.pu_y + j.h + hiy + b + apron;
+        }
         if (x0 < -ref->margin_x || y0 < -ref->margin_y || x1 > ref->width + ref->margin_x || y1 > ref->height + ref->margin_y)
             return fail(c, X265AMD_EINVAL, "job: search window leaves the padded reference plane");
     }
@@ -611,7 +621,7 @@ int x265amd_search_batch_dev(x265amd_ctx *c, const x265amd_plane *fenc, const x2
                              int qp, int method, int subme, const x265amd_job *d_jobs, int njobs, x265amd_result *d_results)
 {
     if (!c || !fenc || !ref || !d_jobs || !d_results || njobs < 0) return fail(c, X265AMD_EINVAL, "null argument");
-    if (method < 0 || method > X265AMD_FULL || method == X265AMD_UMH || subme < 0 || subme > 7)
+    if (method < 0 || method > X265AMD_FULL || subme < 0 || subme > 7)
         return fail(c, X265AMD_EINVAL, "bad method / subme");
     int rc = x265amd_set_qp(c, qp);
     if (rc) return rc;
@@ -693,7 +703,7 @@ int x265amd_lookahead_fields(x265amd_ctx *c, const x265amd_field *fields, int nf
 {
     if (!c || !fields || nfields < 0 || wcu <= 0 || hcu <= 0 || !out_mvs || !out_costs)
         return fail(c, X265AMD_EINVAL, "null argument");
-    if (method < 0 || method > X265AMD_FULL || method == X265AMD_UMH || subme < 0 || subme > 7)
+    if (method < 0 || method > X265AMD_FULL || subme < 0 || subme > 7)
         return fail(c, X265AMD_EINVAL, "bad method / subme");
     if (!nfields) return X265AMD_OK;
     for (int i = 0; i < nfields; i++)

@@ -25,6 +25,9 @@ __constant__ static const int8_t kHex2[8][2] = { {-1,-2}, {-2,0}, {-1,2}, {1,2},
 __constant__ static const uint8_t kMod6m1[8] = { 5, 0, 1, 2, 3, 4, 5, 0 };
 /* first hexagon ring in the order the reference measures it (motion.cpp:673-681) */
 __constant__ static const int8_t kHexRing[6][2] = { {-2,0}, {-1,2}, {1,2}, {2,0}, {1,-2}, {-1,-2} };
+/* radius-4 hexagon grid of the UMH search, motion.cpp:149-155 */
+__constant__ static const int8_t kHex4[16][2] = { {0,-4}, {0,4}, {-2,-3}, {2,-3}, {-4,-2}, {4,-2}, {-4,-1}, {4,-1},
+                                                  {-4,0}, {4,0}, {-4,1}, {4,1}, {-4,2}, {4,2}, {-2,3}, {2,3} };
 /* offsets for the two-point search, motion.cpp:156-166 */
 __constant__ static const int8_t kTwoPoint[16][2] = { {-1,0}, {0,-1}, {-1,-1}, {1,-1}, {-1,0}, {1,0}, {-1,1}, {-1,-1},
                                                       {1,-1}, {1,1}, {-1,0}, {0,1}, {-1,1}, {1,1}, {1,0}, {0,1} };
@@ -165,7 +168,12 @@ struct Searcher
         if (addmv && lane < K)
         {
             const int s = L->sh[lane];
-            L->costs[lane] += mvcost(as_i16(L->mvx[lane] << s), as_i16(L->mvy[lane] << s));
+            if (s & 8)
+                /* UMH hexagon grid: table entries added as ints, MV * 4 without the int16 wrap
+                 * (ADD_MVCOST, motion.cpp:856) */
+                L->costs[lane] += (int)ctab[L->mvx[lane] * 4 - mvpx] + (int)ctab[L->mvy[lane] * 4 - mvpy];
+            else
+                L->costs[lane] += mvcost(as_i16(L->mvx[lane] << s), as_i16(L->mvy[lane] << s));
         }
         wave_sync();
         if (mode == 0) nsad += K; else nsub += K;
@@ -311,6 +319,174 @@ struct Searcher
         fold_pt(K, bmx, bmy, bcost, pn, pd);
     }
 
+    /* candidate queue folded in order; used where the reference evaluates a long run of
+     * candidates without looking at the running best in between */
+    __device__ __forceinline__ void q_flush(int &K, int &bmx, int &bmy, int &bcost)
+    {
+        int pn = 0, pd = 0;
+        fold_pt(K, bmx, bmy, bcost, pn, pd);
+        bmx = as_i16(bmx); bmy = as_i16(bmy);
+        K = 0;
+    }
+    __device__ __forceinline__ void q_add(int &K, int sx_, int sy_, int mx_, int my_, int sh_, int &bmx, int &bmy, int &bcost)
+    {
+        if (K == MAXC) q_flush(K, bmx, bmy, bcost);
+        put(K, sx_, sy_, mx_, my_, sh_, 0);
+        K++;
+    }
+
+    /* COST_MV_X4 of the UMH case: SAD measured relative to pix_base (pbx, pby), MV
+     * bookkeeping relative to omv (motion.cpp:242-258, :732) */
+    __device__ __forceinline__ void umh_x4(int &K, int pbx, int pby, int omx, int omy,
+                                           int d0x, int d0y, int d1x, int d1y, int d2x, int d2y, int d3x, int d3y,
+                                           int &bmx, int &bmy, int &bcost)
+    {
+        q_add(K, pbx + d0x, pby + d0y, as_i16(omx + d0x), as_i16(omy + d0y), 2, bmx, bmy, bcost);
+        q_add(K, pbx + d1x, pby + d1y, as_i16(omx + d1x), as_i16(omy + d1y), 2, bmx, bmy, bcost);
+        q_add(K, pbx + d2x, pby + d2y, as_i16(omx + d2x), as_i16(omy + d2y), 2, bmx, bmy, bcost);
+        q_add(K, pbx + d3x, pby + d3y, as_i16(omx + d3x), as_i16(omy + d3y), 2, bmx, bmy, bcost);
+    }
+
+    /* CROSS, motion.cpp:281-305. The vertical COST_MV calls expand to
+     * fref + omv.x + omv.y + i * stride, i.e. the SAD is taken at (omv.x + omv.y, +-i)
+     * while the MV charged is (omv.x, omv.y +- i); reproduced literally. */
+    __device__ void umh_cross(int &K, int start, int x_max, int y_max, int pbx, int pby, int omx, int omy,
+                              int mnx, int mny, int mxx, int mxy, int &bmx, int &bmy, int &bcost)
+    {
+        int i = start;
+        if (x_max <= (mxx - omx < omx - mnx ? mxx - omx : omx - mnx))
+            for (; i < x_max - 2; i = as_i16(i + 4))
+                umh_x4(K, pbx, pby, omx, omy, i, 0, -i, 0, i + 2, 0, -i - 2, 0, bmx, bmy, bcost);
+        for (; i < x_max; i = as_i16(i + 2))
+        {
+            if (omx + i <= mxx) q_add(K, omx + i, omy, as_i16(omx + i), omy, 2, bmx, bmy, bcost);
+            if (omx - i >= mnx) q_add(K, omx - i, omy, as_i16(omx - i), omy, 2, bmx, bmy, bcost);
+        }
+        i = start;
+        if (y_max <= (mxy - omy < omy - mny ? mxy - omy : omy - mny))
+            for (; i < y_max - 2; i = as_i16(i + 4))
+                umh_x4(K, pbx, pby, omx, omy, 0, i, 0, -i, 0, i + 2, 0, -i - 2, bmx, bmy, bcost);
+        for (; i < y_max; i = as_i16(i + 2))
+        {
+            if (omy + i <= mxy) q_add(K, omx + omy, i, omx, as_i16(omy + i), 2, bmx, bmy, bcost);
+            if (omy - i >= mny) q_add(K, omx + omy, -i, omx, as_i16(omy - i), 2, bmx, bmy, bcost);
+        }
+    }
+
+    /* X265_UMH_SEARCH, motion.cpp:725-909. Returns true when the search continues into
+     * the hexagon refinement (goto me_hex2) with the possibly rescaled merange. */
+    __device__ bool umh(const x265amd_job *job, int mnx, int mny, int mxx, int mxy, int pmx, int pmy,
+                        int &merange, int &bmx, int &bmy, int &bcost)
+    {
+        const int size_scale = (h * h) >> 4; /* motion.cpp:71-72 */
+#define SAD_THRESH(v) (bcost < (((v) >> 4) * size_scale))
+        const int numc = job->numc;
+        const int pbx = bmx, pby = bmy;
+        int omx = bmx, omy = bmy;
+        int K = 0;
+        const int ucost1 = bcost;
+        int cross_start = 1;
+        omx = pmx; omy = pmy;
+        umh_x4(K, pbx, pby, omx, omy, 0, -1, 0, 1, -1, 0, 1, 0, bmx, bmy, bcost);
+        q_flush(K, bmx, bmy, bcost);
+        if (pmx | pmy)
+        {
+            omx = 0; omy = 0;
+            umh_x4(K, pbx, pby, omx, omy, 0, -1, 0, 1, -1, 0, 1, 0, bmx, bmy, bcost);
+            q_flush(K, bmx, bmy, bcost);
+        }
+        const int ucost2 = bcost;
+        if ((bmx | bmy) && !(bmx == pmx && bmy == pmy))
+        {
+            omx = bmx; omy = bmy;
+            umh_x4(K, pbx, pby, omx, omy, 0, -1, 0, 1, -1, 0, 1, 0, bmx, bmy, bcost);
+            q_flush(K, bmx, bmy, bcost);
+        }
+        if (bcost == ucost2) cross_start = 3;
+
+        omx = bmx; omy = bmy;
+        if (bcost == ucost2 && SAD_THRESH(2000))
+        {
+            umh_x4(K, pbx, pby, omx, omy, 0, -2, -1, -1, 1, -1, -2, 0, bmx, bmy, bcost);
+            umh_x4(K, pbx, pby, omx, omy, 2, 0, -1, 1, 1, 1, 0, 2, bmx, bmy, bcost);
+            q_flush(K, bmx, bmy, bcost);
+            if (bcost == ucost1 && SAD_THRESH(500)) return false;
+            if (bcost == ucost2)
+            {
+                const int range = as_i16((merange >> 1) | 1);
+                umh_cross(K, 3, range, range, pbx, pby, omx, omy, mnx, mny, mxx, mxy, bmx, bmy, bcost);
+                umh_x4(K, pbx, pby, omx, omy, -1, -2, 1, -2, -2, -1, 2, -1, bmx, bmy, bcost);
+                umh_x4(K, pbx, pby, omx, omy, -2, 1, 2, 1, -1, 2, 1, 2, bmx, bmy, bcost);
+                q_flush(K, bmx, bmy, bcost);
+                if (bcost == ucost2) return false;
+                cross_start = as_i16(range + 2);
+            }
+        }
+
+        /* adaptive search range from predictor agreement, motion.cpp:767-819 */
+        if (numc)
+        {
+            const int r0[4] = { 3, 3, 4, 4 }, r1[4] = { 3, 4, 4, 4 }, r2[4] = { 4, 4, 4, 5 }, r3[4] = { 4, 4, 5, 6 };
+            const int qmx = job->qmvp[0], qmy = job->qmvp[1];
+            int mvd, denom = 1;
+            const bool is64 = (w == 64 && h == 64);
+            if (numc == 1)
+                mvd = is64 ? 25 : abs(qmx - job->mvc[0][0]) + abs(qmy - job->mvc[0][1]);
+            else
+            {
+                denom = numc - 1;
+                mvd = 0;
+                if (!is64)
+                {
+                    mvd = abs(qmx - job->mvc[0][0]) + abs(qmy - job->mvc[0][1]);
+                    denom++;
+                }
+                for (int i = 0; i < numc - 1; i++)
+                    mvd += abs(job->mvc[i][0] - job->mvc[i + 1][0]) + abs(job->mvc[i][1] - job->mvc[i + 1][1]);
+            }
+            const int sad_ctx = SAD_THRESH(1000) ? 0 : SAD_THRESH(2000) ? 1 : SAD_THRESH(4000) ? 2 : 3;
+            const int mvd_ctx = mvd < 10 * denom ? 0 : mvd < 20 * denom ? 1 : mvd < 40 * denom ? 2 : 3;
+            const int *row = mvd_ctx == 0 ? r0 : mvd_ctx == 1 ? r1 : mvd_ctx == 2 ? r2 : r3;
+            merange = (merange * row[sad_ctx]) >> 2;
+        }
+
+        umh_cross(K, cross_start, merange, merange >> 1, pbx, pby, omx, omy, mnx, mny, mxx, mxy, bmx, bmy, bcost);
+        umh_x4(K, pbx, pby, omx, omy, -2, -2, -2, 2, 2, -2, 2, 2, bmx, bmy, bcost);
+        q_flush(K, bmx, bmy, bcost);
+
+        /* hexagon grid, motion.cpp:826-905 */
+        omx = bmx; omy = bmy;
+        int i = 1;
+        do
+        {
+            int lim = mxx - omx;
+            if (omx - mnx < lim) lim = omx - mnx;
+            if (mxy - omy < lim) lim = mxy - omy;
+            if (omy - mny < lim) lim = omy - mny;
+            if (4 * i > lim)
+            {
+                for (int j = 0; j < 16; j++)
+                {
+                    const int mx = as_i16(omx + as_i16(kHex4[j][0] * as_i16(i))), my = as_i16(omy + as_i16(kHex4[j][1] * as_i16(i)));
+                    if (in_range(mx, my, mnx, mny, mxx, mxy)) q_add(K, mx, my, mx, my, 2, bmx, bmy, bcost);
+                }
+            }
+            else
+            {
+                for (int j = 0; j < 16; j++)
+                {
+                    const int px = omx + kHex4[j][0] * i, py = omy + kHex4[j][1] * i;
+                    q_add(K, px, py, px, py, 8 | 2, bmx, bmy, bcost);
+                }
+            }
+            q_flush(K, bmx, bmy, bcost);
+            i = (i + 1) & 0xffff;
+        }
+        while (i <= merange >> 2);
+#undef SAD_THRESH
+        return in_range(bmx, bmy, mnx, mny, mxx, mxy);
+    }
+
     /* the whole of motionEstimate for one PU */
     __device__ void search(const x265amd_job *job, int method, int subme, x265amd_result *res)
     {
@@ -383,6 +559,9 @@ struct Searcher
         }
         case X265AMD_HEX:
             run_hex = true;
+            break;
+        case X265AMD_UMH:
+            run_hex = umh(job, mnx, mny, mxx, mxy, pmx, pmy, merange, bmx, bmy, bcost);
             break;
         case X265AMD_STAR:
         {
