@@ -1,0 +1,195 @@
+#!/usr/bin/env python3
+"""Motion-estimation throughput on MI355X: BASELINE.json configs[1].
+
+Workload (one step = one batch of synthetic 1080p 8-bit frame pairs per GPU):
+  * full-encode ME: every square PU of the 64/32/16/8 quadtree depths of each frame
+    (42 900 PUs per frame), STAR search (--me star), merange 57, subme 5, predictors
+    taken from the lookahead field of the same frame pair;
+  * lookahead ME: the lowres MV field of each pair (8160 8x8 CUs, HEX, subme 1,
+    merange 16) on a second stream.
+Inputs (planes, job lists) are resident in HBM before the timed region. Results are
+checked against the CPU oracle before anything is reported.
+
+metric value = pixel-SADs evaluated per second over all ranks: (full-pel + sub-pel
+candidates the search visited) x PU area, counted by the kernel itself per PU and equal
+to the oracle's count for the same jobs.
+
+    python bench.py --gpus 1 --steps 10 --warmup 2
+    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+W, H, MARGIN = 1920, 1080, 128
+QP, MERANGE, SUBME = 32, 57, 5
+LA_QP, LA_MERANGE = 12, 16
+HBM_PEAK_GBS = 8000.0
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--pairs", type=int, default=4, help="frame pairs per GPU per step")
+    ap.add_argument("--cpu-sample", type=int, default=4000, help="jobs timed on the host CPU (0 = skip)")
+    ap.add_argument("--method", default="star")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from x265_amd.engine import Engine, METHODS, RESULT_DTYPE, HEX
+    from x265_amd.synth import make_clip, pad_plane, lowres_dims
+    from x265_amd import workload, sharding
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+    method = METHODS[args.method]
+
+    # ---------------- setup (untimed): planes, lookahead fields, job lists, all on the device
+    es = Engine(local_rank, 8)      # search stream
+    el = Engine(local_rank, 8)      # lookahead stream
+    B = args.pairs
+    clip = make_clip(W, H, B + 1, seed=1234 + rank)
+    planes, lowres = [], []
+    for f in clip:
+        buf, org, stride = pad_plane(f, MARGIN)
+        p = es.upload_plane(buf, W, H, MARGIN, MARGIN, stride)
+        planes.append(p)
+        lowres.append(es.lowres_init(p))
+    lw, lh, wcu, hcu = lowres_dims(W, H)
+    ncu = wcu * hcu
+    fields = [(lowres[i + 1][0], lowres[i]) for i in range(B)]
+    la_mvs, la_costs, la_stats = el.lookahead_fields(fields, wcu, hcu, LA_QP, HEX, 1, LA_MERANGE, want_stats=True)
+    la_pixel_sads = int((la_stats["sad_calls"].astype(np.int64) + la_stats["subpel_calls"]).sum()) * 64
+
+    host_jobs, d_jobs, d_res = [], [], []
+    for i in range(B):
+        jobs = workload.square_pu_jobs(W, H, la_mvs[i], wcu, hcu, MERANGE)
+        host_jobs.append(jobs)
+        d_jobs.append(torch.from_numpy(jobs.view(np.uint8).reshape(len(jobs), -1).copy()).to(dev))
+        d_res.append(torch.zeros((len(jobs), RESULT_DTYPE.itemsize), dtype=torch.uint8, device=dev))
+    njobs = len(host_jobs[0])
+    d_fields = el.fields_upload(fields)
+    d_la_mvs = torch.zeros((B, ncu, 2), dtype=torch.int16, device=dev)
+    d_la_costs = torch.zeros((B, ncu), dtype=torch.int32, device=dev)
+    torch.cuda.synchronize()
+
+    s_search = torch.cuda.ExternalStream(es.stream(), device=dev)
+    ev0 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
+    ev1 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
+
+    def step(k=None):
+        el.lookahead_fields_dev(d_fields, B, wcu, hcu, LA_QP, HEX, 1, LA_MERANGE,
+                                d_la_mvs.data_ptr(), d_la_costs.data_ptr())
+        if k is not None:
+            ev0[k].record(s_search)
+        for i in range(B):
+            es.search_batch_dev(planes[i + 1], planes[i], d_jobs[i].data_ptr(), njobs, d_res[i].data_ptr(),
+                                QP, method, SUBME)
+        if k is not None:
+            ev1[k].record(s_search)
+        es.sync()
+        el.sync()
+        if world > 1:
+            # hand the MV / cost records to the rank that feeds the host encoder
+            sharding.gather_records(torch.cat(d_res).view(-1), dist, dst=0)
+            sharding.gather_records(d_la_mvs.view(torch.uint8).view(-1), dist, dst=0)
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        step(k)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # ---------------- accounting
+    res = [r.cpu().numpy().view(RESULT_DTYPE).reshape(-1) for r in d_res]
+    px_search = sum(workload.pixel_sads(host_jobs[i], res[i]) for i in range(B))
+    px_step = px_search + la_pixel_sads
+    total_px = torch.tensor([float(px_step) * args.steps], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(total_px, op=dist.ReduceOp.SUM)
+    value = float(total_px.item()) / elapsed / 1e9
+
+    search_ms = sum(ev0[k].elapsed_time(ev1[k]) for k in range(args.steps)) / (args.steps * B)
+    alg_bytes = sum(workload.algorithmic_bytes(j) for j in host_jobs) / B
+    achieved = alg_bytes / (search_ms * 1e-3) / 1e9
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "traffic.json")
+    if os.path.exists(tpath):
+        traffic = json.load(open(tpath)).get("search_kernel_hbm_bytes_per_launch")
+
+    if rank == 0:
+        # parity gate + CPU baseline: the oracle on a bounded sample of the same jobs
+        from oracle.bindings import Oracle   # checker / baseline only
+        orc = Oracle()
+        cur, org, stride = pad_plane(clip[1], MARGIN)
+        ref, _, _ = pad_plane(clip[0], MARGIN)
+        ctx = orc.make_ctx(8, cur, org, stride, [ref], org, stride, False, QP, method, SUBME)
+        cpu = None
+        if args.cpu_sample > 0:
+            idx = np.linspace(0, njobs - 1, min(args.cpu_sample, njobs)).astype(np.int64)
+            sample = np.ascontiguousarray(host_jobs[0][idx])
+            c0 = time.perf_counter()
+            exp = orc.me_search_batch(ctx, sample)
+            cpu_s = time.perf_counter() - c0
+            got = res[0][idx]
+            if not (np.array_equal(got["mv"], exp["mv"]) and np.array_equal(got["cost"], exp["cost"])
+                    and np.array_equal(got["sad_calls"], exp["sad_calls"])
+                    and np.array_equal(got["subpel_calls"], exp["subpel_calls"])):
+                print("PARITY FAILURE: GPU results differ from the oracle", file=sys.stderr)
+                sys.exit(2)
+            cpu = {"value": workload.pixel_sads(sample, exp) / cpu_s / 1e9, "unit": "Gpixel-SAD/s", "cores": 1,
+                   "kind": "port",
+                   "sample": "%d of the %d PU searches of frame pair 0 (evenly spaced over all four depths), "
+                             "oracle/me_oracle.c -O2 single thread, %.1f s" % (len(sample), njobs, cpu_s)}
+        out = {
+            "metric": "ME Gpixel-SAD/s", "value": value, "unit": "Gpixel-SAD/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+            "config": {"workload": "1080p 8-bit, --me %s --merange %d --subme %d full-encode ME over all 64/32/16/8 "
+                                   "square PUs + lookahead HEX field, %d frame pairs per GPU per step"
+                                   % (args.method, MERANGE, SUBME, B),
+                       "pu_searches_per_step_per_gpu": njobs * B, "lookahead_cus_per_step_per_gpu": ncu * B,
+                       "qp": QP, "parallelism": "frame pairs sharded over %d GPU(s), gather of MV records" % world},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "kernel": "search_kernel<uint8_t,false>", "launch_ms": search_ms,
+                         "algorithmic_bytes_per_launch": alg_bytes},
+            "cpu_baseline": cpu,
+            "fps_equiv": B * args.steps * world / elapsed,
+        }
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

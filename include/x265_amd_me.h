@@ -138,6 +138,15 @@ int x265amd_lookahead_fields(x265amd_ctx *ctx, const x265amd_field *fields, int 
                              int width_in_cu, int height_in_cu, int qp, int method, int subme, int merange,
                              int16_t *out_mvs, int32_t *out_costs, x265amd_result *out_stats /* nfields*ncu or NULL */);
 
+/* Device-resident variant: `d_fields` comes from x265amd_fields_upload (release it with
+ * x265amd_device_free), outputs are DEVICE arrays of the sizes above; asynchronous on
+ * the engine's stream. Same reference path as x265amd_lookahead_fields. */
+int x265amd_fields_upload(x265amd_ctx *ctx, const x265amd_field *fields, int nfields, void **d_fields);
+int x265amd_device_free(x265amd_ctx *ctx, void *d_ptr);
+int x265amd_lookahead_fields_dev(x265amd_ctx *ctx, const void *d_fields, int nfields,
+                                 int width_in_cu, int height_in_cu, int qp, int method, int subme, int merange,
+                                 int16_t *d_mvs, int32_t *d_costs, x265amd_result *d_stats /* or NULL */);
+
 /* ---- primitives table ---- */
 
 /* Mirror of the ME-relevant slice of struct EncoderPrimitives

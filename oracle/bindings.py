@@ -146,6 +146,14 @@ class Oracle:
                                     C.cast(C.pointer(stats), C.c_void_p) if stats is not None else None)
         return (out.x, out.y), cost
 
+    def me_search_batch(self, ctx, jobs):
+        """jobs: numpy array with the engine's job layout (40-byte records); returns 16-byte result records."""
+        res = np.zeros(len(jobs), np.dtype([("mv", "<i2", (2,)), ("cost", "<i4"), ("sad_calls", "<u4"), ("subpel_calls", "<u4")]))
+        jobs = np.ascontiguousarray(jobs)
+        assert jobs.dtype.itemsize == 40
+        self.L.orc_me_search_batch(C.byref(ctx), _p(jobs), len(jobs), _p(res))
+        return res
+
     def subpel_compare(self, ctx, off, w, h, qmv, cmp):
         return self.L.orc_subpel_compare(C.byref(ctx), off, w, h, MV(*qmv), cmp)
 

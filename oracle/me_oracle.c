@@ -158,6 +158,23 @@ int orc_me_search(const orc_me_ctx *c, intptr_t off, int w, int h, orc_mv mvmin,
     return me_search_16(c, off, w, h, mvmin, mvmax, qmvp, numc, mvc, merange, out, st);
 }
 
+void orc_me_search_batch(const orc_me_ctx *c, const orc_job *jobs, int njobs, orc_result *out)
+{
+    for (int i = 0; i < njobs; i++)
+    {
+        const orc_job *j = &jobs[i];
+        orc_mv mn = { j->mvmin[0], j->mvmin[1] }, mx = { j->mvmax[0], j->mvmax[1] }, p = { j->qmvp[0], j->qmvp[1] };
+        orc_mv mvc[4], o;
+        orc_me_stats st;
+        memset(&st, 0, sizeof(st));
+        for (int k = 0; k < 4; k++) { mvc[k].x = j->mvc[k][0]; mvc[k].y = j->mvc[k][1]; }
+        out[i].cost = orc_me_search(c, (intptr_t)j->pu_y * c->fenc_stride + j->pu_x, j->w, j->h, mn, mx, p,
+                                    j->numc, mvc, j->merange, &o, &st);
+        out[i].mv[0] = o.x; out[i].mv[1] = o.y;
+        out[i].sad_calls = st.sad_calls; out[i].subpel_calls = st.subpel_calls;
+    }
+}
+
 int orc_subpel_compare(const orc_me_ctx *c, intptr_t off, int w, int h, orc_mv qmv, int cmp)
 {
     if (c->depth <= 8)

@@ -75,6 +75,24 @@ int orc_me_search(const orc_me_ctx *c, intptr_t pu_offset, int w, int h,
                   orc_mv mvmin, orc_mv mvmax, orc_mv qmvp, int numc, const orc_mv *mvc,
                   int merange, orc_mv *out, orc_me_stats *stats /* may be NULL, accumulated */);
 
+/* Batch driver over an array of jobs laid out like x265amd_job / x265amd_result
+ * (include/x265_amd_me.h); used to time the CPU baseline without per-call overhead. */
+typedef struct
+{
+    int16_t pu_x, pu_y;
+    uint8_t w, h, numc, reserved;
+    int16_t mvmin[2], mvmax[2], qmvp[2];
+    int16_t mvc[4][2];
+    int32_t merange;
+} orc_job;
+typedef struct
+{
+    int16_t mv[2];
+    int32_t cost;
+    uint32_t sad_calls, subpel_calls;
+} orc_result;
+void orc_me_search_batch(const orc_me_ctx *c, const orc_job *jobs, int njobs, orc_result *out);
+
 /* subpelCompare (motion.cpp:1651-1689): cmp 0 = sad, 1 = satd */
 int orc_subpel_compare(const orc_me_ctx *c, intptr_t pu_offset, int w, int h, orc_mv qmv, int cmp);
 

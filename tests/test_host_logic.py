@@ -1,0 +1,120 @@
+"""CPU: host-side logic -- synthetic clips, job builders, sharding, and the N>1 gather over gloo."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+
+from x265_amd import sharding, workload
+from x265_amd.engine import JOB_DTYPE, RESULT_DTYPE
+from x265_amd.synth import make_clip, pad_plane, lowres_dims
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_clip_is_deterministic_and_translating():
+    a = make_clip(128, 96, 3, seed=9)
+    b = make_clip(128, 96, 3, seed=9)
+    assert all(np.array_equal(x, y) for x, y in zip(a, b))
+    # frame i is the base texture moved by (3i, 2i): frame1[y, x] ~ frame0[y + 2, x + 3]
+    d = np.abs(a[1][:-2, :-3].astype(int) - a[0][2:, 3:].astype(int)).mean()
+    assert d < 4.0
+    assert make_clip(64, 64, 1, depth=10)[0].max() > 255
+
+
+def test_pad_plane_replicates_edges():
+    img = np.arange(12, dtype=np.uint8).reshape(3, 4)
+    buf, org, stride = pad_plane(img, 2, 3)
+    p = buf.reshape(-1, stride)
+    assert stride == 8 and org == 3 * 8 + 2
+    assert (p[:3, :2] == 0).all() and (p[-1, -2:] == 11).all() and p[3, 2] == 0 and p[5, 5] == 11
+
+
+def test_lowres_dims():
+    assert lowres_dims(416, 240) == (208, 120, 26, 15)
+    assert lowres_dims(1920, 1080) == (960, 544, 120, 68)
+    assert lowres_dims(3840, 2160) == (1920, 1080, 240, 135)
+
+
+def test_square_pu_jobs_cover_the_picture():
+    wcu, hcu = 120, 68
+    mvs = np.zeros((wcu * hcu, 2), np.int16)
+    mvs[:, 0] = 6
+    jobs = workload.square_pu_jobs(1920, 1080, mvs, wcu, hcu, 57)
+    assert len(jobs) == 30 * 16 + 60 * 33 + 120 * 67 + 240 * 135
+    assert (jobs["qmvp"][:, 0] == 12).all()
+    # windows stay inside a 128-pixel margin incl. the 8-tap apron
+    assert (jobs["pu_x"] + jobs["mvmin"][:, 0] - 8 >= -128).all()
+    assert (jobs["pu_x"] + jobs["w"] + jobs["mvmax"][:, 0] + 8 <= 1920 + 128).all()
+    res = np.zeros(len(jobs), RESULT_DTYPE)
+    res["sad_calls"] = 2
+    res["subpel_calls"] = 1
+    assert workload.pixel_sads(jobs, res) == 3 * int((jobs["w"].astype(int) * jobs["h"]).sum())
+
+
+def test_algorithmic_bytes_formula():
+    j = np.zeros(1, JOB_DTYPE)
+    j["w"], j["h"] = 16, 16
+    j["mvmin"], j["mvmax"] = (-57, -57), (57, 57)
+    assert workload.algorithmic_bytes(j) == 16 * 16 + (16 + 114 + 7) ** 2 + 8
+    assert workload.algorithmic_bytes(j, 2) == 2 * (16 * 16 + (16 + 114 + 7) ** 2) + 8
+
+
+def test_shard_range_partitions_everything():
+    for n in (0, 1, 7, 8, 9, 17, 8160):
+        for world in (1, 2, 3, 8):
+            got = []
+            for r in range(world):
+                lo, hi = sharding.shard_range(n, r, world)
+                got += list(range(lo, hi))
+            assert got == list(range(n))
+    lo, hi, y0, y1 = sharding.shard_rows(34, 1, 8, 92)
+    assert (lo, hi) == (5, 10) and y0 == 5 * 64 - 100 and y1 == 10 * 64 + 100
+
+
+_WORKER = r'''
+import os, sys
+sys.path.insert(0, sys.argv[1])
+import numpy as np, torch, torch.distributed as dist
+from x265_amd import sharding
+from x265_amd.engine import RESULT_DTYPE
+dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%s" % sys.argv[2], rank=int(sys.argv[3]), world_size=2)
+rank = dist.get_rank()
+n_units = 9
+lo, hi = sharding.shard_range(n_units, rank, 2)
+per = 5                                    # pad to the largest shard so gather shapes match
+rec = np.zeros(per * 4, RESULT_DTYPE)
+for u in range(lo, hi):
+    rec["cost"][(u - lo) * 4:(u - lo + 1) * 4] = 1000 + u
+    rec["mv"][(u - lo) * 4:(u - lo + 1) * 4] = (u, -u)
+t = torch.from_numpy(rec.view(np.uint8).copy())
+got = sharding.gather_records(t, dist, dst=0)
+if rank == 0:
+    allrec = np.concatenate([g.numpy().view(RESULT_DTYPE) for g in got])
+    units = []
+    for r in range(2):
+        l, h = sharding.shard_range(n_units, r, 2)
+        units += [int(allrec["cost"][r * per * 4 + k * 4]) - 1000 for k in range(h - l)]
+    assert units == list(range(n_units)), units
+    assert tuple(allrec["mv"][per * 4]) == (5, -5)
+    print("GATHER_OK")
+else:
+    assert got is None
+dist.barrier()
+dist.destroy_process_group()
+'''
+
+
+def test_two_rank_gather_over_gloo(tmp_path):
+    script = tmp_path / "worker.py"
+    script.write_text(_WORKER)
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = str(s.getsockname()[1])
+    s.close()
+    procs = [subprocess.Popen([sys.executable, str(script), ROOT, port, str(r)], stdout=subprocess.PIPE,
+                              stderr=subprocess.STDOUT, text=True) for r in range(2)]
+    outs = [p.communicate(timeout=240)[0] for p in procs]
+    assert all(p.returncode == 0 for p in procs), outs
+    assert "GATHER_OK" in outs[0]

@@ -126,6 +126,9 @@ __device__ __forceinline__ int as_i16(int v) { return (int)(int16_t)v; }
 template<typename P>
 __device__ __forceinline__ void interp_tile(const P *r, int stride, int xf, int yf, int depth, int o[4][4])
 {
+    /* Rows are streamed: each loaded reference row is filtered horizontally (if xf)
+     * and immediately scattered into the (up to 4) output rows whose vertical
+     * footprint contains it, so only the 16 accumulators and one row stay live. */
     const int maxv = (1 << depth) - 1;
     if (yf == 0)
     {
@@ -149,66 +152,73 @@ __device__ __forceinline__ void interp_tile(const P *r, int stride, int xf, int 
                 o[y][x] = clip_pixel(as_i16((sum + 32) >> 6), maxv);
             }
         }
+        return;
     }
-    else if (xf == 0)
+    int cv[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) cv[k] = kLumaTaps[yf][k];
+    int acc[4][4];
+#pragma unroll
+    for (int y = 0; y < 4; y++)
+#pragma unroll
+        for (int x = 0; x < 4; x++) acc[y][x] = 0;
+    if (xf == 0)
     {
-        int c[8];
 #pragma unroll
-        for (int k = 0; k < 8; k++) c[k] = kLumaTaps[yf][k];
-        int v[11][4];
-#pragma unroll
-        for (int y = 0; y < 11; y++)
-            Px<P>::unpack(Px<P>::load(r + (y - 3) * stride), v[y]);
-#pragma unroll
-        for (int y = 0; y < 4; y++)
-#pragma unroll
-            for (int x = 0; x < 4; x++)
-            {
-                int sum = 0;
-#pragma unroll
-                for (int k = 0; k < 8; k++) sum += v[y + k][x] * c[k];
-                o[y][x] = clip_pixel(as_i16((sum + 32) >> 6), maxv);
-            }
-    }
-    else
-    {
-        int ch[8], cv[8];
-#pragma unroll
-        for (int k = 0; k < 8; k++) { ch[k] = kLumaTaps[xf][k]; cv[k] = kLumaTaps[yf][k]; }
-        const int headRoom = 14 - depth;
-        const int shiftH = 6 - headRoom;
-        const int offH = -(8192 << shiftH);
-        const int shiftV = 6 + headRoom;
-        const int offV = (1 << (shiftV - 1)) + (8192 << 6);
-        int im[11][4];
-#pragma unroll
-        for (int y = 0; y < 11; y++)
+        for (int rr = 0; rr < 11; rr++)
         {
-            int px[12];
-            const P *row = r + (y - 3) * stride - 3;
-            Px<P>::unpack(Px<P>::load(row), px);
-            Px<P>::unpack(Px<P>::load(row + 4), px + 4);
-            Px<P>::unpack(Px<P>::load(row + 8), px + 8);
+            int v[4];
+            Px<P>::unpack(Px<P>::load(r + (rr - 3) * stride), v);
 #pragma unroll
-            for (int x = 0; x < 4; x++)
-            {
-                int sum = 0;
+            for (int y = 0; y < 4; y++)
+                if (rr - y >= 0 && rr - y < 8)
+                {
 #pragma unroll
-                for (int k = 0; k < 8; k++) sum += px[x + k] * ch[k];
-                im[y][x] = as_i16((sum + offH) >> shiftH);
-            }
+                    for (int x = 0; x < 4; x++) acc[y][x] += v[x] * cv[rr - y];
+                }
         }
 #pragma unroll
         for (int y = 0; y < 4; y++)
 #pragma unroll
-            for (int x = 0; x < 4; x++)
-            {
-                int sum = 0;
+            for (int x = 0; x < 4; x++) o[y][x] = clip_pixel(as_i16((acc[y][x] + 32) >> 6), maxv);
+        return;
+    }
+    int ch[8];
 #pragma unroll
-                for (int k = 0; k < 8; k++) sum += im[y + k][x] * cv[k];
-                o[y][x] = clip_pixel(as_i16((sum + offV) >> shiftV), maxv);
+    for (int k = 0; k < 8; k++) ch[k] = kLumaTaps[xf][k];
+    const int headRoom = 14 - depth;
+    const int shiftH = 6 - headRoom;
+    const int offH = -(8192 << shiftH);
+    const int shiftV = 6 + headRoom;
+    const int offV = (1 << (shiftV - 1)) + (8192 << 6);
+#pragma unroll
+    for (int rr = 0; rr < 11; rr++)
+    {
+        int px[12], im[4];
+        const P *row = r + (rr - 3) * stride - 3;
+        Px<P>::unpack(Px<P>::load(row), px);
+        Px<P>::unpack(Px<P>::load(row + 4), px + 4);
+        Px<P>::unpack(Px<P>::load(row + 8), px + 8);
+#pragma unroll
+        for (int x = 0; x < 4; x++)
+        {
+            int sum = 0;
+#pragma unroll
+            for (int k = 0; k < 8; k++) sum += px[x + k] * ch[k];
+            im[x] = as_i16((sum + offH) >> shiftH);
+        }
+#pragma unroll
+        for (int y = 0; y < 4; y++)
+            if (rr - y >= 0 && rr - y < 8)
+            {
+#pragma unroll
+                for (int x = 0; x < 4; x++) acc[y][x] += im[x] * cv[rr - y];
             }
     }
+#pragma unroll
+    for (int y = 0; y < 4; y++)
+#pragma unroll
+        for (int x = 0; x < 4; x++) o[y][x] = clip_pixel(as_i16((acc[y][x] + offV) >> shiftV), maxv);
 }
 
 /* cost of one tile given the 4 packed source rows and 16 predicted pixels */

@@ -749,6 +749,54 @@ int x265amd_lookahead_fields(x265amd_ctx *c, const x265amd_field *fields, int nf
     return X265AMD_OK;
 }
 
+int x265amd_fields_upload(x265amd_ctx *c, const x265amd_field *fields, int nfields, void **d_fields)
+{
+    if (!c || !fields || nfields <= 0 || !d_fields) return fail(c, X265AMD_EINVAL, "null argument");
+    std::vector<FieldDev> hf(nfields);
+    for (int i = 0; i < nfields; i++)
+    {
+        hf[i].fenc.origin = fields[i].fenc.origin; hf[i].fenc.stride = fields[i].fenc.stride;
+        for (int k = 0; k < 4; k++) { hf[i].ref[k].origin = fields[i].ref[k].origin; hf[i].ref[k].stride = fields[i].ref[k].stride; }
+    }
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipMalloc(d_fields, nfields * sizeof(FieldDev)));
+    HIPCHK(c, hipMemcpy(*d_fields, hf.data(), nfields * sizeof(FieldDev), hipMemcpyHostToDevice));
+    return X265AMD_OK;
+}
+
+int x265amd_device_free(x265amd_ctx *c, void *d_ptr)
+{
+    if (!c) return X265AMD_EINVAL;
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipFree(d_ptr));
+    return X265AMD_OK;
+}
+
+int x265amd_lookahead_fields_dev(x265amd_ctx *c, const void *d_fields, int nfields, int wcu, int hcu,
+                                 int qp, int method, int subme, int merange,
+                                 int16_t *d_mvs, int32_t *d_costs, x265amd_result *d_stats)
+{
+    if (!c || !d_fields || nfields < 0 || wcu <= 0 || hcu <= 0 || !d_mvs || !d_costs)
+        return fail(c, X265AMD_EINVAL, "null argument");
+    if (method < 0 || method > X265AMD_FULL || subme < 0 || subme > 7)
+        return fail(c, X265AMD_EINVAL, "bad method / subme");
+    int rc = x265amd_set_qp(c, qp);
+    if (rc) return rc;
+    if (!nfields) return X265AMD_OK;
+    HIPCHK(c, hipSetDevice(c->device));
+    LookaheadArgs a;
+    a.fields = (const FieldDev*)d_fields;
+    a.wcu = wcu; a.hcu = hcu; a.depth = c->depth; a.method = method; a.subme = subme; a.merange = merange;
+    a.ctab = c->tables[qp] + 32768;
+    a.mvs = d_mvs; a.costs = d_costs; a.stats = d_stats;
+    if (c->depth <= 8)
+        hipLaunchKernelGGL(lookahead_kernel<uint8_t>, dim3(nfields), dim3(LA_WAVES * 64), 0, c->stream, a);
+    else
+        hipLaunchKernelGGL(lookahead_kernel<uint16_t>, dim3(nfields), dim3(LA_WAVES * 64), 0, c->stream, a);
+    HIPCHK(c, hipGetLastError());
+    return X265AMD_OK;
+}
+
 } /* extern "C" */
 
 #include "me_primitives.inc"

@@ -168,6 +168,37 @@ class Engine:
                                                   C.c_void_p(stats.ctypes.data) if want_stats else None))
         return mvs, costs, stats
 
+    # ---- device-resident variants (pointers are raw device addresses, e.g. torch tensor.data_ptr())
+    def stream(self):
+        return self.L.x265amd_stream(self.ctx)
+
+    def sync(self):
+        self._chk(self.L.x265amd_sync(self.ctx))
+
+    def search_batch_dev(self, fenc, ref, d_jobs, njobs, d_results, qp, method, subme, is_lowres=False):
+        refs = (Plane * 4)(*ref) if is_lowres else (Plane * 1)(ref if isinstance(ref, Plane) else ref[0])
+        self._chk(self.L.x265amd_search_batch_dev(self.ctx, C.byref(fenc), refs, int(is_lowres), qp, method, subme,
+                                                  C.c_void_p(d_jobs), njobs, C.c_void_p(d_results)))
+
+    def fields_upload(self, fields):
+        n = len(fields)
+        arr = (Field * n)()
+        for i, (fe, refs) in enumerate(fields):
+            arr[i].fenc = fe
+            for k in range(4):
+                arr[i].ref[k] = refs[k]
+        d = C.c_void_p()
+        self._chk(self.L.x265amd_fields_upload(self.ctx, arr, n, C.byref(d)))
+        return d
+
+    def device_free(self, d):
+        self._chk(self.L.x265amd_device_free(self.ctx, d))
+
+    def lookahead_fields_dev(self, d_fields, nfields, wcu, hcu, qp, method, subme, merange, d_mvs, d_costs, d_stats=None):
+        self._chk(self.L.x265amd_lookahead_fields_dev(self.ctx, d_fields, nfields, wcu, hcu, qp, method, subme, merange,
+                                                      C.c_void_p(d_mvs), C.c_void_p(d_costs),
+                                                      C.c_void_p(d_stats) if d_stats else None))
+
     def primitives(self):
         p = Primitives()
         self._chk(self.L.x265amd_setup_primitives(self.ctx, C.byref(p)))
