@@ -97,6 +97,10 @@ int x265amd_lowres_init(x265amd_ctx *ctx, const x265amd_plane *src, x265amd_plan
 /* copies a whole padded plane (all rows incl. margins) back to the host */
 int x265amd_plane_download(x265amd_ctx *ctx, const x265amd_plane *plane, void *buf);
 
+/* raw device-to-host copy (after draining the engine's stream); for result arrays and
+ * planes whose sample size differs from the context's (the int16 RK plane) */
+int x265amd_download(x265amd_ctx *ctx, const void *d_src, void *dst, size_t bytes);
+
 /* ---- motion search ---- */
 
 /* MotionEstimate::motionEstimate for `njobs` PUs of one (source, reference) pair
@@ -146,6 +150,59 @@ int x265amd_device_free(x265amd_ctx *ctx, void *d_ptr);
 int x265amd_lookahead_fields_dev(x265amd_ctx *ctx, const void *d_fields, int nfields,
                                  int width_in_cu, int height_in_cu, int qp, int method, int subme, int merange,
                                  int16_t *d_mvs, int32_t *d_costs, x265amd_result *d_stats /* or NULL */);
+
+/* ---- Rockchip path (rd >= 5): CIME + RIME + FME ---- */
+
+/* One 64x64 CTU against one reference picture: everything the 15-argument
+ * MotionEstimate::motionEstimate overload computes for the CTU's 85 CUs
+ * (encoder/motion.cpp:1250-1410, caller TEncSearch.cpp:3704-3822; hardware C-model
+ * twins hardwareC/inter.cpp:679-734 CIME and :2521-2624 RimeAndFme, which
+ * hardwareC.cpp:69-155 asserts equal). The overload keeps the CTU's PMVs in
+ * function-static storage; here they are explicit:
+ *   pmv[0..1]  = Pmv[ref][1..2], the de-duplicated neighbour PMVs (full-pel, even) that
+ *                centre RIME windows 1 and 2 (window 0 is the CIME result);
+ *   mvp[0..2]  = mvNeighBor[7..9], the predictors the MVD cost is taken against
+ *                (TEncSearch.cpp:3788-3805); have_mvd = isHaveMvd.
+ * mvmin/mvmax come from the RK xSetSearchRange (TEncSearch.cpp:4188-4215);
+ * valid_w/h = nValidCtuWidth/Height (:3811-3818). */
+typedef struct
+{
+    int16_t ctu_x, ctu_y;
+    int16_t valid_w, valid_h;
+    int16_t mvmin[2], mvmax[2];
+    int16_t pmv[2][2];
+    int16_t mvp[3][2];
+    uint8_t have_mvd, reserved[3];
+} x265amd_rk_ctu;
+
+typedef struct { int16_t mv[2]; int32_t cost; } x265amd_rk_mv;
+
+/* cime = g_leftPMV (full-pel), rime[i] = g_RimeMv[ref][i] (full-pel), fme[i] = g_FmeMv[ref][i]
+ * = outQMv / return value (quarter-pel), i = offsIdx of OffsFromCtu64 (hardwareC/inter.cpp:23-38):
+ * 0-63 8x8, 64-79 16x16, 80-83 32x32, 84 64x64. CUs outside the picture have cost -1
+ * (TEncCu::isOutPic, TEncCu.cpp:475-493). */
+typedef struct
+{
+    x265amd_rk_mv cime;
+    x265amd_rk_mv rime[85];
+    x265amd_rk_mv fme[85];
+} x265amd_rk_result;
+
+/* MotionReference::init of the RK build (encoder/reference.cpp:161-178): the 4x4-sum
+ * plane of an ORIGINAL picture (downSampleAndSum :143) with replicated borders
+ * (extendEdge :73). `out` describes an int16 plane of (width/4 x height/4) samples with
+ * margins margin/4; `orig` must have margin_x == margin_y. */
+int x265amd_rk_ds_plane(x265amd_ctx *ctx, const x265amd_plane *orig, x265amd_plane *out);
+
+/* fenc: source picture; recon: reconstructed reference (fpelPlane); ds: x265amd_rk_ds_plane
+ * of the reference's original picture (fpelPlaneOrigDS). ctus / results are HOST arrays. */
+int x265amd_rk_ctu_batch(x265amd_ctx *ctx, const x265amd_plane *fenc, const x265amd_plane *recon,
+                         const x265amd_plane *ds, int qp, const x265amd_rk_ctu *ctus, int nctus,
+                         x265amd_rk_result *results);
+/* device-resident, asynchronous on the engine's stream */
+int x265amd_rk_ctu_batch_dev(x265amd_ctx *ctx, const x265amd_plane *fenc, const x265amd_plane *recon,
+                             const x265amd_plane *ds, int qp, const x265amd_rk_ctu *d_ctus, int nctus,
+                             x265amd_rk_result *d_results);
 
 /* ---- primitives table ---- */
 

@@ -42,6 +42,14 @@ class MEStats(C.Structure):
                 ("sad_calls", C.c_uint32), ("subpel_calls", C.c_uint32)]
 
 
+RK_CTU_DTYPE = np.dtype([("ctu_x", "<i2"), ("ctu_y", "<i2"), ("valid_w", "<i2"), ("valid_h", "<i2"),
+                         ("mvmin", "<i2", (2,)), ("mvmax", "<i2", (2,)), ("pmv", "<i2", (2, 2)), ("mvp", "<i2", (3, 2)),
+                         ("have_mvd", "u1"), ("reserved", "u1", (3,))], align=True)
+RK_MV_DTYPE = np.dtype([("mv", "<i2", (2,)), ("cost", "<i4")], align=True)
+RK_RESULT_DTYPE = np.dtype([("cime", RK_MV_DTYPE), ("rime", RK_MV_DTYPE, (85,)), ("fme", RK_MV_DTYPE, (85,))], align=True)
+assert RK_CTU_DTYPE.itemsize == 40 and RK_RESULT_DTYPE.itemsize == 171 * 8
+
+
 def build_oracle():
     import subprocess
     subprocess.check_call(["make", "-C", HERE, "libme_oracle.so"], stdout=subprocess.DEVNULL)
@@ -154,6 +162,20 @@ class Oracle:
         self.L.orc_me_search_batch(C.byref(ctx), _p(jobs), len(jobs), _p(res))
         return res
 
+    def rk_downsample(self, depth, src, origin, width, height, stride, margin4):
+        """4x4-sum plane of the picture, edge-replicated by margin4 samples (reference.cpp:143-178)."""
+        ds = np.zeros((height // 4, width // 4), np.int16)
+        self.L.orc_rk_downsample(depth, _p(src, origin), width, height, C.c_ssize_t(stride), _p(ds), C.c_ssize_t(width // 4))
+        padded = np.pad(ds, margin4, mode="edge")
+        dstride = padded.shape[1]
+        return np.ascontiguousarray(padded).reshape(-1), margin4 * dstride + margin4, dstride
+
+    def rk_ctu_batch(self, ctx, ds, ds_origin, ds_stride, pic_w, pic_h, jobs):
+        jobs = np.ascontiguousarray(jobs, RK_CTU_DTYPE)
+        out = np.zeros(len(jobs), RK_RESULT_DTYPE)
+        self.L.orc_rk_ctu_batch(C.byref(ctx), _p(ds, ds_origin), C.c_ssize_t(ds_stride), pic_w, pic_h, _p(jobs), len(jobs), _p(out))
+        return out
+
     def subpel_compare(self, ctx, off, w, h, qmv, cmp):
         return self.L.orc_subpel_compare(C.byref(ctx), off, w, h, MV(*qmv), cmp)
 
@@ -257,6 +279,53 @@ class Ref:
 
     def subpel_compare(self, off, w, h, plane, origin, stride, qmv, cmp):
         return self.L.ref_me_subpel_compare(self.h, off, w, h, _p(plane, origin), stride, qmv[0], qmv[1], cmp)
+
+    def rk_ds_plane(self, src, origin, width, height, stride, margin4):
+        """MotionReference::downSampleAndSum + extendEdge run by the reference itself."""
+        dstride = width // 4 + 2 * margin4
+        buf = np.zeros((height // 4 + 2 * margin4) * dstride, np.int16)
+        org = margin4 * dstride + margin4
+        self.L.ref_rk_ds_plane(_p(src, origin), width, height, stride, _p(buf, org), dstride, margin4, margin4)
+        return buf, org, dstride
+
+    def rk_ctu(self, fenc, forigin, fstride, qp, recon, rorigin, rstride, ds, ds_origin, ds_stride, pic_w, pic_h, job,
+               ref_idx=0):
+        """All CUs of one CTU through the reference's RK overload, in the encoder's order
+        (the isSavePmv CU first). Returns a record shaped like RK_RESULT_DTYPE."""
+        out = np.zeros(1, RK_RESULT_DTYPE)[0]
+        out["rime"]["cost"] = -1
+        out["fme"]["cost"] = -1
+        nb = np.zeros((10, 2), np.int16)
+        nb[0], nb[1] = job["pmv"][0], job["pmv"][1]
+        nb[7:10] = job["mvp"]
+        cx, cy = int(job["ctu_x"]), int(job["ctu_y"])
+        size_of = lambda i: 8 if i < 64 else 16 if i < 80 else 32 if i < 84 else 64
+        def offs(i):
+            if i < 64: return (i & 7) * 8, (i >> 3) * 8
+            if i < 80: return ((i - 64) & 3) * 16, ((i - 64) >> 2) * 16
+            if i < 84: return ((i - 80) & 1) * 32, ((i - 80) >> 1) * 32
+            return 0, 0
+        inside = [i for i in range(85) if cx + offs(i)[0] + size_of(i) <= pic_w and cy + offs(i)[1] + size_of(i) <= pic_h]
+        # the save CU: the largest CU at the CTU origin that fits (TEncSearch.cpp:4007-4061)
+        save = max((i for i in inside if offs(i) == (0, 0)), key=size_of)
+        order = [save] + [i for i in sorted(inside, reverse=True) if i != save]
+        res = (C.c_int32 * 12)()
+        i16 = lambda v: (C.c_int16 * 2)(int(v[0]), int(v[1]))
+        for n, i in enumerate(order):
+            ox, oy = offs(i)
+            size = size_of(i)
+            depth = {64: 0, 32: 1, 16: 2, 8: 3}[size]
+            self.L.ref_rk_me(self.h, _p(fenc, forigin), C.c_ssize_t(fstride), qp, _p(recon, rorigin), rstride, _p(ds, ds_origin),
+                             (cy + oy) * fstride + cx + ox, size, i16(job["mvmin"]), i16(job["mvmax"]),
+                             _p(nb), 2, int(job["have_mvd"]), int(n == 0), i, depth,
+                             C.c_ssize_t(cx // 4 + (cy // 4) * ds_stride), ds_stride, int(job["valid_w"]), int(job["valid_h"]),
+                             ref_idx, res)
+            out["fme"][i]["mv"] = (res[6], res[7]); out["fme"][i]["cost"] = res[8]
+            assert (res[0], res[1], res[2]) == (res[6], res[7], res[8])
+            out["rime"][i]["mv"] = (res[3], res[4]); out["rime"][i]["cost"] = res[5]
+            if n == 0:
+                out["cime"]["mv"] = (res[9], res[10]); out["cime"]["cost"] = res[11]
+        return out
 
     def lookahead_field(self, fenc, refs, origin, stride, wcu, hcu, qp, method, subme, merange):
         planes = (C.c_void_p * 4)(*[r.ctypes.data + origin * r.itemsize for r in refs])

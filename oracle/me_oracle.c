@@ -175,6 +175,30 @@ void orc_me_search_batch(const orc_me_ctx *c, const orc_job *jobs, int njobs, or
     }
 }
 
+void orc_rk_downsample(int depth, const void *src, int width, int height, intptr_t sstride, int16_t *dst, intptr_t dstride)
+{
+    for (int i = 0; i < height / 4; i++)
+        for (int k = 0; k < width / 4; k++)
+        {
+            int16_t sum = 0;
+            for (int m = 0; m < 4; m++)
+                for (int n = 0; n < 4; n++)
+                    sum = (int16_t)(sum + (depth <= 8 ? ((const uint8_t*)src)[(i * 4 + m) * sstride + k * 4 + n]
+                                                      : ((const uint16_t*)src)[(i * 4 + m) * sstride + k * 4 + n]));
+            dst[i * dstride + k] = sum;
+        }
+}
+
+void orc_rk_ctu_batch(const orc_me_ctx *c, const int16_t *ds_origin, intptr_t ds_stride, int pic_w, int pic_h,
+                      const orc_rk_ctu *jobs, int n, orc_rk_result *out)
+{
+    for (int i = 0; i < n; i++)
+    {
+        if (c->depth <= 8) rk_ctu_8(c, ds_origin, ds_stride, pic_w, pic_h, &jobs[i], &out[i]);
+        else rk_ctu_16(c, ds_origin, ds_stride, pic_w, pic_h, &jobs[i], &out[i]);
+    }
+}
+
 int orc_subpel_compare(const orc_me_ctx *c, intptr_t off, int w, int h, orc_mv qmv, int cmp)
 {
     if (c->depth <= 8)

@@ -93,6 +93,27 @@ typedef struct
 } orc_result;
 void orc_me_search_batch(const orc_me_ctx *c, const orc_job *jobs, int njobs, orc_result *out);
 
+/* ---- Rockchip path: CIME + RIME + FME of one CTU against one reference
+ * (15-argument motionEstimate overload, source/encoder/motion.cpp:1250-1410; twin in
+ * source/hardwareC/inter.cpp:679-734, :2521-2624). Layouts equal x265amd_rk_ctu /
+ * x265amd_rk_result of include/x265_amd_me.h. */
+typedef struct
+{
+    int16_t ctu_x, ctu_y;
+    int16_t valid_w, valid_h;
+    int16_t mvmin[2], mvmax[2];
+    int16_t pmv[2][2];
+    int16_t mvp[3][2];
+    uint8_t have_mvd, reserved[3];
+} orc_rk_ctu;
+typedef struct { int16_t mv[2]; int32_t cost; } orc_rk_mv;
+typedef struct { orc_rk_mv cime, rime[85], fme[85]; } orc_rk_result;
+/* MotionReference::downSampleAndSum (source/encoder/reference.cpp:143-160): 4x4 sums, no padding */
+void orc_rk_downsample(int depth, const void *src, int width, int height, intptr_t sstride, int16_t *dst, intptr_t dstride);
+/* c: depth, fenc_plane/stride, ref_planes[0] = reconstructed reference, ref_stride, cost */
+void orc_rk_ctu_batch(const orc_me_ctx *c, const int16_t *ds_origin, intptr_t ds_stride, int pic_w, int pic_h,
+                      const orc_rk_ctu *jobs, int n, orc_rk_result *out);
+
 /* subpelCompare (motion.cpp:1651-1689): cmp 0 = sad, 1 = satd */
 int orc_subpel_compare(const orc_me_ctx *c, intptr_t pu_offset, int w, int h, orc_mv qmv, int cmp);
 

@@ -867,6 +867,169 @@ me_hex2:
 #undef CLIPQ_Y
 }
 
+
+/* ---------------- Rockchip CIME / RIME / FME: motion.cpp:1220-1648 ---------------- */
+
+/* 4-tap kernels used by the RK fractional search: g_chromaFilter[frac * 2]
+ * (motion.cpp:1455-1490, table TComRom.cpp:183-193) */
+static const int16_t FN(rk_taps)[4][4] = { { 0, 64, 0, 0 }, { -4, 54, 16, -2 }, { -4, 36, 36, -4 }, { -2, 16, 54, -4 } };
+
+/* RK subpelCompare(pfref, ...) evaluated directly on the reference plane; `r` is the
+ * integer position (qmv >> 2) of the block. motion.cpp:1453-1494 with
+ * InterpHoriz :1495, InterpVert :1534, FilterHorizontal :1573, FilterVertical :1608 */
+static int FN(rk_subpel_satd)(const PIXEL *fenc64, const PIXEL *r, intptr_t stride, int qx, int qy, int w, int h, int depth)
+{
+    const int xf = qx & 3, yf = qy & 3;
+    PIXEL fe[64 * 64];
+    for (int y = 0; y < h; y++) memcpy(fe + y * w, fenc64 + y * 64, w * sizeof(PIXEL)); /* pfenc, stride = width */
+    if ((xf | yf) == 0)
+        return FN(satd)(fe, w, r, stride, w, h);
+    PIXEL buf[64 * 64];
+    const int16_t *ch = FN(rk_taps)[xf], *cv = FN(rk_taps)[yf];
+    if (yf == 0)
+    {
+        for (int y = 0; y < h; y++)
+            for (int x = 0; x < w; x++)
+            {
+                int sum = 0;
+                for (int k = 0; k < 4; k++) sum += (int)r[y * stride + x - 1 + k] * ch[k];
+                buf[y * 64 + x] = FN(clip_pix)((int16_t)((sum + 32) >> 6), depth);
+            }
+    }
+    else if (xf == 0)
+    {
+        for (int y = 0; y < h; y++)
+            for (int x = 0; x < w; x++)
+            {
+                int sum = 0;
+                for (int k = 0; k < 4; k++) sum += (int)r[(y - 1 + k) * stride + x] * cv[k];
+                buf[y * 64 + x] = FN(clip_pix)((int16_t)((sum + 32) >> 6), depth);
+            }
+    }
+    else
+    {
+        int16_t im[64 * (64 + 8)];
+        const int headRoom = 14 - depth, shiftH = 6 - headRoom, offH = -(8192 << shiftH);
+        const int shiftV = 6 + headRoom, offV = (1 << (shiftV - 1)) + (8192 << 6);
+        for (int y = 0; y < h + 3; y++)
+            for (int x = 0; x < w; x++)
+            {
+                int sum = 0;
+                for (int k = 0; k < 4; k++) sum += (int)r[(y - 1) * stride + x - 1 + k] * ch[k];
+                im[y * w + x] = (int16_t)((sum + offH) >> shiftH);
+            }
+        for (int y = 0; y < h; y++)
+            for (int x = 0; x < w; x++)
+            {
+                int sum = 0;
+                for (int k = 0; k < 4; k++) sum += (int)im[(y + k) * w + x] * cv[k];
+                buf[y * 64 + x] = FN(clip_pix)((int16_t)((sum + offV) >> shiftV), depth);
+            }
+    }
+    return FN(satd)(fe, w, buf, 64, w, h);
+}
+
+static inline int FN(rk_mvcost3)(const uint16_t *cost, const orc_rk_ctu *j, int x, int y)
+{
+    /* min over the three cost predictors, each sum truncated to uint16 (motion.cpp:1284-1292) */
+    int best = 0x7fffffff;
+    for (int k = 0; k < 3; k++)
+    {
+        int c = (uint16_t)(cost[x - j->mvp[k][0]] + cost[y - j->mvp[k][1]]);
+        if (c < best) best = c;
+    }
+    return j->have_mvd ? best : 0;
+}
+
+static void FN(rk_ctu)(const orc_me_ctx *c, const int16_t *ds, intptr_t ds_stride, int pic_w, int pic_h,
+                       const orc_rk_ctu *j, orc_rk_result *out)
+{
+    const uint16_t *cost = c->cost + 32767;
+    const PIXEL *fplane = (const PIXEL*)c->fenc_plane;
+    const PIXEL *rplane = (const PIXEL*)c->ref_planes[0];
+    const intptr_t fs = c->fenc_stride, rs = c->ref_stride;
+    memset(out, 0, sizeof(*out));
+
+    /* ---- CIME: 4x4-sum downsampled CTU against the downsampled ORIGINAL reference,
+     * full search over [mvmin / 4, mvmax / 4] (motion.cpp:1272-1303) */
+    int16_t ctuDS[16 * 16];
+    {
+        const PIXEL *src = fplane + (intptr_t)j->ctu_y * fs + j->ctu_x; /* the RK build caches 64x64 at the CU offset */
+        for (int i = 0; i < 16; i++)
+            for (int k = 0; k < 16; k++)
+            {
+                int16_t sum = 0;
+                for (int m = 0; m < 4; m++)
+                    for (int n = 0; n < 4; n++) sum = (int16_t)(sum + src[(i * 4 + m) * fs + k * 4 + n]);
+                ctuDS[i * 16 + k] = sum;
+            }
+    }
+    const int16_t *refDS = ds + j->ctu_x / 4 + (intptr_t)(j->ctu_y / 4) * ds_stride;
+    const int cw = j->valid_w / 4, chh = j->valid_h / 4;
+    int bcost = 0x7fffffff;
+    int16_t bx = 0, by = 0;
+    for (int16_t ty = (int16_t)(j->mvmin[1] / 4); ty <= j->mvmax[1] / 4; ty++)
+        for (int16_t tx = (int16_t)(j->mvmin[0] / 4); tx <= j->mvmax[0] / 4; tx++)
+        {
+            int sad = 0;
+            const int16_t *p = refDS + tx + (intptr_t)ty * ds_stride;
+            /* the CTU block is indexed with the VALID width as its row pitch (motion.cpp:1227) */
+            for (int i = 0; i < chh; i++)
+                for (int k = 0; k < cw; k++) sad += abs(p[k + i * ds_stride] - ctuDS[k + i * cw]);
+            int cst = sad + FN(rk_mvcost3)(cost, j, tx, ty);
+            if (cst < bcost) { bcost = cst; bx = tx; by = ty; }
+        }
+    int16_t pmv[3][2];
+    pmv[0][0] = (int16_t)(bx * 4); pmv[0][1] = (int16_t)(by * 4);
+    pmv[1][0] = j->pmv[0][0]; pmv[1][1] = j->pmv[0][1];
+    pmv[2][0] = j->pmv[1][0]; pmv[2][1] = j->pmv[1][1];
+    out->cime.mv[0] = pmv[0][0]; out->cime.mv[1] = pmv[0][1]; out->cime.cost = bcost;
+
+    /* ---- per CU: RIME (3 windows of 16 x 12 full-pel points) then FME (7 x 7 qpel points) */
+    for (int idx = 0; idx < 85; idx++)
+    {
+        int size, ox, oy;
+        if (idx < 64) { size = 8; ox = (idx & 7) * 8; oy = (idx >> 3) * 8; }
+        else if (idx < 80) { size = 16; ox = ((idx - 64) & 3) * 16; oy = ((idx - 64) >> 2) * 16; }
+        else if (idx < 84) { size = 32; ox = ((idx - 80) & 1) * 32; oy = ((idx - 80) >> 1) * 32; }
+        else { size = 64; ox = 0; oy = 0; }
+        if (j->ctu_x + ox + size > pic_w || j->ctu_y + oy + size > pic_h)
+        {
+            out->rime[idx].cost = -1; out->fme[idx].cost = -1;   /* CU outside the picture (TEncCu.cpp:475-493) */
+            continue;
+        }
+        const intptr_t off = (intptr_t)(j->ctu_y + oy) * fs + j->ctu_x + ox;
+        const intptr_t roff = (intptr_t)(j->ctu_y + oy) * rs + j->ctu_x + ox;
+        PIXEL fenc[64 * 64];
+        for (int y = 0; y < size; y++) memcpy(fenc + 64 * y, fplane + off + y * fs, size * sizeof(PIXEL));
+        bcost = 0x7fffffff;
+        int16_t mx = 0, my = 0;
+        for (int p = 0; p < 3; p++)
+            for (int16_t i = -6; i < 6; i++)
+                for (int16_t k = -8; k < 8; k++)
+                {
+                    int16_t tx = (int16_t)(pmv[p][0] + k), ty = (int16_t)(pmv[p][1] + i);
+                    int cst = FN(sad)(fenc, 64, rplane + roff + tx + (intptr_t)ty * rs, rs, size, size) +
+                              FN(rk_mvcost3)(cost, j, tx, ty);
+                    if (cst < bcost) { bcost = cst; mx = tx; my = ty; }
+                }
+        out->rime[idx].mv[0] = mx; out->rime[idx].mv[1] = my; out->rime[idx].cost = bcost;
+
+        const int16_t BX = (int16_t)(mx << 2), BY = (int16_t)(my << 2);
+        bcost = 0x7fffffff;
+        int16_t fx = 0, fy = 0;
+        for (int16_t i = -3; i <= 3; i++)       /* x offset outer, y inner (motion.cpp:1377-1381) */
+            for (int16_t k = -3; k <= 3; k++)
+            {
+                int16_t qx = (int16_t)(BX + i), qy = (int16_t)(BY + k);
+                const PIXEL *r = rplane + roff + (qx >> 2) + (intptr_t)(qy >> 2) * rs;
+                int cst = FN(rk_subpel_satd)(fenc, r, rs, qx, qy, size, size, c->depth) + FN(rk_mvcost3)(cost, j, qx, qy);
+                if (cst < bcost) { bcost = cst; fx = qx; fy = qy; }
+            }
+        out->fme[idx].mv[0] = fx; out->fme[idx].mv[1] = fy; out->fme[idx].cost = bcost;
+    }
+}
+
 #undef S16
 #undef IN_RANGE
 #undef TRY_MV

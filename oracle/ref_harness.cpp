@@ -22,6 +22,8 @@
 #include "motion.h"
 #include "bitcost.h"
 #include "mv.h"
+#include "reference.h"
+#include "hardwareC/inter.h"
 
 #include <string.h>
 #include <stdlib.h>
@@ -246,6 +248,46 @@ int ref_trace_end(void)
         t_part = -1;
     }
     return t_n;
+}
+
+/* ---- Rockchip path: the 15-argument MotionEstimate::motionEstimate overload
+ * (motion.cpp:1250-1410) = CIME + RIME + FME for one CU, called the way
+ * TEncSearch::predInterSearch does (TEncSearch.cpp:3820-3822). The overload keeps
+ * the CTU's PMVs in a function-static array, so CUs of one CTU must be issued
+ * after that CTU's isSavePmv call, as the encoder does. ---- */
+void ref_rk_ds_plane(pixel *origOrigin, int width, int height, int stride, short *dsOrigin, int dsStride,
+                     int marginY4, int marginX4)
+{
+    MotionReference mr;
+    mr.downSampleAndSum(origOrigin, width, height, stride, dsOrigin, dsStride);
+    mr.extendEdge(dsOrigin, marginY4, marginX4, dsStride, width / 4, height / 4);
+}
+
+int ref_rk_me(void *h, pixel *fencPlane, intptr_t fencStride, int qp,
+              pixel *reconOrigin, int stride, short *dsOrigin,
+              int offset, int size, const int16_t *mvmin, const int16_t *mvmax,
+              const int16_t *mvNeighBor /* 10 x {x,y} */, int nMvNeighBor, int isHaveMvd, int isSavePmv,
+              int offsIdx, int depth, intptr_t blockOffset_ds, int stride_ds, int validW, int validH, int refIdx,
+              int32_t *out /* qmv.x qmv.y cost | rime x y cost | fme x y cost | cime x y cost */)
+{
+    RefME *r = (RefME*)h;
+    r->me.setSourcePlane(fencPlane, fencStride);
+    r->me.setQP(qp);
+    r->ref.fpelPlane = reconOrigin;
+    r->ref.fpelPlaneOrigDS = dsOrigin;
+    r->ref.lumaStride = stride;
+    r->ref.isLowres = false;
+    r->me.setSourcePU(offset, size, size);
+    MV nb[10];
+    for (int i = 0; i < 10; i++) nb[i] = MV(mvNeighBor[2 * i], mvNeighBor[2 * i + 1]);
+    MV o;
+    int cost = r->me.motionEstimate(&r->ref, MV(mvmin[0], mvmin[1]), MV(mvmax[0], mvmax[1]), o, nb, nMvNeighBor,
+                                    !!isHaveMvd, !!isSavePmv, offsIdx, depth, blockOffset_ds, stride_ds, validW, validH, refIdx);
+    out[0] = o.x; out[1] = o.y; out[2] = cost;
+    out[3] = g_RimeMv[refIdx][offsIdx].x; out[4] = g_RimeMv[refIdx][offsIdx].y; out[5] = g_RimeMv[refIdx][offsIdx].nSadCost;
+    out[6] = g_FmeMv[refIdx][offsIdx].x; out[7] = g_FmeMv[refIdx][offsIdx].y; out[8] = g_FmeMv[refIdx][offsIdx].nSadCost;
+    out[9] = g_leftPMV[refIdx].x; out[10] = g_leftPMV[refIdx].y; out[11] = g_leftPMV[refIdx].nSadCost;
+    return cost;
 }
 
 } // extern "C"

@@ -143,6 +143,20 @@ def main():
             la["%d_%d_%d_mvs" % (depth, method, subme)] = mvs
             la["%d_%d_%d_costs" % (depth, method, subme)] = costs
     np.savez_compressed(os.path.join(HERE, "lookahead_golden.npz"), **la)
+
+    # ---- Rockchip CIME / RIME / FME (8-bit, as the full RK encoder is 8-bit only)
+    from test_gpu_rk import rk_case, M
+    ref = Ref(8)
+    W, H = 416, 240
+    cur, rorig, recon, org, stride, jobs = rk_case(8, W, H, 5)
+    shas["rk_8"] = [sha(cur), sha(recon)]
+    ds, dorg, dstride = ref.rk_ds_plane(rorig, org, W, H, stride, M // 4)
+    recs = [ref.rk_ctu(cur, org, stride, 30, recon, org, stride, ds, dorg, dstride, W, H, j) for j in jobs]
+    rk = {}
+    for k in ("cime", "rime", "fme"):
+        rk[k + "_mv"] = np.stack([r[k]["mv"] for r in recs])
+        rk[k + "_cost"] = np.stack([r[k]["cost"] for r in recs])
+    np.savez_compressed(os.path.join(HERE, "rk_golden.npz"), **rk)
     json.dump(shas, open(os.path.join(HERE, "input_sha.json"), "w"), indent=0, sort_keys=True)
     print("golden vectors written to", HERE)
 

@@ -1,0 +1,93 @@
+"""GPU: the Rockchip CIME / RIME / FME path (x265amd_rk_ctu_batch, x265amd_rk_ds_plane)
+against the oracle and the reference-generated golden records."""
+import numpy as np
+import pytest
+
+from x265_amd import workload
+from x265_amd.engine import RK_CTU_DTYPE
+from x265_amd.synth import make_clip, pad_plane
+import golden_util as G
+
+pytestmark = pytest.mark.gpu
+M = 304   # the reference's luma margin (TComPicYuv.cpp:85-91)
+
+
+def rk_case(depth, W, H, seed):
+    """(cur, orig ref, recon ref, origin, stride, jobs) -- recon = orig + small noise, as after coding."""
+    clip = make_clip(W, H, 3, seed=seed, depth=depth)
+    maxv = (1 << depth) - 1
+    cur, org, stride = pad_plane(clip[2], M)
+    rorig, _, _ = pad_plane(clip[0], M)
+    noise = np.random.default_rng(seed).integers(-2, 3, clip[0].shape)
+    recon, _, _ = pad_plane(np.clip(clip[0].astype(int) + noise, 0, maxv).astype(clip[0].dtype), M)
+    rng = np.random.default_rng(seed + 1)
+    nctu = ((W + 63) // 64) * ((H + 63) // 64)
+    pmvs = (rng.integers(-12, 13, (nctu, 2, 2)) * 2).astype(np.int16)
+    mvps = (rng.integers(-12, 13, (nctu, 3, 2)) * 2).astype(np.int16)
+    jobs = workload.rk_ctu_jobs(W, H, pmvs, mvps, have_mvd=True)
+    jobs["have_mvd"][::5] = 0
+    return cur, rorig, recon, org, stride, jobs
+
+
+def same(a, b):
+    return all(np.array_equal(a[k]["mv"], b[k]["mv"]) and np.array_equal(a[k]["cost"], b[k]["cost"])
+               for k in ("cime", "rime", "fme"))
+
+
+@pytest.mark.parametrize("size", [(416, 240), (200, 136), (128, 64)])
+def test_rk_vs_oracle(engine8, oracle, size):
+    W, H = size
+    cur, rorig, recon, org, stride, jobs = rk_case(8, W, H, 5)
+    pc = engine8.upload_plane(cur, W, H, M, M, stride)
+    po = engine8.upload_plane(rorig, W, H, M, M, stride)
+    pr = engine8.upload_plane(recon, W, H, M, M, stride)
+    pds = engine8.rk_ds_plane(po)
+    ds, dorg, dstride = oracle.rk_downsample(8, rorig, org, W, H, stride, M // 4)
+    assert pds.stride == dstride
+    assert np.array_equal(engine8.download_ds_plane(pds).reshape(-1), ds)
+    ctx = oracle.make_ctx(8, cur, org, stride, [recon], org, stride, False, 30, 0, 0)
+    exp = oracle.rk_ctu_batch(ctx, ds, dorg, dstride, W, H, jobs)
+    got = engine8.rk_ctu_batch(pc, pr, pds, 30, jobs)
+    assert same(got, exp)
+
+
+def test_rk_golden(engine8):
+    g = np.load(G.GOLD + "/rk_golden.npz")
+    W, H = 416, 240
+    cur, rorig, recon, org, stride, jobs = rk_case(8, W, H, 5)
+    assert [G.sha(cur), G.sha(recon)] == G.input_shas()["rk_8"]
+    pc = engine8.upload_plane(cur, W, H, M, M, stride)
+    po = engine8.upload_plane(rorig, W, H, M, M, stride)
+    pr = engine8.upload_plane(recon, W, H, M, M, stride)
+    got = engine8.rk_ctu_batch(pc, pr, engine8.rk_ds_plane(po), 30, jobs)
+    for k in ("cime", "rime", "fme"):
+        assert np.array_equal(got[k]["mv"], g[k + "_mv"]) and np.array_equal(got[k]["cost"], g[k + "_cost"])
+
+
+def test_rk_10bit_vs_oracle(engine10, oracle):
+    """The RK overload compiles for 16-bit pixels (HIGH_BIT_DEPTH ME-only build); same arithmetic."""
+    W, H = 192, 128
+    cur, rorig, recon, org, stride, jobs = rk_case(10, W, H, 9)
+    pc = engine10.upload_plane(cur, W, H, M, M, stride)
+    po = engine10.upload_plane(rorig, W, H, M, M, stride)
+    pr = engine10.upload_plane(recon, W, H, M, M, stride)
+    pds = engine10.rk_ds_plane(po)
+    ds, dorg, dstride = oracle.rk_downsample(10, rorig, org, W, H, stride, M // 4)
+    ctx = oracle.make_ctx(10, cur, org, stride, [recon], org, stride, False, 36, 0, 0)
+    exp = oracle.rk_ctu_batch(ctx, ds, dorg, dstride, W, H, jobs)
+    assert same(engine10.rk_ctu_batch(pc, pr, pds, 36, jobs), exp)
+
+
+def test_rk_argument_errors(engine8):
+    from x265_amd.engine import EngineError
+    W, H = 128, 64
+    cur, rorig, recon, org, stride, jobs = rk_case(8, W, H, 5)
+    pc = engine8.upload_plane(cur, W, H, M, M, stride)
+    pds = engine8.rk_ds_plane(pc)
+    bad = jobs.copy(); bad["ctu_x"][0] = 8
+    with pytest.raises(EngineError):
+        engine8.rk_ctu_batch(pc, pc, pds, 30, bad)
+    bad = jobs.copy(); bad["mvmax"][0] = (2000, 0)
+    with pytest.raises(EngineError):
+        engine8.rk_ctu_batch(pc, pc, pds, 30, bad)
+    assert len(engine8.rk_ctu_batch(pc, pc, pds, 30, jobs[:0])) == 0

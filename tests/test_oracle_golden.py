@@ -66,3 +66,17 @@ def test_lookahead_field(oracle, depth):
         mvs, costs = oracle.lookahead_field(ctx, pa[3], pa[4], 16)
         assert np.array_equal(mvs, g["%d_%d_%d_mvs" % (depth, method, subme)])
         assert np.array_equal(costs, g["%d_%d_%d_costs" % (depth, method, subme)])
+
+
+def test_rk_ctu_records(oracle):
+    """CIME / RIME / FME records of every CTU of a 416x240 frame pair (incl. the partial bottom row)."""
+    from test_gpu_rk import rk_case, M
+    g = np.load(G.GOLD + "/rk_golden.npz")
+    W, H = 416, 240
+    cur, rorig, recon, org, stride, jobs = rk_case(8, W, H, 5)
+    assert [G.sha(cur), G.sha(recon)] == G.input_shas()["rk_8"]
+    ds, dorg, dstride = oracle.rk_downsample(8, rorig, org, W, H, stride, M // 4)
+    ctx = oracle.make_ctx(8, cur, org, stride, [recon], org, stride, False, 30, 0, 0)
+    got = oracle.rk_ctu_batch(ctx, ds, dorg, dstride, W, H, jobs)
+    for k in ("cime", "rime", "fme"):
+        assert np.array_equal(got[k]["mv"], g[k + "_mv"]) and np.array_equal(got[k]["cost"], g[k + "_cost"]), k

@@ -85,3 +85,21 @@ def test_subpel_compare(oracle, ref):
             for cmp in (0, 1):
                 assert oracle.subpel_compare(ctx, py * stride + px, w, h, q, cmp) == \
                     ref.subpel_compare(py * stride + px, w, h, rpl, org, stride, q, cmp)
+
+
+def test_rk_path(oracle, ref):
+    """RK overload (CIME + RIME + FME) and the downsampled plane, incl. partial CTUs and 16-bit pixels."""
+    from test_gpu_rk import rk_case, M
+    depth = ref.depth
+    for (W, H) in ((200, 136), (128, 64)):
+        cur, rorig, recon, org, stride, jobs = rk_case(depth, W, H, 7)
+        ds_r, dorg_r, dstride_r = ref.rk_ds_plane(rorig, org, W, H, stride, M // 4)
+        ds, dorg, dstride = oracle.rk_downsample(depth, rorig, org, W, H, stride, M // 4)
+        assert (dorg, dstride) == (dorg_r, dstride_r) and np.array_equal(ds, ds_r)
+        qp = 30 + 6 * (depth - 8)
+        ctx = oracle.make_ctx(depth, cur, org, stride, [recon], org, stride, False, qp, 0, 0)
+        got = oracle.rk_ctu_batch(ctx, ds, dorg, dstride, W, H, jobs)
+        for i, j in enumerate(jobs):
+            exp = ref.rk_ctu(cur, org, stride, qp, recon, org, stride, ds, dorg, dstride, W, H, j)
+            for k in ("cime", "rime", "fme"):
+                assert np.array_equal(got[i][k]["mv"], exp[k]["mv"]) and np.array_equal(got[i][k]["cost"], exp[k]["cost"]), (W, H, i, k)

@@ -221,6 +221,75 @@ __device__ __forceinline__ void interp_tile(const P *r, int stride, int xf, int 
         for (int x = 0; x < 4; x++) o[y][x] = clip_pixel(as_i16((acc[y][x] + offV) >> shiftV), maxv);
 }
 
+/* 4-tap kernels of the Rockchip fractional search: g_chromaFilter[frac * 2]
+ * (motion.cpp:1455-1490; table TComRom.cpp:183-193) */
+__constant__ static const int16_t kRkTaps[4][4] = { { 0, 64, 0, 0 }, { -4, 54, 16, -2 }, { -4, 36, 36, -4 }, { -2, 16, 54, -4 } };
+
+/* RK flavour of interp_tile: InterpHoriz / InterpVert / FilterHorizontal + FilterVertical
+ * with N = 4 (motion.cpp:1495-1648), phase (xf, yf) != (0, 0) */
+template<typename P>
+__device__ __forceinline__ void rk_interp_tile(const P *r, int stride, int xf, int yf, int depth, int o[4][4])
+{
+    const int maxv = (1 << depth) - 1;
+    int ch[4], cv[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) { ch[k] = kRkTaps[xf][k]; cv[k] = kRkTaps[yf][k]; }
+    if (yf == 0)
+    {
+#pragma unroll
+        for (int y = 0; y < 4; y++)
+        {
+            int px[8];
+            Px<P>::unpack(Px<P>::load(r + y * stride - 1), px);
+            Px<P>::unpack(Px<P>::load(r + y * stride + 3), px + 4);
+#pragma unroll
+            for (int x = 0; x < 4; x++)
+            {
+                const int sum = px[x] * ch[0] + px[x + 1] * ch[1] + px[x + 2] * ch[2] + px[x + 3] * ch[3];
+                o[y][x] = clip_pixel(as_i16((sum + 32) >> 6), maxv);
+            }
+        }
+        return;
+    }
+    int acc[4][4];
+#pragma unroll
+    for (int y = 0; y < 4; y++)
+#pragma unroll
+        for (int x = 0; x < 4; x++) acc[y][x] = 0;
+    const int headRoom = 14 - depth;
+    const int shiftH = 6 - headRoom, offH = -(8192 << shiftH);
+    const int shiftV = 6 + headRoom, offV = (1 << (shiftV - 1)) + (8192 << 6);
+#pragma unroll
+    for (int rr = 0; rr < 7; rr++)
+    {
+        int v[4];
+        if (xf == 0)
+            Px<P>::unpack(Px<P>::load(r + (rr - 1) * stride), v);
+        else
+        {
+            int px[8];
+            Px<P>::unpack(Px<P>::load(r + (rr - 1) * stride - 1), px);
+            Px<P>::unpack(Px<P>::load(r + (rr - 1) * stride + 3), px + 4);
+#pragma unroll
+            for (int x = 0; x < 4; x++)
+                v[x] = as_i16((px[x] * ch[0] + px[x + 1] * ch[1] + px[x + 2] * ch[2] + px[x + 3] * ch[3] + offH) >> shiftH);
+        }
+#pragma unroll
+        for (int y = 0; y < 4; y++)
+            if (rr - y >= 0 && rr - y < 4)
+            {
+#pragma unroll
+                for (int x = 0; x < 4; x++) acc[y][x] += v[x] * cv[rr - y];
+            }
+    }
+#pragma unroll
+    for (int y = 0; y < 4; y++)
+#pragma unroll
+        for (int x = 0; x < 4; x++)
+            o[y][x] = xf == 0 ? clip_pixel(as_i16((acc[y][x] + 32) >> 6), maxv)
+                              : clip_pixel(as_i16((acc[y][x] + offV) >> shiftV), maxv);
+}
+
 /* cost of one tile given the 4 packed source rows and 16 predicted pixels */
 template<typename P>
 __device__ __forceinline__ int tile_cost_px(const typename Px<P>::quad f[4], const int o[4][4], bool satd)

@@ -197,6 +197,191 @@ __global__ void extend_border_kernel(P *origin, long stride, int w, int h, int m
     origin[y * stride + x] = origin[sy * stride + sx];
 }
 
+
+/* ---- Rockchip path kernels ---- */
+
+/* downSampleAndSum (reference.cpp:143-160): int16 sum of each 4x4 block */
+template<typename P>
+__global__ void rk_downsample_kernel(const P *src, long ss, int16_t *dst, long ds, int w4, int h4)
+{
+    const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y * blockDim.y + threadIdx.y;
+    if (x >= w4 || y >= h4) return;
+    int sum = 0;
+#pragma unroll
+    for (int m = 0; m < 4; m++)
+    {
+        int v[4];
+        Px<P>::unpack(Px<P>::load(src + (long)(4 * y + m) * ss + 4 * x), v);
+        sum += v[0] + v[1] + v[2] + v[3];
+    }
+    dst[y * ds + x] = (int16_t)sum;
+}
+
+struct RkArgs
+{
+    PlaneDev fenc, recon;
+    const int16_t *ds;
+    int ds_stride;
+    int pic_w, pic_h, depth;
+    const uint16_t *ctab;
+    const x265amd_rk_ctu *ctus;
+    x265amd_rk_result *results;
+    int nctus;
+};
+
+/* CIME (motion.cpp:1272-1303): one workgroup per CTU. The 16x16 block of 4x4 sums of the
+ * CTU and the downsampled reference window live in LDS; each thread walks whole
+ * candidates (256 abs-diffs each), and the raster-order strict-'<' winner is the minimum
+ * of the 64-bit key (cost << 32 | visit index). */
+#define CIME_THREADS 256
+template<typename P>
+__global__ __launch_bounds__(CIME_THREADS) void rk_cime_kernel(RkArgs a)
+{
+    extern __shared__ int16_t cime_lds[];
+    __shared__ unsigned long long red[CIME_THREADS / 64];
+    const x265amd_rk_ctu &j = a.ctus[blockIdx.x];
+    int16_t *ctu = cime_lds;            /* 256 */
+    int16_t *win = cime_lds + 256;      /* (nx + 15) x (ny + 15) */
+    const int x0 = j.mvmin[0] / 4, x1 = j.mvmax[0] / 4, y0 = j.mvmin[1] / 4, y1 = j.mvmax[1] / 4;
+    const int nx = x1 - x0 + 1, ny = y1 - y0 + 1;
+    const int ww = nx + 15, wh = ny + 15;
+    const int tid = threadIdx.x;
+    {
+        /* DownSample (motion.cpp:1232-1249) of the 64x64 block cached at the CTU origin */
+        const P *src = (const P*)a.fenc.origin + (long)j.ctu_y * a.fenc.stride + j.ctu_x;
+        const int bx = tid & 15, by = tid >> 4;
+        int sum = 0;
+#pragma unroll
+        for (int m = 0; m < 4; m++)
+        {
+            int v[4];
+            Px<P>::unpack(Px<P>::load(src + (long)(4 * by + m) * a.fenc.stride + 4 * bx), v);
+            sum += v[0] + v[1] + v[2] + v[3];
+        }
+        ctu[tid] = (int16_t)sum;
+    }
+    const int16_t *ref = a.ds + j.ctu_x / 4 + (long)(j.ctu_y / 4) * a.ds_stride + x0 + (long)y0 * a.ds_stride;
+    for (int i = tid; i < ww * wh; i += CIME_THREADS)
+    {
+        const int yy = i / ww, xx = i - yy * ww;
+        win[i] = ref[(long)yy * a.ds_stride + xx];
+    }
+    __syncthreads();
+    const int cw = j.valid_w / 4, ch = j.valid_h / 4;
+    unsigned long long best = ~0ull;
+    for (int c = tid; c < nx * ny; c += CIME_THREADS)
+    {
+        const int cy = c / nx, cx = c - cy * nx;
+        int sad = 0;
+        /* the CTU block is indexed with the valid width as its pitch (motion.cpp:1227) */
+        for (int i = 0; i < ch; i++)
+            for (int k = 0; k < cw; k++)
+                sad += abs((int)win[(cy + i) * ww + cx + k] - (int)ctu[k + i * cw]);
+        int mvc = 0;
+        if (j.have_mvd)
+        {
+            mvc = 0x7fffffff;
+            const int tx = x0 + cx, ty = y0 + cy;
+#pragma unroll
+            for (int k = 0; k < 3; k++)
+            {
+                const int v = ((int)a.ctab[tx - j.mvp[k][0]] + (int)a.ctab[ty - j.mvp[k][1]]) & 0xffff;
+                mvc = v < mvc ? v : mvc;
+            }
+        }
+        const unsigned long long key = ((unsigned long long)(unsigned)(sad + mvc) << 32) | (unsigned)c;
+        best = key < best ? key : best;
+    }
+    for (int o = 1; o < 64; o <<= 1)
+    {
+        const unsigned long long other = __shfl_xor(best, o);
+        best = other < best ? other : best;
+    }
+    if ((tid & 63) == 0) red[tid >> 6] = best;
+    __syncthreads();
+    if (tid == 0)
+    {
+        for (int k = 1; k < CIME_THREADS / 64; k++) best = red[k] < best ? red[k] : best;
+        const int c = (int)(best & 0xffffffffu);
+        const int cy = c / nx, cx = c - cy * nx;
+        x265amd_rk_result &r = a.results[blockIdx.x];
+        r.cime.mv[0] = (int16_t)((x0 + cx) * 4);
+        r.cime.mv[1] = (int16_t)((y0 + cy) * 4);
+        r.cime.cost = (int)(best >> 32);
+    }
+}
+
+/* RIME + FME (motion.cpp:1305-1403): one wave per (CTU, CU). RIME scans three 16x12
+ * full-pel windows row by row (16 candidates per batched evaluation); FME scans the 7x7
+ * quarter-pel grid around the RIME winner, x offset outer, y inner. */
+template<typename P>
+__global__ __launch_bounds__(64) void rk_cu_kernel(RkArgs a)
+{
+    __shared__ WaveLds<P, 64> lds;
+    const int ctuIdx = blockIdx.x / 85, idx = blockIdx.x % 85;
+    const x265amd_rk_ctu &j = a.ctus[ctuIdx];
+    x265amd_rk_result &res = a.results[ctuIdx];
+    const int lane = threadIdx.x & 63;
+    int size, ox, oy;
+    if (idx < 64) { size = 8; ox = (idx & 7) * 8; oy = (idx >> 3) * 8; }
+    else if (idx < 80) { size = 16; ox = ((idx - 64) & 3) * 16; oy = ((idx - 64) >> 2) * 16; }
+    else if (idx < 84) { size = 32; ox = ((idx - 80) & 1) * 32; oy = ((idx - 80) >> 1) * 32; }
+    else { size = 64; ox = 0; oy = 0; }
+    if (j.ctu_x + ox + size > a.pic_w || j.ctu_y + oy + size > a.pic_h)
+    {
+        if (lane == 0)
+        {
+            res.rime[idx].mv[0] = res.rime[idx].mv[1] = 0; res.rime[idx].cost = -1;
+            res.fme[idx].mv[0] = res.fme[idx].mv[1] = 0; res.fme[idx].cost = -1;
+        }
+        return;
+    }
+    Searcher<P, 64, false> S;
+    S.bind(&lds, a.fenc, &a.recon, 1, a.ctab, a.depth, j.ctu_x + ox, j.ctu_y + oy, size, size);
+    S.nsad = S.nsub = 0;
+    S.mvpx = S.mvpy = 0;
+    S.rk_have_mvd = j.have_mvd;
+    for (int k = 0; k < 3; k++) { S.rk_mvp[k][0] = j.mvp[k][0]; S.rk_mvp[k][1] = j.mvp[k][1]; }
+    int pmv[3][2] = { { res.cime.mv[0], res.cime.mv[1] }, { j.pmv[0][0], j.pmv[0][1] }, { j.pmv[1][0], j.pmv[1][1] } };
+    int bcost = 0x7fffffff, bx = 0, by = 0;
+    for (int p = 0; p < 3; p++)
+        for (int i = -6; i < 6; i++)
+        {
+            for (int k = 0; k < 16; k++)
+            {
+                const int tx = as_i16(pmv[p][0] + k - 8), ty = as_i16(pmv[p][1] + i);
+                S.put(k, tx, ty, tx, ty, 16, 0);
+            }
+            S.eval(16, 0, true);
+            for (int k = 0; k < 16; k++)
+            {
+                const int c = S.cost_of(k);
+                if (c < bcost) { bcost = c; bx = uni(lds.mvx[k]); by = uni(lds.mvy[k]); }
+            }
+        }
+    if (lane == 0) { res.rime[idx].mv[0] = (int16_t)bx; res.rime[idx].mv[1] = (int16_t)by; res.rime[idx].cost = bcost; }
+    const int BX = as_i16(bx << 2), BY = as_i16(by << 2);
+    bcost = 0x7fffffff;
+    int fx = 0, fy = 0;
+    for (int c0 = 0; c0 < 49; c0 += MAXC)
+    {
+        const int n = 49 - c0 < MAXC ? 49 - c0 : MAXC;
+        for (int k = 0; k < n; k++)
+        {
+            const int c = c0 + k;
+            const int qx = as_i16(BX + c / 7 - 3), qy = as_i16(BY + c % 7 - 3);
+            S.put(k, qx, qy, qx, qy, 16, 0);
+        }
+        S.eval(n, 3, true);
+        for (int k = 0; k < n; k++)
+        {
+            const int c = S.cost_of(k);
+            if (c < bcost) { bcost = c; fx = uni(lds.mvx[k]); fy = uni(lds.mvy[k]); }
+        }
+    }
+    if (lane == 0) { res.fme[idx].mv[0] = (int16_t)fx; res.fme[idx].mv[1] = (int16_t)fy; res.fme[idx].cost = bcost; }
+}
+
 /* ---- per-call primitives (EncoderPrimitives mirror); operands are staged copies ---- */
 
 /* sad / satd / sa8d of up to 4 reference blocks against one source block.
@@ -527,6 +712,15 @@ int x265amd_plane_download(x265amd_ctx *c, const x265amd_plane *p, void *buf)
     return X265AMD_OK;
 }
 
+int x265amd_download(x265amd_ctx *c, const void *d_src, void *dst, size_t bytes)
+{
+    if (!c || !d_src || !dst) return fail(c, X265AMD_EINVAL, "null argument");
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipMemcpy(dst, d_src, bytes, hipMemcpyDeviceToHost));
+    return X265AMD_OK;
+}
+
 int x265amd_lowres_init(x265amd_ctx *c, const x265amd_plane *src, x265amd_plane out[4])
 {
     if (!c || !src || !src->origin || !out) return fail(c, X265AMD_EINVAL, "null plane");
@@ -794,6 +988,100 @@ int x265amd_lookahead_fields_dev(x265amd_ctx *c, const void *d_fields, int nfiel
     else
         hipLaunchKernelGGL(lookahead_kernel<uint16_t>, dim3(nfields), dim3(LA_WAVES * 64), 0, c->stream, a);
     HIPCHK(c, hipGetLastError());
+    return X265AMD_OK;
+}
+
+int x265amd_rk_ds_plane(x265amd_ctx *c, const x265amd_plane *orig, x265amd_plane *out)
+{
+    if (!c || !orig || !orig->origin || !out) return fail(c, X265AMD_EINVAL, "null plane");
+    if (orig->margin_x != orig->margin_y || (orig->margin_x & 3))
+        return fail(c, X265AMD_EINVAL, "RK downsampled plane needs equal margins that are multiples of 4");
+    const int w4 = orig->width / 4, h4 = orig->height / 4, m4 = orig->margin_x / 4;
+    const int stride = w4 + 2 * m4;
+    void *d = 0;
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipMalloc(&d, (size_t)(h4 + 2 * m4) * stride * sizeof(int16_t)));
+    int16_t *origin = (int16_t*)d + (size_t)m4 * stride + m4;
+    dim3 blk(64, 4), grd((w4 + 63) / 64, (h4 + 3) / 4), grd2((w4 + 2 * m4 + 63) / 64, (h4 + 2 * m4 + 3) / 4);
+    if (c->depth <= 8)
+        hipLaunchKernelGGL(rk_downsample_kernel<uint8_t>, grd, blk, 0, c->stream, (const uint8_t*)orig->origin, (long)orig->stride,
+                           origin, (long)stride, w4, h4);
+    else
+        hipLaunchKernelGGL(rk_downsample_kernel<uint16_t>, grd, blk, 0, c->stream, (const uint16_t*)orig->origin, (long)orig->stride,
+                           origin, (long)stride, w4, h4);
+    hipLaunchKernelGGL(extend_border_kernel<uint16_t>, grd2, blk, 0, c->stream, (uint16_t*)origin, (long)stride, w4, h4, m4, m4);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    out->origin = origin; out->stride = stride; out->width = w4; out->height = h4; out->margin_x = m4; out->margin_y = m4;
+    return X265AMD_OK;
+}
+
+int x265amd_rk_ctu_batch_dev(x265amd_ctx *c, const x265amd_plane *fenc, const x265amd_plane *recon, const x265amd_plane *ds,
+                             int qp, const x265amd_rk_ctu *d_ctus, int nctus, x265amd_rk_result *d_results)
+{
+    if (!c || !fenc || !recon || !ds || !d_ctus || !d_results || nctus < 0) return fail(c, X265AMD_EINVAL, "null argument");
+    int rc = x265amd_set_qp(c, qp);
+    if (rc) return rc;
+    if (!nctus) return X265AMD_OK;
+    HIPCHK(c, hipSetDevice(c->device));
+    RkArgs a;
+    a.fenc.origin = fenc->origin; a.fenc.stride = fenc->stride;
+    a.recon.origin = recon->origin; a.recon.stride = recon->stride;
+    a.ds = (const int16_t*)ds->origin; a.ds_stride = ds->stride;
+    a.pic_w = fenc->width; a.pic_h = fenc->height; a.depth = c->depth;
+    a.ctab = c->tables[qp] + 32768;
+    a.ctus = d_ctus; a.results = d_results; a.nctus = nctus;
+    /* window of the widest range the RK rules allow: (384/2/4*2 + 15) x (320/2/4*2 + 15) int16 */
+    const size_t lds = (256 + 111 * 95) * sizeof(int16_t);
+    if (c->depth <= 8)
+    {
+        hipLaunchKernelGGL(rk_cime_kernel<uint8_t>, dim3(nctus), dim3(CIME_THREADS), lds, c->stream, a);
+        hipLaunchKernelGGL(rk_cu_kernel<uint8_t>, dim3(nctus * 85), dim3(64), 0, c->stream, a);
+    }
+    else
+    {
+        hipLaunchKernelGGL(rk_cime_kernel<uint16_t>, dim3(nctus), dim3(CIME_THREADS), lds, c->stream, a);
+        hipLaunchKernelGGL(rk_cu_kernel<uint16_t>, dim3(nctus * 85), dim3(64), 0, c->stream, a);
+    }
+    HIPCHK(c, hipGetLastError());
+    return X265AMD_OK;
+}
+
+int x265amd_rk_ctu_batch(x265amd_ctx *c, const x265amd_plane *fenc, const x265amd_plane *recon, const x265amd_plane *ds,
+                         int qp, const x265amd_rk_ctu *ctus, int nctus, x265amd_rk_result *results)
+{
+    if (!c || !fenc || !recon || !ds || !ctus || !results || nctus < 0) return fail(c, X265AMD_EINVAL, "null argument");
+    for (int i = 0; i < nctus; i++)
+    {
+        const x265amd_rk_ctu &j = ctus[i];
+        if (j.ctu_x < 0 || j.ctu_y < 0 || (j.ctu_x & 63) || (j.ctu_y & 63) || j.ctu_x >= fenc->width || j.ctu_y >= fenc->height)
+            return fail(c, X265AMD_EINVAL, "rk ctu: origin is not a CTU position inside the picture");
+        if (j.valid_w < 8 || j.valid_w > 64 || j.valid_h < 8 || j.valid_h > 64 || (j.valid_w & 3) || (j.valid_h & 3))
+            return fail(c, X265AMD_EINVAL, "rk ctu: bad valid width / height");
+        if (j.mvmin[0] > j.mvmax[0] || j.mvmin[1] > j.mvmax[1] || j.mvmax[0] / 4 - j.mvmin[0] / 4 + 1 > 96 ||
+            j.mvmax[1] / 4 - j.mvmin[1] / 4 + 1 > 80)
+            return fail(c, X265AMD_EINVAL, "rk ctu: CIME range empty or wider than 96 x 80 downsampled positions");
+        /* CIME window inside the downsampled plane; RIME/FME windows inside the reconstructed plane */
+        if (j.ctu_x / 4 + j.mvmin[0] / 4 < -ds->margin_x || j.ctu_x / 4 + j.mvmax[0] / 4 + 16 > ds->width + ds->margin_x ||
+            j.ctu_y / 4 + j.mvmin[1] / 4 < -ds->margin_y || j.ctu_y / 4 + j.mvmax[1] / 4 + 16 > ds->height + ds->margin_y)
+            return fail(c, X265AMD_EINVAL, "rk ctu: CIME window leaves the downsampled plane");
+        int lo[2] = { j.mvmin[0], j.mvmin[1] }, hi[2] = { j.mvmax[0], j.mvmax[1] };
+        for (int k = 0; k < 2; k++)
+            for (int d = 0; d < 2; d++) { if (j.pmv[k][d] < lo[d]) lo[d] = j.pmv[k][d]; if (j.pmv[k][d] > hi[d]) hi[d] = j.pmv[k][d]; }
+        if (j.ctu_x + lo[0] - 8 - 6 < -recon->margin_x || j.ctu_x + 64 + hi[0] + 8 + 6 > recon->width + recon->margin_x ||
+            j.ctu_y + lo[1] - 6 - 6 < -recon->margin_y || j.ctu_y + 64 + hi[1] + 6 + 6 > recon->height + recon->margin_y)
+            return fail(c, X265AMD_EINVAL, "rk ctu: RIME / FME windows leave the padded reference plane");
+    }
+    if (!nctus) return X265AMD_OK;
+    int rc;
+    HIPCHK(c, hipSetDevice(c->device));
+    if ((rc = ensure(c, &c->d_jobs, &c->jobs_cap, (size_t)nctus * sizeof(x265amd_rk_ctu)))) return rc;
+    if ((rc = ensure(c, &c->d_results, &c->results_cap, (size_t)nctus * sizeof(x265amd_rk_result)))) return rc;
+    HIPCHK(c, hipMemcpyAsync(c->d_jobs, ctus, (size_t)nctus * sizeof(x265amd_rk_ctu), hipMemcpyHostToDevice, c->stream));
+    rc = x265amd_rk_ctu_batch_dev(c, fenc, recon, ds, qp, (const x265amd_rk_ctu*)c->d_jobs, nctus, (x265amd_rk_result*)c->d_results);
+    if (rc) return rc;
+    HIPCHK(c, hipMemcpyAsync(results, c->d_results, (size_t)nctus * sizeof(x265amd_rk_result), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
     return X265AMD_OK;
 }
 

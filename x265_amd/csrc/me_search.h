@@ -66,6 +66,7 @@ struct Searcher
     int mvpx, mvpy;
     int w, h, T, Tp, lTp, wt, inv_wt;
     int lane, depth;
+    int rk_mvp[3][2], rk_have_mvd; /* Rockchip path: three cost predictors (motion.cpp:1284-1292) */
     static constexpr bool is_lowres = LOWRES;
     unsigned nsad, nsub;
 
@@ -129,9 +130,15 @@ struct Searcher
         {
 #pragma unroll
             for (int y = 0; y < 4; y++) q[y] = Px<P>::load(r + y * rstride);
-            return tile_cost_quads<P>(f, q, satd);
+            return tile_cost_quads<P>(f, q, mode >= 2);
         }
         int o[4][4];
+        if (mode == 3)
+        {
+            /* Rockchip FME: 4-tap interpolation + SATD (motion.cpp:1453-1494) */
+            rk_interp_tile<P>(r, rstride, xf, yf, depth, o);
+            return tile_cost_px<P>(f, o, true);
+        }
         interp_tile<P>(r, rstride, xf, yf, depth, o);
         return tile_cost_px<P>(f, o, satd);
         }
@@ -168,7 +175,24 @@ struct Searcher
         if (addmv && lane < K)
         {
             const int s = L->sh[lane];
-            if (s & 8)
+            if (s & 16)
+            {
+                /* Rockchip stages: min over three predictors, each sum truncated to uint16 */
+                int best = 0;
+                if (rk_have_mvd)
+                {
+                    best = 0x7fffffff;
+                    const int x = L->mvx[lane], y = L->mvy[lane];
+#pragma unroll
+                    for (int k = 0; k < 3; k++)
+                    {
+                        const int c = ((int)ctab[x - rk_mvp[k][0]] + (int)ctab[y - rk_mvp[k][1]]) & 0xffff;
+                        best = c < best ? c : best;
+                    }
+                }
+                L->costs[lane] += best;
+            }
+            else if (s & 8)
                 /* UMH hexagon grid: table entries added as ints, MV * 4 without the int16 wrap
                  * (ADD_MVCOST, motion.cpp:856) */
                 L->costs[lane] += (int)ctab[L->mvx[lane] * 4 - mvpx] + (int)ctab[L->mvy[lane] * 4 - mvpy];

@@ -29,6 +29,13 @@ JOB_DTYPE = np.dtype([("pu_x", "<i2"), ("pu_y", "<i2"), ("w", "u1"), ("h", "u1")
                       ("mvc", "<i2", (4, 2)), ("merange", "<i4")], align=True)
 RESULT_DTYPE = np.dtype([("mv", "<i2", (2,)), ("cost", "<i4"), ("sad_calls", "<u4"), ("subpel_calls", "<u4")], align=True)
 assert JOB_DTYPE.itemsize == 40 and RESULT_DTYPE.itemsize == 16
+# x265amd_rk_ctu / x265amd_rk_result
+RK_CTU_DTYPE = np.dtype([("ctu_x", "<i2"), ("ctu_y", "<i2"), ("valid_w", "<i2"), ("valid_h", "<i2"),
+                         ("mvmin", "<i2", (2,)), ("mvmax", "<i2", (2,)), ("pmv", "<i2", (2, 2)), ("mvp", "<i2", (3, 2)),
+                         ("have_mvd", "u1"), ("reserved", "u1", (3,))], align=True)
+RK_MV_DTYPE = np.dtype([("mv", "<i2", (2,)), ("cost", "<i4")], align=True)
+RK_RESULT_DTYPE = np.dtype([("cime", RK_MV_DTYPE), ("rime", RK_MV_DTYPE, (85,)), ("fme", RK_MV_DTYPE, (85,))], align=True)
+assert RK_CTU_DTYPE.itemsize == 40 and RK_RESULT_DTYPE.itemsize == 171 * 8
 
 
 class Plane(C.Structure):
@@ -198,6 +205,31 @@ class Engine:
         self._chk(self.L.x265amd_lookahead_fields_dev(self.ctx, d_fields, nfields, wcu, hcu, qp, method, subme, merange,
                                                       C.c_void_p(d_mvs), C.c_void_p(d_costs),
                                                       C.c_void_p(d_stats) if d_stats else None))
+
+    # ---- Rockchip path
+    def rk_ds_plane(self, orig):
+        out = Plane()
+        self._chk(self.L.x265amd_rk_ds_plane(self.ctx, C.byref(orig), C.byref(out)))
+        return out
+
+    def rk_ctu_batch(self, fenc, recon, ds, qp, ctus):
+        ctus = np.ascontiguousarray(ctus, RK_CTU_DTYPE)
+        res = np.zeros(len(ctus), RK_RESULT_DTYPE)
+        self._chk(self.L.x265amd_rk_ctu_batch(self.ctx, C.byref(fenc), C.byref(recon), C.byref(ds), qp,
+                                              C.c_void_p(ctus.ctypes.data), len(ctus), C.c_void_p(res.ctypes.data)))
+        return res
+
+    def rk_ctu_batch_dev(self, fenc, recon, ds, qp, d_ctus, nctus, d_results):
+        self._chk(self.L.x265amd_rk_ctu_batch_dev(self.ctx, C.byref(fenc), C.byref(recon), C.byref(ds), qp,
+                                                  C.c_void_p(d_ctus), nctus, C.c_void_p(d_results)))
+
+    def download_ds_plane(self, p):
+        """int16 plane of x265amd_rk_ds_plane incl. margins, as (rows, stride)."""
+        n = (p.height + 2 * p.margin_y) * p.stride
+        out = np.zeros(n, np.int16)
+        base = p.origin - (p.margin_y * p.stride + p.margin_x) * 2
+        self._chk(self.L.x265amd_download(self.ctx, C.c_void_p(base), C.c_void_p(out.ctypes.data), C.c_size_t(n * 2)))
+        return out.reshape(-1, p.stride)
 
     def primitives(self):
         p = Primitives()

@@ -57,3 +57,60 @@ def pixel_sads(jobs, results):
     """Pixel-SADs actually evaluated: (full-pel + sub-pel candidates visited) x PU area."""
     area = jobs["w"].astype(np.int64) * jobs["h"].astype(np.int64)
     return int(((results["sad_calls"].astype(np.int64) + results["subpel_calls"].astype(np.int64)) * area).sum())
+
+
+# ---------------------------------------------------------------- Rockchip path
+
+def rk_merange(pic_w, pic_h, me_range_x=384, me_range_y=320):
+    """Effective RK search range for a picture size (TEncSearch.cpp:3717-3742)."""
+    mx = min(384, me_range_x // 4 * 4)
+    my = min(320, me_range_y // 4 * 4)
+    if pic_w < mx + 60 or pic_w <= 352:
+        mx = min(pic_w, mx) // 4 * 2
+    if pic_h < my + 60 or pic_h <= 288:
+        my = min(pic_h, my) // 4 * 2
+    return mx, my
+
+
+def _tdiv(a, b):
+    """C integer division (truncation toward zero)."""
+    q = abs(a) // abs(b)
+    return q if (a < 0) == (b < 0) else -q
+
+
+def rk_search_range(pic_w, pic_h, cu_x, cu_y, merange_x, merange_y, search_range=208, ctu=64):
+    """xSetSearchRange of the RK build with mvp = (0, 0) (TEncSearch.cpp:4188-4215, clipMv
+    TComDataCU.cpp:3386-3410); note mvmax is derived from the already updated mvmin."""
+    def clip(v, lo, hi):
+        return min(hi, max(lo, v))
+    xmax, xmin = (pic_w + search_range - cu_x) << 2, (-ctu - search_range - cu_x) << 2
+    ymax, ymin = (pic_h + search_range - cu_y) << 2, (-ctu - search_range - cu_y) << 2
+    dx, dy = (merange_x // 2) << 2, (merange_y // 2) << 2
+    mnx, mny = clip(-dx, xmin, xmax) >> 2, clip(-dy, ymin, ymax) >> 2
+    mxx, mxy = clip(dx - 4, xmin, xmax) >> 2, clip(dy - 4, ymin, ymax) >> 2
+    mnx, mny, mxx, mxy = _tdiv(mnx, 4), _tdiv(mny, 4), _tdiv(mxx, 4), _tdiv(mxy, 4)
+    mnx = -min(abs(mnx), mxx) * 4
+    mny = -min(abs(mny), mxy) * 4
+    mxx = (min(abs(mnx), mxx) - 1) * 4
+    mxy = (min(abs(mny), mxy) - 1) * 4
+    return (mnx, mny), (mxx, mxy)
+
+
+def rk_ctu_jobs(pic_w, pic_h, pmvs, mvps, have_mvd=True, me_range=(384, 320), dtype=None):
+    """One job per 64x64 CTU in raster order. pmvs: (nctu, 2, 2) even full-pel neighbour PMVs
+    (RIME window centres 1 and 2); mvps: (nctu, 3, 2) cost predictors (TEncSearch.cpp:3788-3805)."""
+    from .engine import RK_CTU_DTYPE
+    ncx, ncy = (pic_w + 63) // 64, (pic_h + 63) // 64
+    jobs = np.zeros(ncx * ncy, dtype or RK_CTU_DTYPE)
+    mx, my = rk_merange(pic_w, pic_h, *me_range)
+    for cy in range(ncy):
+        for cx in range(ncx):
+            j = jobs[cy * ncx + cx]
+            j["ctu_x"], j["ctu_y"] = cx * 64, cy * 64
+            j["valid_w"] = min(64, pic_w - cx * 64)
+            j["valid_h"] = min(64, pic_h - cy * 64)
+            j["mvmin"], j["mvmax"] = rk_search_range(pic_w, pic_h, cx * 64, cy * 64, mx, my)
+            j["pmv"] = pmvs[cy * ncx + cx]
+            j["mvp"] = mvps[cy * ncx + cx]
+            j["have_mvd"] = int(have_mvd)
+    return jobs
