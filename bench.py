@@ -42,6 +42,9 @@ def main():
     ap.add_argument("--pairs", type=int, default=4, help="frame pairs per GPU per step")
     ap.add_argument("--cpu-sample", type=int, default=4000, help="jobs timed on the host CPU (0 = skip)")
     ap.add_argument("--method", default="star")
+    ap.add_argument("--no-window", action="store_true", help="do not stage reference windows in LDS")
+    ap.add_argument("--window-cap", type=int, default=48 * 1024, help="max LDS bytes per PU for the staged window")
+    ap.add_argument("--per-size", action="store_true", help="one search launch per PU size instead of one per frame")
     args = ap.parse_args()
 
     import torch
@@ -77,9 +80,15 @@ def main():
     la_pixel_sads = int((la_stats["sad_calls"].astype(np.int64) + la_stats["subpel_calls"]).sum()) * 64
 
     host_jobs, d_jobs, d_res = [], [], []
+    segs = None     # per PU size: (first job, count, LDS bytes to stage the largest window)
     for i in range(B):
         jobs = workload.square_pu_jobs(W, H, la_mvs[i], wcu, hcu, MERANGE)
         host_jobs.append(jobs)
+        if segs is None:
+            segs = []
+            for s_ in ((64, 32, 16, 8) if args.per_size else (0,)):
+                idx = np.flatnonzero(jobs["w"] == s_) if s_ else np.arange(len(jobs))
+                segs.append((int(idx[0]), len(idx), 0 if args.no_window else min(es.window_bytes(jobs[idx]), args.window_cap)))
         d_jobs.append(torch.from_numpy(jobs.view(np.uint8).reshape(len(jobs), -1).copy()).to(dev))
         d_res.append(torch.zeros((len(jobs), RESULT_DTYPE.itemsize), dtype=torch.uint8, device=dev))
     njobs = len(host_jobs[0])
@@ -98,8 +107,9 @@ def main():
         if k is not None:
             ev0[k].record(s_search)
         for i in range(B):
-            es.search_batch_dev(planes[i + 1], planes[i], d_jobs[i].data_ptr(), njobs, d_res[i].data_ptr(),
-                                QP, method, SUBME)
+            for (first, cnt, win) in segs:
+                es.search_batch_dev(planes[i + 1], planes[i], d_jobs[i].data_ptr() + first * 40, cnt,
+                                    d_res[i].data_ptr() + first * 16, QP, method, SUBME, window_bytes=win)
         if k is not None:
             ev1[k].record(s_search)
         es.sync()
@@ -180,7 +190,7 @@ def main():
                        "qp": QP, "parallelism": "frame pairs sharded over %d GPU(s), gather of MV records" % world},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": "search_kernel<uint8_t,false>", "launch_ms": search_ms,
+                         "kernel": "search_kernel<uint8_t,false> (%d launch(es) per frame)" % len(segs), "launch_ms": search_ms,
                          "algorithmic_bytes_per_launch": alg_bytes},
             "cpu_baseline": cpu,
             "fps_equiv": B * args.steps * world / elapsed,

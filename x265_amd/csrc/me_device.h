@@ -19,6 +19,11 @@
 
 namespace x265amd {
 
+/* All LDS of the ME kernels is carved from this one dynamic array, addressed by byte
+ * offset, so every access is visibly an LDS access (ds_* instructions, not flat). */
+extern __shared__ __attribute__((aligned(16))) unsigned char x265amd_smem[];
+#define AS1 __attribute__((address_space(1)))
+
 /* HEVC luma taps, source/Lib/TLibCommon/TComRom.cpp:175-181 */
 __constant__ static const int16_t kLumaTaps[4][8] = {
     {  0, 0,   0, 64,  0,   0, 0,  0 },
@@ -52,6 +57,19 @@ template<> struct Px<uint8_t>
         return *(const u32u*)p;
     }
     static __device__ __forceinline__ quad load_aligned(const uint8_t *p) { return *(const uint32_t*)p; }
+    static __device__ __forceinline__ quad load_g(const uint8_t AS1 *p)
+    {
+        typedef uint32_t __attribute__((aligned(1))) u32u;
+        return *(const u32u AS1*)p;
+    }
+    /* 4 pixels at an arbitrary byte offset of the LDS array: two aligned dwords + v_alignbyte */
+    static __device__ __forceinline__ quad load_lds(int byteoff)
+    {
+        const uint32_t *q = (const uint32_t*)(x265amd_smem + (byteoff & ~3));
+        return __builtin_amdgcn_alignbyte(q[1], q[0], (uint32_t)(byteoff & 3));
+    }
+    static __device__ __forceinline__ quad load_lds_aligned(int byteoff) { return *(const uint32_t*)(x265amd_smem + byteoff); }
+    static __device__ __forceinline__ void store_lds_aligned(int byteoff, quad v) { *(uint32_t*)(x265amd_smem + byteoff) = v; }
     static __device__ __forceinline__ int sad(quad a, quad b, int acc) { return (int)__builtin_amdgcn_sad_u8(a, b, (uint32_t)acc); }
     static __device__ __forceinline__ void unpack(quad q, int v[4])
     {
@@ -71,6 +89,22 @@ template<> struct Px<uint16_t>
         return make_uint2(q[0], q[1]);
     }
     static __device__ __forceinline__ quad load_aligned(const uint16_t *p) { return *(const uint2*)p; }
+    static __device__ __forceinline__ quad load_g(const uint16_t AS1 *p)
+    {
+        typedef uint32_t __attribute__((aligned(2))) u32u;
+        const u32u AS1 *q = (const u32u AS1*)p;
+        return make_uint2(q[0], q[1]);
+    }
+    /* 4 pixels (8 bytes) at a 2-byte aligned offset: three aligned dwords + v_alignbit */
+    static __device__ __forceinline__ quad load_lds(int byteoff)
+    {
+        const uint32_t *q = (const uint32_t*)(x265amd_smem + (byteoff & ~3));
+        const uint32_t s = (byteoff & 2) * 8;
+        const uint32_t lo = q[0], mid = q[1], hi = q[2];
+        return make_uint2(__builtin_amdgcn_alignbit(mid, lo, s), __builtin_amdgcn_alignbit(hi, mid, s));
+    }
+    static __device__ __forceinline__ quad load_lds_aligned(int byteoff) { return *(const uint2*)(x265amd_smem + byteoff); }
+    static __device__ __forceinline__ void store_lds_aligned(int byteoff, quad v) { *(uint2*)(x265amd_smem + byteoff) = v; }
     static __device__ __forceinline__ int sad(quad a, quad b, int acc)
     {
         return (int)__builtin_amdgcn_sad_u16(a.y, b.y, __builtin_amdgcn_sad_u16(a.x, b.x, (uint32_t)acc));
@@ -82,6 +116,25 @@ template<> struct Px<uint16_t>
     static __device__ __forceinline__ quad avg(quad a, quad b)
     {
         return make_uint2((a.x | b.x) - (((a.x ^ b.x) >> 1) & 0x7fff7fffu), (a.y | b.y) - (((a.y ^ b.y) >> 1) & 0x7fff7fffu));
+    }
+};
+
+/* 4-pixel loads relative to a tile origin, from the staged LDS window or from global memory */
+template<typename P> struct LdsLoader
+{
+    int base, stride; /* byte offset of the tile origin in the LDS array; row pitch in samples */
+    __device__ __forceinline__ typename Px<P>::quad operator()(int dx, int dy) const
+    {
+        return Px<P>::load_lds(base + (dy * stride + dx) * (int)sizeof(P));
+    }
+};
+template<typename P> struct GlobalLoader
+{
+    const P AS1 *p;
+    int stride;
+    __device__ __forceinline__ typename Px<P>::quad operator()(int dx, int dy) const
+    {
+        return Px<P>::load_g(p + (long)dy * stride + dx);
     }
 };
 
@@ -123,102 +176,87 @@ __device__ __forceinline__ int as_i16(int v) { return (int)(int16_t)v; }
  *   xf == 0 : luma_vpp                                           ipfilter.cpp:280-319
  *   else    : luma_hps(isRowExt) into int16, then luma_vsp       ipfilter.cpp:235-278, :359-400
  *             exactly as subpelCompare chains them (motion.cpp:1681-1685) */
-template<typename P>
-__device__ __forceinline__ void interp_tile(const P *r, int stride, int xf, int yf, int depth, int o[4][4])
+template<typename P, class LD>
+__device__ __forceinline__ void interp_tile(const LD &ld, int xf, int yf, int depth, int o[4][4])
 {
-    /* Rows are streamed: each loaded reference row is filtered horizontally (if xf)
-     * and immediately scattered into the (up to 4) output rows whose vertical
-     * footprint contains it, so only the 16 accumulators and one row stay live. */
     const int maxv = (1 << depth) - 1;
+    int ch[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) ch[k] = kLumaTaps[xf][k];
     if (yf == 0)
     {
-        int c[8];
-#pragma unroll
-        for (int k = 0; k < 8; k++) c[k] = kLumaTaps[xf][k];
 #pragma unroll
         for (int y = 0; y < 4; y++)
         {
             int px[12];
-            const P *row = r + y * stride - 3;
-            Px<P>::unpack(Px<P>::load(row), px);
-            Px<P>::unpack(Px<P>::load(row + 4), px + 4);
-            Px<P>::unpack(Px<P>::load(row + 8), px + 8);
+            Px<P>::unpack(ld(-3, y), px);
+            Px<P>::unpack(ld(1, y), px + 4);
+            Px<P>::unpack(ld(5, y), px + 8);
 #pragma unroll
             for (int x = 0; x < 4; x++)
             {
                 int sum = 0;
 #pragma unroll
-                for (int k = 0; k < 8; k++) sum += px[x + k] * c[k];
+                for (int k = 0; k < 8; k++) sum += px[x + k] * ch[k];
                 o[y][x] = clip_pixel(as_i16((sum + 32) >> 6), maxv);
             }
         }
         return;
     }
+    /* Vertical and 2-D phases: reference rows -3 .. 7 stream through an 8-row shift register
+     * (horizontally filtered first when xf != 0); rows are primed in a rolled loop so the code
+     * stays small and only one row of loads is in flight. */
     int cv[8];
 #pragma unroll
     for (int k = 0; k < 8; k++) cv[k] = kLumaTaps[yf][k];
-    int acc[4][4];
+    const int headRoom = 14 - depth;
+    const int shiftH = 6 - headRoom, offH = -(8192 << shiftH);
+    const int shiftV = 6 + headRoom, offV = (1 << (shiftV - 1)) + (8192 << 6);
+    int win[8][4];
+#pragma unroll
+    for (int k = 0; k < 8; k++)
+#pragma unroll
+        for (int x = 0; x < 4; x++) win[k][x] = 0;
+    auto feed = [&](int row)
+    {
+#pragma unroll
+        for (int k = 0; k < 7; k++)
+#pragma unroll
+            for (int x = 0; x < 4; x++) win[k][x] = win[k + 1][x];
+        if (xf == 0)
+            Px<P>::unpack(ld(0, row), win[7]);
+        else
+        {
+            int px[12];
+            Px<P>::unpack(ld(-3, row), px);
+            Px<P>::unpack(ld(1, row), px + 4);
+            Px<P>::unpack(ld(5, row), px + 8);
+#pragma unroll
+            for (int x = 0; x < 4; x++)
+            {
+                int sum = 0;
+#pragma unroll
+                for (int k = 0; k < 8; k++) sum += px[x + k] * ch[k];
+                win[7][x] = as_i16((sum + offH) >> shiftH);
+            }
+        }
+    };
+#pragma unroll 1
+    for (int rr = -3; rr < 4; rr++) feed(rr);
 #pragma unroll
     for (int y = 0; y < 4; y++)
-#pragma unroll
-        for (int x = 0; x < 4; x++) acc[y][x] = 0;
-    if (xf == 0)
     {
-#pragma unroll
-        for (int rr = 0; rr < 11; rr++)
-        {
-            int v[4];
-            Px<P>::unpack(Px<P>::load(r + (rr - 3) * stride), v);
-#pragma unroll
-            for (int y = 0; y < 4; y++)
-                if (rr - y >= 0 && rr - y < 8)
-                {
-#pragma unroll
-                    for (int x = 0; x < 4; x++) acc[y][x] += v[x] * cv[rr - y];
-                }
-        }
-#pragma unroll
-        for (int y = 0; y < 4; y++)
-#pragma unroll
-            for (int x = 0; x < 4; x++) o[y][x] = clip_pixel(as_i16((acc[y][x] + 32) >> 6), maxv);
-        return;
-    }
-    int ch[8];
-#pragma unroll
-    for (int k = 0; k < 8; k++) ch[k] = kLumaTaps[xf][k];
-    const int headRoom = 14 - depth;
-    const int shiftH = 6 - headRoom;
-    const int offH = -(8192 << shiftH);
-    const int shiftV = 6 + headRoom;
-    const int offV = (1 << (shiftV - 1)) + (8192 << 6);
-#pragma unroll
-    for (int rr = 0; rr < 11; rr++)
-    {
-        int px[12], im[4];
-        const P *row = r + (rr - 3) * stride - 3;
-        Px<P>::unpack(Px<P>::load(row), px);
-        Px<P>::unpack(Px<P>::load(row + 4), px + 4);
-        Px<P>::unpack(Px<P>::load(row + 8), px + 8);
+        feed(y + 4);
 #pragma unroll
         for (int x = 0; x < 4; x++)
         {
             int sum = 0;
 #pragma unroll
-            for (int k = 0; k < 8; k++) sum += px[x + k] * ch[k];
-            im[x] = as_i16((sum + offH) >> shiftH);
+            for (int k = 0; k < 8; k++) sum += win[k][x] * cv[k];
+            o[y][x] = xf == 0 ? clip_pixel(as_i16((sum + 32) >> 6), maxv)
+                              : clip_pixel(as_i16((sum + offV) >> shiftV), maxv);
         }
-#pragma unroll
-        for (int y = 0; y < 4; y++)
-            if (rr - y >= 0 && rr - y < 8)
-            {
-#pragma unroll
-                for (int x = 0; x < 4; x++) acc[y][x] += im[x] * cv[rr - y];
-            }
     }
-#pragma unroll
-    for (int y = 0; y < 4; y++)
-#pragma unroll
-        for (int x = 0; x < 4; x++) o[y][x] = clip_pixel(as_i16((acc[y][x] + offV) >> shiftV), maxv);
 }
 
 /* 4-tap kernels of the Rockchip fractional search: g_chromaFilter[frac * 2]
@@ -227,21 +265,24 @@ __constant__ static const int16_t kRkTaps[4][4] = { { 0, 64, 0, 0 }, { -4, 54, 1
 
 /* RK flavour of interp_tile: InterpHoriz / InterpVert / FilterHorizontal + FilterVertical
  * with N = 4 (motion.cpp:1495-1648), phase (xf, yf) != (0, 0) */
-template<typename P>
-__device__ __forceinline__ void rk_interp_tile(const P *r, int stride, int xf, int yf, int depth, int o[4][4])
+template<typename P, class LD>
+__device__ __forceinline__ void rk_interp_tile(const LD &ld, int xf, int yf, int depth, int o[4][4])
 {
     const int maxv = (1 << depth) - 1;
     int ch[4], cv[4];
 #pragma unroll
     for (int k = 0; k < 4; k++) { ch[k] = kRkTaps[xf][k]; cv[k] = kRkTaps[yf][k]; }
+    const int headRoom = 14 - depth;
+    const int shiftH = 6 - headRoom, offH = -(8192 << shiftH);
+    const int shiftV = 6 + headRoom, offV = (1 << (shiftV - 1)) + (8192 << 6);
     if (yf == 0)
     {
 #pragma unroll
         for (int y = 0; y < 4; y++)
         {
             int px[8];
-            Px<P>::unpack(Px<P>::load(r + y * stride - 1), px);
-            Px<P>::unpack(Px<P>::load(r + y * stride + 3), px + 4);
+            Px<P>::unpack(ld(-1, y), px);
+            Px<P>::unpack(ld(3, y), px + 4);
 #pragma unroll
             for (int x = 0; x < 4; x++)
             {
@@ -251,43 +292,43 @@ __device__ __forceinline__ void rk_interp_tile(const P *r, int stride, int xf, i
         }
         return;
     }
-    int acc[4][4];
+    int win[4][4];
 #pragma unroll
-    for (int y = 0; y < 4; y++)
+    for (int k = 0; k < 4; k++)
 #pragma unroll
-        for (int x = 0; x < 4; x++) acc[y][x] = 0;
-    const int headRoom = 14 - depth;
-    const int shiftH = 6 - headRoom, offH = -(8192 << shiftH);
-    const int shiftV = 6 + headRoom, offV = (1 << (shiftV - 1)) + (8192 << 6);
-#pragma unroll
-    for (int rr = 0; rr < 7; rr++)
+        for (int x = 0; x < 4; x++) win[k][x] = 0;
+    auto feed = [&](int row)
     {
-        int v[4];
+#pragma unroll
+        for (int k = 0; k < 3; k++)
+#pragma unroll
+            for (int x = 0; x < 4; x++) win[k][x] = win[k + 1][x];
         if (xf == 0)
-            Px<P>::unpack(Px<P>::load(r + (rr - 1) * stride), v);
+            Px<P>::unpack(ld(0, row), win[3]);
         else
         {
             int px[8];
-            Px<P>::unpack(Px<P>::load(r + (rr - 1) * stride - 1), px);
-            Px<P>::unpack(Px<P>::load(r + (rr - 1) * stride + 3), px + 4);
+            Px<P>::unpack(ld(-1, row), px);
+            Px<P>::unpack(ld(3, row), px + 4);
 #pragma unroll
             for (int x = 0; x < 4; x++)
-                v[x] = as_i16((px[x] * ch[0] + px[x + 1] * ch[1] + px[x + 2] * ch[2] + px[x + 3] * ch[3] + offH) >> shiftH);
+                win[3][x] = as_i16((px[x] * ch[0] + px[x + 1] * ch[1] + px[x + 2] * ch[2] + px[x + 3] * ch[3] + offH) >> shiftH);
         }
-#pragma unroll
-        for (int y = 0; y < 4; y++)
-            if (rr - y >= 0 && rr - y < 4)
-            {
-#pragma unroll
-                for (int x = 0; x < 4; x++) acc[y][x] += v[x] * cv[rr - y];
-            }
-    }
+    };
+#pragma unroll 1
+    for (int rr = -1; rr < 2; rr++) feed(rr);
 #pragma unroll
     for (int y = 0; y < 4; y++)
+    {
+        feed(y + 2);
 #pragma unroll
         for (int x = 0; x < 4; x++)
-            o[y][x] = xf == 0 ? clip_pixel(as_i16((acc[y][x] + 32) >> 6), maxv)
-                              : clip_pixel(as_i16((acc[y][x] + offV) >> shiftV), maxv);
+        {
+            const int sum = win[0][x] * cv[0] + win[1][x] * cv[1] + win[2][x] * cv[2] + win[3][x] * cv[3];
+            o[y][x] = xf == 0 ? clip_pixel(as_i16((sum + 32) >> 6), maxv)
+                              : clip_pixel(as_i16((sum + offV) >> shiftV), maxv);
+        }
+    }
 }
 
 /* cost of one tile given the 4 packed source rows and 16 predicted pixels */

@@ -34,17 +34,24 @@ struct SearchArgs
     const x265amd_job *jobs;
     x265amd_result *results;
     int njobs;
+    int win_cap;   /* bytes of LDS available for the staged reference window */
 };
 
 template<typename P, bool LOWRES>
 __global__ __launch_bounds__(64) void search_kernel(SearchArgs a)
 {
-    __shared__ WaveLds<P, LOWRES ? 8 : 64> lds;
     const int j = xcd_remap(blockIdx.x, a.njobs);
     if (j >= a.njobs) return;
     const x265amd_job *job = a.jobs + j;
     Searcher<P, LOWRES ? 8 : 64, LOWRES> S;
-    S.bind(&lds, a.fenc, a.ref, a.nref, a.ctab, a.depth, job->pu_x, job->pu_y, job->w, job->h);
+    /* window: every full-pel candidate in [mvmin - 3, mvmax + 3] (hexagon / square steps are
+     * unchecked) plus the 8-tap footprint of the sub-pel points around them */
+    const int w = job->w, h = job->h;
+    if (LOWRES)
+        S.bind(0, a.fenc, a.ref, a.nref, a.ctab, a.depth, job->pu_x, job->pu_y, w, h);
+    else
+        S.bind(0, a.fenc, a.ref, a.nref, a.ctab, a.depth, job->pu_x, job->pu_y, w, h,
+               job->mvmin[0] - 8, job->mvmin[1] - 8, job->mvmax[0] + w + 8, job->mvmax[1] + h + 8, a.win_cap);
     S.search(job, a.method, a.subme, a.results + j);
 }
 
@@ -52,15 +59,15 @@ __global__ __launch_bounds__(64) void search_kernel(SearchArgs a)
 template<typename P>
 __global__ __launch_bounds__(64) void subpel_compare_kernel(SearchArgs a, int cmp)
 {
-    __shared__ WaveLds<P, 64> lds;
     const int j = blockIdx.x;
     if (j >= a.njobs) return;
     const x265amd_job *job = a.jobs + j;
     Searcher<P, 64> S;
-    S.bind(&lds, a.fenc, a.ref, a.nref, a.ctab, a.depth, job->pu_x, job->pu_y, job->w, job->h);
+    S.bind(0, a.fenc, a.ref, a.nref, a.ctab, a.depth, job->pu_x, job->pu_y, job->w, job->h);
     S.nsad = S.nsub = 0;
-    S.mvpx = S.mvpy = 0;
-    const int c = S.qdist(job->qmvp[0], job->qmvp[1], cmp ? 2 : 1);
+    S.put(0, job->qmvp[0], job->qmvp[1], job->qmvp[0], job->qmvp[1], 0, 0);
+    S.eval(1, cmp ? 2 : 1, false);
+    const int c = S.cost_of(0);
     if ((threadIdx.x & 63) == 0)
     {
         a.results[j].mv[0] = job->qmvp[0]; a.results[j].mv[1] = job->qmvp[1];
@@ -99,7 +106,6 @@ __device__ __forceinline__ int median3(int a, int b, int c)
 template<typename P>
 __global__ __launch_bounds__(LA_WAVES * 64) void lookahead_kernel(LookaheadArgs a)
 {
-    __shared__ WaveLds<P, 8> lds[LA_WAVES];
     __shared__ x265amd_job jobs[LA_WAVES];
     __shared__ x265amd_result results[LA_WAVES];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -154,7 +160,7 @@ __global__ __launch_bounds__(LA_WAVES * 64) void lookahead_kernel(LookaheadArgs 
             }
             wave_sync();
             Searcher<P, 8, true> S;
-            S.bind(&lds[wave], f.fenc, f.ref, 4, a.ctab, a.depth, cux * 8, cuy * 8, 8, 8);
+            S.bind(wave * wave_lds_bytes<P>(8), f.fenc, f.ref, 4, a.ctab, a.depth, cux * 8, cuy * 8, 8, 8);
             S.search(job, a.method, a.subme, &results[wave]);
             wave_sync();
             if (lane == 0)
@@ -317,7 +323,6 @@ __global__ __launch_bounds__(CIME_THREADS) void rk_cime_kernel(RkArgs a)
 template<typename P>
 __global__ __launch_bounds__(64) void rk_cu_kernel(RkArgs a)
 {
-    __shared__ WaveLds<P, 64> lds;
     const int ctuIdx = blockIdx.x / 85, idx = blockIdx.x % 85;
     const x265amd_rk_ctu &j = a.ctus[ctuIdx];
     x265amd_rk_result &res = a.results[ctuIdx];
@@ -336,12 +341,10 @@ __global__ __launch_bounds__(64) void rk_cu_kernel(RkArgs a)
         }
         return;
     }
-    Searcher<P, 64, false> S;
-    S.bind(&lds, a.fenc, &a.recon, 1, a.ctab, a.depth, j.ctu_x + ox, j.ctu_y + oy, size, size);
+    Searcher<P, 64, false, true> S;
+    S.bind(0, a.fenc, &a.recon, 1, a.ctab, a.depth, j.ctu_x + ox, j.ctu_y + oy, size, size);
     S.nsad = S.nsub = 0;
-    S.mvpx = S.mvpy = 0;
-    S.rk_have_mvd = j.have_mvd;
-    for (int k = 0; k < 3; k++) { S.rk_mvp[k][0] = j.mvp[k][0]; S.rk_mvp[k][1] = j.mvp[k][1]; }
+    S.set_rk_predictors(j.mvp, j.have_mvd);
     int pmv[3][2] = { { res.cime.mv[0], res.cime.mv[1] }, { j.pmv[0][0], j.pmv[0][1] }, { j.pmv[1][0], j.pmv[1][1] } };
     int bcost = 0x7fffffff, bx = 0, by = 0;
     for (int p = 0; p < 3; p++)
@@ -356,7 +359,7 @@ __global__ __launch_bounds__(64) void rk_cu_kernel(RkArgs a)
             for (int k = 0; k < 16; k++)
             {
                 const int c = S.cost_of(k);
-                if (c < bcost) { bcost = c; bx = uni(lds.mvx[k]); by = uni(lds.mvy[k]); }
+                if (c < bcost) { bcost = c; bx = S.mvx_of(k); by = S.mvy_of(k); }
             }
         }
     if (lane == 0) { res.rime[idx].mv[0] = (int16_t)bx; res.rime[idx].mv[1] = (int16_t)by; res.rime[idx].cost = bcost; }
@@ -376,7 +379,7 @@ __global__ __launch_bounds__(64) void rk_cu_kernel(RkArgs a)
         for (int k = 0; k < n; k++)
         {
             const int c = S.cost_of(k);
-            if (c < bcost) { bcost = c; fx = uni(lds.mvx[k]); fy = uni(lds.mvy[k]); }
+            if (c < bcost) { bcost = c; fx = S.mvx_of(k); fy = S.mvy_of(k); }
         }
     }
     if (lane == 0) { res.fme[idx].mv[0] = (int16_t)fx; res.fme[idx].mv[1] = (int16_t)fy; res.fme[idx].cost = bcost; }
@@ -577,6 +580,12 @@ static int ensure(x265amd_ctx *c, void **p, size_t *cap, size_t need)
     return 0;
 }
 
+template<typename K>
+static hipError_t allow_big_lds(K kernel)
+{
+    return hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+}
+
 extern "C" {
 
 int x265amd_partition_from_sizes(int w, int h)
@@ -672,7 +681,8 @@ static int plane_alloc(x265amd_ctx *c, int width, int height, int mx, int my, in
     const int bpp = c->depth > 8 ? 2 : 1;
     void *d = 0;
     HIPCHK(c, hipSetDevice(c->device));
-    HIPCHK(c, hipMalloc(&d, plane_bytes(c, height, my, stride)));
+    /* + slack: window staging reads whole 16-byte chunks and may run past the last row */
+    HIPCHK(c, hipMalloc(&d, plane_bytes(c, height, my, stride) + 256));
     out->origin = (char*)d + ((size_t)my * stride + mx) * bpp;
     out->stride = stride; out->width = width; out->height = height; out->margin_x = mx; out->margin_y = my;
     return X265AMD_OK;
@@ -807,12 +817,24 @@ static void fill_args(x265amd_ctx *c, SearchArgs &a, const x265amd_plane *fenc, 
         const x265amd_plane *r = &ref[i < a.nref ? i : 0];
         a.ref[i].origin = r->origin; a.ref[i].stride = r->stride;
     }
-    a.lowres = is_lowres; a.depth = c->depth; a.method = method; a.subme = subme;
+    a.lowres = is_lowres; a.depth = c->depth; a.method = method; a.subme = subme; a.win_cap = 0;
     a.ctab = c->tables[qp] + 32768;
 }
 
+/* LDS bytes needed to stage the reference window of one job (see Searcher::bind) */
+static int job_window_bytes(const x265amd_job &j, int bps)
+{
+    const int epc = 16 / bps;
+    const int ww = (j.mvmax[0] - j.mvmin[0]) + j.w + 16, rows = (j.mvmax[1] - j.mvmin[1]) + j.h + 16;
+    const int wstride = ((ww + 4 + epc - 1) / epc) * epc;
+    return wstride * rows * bps + 16;
+}
+
+#define MAX_WINDOW_BYTES (150 * 1024)
+
 int x265amd_search_batch_dev(x265amd_ctx *c, const x265amd_plane *fenc, const x265amd_plane *ref, int is_lowres,
-                             int qp, int method, int subme, const x265amd_job *d_jobs, int njobs, x265amd_result *d_results)
+                             int qp, int method, int subme, const x265amd_job *d_jobs, int njobs, x265amd_result *d_results,
+                             int window_bytes)
 {
     if (!c || !fenc || !ref || !d_jobs || !d_results || njobs < 0) return fail(c, X265AMD_EINVAL, "null argument");
     if (method < 0 || method > X265AMD_FULL || subme < 0 || subme > 7)
@@ -824,18 +846,36 @@ int x265amd_search_batch_dev(x265amd_ctx *c, const x265amd_plane *fenc, const x2
     SearchArgs a;
     fill_args(c, a, fenc, ref, is_lowres, qp, method, subme);
     a.jobs = d_jobs; a.results = d_results; a.njobs = njobs;
+    if (window_bytes < 0 || window_bytes > MAX_WINDOW_BYTES) return fail(c, X265AMD_EINVAL, "window_bytes out of range");
+    a.win_cap = is_lowres ? 0 : window_bytes;
     if (c->depth <= 8)
     {
-        if (is_lowres) hipLaunchKernelGGL((search_kernel<uint8_t, true>), dim3(njobs), dim3(64), 0, c->stream, a);
-        else hipLaunchKernelGGL((search_kernel<uint8_t, false>), dim3(njobs), dim3(64), 0, c->stream, a);
+        const size_t lds = wave_lds_bytes<uint8_t>(is_lowres ? 8 : 64) + a.win_cap;
+        if (is_lowres) hipLaunchKernelGGL((search_kernel<uint8_t, true>), dim3(njobs), dim3(64), lds, c->stream, a);
+        else
+        {
+            HIPCHK(c, allow_big_lds(search_kernel<uint8_t, false>));
+            hipLaunchKernelGGL((search_kernel<uint8_t, false>), dim3(njobs), dim3(64), lds, c->stream, a);
+        }
     }
     else
     {
-        if (is_lowres) hipLaunchKernelGGL((search_kernel<uint16_t, true>), dim3(njobs), dim3(64), 0, c->stream, a);
-        else hipLaunchKernelGGL((search_kernel<uint16_t, false>), dim3(njobs), dim3(64), 0, c->stream, a);
+        const size_t lds = wave_lds_bytes<uint16_t>(is_lowres ? 8 : 64) + a.win_cap;
+        if (is_lowres) hipLaunchKernelGGL((search_kernel<uint16_t, true>), dim3(njobs), dim3(64), lds, c->stream, a);
+        else
+        {
+            HIPCHK(c, allow_big_lds(search_kernel<uint16_t, false>));
+            hipLaunchKernelGGL((search_kernel<uint16_t, false>), dim3(njobs), dim3(64), lds, c->stream, a);
+        }
     }
     HIPCHK(c, hipGetLastError());
     return X265AMD_OK;
+}
+
+int x265amd_window_bytes(const x265amd_ctx *c, const x265amd_job *job)
+{
+    if (!c || !job) return X265AMD_EINVAL;
+    return job_window_bytes(*job, c->depth > 8 ? 2 : 1);
 }
 
 int x265amd_sync(x265amd_ctx *c)
@@ -857,8 +897,19 @@ int x265amd_search_batch(x265amd_ctx *c, const x265amd_plane *fenc, const x265am
     if ((rc = ensure(c, &c->d_jobs, &c->jobs_cap, (size_t)njobs * sizeof(x265amd_job)))) return rc;
     if ((rc = ensure(c, &c->d_results, &c->results_cap, (size_t)njobs * sizeof(x265amd_result)))) return rc;
     HIPCHK(c, hipMemcpyAsync(c->d_jobs, jobs, (size_t)njobs * sizeof(x265amd_job), hipMemcpyHostToDevice, c->stream));
+    /* stage windows in LDS when the largest one leaves room for at least 4 PUs per CU */
+    int win = 0;
+    if (!is_lowres)
+    {
+        for (int i = 0; i < njobs; i++)
+        {
+            const int b = job_window_bytes(jobs[i], c->depth > 8 ? 2 : 1);
+            if (b > win) win = b;
+        }
+        if (win > 36 * 1024) win = 36 * 1024;   /* larger windows fall back to L2 reads inside the kernel */
+    }
     rc = x265amd_search_batch_dev(c, fenc, ref, is_lowres, qp, method, subme, (const x265amd_job*)c->d_jobs, njobs,
-                                  (x265amd_result*)c->d_results);
+                                  (x265amd_result*)c->d_results, win);
     if (rc) return rc;
     HIPCHK(c, hipMemcpyAsync(results, c->d_results, (size_t)njobs * sizeof(x265amd_result), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -882,9 +933,9 @@ int x265amd_subpel_compare_batch(x265amd_ctx *c, const x265amd_plane *fenc, cons
     fill_args(c, a, fenc, ref, 0, 12, 0, 0);
     a.jobs = (const x265amd_job*)c->d_jobs; a.results = (x265amd_result*)c->d_results; a.njobs = njobs;
     if (c->depth <= 8)
-        hipLaunchKernelGGL(subpel_compare_kernel<uint8_t>, dim3(njobs), dim3(64), 0, c->stream, a, cmp);
+        hipLaunchKernelGGL(subpel_compare_kernel<uint8_t>, dim3(njobs), dim3(64), wave_lds_bytes<uint8_t>(64), c->stream, a, cmp);
     else
-        hipLaunchKernelGGL(subpel_compare_kernel<uint16_t>, dim3(njobs), dim3(64), 0, c->stream, a, cmp);
+        hipLaunchKernelGGL(subpel_compare_kernel<uint16_t>, dim3(njobs), dim3(64), wave_lds_bytes<uint16_t>(64), c->stream, a, cmp);
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipMemcpyAsync(results, c->d_results, (size_t)njobs * sizeof(x265amd_result), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -932,9 +983,9 @@ int x265amd_lookahead_fields(x265amd_ctx *c, const x265amd_field *fields, int nf
     a.costs = (int32_t*)((char*)c->d_results + mvbytes);
     a.stats = out_stats ? (x265amd_result*)((char*)c->d_results + mvbytes + cbytes) : 0;
     if (c->depth <= 8)
-        hipLaunchKernelGGL(lookahead_kernel<uint8_t>, dim3(nfields), dim3(LA_WAVES * 64), 0, c->stream, a);
+        hipLaunchKernelGGL(lookahead_kernel<uint8_t>, dim3(nfields), dim3(LA_WAVES * 64), LA_WAVES * wave_lds_bytes<uint8_t>(8), c->stream, a);
     else
-        hipLaunchKernelGGL(lookahead_kernel<uint16_t>, dim3(nfields), dim3(LA_WAVES * 64), 0, c->stream, a);
+        hipLaunchKernelGGL(lookahead_kernel<uint16_t>, dim3(nfields), dim3(LA_WAVES * 64), LA_WAVES * wave_lds_bytes<uint16_t>(8), c->stream, a);
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipMemcpyAsync(out_mvs, a.mvs, mvbytes, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipMemcpyAsync(out_costs, a.costs, cbytes, hipMemcpyDeviceToHost, c->stream));
@@ -984,9 +1035,9 @@ int x265amd_lookahead_fields_dev(x265amd_ctx *c, const void *d_fields, int nfiel
     a.ctab = c->tables[qp] + 32768;
     a.mvs = d_mvs; a.costs = d_costs; a.stats = d_stats;
     if (c->depth <= 8)
-        hipLaunchKernelGGL(lookahead_kernel<uint8_t>, dim3(nfields), dim3(LA_WAVES * 64), 0, c->stream, a);
+        hipLaunchKernelGGL(lookahead_kernel<uint8_t>, dim3(nfields), dim3(LA_WAVES * 64), LA_WAVES * wave_lds_bytes<uint8_t>(8), c->stream, a);
     else
-        hipLaunchKernelGGL(lookahead_kernel<uint16_t>, dim3(nfields), dim3(LA_WAVES * 64), 0, c->stream, a);
+        hipLaunchKernelGGL(lookahead_kernel<uint16_t>, dim3(nfields), dim3(LA_WAVES * 64), LA_WAVES * wave_lds_bytes<uint16_t>(8), c->stream, a);
     HIPCHK(c, hipGetLastError());
     return X265AMD_OK;
 }
@@ -1036,12 +1087,12 @@ int x265amd_rk_ctu_batch_dev(x265amd_ctx *c, const x265amd_plane *fenc, const x2
     if (c->depth <= 8)
     {
         hipLaunchKernelGGL(rk_cime_kernel<uint8_t>, dim3(nctus), dim3(CIME_THREADS), lds, c->stream, a);
-        hipLaunchKernelGGL(rk_cu_kernel<uint8_t>, dim3(nctus * 85), dim3(64), 0, c->stream, a);
+        hipLaunchKernelGGL(rk_cu_kernel<uint8_t>, dim3(nctus * 85), dim3(64), wave_lds_bytes<uint8_t>(64), c->stream, a);
     }
     else
     {
         hipLaunchKernelGGL(rk_cime_kernel<uint16_t>, dim3(nctus), dim3(CIME_THREADS), lds, c->stream, a);
-        hipLaunchKernelGGL(rk_cu_kernel<uint16_t>, dim3(nctus * 85), dim3(64), 0, c->stream, a);
+        hipLaunchKernelGGL(rk_cu_kernel<uint16_t>, dim3(nctus * 85), dim3(64), wave_lds_bytes<uint16_t>(64), c->stream, a);
     }
     HIPCHK(c, hipGetLastError());
     return X265AMD_OK;

@@ -41,174 +41,231 @@ struct PlaneDev
     int stride;
 };
 
-/* per-wave LDS working set */
-template<typename P, int ROWS = 64>
-struct WaveLds
+/* Per-wave LDS layout, byte offsets from the wave's base. Candidate arrays hold MAXC ints. */
+enum
 {
-    P   fenc[ROWS * 64];   /* source PU, stride 64 (FENC_STRIDE) */
-    int sx[MAXC], sy[MAXC];   /* where to measure: full-pel offset, or qpel MV */
-    int mvx[MAXC], mvy[MAXC]; /* MV charged for the candidate (same units) */
-    int sh[MAXC];             /* left shift applied to mv before the cost lookup */
-    int meta[MAXC];
-    int costs[MAXC];
+    L_SX = 0, L_SY = 64,         /* where to measure: full-pel offset, or qpel MV */
+    L_MVX = 128, L_MVY = 192,    /* MV charged for the candidate (same units) */
+    L_SH = 256,                  /* left shift applied to mv before the cost lookup, + flavour flags */
+    L_META = 320, L_COSTS = 384,
+    L_CTX = 448,                 /* EvalCtx */
+    L_FENC = 704                 /* source PU, row pitch 64 samples (FENC_STRIDE) */
 };
+
+/* Everything the batched evaluation needs, parked in LDS so that the evaluation routine
+ * is an ordinary function of (base, K, mode) and the search logic stays in registers. */
+struct EvalCtx
+{
+    unsigned long long ref[4];   /* global addresses of the plane origins */
+    unsigned long long ctab;     /* centred MVD cost table */
+    long roff;                   /* pu_y * rstride + pu_x */
+    int rstride, w, h, T, Tp, lTp, wt, inv_wt, depth;
+    int mvpx, mvpy;
+    int rk_have_mvd, rk_mvp[3][2];
+    /* staged reference window: PU-relative [wx0, wx1) x [wy0, wy1), row pitch wstride samples,
+     * at byte offset woff from the wave's base; wx1 <= wx0 when nothing is staged */
+    int wx0, wy0, wx1, wy1, wstride, woff;
+};
+
+__device__ __forceinline__ int *lds_i(int base, int off) { return (int*)(x265amd_smem + base + off); }
+__device__ __forceinline__ EvalCtx *lds_ctx(int base) { return (EvalCtx*)(x265amd_smem + base + L_CTX); }
+
+template<typename P> constexpr int wave_lds_bytes(int rows) { return L_FENC + rows * 64 * (int)sizeof(P); }
+
+/* cost of tile t of candidate k. mode 0: full-pel SAD at offset (sx, sy); mode 1 / 2: SAD /
+ * SATD at qpel MV (sx, sy) through subpelCompare or lowresQPelCost; mode 3: Rockchip FME */
+template<typename P, bool LOWRES, bool RK>
+__device__ __forceinline__ int tile_cost(int base, const EvalCtx &c, int k, int t, int mode)
+{
+    const int ty = (t * c.inv_wt) >> 16, tx = t - ty * c.wt;
+    typename Px<P>::quad f[4], q[4];
+#pragma unroll
+    for (int y = 0; y < 4; y++) f[y] = Px<P>::load_lds_aligned(base + L_FENC + ((ty * 4 + y) * 64 + tx * 4) * (int)sizeof(P));
+    const int cx = lds_i(base, L_SX)[k], cy = lds_i(base, L_SY)[k];
+    const P AS1 *ref0 = (const P AS1*)c.ref[0];
+    if (mode == 0)
+    {
+        const int X = cx + tx * 4, Y = cy + ty * 4;
+        if (X >= c.wx0 && X + 4 <= c.wx1 && Y >= c.wy0 && Y + 4 <= c.wy1)
+        {
+            const int o = base + c.woff + ((Y - c.wy0) * c.wstride + (X - c.wx0)) * (int)sizeof(P);
+#pragma unroll
+            for (int y = 0; y < 4; y++) q[y] = Px<P>::load_lds(o + y * c.wstride * (int)sizeof(P));
+        }
+        else
+        {
+            const P AS1 *r = ref0 + c.roff + (long)Y * c.rstride + X;
+#pragma unroll
+            for (int y = 0; y < 4; y++) q[y] = Px<P>::load_g(r + y * c.rstride);
+        }
+        return tile_cost_quads<P>(f, q, false);
+    }
+    if constexpr (LOWRES)
+    {
+        /* lowres.h:78-97: pick the hpel plane; odd qpel = average with the next one */
+        const bool satd = mode == 2;
+        const int hpelA = (cy & 2) | ((cx & 2) >> 1);
+        const P AS1 *ra = (const P AS1*)c.ref[hpelA] + c.roff + (long)((cy >> 2) + ty * 4) * c.rstride + (cx >> 2) + tx * 4;
+#pragma unroll
+        for (int y = 0; y < 4; y++) q[y] = Px<P>::load_g(ra + y * c.rstride);
+        if ((cx | cy) & 1)
+        {
+            const int bx = as_i16(cx + (cx & 1) * 2), by = as_i16(cy + (cy & 1) * 2);
+            const int hpelB = (by & 2) | ((bx & 2) >> 1);
+            const P AS1 *rb = (const P AS1*)c.ref[hpelB] + c.roff + (long)((by >> 2) + ty * 4) * c.rstride + (bx >> 2) + tx * 4;
+#pragma unroll
+            for (int y = 0; y < 4; y++) q[y] = Px<P>::avg(q[y], Px<P>::load_g(rb + y * c.rstride));
+        }
+        return tile_cost_quads<P>(f, q, satd);
+    }
+    else
+    {
+        const int xf = cx & 3, yf = cy & 3;
+        const int X = (cx >> 2) + tx * 4, Y = (cy >> 2) + ty * 4;
+        /* footprint of the 8-tap filters: 3 left / above, 4 right / below, + the 4-byte over-read */
+        const bool inwin = X - 3 >= c.wx0 && X + 9 <= c.wx1 && Y - 3 >= c.wy0 && Y + 8 <= c.wy1;
+        int o[4][4];
+        if (inwin)
+        {
+            LdsLoader<P> ld = { base + c.woff + ((Y - c.wy0) * c.wstride + (X - c.wx0)) * (int)sizeof(P), c.wstride };
+            if ((xf | yf) == 0)
+            {
+#pragma unroll
+                for (int y = 0; y < 4; y++) q[y] = ld(0, y);
+                return tile_cost_quads<P>(f, q, mode >= 2);
+            }
+            if constexpr (RK) rk_interp_tile<P>(ld, xf, yf, c.depth, o);
+            else interp_tile<P>(ld, xf, yf, c.depth, o);
+        }
+        else
+        {
+            GlobalLoader<P> ld = { ref0 + c.roff + (long)Y * c.rstride + X, c.rstride };
+            if ((xf | yf) == 0)
+            {
+#pragma unroll
+                for (int y = 0; y < 4; y++) q[y] = ld(0, y);
+                return tile_cost_quads<P>(f, q, mode >= 2);
+            }
+            if constexpr (RK) rk_interp_tile<P>(ld, xf, yf, c.depth, o);
+            else interp_tile<P>(ld, xf, yf, c.depth, o);
+        }
+        return tile_cost_px<P>(f, o, mode >= 2);
+    }
+}
+
+/* costs[k] = distortion(k) [+ mvcost(mv[k] << sh[k])] for k < K. One call per decision
+ * point of the search; (candidate, tile) pairs are spread over the lanes. */
+template<typename P, bool LOWRES, bool RK>
+__device__ __noinline__ void eval_batch(int base, int K, int mode, int addmv)
+{
+    wave_sync();
+    EvalCtx c;
+    {
+        /* the context is wave-uniform: pull it into scalar registers */
+        const int *src = (const int*)lds_ctx(base);
+        int *dst = (int*)&c;
+#pragma unroll
+        for (int i = 0; i < (int)(sizeof(EvalCtx) / 4); i++) dst[i] = uni(src[i]);
+    }
+    const int lane = threadIdx.x & 63;
+    /* the lambda * bits term of candidate `lane` is gathered first so that its table loads
+     * overlap the distortion work */
+    /* mode < 0: mixed batch, candidate k carries its own mode in meta bits 0-3 and its
+     * "add mvcost" flag in bit 4 */
+    const bool mixed = mode < 0;
+    int mvc = 0;
+    if (lane < K && (mixed ? (lds_i(base, L_META)[lane] >> 4) & 1 : addmv))
+    {
+        const uint16_t AS1 *ctab = (const uint16_t AS1*)c.ctab;
+        const int s = lds_i(base, L_SH)[lane];
+        const int mx = lds_i(base, L_MVX)[lane], my = lds_i(base, L_MVY)[lane];
+        if (s & 16)
+        {
+            /* Rockchip stages: min over three predictors, each sum truncated to uint16
+             * (motion.cpp:1284-1292) */
+            if (c.rk_have_mvd)
+            {
+                mvc = 0x7fffffff;
+#pragma unroll
+                for (int k = 0; k < 3; k++)
+                {
+                    const int v = ((int)ctab[mx - c.rk_mvp[k][0]] + (int)ctab[my - c.rk_mvp[k][1]]) & 0xffff;
+                    mvc = v < mvc ? v : mvc;
+                }
+            }
+        }
+        else if (s & 8)
+            /* UMH hexagon grid: table entries added as ints, MV * 4 without the int16 wrap
+             * (ADD_MVCOST, motion.cpp:856) */
+            mvc = (int)ctab[mx * 4 - c.mvpx] + (int)ctab[my * 4 - c.mvpy];
+        else
+            /* bitcost.h:46 -- the sum is truncated to uint16 */
+            mvc = ((int)ctab[as_i16(mx << s) - c.mvpx] + (int)ctab[as_i16(my << s) - c.mvpy]) & 0xffff;
+    }
+    if (c.Tp <= 64)
+    {
+        const int g = lane >> c.lTp, t = lane & (c.Tp - 1);
+        const int cpp = 64 >> c.lTp;
+        for (int k0 = 0; k0 < K; k0 += cpp)
+        {
+            const int k = k0 + g;
+            int v = 0;
+            if (k < K && t < c.T) v = tile_cost<P, LOWRES, RK>(base, c, k, t, mixed ? lds_i(base, L_META)[k] & 15 : mode);
+            for (int o = 1; o < c.Tp; o <<= 1) v += __shfl_xor(v, o);
+            if (t == 0 && k < K) lds_i(base, L_COSTS)[k] = v;
+        }
+    }
+    else
+    {
+        for (int k = 0; k < K; k++)
+        {
+            int v = 0;
+            const int km = mixed ? uni(lds_i(base, L_META)[k]) & 15 : mode;
+            for (int t = lane; t < c.T; t += 64) v += tile_cost<P, LOWRES, RK>(base, c, k, t, km);
+            for (int o = 1; o < 64; o <<= 1) v += __shfl_xor(v, o);
+            if (lane == 0) lds_i(base, L_COSTS)[k] = v;
+        }
+    }
+    wave_sync();
+    if (lane < K) lds_i(base, L_COSTS)[lane] += mvc;
+    wave_sync();
+}
 
 /* LOWRES selects the lookahead flavour at compile time (half-pel planes instead of
  * interpolation), which keeps the 8-tap code out of the lookahead kernel. */
-template<typename P, int ROWS = 64, bool LOWRES = false>
+template<typename P, int ROWS = 64, bool LOWRES = false, bool RK = false>
 struct Searcher
 {
-    WaveLds<P, ROWS> *L;
-    const P *ref[4];
-    long roff;          /* pu_y * rstride + pu_x */
-    int rstride;
-    const uint16_t *ctab; /* centred MVD cost table */
+    int base;           /* byte offset of this wave's LDS block */
+    int w, h, lane;
     int mvpx, mvpy;
-    int w, h, T, Tp, lTp, wt, inv_wt;
-    int lane, depth;
-    int rk_mvp[3][2], rk_have_mvd; /* Rockchip path: three cost predictors (motion.cpp:1284-1292) */
-    static constexpr bool is_lowres = LOWRES;
     unsigned nsad, nsub;
 
-    __device__ __forceinline__ int mvcost(int x, int y) const
+    __device__ __forceinline__ void eval(int K, int mode, bool addmv)
     {
-        /* bitcost.h:46 -- the sum is truncated to uint16 */
-        return ((int)ctab[x - mvpx] + (int)ctab[y - mvpy]) & 0xffff;
-    }
-
-    __device__ __forceinline__ void tile_xy(int t, int &tx, int &ty) const
-    {
-        ty = (t * inv_wt) >> 16;
-        tx = t - ty * wt;
-    }
-
-    __device__ __forceinline__ void load_fenc_tile(int tx, int ty, typename Px<P>::quad f[4]) const
-    {
-#pragma unroll
-        for (int y = 0; y < 4; y++) f[y] = Px<P>::load_aligned(L->fenc + (ty * 4 + y) * 64 + tx * 4);
-    }
-
-    /* cost of tile t of candidate k. mode 0: full-pel SAD at offset (sx, sy);
-     * mode 1/2: SAD / SATD at qpel MV (sx, sy) through subpelCompare or lowresQPelCost */
-    __device__ __forceinline__ int tile_cost(int k, int t, int mode) const
-    {
-        int tx, ty;
-        tile_xy(t, tx, ty);
-        typename Px<P>::quad f[4], q[4];
-        load_fenc_tile(tx, ty, f);
-        const int cx = L->sx[k], cy = L->sy[k];
-        if (mode == 0)
-        {
-            const P *r = ref[0] + roff + (long)(cy + ty * 4) * rstride + cx + tx * 4;
-#pragma unroll
-            for (int y = 0; y < 4; y++) q[y] = Px<P>::load(r + y * rstride);
-            return tile_cost_quads<P>(f, q, false);
-        }
-        const bool satd = mode == 2;
-        if constexpr (LOWRES)
-        {
-            /* lowres.h:78-97: pick the hpel plane; odd qpel = average with the next one */
-            const int hpelA = (cy & 2) | ((cx & 2) >> 1);
-            const P *ra = ref[hpelA] + roff + (long)((cy >> 2) + ty * 4) * rstride + (cx >> 2) + tx * 4;
-#pragma unroll
-            for (int y = 0; y < 4; y++) q[y] = Px<P>::load(ra + y * rstride);
-            if ((cx | cy) & 1)
-            {
-                const int bx = as_i16(cx + (cx & 1) * 2), by = as_i16(cy + (cy & 1) * 2);
-                const int hpelB = (by & 2) | ((bx & 2) >> 1);
-                const P *rb = ref[hpelB] + roff + (long)((by >> 2) + ty * 4) * rstride + (bx >> 2) + tx * 4;
-#pragma unroll
-                for (int y = 0; y < 4; y++) q[y] = Px<P>::avg(q[y], Px<P>::load(rb + y * rstride));
-            }
-            return tile_cost_quads<P>(f, q, satd);
-        }
-        else
-        {
-        const int xf = cx & 3, yf = cy & 3;
-        const P *r = ref[0] + roff + (long)((cy >> 2) + ty * 4) * rstride + (cx >> 2) + tx * 4;
-        if ((xf | yf) == 0)
-        {
-#pragma unroll
-            for (int y = 0; y < 4; y++) q[y] = Px<P>::load(r + y * rstride);
-            return tile_cost_quads<P>(f, q, mode >= 2);
-        }
-        int o[4][4];
-        if (mode == 3)
-        {
-            /* Rockchip FME: 4-tap interpolation + SATD (motion.cpp:1453-1494) */
-            rk_interp_tile<P>(r, rstride, xf, yf, depth, o);
-            return tile_cost_px<P>(f, o, true);
-        }
-        interp_tile<P>(r, rstride, xf, yf, depth, o);
-        return tile_cost_px<P>(f, o, satd);
-        }
-    }
-
-    /* costs[k] = distortion(k) [+ mvcost(mv[k] << sh[k])] for k < K */
-    __device__ __noinline__ void eval(int K, int mode, bool addmv)
-    {
-        wave_sync();
-        if (Tp <= 64)
-        {
-            const int g = lane >> lTp, t = lane & (Tp - 1);
-            const int cpp = 64 >> lTp;
-            for (int k0 = 0; k0 < K; k0 += cpp)
-            {
-                const int k = k0 + g;
-                int v = 0;
-                if (k < K && t < T) v = tile_cost(k, t, mode);
-                for (int o = 1; o < Tp; o <<= 1) v += __shfl_xor(v, o);
-                if (t == 0 && k < K) L->costs[k] = v;
-            }
-        }
-        else
-        {
-            for (int k = 0; k < K; k++)
-            {
-                int v = 0;
-                for (int t = lane; t < T; t += 64) v += tile_cost(k, t, mode);
-                for (int o = 1; o < 64; o <<= 1) v += __shfl_xor(v, o);
-                if (lane == 0) L->costs[k] = v;
-            }
-        }
-        wave_sync();
-        if (addmv && lane < K)
-        {
-            const int s = L->sh[lane];
-            if (s & 16)
-            {
-                /* Rockchip stages: min over three predictors, each sum truncated to uint16 */
-                int best = 0;
-                if (rk_have_mvd)
-                {
-                    best = 0x7fffffff;
-                    const int x = L->mvx[lane], y = L->mvy[lane];
-#pragma unroll
-                    for (int k = 0; k < 3; k++)
-                    {
-                        const int c = ((int)ctab[x - rk_mvp[k][0]] + (int)ctab[y - rk_mvp[k][1]]) & 0xffff;
-                        best = c < best ? c : best;
-                    }
-                }
-                L->costs[lane] += best;
-            }
-            else if (s & 8)
-                /* UMH hexagon grid: table entries added as ints, MV * 4 without the int16 wrap
-                 * (ADD_MVCOST, motion.cpp:856) */
-                L->costs[lane] += (int)ctab[L->mvx[lane] * 4 - mvpx] + (int)ctab[L->mvy[lane] * 4 - mvpy];
-            else
-                L->costs[lane] += mvcost(as_i16(L->mvx[lane] << s), as_i16(L->mvy[lane] << s));
-        }
-        wave_sync();
+        eval_batch<P, LOWRES, RK>(base, K, mode, addmv ? 1 : 0);
         if (mode == 0) nsad += K; else nsub += K;
     }
 
     __device__ __forceinline__ void put(int k, int sx_, int sy_, int mx_, int my_, int sh_, int meta_)
     {
-        L->sx[k] = sx_; L->sy[k] = sy_; L->mvx[k] = mx_; L->mvy[k] = my_; L->sh[k] = sh_; L->meta[k] = meta_;
+        lds_i(base, L_SX)[k] = sx_; lds_i(base, L_SY)[k] = sy_;
+        lds_i(base, L_MVX)[k] = mx_; lds_i(base, L_MVY)[k] = my_;
+        lds_i(base, L_SH)[k] = sh_; lds_i(base, L_META)[k] = meta_;
     }
 
-    __device__ __forceinline__ int cost_of(int k) const { return uni(L->costs[k]); }
+    __device__ __forceinline__ int cost_of(int k) const { return uni(lds_i(base, L_COSTS)[k]); }
+    __device__ __forceinline__ int mvx_of(int k) const { return uni(lds_i(base, L_MVX)[k]); }
+    __device__ __forceinline__ int mvy_of(int k) const { return uni(lds_i(base, L_MVY)[k]); }
+    __device__ __forceinline__ int meta_of(int k) const { return uni(lds_i(base, L_META)[k]); }
+
+    /* setMVP (bitcost.h:43) */
+    __device__ __forceinline__ void set_mvp(int x, int y)
+    {
+        mvpx = x; mvpy = y;
+        wave_sync();
+        if (lane == 0) { lds_ctx(base)->mvpx = x; lds_ctx(base)->mvpy = y; }
+    }
 
     /* single evaluations */
     __device__ __forceinline__ int fpcost(int mx, int my)
@@ -241,8 +298,8 @@ struct Searcher
             if (c < bcost)
             {
                 bcost = c;
-                bmx = uni(L->mvx[k]); bmy = uni(L->mvy[k]);
-                const int m = uni(L->meta[k]);
+                bmx = mvx_of(k); bmy = mvy_of(k);
+                const int m = meta_of(k);
                 bPointNr = m & 0xff; bDistance = m >> 8;
             }
         }
@@ -251,7 +308,7 @@ struct Searcher
     /* StarPatternSearch, motion.cpp:307-547. One diamond ring per round; every
      * in-range point of a round is independent of the others, so a round is one
      * batched evaluation folded in the reference's visit order. */
-    __device__ void star_pattern(int mnx, int mny, int mxx, int mxy, int &bmx, int &bmy, int &bcost,
+    __device__ __forceinline__ void star_pattern(int mnx, int mny, int mxx, int mxy, int &bmx, int &bmy, int &bcost,
                                  int &bPointNr, int &bDistance, int earlyExitIters, int merange)
     {
         const int ox = bmx, oy = bmy;
@@ -374,7 +431,7 @@ struct Searcher
     /* CROSS, motion.cpp:281-305. The vertical COST_MV calls expand to
      * fref + omv.x + omv.y + i * stride, i.e. the SAD is taken at (omv.x + omv.y, +-i)
      * while the MV charged is (omv.x, omv.y +- i); reproduced literally. */
-    __device__ void umh_cross(int &K, int start, int x_max, int y_max, int pbx, int pby, int omx, int omy,
+    __device__ __forceinline__ void umh_cross(int &K, int start, int x_max, int y_max, int pbx, int pby, int omx, int omy,
                               int mnx, int mny, int mxx, int mxy, int &bmx, int &bmy, int &bcost)
     {
         int i = start;
@@ -399,7 +456,7 @@ struct Searcher
 
     /* X265_UMH_SEARCH, motion.cpp:725-909. Returns true when the search continues into
      * the hexagon refinement (goto me_hex2) with the possibly rescaled merange. */
-    __device__ bool umh(const x265amd_job *job, int mnx, int mny, int mxx, int mxy, int pmx, int pmy,
+    __device__ __forceinline__ bool umh(const x265amd_job *job, int mnx, int mny, int mxx, int mxy, int pmx, int pmy,
                         int &merange, int &bmx, int &bmy, int &bcost)
     {
         const int size_scale = (h * h) >> 4; /* motion.cpp:71-72 */
@@ -512,44 +569,64 @@ struct Searcher
     }
 
     /* the whole of motionEstimate for one PU */
-    __device__ void search(const x265amd_job *job, int method, int subme, x265amd_result *res)
+    __device__ __forceinline__ void search(const x265amd_job *job, int method, int subme, x265amd_result *res)
     {
         const int mnx = job->mvmin[0], mny = job->mvmin[1], mxx = job->mvmax[0], mxy = job->mvmax[1];
         const int qmnx = as_i16(mnx << 2), qmny = as_i16(mny << 2), qmxx = as_i16(mxx << 2), qmxy = as_i16(mxy << 2);
         const int numc = job->numc;
         int merange = job->merange;
-        mvpx = job->qmvp[0]; mvpy = job->qmvp[1]; /* setMVP, bitcost.h:43 */
+        set_mvp(job->qmvp[0], job->qmvp[1]);
         nsad = 0; nsub = 0;
 
 #define CLIPX(v) ((v) > qmxx ? qmxx : ((v) < qmnx ? qmnx : (v)))
 #define CLIPY(v) ((v) > qmxy ? qmxy : ((v) < qmny ? qmny : (v)))
-        /* clipped qpel predictor, measured without its own mvcost (motion.cpp:575-582) */
+        /* Start-up candidates (motion.cpp:575-621): the clipped qpel predictor (no mvcost of its
+         * own), its full-pel rounding, MV(0,0) and the qpel candidates are all independent
+         * measurements, so they form ONE mixed batch (per-candidate mode in `meta`); the
+         * reference's sequential tests -- including "skip a candidate equal to the current
+         * bestpre" -- are then replayed on the costs, which also keeps the counters exact. */
         int pmx = CLIPX(mvpx), pmy = CLIPY(mvpy);
         int bpx = pmx, bpy = pmy;
-        int bprecost = qdist(pmx, pmy, 1);
-
         int bmx = as_i16((pmx + 2) >> 2), bmy = as_i16((pmy + 2) >> 2);
-        int bcost = bprecost;
-        if ((pmx | pmy) & 3)
-            bcost = fpcost(bmx, bmy);
-        if (pmx | pmy)
+        int K = 0;
+        put(K++, pmx, pmy, pmx, pmy, 0, 1);                          /* SAD at qpel, no mvcost */
+        const int kFp = ((pmx | pmy) & 3) ? K : -1;
+        if (kFp >= 0) put(K++, bmx, bmy, bmx, bmy, 2, 0 | 16);       /* full-pel SAD + mvcost */
+        const int kZero = (pmx | pmy) ? K : -1;
+        if (kZero >= 0) put(K++, 0, 0, 0, 0, 2, 0 | 16);
+        int kc[4], ccx[4], ccy[4];
+        for (int i = 0; i < 4; i++)
         {
-            const int c = fpcost(0, 0);
-            if (c < bcost) { bcost = c; bmx = 0; bmy = 0; }
-        }
-
-        /* qpel candidates, motion.cpp:603-621 (sequential: each test depends on bestpre) */
-        for (int i = 0; i < numc; i++)
-        {
-            const int cx = CLIPX((int)job->mvc[i][0]), cy = CLIPY((int)job->mvc[i][1]);
-            if ((cx | cy) && !(cx == pmx && cy == pmy) && !(cx == bpx && cy == bpy))
+            kc[i] = -1; ccx[i] = 0; ccy[i] = 0;
+            if (i < numc)
             {
-                put(0, cx, cy, cx, cy, 0, 0);
-                eval(1, 1, true);
-                const int c = cost_of(0);
-                if (c < bprecost) { bprecost = c; bpx = cx; bpy = cy; }
+                ccx[i] = CLIPX((int)job->mvc[i][0]); ccy[i] = CLIPY((int)job->mvc[i][1]);
+                if ((ccx[i] | ccy[i]) && !(ccx[i] == pmx && ccy[i] == pmy))
+                {
+                    kc[i] = K;
+                    put(K++, ccx[i], ccy[i], ccx[i], ccy[i], 0, 1 | 16);
+                }
             }
         }
+        eval_batch<P, LOWRES, RK>(base, K, -1, 0);
+        int bprecost = cost_of(0);
+        nsub++;
+        int bcost = bprecost;
+        if (kFp >= 0) { bcost = cost_of(kFp); nsad++; }
+        if (kZero >= 0)
+        {
+            const int c = cost_of(kZero);
+            nsad++;
+            if (c < bcost) { bcost = c; bmx = 0; bmy = 0; }
+        }
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+            if (kc[i] >= 0 && !(ccx[i] == bpx && ccy[i] == bpy))
+            {
+                const int c = cost_of(kc[i]);
+                nsub++;
+                if (c < bprecost) { bprecost = c; bpx = ccx[i]; bpy = ccy[i]; }
+            }
 #undef CLIPX
 #undef CLIPY
         pmx = as_i16((pmx + 2) >> 2); pmy = as_i16((pmy + 2) >> 2);
@@ -576,7 +653,7 @@ struct Searcher
                     if (c < bcost) { bcost = c; dir = k; }
                 }
                 if (dir < 0) break;
-                bmx = uni(L->mvx[dir]); bmy = uni(L->mvy[dir]);
+                bmx = mvx_of(dir); bmy = mvy_of(dir);
             }
             while (--i && in_range(bmx, bmy, mnx, mny, mxx, mxy));
             break;
@@ -730,7 +807,7 @@ struct Searcher
         {
             /* all directions of one refinement round share the same centre, so a
              * round is one batched evaluation (motion.cpp:1077-1141) */
-            if (is_lowres)
+            if (LOWRES)
             {
                 refine_round(qx, qy, bcost, hpel_dirs, 2, 1);
                 put(0, qx, qy, qx, qy, 0, 0);
@@ -786,38 +863,74 @@ struct Searcher
         qx = as_i16(qx + kSquare1[bdir][0] * step); qy = as_i16(qy + kSquare1[bdir][1] * step);
     }
 
-    /* bind to a PU: geometry, tile tables, and the source block copy
-     * (setSourcePU, motion.cpp:116-142) */
-    __device__ __forceinline__ void bind(WaveLds<P, ROWS> *lds, const PlaneDev &fencPl, const PlaneDev *refPl, int nref,
-                                         const uint16_t *costTab, int depth_,
-                                         int pu_x, int pu_y, int w_, int h_)
+    /* bind to a PU: geometry, tile tables, the source block copy (setSourcePU,
+     * motion.cpp:116-142) and, when it fits in `win_cap` bytes, the reference window
+     * [x0, x1) x [y0, y1) (PU-relative) staged in LDS with 16-byte coalesced loads. */
+    __device__ __forceinline__ void bind(int lds_base, const PlaneDev &fencPl, const PlaneDev *refPl, int nref,
+                                         const uint16_t *costTab, int depth_, int pu_x, int pu_y, int w_, int h_,
+                                         int x0 = 0, int y0 = 0, int x1 = 0, int y1 = 0, int win_cap = 0)
     {
-        L = lds;
+        base = lds_base;
         lane = threadIdx.x & 63;
-        depth = depth_;
-        ctab = costTab;
         w = w_; h = h_;
-        wt = w >> 2;
-        T = wt * (h >> 2);
-        lTp = 0;
+        mvpx = mvpy = 0;
+        const int wt = w >> 2, T = wt * (h >> 2);
+        int lTp = 0;
         while ((1 << lTp) < T) lTp++;
-        Tp = 1 << lTp;
-        inv_wt = (65536 + wt - 1) / wt;
-        rstride = refPl[0].stride;
-        roff = (long)pu_y * rstride + pu_x;
-        for (int i = 0; i < 4; i++) ref[i] = (const P*)refPl[i < nref ? i : 0].origin;
-        const P *src = (const P*)fencPl.origin + (long)pu_y * fencPl.stride + pu_x;
+        const int inv_wt = (65536 + wt - 1) / wt;
+        const int rstride = refPl[0].stride;
+        const long roff = (long)pu_y * rstride + pu_x;
+        const int epc = 16 / (int)sizeof(P);               /* samples per 16-byte chunk */
+        int wstride = ((x1 - x0 + 4 + epc - 1) / epc) * epc; /* + 4 samples: the aligned-pair LDS read may touch them */
+        const int rows = y1 - y0;
+        const int woff = wave_lds_bytes<P>(ROWS);
+        const bool staged = x1 > x0 && rows > 0 && wstride * rows * (int)sizeof(P) + 16 <= win_cap;
         wave_sync();
+        if (lane == 0)
+        {
+            EvalCtx *c = lds_ctx(base);
+            for (int i = 0; i < 4; i++) c->ref[i] = (unsigned long long)refPl[i < nref ? i : 0].origin;
+            c->ctab = (unsigned long long)costTab;
+            c->roff = roff;
+            c->rstride = rstride; c->w = w; c->h = h; c->T = T; c->Tp = 1 << lTp; c->lTp = lTp; c->wt = wt; c->inv_wt = inv_wt;
+            c->depth = depth_; c->mvpx = 0; c->mvpy = 0; c->rk_have_mvd = 0;
+            c->wx0 = x0; c->wy0 = y0; c->wx1 = staged ? x1 : x0; c->wy1 = y1; c->wstride = wstride; c->woff = woff;
+        }
+        const P AS1 *src = (const P AS1*)fencPl.origin + (long)pu_y * fencPl.stride + pu_x;
         for (int t = lane; t < T; t += 64)
         {
-            int tx, ty;
-            tile_xy(t, tx, ty);
+            const int ty = (t * inv_wt) >> 16, tx = t - ty * wt;
 #pragma unroll
             for (int y = 0; y < 4; y++)
+                Px<P>::store_lds_aligned(base + L_FENC + ((ty * 4 + y) * 64 + tx * 4) * (int)sizeof(P),
+                                         Px<P>::load_g(src + (long)(ty * 4 + y) * fencPl.stride + tx * 4));
+        }
+        if (staged)
+        {
+            typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+            typedef u32x4 __attribute__((aligned(1))) u32x4u;
+            const int chunks = wstride / epc, total = chunks * rows;
+            const int inv_ch = ((1 << 20) + chunks - 1) / chunks;
+            const P AS1 *r0 = (const P AS1*)refPl[0].origin + roff + (long)y0 * rstride + x0;
+            for (int i = lane; i < total; i += 64)
             {
-                typename Px<P>::quad q = Px<P>::load(src + (long)(ty * 4 + y) * fencPl.stride + tx * 4);
-                *(typename Px<P>::quad*)(L->fenc + (ty * 4 + y) * 64 + tx * 4) = q;
+                const int r = (int)(((long)i * inv_ch) >> 20), ch = i - r * chunks;
+                const u32x4 v = *(const u32x4u AS1*)(r0 + (long)r * rstride + ch * epc);
+                *(u32x4*)(x265amd_smem + base + woff + (r * wstride + ch * epc) * (int)sizeof(P)) = v;
             }
+        }
+        wave_sync();
+    }
+
+    /* Rockchip stages: the three cost predictors (motion.cpp:1284-1292) */
+    __device__ __forceinline__ void set_rk_predictors(const int16_t mvp[3][2], int have_mvd)
+    {
+        wave_sync();
+        if (lane == 0)
+        {
+            EvalCtx *c = lds_ctx(base);
+            c->rk_have_mvd = have_mvd;
+            for (int k = 0; k < 3; k++) { c->rk_mvp[k][0] = mvp[k][0]; c->rk_mvp[k][1] = mvp[k][1]; }
         }
         wave_sync();
     }
