@@ -29,7 +29,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 W, H, MARGIN = 1920, 1080, 128
-QP, MERANGE, SUBME = 32, 57, 5
+QP, MERANGE, SUBME_DEFAULT = 32, 57, 5
 LA_QP, LA_MERANGE = 12, 16
 HBM_PEAK_GBS = 8000.0
 
@@ -42,8 +42,7 @@ def main():
     ap.add_argument("--pairs", type=int, default=4, help="frame pairs per GPU per step")
     ap.add_argument("--cpu-sample", type=int, default=4000, help="jobs timed on the host CPU (0 = skip)")
     ap.add_argument("--method", default="star")
-    ap.add_argument("--no-window", action="store_true", help="do not stage reference windows in LDS")
-    ap.add_argument("--window-cap", type=int, default=48 * 1024, help="max LDS bytes per PU for the staged window")
+    ap.add_argument("--subme", type=int, default=SUBME_DEFAULT, help="sub-pel refinement level (experiments only)")
     ap.add_argument("--per-size", action="store_true", help="one search launch per PU size instead of one per frame")
     args = ap.parse_args()
 
@@ -61,6 +60,7 @@ def main():
     if world > 1:
         dist.init_process_group("nccl", device_id=dev)
     method = METHODS[args.method]
+    SUBME = args.subme
 
     # ---------------- setup (untimed): planes, lookahead fields, job lists, all on the device
     es = Engine(local_rank, 8)      # search stream
@@ -80,7 +80,7 @@ def main():
     la_pixel_sads = int((la_stats["sad_calls"].astype(np.int64) + la_stats["subpel_calls"]).sum()) * 64
 
     host_jobs, d_jobs, d_res = [], [], []
-    segs = None     # per PU size: (first job, count, LDS bytes to stage the largest window)
+    segs = None     # per launch: (first job, count, largest PU size)
     for i in range(B):
         jobs = workload.square_pu_jobs(W, H, la_mvs[i], wcu, hcu, MERANGE)
         host_jobs.append(jobs)
@@ -88,7 +88,7 @@ def main():
             segs = []
             for s_ in ((64, 32, 16, 8) if args.per_size else (0,)):
                 idx = np.flatnonzero(jobs["w"] == s_) if s_ else np.arange(len(jobs))
-                segs.append((int(idx[0]), len(idx), 0 if args.no_window else min(es.window_bytes(jobs[idx]), args.window_cap)))
+                segs.append((int(idx[0]), len(idx), s_))
         d_jobs.append(torch.from_numpy(jobs.view(np.uint8).reshape(len(jobs), -1).copy()).to(dev))
         d_res.append(torch.zeros((len(jobs), RESULT_DTYPE.itemsize), dtype=torch.uint8, device=dev))
     njobs = len(host_jobs[0])
@@ -109,7 +109,7 @@ def main():
         for i in range(B):
             for (first, cnt, win) in segs:
                 es.search_batch_dev(planes[i + 1], planes[i], d_jobs[i].data_ptr() + first * 40, cnt,
-                                    d_res[i].data_ptr() + first * 16, QP, method, SUBME, window_bytes=win)
+                                    d_res[i].data_ptr() + first * 16, QP, method, SUBME, max_pu_dim=win)
         if k is not None:
             ev1[k].record(s_search)
         es.sync()

@@ -113,15 +113,14 @@ int x265amd_search_batch(x265amd_ctx *ctx, const x265amd_plane *fenc, const x265
                          int qp, int method, int subme,
                          const x265amd_job *jobs, int njobs, x265amd_result *results);
 /* Same, with jobs and results already in DEVICE memory; asynchronous on the
- * engine's stream (x265amd_sync waits). `window_bytes` is the LDS budget per PU for
- * staging its reference window (x265amd_window_bytes gives what a job needs; 0 disables
- * staging; jobs that need more read through L2 instead, with identical results). It trades
- * occupancy for latency: a CU has 160 KB of LDS. Planes must be readable 32 bytes past
- * their last sample (planes made by this library are). */
+ * engine's stream (x265amd_sync waits). The jobs are not validated. `max_pu_dim` (8, 16, 32,
+ * 64; 0 = 64) is the largest PU width / height in the batch: LDS per PU is reserved for that
+ * size, so batches of small PUs keep more PUs resident per CU; a larger job in the batch gets
+ * cost -1 and is not searched. Planes must be readable 32 bytes past their last sample
+ * (planes made by this library are). */
 int x265amd_search_batch_dev(x265amd_ctx *ctx, const x265amd_plane *fenc, const x265amd_plane *ref, int is_lowres,
                              int qp, int method, int subme,
-                             const x265amd_job *d_jobs, int njobs, x265amd_result *d_results, int window_bytes);
-int x265amd_window_bytes(const x265amd_ctx *ctx, const x265amd_job *job);
+                             const x265amd_job *d_jobs, int njobs, x265amd_result *d_results, int max_pu_dim);
 int x265amd_sync(x265amd_ctx *ctx);
 
 /* MotionEstimate::subpelCompare (encoder/motion.cpp:1651-1689) for njobs PUs:

@@ -16,13 +16,16 @@ using namespace x265amd;
 
 /* ------------------------------------------------------------------ kernels */
 
-/* XCD-aware job order: consecutive workgroup ids land on different XCDs (each with
- * its own L2), so ids are remapped to give every XCD one contiguous run of jobs --
- * neighbouring PUs read overlapping reference windows and then share an L2. */
+/* XCD-aware job order: consecutive workgroup ids land on different XCDs (each with its
+ * own L2). Jobs are dealt to the XCDs in runs of 32 neighbours, so PUs that read
+ * overlapping reference pixels share an L2 while every XCD still sees the same mix of
+ * PU sizes (a batch usually lists the large, expensive PUs first). */
 __device__ __forceinline__ int xcd_remap(int bid, int n)
 {
-    const int q = n >> 3, r = n & 7, x = bid & 7;
-    return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (bid >> 3);
+    const int C = 32;
+    if (bid >= (n & ~(8 * C - 1))) return bid;
+    const int x = bid & 7, i = bid >> 3;
+    return ((i / C) * 8 + x) * C + (i % C);
 }
 
 struct SearchArgs
@@ -34,7 +37,7 @@ struct SearchArgs
     const x265amd_job *jobs;
     x265amd_result *results;
     int njobs;
-    int win_cap;   /* bytes of LDS available for the staged reference window */
+    int max_dim;   /* largest PU width / height the launch reserved LDS for */
 };
 
 template<typename P, bool LOWRES>
@@ -44,14 +47,18 @@ __global__ __launch_bounds__(64) void search_kernel(SearchArgs a)
     if (j >= a.njobs) return;
     const x265amd_job *job = a.jobs + j;
     Searcher<P, LOWRES ? 8 : 64, LOWRES> S;
-    /* window: every full-pel candidate in [mvmin - 3, mvmax + 3] (hexagon / square steps are
-     * unchecked) plus the 8-tap footprint of the sub-pel points around them */
     const int w = job->w, h = job->h;
-    if (LOWRES)
-        S.bind(0, a.fenc, a.ref, a.nref, a.ctab, a.depth, job->pu_x, job->pu_y, w, h);
-    else
-        S.bind(0, a.fenc, a.ref, a.nref, a.ctab, a.depth, job->pu_x, job->pu_y, w, h,
-               job->mvmin[0] - 8, job->mvmin[1] - 8, job->mvmax[0] + w + 8, job->mvmax[1] + h + 8, a.win_cap);
+    if (w > a.max_dim || h > a.max_dim)
+    {
+        /* the launch did not reserve LDS for a PU this large */
+        if (threadIdx.x == 0)
+        {
+            x265amd_result r = { { 0, 0 }, -1, 0, 0 };
+            a.results[j] = r;
+        }
+        return;
+    }
+    S.bind(0, a.fenc, a.ref, a.nref, a.ctab, a.depth, job->pu_x, job->pu_y, w, h, a.max_dim, plane_budget(a.max_dim));
     S.search(job, a.method, a.subme, a.results + j);
 }
 
@@ -63,7 +70,7 @@ __global__ __launch_bounds__(64) void subpel_compare_kernel(SearchArgs a, int cm
     if (j >= a.njobs) return;
     const x265amd_job *job = a.jobs + j;
     Searcher<P, 64> S;
-    S.bind(0, a.fenc, a.ref, a.nref, a.ctab, a.depth, job->pu_x, job->pu_y, job->w, job->h);
+    S.bind(0, a.fenc, a.ref, a.nref, a.ctab, a.depth, job->pu_x, job->pu_y, job->w, job->h, 64, plane_budget(64));
     S.nsad = S.nsub = 0;
     S.put(0, job->qmvp[0], job->qmvp[1], job->qmvp[0], job->qmvp[1], 0, 0);
     S.eval(1, cmp ? 2 : 1, false);
@@ -356,11 +363,8 @@ __global__ __launch_bounds__(64) void rk_cu_kernel(RkArgs a)
                 S.put(k, tx, ty, tx, ty, 16, 0);
             }
             S.eval(16, 0, true);
-            for (int k = 0; k < 16; k++)
-            {
-                const int c = S.cost_of(k);
-                if (c < bcost) { bcost = c; bx = S.mvx_of(k); by = S.mvy_of(k); }
-            }
+            const int kb = S.fold_min(16, bcost);
+            if (kb >= 0) { bx = S.mvx_of(kb); by = S.mvy_of(kb); }
         }
     if (lane == 0) { res.rime[idx].mv[0] = (int16_t)bx; res.rime[idx].mv[1] = (int16_t)by; res.rime[idx].cost = bcost; }
     const int BX = as_i16(bx << 2), BY = as_i16(by << 2);
@@ -376,11 +380,8 @@ __global__ __launch_bounds__(64) void rk_cu_kernel(RkArgs a)
             S.put(k, qx, qy, qx, qy, 16, 0);
         }
         S.eval(n, 3, true);
-        for (int k = 0; k < n; k++)
-        {
-            const int c = S.cost_of(k);
-            if (c < bcost) { bcost = c; fx = S.mvx_of(k); fy = S.mvy_of(k); }
-        }
+        const int kb = S.fold_min(n, bcost);
+        if (kb >= 0) { fx = S.mvx_of(kb); fy = S.mvy_of(kb); }
     }
     if (lane == 0) { res.fme[idx].mv[0] = (int16_t)fx; res.fme[idx].mv[1] = (int16_t)fy; res.fme[idx].cost = bcost; }
 }
@@ -580,10 +581,15 @@ static int ensure(x265amd_ctx *c, void **p, size_t *cap, size_t need)
     return 0;
 }
 
-template<typename K>
-static hipError_t allow_big_lds(K kernel)
+template<typename P>
+static int launch_search(x265amd_ctx *c, const SearchArgs &a, int is_lowres)
 {
-    return hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (is_lowres)
+        hipLaunchKernelGGL((search_kernel<P, true>), dim3(a.njobs), dim3(64), wave_lds_bytes<P>(8), c->stream, a);
+    else
+        hipLaunchKernelGGL((search_kernel<P, false>), dim3(a.njobs), dim3(64), wave_lds_bytes<P>(a.max_dim, true), c->stream, a);
+    HIPCHK(c, hipGetLastError());
+    return X265AMD_OK;
 }
 
 extern "C" {
@@ -817,28 +823,20 @@ static void fill_args(x265amd_ctx *c, SearchArgs &a, const x265amd_plane *fenc, 
         const x265amd_plane *r = &ref[i < a.nref ? i : 0];
         a.ref[i].origin = r->origin; a.ref[i].stride = r->stride;
     }
-    a.lowres = is_lowres; a.depth = c->depth; a.method = method; a.subme = subme; a.win_cap = 0;
+    a.lowres = is_lowres; a.depth = c->depth; a.method = method; a.subme = subme; a.max_dim = is_lowres ? 8 : 64;
     a.ctab = c->tables[qp] + 32768;
 }
 
-/* LDS bytes needed to stage the reference window of one job (see Searcher::bind) */
-static int job_window_bytes(const x265amd_job &j, int bps)
-{
-    const int epc = 16 / bps;
-    const int ww = (j.mvmax[0] - j.mvmin[0]) + j.w + 16, rows = (j.mvmax[1] - j.mvmin[1]) + j.h + 16;
-    const int wstride = ((ww + 4 + epc - 1) / epc) * epc;
-    return wstride * rows * bps + 16;
-}
-
-#define MAX_WINDOW_BYTES (150 * 1024)
-
 int x265amd_search_batch_dev(x265amd_ctx *c, const x265amd_plane *fenc, const x265amd_plane *ref, int is_lowres,
                              int qp, int method, int subme, const x265amd_job *d_jobs, int njobs, x265amd_result *d_results,
-                             int window_bytes)
+                             int max_pu_dim)
 {
     if (!c || !fenc || !ref || !d_jobs || !d_results || njobs < 0) return fail(c, X265AMD_EINVAL, "null argument");
     if (method < 0 || method > X265AMD_FULL || subme < 0 || subme > 7)
         return fail(c, X265AMD_EINVAL, "bad method / subme");
+    if (max_pu_dim == 0) max_pu_dim = 64;
+    if (!(max_pu_dim == 8 || max_pu_dim == 16 || max_pu_dim == 32 || max_pu_dim == 64))
+        return fail(c, X265AMD_EINVAL, "max_pu_dim must be 0, 8, 16, 32 or 64");
     int rc = x265amd_set_qp(c, qp);
     if (rc) return rc;
     if (!njobs) return X265AMD_OK;
@@ -846,36 +844,8 @@ int x265amd_search_batch_dev(x265amd_ctx *c, const x265amd_plane *fenc, const x2
     SearchArgs a;
     fill_args(c, a, fenc, ref, is_lowres, qp, method, subme);
     a.jobs = d_jobs; a.results = d_results; a.njobs = njobs;
-    if (window_bytes < 0 || window_bytes > MAX_WINDOW_BYTES) return fail(c, X265AMD_EINVAL, "window_bytes out of range");
-    a.win_cap = is_lowres ? 0 : window_bytes;
-    if (c->depth <= 8)
-    {
-        const size_t lds = wave_lds_bytes<uint8_t>(is_lowres ? 8 : 64) + a.win_cap;
-        if (is_lowres) hipLaunchKernelGGL((search_kernel<uint8_t, true>), dim3(njobs), dim3(64), lds, c->stream, a);
-        else
-        {
-            HIPCHK(c, allow_big_lds(search_kernel<uint8_t, false>));
-            hipLaunchKernelGGL((search_kernel<uint8_t, false>), dim3(njobs), dim3(64), lds, c->stream, a);
-        }
-    }
-    else
-    {
-        const size_t lds = wave_lds_bytes<uint16_t>(is_lowres ? 8 : 64) + a.win_cap;
-        if (is_lowres) hipLaunchKernelGGL((search_kernel<uint16_t, true>), dim3(njobs), dim3(64), lds, c->stream, a);
-        else
-        {
-            HIPCHK(c, allow_big_lds(search_kernel<uint16_t, false>));
-            hipLaunchKernelGGL((search_kernel<uint16_t, false>), dim3(njobs), dim3(64), lds, c->stream, a);
-        }
-    }
-    HIPCHK(c, hipGetLastError());
-    return X265AMD_OK;
-}
-
-int x265amd_window_bytes(const x265amd_ctx *c, const x265amd_job *job)
-{
-    if (!c || !job) return X265AMD_EINVAL;
-    return job_window_bytes(*job, c->depth > 8 ? 2 : 1);
+    if (!is_lowres) a.max_dim = max_pu_dim;
+    return c->depth <= 8 ? launch_search<uint8_t>(c, a, is_lowres) : launch_search<uint16_t>(c, a, is_lowres);
 }
 
 int x265amd_sync(x265amd_ctx *c)
@@ -897,19 +867,15 @@ int x265amd_search_batch(x265amd_ctx *c, const x265amd_plane *fenc, const x265am
     if ((rc = ensure(c, &c->d_jobs, &c->jobs_cap, (size_t)njobs * sizeof(x265amd_job)))) return rc;
     if ((rc = ensure(c, &c->d_results, &c->results_cap, (size_t)njobs * sizeof(x265amd_result)))) return rc;
     HIPCHK(c, hipMemcpyAsync(c->d_jobs, jobs, (size_t)njobs * sizeof(x265amd_job), hipMemcpyHostToDevice, c->stream));
-    /* stage windows in LDS when the largest one leaves room for at least 4 PUs per CU */
-    int win = 0;
-    if (!is_lowres)
+    /* LDS per PU is sized for the largest PU of the batch */
+    int dim = 8;
+    for (int i = 0; i < njobs; i++)
     {
-        for (int i = 0; i < njobs; i++)
-        {
-            const int b = job_window_bytes(jobs[i], c->depth > 8 ? 2 : 1);
-            if (b > win) win = b;
-        }
-        if (win > 36 * 1024) win = 36 * 1024;   /* larger windows fall back to L2 reads inside the kernel */
+        const int d = jobs[i].w > jobs[i].h ? jobs[i].w : jobs[i].h;
+        while (dim < d) dim <<= 1;
     }
     rc = x265amd_search_batch_dev(c, fenc, ref, is_lowres, qp, method, subme, (const x265amd_job*)c->d_jobs, njobs,
-                                  (x265amd_result*)c->d_results, win);
+                                  (x265amd_result*)c->d_results, dim);
     if (rc) return rc;
     HIPCHK(c, hipMemcpyAsync(results, c->d_results, (size_t)njobs * sizeof(x265amd_result), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -933,9 +899,9 @@ int x265amd_subpel_compare_batch(x265amd_ctx *c, const x265amd_plane *fenc, cons
     fill_args(c, a, fenc, ref, 0, 12, 0, 0);
     a.jobs = (const x265amd_job*)c->d_jobs; a.results = (x265amd_result*)c->d_results; a.njobs = njobs;
     if (c->depth <= 8)
-        hipLaunchKernelGGL(subpel_compare_kernel<uint8_t>, dim3(njobs), dim3(64), wave_lds_bytes<uint8_t>(64), c->stream, a, cmp);
+        hipLaunchKernelGGL(subpel_compare_kernel<uint8_t>, dim3(njobs), dim3(64), wave_lds_bytes<uint8_t>(64, true), c->stream, a, cmp);
     else
-        hipLaunchKernelGGL(subpel_compare_kernel<uint16_t>, dim3(njobs), dim3(64), wave_lds_bytes<uint16_t>(64), c->stream, a, cmp);
+        hipLaunchKernelGGL(subpel_compare_kernel<uint16_t>, dim3(njobs), dim3(64), wave_lds_bytes<uint16_t>(64, true), c->stream, a, cmp);
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipMemcpyAsync(results, c->d_results, (size_t)njobs * sizeof(x265amd_result), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));

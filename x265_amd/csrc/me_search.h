@@ -48,12 +48,16 @@ enum
     L_MVX = 128, L_MVY = 192,    /* MV charged for the candidate (same units) */
     L_SH = 256,                  /* left shift applied to mv before the cost lookup, + flavour flags */
     L_META = 320, L_COSTS = 384,
-    L_CTX = 448,                 /* EvalCtx */
-    L_FENC = 704                 /* source PU, row pitch 64 samples (FENC_STRIDE) */
+    L_CPL = 448,                 /* sub-pel candidates: plane | (row + 16) << 8 | yfrac << 16 | satd << 18 */
+    L_CLIST = 512,               /* candidates served by the planes currently in LDS */
+    L_PDESC = 576,               /* MAXC plane descriptors of 32 bytes */
+    L_TAPS = 1088,               /* 4 phases x 12 dwords of packed filter taps */
+    L_CTX = 1280,                /* EvalCtx */
+    L_FENC = 1536                /* source PU, row pitch 64 samples (FENC_STRIDE) */
 };
 
-/* Everything the batched evaluation needs, parked in LDS so that the evaluation routine
- * is an ordinary function of (base, K, mode) and the search logic stays in registers. */
+/* Everything the batched evaluation needs, parked in LDS so that the evaluation routines
+ * are ordinary functions of (base, K, mode) and the search logic stays in registers. */
 struct EvalCtx
 {
     unsigned long long ref[4];   /* global addresses of the plane origins */
@@ -62,20 +66,116 @@ struct EvalCtx
     int rstride, w, h, T, Tp, lTp, wt, inv_wt, depth;
     int mvpx, mvpy;
     int rk_have_mvd, rk_mvp[3][2];
-    /* staged reference window: PU-relative [wx0, wx1) x [wy0, wy1), row pitch wstride samples,
-     * at byte offset woff from the wave's base; wx1 <= wx0 when nothing is staged */
-    int wx0, wy0, wx1, wy1, wstride, woff;
+    int planes_off, plane_budget; /* LDS area for the interpolation planes of the sub-pel stage */
 };
 
 __device__ __forceinline__ int *lds_i(int base, int off) { return (int*)(x265amd_smem + base + off); }
 __device__ __forceinline__ EvalCtx *lds_ctx(int base) { return (EvalCtx*)(x265amd_smem + base + L_CTX); }
+__device__ __forceinline__ unsigned long long uni64(unsigned long long v)
+{
+    return ((unsigned long long)(unsigned)uni((int)(v >> 32)) << 32) | (unsigned)uni((int)v);
+}
 
-template<typename P> constexpr int wave_lds_bytes(int rows) { return L_FENC + rows * 64 * (int)sizeof(P); }
+/* LDS bytes of the interpolation planes for PUs up to dim x dim: one plane is w columns of
+ * (h + 10) int16 rows; small PUs keep all (up to six) planes of a refinement round at once,
+ * large ones work through them one or two at a time. */
+constexpr int plane_bytes(int dim) { return dim * ((dim + 10) & ~1) * 2; }
+constexpr int plane_budget(int dim)
+{
+    return plane_bytes(dim) > 6144 ? plane_bytes(dim) : (6 * plane_bytes(dim) < 6144 ? 6 * plane_bytes(dim) : 6144);
+}
+/* per-wave LDS: candidate arrays + context + source block of `rows` rows [+ planes] */
+template<typename P> constexpr int wave_lds_bytes(int rows, bool planes = false)
+{
+    return L_FENC + rows * 64 * (int)sizeof(P) + (planes ? plane_budget(rows) + 16 : 0);
+}
 
-/* cost of tile t of candidate k. mode 0: full-pel SAD at offset (sx, sy); mode 1 / 2: SAD /
- * SATD at qpel MV (sx, sy) through subpelCompare or lowresQPelCost; mode 3: Rockchip FME */
+/* sum over each group of 2^l adjacent lanes, left in every lane of the group */
+__device__ __forceinline__ int seg_sum(int v, int l)
+{
+    if (l >= 1) v += __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xf, 0xf, false);  /* quad_perm [1,0,3,2] */
+    if (l >= 2) v += __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xf, 0xf, false);  /* quad_perm [2,3,0,1] */
+    if (l >= 3) v += __builtin_amdgcn_update_dpp(0, v, 0x141, 0xf, 0xf, false); /* row_half_mirror */
+    if (l >= 4) v += __builtin_amdgcn_update_dpp(0, v, 0x140, 0xf, 0xf, false); /* row_mirror */
+    if (l >= 5) v += __shfl_xor(v, 16);
+    if (l >= 6) v += __shfl_xor(v, 32);
+    return v;
+}
+
+/* minimum over each row of 16 lanes */
+__device__ __forceinline__ int row_min16(int v)
+{
+    int o;
+    o = __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xf, 0xf, false); v = o < v ? o : v;
+    o = __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xf, 0xf, false); v = o < v ? o : v;
+    o = __builtin_amdgcn_update_dpp(0, v, 0x141, 0xf, 0xf, false); v = o < v ? o : v;
+    o = __builtin_amdgcn_update_dpp(0, v, 0x140, 0xf, 0xf, false); v = o < v ? o : v;
+    return v;
+}
+
+/* lambda * bits term of candidate `lane` (0 for lanes that have none) */
+__device__ __forceinline__ int gather_mvcost(int base, int K, int mode, int addmv)
+{
+    const int lane = threadIdx.x & 63;
+    const EvalCtx *cx = lds_ctx(base);
+    int mvc = 0;
+    /* mode < 0: mixed batch, candidate k carries its own mode in meta bits 0-3 and its
+     * "add mvcost" flag in bit 4 */
+    if (lane < K && (mode < 0 ? (lds_i(base, L_META)[lane] >> 4) & 1 : addmv))
+    {
+        const uint16_t AS1 *ctab = (const uint16_t AS1*)uni64(cx->ctab);
+        const int mvpx = uni(cx->mvpx), mvpy = uni(cx->mvpy);
+        const int s = lds_i(base, L_SH)[lane];
+        const int mx = lds_i(base, L_MVX)[lane], my = lds_i(base, L_MVY)[lane];
+        if (s & 16)
+        {
+            /* Rockchip stages: min over three predictors, each sum truncated to uint16
+             * (motion.cpp:1284-1292) */
+            if (uni(cx->rk_have_mvd))
+            {
+                mvc = 0x7fffffff;
+#pragma unroll
+                for (int k = 0; k < 3; k++)
+                {
+                    const int v = ((int)ctab[mx - uni(cx->rk_mvp[k][0])] + (int)ctab[my - uni(cx->rk_mvp[k][1])]) & 0xffff;
+                    mvc = v < mvc ? v : mvc;
+                }
+            }
+        }
+        else if (s & 8)
+            /* UMH hexagon grid: table entries added as ints, MV * 4 without the int16 wrap
+             * (ADD_MVCOST, motion.cpp:856) */
+            mvc = (int)ctab[mx * 4 - mvpx] + (int)ctab[my * 4 - mvpy];
+        else
+            /* bitcost.h:46 -- the sum is truncated to uint16 */
+            mvc = ((int)ctab[as_i16(mx << s) - mvpx] + (int)ctab[as_i16(my << s) - mvpy]) & 0xffff;
+    }
+    return mvc;
+}
+
+/* wave-uniform geometry of the PU, pulled from the LDS context into scalar registers */
+struct Geo
+{
+    const void AS1 *ref[4];
+    long roff;
+    int rstride, T, Tp, lTp, wt, inv_wt, depth;
+    template<bool ALLREFS> __device__ __forceinline__ void load(int base)
+    {
+        const EvalCtx *cx = lds_ctx(base);
+        ref[0] = (const void AS1*)uni64(cx->ref[0]);
+        if (ALLREFS)
+            for (int i = 1; i < 4; i++) ref[i] = (const void AS1*)uni64(cx->ref[i]);
+        roff = (long)uni64((unsigned long long)cx->roff);
+        rstride = uni(cx->rstride); T = uni(cx->T); Tp = uni(cx->Tp); lTp = uni(cx->lTp);
+        wt = uni(cx->wt); inv_wt = uni(cx->inv_wt); depth = uni(cx->depth);
+    }
+};
+
+/* cost of tile t of candidate k measured by one lane on its own. mode 0: full-pel SAD at
+ * offset (sx, sy); mode 1 / 2 (lookahead only): SAD / SATD at qpel MV (sx, sy) through
+ * lowresQPelCost; mode 3: Rockchip FME */
 template<typename P, bool LOWRES, bool RK>
-__device__ __forceinline__ int tile_cost(int base, const EvalCtx &c, int k, int t, int mode)
+__device__ __forceinline__ int tile_cost(int base, const Geo &c, int k, int t, int mode)
 {
     const int ty = (t * c.inv_wt) >> 16, tx = t - ty * c.wt;
     typename Px<P>::quad f[4], q[4];
@@ -85,19 +185,9 @@ __device__ __forceinline__ int tile_cost(int base, const EvalCtx &c, int k, int 
     const P AS1 *ref0 = (const P AS1*)c.ref[0];
     if (mode == 0)
     {
-        const int X = cx + tx * 4, Y = cy + ty * 4;
-        if (X >= c.wx0 && X + 4 <= c.wx1 && Y >= c.wy0 && Y + 4 <= c.wy1)
-        {
-            const int o = base + c.woff + ((Y - c.wy0) * c.wstride + (X - c.wx0)) * (int)sizeof(P);
+        const P AS1 *r = ref0 + c.roff + (long)(cy + ty * 4) * c.rstride + cx + tx * 4;
 #pragma unroll
-            for (int y = 0; y < 4; y++) q[y] = Px<P>::load_lds(o + y * c.wstride * (int)sizeof(P));
-        }
-        else
-        {
-            const P AS1 *r = ref0 + c.roff + (long)Y * c.rstride + X;
-#pragma unroll
-            for (int y = 0; y < 4; y++) q[y] = Px<P>::load_g(r + y * c.rstride);
-        }
+        for (int y = 0; y < 4; y++) q[y] = Px<P>::load_g(r + y * c.rstride);
         return tile_cost_quads<P>(f, q, false);
     }
     if constexpr (LOWRES)
@@ -118,101 +208,123 @@ __device__ __forceinline__ int tile_cost(int base, const EvalCtx &c, int k, int 
         }
         return tile_cost_quads<P>(f, q, satd);
     }
-    else
+    else if constexpr (RK)
     {
         const int xf = cx & 3, yf = cy & 3;
-        const int X = (cx >> 2) + tx * 4, Y = (cy >> 2) + ty * 4;
-        /* footprint of the 8-tap filters: 3 left / above, 4 right / below, + the 4-byte over-read */
-        const bool inwin = X - 3 >= c.wx0 && X + 9 <= c.wx1 && Y - 3 >= c.wy0 && Y + 8 <= c.wy1;
+        GlobalLoader<P> ld = { ref0 + c.roff + (long)((cy >> 2) + ty * 4) * c.rstride + (cx >> 2) + tx * 4, c.rstride };
+        if ((xf | yf) == 0)
+        {
+#pragma unroll
+            for (int y = 0; y < 4; y++) q[y] = ld(0, y);
+            return tile_cost_quads<P>(f, q, true);
+        }
         int o[4][4];
-        if (inwin)
-        {
-            LdsLoader<P> ld = { base + c.woff + ((Y - c.wy0) * c.wstride + (X - c.wx0)) * (int)sizeof(P), c.wstride };
-            if ((xf | yf) == 0)
-            {
-#pragma unroll
-                for (int y = 0; y < 4; y++) q[y] = ld(0, y);
-                return tile_cost_quads<P>(f, q, mode >= 2);
-            }
-            if constexpr (RK) rk_interp_tile<P>(ld, xf, yf, c.depth, o);
-            else interp_tile<P>(ld, xf, yf, c.depth, o);
-        }
-        else
-        {
-            GlobalLoader<P> ld = { ref0 + c.roff + (long)Y * c.rstride + X, c.rstride };
-            if ((xf | yf) == 0)
-            {
-#pragma unroll
-                for (int y = 0; y < 4; y++) q[y] = ld(0, y);
-                return tile_cost_quads<P>(f, q, mode >= 2);
-            }
-            if constexpr (RK) rk_interp_tile<P>(ld, xf, yf, c.depth, o);
-            else interp_tile<P>(ld, xf, yf, c.depth, o);
-        }
-        return tile_cost_px<P>(f, o, mode >= 2);
+        rk_interp_tile<P>(ld, xf, yf, c.depth, o);
+        return tile_cost_px<P>(f, o, true);
     }
+    else
+        return 0;   /* sub-pel points of the classic path go through eval_planes */
 }
 
-/* costs[k] = distortion(k) [+ mvcost(mv[k] << sh[k])] for k < K. One call per decision
- * point of the search; (candidate, tile) pairs are spread over the lanes. */
+/* costs[k] = distortion(k) [+ mvcost(mv[k] << sh[k])] for k < K, every (candidate, tile) pair
+ * measured independently by one lane. Serves all full-pel batches, and the sub-pel batches
+ * of the lookahead (half-pel planes) and Rockchip (4-tap) flavours. */
 template<typename P, bool LOWRES, bool RK>
 __device__ __noinline__ void eval_batch(int base, int K, int mode, int addmv)
 {
     wave_sync();
-    EvalCtx c;
-    {
-        /* the context is wave-uniform: pull it into scalar registers */
-        const int *src = (const int*)lds_ctx(base);
-        int *dst = (int*)&c;
-#pragma unroll
-        for (int i = 0; i < (int)(sizeof(EvalCtx) / 4); i++) dst[i] = uni(src[i]);
-    }
+    Geo c;
+    c.load<LOWRES>(base);
     const int lane = threadIdx.x & 63;
     /* the lambda * bits term of candidate `lane` is gathered first so that its table loads
      * overlap the distortion work */
-    /* mode < 0: mixed batch, candidate k carries its own mode in meta bits 0-3 and its
-     * "add mvcost" flag in bit 4 */
     const bool mixed = mode < 0;
-    int mvc = 0;
-    if (lane < K && (mixed ? (lds_i(base, L_META)[lane] >> 4) & 1 : addmv))
-    {
-        const uint16_t AS1 *ctab = (const uint16_t AS1*)c.ctab;
-        const int s = lds_i(base, L_SH)[lane];
-        const int mx = lds_i(base, L_MVX)[lane], my = lds_i(base, L_MVY)[lane];
-        if (s & 16)
-        {
-            /* Rockchip stages: min over three predictors, each sum truncated to uint16
-             * (motion.cpp:1284-1292) */
-            if (c.rk_have_mvd)
-            {
-                mvc = 0x7fffffff;
-#pragma unroll
-                for (int k = 0; k < 3; k++)
-                {
-                    const int v = ((int)ctab[mx - c.rk_mvp[k][0]] + (int)ctab[my - c.rk_mvp[k][1]]) & 0xffff;
-                    mvc = v < mvc ? v : mvc;
-                }
-            }
-        }
-        else if (s & 8)
-            /* UMH hexagon grid: table entries added as ints, MV * 4 without the int16 wrap
-             * (ADD_MVCOST, motion.cpp:856) */
-            mvc = (int)ctab[mx * 4 - c.mvpx] + (int)ctab[my * 4 - c.mvpy];
-        else
-            /* bitcost.h:46 -- the sum is truncated to uint16 */
-            mvc = ((int)ctab[as_i16(mx << s) - c.mvpx] + (int)ctab[as_i16(my << s) - c.mvpy]) & 0xffff;
-    }
+    const int mvc = gather_mvcost(base, K, mode, addmv);
     if (c.Tp <= 64)
     {
         const int g = lane >> c.lTp, t = lane & (c.Tp - 1);
         const int cpp = 64 >> c.lTp;
-        for (int k0 = 0; k0 < K; k0 += cpp)
+        if (mode == 0)
         {
-            const int k = k0 + g;
+            /* full-pel SAD: the lane's source tile is loaded once; two passes are issued back
+             * to back so that their reference loads are in flight together */
+            const int tt = t < c.T ? t : 0;
+            const int ty = (tt * c.inv_wt) >> 16, tx = tt - ty * c.wt;
+            typename Px<P>::quad f[4];
+#pragma unroll
+            for (int y = 0; y < 4; y++) f[y] = Px<P>::load_lds_aligned(base + L_FENC + ((ty * 4 + y) * 64 + tx * 4) * (int)sizeof(P));
+            const P AS1 *r0 = (const P AS1*)c.ref[0] + c.roff + (long)(ty * 4) * c.rstride + tx * 4;
+            for (int k0 = 0; k0 < K; k0 += 2 * cpp)
+            {
+                typename Px<P>::quad q[2][4];
+                int kk[2];
+#pragma unroll
+                for (int u = 0; u < 2; u++)
+                {
+                    kk[u] = k0 + u * cpp + g;
+                    const int kc = kk[u] < K ? kk[u] : K - 1;
+                    const P AS1 *r = r0 + (long)lds_i(base, L_SY)[kc] * c.rstride + lds_i(base, L_SX)[kc];
+#pragma unroll
+                    for (int y = 0; y < 4; y++) q[u][y] = Px<P>::load_g(r + y * c.rstride);
+                }
+#pragma unroll
+                for (int u = 0; u < 2; u++)
+                {
+                    int v = 0;
+#pragma unroll
+                    for (int y = 0; y < 4; y++) v = Px<P>::sad(f[y], q[u][y], v);
+                    v = (kk[u] < K && t < c.T) ? v : 0;
+                    v = seg_sum(v, c.lTp);
+                    if (t == 0 && kk[u] < K) lds_i(base, L_COSTS)[kk[u]] = v;
+                }
+            }
+        }
+        else
+            for (int k0 = 0; k0 < K; k0 += cpp)
+            {
+                const int k = k0 + g;
+                int v = 0;
+                if (k < K && t < c.T) v = tile_cost<P, LOWRES, RK>(base, c, k, t, mixed ? lds_i(base, L_META)[k] & 15 : mode);
+                v = seg_sum(v, c.lTp);
+                if (t == 0 && k < K) lds_i(base, L_COSTS)[k] = v;
+            }
+    }
+    else if (mode == 0)
+    {
+        /* more than 64 tiles (T is 128, 192 or 256): the lane's up to four source tiles stay in
+         * registers across candidates and all loads of a candidate are issued together */
+        typename Px<P>::quad f[4][4];
+        long toff[4];
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+        {
+            const int t = lane + 64 * i < c.T ? lane + 64 * i : lane;
+            const int ty = (t * c.inv_wt) >> 16, tx = t - ty * c.wt;
+            toff[i] = (long)(ty * 4) * c.rstride + tx * 4;
+#pragma unroll
+            for (int y = 0; y < 4; y++) f[i][y] = Px<P>::load_lds_aligned(base + L_FENC + ((ty * 4 + y) * 64 + tx * 4) * (int)sizeof(P));
+        }
+        const P AS1 *r0 = (const P AS1*)c.ref[0] + c.roff;
+        const int nt = c.T >> 6;
+        for (int k = 0; k < K; k++)
+        {
+            const P AS1 *r = r0 + (long)uni(lds_i(base, L_SY)[k]) * c.rstride + uni(lds_i(base, L_SX)[k]);
+            typename Px<P>::quad q[4][4];
+#pragma unroll
+            for (int i = 0; i < 4; i++)
+#pragma unroll
+                for (int y = 0; y < 4; y++) q[i][y] = Px<P>::load_g(r + toff[i] + y * c.rstride);
             int v = 0;
-            if (k < K && t < c.T) v = tile_cost<P, LOWRES, RK>(base, c, k, t, mixed ? lds_i(base, L_META)[k] & 15 : mode);
-            for (int o = 1; o < c.Tp; o <<= 1) v += __shfl_xor(v, o);
-            if (t == 0 && k < K) lds_i(base, L_COSTS)[k] = v;
+#pragma unroll
+            for (int i = 0; i < 4; i++)
+            {
+                int s = 0;
+#pragma unroll
+                for (int y = 0; y < 4; y++) s = Px<P>::sad(f[i][y], q[i][y], s);
+                v += i < nt ? s : 0;
+            }
+            v = seg_sum(v, 6);
+            if (lane == 0) lds_i(base, L_COSTS)[k] = v;
         }
     }
     else
@@ -222,11 +334,246 @@ __device__ __noinline__ void eval_batch(int base, int K, int mode, int addmv)
             int v = 0;
             const int km = mixed ? uni(lds_i(base, L_META)[k]) & 15 : mode;
             for (int t = lane; t < c.T; t += 64) v += tile_cost<P, LOWRES, RK>(base, c, k, t, km);
-            for (int o = 1; o < 64; o <<= 1) v += __shfl_xor(v, o);
+            v = seg_sum(v, 6);
             if (lane == 0) lds_i(base, L_COSTS)[k] = v;
         }
     }
     wave_sync();
+    if (lane < K) lds_i(base, L_COSTS)[lane] += mvc;
+    wave_sync();
+}
+
+/* ---- sub-pel batches of the classic path: separable interpolation through LDS planes ----
+ *
+ * subpelCompare (motion.cpp:1651-1689) filters every candidate block on its own. Here the
+ * candidates of a batch first share their horizontal pass: all candidates with the same qpel
+ * x (and the same kind of first pass) read one "plane" -- the horizontally filtered rows they
+ * need, computed once by the whole wave into LDS as int16, column-major so that vertically
+ * adjacent samples pair up in a dword. The vertical pass then runs per (candidate, 4x4 tile)
+ * lane on v_dot2_i32_i16, straight into the SAD / SATD against the source tile.
+ *
+ * Plane kinds (xf, yf = fractional parts of the candidate MV):
+ *   xf != 0, yf != 0  luma_hps intermediates (ipfilter.cpp:235-278), then luma_vsp (:359-400)
+ *   xf != 0, yf == 0  finished luma_hpp pixels (:194-233); the vertical pass is the identity
+ *   xf == 0           source pixels; the vertical pass is luma_vpp (:280-319) or the identity
+ * The identity is the phase-0 filter {0,0,0,64,0,0,0,0} followed by (x + 32) >> 6, so the
+ * vertical pass has one code path with per-lane taps, offset and shift. */
+
+typedef short s16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ int dot2(uint32_t a, uint32_t b, int c)
+{
+    return __builtin_amdgcn_sdot2(__builtin_bit_cast(s16x2, a), __builtin_bit_cast(s16x2, b), c, false);
+}
+
+/* four horizontally adjacent 8-tap sums; s points at the sample 3 to the left of the first */
+template<typename P> struct HFilter;
+template<> struct HFilter<uint8_t>
+{
+    static __device__ __forceinline__ void run(const uint8_t AS1 *s, const int *taps, int sum[4])
+    {
+        /* pixels are biased to signed bytes for v_dot4_i32_i8; the taps of every phase add up to
+         * 64, so the bias comes back as + 128 * 64 */
+        const uint32_t d0 = Px<uint8_t>::load_g(s) ^ 0x80808080u, d1 = Px<uint8_t>::load_g(s + 4) ^ 0x80808080u,
+                       d2 = Px<uint8_t>::load_g(s + 8) ^ 0x80808080u;
+        const int tlo = taps[9], thi = taps[10];
+        sum[0] = __builtin_amdgcn_sdot4(d0, tlo, __builtin_amdgcn_sdot4(d1, thi, 8192, false), false);
+#pragma unroll
+        for (int x = 1; x < 4; x++)
+            sum[x] = __builtin_amdgcn_sdot4(__builtin_amdgcn_alignbyte(d1, d0, x), tlo,
+                                            __builtin_amdgcn_sdot4(__builtin_amdgcn_alignbyte(d2, d1, x), thi, 8192, false), false);
+    }
+};
+template<> struct HFilter<uint16_t>
+{
+    static __device__ __forceinline__ void run(const uint16_t AS1 *s, const int *taps, int sum[4])
+    {
+        const uint2 a = Px<uint16_t>::load_g(s), b = Px<uint16_t>::load_g(s + 4), c = Px<uint16_t>::load_g(s + 8);
+        const uint32_t D[6] = { a.x, a.y, b.x, b.y, c.x, c.y };
+        uint32_t A[5];
+#pragma unroll
+        for (int i = 0; i < 5; i++) A[i] = __builtin_amdgcn_alignbit(D[i + 1], D[i], 16);
+        const uint32_t t0 = taps[0], t1 = taps[1], t2 = taps[2], t3 = taps[3];
+        sum[0] = dot2(D[0], t0, dot2(D[1], t1, dot2(D[2], t2, dot2(D[3], t3, 0))));
+        sum[1] = dot2(A[0], t0, dot2(A[1], t1, dot2(A[2], t2, dot2(A[3], t3, 0))));
+        sum[2] = dot2(D[1], t0, dot2(D[2], t1, dot2(D[3], t2, dot2(D[4], t3, 0))));
+        sum[3] = dot2(A[1], t0, dot2(A[2], t1, dot2(A[3], t2, dot2(A[4], t3, 0))));
+    }
+};
+
+/* vertical pass + cost of tile t of candidate k against the planes in LDS */
+template<typename P>
+__device__ __forceinline__ int plane_tile_cost(int base, int k, int t, int wt, int inv_wt, int depth)
+{
+    const int cpl = lds_i(base, L_CPL)[k];
+    const int *d = lds_i(base, L_PDESC + (cpl & 255) * 32);
+    const int ps = (d[1] >> 2) & 1, poff = d[3], prow = d[4];
+    const int ty = (t * inv_wt) >> 16, tx = t - ty * wt;
+    const int R = ((cpl >> 8) & 255) - 16 + 4 * ty;
+    const uint32_t sh16 = (R & 1) * 16;
+    const int *tp = lds_i(base, L_TAPS + ((cpl >> 16) & 3) * 48);
+    uint32_t ev[4], od[5];
+#pragma unroll
+    for (int i = 0; i < 4; i++) ev[i] = tp[i];
+#pragma unroll
+    for (int i = 0; i < 5; i++) od[i] = tp[4 + i];
+    const int headRoom = 14 - depth, maxv = (1 << depth) - 1;
+    const int shiftV = ps ? 6 + headRoom : 6;
+    const int offV = ps ? (1 << (5 + headRoom)) + (8192 << 6) : 32;
+    int o[4][4];
+#pragma unroll
+    for (int x = 0; x < 4; x++)
+    {
+        const uint32_t *col = (const uint32_t*)(x265amd_smem + base + poff + ((tx * 4 + x) * prow + (R & ~1)) * 2);
+        uint32_t E[7], e[6];
+#pragma unroll
+        for (int i = 0; i < 7; i++) E[i] = col[i];
+#pragma unroll
+        for (int i = 0; i < 6; i++) e[i] = __builtin_amdgcn_alignbit(E[i + 1], E[i], sh16);
+        const int s0 = dot2(e[0], ev[0], dot2(e[1], ev[1], dot2(e[2], ev[2], dot2(e[3], ev[3], offV))));
+        const int s1 = dot2(e[0], od[0], dot2(e[1], od[1], dot2(e[2], od[2], dot2(e[3], od[3], dot2(e[4], od[4], offV)))));
+        const int s2 = dot2(e[1], ev[0], dot2(e[2], ev[1], dot2(e[3], ev[2], dot2(e[4], ev[3], offV))));
+        const int s3 = dot2(e[1], od[0], dot2(e[2], od[1], dot2(e[3], od[2], dot2(e[4], od[3], dot2(e[5], od[4], offV)))));
+        o[0][x] = clip_pixel(as_i16(s0 >> shiftV), maxv);
+        o[1][x] = clip_pixel(as_i16(s1 >> shiftV), maxv);
+        o[2][x] = clip_pixel(as_i16(s2 >> shiftV), maxv);
+        o[3][x] = clip_pixel(as_i16(s3 >> shiftV), maxv);
+    }
+    typename Px<P>::quad f[4];
+#pragma unroll
+    for (int y = 0; y < 4; y++) f[y] = Px<P>::load_lds_aligned(base + L_FENC + ((ty * 4 + y) * 64 + tx * 4) * (int)sizeof(P));
+    return tile_cost_px<P>(f, o, (cpl >> 18) & 1);
+}
+
+/* costs[k] for K sub-pel (or mixed) candidates of the classic path; mode as in eval_batch */
+template<typename P>
+__device__ __noinline__ void eval_planes(int base, int K, int mode, int addmv)
+{
+    wave_sync();
+    const int lane = threadIdx.x & 63;
+    const EvalCtx *cx = lds_ctx(base);
+    const int mvc = gather_mvcost(base, K, mode, addmv);
+    const P AS1 *ref0 = (const P AS1*)uni64(cx->ref[0]) + (long)uni64((unsigned long long)cx->roff);
+    const int rstride = uni(cx->rstride), w = uni(cx->w), h = uni(cx->h), depth = uni(cx->depth);
+    const int T = uni(cx->T), lTp = uni(cx->lTp), wt = uni(cx->wt), inv_wt = uni(cx->inv_wt);
+    const int planes_off = uni(cx->planes_off), budget = uni(cx->plane_budget);
+
+    /* ---- plan: lane k describes candidate k, lane p collects plane p ---- */
+    int qx = 0, qy = 0, cm = 0;
+    if (lane < K)
+    {
+        qx = lds_i(base, L_SX)[lane]; qy = lds_i(base, L_SY)[lane];
+        cm = mode < 0 ? lds_i(base, L_META)[lane] & 15 : mode;
+        if (cm == 0) { qx <<= 2; qy <<= 2; }   /* full-pel member of a mixed batch */
+    }
+    const int yf = qy & 3, Y = qy >> 2;
+    const int key = (qx << 1) | ((qx & 3) && yf ? 1 : 0);
+    int pkey = 0, pymin = 0, pymax = 0, papron = 0, mypl = 0, np = 0;
+    for (int k = 0; k < K; k++)
+    {
+        const int kk = __builtin_amdgcn_readlane(key, k), kY = __builtin_amdgcn_readlane(Y, k);
+        const int kap = __builtin_amdgcn_readlane(yf, k) != 0;
+        const int nmin = pymin < kY ? pymin : kY, nmax = pymax > kY ? pymax : kY;
+        /* candidates share a plane when its rows grow by at most one */
+        const unsigned long long m = __ballot(lane < np && pkey == kk && nmax - nmin <= 1);
+        const int p = m ? (int)__builtin_ctzll(m) : np;
+        if (lane == p)
+        {
+            if (m) { pymin = nmin; pymax = nmax; papron |= kap; }
+            else { pkey = kk; pymin = pymax = kY; papron = kap; }
+        }
+        if (!m) np++;
+        if (lane == k) mypl = p;
+    }
+    const int pY0 = pymin - (papron ? 3 : 0);
+    const int pnrows = pymax - pymin + h + (papron ? 7 : 0);
+    const int pprow = (pnrows + 2) & ~1;
+    const int pbytes = w * pprow * 2, pitems = pnrows * wt;
+    {
+        const int Y0 = __shfl(pY0, mypl);
+        if (lane < K) lds_i(base, L_CPL)[lane] = mypl | ((Y - 3 - Y0 + 16) << 8) | (yf << 16) | ((cm == 2 ? 1 : 0) << 18);
+    }
+
+    const int headRoom = 14 - depth, maxv = (1 << depth) - 1;
+    const int shiftH = 6 - headRoom, offH = -(8192 << shiftH);
+    for (int p0 = 0; p0 < np;)
+    {
+        /* ---- the planes that fit in LDS together ---- */
+        int acc = 0, items = 0, p1 = p0, my_poff = 0, my_istart = 0;
+        while (p1 < np)
+        {
+            const int b = __builtin_amdgcn_readlane(pbytes, p1);
+            if (p1 > p0 && acc + b > budget) break;
+            if (lane == p1) { my_poff = acc; my_istart = items; }
+            acc += b;
+            items += __builtin_amdgcn_readlane(pitems, p1);
+            p1++;
+        }
+        if (lane >= p0 && lane < p1)
+        {
+            int *d = lds_i(base, L_PDESC + lane * 32);
+            const int pqx = pkey >> 1;
+            d[0] = pY0 * rstride + (pqx >> 2) - 3;
+            d[1] = (pqx & 3) | ((pkey & 1) << 2);
+            d[2] = my_istart; d[3] = planes_off + my_poff; d[4] = pprow;
+        }
+        const bool inch = lane < K && mypl >= p0 && mypl < p1;
+        const unsigned long long cmask = __ballot(inch);
+        const int nc = __builtin_popcountll(cmask);
+        if (inch) lds_i(base, L_CLIST)[__builtin_popcountll(cmask & ((1ull << lane) - 1))] = lane;
+        wave_sync();
+
+        /* ---- horizontal pass: one item = 4 adjacent samples of one plane row ---- */
+        for (int i0 = 0; i0 < items; i0 += 64)
+        {
+            const bool act = i0 + lane < items;
+            const int i = act ? i0 + lane : items - 1;
+            int p = p0;
+            for (int q = p0 + 1; q < p1; q++) p += i >= lds_i(base, L_PDESC + q * 32)[2] ? 1 : 0;
+            const int *d = lds_i(base, L_PDESC + p * 32);
+            const int xfps = d[1], li = i - d[2], poff = d[3], prow = d[4];
+            const int r = (li * inv_wt) >> 16, q4 = li - r * wt;
+            int sum[4];
+            HFilter<P>::run(ref0 + d[0] + (long)r * rstride + 4 * q4, lds_i(base, L_TAPS + (xfps & 3) * 48), sum);
+            const bool ps = xfps & 4;
+            const int off = ps ? offH : 32, sh = ps ? shiftH : 6, lo = ps ? -32768 : 0, hi = ps ? 32767 : maxv;
+            int16_t *dst = (int16_t*)(x265amd_smem + base + poff) + (4 * q4) * prow + r;
+            if (act)
+#pragma unroll
+                for (int x = 0; x < 4; x++)
+                {
+                    int v = as_i16((sum[x] + off) >> sh);
+                    v = v < lo ? lo : (v > hi ? hi : v);
+                    dst[x * prow] = (int16_t)v;
+                }
+        }
+        wave_sync();
+
+        /* ---- vertical pass + cost per (candidate, tile) ---- */
+        if (lTp <= 6)
+        {
+            const int g = lane >> lTp, t = lane & ((1 << lTp) - 1), cpp = 64 >> lTp;
+            for (int j0 = 0; j0 < nc; j0 += cpp)
+            {
+                const int j = j0 + g;
+                const bool act = j < nc && t < T;
+                const int k = lds_i(base, L_CLIST)[act ? j : 0];
+                int v = plane_tile_cost<P>(base, k, act ? t : 0, wt, inv_wt, depth);
+                v = seg_sum(act ? v : 0, lTp);
+                if (act && t == 0) lds_i(base, L_COSTS)[k] = v;
+            }
+        }
+        else
+            for (int j = 0; j < nc; j++)
+            {
+                const int k = uni(lds_i(base, L_CLIST)[j]);
+                int v = 0;
+                for (int t = lane; t < T; t += 64) v += plane_tile_cost<P>(base, k, t, wt, inv_wt, depth);
+                v = seg_sum(v, 6);
+                if (lane == 0) lds_i(base, L_COSTS)[k] = v;
+            }
+        wave_sync();
+        p0 = p1;
+    }
     if (lane < K) lds_i(base, L_COSTS)[lane] += mvc;
     wave_sync();
 }
@@ -243,8 +590,22 @@ struct Searcher
 
     __device__ __forceinline__ void eval(int K, int mode, bool addmv)
     {
-        eval_batch<P, LOWRES, RK>(base, K, mode, addmv ? 1 : 0);
-        if (mode == 0) nsad += K; else nsub += K;
+        /* sub-pel (and mixed) batches of the classic path interpolate through LDS planes */
+        if (!LOWRES && !RK && mode != 0) eval_planes<P>(base, K, mode, addmv ? 1 : 0);
+        else eval_batch<P, LOWRES, RK>(base, K, mode, addmv ? 1 : 0);
+        if (mode == 0) nsad += K; else if (mode > 0) nsub += K;
+    }
+
+    /* First minimum of costs[0..K) in index order if it beats bcost (the reference's chain of
+     * strict '<' tests); returns its index or -1. Costs stay below 2^26, so cost << 5 | index
+     * orders candidates exactly like the sequential scan. K <= MAXC = 16: one DPP row. */
+    __device__ __forceinline__ int fold_min(int K, int &bcost)
+    {
+        int key = 0x7fffffff;
+        if (lane < K) key = (lds_i(base, L_COSTS)[lane] << 5) | lane;
+        key = uni(row_min16(key));
+        if ((key >> 5) < bcost) { bcost = key >> 5; return key & 31; }
+        return -1;
     }
 
     __device__ __forceinline__ void put(int k, int sx_, int sy_, int mx_, int my_, int sh_, int meta_)
@@ -292,16 +653,12 @@ struct Searcher
     {
         if (!K) return;
         eval(K, 0, true);
-        for (int k = 0; k < K; k++)
+        const int k = fold_min(K, bcost);
+        if (k >= 0)
         {
-            const int c = cost_of(k);
-            if (c < bcost)
-            {
-                bcost = c;
-                bmx = mvx_of(k); bmy = mvy_of(k);
-                const int m = meta_of(k);
-                bPointNr = m & 0xff; bDistance = m >> 8;
-            }
+            bmx = mvx_of(k); bmy = mvy_of(k);
+            const int m = meta_of(k);
+            bPointNr = m & 0xff; bDistance = m >> 8;
         }
     }
 
@@ -608,7 +965,7 @@ struct Searcher
                 }
             }
         }
-        eval_batch<P, LOWRES, RK>(base, K, -1, 0);
+        eval(K, -1, false);
         int bprecost = cost_of(0);
         nsub++;
         int bcost = bprecost;
@@ -646,12 +1003,7 @@ struct Searcher
                 put(2, bmx - 1, bmy, as_i16(bmx - 1), as_i16(bmy), 2, 0);
                 put(3, bmx + 1, bmy, as_i16(bmx + 1), as_i16(bmy), 2, 0);
                 eval(4, 0, true);
-                int dir = -1;
-                for (int k = 0; k < 4; k++)
-                {
-                    const int c = cost_of(k);
-                    if (c < bcost) { bcost = c; dir = k; }
-                }
+                const int dir = fold_min(4, bcost);
                 if (dir < 0) break;
                 bmx = mvx_of(dir); bmy = mvy_of(dir);
             }
@@ -753,13 +1105,8 @@ struct Searcher
             for (int k = 0; k < 6; k++)
                 put(k, bmx + kHexRing[k][0], bmy + kHexRing[k][1], as_i16(bmx + kHexRing[k][0]), as_i16(bmy + kHexRing[k][1]), 2, 0);
             eval(6, 0, true);
-            int code = 0;
-            for (int k = 0; k < 6; k++)
-            {
-                const int c = cost_of(k);
-                if (c < bcost) { bcost = c; code = k + 2; }
-            }
-            if (code)
+            const int code = fold_min(6, bcost) + 2;
+            if (code > 1)
             {
                 int dir = code - 2;
                 bmx = as_i16(bmx + kHex2[dir + 1][0]); bmy = as_i16(bmy + kHex2[dir + 1][1]);
@@ -769,12 +1116,7 @@ struct Searcher
                         put(k, bmx + kHex2[dir + k][0], bmy + kHex2[dir + k][1],
                             as_i16(bmx + kHex2[dir + k][0]), as_i16(bmy + kHex2[dir + k][1]), 2, 0);
                     eval(3, 0, true);
-                    int step = 0;
-                    for (int k = 0; k < 3; k++)
-                    {
-                        const int c = cost_of(k);
-                        if (c < bcost) { bcost = c; step = k + 1; }
-                    }
+                    const int step = fold_min(3, bcost) + 1;
                     if (!step) break;
                     dir += step - 2;
                     dir = kMod6m1[dir + 1];
@@ -786,12 +1128,7 @@ struct Searcher
                 put(k - 1, bmx + kSquare1[k][0], bmy + kSquare1[k][1],
                     as_i16(bmx + kSquare1[k][0]), as_i16(bmy + kSquare1[k][1]), 2, 0);
             eval(8, 0, true);
-            int dir = 0;
-            for (int k = 0; k < 8; k++)
-            {
-                const int c = cost_of(k);
-                if (c < bcost) { bcost = c; dir = k + 1; }
-            }
+            const int dir = fold_min(8, bcost) + 1;
             bmx = as_i16(bmx + kSquare1[dir][0]); bmy = as_i16(bmy + kSquare1[dir][1]);
         }
 
@@ -854,21 +1191,16 @@ struct Searcher
             put(i - 1, tx, ty, tx, ty, 0, 0);
         }
         eval(dirs, mode, true);
-        int bdir = 0;
-        for (int i = 1; i <= dirs; i++)
-        {
-            const int c = cost_of(i - 1);
-            if (c < bcost) { bcost = c; bdir = i; }
-        }
+        const int bdir = fold_min(dirs, bcost) + 1;
         qx = as_i16(qx + kSquare1[bdir][0] * step); qy = as_i16(qy + kSquare1[bdir][1] * step);
     }
 
     /* bind to a PU: geometry, tile tables, the source block copy (setSourcePU,
-     * motion.cpp:116-142) and, when it fits in `win_cap` bytes, the reference window
-     * [x0, x1) x [y0, y1) (PU-relative) staged in LDS with 16-byte coalesced loads. */
+     * motion.cpp:116-142) and the packed filter taps. `fenc_rows` is the height the launch
+     * reserved for source blocks; the interpolation planes follow them. */
     __device__ __forceinline__ void bind(int lds_base, const PlaneDev &fencPl, const PlaneDev *refPl, int nref,
                                          const uint16_t *costTab, int depth_, int pu_x, int pu_y, int w_, int h_,
-                                         int x0 = 0, int y0 = 0, int x1 = 0, int y1 = 0, int win_cap = 0)
+                                         int fenc_rows = ROWS, int budget = 0)
     {
         base = lds_base;
         lane = threadIdx.x & 63;
@@ -880,11 +1212,6 @@ struct Searcher
         const int inv_wt = (65536 + wt - 1) / wt;
         const int rstride = refPl[0].stride;
         const long roff = (long)pu_y * rstride + pu_x;
-        const int epc = 16 / (int)sizeof(P);               /* samples per 16-byte chunk */
-        int wstride = ((x1 - x0 + 4 + epc - 1) / epc) * epc; /* + 4 samples: the aligned-pair LDS read may touch them */
-        const int rows = y1 - y0;
-        const int woff = wave_lds_bytes<P>(ROWS);
-        const bool staged = x1 > x0 && rows > 0 && wstride * rows * (int)sizeof(P) + 16 <= win_cap;
         wave_sync();
         if (lane == 0)
         {
@@ -894,7 +1221,24 @@ struct Searcher
             c->roff = roff;
             c->rstride = rstride; c->w = w; c->h = h; c->T = T; c->Tp = 1 << lTp; c->lTp = lTp; c->wt = wt; c->inv_wt = inv_wt;
             c->depth = depth_; c->mvpx = 0; c->mvpy = 0; c->rk_have_mvd = 0;
-            c->wx0 = x0; c->wy0 = y0; c->wx1 = staged ? x1 : x0; c->wy1 = y1; c->wstride = wstride; c->woff = woff;
+            c->planes_off = L_FENC + fenc_rows * 64 * (int)sizeof(P); c->plane_budget = budget;
+        }
+        if (!LOWRES && !RK && lane < 48)
+        {
+            /* per phase: 4 dwords of tap pairs (c0,c1)..(c6,c7), 5 dwords of the same taps moved down
+             * one sample (0,c0),(c1,c2)..(c7,0), 2 dwords of taps as signed bytes */
+            const int ph = lane / 12, sl = lane - ph * 12;
+            int c[8];
+#pragma unroll
+            for (int k = 0; k < 8; k++) c[k] = kLumaTaps[ph][k];
+            int v = 0;
+            for (int k = 0; k < 8; k++)
+            {
+                if (sl < 4) { if (k == 2 * sl) v |= c[k] & 0xffff; if (k == 2 * sl + 1) v |= (int)((unsigned)c[k] << 16); }
+                else if (sl < 9) { const int j = sl - 4; if (k == 2 * j - 1) v |= c[k] & 0xffff; if (k == 2 * j) v |= (int)((unsigned)c[k] << 16); }
+                else if (sl < 11) { if ((k >> 2) == sl - 9) v |= (c[k] & 0xff) << (8 * (k & 3)); }
+            }
+            lds_i(base, L_TAPS)[lane] = v;
         }
         const P AS1 *src = (const P AS1*)fencPl.origin + (long)pu_y * fencPl.stride + pu_x;
         for (int t = lane; t < T; t += 64)
@@ -904,20 +1248,6 @@ struct Searcher
             for (int y = 0; y < 4; y++)
                 Px<P>::store_lds_aligned(base + L_FENC + ((ty * 4 + y) * 64 + tx * 4) * (int)sizeof(P),
                                          Px<P>::load_g(src + (long)(ty * 4 + y) * fencPl.stride + tx * 4));
-        }
-        if (staged)
-        {
-            typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-            typedef u32x4 __attribute__((aligned(1))) u32x4u;
-            const int chunks = wstride / epc, total = chunks * rows;
-            const int inv_ch = ((1 << 20) + chunks - 1) / chunks;
-            const P AS1 *r0 = (const P AS1*)refPl[0].origin + roff + (long)y0 * rstride + x0;
-            for (int i = lane; i < total; i += 64)
-            {
-                const int r = (int)(((long)i * inv_ch) >> 20), ch = i - r * chunks;
-                const u32x4 v = *(const u32x4u AS1*)(r0 + (long)r * rstride + ch * epc);
-                *(u32x4*)(x265amd_smem + base + woff + (r * wstride + ch * epc) * (int)sizeof(P)) = v;
-            }
         }
         wave_sync();
     }

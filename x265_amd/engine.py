@@ -182,20 +182,10 @@ class Engine:
     def sync(self):
         self._chk(self.L.x265amd_sync(self.ctx))
 
-    def window_bytes(self, jobs):
-        """LDS bytes needed to stage the largest reference window of `jobs`."""
-        jobs = np.ascontiguousarray(jobs, JOB_DTYPE)
-        bps = 1 if self.depth <= 8 else 2
-        epc = 16 // bps
-        ww = (jobs["mvmax"][:, 0].astype(np.int64) - jobs["mvmin"][:, 0]) + jobs["w"] + 16
-        rows = (jobs["mvmax"][:, 1].astype(np.int64) - jobs["mvmin"][:, 1]) + jobs["h"] + 16
-        wstride = (ww + 4 + epc - 1) // epc * epc
-        return int((wstride * rows * bps + 16).max()) if len(jobs) else 0
-
-    def search_batch_dev(self, fenc, ref, d_jobs, njobs, d_results, qp, method, subme, is_lowres=False, window_bytes=0):
+    def search_batch_dev(self, fenc, ref, d_jobs, njobs, d_results, qp, method, subme, is_lowres=False, max_pu_dim=0):
         refs = (Plane * 4)(*ref) if is_lowres else (Plane * 1)(ref if isinstance(ref, Plane) else ref[0])
         self._chk(self.L.x265amd_search_batch_dev(self.ctx, C.byref(fenc), refs, int(is_lowres), qp, method, subme,
-                                                  C.c_void_p(d_jobs), njobs, C.c_void_p(d_results), window_bytes))
+                                                  C.c_void_p(d_jobs), njobs, C.c_void_p(d_results), max_pu_dim))
 
     def fields_upload(self, fields):
         n = len(fields)
