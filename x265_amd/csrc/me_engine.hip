@@ -355,32 +355,26 @@ __global__ __launch_bounds__(64) void rk_cu_kernel(RkArgs a)
     int pmv[3][2] = { { res.cime.mv[0], res.cime.mv[1] }, { j.pmv[0][0], j.pmv[0][1] }, { j.pmv[1][0], j.pmv[1][1] } };
     int bcost = 0x7fffffff, bx = 0, by = 0;
     for (int p = 0; p < 3; p++)
-        for (int i = -6; i < 6; i++)
+        for (int i0 = -6; i0 < 6; i0 += 4)
         {
-            for (int k = 0; k < 16; k++)
-            {
-                const int tx = as_i16(pmv[p][0] + k - 8), ty = as_i16(pmv[p][1] + i);
-                S.put(k, tx, ty, tx, ty, 16, 0);
-            }
-            S.eval(16, 0, true);
-            const int kb = S.fold_min(16, bcost);
+            /* four 16-wide rows of the window per batch, one lane per position */
+            const int tx = as_i16(pmv[p][0] + (lane & 15) - 8), ty = as_i16(pmv[p][1] + i0 + (lane >> 4));
+            S.put_lanes(true, tx, ty, tx, ty, 16, 0);
+            S.eval(64, 0, true);
+            const int kb = S.fold_min(64, bcost);
             if (kb >= 0) { bx = S.mvx_of(kb); by = S.mvy_of(kb); }
         }
     if (lane == 0) { res.rime[idx].mv[0] = (int16_t)bx; res.rime[idx].mv[1] = (int16_t)by; res.rime[idx].cost = bcost; }
     const int BX = as_i16(bx << 2), BY = as_i16(by << 2);
     bcost = 0x7fffffff;
     int fx = 0, fy = 0;
-    for (int c0 = 0; c0 < 49; c0 += MAXC)
     {
-        const int n = 49 - c0 < MAXC ? 49 - c0 : MAXC;
-        for (int k = 0; k < n; k++)
-        {
-            const int c = c0 + k;
-            const int qx = as_i16(BX + c / 7 - 3), qy = as_i16(BY + c % 7 - 3);
-            S.put(k, qx, qy, qx, qy, 16, 0);
-        }
-        S.eval(n, 3, true);
-        const int kb = S.fold_min(n, bcost);
+        /* the 7x7 grid in one batch: lane c -> (c / 7, c % 7) */
+        const int cx = (lane * 37) >> 8, cy = lane - cx * 7;
+        const int qx = as_i16(BX + cx - 3), qy = as_i16(BY + cy - 3);
+        S.put_lanes(lane < 49, qx, qy, qx, qy, 16, 0);
+        S.eval(49, 3, true);
+        const int kb = S.fold_min(49, bcost);
         if (kb >= 0) { fx = S.mvx_of(kb); fy = S.mvy_of(kb); }
     }
     if (lane == 0) { res.fme[idx].mv[0] = (int16_t)fx; res.fme[idx].mv[1] = (int16_t)fy; res.fme[idx].cost = bcost; }

@@ -18,7 +18,8 @@
 
 namespace x265amd {
 
-#define MAXC 16
+#define MAXC 64   /* candidates per batched evaluation: one per lane */
+#define MAXP 16   /* candidates of one sub-pel batch (interpolation planes) */
 
 /* radius-2 hexagon with wrap-around entries, (x-1)%6, motion.cpp:145-146 */
 __constant__ static const int8_t kHex2[8][2] = { {-1,-2}, {-2,0}, {-1,2}, {1,2}, {2,0}, {1,-2}, {-1,-2}, {-2,0} };
@@ -35,6 +36,36 @@ __constant__ static const int8_t kTwoPoint[16][2] = { {-1,0}, {0,-1}, {-1,-1}, {
 __constant__ static const int8_t kWorkload[8][5] = { {1,4,0,4,0}, {1,4,1,4,0}, {1,4,1,4,1}, {2,4,1,4,1},
                                                      {2,4,2,4,1}, {1,8,1,8,1}, {2,8,1,8,1}, {2,8,2,8,1} };
 
+/* Packed 8-tap luma filters for the plane-based sub-pel stage, 12 dwords per phase: 4 dwords of
+ * int16 tap pairs (c0,c1)..(c6,c7); 5 dwords of the same taps moved down one sample
+ * (0,c0),(c1,c2)..(c7,0); 2 dwords of taps as signed bytes; 1 unused */
+struct TapWords
+{
+    int w[48];
+    constexpr TapWords() : w()
+    {
+        const int taps[4][8] = { { 0, 0, 0, 64, 0, 0, 0, 0 }, { -1, 4, -10, 58, 17, -5, 1, 0 },
+                                 { -1, 4, -11, 40, 40, -11, 4, -1 }, { 0, 1, -5, 17, 58, -10, 4, -1 } };
+        for (int ph = 0; ph < 4; ph++)
+        {
+            const int *c = taps[ph];
+            for (int i = 0; i < 4; i++) w[ph * 12 + i] = (int)((unsigned)(c[2 * i] & 0xffff) | ((unsigned)(c[2 * i + 1] & 0xffff) << 16));
+            for (int j = 0; j < 5; j++)
+            {
+                const int lo = j ? c[2 * j - 1] : 0, hi = j < 4 ? c[2 * j] : 0;
+                w[ph * 12 + 4 + j] = (int)((unsigned)(lo & 0xffff) | ((unsigned)(hi & 0xffff) << 16));
+            }
+            for (int b = 0; b < 2; b++)
+            {
+                unsigned v = 0;
+                for (int k = 0; k < 4; k++) v |= (unsigned)(c[4 * b + k] & 0xff) << (8 * k);
+                w[ph * 12 + 9 + b] = (int)v;
+            }
+        }
+    }
+};
+__constant__ static const TapWords kTapWords = TapWords();
+
 struct PlaneDev
 {
     const void *origin;
@@ -44,16 +75,16 @@ struct PlaneDev
 /* Per-wave LDS layout, byte offsets from the wave's base. Candidate arrays hold MAXC ints. */
 enum
 {
-    L_SX = 0, L_SY = 64,         /* where to measure: full-pel offset, or qpel MV */
-    L_MVX = 128, L_MVY = 192,    /* MV charged for the candidate (same units) */
-    L_SH = 256,                  /* left shift applied to mv before the cost lookup, + flavour flags */
-    L_META = 320, L_COSTS = 384,
-    L_CPL = 448,                 /* sub-pel candidates: plane | (row + 16) << 8 | yfrac << 16 | satd << 18 */
-    L_CLIST = 512,               /* candidates served by the planes currently in LDS */
-    L_PDESC = 576,               /* MAXC plane descriptors of 32 bytes */
-    L_TAPS = 1088,               /* 4 phases x 12 dwords of packed filter taps */
-    L_CTX = 1280,                /* EvalCtx */
-    L_FENC = 1536                /* source PU, row pitch 64 samples (FENC_STRIDE) */
+    L_SX = 0, L_SY = 256,        /* where to measure: full-pel offset, or qpel MV */
+    L_MVX = 512, L_MVY = 768,    /* MV charged for the candidate (same units) */
+    L_SH = 1024,                 /* left shift applied to mv before the cost lookup, + flavour flags */
+    L_META = 1280, L_COSTS = 1536,
+    L_CPL = 1792,                /* sub-pel candidates: plane | (row + 16) << 8 | yfrac << 16 | satd << 18 */
+    L_CLIST = 1856,              /* candidates served by the planes currently in LDS */
+    L_PDESC = 1920,              /* MAXP plane descriptors of 32 bytes */
+    L_TAPS = 2432,               /* 4 phases x 12 dwords of packed filter taps */
+    L_CTX = 2624,                /* EvalCtx */
+    L_FENC = 2880                /* source PU, row pitch 64 samples (FENC_STRIDE) */
 };
 
 /* Everything the batched evaluation needs, parked in LDS so that the evaluation routines
@@ -113,6 +144,26 @@ __device__ __forceinline__ int row_min16(int v)
     return v;
 }
 
+/* minimum over the wave, as a scalar */
+__device__ __forceinline__ int wave_min(int v)
+{
+    v = row_min16(v);
+    const int a = __builtin_amdgcn_readlane(v, 0), b = __builtin_amdgcn_readlane(v, 16);
+    const int c = __builtin_amdgcn_readlane(v, 32), d = __builtin_amdgcn_readlane(v, 48);
+    const int ab = a < b ? a : b, cd = c < d ? c : d;
+    return ab < cd ? ab : cd;
+}
+
+/* table of up to 16 small signed values (-4 .. 11) packed as nibbles, for per-lane lookups
+ * without a memory access */
+template<int N> constexpr unsigned long long nibs(const int (&v)[N])
+{
+    unsigned long long r = 0;
+    for (int i = 0; i < N; i++) r |= (unsigned long long)((v[i] + 4) & 15) << (4 * i);
+    return r;
+}
+__device__ __forceinline__ int nib(unsigned long long t, int i) { return (int)((t >> (4 * i)) & 15) - 4; }
+
 /* lambda * bits term of candidate `lane` (0 for lanes that have none) */
 __device__ __forceinline__ int gather_mvcost(int base, int K, int mode, int addmv)
 {
@@ -159,6 +210,12 @@ struct Geo
     const void AS1 *ref[4];
     long roff;
     int rstride, T, Tp, lTp, wt, inv_wt, depth;
+    /* ref[i] for a per-lane i, by selects (indexing the array would put it in scratch memory) */
+    __device__ __forceinline__ const void AS1 *pick(int i) const
+    {
+        const void AS1 *lo = (i & 1) ? ref[1] : ref[0], *hi = (i & 1) ? ref[3] : ref[2];
+        return (i & 2) ? hi : lo;
+    }
     template<bool ALLREFS> __device__ __forceinline__ void load(int base)
     {
         const EvalCtx *cx = lds_ctx(base);
@@ -195,14 +252,14 @@ __device__ __forceinline__ int tile_cost(int base, const Geo &c, int k, int t, i
         /* lowres.h:78-97: pick the hpel plane; odd qpel = average with the next one */
         const bool satd = mode == 2;
         const int hpelA = (cy & 2) | ((cx & 2) >> 1);
-        const P AS1 *ra = (const P AS1*)c.ref[hpelA] + c.roff + (long)((cy >> 2) + ty * 4) * c.rstride + (cx >> 2) + tx * 4;
+        const P AS1 *ra = (const P AS1*)c.pick(hpelA) + c.roff + (long)((cy >> 2) + ty * 4) * c.rstride + (cx >> 2) + tx * 4;
 #pragma unroll
         for (int y = 0; y < 4; y++) q[y] = Px<P>::load_g(ra + y * c.rstride);
         if ((cx | cy) & 1)
         {
             const int bx = as_i16(cx + (cx & 1) * 2), by = as_i16(cy + (cy & 1) * 2);
             const int hpelB = (by & 2) | ((bx & 2) >> 1);
-            const P AS1 *rb = (const P AS1*)c.ref[hpelB] + c.roff + (long)((by >> 2) + ty * 4) * c.rstride + (bx >> 2) + tx * 4;
+            const P AS1 *rb = (const P AS1*)c.pick(hpelB) + c.roff + (long)((by >> 2) + ty * 4) * c.rstride + (bx >> 2) + tx * 4;
 #pragma unroll
             for (int y = 0; y < 4; y++) q[y] = Px<P>::avg(q[y], Px<P>::load_g(rb + y * c.rstride));
         }
@@ -400,9 +457,13 @@ template<> struct HFilter<uint16_t>
     }
 };
 
-/* vertical pass + cost of tile t of candidate k against the planes in LDS */
+/* Vertical pass + cost for column x of tile t of candidate k against the planes in LDS.
+ * The four lanes of a quad hold the four columns of one 4x4 tile. SAD: the lane's share is
+ * the sum over its column. SATD: the vertical Hadamard runs inside the lane, the horizontal
+ * one across the quad (DPP), and each lane returns the abs-sum of its four coefficients; the
+ * caller halves the total (every tile's abs-sum is even, pixel.cpp:226). */
 template<typename P>
-__device__ __forceinline__ int plane_tile_cost(int base, int k, int t, int wt, int inv_wt, int depth)
+__device__ __forceinline__ int plane_column_cost(int base, int k, int t, int x, int wt, int inv_wt, int depth)
 {
     const int cpl = lds_i(base, L_CPL)[k];
     const int *d = lds_i(base, L_PDESC + (cpl & 255) * 32);
@@ -411,37 +472,45 @@ __device__ __forceinline__ int plane_tile_cost(int base, int k, int t, int wt, i
     const int R = ((cpl >> 8) & 255) - 16 + 4 * ty;
     const uint32_t sh16 = (R & 1) * 16;
     const int *tp = lds_i(base, L_TAPS + ((cpl >> 16) & 3) * 48);
-    uint32_t ev[4], od[5];
+    const int headRoom = 14 - depth, maxv = (1 << depth) - 1;
+    const int shiftV = ps ? 6 + headRoom : 6;
+    const int offV = ps ? (1 << (5 + headRoom)) + (8192 << 6) : 32;
+    const uint32_t *col = (const uint32_t*)(x265amd_smem + base + poff + ((tx * 4 + x) * prow + (R & ~1)) * 2);
+    uint32_t E[7], e[6], ev[4], od[5];
+#pragma unroll
+    for (int i = 0; i < 7; i++) E[i] = col[i];
 #pragma unroll
     for (int i = 0; i < 4; i++) ev[i] = tp[i];
 #pragma unroll
     for (int i = 0; i < 5; i++) od[i] = tp[4 + i];
-    const int headRoom = 14 - depth, maxv = (1 << depth) - 1;
-    const int shiftV = ps ? 6 + headRoom : 6;
-    const int offV = ps ? (1 << (5 + headRoom)) + (8192 << 6) : 32;
-    int o[4][4];
 #pragma unroll
-    for (int x = 0; x < 4; x++)
+    for (int i = 0; i < 6; i++) e[i] = __builtin_amdgcn_alignbit(E[i + 1], E[i], sh16);
+    int o[4];
+    o[0] = dot2(e[0], ev[0], dot2(e[1], ev[1], dot2(e[2], ev[2], dot2(e[3], ev[3], offV))));
+    o[1] = dot2(e[0], od[0], dot2(e[1], od[1], dot2(e[2], od[2], dot2(e[3], od[3], dot2(e[4], od[4], offV)))));
+    o[2] = dot2(e[1], ev[0], dot2(e[2], ev[1], dot2(e[3], ev[2], dot2(e[4], ev[3], offV))));
+    o[3] = dot2(e[1], od[0], dot2(e[2], od[1], dot2(e[3], od[2], dot2(e[4], od[3], dot2(e[5], od[4], offV)))));
+    const P *f = (const P*)(x265amd_smem + base + L_FENC) + (ty * 4) * 64 + tx * 4 + x;
+    int dv[4];
+#pragma unroll
+    for (int y = 0; y < 4; y++) dv[y] = (int)f[y * 64] - clip_pixel(as_i16(o[y] >> shiftV), maxv);
+    if (!((cpl >> 18) & 1))
+        return abs(dv[0]) + abs(dv[1]) + abs(dv[2]) + abs(dv[3]);
+    const int a0 = dv[0] + dv[1], a1 = dv[0] - dv[1], a2 = dv[2] + dv[3], a3 = dv[2] - dv[3];
+    int c[4] = { a0 + a2, a1 + a3, a0 - a2, a1 - a3 };
+    const int n1 = -(x & 1), n2 = -((x >> 1) & 1);
+    int s = 0;
+#pragma unroll
+    for (int i = 0; i < 4; i++)
     {
-        const uint32_t *col = (const uint32_t*)(x265amd_smem + base + poff + ((tx * 4 + x) * prow + (R & ~1)) * 2);
-        uint32_t E[7], e[6];
-#pragma unroll
-        for (int i = 0; i < 7; i++) E[i] = col[i];
-#pragma unroll
-        for (int i = 0; i < 6; i++) e[i] = __builtin_amdgcn_alignbit(E[i + 1], E[i], sh16);
-        const int s0 = dot2(e[0], ev[0], dot2(e[1], ev[1], dot2(e[2], ev[2], dot2(e[3], ev[3], offV))));
-        const int s1 = dot2(e[0], od[0], dot2(e[1], od[1], dot2(e[2], od[2], dot2(e[3], od[3], dot2(e[4], od[4], offV)))));
-        const int s2 = dot2(e[1], ev[0], dot2(e[2], ev[1], dot2(e[3], ev[2], dot2(e[4], ev[3], offV))));
-        const int s3 = dot2(e[1], od[0], dot2(e[2], od[1], dot2(e[3], od[2], dot2(e[4], od[3], dot2(e[5], od[4], offV)))));
-        o[0][x] = clip_pixel(as_i16(s0 >> shiftV), maxv);
-        o[1][x] = clip_pixel(as_i16(s1 >> shiftV), maxv);
-        o[2][x] = clip_pixel(as_i16(s2 >> shiftV), maxv);
-        o[3][x] = clip_pixel(as_i16(s3 >> shiftV), maxv);
+        /* butterfly with the lane one column over, then two columns over: the lower lane of a
+         * pair keeps the sum, the upper one the difference */
+        int v = c[i];
+        v = ((v ^ n1) - n1) + __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xf, 0xf, false);
+        v = ((v ^ n2) - n2) + __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xf, 0xf, false);
+        s += abs(v);
     }
-    typename Px<P>::quad f[4];
-#pragma unroll
-    for (int y = 0; y < 4; y++) f[y] = Px<P>::load_lds_aligned(base + L_FENC + ((ty * 4 + y) * 64 + tx * 4) * (int)sizeof(P));
-    return tile_cost_px<P>(f, o, (cpl >> 18) & 1);
+    return s;
 }
 
 /* costs[k] for K sub-pel (or mixed) candidates of the classic path; mode as in eval_batch */
@@ -548,28 +617,29 @@ __device__ __noinline__ void eval_planes(int base, int K, int mode, int addmv)
         }
         wave_sync();
 
-        /* ---- vertical pass + cost per (candidate, tile) ---- */
-        if (lTp <= 6)
+        /* ---- vertical pass + cost: one lane per (candidate, tile, column) ---- */
+        if (lTp <= 4)
         {
-            const int g = lane >> lTp, t = lane & ((1 << lTp) - 1), cpp = 64 >> lTp;
+            const int l4 = lTp + 2, g = lane >> l4, t = (lane >> 2) & ((1 << lTp) - 1), cpp = 64 >> l4;
             for (int j0 = 0; j0 < nc; j0 += cpp)
             {
                 const int j = j0 + g;
                 const bool act = j < nc && t < T;
                 const int k = lds_i(base, L_CLIST)[act ? j : 0];
-                int v = plane_tile_cost<P>(base, k, act ? t : 0, wt, inv_wt, depth);
-                v = seg_sum(act ? v : 0, lTp);
-                if (act && t == 0) lds_i(base, L_COSTS)[k] = v;
+                int v = plane_column_cost<P>(base, k, act ? t : 0, lane & 3, wt, inv_wt, depth);
+                v = seg_sum(act ? v : 0, l4);
+                if (act && (lane & ((1 << l4) - 1)) == 0) lds_i(base, L_COSTS)[k] = v >> ((lds_i(base, L_CPL)[k] >> 18) & 1);
             }
         }
         else
+            /* 32 tiles or more (always a multiple of 16): 16 tiles per pass */
             for (int j = 0; j < nc; j++)
             {
                 const int k = uni(lds_i(base, L_CLIST)[j]);
                 int v = 0;
-                for (int t = lane; t < T; t += 64) v += plane_tile_cost<P>(base, k, t, wt, inv_wt, depth);
+                for (int t0 = 0; t0 < T; t0 += 16) v += plane_column_cost<P>(base, k, t0 + (lane >> 2), lane & 3, wt, inv_wt, depth);
                 v = seg_sum(v, 6);
-                if (lane == 0) lds_i(base, L_COSTS)[k] = v;
+                if (lane == 0) lds_i(base, L_COSTS)[k] = v >> ((lds_i(base, L_CPL)[k] >> 18) & 1);
             }
         wave_sync();
         p0 = p1;
@@ -577,6 +647,30 @@ __device__ __noinline__ void eval_planes(int base, int K, int mode, int addmv)
     if (lane < K) lds_i(base, L_COSTS)[lane] += mvc;
     wave_sync();
 }
+
+/* The fields of a job as wave-uniform scalars. Jobs may sit in LDS or behind a generic
+ * pointer, where the compiler cannot see that every lane reads the same value. */
+struct JobRegs
+{
+    int mnx, mny, mxx, mxy, qmx, qmy, numc, merange;
+    int cx[4], cy[4];
+    __device__ __forceinline__ void load(const x265amd_job *job)
+    {
+        const int *p = (const int*)job;
+        const int d1 = uni(p[1]), d2 = uni(p[2]), d3 = uni(p[3]), d4 = uni(p[4]);
+        numc = (d1 >> 16) & 0xff;
+        mnx = as_i16(d2); mny = d2 >> 16; mxx = as_i16(d3); mxy = d3 >> 16; qmx = as_i16(d4); qmy = d4 >> 16;
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+        {
+            const int d = uni(p[5 + i]);
+            cx[i] = as_i16(d); cy[i] = d >> 16;
+        }
+        merange = uni(p[9]);
+    }
+    __device__ __forceinline__ int mvcx(int i) const { return i == 0 ? cx[0] : (i == 1 ? cx[1] : (i == 2 ? cx[2] : cx[3])); }
+    __device__ __forceinline__ int mvcy(int i) const { return i == 0 ? cy[0] : (i == 1 ? cy[1] : (i == 2 ? cy[2] : cy[3])); }
+};
 
 /* LOWRES selects the lookahead flavour at compile time (half-pel planes instead of
  * interpolation), which keeps the 8-tap code out of the lookahead kernel. */
@@ -596,16 +690,31 @@ struct Searcher
         if (mode == 0) nsad += K; else if (mode > 0) nsub += K;
     }
 
-    /* First minimum of costs[0..K) in index order if it beats bcost (the reference's chain of
-     * strict '<' tests); returns its index or -1. Costs stay below 2^26, so cost << 5 | index
-     * orders candidates exactly like the sequential scan. K <= MAXC = 16: one DPP row. */
-    __device__ __forceinline__ int fold_min(int K, int &bcost)
+    /* First minimum of costs[k0..k1) in index order if it beats bcost (the reference's chain of
+     * strict '<' tests); returns its index or -1. Costs stay below 2^25, so cost << 6 | index
+     * orders candidates exactly like the sequential scan. */
+    __device__ __forceinline__ int fold_range(int k0, int k1, int &bcost)
     {
         int key = 0x7fffffff;
-        if (lane < K) key = (lds_i(base, L_COSTS)[lane] << 5) | lane;
-        key = uni(row_min16(key));
-        if ((key >> 5) < bcost) { bcost = key >> 5; return key & 31; }
+        if (lane >= k0 && lane < k1) key = (lds_i(base, L_COSTS)[lane] << 6) | lane;
+        key = k1 <= 16 ? uni(row_min16(key)) : wave_min(key);
+        if ((key >> 6) < bcost) { bcost = key >> 6; return key & 63; }
         return -1;
+    }
+    __device__ __forceinline__ int fold_min(int K, int &bcost) { return fold_range(0, K, bcost); }
+
+    /* queue one candidate per lane that has one (`ok`), in lane order; returns their number */
+    __device__ __forceinline__ int put_lanes(bool ok, int sx_, int sy_, int mx_, int my_, int sh_, int meta_)
+    {
+        const unsigned long long m = __ballot(ok);
+        if (ok)
+        {
+            const int k = __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0));
+            lds_i(base, L_SX)[k] = sx_; lds_i(base, L_SY)[k] = sy_;
+            lds_i(base, L_MVX)[k] = mx_; lds_i(base, L_MVY)[k] = my_;
+            lds_i(base, L_SH)[k] = sh_; lds_i(base, L_META)[k] = meta_;
+        }
+        return (int)__builtin_popcountll(m);
     }
 
     __device__ __forceinline__ void put(int k, int sx_, int sy_, int mx_, int my_, int sh_, int meta_)
@@ -662,83 +771,70 @@ struct Searcher
         }
     }
 
-    /* StarPatternSearch, motion.cpp:307-547. One diamond ring per round; every
-     * in-range point of a round is independent of the others, so a round is one
-     * batched evaluation folded in the reference's visit order. */
+    /* first lane of star round r when all rounds are laid out back to back: round 0 (distance 1)
+     * has 4 points, rounds 1-3 (distance 2, 4, 8) have 8, later rounds 16 */
+    static __device__ __forceinline__ int star_start(int r) { return r == 0 ? 0 : (r <= 4 ? 8 * r - 4 : 16 * r - 36); }
+
+    /* StarPatternSearch, motion.cpp:307-547. All rounds measure around the same centre and
+     * only look at the running best to count rounds without improvement, so the rounds that
+     * are certain to run (earlyExitIters minus the current count) form ONE batch: lane i takes
+     * point i of the concatenated rounds, points outside the search range drop out, and the
+     * per-round bookkeeping is replayed on the costs in visit order. */
     __device__ __forceinline__ void star_pattern(int mnx, int mny, int mxx, int mxy, int &bmx, int &bmy, int &bcost,
                                  int &bPointNr, int &bDistance, int earlyExitIters, int merange)
     {
+        /* point offsets in units of distance (round 0), distance / 2 (rounds 1-3, visit order
+         * 2,1,3,4,5,6,8,7), distance / 4 (later rounds); motion.cpp:330-540 */
+        constexpr unsigned long long X4 = nibs({ 0, -1, 1, 0 }), Y4 = nibs({ -1, 0, 0, 1 }), P4 = nibs({ 2, 4, 5, 7 });
+        constexpr unsigned long long X8 = nibs({ 0, -1, 1, -2, 2, -1, 1, 0 }), Y8 = nibs({ -2, -1, -1, 0, 0, 1, 1, 2 }),
+                                     P8 = nibs({ 2, 1, 3, 4, 5, 6, 8, 7 });
+        constexpr unsigned long long X16 = nibs({ 0, -4, 4, 0, -1, 1, -1, 1, -2, 2, -2, 2, -3, 3, -3, 3 }),
+                                     Y16 = nibs({ -4, 0, 0, 4, -3, -3, 3, 3, -2, -2, 2, 2, -1, -1, 1, 1 });
         const int ox = bmx, oy = bmy;
-        int saved = bcost, rounds = 0;
-        int K;
-#define QPT(x_, y_, pt_, d_) do { put(K, (x_), (y_), (x_), (y_), 2, (pt_) | ((d_) << 8)); K++; } while (0)
+        int rl = 3;
+        for (int d = 16; d <= as_i16(merange) && d > 0; d = as_i16(d << 1)) rl++;
+        int rounds = 0;
+        for (int ra = 0; ra <= rl;)
         {
-            const int top = as_i16(oy - 1), bottom = as_i16(oy + 1), left = as_i16(ox - 1), right = as_i16(ox + 1);
-            K = 0;
-            if (top >= mny) QPT(ox, top, 2, 1);
-            if (left >= mnx) QPT(left, oy, 4, 1);
-            if (right <= mxx) QPT(right, oy, 5, 1);
-            if (bottom <= mxy) QPT(ox, bottom, 7, 1);
-            fold_pt(K, bmx, bmy, bcost, bPointNr, bDistance);
-            if (bcost < saved) rounds = 0;
-            else if (++rounds >= earlyExitIters) return;
-        }
-        for (int dist = 2; dist <= 8; dist <<= 1)
-        {
-            const int hd = dist >> 1;
-            const int top = as_i16(oy - dist), bottom = as_i16(oy + dist), left = as_i16(ox - dist), right = as_i16(ox + dist);
-            const int top2 = as_i16(oy - hd), bottom2 = as_i16(oy + hd), left2 = as_i16(ox - hd), right2 = as_i16(ox + hd);
-            saved = bcost;
-            K = 0;
-            /* visit order 2,1,3,4,5,6,8,7 in both the all-inside and the clipped branch */
-            if (top >= mny) QPT(ox, top, 2, dist);
-            if (top2 >= mny)
+            int rb = ra + (earlyExitIters - rounds) - 1;
+            if (rb > rl) rb = rl;
+            while (star_start(rb + 1) - star_start(ra) > MAXC) rb--;
+            const int local = lane + star_start(ra);
+            int r, i;
+            if (local < 4) { r = 0; i = local; }
+            else if (local < 28) { r = 1 + ((local - 4) >> 3); i = (local - 4) & 7; }
+            else { r = 4 + ((local - 28) >> 4); i = (local - 28) & 15; }
+            const int d = 1 << r;
+            const int ux = nib(r == 0 ? X4 : (r < 4 ? X8 : X16), i), uy = nib(r == 0 ? Y4 : (r < 4 ? Y8 : Y16), i);
+            const int unit = r == 0 ? 1 : (r < 4 ? d >> 1 : d >> 2);
+            const int dx = ux * unit, dy = uy * unit;
+            const int pt = r == 0 ? nib(P4, i) : (r < 4 ? nib(P8, i) : 0);
+            const int dd = (r >= 1 && r < 4 && (ux & 1)) ? d >> 1 : d;
+            const int x = as_i16(ox + dx), y = as_i16(oy + dy);
+            /* the reference tests only the bounds a point can cross */
+            const bool ok = r <= rb && (dy >= 0 || y >= mny) && (dy <= 0 || y <= mxy) && (dx >= 0 || x >= mnx) && (dx <= 0 || x <= mxx);
+            const unsigned long long m = __ballot(ok);
+            const int K = put_lanes(ok, x, y, x, y, 2, pt | (dd << 8));
+            if (K) eval(K, 0, true);
+            int k0 = 0;
+            for (int r2 = ra; r2 <= rb; r2++)
             {
-                if (left2 >= mnx) QPT(left2, top2, 1, hd);
-                if (right2 <= mxx) QPT(right2, top2, 3, hd);
-            }
-            if (left >= mnx) QPT(left, oy, 4, dist);
-            if (right <= mxx) QPT(right, oy, 5, dist);
-            if (bottom2 <= mxy)
-            {
-                if (left2 >= mnx) QPT(left2, bottom2, 6, hd);
-                if (right2 <= mxx) QPT(right2, bottom2, 8, hd);
-            }
-            if (bottom <= mxy) QPT(ox, bottom, 7, dist);
-            fold_pt(K, bmx, bmy, bcost, bPointNr, bDistance);
-            if (bcost < saved) rounds = 0;
-            else if (++rounds >= earlyExitIters) return;
-        }
-        for (int dist = 16; dist <= as_i16(merange) && dist > 0; dist = as_i16(dist << 1))
-        {
-            const int top = as_i16(oy - dist), bottom = as_i16(oy + dist), left = as_i16(ox - dist), right = as_i16(ox + dist);
-            saved = bcost;
-            K = 0;
-            if (top >= mny) QPT(ox, top, 0, dist);
-            if (left >= mnx) QPT(left, oy, 0, dist);
-            if (right <= mxx) QPT(right, oy, 0, dist);
-            if (bottom <= mxy) QPT(ox, bottom, 0, dist);
-            for (int index = 1; index < 4; index++)
-            {
-                const int q = (dist >> 2) * index;
-                const int posYT = as_i16(top + q), posYB = as_i16(bottom - q);
-                const int posXL = as_i16(ox - q), posXR = as_i16(ox + q);
-                if (posYT >= mny)
+                const int n2 = r2 == 0 ? 4 : (r2 < 4 ? 8 : 16);
+                const int n = (int)__builtin_popcountll(m & (((1ull << n2) - 1) << (star_start(r2) - star_start(ra))));
+                const int saved = bcost;
+                const int k = fold_range(k0, k0 + n, bcost);
+                if (k >= 0)
                 {
-                    if (posXL >= mnx) QPT(posXL, posYT, 0, dist);
-                    if (posXR <= mxx) QPT(posXR, posYT, 0, dist);
+                    bmx = mvx_of(k); bmy = mvy_of(k);
+                    const int mt = meta_of(k);
+                    bPointNr = mt & 0xff; bDistance = mt >> 8;
                 }
-                if (posYB <= mxy)
-                {
-                    if (posXL >= mnx) QPT(posXL, posYB, 0, dist);
-                    if (posXR <= mxx) QPT(posXR, posYB, 0, dist);
-                }
+                k0 += n;
+                if (bcost < saved) rounds = 0;
+                else if (++rounds >= earlyExitIters) return;
             }
-            fold_pt(K, bmx, bmy, bcost, bPointNr, bDistance);
-            if (bcost < saved) rounds = 0;
-            else if (++rounds >= earlyExitIters) return;
+            ra = rb + 1;
         }
-#undef QPT
     }
 
     /* Two extra points next to a distance-1 winner, motion.cpp:918-946 / :992-1015 */
@@ -813,12 +909,12 @@ struct Searcher
 
     /* X265_UMH_SEARCH, motion.cpp:725-909. Returns true when the search continues into
      * the hexagon refinement (goto me_hex2) with the possibly rescaled merange. */
-    __device__ __forceinline__ bool umh(const x265amd_job *job, int mnx, int mny, int mxx, int mxy, int pmx, int pmy,
+    __device__ __forceinline__ bool umh(const JobRegs &J, int mnx, int mny, int mxx, int mxy, int pmx, int pmy,
                         int &merange, int &bmx, int &bmy, int &bcost)
     {
         const int size_scale = (h * h) >> 4; /* motion.cpp:71-72 */
 #define SAD_THRESH(v) (bcost < (((v) >> 4) * size_scale))
-        const int numc = job->numc;
+        const int numc = J.numc;
         const int pbx = bmx, pby = bmy;
         int omx = bmx, omy = bmy;
         int K = 0;
@@ -864,28 +960,28 @@ struct Searcher
         /* adaptive search range from predictor agreement, motion.cpp:767-819 */
         if (numc)
         {
-            const int r0[4] = { 3, 3, 4, 4 }, r1[4] = { 3, 4, 4, 4 }, r2[4] = { 4, 4, 4, 5 }, r3[4] = { 4, 4, 5, 6 };
-            const int qmx = job->qmvp[0], qmy = job->qmvp[1];
+            /* range multipliers [mvd_ctx][sad_ctx], motion.cpp:769-772 */
+            constexpr unsigned long long RANGE_MUL = nibs({ 3, 3, 4, 4, 3, 4, 4, 4, 4, 4, 4, 5, 4, 4, 5, 6 });
+            const int qmx = J.qmx, qmy = J.qmy;
             int mvd, denom = 1;
             const bool is64 = (w == 64 && h == 64);
             if (numc == 1)
-                mvd = is64 ? 25 : abs(qmx - job->mvc[0][0]) + abs(qmy - job->mvc[0][1]);
+                mvd = is64 ? 25 : abs(qmx - J.cx[0]) + abs(qmy - J.cy[0]);
             else
             {
                 denom = numc - 1;
                 mvd = 0;
                 if (!is64)
                 {
-                    mvd = abs(qmx - job->mvc[0][0]) + abs(qmy - job->mvc[0][1]);
+                    mvd = abs(qmx - J.cx[0]) + abs(qmy - J.cy[0]);
                     denom++;
                 }
                 for (int i = 0; i < numc - 1; i++)
-                    mvd += abs(job->mvc[i][0] - job->mvc[i + 1][0]) + abs(job->mvc[i][1] - job->mvc[i + 1][1]);
+                    mvd += abs(J.mvcx(i) - J.mvcx(i + 1)) + abs(J.mvcy(i) - J.mvcy(i + 1));
             }
             const int sad_ctx = SAD_THRESH(1000) ? 0 : SAD_THRESH(2000) ? 1 : SAD_THRESH(4000) ? 2 : 3;
             const int mvd_ctx = mvd < 10 * denom ? 0 : mvd < 20 * denom ? 1 : mvd < 40 * denom ? 2 : 3;
-            const int *row = mvd_ctx == 0 ? r0 : mvd_ctx == 1 ? r1 : mvd_ctx == 2 ? r2 : r3;
-            merange = (merange * row[sad_ctx]) >> 2;
+            merange = (merange * nib(RANGE_MUL, mvd_ctx * 4 + sad_ctx)) >> 2;
         }
 
         umh_cross(K, cross_start, merange, merange >> 1, pbx, pby, omx, omy, mnx, mny, mxx, mxy, bmx, bmy, bcost);
@@ -928,12 +1024,18 @@ struct Searcher
     /* the whole of motionEstimate for one PU */
     __device__ __forceinline__ void search(const x265amd_job *job, int method, int subme, x265amd_result *res)
     {
-        const int mnx = job->mvmin[0], mny = job->mvmin[1], mxx = job->mvmax[0], mxy = job->mvmax[1];
+        JobRegs J;
+        J.load(job);
+        const int mnx = J.mnx, mny = J.mny, mxx = J.mxx, mxy = J.mxy;
         const int qmnx = as_i16(mnx << 2), qmny = as_i16(mny << 2), qmxx = as_i16(mxx << 2), qmxy = as_i16(mxy << 2);
-        const int numc = job->numc;
-        int merange = job->merange;
-        set_mvp(job->qmvp[0], job->qmvp[1]);
+        const int numc = J.numc;
+        int merange = J.merange;
+        set_mvp(J.qmx, J.qmy);
         nsad = 0; nsub = 0;
+        /* the pattern tables of motion.cpp:145-147, :673-681 as nibble-packed immediates */
+        constexpr unsigned long long SQX = nibs({ 0, 0, 0, -1, 1, -1, -1, 1, 1 }), SQY = nibs({ 0, -1, 1, 0, 0, -1, 1, -1, 1 });
+        constexpr unsigned long long HRX = nibs({ -2, -1, 1, 2, 1, -1 }), HRY = nibs({ 0, 2, 2, 0, -2, -2 });
+        constexpr unsigned long long H2X = nibs({ -1, -2, -1, 1, 2, 1, -1, -2 }), H2Y = nibs({ -2, 0, 2, 2, 0, -2, -2, 0 });
 
 #define CLIPX(v) ((v) > qmxx ? qmxx : ((v) < qmnx ? qmnx : (v)))
 #define CLIPY(v) ((v) > qmxy ? qmxy : ((v) < qmny ? qmny : (v)))
@@ -952,12 +1054,13 @@ struct Searcher
         const int kZero = (pmx | pmy) ? K : -1;
         if (kZero >= 0) put(K++, 0, 0, 0, 0, 2, 0 | 16);
         int kc[4], ccx[4], ccy[4];
+#pragma unroll
         for (int i = 0; i < 4; i++)
         {
             kc[i] = -1; ccx[i] = 0; ccy[i] = 0;
             if (i < numc)
             {
-                ccx[i] = CLIPX((int)job->mvc[i][0]); ccy[i] = CLIPY((int)job->mvc[i][1]);
+                ccx[i] = CLIPX(J.cx[i]); ccy[i] = CLIPY(J.cy[i]);
                 if ((ccx[i] | ccy[i]) && !(ccx[i] == pmx && ccy[i] == pmy))
                 {
                     kc[i] = K;
@@ -998,10 +1101,8 @@ struct Searcher
             int i = merange;
             do
             {
-                put(0, bmx, bmy - 1, as_i16(bmx), as_i16(bmy - 1), 2, 0);
-                put(1, bmx, bmy + 1, as_i16(bmx), as_i16(bmy + 1), 2, 0);
-                put(2, bmx - 1, bmy, as_i16(bmx - 1), as_i16(bmy), 2, 0);
-                put(3, bmx + 1, bmy, as_i16(bmx + 1), as_i16(bmy), 2, 0);
+                put_lanes(lane < 4, bmx + nib(SQX, lane + 1), bmy + nib(SQY, lane + 1),
+                          as_i16(bmx + nib(SQX, lane + 1)), as_i16(bmy + nib(SQY, lane + 1)), 2, 0);
                 eval(4, 0, true);
                 const int dir = fold_min(4, bcost);
                 if (dir < 0) break;
@@ -1014,7 +1115,7 @@ struct Searcher
             run_hex = true;
             break;
         case X265AMD_UMH:
-            run_hex = umh(job, mnx, mny, mxx, mxy, pmx, pmy, merange, bmx, bmy, bcost);
+            run_hex = umh(J, mnx, mny, mxx, mxy, pmx, pmy, merange, bmx, bmy, bcost);
             break;
         case X265AMD_STAR:
         {
@@ -1037,33 +1138,31 @@ struct Searcher
 
             if (bDistance > 5)
             {
-                /* raster refinement with step 5. Groups of four consecutive x positions are
-                 * costed together; the 4th one's MV bits use tmv << 3 (motion.cpp:975). */
-                for (int ty = as_i16(mny); ty <= mxy; ty = as_i16(ty + 5))
+                /* raster refinement with step 5 (motion.cpp:952-990): row-major scan; within a row the
+                 * points go in groups of four while a whole group fits, and the MV bits of a
+                 * group's 4th point use tmv << 3 (:975). One lane per point. */
+                const int nx = (mxx - mnx) / 5 + 1;
+                const int grouped = mxx - mnx >= 15 ? ((mxx - mnx - 15) / 20 + 1) * 4 : 0;
+                int pn, pd;
+                if (nx <= MAXC)
                 {
-                    int K = 0;
-                    for (int tx = as_i16(mnx); tx <= mxx; tx = as_i16(tx + 5))
+                    const int rpb = MAXC / nx, inv = (65536 + nx - 1) / nx;
+                    const int rs = (lane * inv) >> 16, j = lane - rs * nx;
+                    for (int ty = mny; ty <= mxy; ty += 5 * rpb)
                     {
-                        if (tx + 15 <= mxx)
-                        {
-                            if (K + 4 > MAXC) { int pn, pd; fold_pt(K, bmx, bmy, bcost, pn, pd); K = 0; }
-                            for (int k = 0; k < 4; k++)
-                            {
-                                put(K, tx + 5 * k, ty, as_i16(tx + 5 * k), ty, k == 3 ? 3 : 2, 0);
-                                K++;
-                            }
-                            tx = as_i16(tx + 15);
-                        }
-                        else
-                        {
-                            if (K + 1 > MAXC) { int pn, pd; fold_pt(K, bmx, bmy, bcost, pn, pd); K = 0; }
-                            put(K, tx, ty, tx, ty, 2, 0);
-                            K++;
-                        }
+                        const int y = ty + 5 * rs, x = mnx + 5 * j;
+                        const int K = put_lanes(rs < rpb && y <= mxy, x, y, as_i16(x), y, (j < grouped && (j & 3) == 3) ? 3 : 2, 0);
+                        fold_pt(K, bmx, bmy, bcost, pn, pd);
                     }
-                    int pn, pd;
-                    fold_pt(K, bmx, bmy, bcost, pn, pd);
                 }
+                else
+                    for (int ty = mny; ty <= mxy; ty += 5)
+                        for (int j0 = 0; j0 < nx; j0 += MAXC)
+                        {
+                            const int j = j0 + lane, x = mnx + 5 * j;
+                            const int K = put_lanes(j < nx, x, ty, as_i16(x), ty, (j < grouped && (j & 3) == 3) ? 3 : 2, 0);
+                            fold_pt(K, bmx, bmy, bcost, pn, pd);
+                        }
             }
 
             while (bDistance > 0)
@@ -1082,15 +1181,27 @@ struct Searcher
         }
         case X265AMD_FULL:
         {
-            /* motion.cpp:1021-1056: raster scan, strict '<' keeps the first minimum */
-            int K = 0, pn, pd;
-            for (int ty = mny; ty <= mxy; ty++)
-                for (int tx = mnx; tx <= mxx; tx++)
+            /* motion.cpp:1021-1056: raster scan, strict '<' keeps the first minimum; one lane per
+             * position, several short rows per batch */
+            const int nx = mxx - mnx + 1;
+            int pn, pd;
+            if (nx <= MAXC)
+            {
+                const int rpb = MAXC / nx, inv = (65536 + nx - 1) / nx;
+                const int rs = (lane * inv) >> 16, j = lane - rs * nx;
+                for (int ty = mny; ty <= mxy; ty += rpb)
                 {
-                    put(K, tx, ty, tx, ty, 2, 0);
-                    if (++K == MAXC) { fold_pt(K, bmx, bmy, bcost, pn, pd); K = 0; }
+                    const int K = put_lanes(rs < rpb && ty + rs <= mxy, mnx + j, ty + rs, mnx + j, ty + rs, 2, 0);
+                    fold_pt(K, bmx, bmy, bcost, pn, pd);
                 }
-            fold_pt(K, bmx, bmy, bcost, pn, pd);
+            }
+            else
+                for (int ty = mny; ty <= mxy; ty++)
+                    for (int j0 = 0; j0 < nx; j0 += MAXC)
+                    {
+                        const int K = put_lanes(j0 + lane < nx, mnx + j0 + lane, ty, mnx + j0 + lane, ty, 2, 0);
+                        fold_pt(K, bmx, bmy, bcost, pn, pd);
+                    }
             break;
         }
         default:
@@ -1102,8 +1213,7 @@ struct Searcher
             /* motion.cpp:651-723. Hexagon points and the closing square are evaluated
              * without a range check, as in the reference. */
             /* first ring: direction codes 2..7 in measuring order */
-            for (int k = 0; k < 6; k++)
-                put(k, bmx + kHexRing[k][0], bmy + kHexRing[k][1], as_i16(bmx + kHexRing[k][0]), as_i16(bmy + kHexRing[k][1]), 2, 0);
+            put_lanes(lane < 6, bmx + nib(HRX, lane), bmy + nib(HRY, lane), as_i16(bmx + nib(HRX, lane)), as_i16(bmy + nib(HRY, lane)), 2, 0);
             eval(6, 0, true);
             const int code = fold_min(6, bcost) + 2;
             if (code > 1)
@@ -1112,9 +1222,8 @@ struct Searcher
                 bmx = as_i16(bmx + kHex2[dir + 1][0]); bmy = as_i16(bmy + kHex2[dir + 1][1]);
                 for (int i = (merange >> 1) - 1; i > 0 && in_range(bmx, bmy, mnx, mny, mxx, mxy); i--)
                 {
-                    for (int k = 0; k < 3; k++)
-                        put(k, bmx + kHex2[dir + k][0], bmy + kHex2[dir + k][1],
-                            as_i16(bmx + kHex2[dir + k][0]), as_i16(bmy + kHex2[dir + k][1]), 2, 0);
+                    put_lanes(lane < 3, bmx + nib(H2X, dir + lane), bmy + nib(H2Y, dir + lane),
+                              as_i16(bmx + nib(H2X, dir + lane)), as_i16(bmy + nib(H2Y, dir + lane)), 2, 0);
                     eval(3, 0, true);
                     const int step = fold_min(3, bcost) + 1;
                     if (!step) break;
@@ -1124,9 +1233,8 @@ struct Searcher
                 }
             }
             /* square refine */
-            for (int k = 1; k <= 8; k++)
-                put(k - 1, bmx + kSquare1[k][0], bmy + kSquare1[k][1],
-                    as_i16(bmx + kSquare1[k][0]), as_i16(bmy + kSquare1[k][1]), 2, 0);
+            put_lanes(lane < 8, bmx + nib(SQX, lane + 1), bmy + nib(SQY, lane + 1),
+                      as_i16(bmx + nib(SQX, lane + 1)), as_i16(bmy + nib(SQY, lane + 1)), 2, 0);
             eval(8, 0, true);
             const int dir = fold_min(8, bcost) + 1;
             bmx = as_i16(bmx + kSquare1[dir][0]); bmy = as_i16(bmy + kSquare1[dir][1]);
@@ -1146,32 +1254,30 @@ struct Searcher
              * round is one batched evaluation (motion.cpp:1077-1141) */
             if (LOWRES)
             {
-                refine_round(qx, qy, bcost, hpel_dirs, 2, 1);
-                put(0, qx, qy, qx, qy, 0, 0);
-                eval(1, 2, true);
-                bcost = cost_of(0);
-                refine_round(qx, qy, bcost, qpel_dirs, 1, 2);
+                refine_round(qx, qy, bcost, hpel_dirs, 2, 1, false);
+                refine_round(qx, qy, bcost, qpel_dirs, 1, 2, true);
             }
             else
             {
-                int hmode = 1;
-                if (hpel_satd)
-                {
-                    put(0, qx, qy, qx, qy, 0, 0);
-                    eval(1, 2, true);
-                    bcost = cost_of(0);
-                    hmode = 2;
-                }
+                /* the SATD re-measure of the centre rides along with the first round that uses SATD */
+                bool centre = hpel_satd != 0;
                 for (int it = 0; it < hpel_iters; it++)
-                    refine_round(qx, qy, bcost, hpel_dirs, 2, hmode);
-                if (!hpel_satd)
+                {
+                    refine_round(qx, qy, bcost, hpel_dirs, 2, hpel_satd ? 2 : 1, centre);
+                    centre = false;
+                }
+                centre = !hpel_satd;
+                if (centre && !qpel_iters)
                 {
                     put(0, qx, qy, qx, qy, 0, 0);
                     eval(1, 2, true);
                     bcost = cost_of(0);
                 }
                 for (int it = 0; it < qpel_iters; it++)
-                    refine_round(qx, qy, bcost, qpel_dirs, 1, 2);
+                {
+                    refine_round(qx, qy, bcost, qpel_dirs, 1, 2, centre);
+                    centre = false;
+                }
             }
         }
 
@@ -1183,15 +1289,19 @@ struct Searcher
         }
     }
 
-    __device__ __forceinline__ void refine_round(int &qx, int &qy, int &bcost, int dirs, int step, int mode)
+    /* One refinement round: the `dirs` neighbours of (qx, qy) at distance `step` in the order
+     * of the square table, one lane each. With `centre`, (qx, qy) itself is measured in the same
+     * batch and its cost replaces bcost first (the SATD re-measure of motion.cpp:1086, :1117). */
+    __device__ __forceinline__ void refine_round(int &qx, int &qy, int &bcost, int dirs, int step, int mode, bool centre)
     {
-        for (int i = 1; i <= dirs; i++)
-        {
-            const int tx = as_i16(qx + kSquare1[i][0] * step), ty = as_i16(qy + kSquare1[i][1] * step);
-            put(i - 1, tx, ty, tx, ty, 0, 0);
-        }
-        eval(dirs, mode, true);
-        const int bdir = fold_min(dirs, bcost) + 1;
+        constexpr unsigned long long SQX = nibs({ 0, 0, 0, -1, 1, -1, -1, 1, 1 }), SQY = nibs({ 0, -1, 1, 0, 0, -1, 1, -1, 1 });
+        const int k0 = centre ? 1 : 0, i = lane + 1 - k0;
+        const int tx = as_i16(qx + nib(SQX, i) * step), ty = as_i16(qy + nib(SQY, i) * step);
+        put_lanes(lane < k0 + dirs, tx, ty, tx, ty, 0, 0);
+        eval(k0 + dirs, mode, true);
+        if (centre) bcost = cost_of(0);
+        const int k = fold_range(k0, k0 + dirs, bcost);
+        const int bdir = k < 0 ? 0 : k - k0 + 1;
         qx = as_i16(qx + kSquare1[bdir][0] * step); qy = as_i16(qy + kSquare1[bdir][1] * step);
     }
 
@@ -1223,23 +1333,7 @@ struct Searcher
             c->depth = depth_; c->mvpx = 0; c->mvpy = 0; c->rk_have_mvd = 0;
             c->planes_off = L_FENC + fenc_rows * 64 * (int)sizeof(P); c->plane_budget = budget;
         }
-        if (!LOWRES && !RK && lane < 48)
-        {
-            /* per phase: 4 dwords of tap pairs (c0,c1)..(c6,c7), 5 dwords of the same taps moved down
-             * one sample (0,c0),(c1,c2)..(c7,0), 2 dwords of taps as signed bytes */
-            const int ph = lane / 12, sl = lane - ph * 12;
-            int c[8];
-#pragma unroll
-            for (int k = 0; k < 8; k++) c[k] = kLumaTaps[ph][k];
-            int v = 0;
-            for (int k = 0; k < 8; k++)
-            {
-                if (sl < 4) { if (k == 2 * sl) v |= c[k] & 0xffff; if (k == 2 * sl + 1) v |= (int)((unsigned)c[k] << 16); }
-                else if (sl < 9) { const int j = sl - 4; if (k == 2 * j - 1) v |= c[k] & 0xffff; if (k == 2 * j) v |= (int)((unsigned)c[k] << 16); }
-                else if (sl < 11) { if ((k >> 2) == sl - 9) v |= (c[k] & 0xff) << (8 * (k & 3)); }
-            }
-            lds_i(base, L_TAPS)[lane] = v;
-        }
+        if (!LOWRES && !RK && lane < 48) lds_i(base, L_TAPS)[lane] = kTapWords.w[lane];
         const P AS1 *src = (const P AS1*)fencPl.origin + (long)pu_y * fencPl.stride + pu_x;
         for (int t = lane; t < T; t += 64)
         {
