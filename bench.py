@@ -44,6 +44,7 @@ def main():
     ap.add_argument("--method", default="star")
     ap.add_argument("--subme", type=int, default=SUBME_DEFAULT, help="sub-pel refinement level (experiments only)")
     ap.add_argument("--per-size", action="store_true", help="one search launch per PU size instead of one per frame")
+    ap.add_argument("--split", action="store_true", help="two launches per frame on two streams: 64/32 PUs and 16/8 PUs")
     args = ap.parse_args()
 
     import torch
@@ -65,6 +66,7 @@ def main():
     # ---------------- setup (untimed): planes, lookahead fields, job lists, all on the device
     es = Engine(local_rank, 8)      # search stream
     el = Engine(local_rank, 8)      # lookahead stream
+    eb = Engine(local_rank, 8) if args.split else es   # stream of the large-PU launches
     B = args.pairs
     clip = make_clip(W, H, B + 1, seed=1234 + rank)
     planes, lowres = [], []
@@ -86,9 +88,14 @@ def main():
         host_jobs.append(jobs)
         if segs is None:
             segs = []
-            for s_ in ((64, 32, 16, 8) if args.per_size else (0,)):
-                idx = np.flatnonzero(jobs["w"] == s_) if s_ else np.arange(len(jobs))
-                segs.append((int(idx[0]), len(idx), s_))
+            if args.split:
+                big = np.flatnonzero(jobs["w"] >= 32)
+                small = np.flatnonzero(jobs["w"] < 32)
+                segs = [(int(big[0]), len(big), 64, eb), (int(small[0]), len(small), 16, es)]
+            else:
+                for s_ in ((64, 32, 16, 8) if args.per_size else (0,)):
+                    idx = np.flatnonzero(jobs["w"] == s_) if s_ else np.arange(len(jobs))
+                    segs.append((int(idx[0]), len(idx), s_, es))
         d_jobs.append(torch.from_numpy(jobs.view(np.uint8).reshape(len(jobs), -1).copy()).to(dev))
         d_res.append(torch.zeros((len(jobs), RESULT_DTYPE.itemsize), dtype=torch.uint8, device=dev))
     njobs = len(host_jobs[0])
@@ -107,12 +114,13 @@ def main():
         if k is not None:
             ev0[k].record(s_search)
         for i in range(B):
-            for (first, cnt, win) in segs:
-                es.search_batch_dev(planes[i + 1], planes[i], d_jobs[i].data_ptr() + first * 40, cnt,
-                                    d_res[i].data_ptr() + first * 16, QP, method, SUBME, max_pu_dim=win)
+            for (first, cnt, dim, eng) in segs:
+                eng.search_batch_dev(planes[i + 1], planes[i], d_jobs[i].data_ptr() + first * 40, cnt,
+                                     d_res[i].data_ptr() + first * 16, QP, method, SUBME, max_pu_dim=dim)
         if k is not None:
             ev1[k].record(s_search)
         es.sync()
+        eb.sync()
         el.sync()
         if world > 1:
             # hand the MV / cost records to the rank that feeds the host encoder

@@ -107,13 +107,13 @@ __device__ __forceinline__ unsigned long long uni64(unsigned long long v)
     return ((unsigned long long)(unsigned)uni((int)(v >> 32)) << 32) | (unsigned)uni((int)v);
 }
 
-/* LDS bytes of the interpolation planes for PUs up to dim x dim: one plane is w columns of
- * (h + 10) int16 rows; small PUs keep all (up to six) planes of a refinement round at once,
- * large ones work through them one or two at a time. */
-constexpr int plane_bytes(int dim) { return dim * ((dim + 10) & ~1) * 2; }
+/* LDS bytes of the interpolation planes for PUs up to dim x dim. One plane is at most
+ * PLANE_COLS columns of (h + 10) int16 rows (wider PUs go block by block); the budget holds
+ * the six planes a refinement round of a 16x16 PU can need, or two blocks of a 64-row PU. */
+#define PLANE_COLS 16
 constexpr int plane_budget(int dim)
 {
-    return plane_bytes(dim) > 6144 ? plane_bytes(dim) : (6 * plane_bytes(dim) < 6144 ? 6 * plane_bytes(dim) : 6144);
+    return 6 * (dim < PLANE_COLS ? dim : PLANE_COLS) * (((dim < PLANE_COLS ? dim : PLANE_COLS) + 10) & ~1) * 2;
 }
 /* per-wave LDS: candidate arrays + context + source block of `rows` rows [+ planes] */
 template<typename P> constexpr int wave_lds_bytes(int rows, bool planes = false)
@@ -462,27 +462,45 @@ template<> struct HFilter<uint16_t>
  * the sum over its column. SATD: the vertical Hadamard runs inside the lane, the horizontal
  * one across the quad (DPP), and each lane returns the abs-sum of its four coefficients; the
  * caller halves the total (every tile's abs-sum is even, pixel.cpp:226). */
-template<typename P>
-__device__ __forceinline__ int plane_column_cost(int base, int k, int t, int x, int wt, int inv_wt, int depth)
+struct ColCand
 {
-    const int cpl = lds_i(base, L_CPL)[k];
-    const int *d = lds_i(base, L_PDESC + (cpl & 255) * 32);
-    const int ps = (d[1] >> 2) & 1, poff = d[3], prow = d[4];
+    /* what the vertical pass needs to know about a candidate: its plane (byte offset, row pitch),
+     * first plane row of the window of tile row 0, output shift / rounding offset, cost flavour,
+     * and the packed taps of its vertical phase */
+    int poff, prow, R0, shiftV, offV, satd;
+    uint32_t ev[4], od[5];
+    template<bool UNIFORM> __device__ __forceinline__ void load(int base, int k, int depth)
+    {
+#define U_(v) (UNIFORM ? uni(v) : (v))
+        const int cpl = U_(lds_i(base, L_CPL)[k]);
+        const int *d = lds_i(base, L_PDESC + (cpl & 255) * 32);
+        const int ps = (U_(d[1]) >> 2) & 1, headRoom = 14 - depth;
+        poff = U_(d[3]); prow = U_(d[4]);
+        R0 = ((cpl >> 8) & 255) - 16;
+        satd = (cpl >> 18) & 1;
+        shiftV = ps ? 6 + headRoom : 6;
+        offV = ps ? (1 << (5 + headRoom)) + (8192 << 6) : 32;
+        const int *tp = lds_i(base, L_TAPS + ((cpl >> 16) & 3) * 48);
+#pragma unroll
+        for (int i = 0; i < 4; i++) ev[i] = U_(tp[i]);
+#pragma unroll
+        for (int i = 0; i < 5; i++) od[i] = U_(tp[4 + i]);
+#undef U_
+    }
+};
+
+template<typename P>
+__device__ __forceinline__ int plane_column_cost(int base, const ColCand &cc, int t, int x, int wt, int inv_wt, int cb, int depth)
+{
+    const int poff = cc.poff, prow = cc.prow, shiftV = cc.shiftV, offV = cc.offV, maxv = (1 << depth) - 1;
+    const uint32_t *ev = cc.ev, *od = cc.od;
     const int ty = (t * inv_wt) >> 16, tx = t - ty * wt;
-    const int R = ((cpl >> 8) & 255) - 16 + 4 * ty;
+    const int R = cc.R0 + 4 * ty;
     const uint32_t sh16 = (R & 1) * 16;
-    const int *tp = lds_i(base, L_TAPS + ((cpl >> 16) & 3) * 48);
-    const int headRoom = 14 - depth, maxv = (1 << depth) - 1;
-    const int shiftV = ps ? 6 + headRoom : 6;
-    const int offV = ps ? (1 << (5 + headRoom)) + (8192 << 6) : 32;
     const uint32_t *col = (const uint32_t*)(x265amd_smem + base + poff + ((tx * 4 + x) * prow + (R & ~1)) * 2);
-    uint32_t E[7], e[6], ev[4], od[5];
+    uint32_t E[7], e[6];
 #pragma unroll
     for (int i = 0; i < 7; i++) E[i] = col[i];
-#pragma unroll
-    for (int i = 0; i < 4; i++) ev[i] = tp[i];
-#pragma unroll
-    for (int i = 0; i < 5; i++) od[i] = tp[4 + i];
 #pragma unroll
     for (int i = 0; i < 6; i++) e[i] = __builtin_amdgcn_alignbit(E[i + 1], E[i], sh16);
     int o[4];
@@ -490,11 +508,11 @@ __device__ __forceinline__ int plane_column_cost(int base, int k, int t, int x, 
     o[1] = dot2(e[0], od[0], dot2(e[1], od[1], dot2(e[2], od[2], dot2(e[3], od[3], dot2(e[4], od[4], offV)))));
     o[2] = dot2(e[1], ev[0], dot2(e[2], ev[1], dot2(e[3], ev[2], dot2(e[4], ev[3], offV))));
     o[3] = dot2(e[1], od[0], dot2(e[2], od[1], dot2(e[3], od[2], dot2(e[4], od[3], dot2(e[5], od[4], offV)))));
-    const P *f = (const P*)(x265amd_smem + base + L_FENC) + (ty * 4) * 64 + tx * 4 + x;
+    const P *f = (const P*)(x265amd_smem + base + L_FENC) + (ty * 4) * 64 + cb + tx * 4 + x;
     int dv[4];
 #pragma unroll
     for (int y = 0; y < 4; y++) dv[y] = (int)f[y * 64] - clip_pixel(as_i16(o[y] >> shiftV), maxv);
-    if (!((cpl >> 18) & 1))
+    if (!cc.satd)
         return abs(dv[0]) + abs(dv[1]) + abs(dv[2]) + abs(dv[3]);
     const int a0 = dv[0] + dv[1], a1 = dv[0] - dv[1], a2 = dv[2] + dv[3], a3 = dv[2] - dv[3];
     int c[4] = { a0 + a2, a1 + a3, a0 - a2, a1 - a3 };
@@ -556,7 +574,6 @@ __device__ __noinline__ void eval_planes(int base, int K, int mode, int addmv)
     const int pY0 = pymin - (papron ? 3 : 0);
     const int pnrows = pymax - pymin + h + (papron ? 7 : 0);
     const int pprow = (pnrows + 2) & ~1;
-    const int pbytes = w * pprow * 2, pitems = pnrows * wt;
     {
         const int Y0 = __shfl(pY0, mypl);
         if (lane < K) lds_i(base, L_CPL)[lane] = mypl | ((Y - 3 - Y0 + 16) << 8) | (yf << 16) | ((cm == 2 ? 1 : 0) << 18);
@@ -564,87 +581,137 @@ __device__ __noinline__ void eval_planes(int base, int K, int mode, int addmv)
 
     const int headRoom = 14 - depth, maxv = (1 << depth) - 1;
     const int shiftH = 6 - headRoom, offH = -(8192 << shiftH);
-    for (int p0 = 0; p0 < np;)
+    /* PUs wider than PLANE_COLS are worked through in column blocks, which bounds the LDS a plane
+     * needs; the candidates' costs add up over the blocks */
+    for (int cb = 0; cb < w; cb += PLANE_COLS)
     {
-        /* ---- the planes that fit in LDS together ---- */
-        int acc = 0, items = 0, p1 = p0, my_poff = 0, my_istart = 0;
-        while (p1 < np)
+        const int cw = w - cb < PLANE_COLS ? w - cb : PLANE_COLS;
+        const int wtb = cw >> 2, inv_wtb = (65536 + wtb - 1) / wtb, Tb = wtb * (h >> 2);
+        int lTb = 0;
+        while ((1 << lTb) < Tb) lTb++;
+        const int pbytes = cw * pprow * 2, pitems = pnrows * wtb;
+        for (int p0 = 0; p0 < np;)
         {
-            const int b = __builtin_amdgcn_readlane(pbytes, p1);
-            if (p1 > p0 && acc + b > budget) break;
-            if (lane == p1) { my_poff = acc; my_istart = items; }
-            acc += b;
-            items += __builtin_amdgcn_readlane(pitems, p1);
-            p1++;
-        }
-        if (lane >= p0 && lane < p1)
-        {
-            int *d = lds_i(base, L_PDESC + lane * 32);
-            const int pqx = pkey >> 1;
-            d[0] = pY0 * rstride + (pqx >> 2) - 3;
-            d[1] = (pqx & 3) | ((pkey & 1) << 2);
-            d[2] = my_istart; d[3] = planes_off + my_poff; d[4] = pprow;
-        }
-        const bool inch = lane < K && mypl >= p0 && mypl < p1;
-        const unsigned long long cmask = __ballot(inch);
-        const int nc = __builtin_popcountll(cmask);
-        if (inch) lds_i(base, L_CLIST)[__builtin_popcountll(cmask & ((1ull << lane) - 1))] = lane;
-        wave_sync();
+            /* ---- the planes that fit in LDS together ---- */
+            int acc = 0, items = 0, p1 = p0, my_poff = 0, my_istart = 0;
+            while (p1 < np)
+            {
+                const int b = __builtin_amdgcn_readlane(pbytes, p1);
+                if (p1 > p0 && acc + b > budget) break;
+                if (lane == p1) { my_poff = acc; my_istart = items; }
+                acc += b;
+                items += __builtin_amdgcn_readlane(pitems, p1);
+                p1++;
+            }
+            if (lane >= p0 && lane < p1)
+            {
+                int *d = lds_i(base, L_PDESC + lane * 32);
+                const int pqx = pkey >> 1;
+                d[0] = pY0 * rstride + (pqx >> 2) - 3 + cb;
+                d[1] = (pqx & 3) | ((pkey & 1) << 2);
+                d[2] = my_istart; d[3] = planes_off + my_poff; d[4] = pprow;
+            }
+            const bool inch = lane < K && mypl >= p0 && mypl < p1;
+            const unsigned long long cmask = __ballot(inch);
+            const int nc = __builtin_popcountll(cmask);
+            if (inch) lds_i(base, L_CLIST)[__builtin_popcountll(cmask & ((1ull << lane) - 1))] = lane;
+            wave_sync();
 
-        /* ---- horizontal pass: one item = 4 adjacent samples of one plane row ---- */
-        for (int i0 = 0; i0 < items; i0 += 64)
-        {
-            const bool act = i0 + lane < items;
-            const int i = act ? i0 + lane : items - 1;
-            int p = p0;
-            for (int q = p0 + 1; q < p1; q++) p += i >= lds_i(base, L_PDESC + q * 32)[2] ? 1 : 0;
-            const int *d = lds_i(base, L_PDESC + p * 32);
-            const int xfps = d[1], li = i - d[2], poff = d[3], prow = d[4];
-            const int r = (li * inv_wt) >> 16, q4 = li - r * wt;
-            int sum[4];
-            HFilter<P>::run(ref0 + d[0] + (long)r * rstride + 4 * q4, lds_i(base, L_TAPS + (xfps & 3) * 48), sum);
-            const bool ps = xfps & 4;
-            const int off = ps ? offH : 32, sh = ps ? shiftH : 6, lo = ps ? -32768 : 0, hi = ps ? 32767 : maxv;
-            int16_t *dst = (int16_t*)(x265amd_smem + base + poff) + (4 * q4) * prow + r;
-            if (act)
+            /* ---- horizontal pass: one item = 4 adjacent samples of one plane row ---- */
+            if (p1 == p0 + 1)
+            {
+                /* a single plane (the large-PU case): its description stays in scalar registers */
+                const int *d = lds_i(base, L_PDESC + p0 * 32);
+                const int src = uni(d[0]), xfps = uni(d[1]), poff = uni(d[3]), prow = uni(d[4]);
+                const int *tp = lds_i(base, L_TAPS + (xfps & 3) * 48);
+                int taps[11];
 #pragma unroll
-                for (int x = 0; x < 4; x++)
+                for (int i = 0; i < 11; i++) taps[i] = uni(tp[i]);
+                const bool ps = xfps & 4;
+                const int off = ps ? offH : 32, sh = ps ? shiftH : 6, lo = ps ? -32768 : 0, hi = ps ? 32767 : maxv;
+                for (int i0 = 0; i0 < items; i0 += 64)
                 {
-                    int v = as_i16((sum[x] + off) >> sh);
-                    v = v < lo ? lo : (v > hi ? hi : v);
-                    dst[x * prow] = (int16_t)v;
+                    const bool act = i0 + lane < items;
+                    const int i = act ? i0 + lane : items - 1;
+                    const int r = (i * inv_wtb) >> 16, q4 = i - r * wtb;
+                    int sum[4];
+                    HFilter<P>::run(ref0 + src + (long)r * rstride + 4 * q4, taps, sum);
+                    int16_t *dst = (int16_t*)(x265amd_smem + base + poff) + (4 * q4) * prow + r;
+                    if (act)
+#pragma unroll
+                        for (int x = 0; x < 4; x++)
+                        {
+                            int v = as_i16((sum[x] + off) >> sh);
+                            v = v < lo ? lo : (v > hi ? hi : v);
+                            dst[x * prow] = (int16_t)v;
+                        }
                 }
-        }
-        wave_sync();
+            }
+            else
+                for (int i0 = 0; i0 < items; i0 += 64)
+                {
+                    const bool act = i0 + lane < items;
+                    const int i = act ? i0 + lane : items - 1;
+                    int p = p0;
+                    for (int q = p0 + 1; q < p1; q++) p += i >= lds_i(base, L_PDESC + q * 32)[2] ? 1 : 0;
+                    const int *d = lds_i(base, L_PDESC + p * 32);
+                    const int xfps = d[1], li = i - d[2], poff = d[3], prow = d[4];
+                    const int r = (li * inv_wtb) >> 16, q4 = li - r * wtb;
+                    int sum[4];
+                    HFilter<P>::run(ref0 + d[0] + (long)r * rstride + 4 * q4, lds_i(base, L_TAPS + (xfps & 3) * 48), sum);
+                    const bool ps = xfps & 4;
+                    const int off = ps ? offH : 32, sh = ps ? shiftH : 6, lo = ps ? -32768 : 0, hi = ps ? 32767 : maxv;
+                    int16_t *dst = (int16_t*)(x265amd_smem + base + poff) + (4 * q4) * prow + r;
+                    if (act)
+#pragma unroll
+                        for (int x = 0; x < 4; x++)
+                        {
+                            int v = as_i16((sum[x] + off) >> sh);
+                            v = v < lo ? lo : (v > hi ? hi : v);
+                            dst[x * prow] = (int16_t)v;
+                        }
+                }
+            wave_sync();
 
-        /* ---- vertical pass + cost: one lane per (candidate, tile, column) ---- */
-        if (lTp <= 4)
-        {
-            const int l4 = lTp + 2, g = lane >> l4, t = (lane >> 2) & ((1 << lTp) - 1), cpp = 64 >> l4;
-            for (int j0 = 0; j0 < nc; j0 += cpp)
+            /* ---- vertical pass + cost: one lane per (candidate, tile, column) ---- */
+            if (lTb <= 4)
             {
-                const int j = j0 + g;
-                const bool act = j < nc && t < T;
-                const int k = lds_i(base, L_CLIST)[act ? j : 0];
-                int v = plane_column_cost<P>(base, k, act ? t : 0, lane & 3, wt, inv_wt, depth);
-                v = seg_sum(act ? v : 0, l4);
-                if (act && (lane & ((1 << l4) - 1)) == 0) lds_i(base, L_COSTS)[k] = v >> ((lds_i(base, L_CPL)[k] >> 18) & 1);
+                const int l4 = lTb + 2, g = lane >> l4, t = (lane >> 2) & ((1 << lTb) - 1), cpp = 64 >> l4;
+                for (int j0 = 0; j0 < nc; j0 += cpp)
+                {
+                    const int j = j0 + g;
+                    const bool act = j < nc && t < Tb;
+                    const int k = lds_i(base, L_CLIST)[act ? j : 0];
+                    ColCand cc;
+                    cc.load<false>(base, k, depth);
+                    int v = plane_column_cost<P>(base, cc, act ? t : 0, lane & 3, wtb, inv_wtb, cb, depth);
+                    v = seg_sum(act ? v : 0, l4);
+                    if (act && (lane & ((1 << l4) - 1)) == 0) lds_i(base, L_COSTS)[k] = (cb ? lds_i(base, L_COSTS)[k] : 0) + v;
+                }
             }
+            else
+                /* more than 16 tiles in the block: 16 tiles per pass */
+                for (int j = 0; j < nc; j++)
+                {
+                    const int k = uni(lds_i(base, L_CLIST)[j]);
+                    ColCand cc;   /* the same for every lane: kept in scalar registers */
+                    cc.load<true>(base, k, depth);
+                    int v = 0;
+                    for (int t0 = 0; t0 < Tb; t0 += 16)
+                    {
+                        const int t = t0 + (lane >> 2);
+                        const int c = plane_column_cost<P>(base, cc, t < Tb ? t : 0, lane & 3, wtb, inv_wtb, cb, depth);
+                        v += t < Tb ? c : 0;
+                    }
+                    v = seg_sum(v, 6);
+                    if (lane == 0) lds_i(base, L_COSTS)[k] = (cb ? lds_i(base, L_COSTS)[k] : 0) + v;
+                }
+            wave_sync();
+            p0 = p1;
         }
-        else
-            /* 32 tiles or more (always a multiple of 16): 16 tiles per pass */
-            for (int j = 0; j < nc; j++)
-            {
-                const int k = uni(lds_i(base, L_CLIST)[j]);
-                int v = 0;
-                for (int t0 = 0; t0 < T; t0 += 16) v += plane_column_cost<P>(base, k, t0 + (lane >> 2), lane & 3, wt, inv_wt, depth);
-                v = seg_sum(v, 6);
-                if (lane == 0) lds_i(base, L_COSTS)[k] = v >> ((lds_i(base, L_CPL)[k] >> 18) & 1);
-            }
-        wave_sync();
-        p0 = p1;
     }
-    if (lane < K) lds_i(base, L_COSTS)[lane] += mvc;
+    /* SATD: every tile's abs-sum is even, so halving the total equals halving per tile */
+    if (lane < K) lds_i(base, L_COSTS)[lane] = (lds_i(base, L_COSTS)[lane] >> ((lds_i(base, L_CPL)[lane] >> 18) & 1)) + mvc;
     wave_sync();
 }
 
