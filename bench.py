@@ -6,7 +6,7 @@ Workload (one step = one batch of synthetic 1080p 8-bit frame pairs per GPU):
     (42 900 PUs per frame), STAR search (--me star), merange 57, subme 5, predictors
     taken from the lookahead field of the same frame pair;
   * lookahead ME: the lowres MV field of each pair (8160 8x8 CUs, HEX, subme 1,
-    merange 16) on a second stream.
+    merange 16) on its own stream.
 Inputs (planes, job lists) are resident in HBM before the timed region. Results are
 checked against the CPU oracle before anything is reported.
 
@@ -39,12 +39,14 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--pairs", type=int, default=4, help="frame pairs per GPU per step")
-    ap.add_argument("--cpu-sample", type=int, default=4000, help="jobs timed on the host CPU (0 = skip)")
+    ap.add_argument("--pairs", type=int, default=32, help="frame pairs per GPU per step")
+    ap.add_argument("--cpu-pairs", type=int, default=24,
+                    help="frame pairs whose PU searches are re-run on one host core (parity gate + CPU baseline; 0 = skip)")
     ap.add_argument("--method", default="star")
     ap.add_argument("--subme", type=int, default=SUBME_DEFAULT, help="sub-pel refinement level (experiments only)")
-    ap.add_argument("--per-size", action="store_true", help="one search launch per PU size instead of one per frame")
-    ap.add_argument("--split", action="store_true", help="two launches per frame on two streams: 64/32 PUs and 16/8 PUs")
+    ap.add_argument("--launch", choices=("split", "single", "per-size"), default="split",
+                    help="search launches per frame: split = 16/8 PUs and 64/32 PUs on two streams (LDS per PU sized "
+                         "per class); single = one launch; per-size = four launches on one stream")
     args = ap.parse_args()
 
     import torch
@@ -64,9 +66,9 @@ def main():
     SUBME = args.subme
 
     # ---------------- setup (untimed): planes, lookahead fields, job lists, all on the device
-    es = Engine(local_rank, 8)      # search stream
+    es = Engine(local_rank, 8)      # search stream (all launches, or the 16/8 class)
     el = Engine(local_rank, 8)      # lookahead stream
-    eb = Engine(local_rank, 8) if args.split else es   # stream of the large-PU launches
+    eb = Engine(local_rank, 8) if args.launch == "split" else es   # stream of the 64/32 class
     B = args.pairs
     clip = make_clip(W, H, B + 1, seed=1234 + rank)
     planes, lowres = [], []
@@ -82,20 +84,20 @@ def main():
     la_pixel_sads = int((la_stats["sad_calls"].astype(np.int64) + la_stats["subpel_calls"]).sum()) * 64
 
     host_jobs, d_jobs, d_res = [], [], []
-    segs = None     # per launch: (first job, count, largest PU size)
+    segs = None     # per launch of a frame: (first job, count, largest PU size, engine); timed launch first
     for i in range(B):
-        jobs = workload.square_pu_jobs(W, H, la_mvs[i], wcu, hcu, MERANGE)
+        jobs = workload.square_pu_jobs(W, H, la_mvs[i], wcu, hcu, MERANGE)   # sorted 64, 32, 16, 8
         host_jobs.append(jobs)
         if segs is None:
-            segs = []
-            if args.split:
-                big = np.flatnonzero(jobs["w"] >= 32)
-                small = np.flatnonzero(jobs["w"] < 32)
-                segs = [(int(big[0]), len(big), 64, eb), (int(small[0]), len(small), 16, es)]
+            def seg(sel, dim, eng):
+                idx = np.flatnonzero(sel)
+                return (int(idx[0]), len(idx), dim, eng)
+            if args.launch == "split":
+                segs = [seg(jobs["w"] <= 16, 16, es), seg(jobs["w"] >= 32, 64, eb)]
+            elif args.launch == "single":
+                segs = [seg(jobs["w"] > 0, 64, es)]
             else:
-                for s_ in ((64, 32, 16, 8) if args.per_size else (0,)):
-                    idx = np.flatnonzero(jobs["w"] == s_) if s_ else np.arange(len(jobs))
-                    segs.append((int(idx[0]), len(idx), s_, es))
+                segs = [seg(jobs["w"] == s_, s_, es) for s_ in (8, 16, 32, 64)]
         d_jobs.append(torch.from_numpy(jobs.view(np.uint8).reshape(len(jobs), -1).copy()).to(dev))
         d_res.append(torch.zeros((len(jobs), RESULT_DTYPE.itemsize), dtype=torch.uint8, device=dev))
     njobs = len(host_jobs[0])
@@ -104,6 +106,9 @@ def main():
     d_la_costs = torch.zeros((B, ncu), dtype=torch.int32, device=dev)
     torch.cuda.synchronize()
 
+    # the roofline kernel is the first launch class (all of a frame, or its 16/8 PUs); its launches are
+    # the only work on es's stream in split / single mode, so events on that stream bracket exactly them
+    timed_first, timed_cnt = segs[0][0], segs[0][1]
     s_search = torch.cuda.ExternalStream(es.stream(), device=dev)
     ev0 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
     ev1 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
@@ -111,10 +116,14 @@ def main():
     def step(k=None):
         el.lookahead_fields_dev(d_fields, B, wcu, hcu, LA_QP, HEX, 1, LA_MERANGE,
                                 d_la_mvs.data_ptr(), d_la_costs.data_ptr())
+        for (first, cnt, dim, eng) in segs[1:] if args.launch == "split" else ():
+            for i in range(B):
+                eng.search_batch_dev(planes[i + 1], planes[i], d_jobs[i].data_ptr() + first * 40, cnt,
+                                     d_res[i].data_ptr() + first * 16, QP, method, SUBME, max_pu_dim=dim)
         if k is not None:
             ev0[k].record(s_search)
         for i in range(B):
-            for (first, cnt, dim, eng) in segs:
+            for (first, cnt, dim, eng) in segs if args.launch != "split" else segs[:1]:
                 eng.search_batch_dev(planes[i + 1], planes[i], d_jobs[i].data_ptr() + first * 40, cnt,
                                      d_res[i].data_ptr() + first * 16, QP, method, SUBME, max_pu_dim=dim)
         if k is not None:
@@ -155,38 +164,46 @@ def main():
         dist.all_reduce(total_px, op=dist.ReduceOp.SUM)
     value = float(total_px.item()) / elapsed / 1e9
 
-    search_ms = sum(ev0[k].elapsed_time(ev1[k]) for k in range(args.steps)) / (args.steps * B)
-    alg_bytes = sum(workload.algorithmic_bytes(j) for j in host_jobs) / B
-    achieved = alg_bytes / (search_ms * 1e-3) / 1e9
+    nlaunch = 1 if args.launch != "per-size" else len(segs)
+    launch_ms = sum(ev0[k].elapsed_time(ev1[k]) for k in range(args.steps)) / (args.steps * B * nlaunch)
+    tsel = slice(timed_first, timed_first + timed_cnt) if args.launch != "per-size" else slice(0, njobs)
+    alg_bytes = sum(workload.algorithmic_bytes(j[tsel]) for j in host_jobs) / (B * nlaunch)
+    achieved = alg_bytes / (launch_ms * 1e-3) / 1e9
     traffic = None
     tpath = os.path.join(ROOT, "profiles", "traffic.json")
     if os.path.exists(tpath):
-        traffic = json.load(open(tpath)).get("search_kernel_hbm_bytes_per_launch")
+        traffic = json.load(open(tpath)).get("search_kernel_hbm_bytes_per_launch", {}).get(args.launch)
 
     if rank == 0:
-        # parity gate + CPU baseline: the oracle on a bounded sample of the same jobs
+        # parity gate + CPU baseline: the oracle re-runs every PU search of the first frame pairs
         from oracle.bindings import Oracle   # checker / baseline only
         orc = Oracle()
-        cur, org, stride = pad_plane(clip[1], MARGIN)
-        ref, _, _ = pad_plane(clip[0], MARGIN)
-        ctx = orc.make_ctx(8, cur, org, stride, [ref], org, stride, False, QP, method, SUBME)
         cpu = None
-        if args.cpu_sample > 0:
-            idx = np.linspace(0, njobs - 1, min(args.cpu_sample, njobs)).astype(np.int64)
-            sample = np.ascontiguousarray(host_jobs[0][idx])
-            c0 = time.perf_counter()
-            exp = orc.me_search_batch(ctx, sample)
-            cpu_s = time.perf_counter() - c0
-            got = res[0][idx]
-            if not (np.array_equal(got["mv"], exp["mv"]) and np.array_equal(got["cost"], exp["cost"])
-                    and np.array_equal(got["sad_calls"], exp["sad_calls"])
-                    and np.array_equal(got["subpel_calls"], exp["subpel_calls"])):
-                print("PARITY FAILURE: GPU results differ from the oracle", file=sys.stderr)
-                sys.exit(2)
-            cpu = {"value": workload.pixel_sads(sample, exp) / cpu_s / 1e9, "unit": "Gpixel-SAD/s", "cores": 1,
-                   "kind": "port",
-                   "sample": "%d of the %d PU searches of frame pair 0 (evenly spaced over all four depths), "
-                             "oracle/me_oracle.c -O2 single thread, %.1f s" % (len(sample), njobs, cpu_s)}
+        ncpu = min(args.cpu_pairs, B)
+        if ncpu > 0:
+            cpu_s, cpu_px = 0.0, 0
+            for i in range(ncpu):
+                cur, org, stride = pad_plane(clip[i + 1], MARGIN)
+                ref, _, _ = pad_plane(clip[i], MARGIN)
+                ctx = orc.make_ctx(8, cur, org, stride, [ref], org, stride, False, QP, method, SUBME)
+                c0 = time.perf_counter()
+                exp = orc.me_search_batch(ctx, host_jobs[i])
+                cpu_s += time.perf_counter() - c0
+                got = res[i]
+                if not (np.array_equal(got["mv"], exp["mv"]) and np.array_equal(got["cost"], exp["cost"])
+                        and np.array_equal(got["sad_calls"], exp["sad_calls"])
+                        and np.array_equal(got["subpel_calls"], exp["subpel_calls"])):
+                    print("PARITY FAILURE: GPU results of frame pair %d differ from the oracle" % i, file=sys.stderr)
+                    sys.exit(2)
+                cpu_px += workload.pixel_sads(host_jobs[i], exp)
+            cpu = {"value": cpu_px / cpu_s / 1e9, "unit": "Gpixel-SAD/s", "cores": 1, "kind": "port",
+                   "sample": "all %d PU searches of %d of the %d frame pairs of one step (the lookahead fields are not "
+                             "in the sample), oracle/me_oracle.c -O3 single thread, %.1f s; every result compared "
+                             "with the GPU's" % (njobs * ncpu, ncpu, B, cpu_s)}
+        kernel = {"split": "search_kernel<uint8_t,false>, the launch over a frame's %d 16x16 + 8x8 PUs (its 64/32 PUs run "
+                           "concurrently on a second stream)" % timed_cnt,
+                  "single": "search_kernel<uint8_t,false>, one launch per frame (%d PUs)" % timed_cnt,
+                  "per-size": "search_kernel<uint8_t,false>, average of the 4 per-size launches of a frame"}[args.launch]
         out = {
             "metric": "ME Gpixel-SAD/s", "value": value, "unit": "Gpixel-SAD/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
@@ -195,11 +212,11 @@ def main():
                                    "square PUs + lookahead HEX field, %d frame pairs per GPU per step"
                                    % (args.method, MERANGE, SUBME, B),
                        "pu_searches_per_step_per_gpu": njobs * B, "lookahead_cus_per_step_per_gpu": ncu * B,
-                       "qp": QP, "parallelism": "frame pairs sharded over %d GPU(s), gather of MV records" % world},
+                       "qp": QP, "launch": args.launch,
+                       "parallelism": "frame pairs sharded over %d GPU(s), gather of MV records" % world},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": "search_kernel<uint8_t,false> (%d launch(es) per frame)" % len(segs), "launch_ms": search_ms,
-                         "algorithmic_bytes_per_launch": alg_bytes},
+                         "kernel": kernel, "launch_ms": launch_ms, "algorithmic_bytes_per_launch": alg_bytes},
             "cpu_baseline": cpu,
             "fps_equiv": B * args.steps * world / elapsed,
         }
