@@ -327,6 +327,32 @@ class Ref:
                 out["cime"]["mv"] = (res[9], res[10]); out["cime"]["cost"] = res[11]
         return out
 
+    def cmodel_cime(self, cur, ref, pic_w, pic_h, qp, ctu_addr, sw_w, sw_h, neigh):
+        """The hardware C-model's coarse search for one CTU (CoarseIntMotionEstimation::CIME). `cur` / `ref` are
+        unpadded 8-bit pictures (2-D arrays); `neigh` the 28 neighbour MVs. Returns (mv, cost, mvp[3])."""
+        assert self.depth == 8
+        cur = np.ascontiguousarray(cur, np.uint8)
+        ref = np.ascontiguousarray(ref, np.uint8)
+        nb = np.ascontiguousarray(neigh, np.int16).reshape(28, 2)
+        out = np.zeros(8, np.int16)
+        cost = self.L.ref_cmodel_cime(_p(cur), cur.shape[1], _p(ref), ref.shape[1], pic_w, pic_h, qp, ctu_addr, sw_w, sw_h,
+                                      _p(nb), _p(out))
+        return (int(out[0]), int(out[1])), cost, out[2:].reshape(3, 2).copy()
+
+    def cmodel_rime_fme(self, cur, ref, pic_w, pic_h, qp, ctu_addr, neigh, cime_mv):
+        """The hardware C-model's refine + fractional stages for the 85 CUs of one CTU
+        (RefineIntMotionEstimation::RimeAndFme). Returns (rime[85] {mv, cost}, fme[85] {mv, cost}, window
+        centres pmv[3], cost predictors mvp[3])."""
+        assert self.depth == 8
+        cur = np.ascontiguousarray(cur, np.uint8)
+        ref = np.ascontiguousarray(ref, np.uint8)
+        nb = np.ascontiguousarray(neigh, np.int16).reshape(28, 2)
+        cm = np.ascontiguousarray(cime_mv, np.int16)
+        out = np.zeros(85 * 6 + 12, np.int32)
+        self.L.ref_cmodel_rime_fme(_p(cur), cur.shape[1], _p(ref), ref.shape[1], pic_w, pic_h, qp, ctu_addr, _p(nb), _p(cm), _p(out))
+        cu = out[:510].reshape(85, 6)
+        return cu[:, 0:3].copy(), cu[:, 3:6].copy(), out[510:516].reshape(3, 2).copy(), out[516:522].reshape(3, 2).copy()
+
     def lookahead_field(self, fenc, refs, origin, stride, wcu, hcu, qp, method, subme, merange):
         planes = (C.c_void_p * 4)(*[r.ctypes.data + origin * r.itemsize for r in refs])
         mvs = np.zeros((hcu * wcu, 2), np.int16)

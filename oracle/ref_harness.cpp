@@ -290,4 +290,109 @@ int ref_rk_me(void *h, pixel *fencPlane, intptr_t fencStride, int qp,
     return cost;
 }
 
+/* ---- C-model twin of the coarse stage: CoarseIntMotionEstimation::CIME
+ * (hardwareC/inter.cpp:679-734) driven the way TEncCu::CimePrepare does
+ * (TEncCu.cpp:361-474): picture size, one P-slice reference, search-window size, CTU
+ * address, QP, the original picture, the reference to down-sample, the 28 neighbour MVs.
+ * The model prefetches its own edge-replicated window (inter.cpp:296-647) and derives
+ * its three cost predictors with setMvp (:755-842); both are returned so that the
+ * x265-side path can be given the same predictors. 8-bit only, as the model is. ---- */
+#if !HIGH_BIT_DEPTH
+int ref_cmodel_cime(const unsigned char *cur, int curStride, const unsigned char *refPic, int refStride,
+                    int picW, int picH, int qp, int ctuAddr, int swW, int swH,
+                    const int16_t *neigh /* nAllNeighMv x {x,y} */, int16_t *out /* mv.x mv.y mvp[3].{x,y} */)
+{
+    CoarseIntMotionEstimation c;
+    c.setPicWidth(picW); c.setPicHeight(picH);
+    c.setRefPicNum(1, 0); c.setRefPicNum(0, 1);
+    c.setSliceType(p_slice);
+    c.Create(swW, swH);
+    c.setCtuPosInPic(ctuAddr);
+    c.setQP((char)qp);
+    c.setOrigPic(const_cast<unsigned char*>(cur), curStride);
+    c.setDownSamplePic(const_cast<unsigned char*>(refPic), refStride, 0);
+    for (int i = 0; i < nAllNeighMv; i++)
+    {
+        Mv m; m.x = neigh[2 * i]; m.y = neigh[2 * i + 1];
+        c.setNeighMv(m, 0, i);
+    }
+    c.CIME(c.getOrigPic(), c.getRefPicDS(0), 0);
+    Mv r = c.getCimeMv(0), mvp[3];
+    c.setMvp(mvp, 0);
+    out[0] = r.x; out[1] = r.y;
+    for (int i = 0; i < 3; i++) { out[2 + 2 * i] = mvp[i].x; out[3 + 2 * i] = mvp[i].y; }
+    const int cost = r.nSadCost;
+    c.Destroy();
+    return cost;
+}
+
+/* C-model twin of the refine + fractional stages: RefineIntMotionEstimation::RimeAndFme
+ * (hardwareC/inter.cpp:2521-2624) for all 85 CUs of one CTU, set up the way
+ * TEncCu::RimeAndFmePrepare does (TEncCu.cpp:509-687): pictures copied in, the CTU's
+ * neighbour MVs and coarse MV given to setPmv, the three CTU search windows prefetched,
+ * then per CU its own windows. Chroma is not part of the motion search; flat planes stand
+ * in for it. out: per CU {rime.x, rime.y, rime.cost, fme.x, fme.y, fme.cost} (cost -1 for CUs
+ * outside the picture), then the three window centres and the three cost predictors the
+ * model derived. */
+int ref_cmodel_rime_fme(const unsigned char *cur, int curStride, const unsigned char *refPic, int refStride,
+                        int picW, int picH, int qp, int ctuAddr, const int16_t *neigh, const int16_t *cimeMv,
+                        int32_t *out /* 85 * 6 + 12 */)
+{
+    static RefineIntMotionEstimation r;
+    r.setPicWidth(picW); r.setPicHeight(picH);
+    r.setRefPicNum(1, 0); r.setRefPicNum(0, 1);
+    r.setSliceType(p_slice);
+    r.CreatePicInfo();
+    const int cw = picW / 2, ch = picH / 2;
+    unsigned char *flat = new unsigned char[cw * ch];
+    memset(flat, 128, cw * ch);
+    r.setOrigPic(const_cast<unsigned char*>(cur), curStride, flat, cw, flat, cw);
+    r.setRefPic(const_cast<unsigned char*>(refPic), refStride, flat, cw, flat, cw, 0);
+    r.setCtuSize(64);
+    r.setCtuPosInPic(ctuAddr);
+    r.setQP((char)qp);
+    Mv nb[nAllNeighMv], cm;
+    for (int i = 0; i < nAllNeighMv; i++) { nb[i].x = neigh[2 * i]; nb[i].y = neigh[2 * i + 1]; }
+    cm.x = cimeMv[0]; cm.y = cimeMv[1];
+    r.setPmv(nb, cm, 0);
+    r.PrefetchCtuLumaInfo(0);
+    r.PrefetchCtuChromaInfo(0);
+    for (int cu = 0; cu < 85; cu++)
+    {
+        const int size = cu < 64 ? 8 : (cu < 80 ? 16 : (cu < 84 ? 32 : 64));
+        r.setCuPosInCtu(cu);
+        r.CreateCuInfo(size + 2 * (nRimeWidth + 4), size + 2 * (nRimeHeight + 4), size);
+        int32_t *o = out + 6 * cu;
+        if (r.PrefetchCuInfo(0))
+        {
+            r.RimeAndFme(0);
+            Mv a = r.getRimeMv(0), b = r.getFmeMv(0);
+            o[0] = a.x; o[1] = a.y; o[2] = a.nSadCost; o[3] = b.x; o[4] = b.y; o[5] = b.nSadCost;
+        }
+        else { o[0] = o[1] = o[3] = o[4] = 0; o[2] = o[5] = -1; }
+        r.DestroyCuInfo();
+    }
+    Mv mvp[3];
+    r.setMvp(mvp, nb);
+    for (int i = 0; i < 3; i++)
+    {
+        Mv p; r.getPmv(p, 0, i);
+        out[510 + 2 * i] = p.x; out[511 + 2 * i] = p.y;
+        out[516 + 2 * i] = mvp[i].x; out[517 + 2 * i] = mvp[i].y;
+    }
+    r.DestroyPicInfo();
+    delete[] flat;
+    return 0;
+}
+#else
+int ref_cmodel_rime_fme(const unsigned char*, int, const unsigned char*, int, int, int, int, int, const int16_t*, const int16_t*, int32_t*)
+{
+    return -1;
+}
+int ref_cmodel_cime(const unsigned char*, int, const unsigned char*, int, int, int, int, int, int, int, const int16_t*, int16_t*)
+{
+    return -1;
+}
+#endif
+
 } // extern "C"

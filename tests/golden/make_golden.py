@@ -22,7 +22,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 from oracle.bindings import Ref, PARTITIONS, METHODS  # noqa: E402
 from util import clip_planes, random_jobs, host_lowres_planes, margin_for  # noqa: E402
 from oracle.bindings import Oracle  # noqa: E402
-from x265_amd.synth import make_clip  # noqa: E402
+from x265_amd.synth import make_clip, pad_plane  # noqa: E402
 
 ME_W, ME_H = 192, 128
 LA_W, LA_H = 416, 240
@@ -157,19 +157,42 @@ def main():
         rk[k + "_mv"] = np.stack([r[k]["mv"] for r in recs])
         rk[k + "_cost"] = np.stack([r[k]["cost"] for r in recs])
     np.savez_compressed(os.path.join(HERE, "rk_golden.npz"), **rk)
+    make_cmodel(shas)
     json.dump(shas, open(os.path.join(HERE, "input_sha.json"), "w"), indent=0, sort_keys=True)
     print("golden vectors written to", HERE)
 
 
-class ref_as_orc:
-    """Adapter so util.host_lowres_planes can drive the reference's downscaler."""
-
-    def __init__(self, ref):
-        self.ref = ref
-
-    def lowres_core(self, depth, src, so, ss, w, h):
-        return self.ref.lowres_core(src, so, ss, w, h)
+def make_cmodel(shas):
+    """Records of the reference's hardware C-model: coarse stage (CoarseIntMotionEstimation::CIME,
+    hardwareC/inter.cpp:679-734), refine + fractional stages for the 85 CUs of each CTU
+    (RefineIntMotionEstimation::RimeAndFme, :2521-2624), and the window centres / cost predictors the model
+    derived from the neighbour MVs (setPmv :882-989, setMvp :755-842, :991-1080)."""
+    from test_gpu_rk import cmodel_case, M
+    ref = Ref(8)
+    W, H, qp, clip, recon_pic, (sw_w, sw_h), neigh, jobs = cmodel_case()
+    cur, org, stride = pad_plane(clip[1], M)
+    rorig, _, _ = pad_plane(clip[0], M)
+    recon, _, _ = pad_plane(recon_pic, M)
+    shas["cmodel_8"] = [sha(cur), sha(rorig), sha(recon)]
+    out = {k: [] for k in ("cime_mv", "cime_cost", "rime_mv", "rime_cost", "fme_mv", "fme_cost", "pmv", "mvp")}
+    for a in range(len(jobs)):
+        mv, cost, mvp = ref.cmodel_cime(clip[1], clip[0], W, H, qp, a, sw_w, sw_h, neigh[a])
+        rime, fme, pmv, mvp_r = ref.cmodel_rime_fme(clip[1], recon_pic, W, H, qp, a, neigh[a], mv)
+        assert np.array_equal(mvp, mvp_r)
+        out["cime_mv"].append(mv); out["cime_cost"].append(cost)
+        out["rime_mv"].append(rime[:, :2]); out["rime_cost"].append(rime[:, 2])
+        out["fme_mv"].append(fme[:, :2]); out["fme_cost"].append(fme[:, 2])
+        out["pmv"].append(pmv); out["mvp"].append(mvp)
+    np.savez_compressed(os.path.join(HERE, "cmodel_golden.npz"),
+                        **{k: np.array(v, np.int32 if k.endswith("cost") else np.int16) for k, v in out.items()})
 
 
 if __name__ == "__main__":
-    main()
+    if sys.argv[1:] == ["cmodel"]:
+        # only (re)generate the C-model records, keeping the other files as they are
+        shas_path = os.path.join(HERE, "input_sha.json")
+        shas_ = json.load(open(shas_path))
+        make_cmodel(shas_)
+        json.dump(shas_, open(shas_path, "w"), indent=0, sort_keys=True)
+    else:
+        main()

@@ -29,6 +29,28 @@ def rk_case(depth, W, H, seed):
     return cur, rorig, recon, org, stride, jobs
 
 
+def cmodel_case():
+    """Inputs of the C-model twin checks: (W, H, qp, clip, recon picture, search-window size of the coarse stage,
+    per-CTU 28 neighbour MVs, jobs without predictors). The coarse window is range / 4 + 16 samples of the 4x4-sum
+    plane (TEncCu.cpp:404-406) and the MV range follows from it (hardwareC/inter.cpp:683-685)."""
+    W, H, meX, meY, qp = 320, 192, 96, 64, 31
+    clip = make_clip(W, H, 2, seed=17)
+    noise = np.random.default_rng(3).integers(-2, 3, clip[0].shape)
+    recon_pic = np.clip(clip[0].astype(int) + noise, 0, 255).astype(np.uint8)
+    sw_w, sw_h = meX // 4 + 16, meY // 4 + 16
+    lo_x, lo_y = -(sw_w - 16) // 2, -(sw_h - 16) // 2
+    wctu, hctu = (W + 63) // 64, (H + 63) // 64
+    neigh = (np.random.default_rng(23).integers(-16, 17, (wctu * hctu, 28, 2)) * 2).astype(np.int16)
+    jobs = np.zeros(wctu * hctu, RK_CTU_DTYPE)
+    for a in range(wctu * hctu):
+        cx, cy = (a % wctu) * 64, (a // wctu) * 64
+        jobs[a]["ctu_x"], jobs[a]["ctu_y"] = cx, cy
+        jobs[a]["valid_w"], jobs[a]["valid_h"] = min(64, W - cx), min(64, H - cy)
+        jobs[a]["mvmin"], jobs[a]["mvmax"] = (4 * lo_x, 4 * lo_y), (4 * (-1 - lo_x), 4 * (-1 - lo_y))
+        jobs[a]["have_mvd"] = 1
+    return W, H, qp, clip, recon_pic, (sw_w, sw_h), neigh, jobs
+
+
 def same(a, b):
     return all(np.array_equal(a[k]["mv"], b[k]["mv"]) and np.array_equal(a[k]["cost"], b[k]["cost"])
                for k in ("cime", "rime", "fme"))
@@ -91,3 +113,23 @@ def test_rk_argument_errors(engine8):
     with pytest.raises(EngineError):
         engine8.rk_ctu_batch(pc, pc, pds, 30, bad)
     assert len(engine8.rk_ctu_batch(pc, pc, pds, 30, jobs[:0])) == 0
+
+
+def test_rk_matches_cmodel_golden(engine8):
+    """All three stages against records made by the reference's hardware C-model
+    (CoarseIntMotionEstimation::CIME, RefineIntMotionEstimation::RimeAndFme), which works on its own
+    prefetched, edge-replicated search windows."""
+    g = np.load(G.GOLD + "/cmodel_golden.npz")
+    W, H, qp, clip, recon_pic, sw, neigh, jobs = cmodel_case()
+    cur, org, stride = pad_plane(clip[1], M)
+    rorig, _, _ = pad_plane(clip[0], M)
+    recon, _, _ = pad_plane(recon_pic, M)
+    assert [G.sha(cur), G.sha(rorig), G.sha(recon)] == G.input_shas()["cmodel_8"]
+    jobs["mvp"] = g["mvp"]
+    jobs["pmv"] = g["pmv"][:, 1:3]
+    pc = engine8.upload_plane(cur, W, H, M, M, stride)
+    po = engine8.upload_plane(rorig, W, H, M, M, stride)
+    pr = engine8.upload_plane(recon, W, H, M, M, stride)
+    got = engine8.rk_ctu_batch(pc, pr, engine8.rk_ds_plane(po), qp, jobs)
+    for k in ("cime", "rime", "fme"):
+        assert np.array_equal(got[k]["mv"], g[k + "_mv"]) and np.array_equal(got[k]["cost"], g[k + "_cost"]), k

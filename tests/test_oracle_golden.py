@@ -80,3 +80,22 @@ def test_rk_ctu_records(oracle):
     got = oracle.rk_ctu_batch(ctx, ds, dorg, dstride, W, H, jobs)
     for k in ("cime", "rime", "fme"):
         assert np.array_equal(got[k]["mv"], g[k + "_mv"]) and np.array_equal(got[k]["cost"], g[k + "_cost"]), k
+
+
+def test_rk_matches_cmodel_records(oracle):
+    """Oracle CIME / RIME / FME == the hardware C-model's records (made by tests/golden/make_golden.py)."""
+    from test_gpu_rk import cmodel_case, M
+    from x265_amd.synth import pad_plane
+    g = np.load(G.GOLD + "/cmodel_golden.npz")
+    W, H, qp, clip, recon_pic, sw, neigh, jobs = cmodel_case()
+    cur, org, stride = pad_plane(clip[1], M)
+    rorig, _, _ = pad_plane(clip[0], M)
+    recon, _, _ = pad_plane(recon_pic, M)
+    assert [G.sha(cur), G.sha(rorig), G.sha(recon)] == G.input_shas()["cmodel_8"]
+    jobs["mvp"] = g["mvp"]
+    jobs["pmv"] = g["pmv"][:, 1:3]
+    ds, dorg, dstride = oracle.rk_downsample(8, rorig, org, W, H, stride, M // 4)
+    ctx = oracle.make_ctx(8, cur, org, stride, [recon], org, stride, False, qp, 0, 0)
+    got = oracle.rk_ctu_batch(ctx, ds, dorg, dstride, W, H, jobs)
+    for k in ("cime", "rime", "fme"):
+        assert np.array_equal(got[k]["mv"], g[k + "_mv"]) and np.array_equal(got[k]["cost"], g[k + "_cost"]), k
