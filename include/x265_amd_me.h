@@ -123,6 +123,14 @@ int x265amd_search_batch_dev(x265amd_ctx *ctx, const x265amd_plane *fenc, const 
                              const x265amd_job *d_jobs, int njobs, x265amd_result *d_results, int max_pu_dim);
 int x265amd_sync(x265amd_ctx *ctx);
 
+/* X265_FULL_SEARCH (encoder/motion.cpp:1021-1056) on 8-bit planes scans each PU's search range
+ * from a copy of the reference window in LDS; ranges too large for the window are scanned in
+ * strips. `bytes` (8192 .. 131072, default 65536) is the LDS one PU may use for that copy when
+ * the jobs are device-resident (x265amd_search_batch sizes it from the jobs it is given, up to
+ * this limit): smaller windows keep more PUs resident per compute unit. Tuning only; results do
+ * not depend on it. */
+int x265amd_set_esa_window_bytes(x265amd_ctx *ctx, int bytes);
+
 /* MotionEstimate::subpelCompare (encoder/motion.cpp:1651-1689) for njobs PUs:
  * job.qmvp is the qpel MV to evaluate, cmp 0 = sad, 1 = satd; results[i].cost. */
 int x265amd_subpel_compare_batch(x265amd_ctx *ctx, const x265amd_plane *fenc, const x265amd_plane *ref,

@@ -172,3 +172,41 @@ def test_full_size_properties(engine8):
     t = engine8.cost_table(30).astype(np.int64)
     assert (r["cost"] == t[32767 + 12] + t[32767 - 8]).all()
     assert (r["sad_calls"] == 81).all()   # the 9x9 raster; the zero predictor itself is measured through subpelCompare
+
+
+def test_exhaustive_search_windows(engine8, oracle):
+    """X265_FULL_SEARCH through the LDS-window kernel: ranges that are not multiples of the lane patch
+    (4 columns x 8 rows), asymmetric and clipped ranges, every partition height class, and the same
+    jobs again with the smallest window budget so that the range is scanned in several x / y strips."""
+    W, H = 256, 160
+    m = 110
+    fenc, ref, org, stride = clip_planes(W, H, 8, "texture", seed=21, margin=m)
+    pf = engine8.upload_plane(fenc, W, H, m, m, stride)
+    pr = engine8.upload_plane(ref, W, H, m, m, stride)
+    rng = np.random.default_rng(77)
+    parts = [(8, 8), (16, 16), (32, 32), (64, 64), (12, 16), (16, 4), (4, 16), (24, 32), (64, 16), (48, 64), (8, 32)]
+    jobs = make_jobs(len(parts) * 2)
+    for i in range(len(jobs)):
+        w, h = parts[i % len(parts)]
+        j = jobs[i]
+        j["pu_x"], j["pu_y"], j["w"], j["h"] = int(rng.integers(0, (W - w) // 4 + 1)) * 4, int(rng.integers(0, (H - h) // 4 + 1)) * 4, w, h
+        rx0, rx1, ry0, ry1 = (int(v) for v in rng.integers(1, 45, 4))
+        qmvp = (int(rng.integers(-40, 41)), int(rng.integers(-40, 41)))
+        cx, cy = qmvp[0] >> 2, qmvp[1] >> 2
+        j["mvmin"], j["mvmax"] = (cx - rx0, cy - ry0), (cx + rx1, cy + ry1)
+        j["qmvp"] = qmvp
+        j["numc"] = 2
+        j["mvc"][0] = (int(rng.integers(-60, 61)), int(rng.integers(-60, 61)))
+        j["mvc"][1] = (0, 4)
+        j["merange"] = 45
+    mv, cost, sc, qc = oracle_search(oracle, 8, fenc, [ref], org, stride, jobs, 27, METHODS["full"], 5)
+    for budget in (65536, 8192):
+        engine8.set_esa_window_bytes(budget)
+        r = engine8.search_batch(pf, pr, jobs, 27, METHODS["full"], 5)
+        assert np.array_equal(r["mv"], mv) and np.array_equal(r["cost"], cost), budget
+        assert np.array_equal(r["sad_calls"], sc) and np.array_equal(r["subpel_calls"], qc), budget
+    engine8.set_esa_window_bytes(65536)
+    with pytest.raises(EngineError):
+        engine8.set_esa_window_bytes(100)
+    engine8.free_plane(pf)
+    engine8.free_plane(pr)

@@ -62,6 +62,8 @@ __global__ __launch_bounds__(64) void search_kernel(SearchArgs a)
     S.search(job, a.method, a.subme, a.results + j);
 }
 
+#include "me_esa.h"   /* esa_kernel: uses SearchArgs and xcd_remap */
+
 /* subpelCompare for a batch of PUs (motion.cpp:1651-1689) */
 template<typename P>
 __global__ __launch_bounds__(64) void subpel_compare_kernel(SearchArgs a, int cmp)
@@ -554,7 +556,12 @@ struct x265amd_ctx
     void *d_results; size_t results_cap;
     void *d_stage; size_t stage_cap;   /* staging for the per-call primitives */
     int32_t *d_out;
+    int esa_window_bytes;              /* LDS the exhaustive search may use per PU for its window */
 };
+
+#define ESA_WINDOW_DEFAULT 65536
+#define ESA_WINDOW_MIN 8192
+#define ESA_WINDOW_MAX 131072
 
 static int fail(x265amd_ctx *c, int code, const std::string &msg)
 {
@@ -573,6 +580,22 @@ static int ensure(x265amd_ctx *c, void **p, size_t *cap, size_t need)
     HIPCHK(c, hipMalloc(p, n));
     *cap = n;
     return 0;
+}
+
+/* X265_FULL_SEARCH on 8-bit planes: workgroup-per-PU scan through an LDS window */
+static int launch_esa(x265amd_ctx *c, const SearchArgs &a, int window_bytes)
+{
+    static bool lds_raised = false;
+    if (!lds_raised)
+    {
+        HIPCHK(c, hipFuncSetAttribute((const void*)esa_kernel<uint8_t>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      wave_lds_bytes<uint8_t>(64, true) + 128 + ESA_WINDOW_MAX));
+        lds_raised = true;
+    }
+    const int lds = ((wave_lds_bytes<uint8_t>(a.max_dim, true) + 15) & ~15) + 64 + window_bytes;
+    hipLaunchKernelGGL(esa_kernel<uint8_t>, dim3(a.njobs), dim3(ESA_THREADS), lds, c->stream, a, window_bytes);
+    HIPCHK(c, hipGetLastError());
+    return X265AMD_OK;
 }
 
 template<typename P>
@@ -603,6 +626,7 @@ int x265amd_create(int device, int bit_depth, x265amd_ctx **out)
     x265amd_ctx *c = new x265amd_ctx();
     c->device = device; c->depth = bit_depth;
     c->d_jobs = c->d_results = c->d_stage = 0; c->jobs_cap = c->results_cap = c->stage_cap = 0; c->d_out = 0;
+    c->esa_window_bytes = ESA_WINDOW_DEFAULT;
     if (hipSetDevice(device) != hipSuccess || hipStreamCreate(&c->stream) != hipSuccess ||
         hipMalloc((void**)&c->d_out, 64) != hipSuccess)
     {
@@ -821,9 +845,16 @@ static void fill_args(x265amd_ctx *c, SearchArgs &a, const x265amd_plane *fenc, 
     a.ctab = c->tables[qp] + 32768;
 }
 
-int x265amd_search_batch_dev(x265amd_ctx *c, const x265amd_plane *fenc, const x265amd_plane *ref, int is_lowres,
-                             int qp, int method, int subme, const x265amd_job *d_jobs, int njobs, x265amd_result *d_results,
-                             int max_pu_dim)
+int x265amd_set_esa_window_bytes(x265amd_ctx *c, int bytes)
+{
+    if (!c || bytes < ESA_WINDOW_MIN || bytes > ESA_WINDOW_MAX) return fail(c, X265AMD_EINVAL, "window bytes out of range");
+    c->esa_window_bytes = bytes & ~15;
+    return X265AMD_OK;
+}
+
+static int search_dev(x265amd_ctx *c, const x265amd_plane *fenc, const x265amd_plane *ref, int is_lowres,
+                      int qp, int method, int subme, const x265amd_job *d_jobs, int njobs, x265amd_result *d_results,
+                      int max_pu_dim, int esa_window)
 {
     if (!c || !fenc || !ref || !d_jobs || !d_results || njobs < 0) return fail(c, X265AMD_EINVAL, "null argument");
     if (method < 0 || method > X265AMD_FULL || subme < 0 || subme > 7)
@@ -839,7 +870,16 @@ int x265amd_search_batch_dev(x265amd_ctx *c, const x265amd_plane *fenc, const x2
     fill_args(c, a, fenc, ref, is_lowres, qp, method, subme);
     a.jobs = d_jobs; a.results = d_results; a.njobs = njobs;
     if (!is_lowres) a.max_dim = max_pu_dim;
+    if (method == X265AMD_FULL && !is_lowres && c->depth <= 8) return launch_esa(c, a, esa_window);
     return c->depth <= 8 ? launch_search<uint8_t>(c, a, is_lowres) : launch_search<uint16_t>(c, a, is_lowres);
+}
+
+int x265amd_search_batch_dev(x265amd_ctx *c, const x265amd_plane *fenc, const x265amd_plane *ref, int is_lowres,
+                             int qp, int method, int subme, const x265amd_job *d_jobs, int njobs, x265amd_result *d_results,
+                             int max_pu_dim)
+{
+    return search_dev(c, fenc, ref, is_lowres, qp, method, subme, d_jobs, njobs, d_results, max_pu_dim,
+                      c ? c->esa_window_bytes : 0);
 }
 
 int x265amd_sync(x265amd_ctx *c)
@@ -868,8 +908,18 @@ int x265amd_search_batch(x265amd_ctx *c, const x265amd_plane *fenc, const x265am
         const int d = jobs[i].w > jobs[i].h ? jobs[i].w : jobs[i].h;
         while (dim < d) dim <<= 1;
     }
-    rc = x265amd_search_batch_dev(c, fenc, ref, is_lowres, qp, method, subme, (const x265amd_job*)c->d_jobs, njobs,
-                                  (x265amd_result*)c->d_results, dim);
+    /* exhaustive search: no more window LDS than the largest range of the batch needs */
+    int window = ESA_WINDOW_MIN;
+    if (method == X265AMD_FULL)
+        for (int i = 0; i < njobs; i++)
+        {
+            const int nxg = (jobs[i].mvmax[0] - jobs[i].mvmin[0] + 4) >> 2;
+            const int nyg = (jobs[i].mvmax[1] - jobs[i].mvmin[1] + ESA_R) / ESA_R;
+            const long need = (long)16 * nxg + (long)esa_pitch(nxg, jobs[i].w) * (nyg * ESA_R + jobs[i].h - 1) + 4 * ESA_R * nyg;
+            if (need > window) window = need > c->esa_window_bytes ? c->esa_window_bytes : (int)((need + 15) & ~15);
+        }
+    rc = search_dev(c, fenc, ref, is_lowres, qp, method, subme, (const x265amd_job*)c->d_jobs, njobs,
+                    (x265amd_result*)c->d_results, dim, window);
     if (rc) return rc;
     HIPCHK(c, hipMemcpyAsync(results, c->d_results, (size_t)njobs * sizeof(x265amd_result), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));

@@ -1,0 +1,293 @@
+/* Exhaustive integer search (X265_FULL_SEARCH, source/encoder/motion.cpp:1021-1056) as a
+ * workgroup-per-PU kernel for 8-bit planes.
+ *
+ * The reference scans [mvmin, mvmax] in raster order and keeps the first position whose
+ * SAD + lambda * bits beats everything before it. Here the reference window of the PU is staged
+ * once into LDS, and every lane owns a 4 x ESA_R patch of candidate positions:
+ *   - v_qsad_pk_u16_u8 measures four horizontally adjacent candidates against four source
+ *     pixels in one instruction (the 64-bit operand is the sliding reference window, so no
+ *     byte realignment is needed: a lane's first candidate sits on a dword of the LDS window);
+ *   - the ESA_R vertically adjacent candidates share every reference row the lane loads: the
+ *     row that is source row y for candidate c is source row y - 1 for candidate c + 1.
+ * Sums stay packed in 16 bits for at most 64 accumulations (64 * 4 * 255 < 65536) and are
+ * widened per column of 4 pixels. The winner is the minimum of (cost, raster index), which is
+ * the position the sequential strict-'<' scan would have kept.
+ *
+ * Wave 0 of the workgroup also runs the stages around the scan (start-up candidates before,
+ * sub-pel refinement after) through the one-wave Searcher.
+ */
+#ifndef X265AMD_ME_ESA_H
+#define X265AMD_ME_ESA_H
+
+#include "me_search.h"
+
+namespace x265amd {
+
+#define ESA_THREADS 256
+#define ESA_R 8                  /* candidate rows per lane */
+#define ESA_SENTINEL 0x1000000   /* added to the cost of positions outside the range */
+
+/* how one PU's scan is laid out; the same values in every thread of the workgroup */
+struct EsaGeo
+{
+    int nx, ny;       /* positions per row / rows of the search range */
+    int nxg, nyg;     /* groups of 4 columns / ESA_R rows */
+    int xgs, ygs;     /* groups per LDS strip */
+    int pitch;        /* window row pitch in bytes: a whole, odd number of dwords */
+    int off_cx, off_cy, off_win;   /* LDS byte offsets */
+};
+
+__host__ __device__ inline int esa_pitch(int xgs, int w)
+{
+    int pd = xgs + (w >> 2) + 1;   /* dwords a row of the strip needs: the last lane reads one past its columns */
+    return (pd | 1) * 4;
+}
+
+/* LDS bytes a strip of xgs x ygs groups needs after the fixed part */
+__host__ __device__ inline int esa_strip_bytes(int xgs, int ygs, int w, int h)
+{
+    return 16 * xgs + 4 * ESA_R * ygs + esa_pitch(xgs, w) * (ygs * ESA_R + h - 1);
+}
+
+/* Largest strips that fit `budget` bytes, evened out over the range; false if not even one
+ * group fits. */
+__host__ __device__ inline bool esa_plan(int nx, int ny, int w, int h, int budget, EsaGeo &g)
+{
+    g.nx = nx; g.ny = ny;
+    g.nxg = (nx + 3) >> 2; g.nyg = (ny + ESA_R - 1) / ESA_R;
+    int xgs = g.nxg;
+    while (xgs > 1 && esa_strip_bytes(xgs, 1, w, h) > budget) xgs = (xgs + 1) >> 1;
+    if (esa_strip_bytes(xgs, 1, w, h) > budget) return false;
+    const int nxs = (g.nxg + xgs - 1) / xgs;
+    xgs = (g.nxg + nxs - 1) / nxs;
+    const int p = esa_pitch(xgs, w);
+    int ygs = (budget - 16 * xgs - p * (h - 1)) / (ESA_R * (p + 4));
+    if (ygs > g.nyg) ygs = g.nyg;
+    const int nys = (g.nyg + ygs - 1) / ygs;
+    ygs = (g.nyg + nys - 1) / nys;
+    g.xgs = xgs; g.ygs = ygs; g.pitch = p;
+    return true;
+}
+
+/* two consecutive dwords of LDS at a 4-byte aligned offset */
+__device__ __forceinline__ uint64_t lds_pair(int off)
+{
+    const uint32_t *q = (const uint32_t*)(x265amd_smem + off);
+    return ((uint64_t)q[1] << 32) | q[0];
+}
+
+/* SADs of the 4 x ESA_R candidates whose first one has its top-left reference pixel at LDS byte
+ * `org`; the source block (w x h) sits at `fenc` with a pitch of 64 bytes */
+__device__ __forceinline__ void esa_patch(int org, int pitch, int fenc, int w, int h, uint32_t tot[ESA_R][4])
+{
+    static_assert(ESA_R == 8, "the row bookkeeping below is written for 8 candidate rows");
+    uint64_t a16[ESA_R];
+#pragma unroll
+    for (int c = 0; c < ESA_R; c++)
+    {
+        a16[c] = 0;
+#pragma unroll
+        for (int i = 0; i < 4; i++) tot[c][i] = 0;
+    }
+    int cnt = 0;
+    const int ncol = w >> 2;
+    for (int j = 0; j < ncol; j++)
+    {
+        const int col = org + 4 * j, fcol = fenc + 4 * j;
+        /* Source row y meets reference rows y .. y + 7 (one per candidate row). A block of N
+         * source rows starting at y0 therefore needs rows y0 .. y0 + 6, kept from the block
+         * before (old), and N new ones; all loads of a block are issued before its SADs. */
+        uint64_t old[7];
+#pragma unroll
+        for (int k = 0; k < 7; k++) old[k] = lds_pair(col + k * pitch);
+        int y0 = 0;
+        for (; y0 + 8 <= h; y0 += 8)
+        {
+            uint64_t nw[8];
+            uint32_t f[8];
+#pragma unroll
+            for (int k = 0; k < 8; k++)
+            {
+                f[k] = *(const uint32_t*)(x265amd_smem + fcol + (y0 + k) * 64);
+                nw[k] = lds_pair(col + (y0 + 7 + k) * pitch);
+            }
+#pragma unroll
+            for (int yy = 0; yy < 8; yy++)
+#pragma unroll
+                for (int c = 0; c < ESA_R; c++)
+                    a16[c] = __builtin_amdgcn_qsad_pk_u16_u8(yy + c < 7 ? old[yy + c < 7 ? yy + c : 0] : nw[yy + c < 7 ? 0 : yy + c - 7], f[yy], a16[c]);
+#pragma unroll
+            for (int k = 0; k < 7; k++) old[k] = nw[k + 1];
+        }
+        if (h & 4)
+        {
+            /* heights 4 and 12: a last block of four source rows */
+            uint64_t nw[4];
+            uint32_t f[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++)
+            {
+                f[k] = *(const uint32_t*)(x265amd_smem + fcol + (y0 + k) * 64);
+                nw[k] = lds_pair(col + (y0 + 7 + k) * pitch);
+            }
+#pragma unroll
+            for (int yy = 0; yy < 4; yy++)
+#pragma unroll
+                for (int c = 0; c < ESA_R; c++)
+                    a16[c] = __builtin_amdgcn_qsad_pk_u16_u8(yy + c < 7 ? old[yy + c < 7 ? yy + c : 0] : nw[yy + c < 7 ? 0 : yy + c - 7], f[yy], a16[c]);
+        }
+        cnt += h;
+        if (cnt + h > 64 || j == ncol - 1)
+        {
+#pragma unroll
+            for (int c = 0; c < ESA_R; c++)
+            {
+                const uint32_t lo = (uint32_t)a16[c], hi = (uint32_t)(a16[c] >> 32);
+                tot[c][0] += lo & 0xffff; tot[c][1] += lo >> 16;
+                tot[c][2] += hi & 0xffff; tot[c][3] += hi >> 16;
+                a16[c] = 0;
+            }
+            cnt = 0;
+        }
+    }
+}
+
+/* One workgroup per PU. LDS: [Searcher block of wave 0][counter, per-wave winners][cost of
+ * each column's MV x][cost of each row's MV y][reference window strip]. */
+template<typename P>
+__global__ __launch_bounds__(ESA_THREADS) void esa_kernel(SearchArgs a, int win_budget)
+{
+    static_assert(sizeof(P) == 1, "the packed quad-SAD path is for 8-bit samples");
+    const int j = xcd_remap(blockIdx.x, a.njobs);
+    if (j >= a.njobs) return;
+    const x265amd_job *job = a.jobs + j;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    JobRegs J;
+    J.load(job);
+    const int w = uni(job->w), h = uni(job->h);
+    EsaGeo g;
+    const int nx = J.mxx - J.mnx + 1, ny = J.mxy - J.mny + 1;
+    if (w > a.max_dim || h > a.max_dim || nx <= 0 || ny <= 0 || !esa_plan(nx, ny, w, h, win_budget, g))
+    {
+        if (tid == 0)
+        {
+            x265amd_result r = { { 0, 0 }, -1, 0, 0 };
+            a.results[j] = r;
+        }
+        return;
+    }
+    const int SB = (wave_lds_bytes<P>(a.max_dim, true) + 15) & ~15;
+    const int E_CNT = SB, E_RED = SB + 16;
+    g.off_cx = SB + 64;
+    g.off_cy = g.off_cx + 16 * g.xgs;
+    g.off_win = g.off_cy + 4 * ESA_R * g.ygs;
+
+    Searcher<P, 64> S;
+    SearchState st;
+    if (wave == 0)
+        S.bind(0, a.fenc, a.ref, a.nref, a.ctab, a.depth, J.pux, J.puy, w, h, a.max_dim, plane_budget(a.max_dim));
+
+    const uint16_t AS1 *ctab = (const uint16_t AS1*)a.ctab;
+    const P AS1 *ref = (const P AS1*)a.ref[0].origin + (long)J.puy * a.ref[0].stride + J.pux;
+    const int rstride = a.ref[0].stride;
+    const int pd = g.pitch >> 2;
+    uint32_t bc = 0xffffffffu, bi = 0xffffffffu;   /* this lane's best (cost, raster index) */
+    bool first = true;
+    for (int ys0 = 0; ys0 < g.nyg; ys0 += g.ygs)
+        for (int xs0 = 0; xs0 < g.nxg; xs0 += g.xgs)
+        {
+            const int xgc = g.nxg - xs0 < g.xgs ? g.nxg - xs0 : g.xgs;   /* groups in this strip */
+            const int ygc = g.nyg - ys0 < g.ygs ? g.nyg - ys0 : g.ygs;
+            if (!first) __syncthreads();
+            /* lambda * bits of each column / row of the strip, as the reference's two table
+             * operands (bitcost.h:46); positions outside the range carry the sentinel */
+            for (int i = tid; i < 4 * xgc; i += ESA_THREADS)
+            {
+                const int dxi = xs0 * 4 + i;
+                lds_i(0, g.off_cx)[i] = dxi < nx ? (int)ctab[as_i16((J.mnx + dxi) << 2) - J.qmx] : ESA_SENTINEL;
+            }
+            for (int i = tid; i < ESA_R * ygc; i += ESA_THREADS)
+            {
+                const int dyi = ys0 * ESA_R + i;
+                lds_i(0, g.off_cy)[i] = dyi < ny ? (int)ctab[as_i16((J.mny + dyi) << 2) - J.qmy] : ESA_SENTINEL;
+            }
+            {
+                /* window strip: rows below the last row any valid candidate needs repeat that
+                 * row, columns stop within 7 bytes of the last needed one */
+                const int rows = ygc * ESA_R + h - 1;
+                const int rlast = (ny - 1 - ys0 * ESA_R) + h - 1;
+                const int dlast = (nx - 1 - xs0 * 4 + w - 1 + 4) >> 2;
+                const P AS1 *src = ref + (long)(J.mny + ys0 * ESA_R) * rstride + J.mnx + xs0 * 4;
+                for (int r = wave; r < rows; r += ESA_THREADS / 64)
+                {
+                    const P AS1 *srow = src + (long)(r < rlast ? r : rlast) * rstride;
+                    for (int d = lane; d < pd; d += 64)
+                        *(uint32_t*)(x265amd_smem + g.off_win + r * g.pitch + 4 * d) = Px<P>::load_g(srow + 4 * (d < dlast ? d : dlast));
+                }
+            }
+            if (tid == 0) *lds_i(0, E_CNT) = 0;
+            __syncthreads();
+            if (first && wave == 0) S.startup(J, st);
+            first = false;
+
+            const int ni = xgc * ygc, inv = (65536 + xgc - 1) / xgc;
+            for (;;)
+            {
+                int i0 = 0;
+                if (lane == 0) i0 = atomicAdd(lds_i(0, E_CNT), 64);
+                i0 = uni(i0);
+                if (i0 >= ni) break;
+                const bool live = i0 + lane < ni;
+                const int it = live ? i0 + lane : ni - 1;
+                const int yg = (it * inv) >> 16, xg = it - yg * xgc;
+                uint32_t tot[ESA_R][4];
+                esa_patch(g.off_win + yg * ESA_R * g.pitch + xg * 4, g.pitch, L_FENC, w, h, tot);
+                int cx[4];
+#pragma unroll
+                for (int i = 0; i < 4; i++) cx[i] = lds_i(0, g.off_cx)[xg * 4 + i];
+                uint32_t best = 0xffffffffu;
+#pragma unroll
+                for (int c = 0; c < ESA_R; c++)
+                {
+                    const int cy = lds_i(0, g.off_cy)[yg * ESA_R + c];
+#pragma unroll
+                    for (int i = 0; i < 4; i++)
+                    {
+                        /* uint16 wrap of the sum of the two table entries; the sentinel bits survive */
+                        const uint32_t cost = tot[c][i] + ((uint32_t)(cx[i] + cy) & 0x0300ffffu);
+                        const uint32_t key = (cost << 5) | (uint32_t)(c * 4 + i);
+                        best = key < best ? key : best;
+                    }
+                }
+                const uint32_t cost = best >> 5, ci = best & 31;
+                const uint32_t idx = (uint32_t)((ys0 + yg) * ESA_R + (ci >> 2)) * (uint32_t)nx + (uint32_t)((xs0 + xg) * 4 + (ci & 3));
+                if (live && cost < ESA_SENTINEL && (cost < bc || (cost == bc && idx < bi))) { bc = cost; bi = idx; }
+            }
+        }
+    for (int o = 1; o < 64; o <<= 1)
+    {
+        const uint32_t oc = __shfl_xor(bc, o), oi = __shfl_xor(bi, o);
+        if (oc < bc || (oc == bc && oi < bi)) { bc = oc; bi = oi; }
+    }
+    if (lane == 0) { lds_i(0, E_RED)[2 * wave] = (int)bc; lds_i(0, E_RED)[2 * wave + 1] = (int)bi; }
+    __syncthreads();
+    if (wave == 0)
+    {
+        for (int k = 1; k < ESA_THREADS / 64; k++)
+        {
+            const uint32_t oc = (uint32_t)uni(lds_i(0, E_RED)[2 * k]), oi = (uint32_t)uni(lds_i(0, E_RED)[2 * k + 1]);
+            if (oc < bc || (oc == bc && oi < bi)) { bc = oc; bi = oi; }
+        }
+        bc = (uint32_t)uni((int)bc); bi = (uint32_t)uni((int)bi);
+        if (bc < (uint32_t)st.bcost)
+        {
+            const int by = (int)(bi / (uint32_t)nx);
+            st.bcost = (int)bc; st.bmy = J.mny + by; st.bmx = J.mnx + (int)(bi - (uint32_t)by * (uint32_t)nx);
+        }
+        S.nsad += (unsigned)(nx * ny);
+        S.finish(a.subme, st, a.results + j);
+    }
+}
+
+} // namespace x265amd
+#endif

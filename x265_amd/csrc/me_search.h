@@ -719,12 +719,13 @@ __device__ __noinline__ void eval_planes(int base, int K, int mode, int addmv)
  * pointer, where the compiler cannot see that every lane reads the same value. */
 struct JobRegs
 {
-    int mnx, mny, mxx, mxy, qmx, qmy, numc, merange;
+    int pux, puy, mnx, mny, mxx, mxy, qmx, qmy, numc, merange;
     int cx[4], cy[4];
     __device__ __forceinline__ void load(const x265amd_job *job)
     {
         const int *p = (const int*)job;
-        const int d1 = uni(p[1]), d2 = uni(p[2]), d3 = uni(p[3]), d4 = uni(p[4]);
+        const int d0 = uni(p[0]), d1 = uni(p[1]), d2 = uni(p[2]), d3 = uni(p[3]), d4 = uni(p[4]);
+        pux = as_i16(d0); puy = d0 >> 16;
         numc = (d1 >> 16) & 0xff;
         mnx = as_i16(d2); mny = d2 >> 16; mxx = as_i16(d3); mxy = d3 >> 16; qmx = as_i16(d4); qmy = d4 >> 16;
 #pragma unroll
@@ -737,6 +738,13 @@ struct JobRegs
     }
     __device__ __forceinline__ int mvcx(int i) const { return i == 0 ? cx[0] : (i == 1 ? cx[1] : (i == 2 ? cx[2] : cx[3])); }
     __device__ __forceinline__ int mvcy(int i) const { return i == 0 ? cy[0] : (i == 1 ? cy[1] : (i == 2 ? cy[2] : cy[3])); }
+};
+
+/* what the stages of one search hand to each other: the full-pel best (bmv, bcost), the best
+ * qpel predictor (bestpre, bprecost) and the rounded predictor pmv (motion.cpp:575-621) */
+struct SearchState
+{
+    int bmx, bmy, bcost, bprecost, bpx, bpy, pmx, pmy;
 };
 
 /* LOWRES selects the lookahead flavour at compile time (half-pel planes instead of
@@ -1093,16 +1101,20 @@ struct Searcher
     {
         JobRegs J;
         J.load(job);
+        SearchState st;
+        startup(J, st);
+        integer(J, method, st);
+        finish(subme, st, res);
+    }
+
+    /* motion.cpp:562-621: predictor, MV(0,0) and the qpel candidates */
+    __device__ __forceinline__ void startup(const JobRegs &J, SearchState &st)
+    {
         const int mnx = J.mnx, mny = J.mny, mxx = J.mxx, mxy = J.mxy;
         const int qmnx = as_i16(mnx << 2), qmny = as_i16(mny << 2), qmxx = as_i16(mxx << 2), qmxy = as_i16(mxy << 2);
         const int numc = J.numc;
-        int merange = J.merange;
         set_mvp(J.qmx, J.qmy);
         nsad = 0; nsub = 0;
-        /* the pattern tables of motion.cpp:145-147, :673-681 as nibble-packed immediates */
-        constexpr unsigned long long SQX = nibs({ 0, 0, 0, -1, 1, -1, -1, 1, 1 }), SQY = nibs({ 0, -1, 1, 0, 0, -1, 1, -1, 1 });
-        constexpr unsigned long long HRX = nibs({ -2, -1, 1, 2, 1, -1 }), HRY = nibs({ 0, 2, 2, 0, -2, -2 });
-        constexpr unsigned long long H2X = nibs({ -1, -2, -1, 1, 2, 1, -1, -2 }), H2Y = nibs({ -2, 0, 2, 2, 0, -2, -2, 0 });
 
 #define CLIPX(v) ((v) > qmxx ? qmxx : ((v) < qmnx ? qmnx : (v)))
 #define CLIPY(v) ((v) > qmxy ? qmxy : ((v) < qmny ? qmny : (v)))
@@ -1156,7 +1168,21 @@ struct Searcher
             }
 #undef CLIPX
 #undef CLIPY
-        pmx = as_i16((pmx + 2) >> 2); pmy = as_i16((pmy + 2) >> 2);
+        st.pmx = as_i16((pmx + 2) >> 2); st.pmy = as_i16((pmy + 2) >> 2);
+        st.bmx = bmx; st.bmy = bmy; st.bcost = bcost; st.bprecost = bprecost; st.bpx = bpx; st.bpy = bpy;
+    }
+
+    /* the integer search proper, motion.cpp:626-1061 */
+    __device__ __forceinline__ void integer(const JobRegs &J, int method, SearchState &st)
+    {
+        const int mnx = J.mnx, mny = J.mny, mxx = J.mxx, mxy = J.mxy;
+        const int pmx = st.pmx, pmy = st.pmy;
+        int merange = J.merange;
+        int bmx = st.bmx, bmy = st.bmy, bcost = st.bcost;
+        /* the pattern tables of motion.cpp:145-147, :673-681 as nibble-packed immediates */
+        constexpr unsigned long long SQX = nibs({ 0, 0, 0, -1, 1, -1, -1, 1, 1 }), SQY = nibs({ 0, -1, 1, 0, 0, -1, 1, -1, 1 });
+        constexpr unsigned long long HRX = nibs({ -2, -1, 1, 2, 1, -1 }), HRY = nibs({ 0, 2, 2, 0, -2, -2 });
+        constexpr unsigned long long H2X = nibs({ -1, -2, -1, 1, 2, 1, -1, -2 }), H2Y = nibs({ -2, 0, 2, 2, 0, -2, -2, 0 });
 
         bool run_hex = false;
         switch (method)
@@ -1307,10 +1333,17 @@ struct Searcher
             bmx = as_i16(bmx + kSquare1[dir][0]); bmy = as_i16(bmy + kSquare1[dir][1]);
         }
 
-        /* motion.cpp:1063-1069 */
+        st.bmx = bmx; st.bmy = bmy; st.bcost = bcost;
+    }
+
+    /* choice between the full-pel winner and the best qpel predictor, then the sub-pel
+     * refinement; motion.cpp:1063-1145 */
+    __device__ __forceinline__ void finish(int subme, const SearchState &st, x265amd_result *res)
+    {
+        int bcost = st.bcost;
         int qx, qy;
-        if (bprecost < bcost) { qx = bpx; qy = bpy; bcost = bprecost; }
-        else { qx = as_i16(bmx << 2); qy = as_i16(bmy << 2); }
+        if (st.bprecost < bcost) { qx = st.bpx; qy = st.bpy; bcost = st.bprecost; }
+        else { qx = as_i16(st.bmx << 2); qy = as_i16(st.bmy << 2); }
 
         const int hpel_iters = kWorkload[subme][0], hpel_dirs = kWorkload[subme][1];
         const int qpel_iters = kWorkload[subme][2], qpel_dirs = kWorkload[subme][3], hpel_satd = kWorkload[subme][4];

@@ -182,6 +182,10 @@ class Engine:
     def sync(self):
         self._chk(self.L.x265amd_sync(self.ctx))
 
+    def set_esa_window_bytes(self, nbytes):
+        """LDS one PU of an exhaustive (FULL) search may use for its reference window; tuning only."""
+        self._chk(self.L.x265amd_set_esa_window_bytes(self.ctx, int(nbytes)))
+
     def search_batch_dev(self, fenc, ref, d_jobs, njobs, d_results, qp, method, subme, is_lowres=False, max_pu_dim=0):
         refs = (Plane * 4)(*ref) if is_lowres else (Plane * 1)(ref if isinstance(ref, Plane) else ref[0])
         self._chk(self.L.x265amd_search_batch_dev(self.ctx, C.byref(fenc), refs, int(is_lowres), qp, method, subme,
