@@ -62,7 +62,7 @@ __global__ __launch_bounds__(64) void search_kernel(SearchArgs a)
     S.search(job, a.method, a.subme, a.results + j);
 }
 
-#include "me_esa.h"   /* esa_kernel: uses SearchArgs and xcd_remap */
+#include "me_esa.h"   /* esa_scan_kernel, esa_finish_kernel: use SearchArgs and xcd_remap */
 
 /* subpelCompare for a batch of PUs (motion.cpp:1651-1689) */
 template<typename P>
@@ -559,7 +559,7 @@ struct x265amd_ctx
     int esa_window_bytes;              /* LDS the exhaustive search may use per PU for its window */
 };
 
-#define ESA_WINDOW_DEFAULT 65536
+#define ESA_WINDOW_DEFAULT 36864
 #define ESA_WINDOW_MIN 8192
 #define ESA_WINDOW_MAX 131072
 
@@ -582,18 +582,21 @@ static int ensure(x265amd_ctx *c, void **p, size_t *cap, size_t need)
     return 0;
 }
 
-/* X265_FULL_SEARCH on 8-bit planes: workgroup-per-PU scan through an LDS window */
+/* X265_FULL_SEARCH on 8-bit planes: workgroup-per-PU scan through an LDS window, then the
+ * one-wave stages around it */
 static int launch_esa(x265amd_ctx *c, const SearchArgs &a, int window_bytes)
 {
     static bool lds_raised = false;
     if (!lds_raised)
     {
-        HIPCHK(c, hipFuncSetAttribute((const void*)esa_kernel<uint8_t>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                      wave_lds_bytes<uint8_t>(64, true) + 128 + ESA_WINDOW_MAX));
+        HIPCHK(c, hipFuncSetAttribute((const void*)esa_scan_kernel<uint8_t>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      esa_fixed_lds(64) + ESA_WINDOW_MAX));
         lds_raised = true;
     }
-    const int lds = ((wave_lds_bytes<uint8_t>(a.max_dim, true) + 15) & ~15) + 64 + window_bytes;
-    hipLaunchKernelGGL(esa_kernel<uint8_t>, dim3(a.njobs), dim3(ESA_THREADS), lds, c->stream, a, window_bytes);
+    hipLaunchKernelGGL(esa_scan_kernel<uint8_t>, dim3(a.njobs), dim3(ESA_THREADS), esa_fixed_lds(a.max_dim) + window_bytes,
+                       c->stream, a, window_bytes);
+    hipLaunchKernelGGL(esa_finish_kernel<uint8_t>, dim3(a.njobs), dim3(64), wave_lds_bytes<uint8_t>(a.max_dim, true),
+                       c->stream, a, window_bytes);
     HIPCHK(c, hipGetLastError());
     return X265AMD_OK;
 }

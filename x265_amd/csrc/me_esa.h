@@ -13,8 +13,9 @@
  * widened per column of 4 pixels. The winner is the minimum of (cost, raster index), which is
  * the position the sequential strict-'<' scan would have kept.
  *
- * Wave 0 of the workgroup also runs the stages around the scan (start-up candidates before,
- * sub-pel refinement after) through the one-wave Searcher.
+ * The stages around the scan (start-up candidates, sub-pel refinement) run in a second kernel,
+ * one wave per PU through the Searcher, so that the scan's workgroups hold their LDS only
+ * while all of their waves are busy.
  */
 #ifndef X265AMD_ME_ESA_H
 #define X265AMD_ME_ESA_H
@@ -23,7 +24,9 @@
 
 namespace x265amd {
 
+#ifndef ESA_THREADS
 #define ESA_THREADS 256
+#endif
 #define ESA_R 8                  /* candidate rows per lane */
 #define ESA_SENTINEL 0x1000000   /* added to the cost of positions outside the range */
 
@@ -33,14 +36,13 @@ struct EsaGeo
     int nx, ny;       /* positions per row / rows of the search range */
     int nxg, nyg;     /* groups of 4 columns / ESA_R rows */
     int xgs, ygs;     /* groups per LDS strip */
-    int pitch;        /* window row pitch in bytes: a whole, odd number of dwords */
+    int pitch;        /* window row pitch in bytes, a whole number of dwords */
     int off_cx, off_cy, off_win;   /* LDS byte offsets */
 };
 
 __host__ __device__ inline int esa_pitch(int xgs, int w)
 {
-    int pd = xgs + (w >> 2) + 1;   /* dwords a row of the strip needs: the last lane reads one past its columns */
-    return (pd | 1) * 4;
+    return (xgs + (w >> 2) + 1) * 4;   /* the last lane reads one dword past its columns */
 }
 
 /* LDS bytes a strip of xgs x ygs groups needs after the fixed part */
@@ -100,17 +102,22 @@ __device__ __forceinline__ void esa_patch(int org, int pitch, int fenc, int w, i
         uint64_t old[7];
 #pragma unroll
         for (int k = 0; k < 7; k++) old[k] = lds_pair(col + k * pitch);
+        /* the first source dword of a block is fetched one block ahead, so that a block's SADs
+         * start at once and its own loads have the first seven SADs to arrive in */
+        uint32_t f0 = *(const uint32_t*)(x265amd_smem + fcol);
         int y0 = 0;
         for (; y0 + 8 <= h; y0 += 8)
         {
             uint64_t nw[8];
             uint32_t f[8];
+            f[0] = f0;
 #pragma unroll
             for (int k = 0; k < 8; k++)
             {
-                f[k] = *(const uint32_t*)(x265amd_smem + fcol + (y0 + k) * 64);
                 nw[k] = lds_pair(col + (y0 + 7 + k) * pitch);
+                if (k) f[k] = *(const uint32_t*)(x265amd_smem + fcol + (y0 + k) * 64);
             }
+            f0 = *(const uint32_t*)(x265amd_smem + fcol + (y0 + 8 < h ? y0 + 8 : y0) * 64);
 #pragma unroll
             for (int yy = 0; yy < 8; yy++)
 #pragma unroll
@@ -124,11 +131,12 @@ __device__ __forceinline__ void esa_patch(int org, int pitch, int fenc, int w, i
             /* heights 4 and 12: a last block of four source rows */
             uint64_t nw[4];
             uint32_t f[4];
+            f[0] = f0;
 #pragma unroll
             for (int k = 0; k < 4; k++)
             {
-                f[k] = *(const uint32_t*)(x265amd_smem + fcol + (y0 + k) * 64);
                 nw[k] = lds_pair(col + (y0 + 7 + k) * pitch);
+                if (k) f[k] = *(const uint32_t*)(x265amd_smem + fcol + (y0 + k) * 64);
             }
 #pragma unroll
             for (int yy = 0; yy < 4; yy++)
@@ -152,41 +160,67 @@ __device__ __forceinline__ void esa_patch(int org, int pitch, int fenc, int w, i
     }
 }
 
-/* One workgroup per PU. LDS: [Searcher block of wave 0][counter, per-wave winners][cost of
- * each column's MV x][cost of each row's MV y][reference window strip]. */
+/* LDS layout of the scan kernel: [counter, per-wave winners][source block, pitch 64][cost of
+ * each column's MV x][cost of each row's MV y][reference window strip] */
+#define ESA_L_CNT 0
+#define ESA_L_RED 16
+#define ESA_L_FENC 64
+__host__ __device__ inline int esa_fixed_lds(int max_dim) { return ESA_L_FENC + max_dim * 64; }
+
+/* A job the scan cannot take (PU larger than the launch allows, empty range, window budget too
+ * small for a single group) gets cost -1 from both kernels. */
+__device__ __forceinline__ bool esa_job_ok(const JobRegs &J, int w, int h, int max_dim, int win_budget, EsaGeo &g)
+{
+    const int nx = J.mxx - J.mnx + 1, ny = J.mxy - J.mny + 1;
+    return w <= max_dim && h <= max_dim && nx > 0 && ny > 0 && esa_plan(nx, ny, w, h, win_budget, g);
+}
+
+/* The raster scan of motion.cpp:1025-1053 for one PU per workgroup: writes the smallest
+ * (SAD + lambda * bits, raster index) of the range into results[j].cost / .sad_calls, where
+ * esa_finish_kernel picks it up. */
 template<typename P>
-__global__ __launch_bounds__(ESA_THREADS) void esa_kernel(SearchArgs a, int win_budget)
+__global__ __launch_bounds__(ESA_THREADS) void esa_scan_kernel(SearchArgs a, int win_budget)
 {
     static_assert(sizeof(P) == 1, "the packed quad-SAD path is for 8-bit samples");
     const int j = xcd_remap(blockIdx.x, a.njobs);
     if (j >= a.njobs) return;
     const x265amd_job *job = a.jobs + j;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+#ifdef X265AMD_TRACE
+    /* debug builds only: per-wave start / end time (100 MHz counter) and placement, in a side
+     * buffer behind the result records */
+    unsigned long long *trace = (unsigned long long*)(a.results + a.njobs) + ((size_t)blockIdx.x * (ESA_THREADS / 64) + wave) * 4;
+    if (lane == 0)
+    {
+        trace[0] = wall_clock64();
+        trace[2] = ((unsigned long long)__builtin_amdgcn_s_getreg(63508) << 32) | (unsigned)__builtin_amdgcn_s_getreg(63492);
+    }
+#endif
     JobRegs J;
     J.load(job);
     const int w = uni(job->w), h = uni(job->h);
     EsaGeo g;
-    const int nx = J.mxx - J.mnx + 1, ny = J.mxy - J.mny + 1;
-    if (w > a.max_dim || h > a.max_dim || nx <= 0 || ny <= 0 || !esa_plan(nx, ny, w, h, win_budget, g))
+    if (!esa_job_ok(J, w, h, a.max_dim, win_budget, g))
     {
-        if (tid == 0)
-        {
-            x265amd_result r = { { 0, 0 }, -1, 0, 0 };
-            a.results[j] = r;
-        }
+        if (tid == 0) { a.results[j].cost = -1; a.results[j].sad_calls = 0; }
         return;
     }
-    const int SB = (wave_lds_bytes<P>(a.max_dim, true) + 15) & ~15;
-    const int E_CNT = SB, E_RED = SB + 16;
-    g.off_cx = SB + 64;
+    const int nx = g.nx, ny = g.ny;
+    g.off_cx = esa_fixed_lds(a.max_dim);
     g.off_cy = g.off_cx + 16 * g.xgs;
     g.off_win = g.off_cy + 4 * ESA_R * g.ygs;
 
-    Searcher<P, 64> S;
-    SearchState st;
-    if (wave == 0)
-        S.bind(0, a.fenc, a.ref, a.nref, a.ctab, a.depth, J.pux, J.puy, w, h, a.max_dim, plane_budget(a.max_dim));
-
+    {
+        /* source block into LDS, pitch 64 (setSourcePU, motion.cpp:116-142) */
+        const char AS1 *src = (const char AS1*)a.fenc.origin + (long)J.puy * a.fenc.stride + J.pux;
+        const int wd = w >> 2;
+        for (int i = tid; i < wd * h; i += ESA_THREADS)
+        {
+            const int y = i / wd, x = i - y * wd;
+            typedef uint32_t __attribute__((aligned(1))) u32u;
+            *(uint32_t*)(x265amd_smem + ESA_L_FENC + y * 64 + 4 * x) = *(const u32u AS1*)(src + (long)y * a.fenc.stride + 4 * x);
+        }
+    }
     const uint16_t AS1 *ctab = (const uint16_t AS1*)a.ctab;
     const P AS1 *ref = (const P AS1*)a.ref[0].origin + (long)J.puy * a.ref[0].stride + J.pux;
     const int rstride = a.ref[0].stride;
@@ -199,6 +233,7 @@ __global__ __launch_bounds__(ESA_THREADS) void esa_kernel(SearchArgs a, int win_
             const int xgc = g.nxg - xs0 < g.xgs ? g.nxg - xs0 : g.xgs;   /* groups in this strip */
             const int ygc = g.nyg - ys0 < g.ygs ? g.nyg - ys0 : g.ygs;
             if (!first) __syncthreads();
+            first = false;
             /* lambda * bits of each column / row of the strip, as the reference's two table
              * operands (bitcost.h:46); positions outside the range carry the sentinel */
             for (int i = tid; i < 4 * xgc; i += ESA_THREADS)
@@ -213,35 +248,51 @@ __global__ __launch_bounds__(ESA_THREADS) void esa_kernel(SearchArgs a, int win_
             }
             {
                 /* window strip: rows below the last row any valid candidate needs repeat that
-                 * row, columns stop within 7 bytes of the last needed one */
+                 * row, columns stop within 7 bytes of the last needed one. A wave copies whole
+                 * rows (lane = dword), eight rows in flight before the first is stored. */
                 const int rows = ygc * ESA_R + h - 1;
                 const int rlast = (ny - 1 - ys0 * ESA_R) + h - 1;
                 const int dlast = (nx - 1 - xs0 * 4 + w - 1 + 4) >> 2;
-                const P AS1 *src = ref + (long)(J.mny + ys0 * ESA_R) * rstride + J.mnx + xs0 * 4;
-                for (int r = wave; r < rows; r += ESA_THREADS / 64)
+                const char AS1 *src0 = (const char AS1*)(ref + (long)(J.mny + ys0 * ESA_R) * rstride + J.mnx + xs0 * 4);
+                for (int d0 = 0; d0 < pd; d0 += 64)
                 {
-                    const P AS1 *srow = src + (long)(r < rlast ? r : rlast) * rstride;
-                    for (int d = lane; d < pd; d += 64)
-                        *(uint32_t*)(x265amd_smem + g.off_win + r * g.pitch + 4 * d) = Px<P>::load_g(srow + 4 * (d < dlast ? d : dlast));
+                    const int d = d0 + lane;
+                    const unsigned voff = 4u * (unsigned)(d < dlast ? d : dlast);
+                    for (int r0 = wave; r0 < rows; r0 += 8 * (ESA_THREADS / 64))
+                    {
+                        uint32_t v[8];
+#pragma unroll
+                        for (int u = 0; u < 8; u++)
+                        {
+                            int r = r0 + u * (ESA_THREADS / 64);
+                            r = r < rlast ? r : rlast;
+                            typedef uint32_t __attribute__((aligned(1))) u32u;
+                            v[u] = *(const u32u AS1*)(src0 + (long)r * rstride + voff);
+                        }
+#pragma unroll
+                        for (int u = 0; u < 8; u++)
+                        {
+                            const int r = r0 + u * (ESA_THREADS / 64);
+                            if (r < rows && d < pd) *(uint32_t*)(x265amd_smem + g.off_win + r * g.pitch + 4 * d) = v[u];
+                        }
+                    }
                 }
             }
-            if (tid == 0) *lds_i(0, E_CNT) = 0;
+            if (tid == 0) *lds_i(0, ESA_L_CNT) = 0;
             __syncthreads();
-            if (first && wave == 0) S.startup(J, st);
-            first = false;
 
             const int ni = xgc * ygc, inv = (65536 + xgc - 1) / xgc;
             for (;;)
             {
                 int i0 = 0;
-                if (lane == 0) i0 = atomicAdd(lds_i(0, E_CNT), 64);
+                if (lane == 0) i0 = atomicAdd(lds_i(0, ESA_L_CNT), 64);
                 i0 = uni(i0);
                 if (i0 >= ni) break;
                 const bool live = i0 + lane < ni;
                 const int it = live ? i0 + lane : ni - 1;
                 const int yg = (it * inv) >> 16, xg = it - yg * xgc;
                 uint32_t tot[ESA_R][4];
-                esa_patch(g.off_win + yg * ESA_R * g.pitch + xg * 4, g.pitch, L_FENC, w, h, tot);
+                esa_patch(g.off_win + yg * ESA_R * g.pitch + xg * 4, g.pitch, ESA_L_FENC, w, h, tot);
                 int cx[4];
 #pragma unroll
                 for (int i = 0; i < 4; i++) cx[i] = lds_i(0, g.off_cx)[xg * 4 + i];
@@ -269,24 +320,57 @@ __global__ __launch_bounds__(ESA_THREADS) void esa_kernel(SearchArgs a, int win_
         const uint32_t oc = __shfl_xor(bc, o), oi = __shfl_xor(bi, o);
         if (oc < bc || (oc == bc && oi < bi)) { bc = oc; bi = oi; }
     }
-    if (lane == 0) { lds_i(0, E_RED)[2 * wave] = (int)bc; lds_i(0, E_RED)[2 * wave + 1] = (int)bi; }
+    if (lane == 0) { lds_i(0, ESA_L_RED)[2 * wave] = (int)bc; lds_i(0, ESA_L_RED)[2 * wave + 1] = (int)bi; }
     __syncthreads();
-    if (wave == 0)
+    if (tid == 0)
     {
         for (int k = 1; k < ESA_THREADS / 64; k++)
         {
-            const uint32_t oc = (uint32_t)uni(lds_i(0, E_RED)[2 * k]), oi = (uint32_t)uni(lds_i(0, E_RED)[2 * k + 1]);
+            const uint32_t oc = (uint32_t)lds_i(0, ESA_L_RED)[2 * k], oi = (uint32_t)lds_i(0, ESA_L_RED)[2 * k + 1];
             if (oc < bc || (oc == bc && oi < bi)) { bc = oc; bi = oi; }
         }
-        bc = (uint32_t)uni((int)bc); bi = (uint32_t)uni((int)bi);
-        if (bc < (uint32_t)st.bcost)
-        {
-            const int by = (int)(bi / (uint32_t)nx);
-            st.bcost = (int)bc; st.bmy = J.mny + by; st.bmx = J.mnx + (int)(bi - (uint32_t)by * (uint32_t)nx);
-        }
-        S.nsad += (unsigned)(nx * ny);
-        S.finish(a.subme, st, a.results + j);
+        a.results[j].cost = (int)bc;
+        a.results[j].sad_calls = bi;
     }
+#ifdef X265AMD_TRACE
+    if (lane == 0) trace[1] = trace[3] = wall_clock64();
+#endif
+}
+
+/* The stages around the scan, one wave per PU: the start-up candidates (motion.cpp:562-621, which
+ * do not depend on the scan), the scan's winner folded in with the reference's strict '<', then
+ * the sub-pel refinement. */
+template<typename P>
+__global__ __launch_bounds__(64) void esa_finish_kernel(SearchArgs a, int win_budget)
+{
+    const int j = xcd_remap(blockIdx.x, a.njobs);
+    if (j >= a.njobs) return;
+    const x265amd_job *job = a.jobs + j;
+    JobRegs J;
+    J.load(job);
+    const int w = uni(job->w), h = uni(job->h);
+    EsaGeo g;
+    if (!esa_job_ok(J, w, h, a.max_dim, win_budget, g))
+    {
+        if (threadIdx.x == 0)
+        {
+            x265amd_result r = { { 0, 0 }, -1, 0, 0 };
+            a.results[j] = r;
+        }
+        return;
+    }
+    const uint32_t bc = (uint32_t)uni(a.results[j].cost), bi = (uint32_t)uni((int)a.results[j].sad_calls);
+    Searcher<P, 64> S;
+    SearchState st;
+    S.bind(0, a.fenc, a.ref, a.nref, a.ctab, a.depth, J.pux, J.puy, w, h, a.max_dim, plane_budget(a.max_dim));
+    S.startup(J, st);
+    if (bc < (uint32_t)st.bcost)
+    {
+        const int by = (int)(bi / (uint32_t)g.nx);
+        st.bcost = (int)bc; st.bmy = J.mny + by; st.bmx = J.mnx + (int)(bi - (uint32_t)by * (uint32_t)g.nx);
+    }
+    S.nsad += (unsigned)(g.nx * g.ny);
+    S.finish(a.subme, st, a.results + j);
 }
 
 } // namespace x265amd
