@@ -56,7 +56,7 @@ def same(a, b):
                for k in ("cime", "rime", "fme"))
 
 
-@pytest.mark.parametrize("size", [(416, 240), (200, 136), (128, 64)])
+@pytest.mark.parametrize("size", [(416, 240), (200, 136), (128, 64), (204, 140)])
 def test_rk_vs_oracle(engine8, oracle, size):
     W, H = size
     cur, rorig, recon, org, stride, jobs = rk_case(8, W, H, 5)

@@ -244,23 +244,31 @@ struct RkArgs
     int nctus;
 };
 
-/* CIME (motion.cpp:1272-1303): one workgroup per CTU. The 16x16 block of 4x4 sums of the
- * CTU and the downsampled reference window live in LDS; each thread walks whole
- * candidates (256 abs-diffs each), and the raster-order strict-'<' winner is the minimum
+/* CIME (motion.cpp:1272-1303): one workgroup per CTU. The 16x16 block of 4x4 sums of the CTU,
+ * the downsampled reference window and the lambda * bits of every column / row (three
+ * predictors each) live in LDS. A thread measures two horizontally adjacent positions at a time:
+ * both read the same dwords of a window row (sample pairs), the odd one through v_alignbit, and
+ * v_sad_u16 takes two samples per instruction. The raster-order strict-'<' winner is the minimum
  * of the 64-bit key (cost << 32 | visit index). */
-#define CIME_THREADS 256
+#define CIME_THREADS 1024
+#define CIME_MAX_NX 96
+#define CIME_MAX_NY 80
 template<typename P>
 __global__ __launch_bounds__(CIME_THREADS) void rk_cime_kernel(RkArgs a)
 {
     extern __shared__ int16_t cime_lds[];
     __shared__ unsigned long long red[CIME_THREADS / 64];
+    __shared__ uint16_t costx[3][CIME_MAX_NX], costy[3][CIME_MAX_NY];
     const x265amd_rk_ctu &j = a.ctus[blockIdx.x];
-    int16_t *ctu = cime_lds;            /* 256 */
-    int16_t *win = cime_lds + 256;      /* (nx + 15) x (ny + 15) */
+    int16_t *ctu = cime_lds;            /* 256: the block as DownSample leaves it, pitch 16 */
+    int16_t *blk = cime_lds + 256;      /* 256: the block as SAD reads it (pitch = valid width), re-pitched to 16 and zero padded */
+    int16_t *win = cime_lds + 512;      /* (nx + 15, rounded up to even) x (ny + 15) */
     const int x0 = j.mvmin[0] / 4, x1 = j.mvmax[0] / 4, y0 = j.mvmin[1] / 4, y1 = j.mvmax[1] / 4;
     const int nx = x1 - x0 + 1, ny = y1 - y0 + 1;
-    const int ww = nx + 15, wh = ny + 15;
+    const int ww = (nx + 15 + 1) & ~1, wh = ny + 15;
     const int tid = threadIdx.x;
+    const int cw = j.valid_w / 4, ch = j.valid_h / 4;
+    if (tid < 256)
     {
         /* DownSample (motion.cpp:1232-1249) of the 64x64 block cached at the CTU origin */
         const P *src = (const P*)a.fenc.origin + (long)j.ctu_y * a.fenc.stride + j.ctu_x;
@@ -279,33 +287,66 @@ __global__ __launch_bounds__(CIME_THREADS) void rk_cime_kernel(RkArgs a)
     for (int i = tid; i < ww * wh; i += CIME_THREADS)
     {
         const int yy = i / ww, xx = i - yy * ww;
-        win[i] = ref[(long)yy * a.ds_stride + xx];
+        win[i] = xx < nx + 15 ? ref[(long)yy * a.ds_stride + xx] : (int16_t)0;
+    }
+    if (j.have_mvd)
+    {
+        /* mvcost(tmv) per predictor = costx + costy truncated to uint16 (bitcost.h:46) */
+        for (int i = tid; i < 3 * nx; i += CIME_THREADS) { const int k = i / nx, c = i - k * nx; costx[k][c] = a.ctab[x0 + c - j.mvp[k][0]]; }
+        for (int i = tid; i < 3 * ny; i += CIME_THREADS) { const int k = i / ny, c = i - k * ny; costy[k][c] = a.ctab[y0 + c - j.mvp[k][1]]; }
     }
     __syncthreads();
-    const int cw = j.valid_w / 4, ch = j.valid_h / 4;
-    unsigned long long best = ~0ull;
-    for (int c = tid; c < nx * ny; c += CIME_THREADS)
+    if (tid < 256)
     {
-        const int cy = c / nx, cx = c - cy * nx;
-        int sad = 0;
         /* the CTU block is indexed with the valid width as its pitch (motion.cpp:1227) */
+        const int k = tid & 15, i = tid >> 4;
+        blk[tid] = (k < cw && i < ch) ? ctu[k + i * cw] : (int16_t)0;
+    }
+    __syncthreads();
+    const int nd = (cw + 1) >> 1;       /* dwords (sample pairs) per block row */
+    const uint32_t lastmask = (cw & 1) ? 0xffffu : 0xffffffffu;
+    const int npx = (nx + 1) >> 1;      /* position pairs per row */
+    unsigned long long best = ~0ull;
+    for (int c = tid; c < npx * ny; c += CIME_THREADS)
+    {
+        const int cy = c / npx, cx = (c - cy * npx) * 2;
+        uint32_t se = 0, so = 0;
         for (int i = 0; i < ch; i++)
-            for (int k = 0; k < cw; k++)
-                sad += abs((int)win[(cy + i) * ww + cx + k] - (int)ctu[k + i * cw]);
-        int mvc = 0;
-        if (j.have_mvd)
         {
-            mvc = 0x7fffffff;
-            const int tx = x0 + cx, ty = y0 + cy;
+            const uint32_t *r = (const uint32_t*)(win + (cy + i) * ww + cx);
+            const uint32_t *f = (const uint32_t*)(blk + i * 16);
+            uint32_t rr[9];
 #pragma unroll
-            for (int k = 0; k < 3; k++)
-            {
-                const int v = ((int)a.ctab[tx - j.mvp[k][0]] + (int)a.ctab[ty - j.mvp[k][1]]) & 0xffff;
-                mvc = v < mvc ? v : mvc;
-            }
+            for (int d = 0; d < 9; d++) rr[d] = r[d];
+#pragma unroll
+            for (int d = 0; d < 8; d++)
+                if (d < nd)
+                {
+                    /* an odd last sample of the block row is paired with a zero on both sides */
+                    const uint32_t m = d == nd - 1 ? lastmask : 0xffffffffu;
+                    se = __builtin_amdgcn_sad_u16(f[d], rr[d] & m, se);
+                    so = __builtin_amdgcn_sad_u16(f[d], __builtin_amdgcn_alignbit(rr[d + 1], rr[d], 16) & m, so);
+                }
         }
-        const unsigned long long key = ((unsigned long long)(unsigned)(sad + mvc) << 32) | (unsigned)c;
-        best = key < best ? key : best;
+#pragma unroll
+        for (int o = 0; o < 2; o++)
+        {
+            const int px = cx + o;
+            if (px >= nx) break;
+            int mvc = 0;
+            if (j.have_mvd)
+            {
+                mvc = 0x7fffffff;
+#pragma unroll
+                for (int k = 0; k < 3; k++)
+                {
+                    const int v = ((int)costx[k][px] + (int)costy[k][cy]) & 0xffff;
+                    mvc = v < mvc ? v : mvc;
+                }
+            }
+            const unsigned long long key = ((unsigned long long)((o ? so : se) + (uint32_t)mvc) << 32) | (unsigned)(cy * nx + px);
+            best = key < best ? key : best;
+        }
     }
     for (int o = 1; o < 64; o <<= 1)
     {
@@ -329,7 +370,10 @@ __global__ __launch_bounds__(CIME_THREADS) void rk_cime_kernel(RkArgs a)
 /* RIME + FME (motion.cpp:1305-1403): one wave per (CTU, CU). RIME scans three 16x12
  * full-pel windows row by row (16 candidates per batched evaluation); FME scans the 7x7
  * quarter-pel grid around the RIME winner, x offset outer, y inner. */
-template<typename P>
+#include "me_rk_rime.h"   /* rk_rime_kernel: RIME of a whole CTU from 8x8 block surfaces; uses RkArgs */
+
+/* HAVE_RIME: the full-pel stage was done by rk_rime_kernel, only FME runs here */
+template<typename P, bool HAVE_RIME>
 __global__ __launch_bounds__(64) void rk_cu_kernel(RkArgs a)
 {
     const int ctuIdx = blockIdx.x / 85, idx = blockIdx.x % 85;
@@ -354,22 +398,48 @@ __global__ __launch_bounds__(64) void rk_cu_kernel(RkArgs a)
     S.bind(0, a.fenc, &a.recon, 1, a.ctab, a.depth, j.ctu_x + ox, j.ctu_y + oy, size, size);
     S.nsad = S.nsub = 0;
     S.set_rk_predictors(j.mvp, j.have_mvd);
-    int pmv[3][2] = { { res.cime.mv[0], res.cime.mv[1] }, { j.pmv[0][0], j.pmv[0][1] }, { j.pmv[1][0], j.pmv[1][1] } };
     int bcost = 0x7fffffff, bx = 0, by = 0;
-    for (int p = 0; p < 3; p++)
-        for (int i0 = -6; i0 < 6; i0 += 4)
-        {
-            /* four 16-wide rows of the window per batch, one lane per position */
-            const int tx = as_i16(pmv[p][0] + (lane & 15) - 8), ty = as_i16(pmv[p][1] + i0 + (lane >> 4));
-            S.put_lanes(true, tx, ty, tx, ty, 16, 0);
-            S.eval(64, 0, true);
-            const int kb = S.fold_min(64, bcost);
-            if (kb >= 0) { bx = S.mvx_of(kb); by = S.mvy_of(kb); }
-        }
-    if (lane == 0) { res.rime[idx].mv[0] = (int16_t)bx; res.rime[idx].mv[1] = (int16_t)by; res.rime[idx].cost = bcost; }
+    if (HAVE_RIME)
+    {
+        bx = uni(res.rime[idx].mv[0]); by = uni(res.rime[idx].mv[1]);
+    }
+    else
+    {
+        int pmv[3][2] = { { res.cime.mv[0], res.cime.mv[1] }, { j.pmv[0][0], j.pmv[0][1] }, { j.pmv[1][0], j.pmv[1][1] } };
+        for (int p = 0; p < 3; p++)
+            for (int i0 = -6; i0 < 6; i0 += 4)
+            {
+                /* four 16-wide rows of the window per batch, one lane per position */
+                const int tx = as_i16(pmv[p][0] + (lane & 15) - 8), ty = as_i16(pmv[p][1] + i0 + (lane >> 4));
+                S.put_lanes(true, tx, ty, tx, ty, 16, 0);
+                S.eval(64, 0, true);
+                const int kb = S.fold_min(64, bcost);
+                if (kb >= 0) { bx = S.mvx_of(kb); by = S.mvy_of(kb); }
+            }
+        if (lane == 0) { res.rime[idx].mv[0] = (int16_t)bx; res.rime[idx].mv[1] = (int16_t)by; res.rime[idx].cost = bcost; }
+    }
     const int BX = as_i16(bx << 2), BY = as_i16(by << 2);
     bcost = 0x7fffffff;
     int fx = 0, fy = 0;
+    {
+        /* the reference region of the 49 fractional positions, copied once into LDS (the
+         * reference copies the same neighbourhood into pfref, motion.cpp:1382-1389) */
+        const int cols = RK_REGION_COLS(size), rows = RK_REGION_ROWS(size), rx0 = bx - 2, ry0 = by - 2;
+        const int woff = wave_lds_bytes<P>(64);
+        const P AS1 *src = (const P AS1*)a.recon.origin + (long)(j.ctu_y + oy + ry0) * a.recon.stride + j.ctu_x + ox + rx0;
+        const int qd = cols >> 2;
+        for (int i = lane; i < rows * qd; i += 64)
+        {
+            const int r = i / qd, q = i - r * qd;
+            Px<P>::store_lds_aligned(woff + (r * cols + 4 * q) * (int)sizeof(P), Px<P>::load_g(src + (long)r * a.recon.stride + 4 * q));
+        }
+        if (lane == 0)
+        {
+            EvalCtx *ec = lds_ctx(0);
+            ec->rk_win = woff; ec->rk_pitch = cols; ec->rk_x0 = rx0; ec->rk_y0 = ry0;
+        }
+        wave_sync();
+    }
     {
         /* the 7x7 grid in one batch: lane c -> (c / 7, c % 7) */
         const int cx = (lane * 37) >> 8, cy = lane - cx * 7;
@@ -1096,16 +1166,23 @@ int x265amd_rk_ctu_batch_dev(x265amd_ctx *c, const x265amd_plane *fenc, const x2
     a.ctab = c->tables[qp] + 32768;
     a.ctus = d_ctus; a.results = d_results; a.nctus = nctus;
     /* window of the widest range the RK rules allow: (384/2/4*2 + 15) x (320/2/4*2 + 15) int16 */
-    const size_t lds = (256 + 111 * 95) * sizeof(int16_t);
+    const size_t lds = (512 + 112 * 95 + 16) * sizeof(int16_t);
     if (c->depth <= 8)
     {
+        static bool lds_raised = false;
+        if (!lds_raised)
+        {
+            HIPCHK(c, hipFuncSetAttribute((const void*)rk_rime_kernel<uint8_t>, hipFuncAttributeMaxDynamicSharedMemorySize, RL_TOTAL));
+            lds_raised = true;
+        }
         hipLaunchKernelGGL(rk_cime_kernel<uint8_t>, dim3(nctus), dim3(CIME_THREADS), lds, c->stream, a);
-        hipLaunchKernelGGL(rk_cu_kernel<uint8_t>, dim3(nctus * 85), dim3(64), wave_lds_bytes<uint8_t>(64), c->stream, a);
+        hipLaunchKernelGGL(rk_rime_kernel<uint8_t>, dim3(nctus), dim3(RIME_THREADS), RL_TOTAL, c->stream, a);
+        hipLaunchKernelGGL((rk_cu_kernel<uint8_t, true>), dim3(nctus * 85), dim3(64), wave_lds_bytes<uint8_t>(64) + rk_region_bytes<uint8_t>(64), c->stream, a);
     }
     else
     {
         hipLaunchKernelGGL(rk_cime_kernel<uint16_t>, dim3(nctus), dim3(CIME_THREADS), lds, c->stream, a);
-        hipLaunchKernelGGL(rk_cu_kernel<uint16_t>, dim3(nctus * 85), dim3(64), wave_lds_bytes<uint16_t>(64), c->stream, a);
+        hipLaunchKernelGGL((rk_cu_kernel<uint16_t, false>), dim3(nctus * 85), dim3(64), wave_lds_bytes<uint16_t>(64) + rk_region_bytes<uint16_t>(64), c->stream, a);
     }
     HIPCHK(c, hipGetLastError());
     return X265AMD_OK;

@@ -1,0 +1,205 @@
+/* RIME of the Rockchip path for a whole CTU at once (8-bit planes).
+ *
+ * Reference: source/encoder/motion.cpp:1305-1361 (C-model twin hardwareC/inter.cpp:2521-2560).
+ * Every CU of a CTU scans the same three windows of 16 x 12 full-pel positions -- the window
+ * centres Pmv[0..2] are per CTU -- and adds the same lambda * bits term per position. Because
+ * all CUs move by the same displacement, the SAD of a 16x16, 32x32 or 64x64 CU at one position
+ * is the sum of the SADs of the 8x8 blocks it covers. So one workgroup per CTU
+ *   1. copies the CTU and the three reference windows into LDS,
+ *   2. measures every 8x8 block at every position (v_qsad_pk_u16_u8: four horizontally adjacent
+ *      positions per instruction, three vertically adjacent ones sharing the loaded rows),
+ *   3. adds the block surfaces up the quadtree,
+ *   4. takes, per CU, the first minimum of SAD + lambda * bits in the reference's visit order
+ *      (window, row, column; strict '<').
+ * The 85 results go to x265amd_rk_result::rime; the fractional stage reads them from there.
+ */
+#ifndef X265AMD_ME_RK_RIME_H
+#define X265AMD_ME_RK_RIME_H
+
+#include "me_search.h"
+
+namespace x265amd {
+
+#define RIME_THREADS 1024
+#define RIME_NCAND 576            /* 3 windows x 12 rows x 16 columns; index = visit order */
+#define RIME_WPITCH 84            /* bytes per window row: 64 + 15 columns and the dword a lane reads past them */
+#define RIME_WROWS 75             /* 64 + 11 rows */
+#define RIME_RR 3                 /* vertically adjacent positions per lane */
+
+enum
+{
+    RL_FENC = 0,                                  /* 64 x 64 source, pitch 64 */
+    RL_MVC = 4096,                                /* int[576]: lambda * bits per position */
+    RL_BEST = RL_MVC + 4 * RIME_NCAND,            /* uint[85]: running minimum key per CU */
+    RL_WIN = RL_BEST + 4 * 88,                    /* 3 windows */
+    RL_S8 = RL_WIN + ((3 * RIME_WROWS * RIME_WPITCH + 15) & ~15),   /* uint16[64 blocks][576] */
+    RL_S16 = RL_S8 + 2 * 64 * RIME_NCAND,         /* uint16[16][576] */
+    RL_S32 = RL_S16 + 2 * 16 * RIME_NCAND,        /* uint32[4][576] */
+    RL_S64 = RL_S32 + 4 * 4 * RIME_NCAND,         /* uint32[576] */
+    RL_TOTAL = RL_S64 + 4 * RIME_NCAND
+};
+
+__device__ __forceinline__ uint64_t rime_pair(int off)
+{
+    const uint32_t *q = (const uint32_t*)(x265amd_smem + off);
+    return ((uint64_t)q[1] << 32) | q[0];
+}
+
+template<typename P>
+__global__ __launch_bounds__(RIME_THREADS) void rk_rime_kernel(RkArgs a)
+{
+    static_assert(sizeof(P) == 1, "the packed quad-SAD path is for 8-bit samples");
+    const x265amd_rk_ctu &j = a.ctus[blockIdx.x];
+    x265amd_rk_result &res = a.results[blockIdx.x];
+    const int tid = threadIdx.x;
+    const int pmv[3][2] = { { res.cime.mv[0], res.cime.mv[1] }, { j.pmv[0][0], j.pmv[0][1] }, { j.pmv[1][0], j.pmv[1][1] } };
+
+    /* ---- 1. source CTU, windows, lambda * bits ---- */
+    {
+        typedef uint32_t __attribute__((aligned(1))) u32u;
+        const char AS1 *src = (const char AS1*)a.fenc.origin + (long)j.ctu_y * a.fenc.stride + j.ctu_x;
+        {
+            const int y = tid >> 4, x = tid & 15;     /* 64 rows x 16 dwords */
+            *(uint32_t*)(x265amd_smem + RL_FENC + y * 64 + 4 * x) = *(const u32u AS1*)(src + (long)y * a.fenc.stride + 4 * x);
+        }
+        const char AS1 *rec = (const char AS1*)a.recon.origin + (long)j.ctu_y * a.recon.stride + j.ctu_x;
+        const int wd = RIME_WPITCH / 4;
+        for (int i = tid; i < 3 * RIME_WROWS * wd; i += RIME_THREADS)
+        {
+            const int p = i / (RIME_WROWS * wd), r = (i - p * RIME_WROWS * wd) / wd, d = i - (p * RIME_WROWS + r) * wd;
+            const int px = as_i16(pmv[p][0] - 8), py = as_i16(pmv[p][1] - 6);   /* first position of the window */
+            *(uint32_t*)(x265amd_smem + RL_WIN + (p * RIME_WROWS + r) * RIME_WPITCH + 4 * d) =
+                *(const u32u AS1*)(rec + (long)(py + r) * a.recon.stride + px + 4 * d);
+        }
+        if (tid < RIME_NCAND)
+        {
+            /* the smallest of the three predictors' costs, each sum truncated to uint16
+             * (motion.cpp:1347-1355) */
+            const int p = tid / 192, i = (tid - p * 192) >> 4, jx = tid & 15;
+            const int tx = as_i16(pmv[p][0] + jx - 8), ty = as_i16(pmv[p][1] + i - 6);
+            int mvc = 0;
+            if (j.have_mvd)
+            {
+                const uint16_t AS1 *ctab = (const uint16_t AS1*)a.ctab;
+                mvc = 0x7fffffff;
+#pragma unroll
+                for (int k = 0; k < 3; k++)
+                {
+                    const int v = ((int)ctab[tx - j.mvp[k][0]] + (int)ctab[ty - j.mvp[k][1]]) & 0xffff;
+                    mvc = v < mvc ? v : mvc;
+                }
+            }
+            lds_i(0, RL_MVC)[tid] = mvc;
+        }
+        if (tid < 85) ((uint32_t*)(x265amd_smem + RL_BEST))[tid] = 0xffffffffu;
+    }
+    __syncthreads();
+
+    /* ---- 2. 8x8 block surfaces: item = (block, window, row group of 3, column group of 4) ---- */
+    const int nbx = j.valid_w >> 3, nby = j.valid_h >> 3;     /* blocks inside the picture */
+    for (int it = tid; it < 64 * 3 * 4 * 4; it += RIME_THREADS)
+    {
+        const int xg = it & 3, yg = (it >> 2) & 3, pb = it >> 4;
+        const int p = pb % 3, blk = pb / 3;
+        const int bx = blk & 7, by = blk >> 3;
+        if (bx >= nbx || by >= nby) continue;
+        const int org = RL_WIN + (p * RIME_WROWS + by * 8 + yg * RIME_RR) * RIME_WPITCH + bx * 8 + xg * 4;
+        const int fo = RL_FENC + by * 8 * 64 + bx * 8;
+        uint64_t acc[RIME_RR];
+#pragma unroll
+        for (int c = 0; c < RIME_RR; c++) acc[c] = 0;
+#pragma unroll
+        for (int col = 0; col < 2; col++)
+        {
+            uint64_t rows[8 + RIME_RR - 1];
+            uint32_t f[8];
+#pragma unroll
+            for (int k = 0; k < 8 + RIME_RR - 1; k++) rows[k] = rime_pair(org + 4 * col + k * RIME_WPITCH);
+#pragma unroll
+            for (int k = 0; k < 8; k++) f[k] = *(const uint32_t*)(x265amd_smem + fo + 4 * col + k * 64);
+#pragma unroll
+            for (int y = 0; y < 8; y++)
+#pragma unroll
+                for (int c = 0; c < RIME_RR; c++) acc[c] = __builtin_amdgcn_qsad_pk_u16_u8(rows[y + c], f[y], acc[c]);
+        }
+        /* an 8x8 SAD is at most 16320: the packed 16-bit sums are the surface entries */
+#pragma unroll
+        for (int c = 0; c < RIME_RR; c++)
+            *(uint64_t*)(x265amd_smem + RL_S8 + 2 * (blk * RIME_NCAND + p * 192 + (yg * RIME_RR + c) * 16 + xg * 4)) = acc[c];
+    }
+    __syncthreads();
+
+    /* ---- 3. up the quadtree ---- */
+    const uint16_t *s8 = (const uint16_t*)(x265amd_smem + RL_S8);
+    uint16_t *s16 = (uint16_t*)(x265amd_smem + RL_S16);
+    uint32_t *s32 = (uint32_t*)(x265amd_smem + RL_S32), *s64 = (uint32_t*)(x265amd_smem + RL_S64);
+    for (int i = tid; i < 16 * RIME_NCAND; i += RIME_THREADS)
+    {
+        const int cu = i / RIME_NCAND, cand = i - cu * RIME_NCAND;
+        const int b0 = (cu >> 2) * 16 + (cu & 3) * 2;      /* top-left 8x8 block of the 16x16 CU */
+        /* at most 4 x 16320 = 65280: still 16 bits */
+        s16[i] = (uint16_t)(s8[b0 * RIME_NCAND + cand] + s8[(b0 + 1) * RIME_NCAND + cand] +
+                            s8[(b0 + 8) * RIME_NCAND + cand] + s8[(b0 + 9) * RIME_NCAND + cand]);
+    }
+    __syncthreads();
+    for (int i = tid; i < 4 * RIME_NCAND; i += RIME_THREADS)
+    {
+        const int cu = i / RIME_NCAND, cand = i - cu * RIME_NCAND;
+        const int c0 = (cu >> 1) * 8 + (cu & 1) * 2;       /* top-left 16x16 CU of the 32x32 CU */
+        s32[i] = (uint32_t)s16[c0 * RIME_NCAND + cand] + s16[(c0 + 1) * RIME_NCAND + cand] +
+                 s16[(c0 + 4) * RIME_NCAND + cand] + s16[(c0 + 5) * RIME_NCAND + cand];
+    }
+    __syncthreads();
+    if (tid < RIME_NCAND) s64[tid] = s32[tid] + s32[RIME_NCAND + tid] + s32[2 * RIME_NCAND + tid] + s32[3 * RIME_NCAND + tid];
+    __syncthreads();
+
+    /* ---- 4. per CU: first minimum in visit order; 12 threads share a CU ---- */
+    uint32_t *best = (uint32_t*)(x265amd_smem + RL_BEST);
+    if (tid < 85 * 12)
+    {
+        const int idx = tid / 12, part = tid - idx * 12;
+        int size, ox, oy;
+        if (idx < 64) { size = 8; ox = (idx & 7) * 8; oy = (idx >> 3) * 8; }
+        else if (idx < 80) { size = 16; ox = ((idx - 64) & 3) * 16; oy = ((idx - 64) >> 2) * 16; }
+        else if (idx < 84) { size = 32; ox = ((idx - 80) & 1) * 32; oy = ((idx - 80) >> 1) * 32; }
+        else { size = 64; ox = 0; oy = 0; }
+        if (j.ctu_x + ox + size <= a.pic_w && j.ctu_y + oy + size <= a.pic_h)
+        {
+            const int *mvc = lds_i(0, RL_MVC);
+            uint32_t key = 0xffffffffu;
+            /* cost < 2^21, so (cost << 10 | visit index) orders like the sequential strict-'<' scan */
+            for (int k = 0; k < 48; k++)
+            {
+                const int cand = part * 48 + k;
+                uint32_t sad;
+                if (idx < 64) sad = s8[idx * RIME_NCAND + cand];
+                else if (idx < 80) sad = s16[(idx - 64) * RIME_NCAND + cand];
+                else if (idx < 84) sad = s32[(idx - 80) * RIME_NCAND + cand];
+                else sad = s64[cand];
+                const uint32_t kk = ((sad + (uint32_t)mvc[cand]) << 10) | (uint32_t)cand;
+                key = kk < key ? kk : key;
+            }
+            atomicMin(&best[idx], key);
+        }
+    }
+    __syncthreads();
+    if (tid < 85)
+    {
+        const uint32_t key = best[tid];
+        if (key == 0xffffffffu)
+        {
+            /* CU outside the picture (TEncCu.cpp:475-493) */
+            res.rime[tid].mv[0] = res.rime[tid].mv[1] = 0; res.rime[tid].cost = -1;
+        }
+        else
+        {
+            const int cand = key & 1023, p = cand / 192, i = (cand - p * 192) >> 4, jx = cand & 15;
+            res.rime[tid].mv[0] = (int16_t)(pmv[p][0] + jx - 8);
+            res.rime[tid].mv[1] = (int16_t)(pmv[p][1] + i - 6);
+            res.rime[tid].cost = (int)(key >> 10);
+        }
+    }
+}
+
+} // namespace x265amd
+#endif

@@ -97,8 +97,18 @@ struct EvalCtx
     int rstride, w, h, T, Tp, lTp, wt, inv_wt, depth;
     int mvpx, mvpy;
     int rk_have_mvd, rk_mvp[3][2];
+    int rk_win, rk_pitch, rk_x0, rk_y0; /* Rockchip FME: the reference region staged in LDS (byte offset, pitch in samples) and the MV of its first sample */
     int planes_off, plane_budget; /* LDS area for the interpolation planes of the sub-pel stage */
 };
+
+static_assert(sizeof(EvalCtx) <= L_FENC - L_CTX, "EvalCtx must fit its LDS slot");
+
+/* LDS bytes of the reference region the Rockchip fractional stage reads for a size x size CU:
+ * the integer parts of the 49 positions are the RIME vector + {-1, 0}, the 4-tap filters reach
+ * one sample before and two after, and tiles are loaded as whole quads */
+#define RK_REGION_COLS(size) ((size) + 8)
+#define RK_REGION_ROWS(size) ((size) + 4)
+template<typename P> constexpr int rk_region_bytes(int size) { return RK_REGION_COLS(size) * RK_REGION_ROWS(size) * (int)sizeof(P) + 16; }
 
 __device__ __forceinline__ int *lds_i(int base, int off) { return (int*)(x265amd_smem + base + off); }
 __device__ __forceinline__ EvalCtx *lds_ctx(int base) { return (EvalCtx*)(x265amd_smem + base + L_CTX); }
@@ -268,7 +278,9 @@ __device__ __forceinline__ int tile_cost(int base, const Geo &c, int k, int t, i
     else if constexpr (RK)
     {
         const int xf = cx & 3, yf = cy & 3;
-        GlobalLoader<P> ld = { ref0 + c.roff + (long)((cy >> 2) + ty * 4) * c.rstride + (cx >> 2) + tx * 4, c.rstride };
+        const EvalCtx *ec = lds_ctx(base);
+        const int pitch = uni(ec->rk_pitch);
+        LdsLoader<P> ld = { base + uni(ec->rk_win) + (((cy >> 2) - uni(ec->rk_y0) + ty * 4) * pitch + (cx >> 2) - uni(ec->rk_x0) + tx * 4) * (int)sizeof(P), pitch };
         if ((xf | yf) == 0)
         {
 #pragma unroll
