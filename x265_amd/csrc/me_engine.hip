@@ -370,7 +370,7 @@ __global__ __launch_bounds__(CIME_THREADS) void rk_cime_kernel(RkArgs a)
 /* RIME + FME (motion.cpp:1305-1403): one wave per (CTU, CU). RIME scans three 16x12
  * full-pel windows row by row (16 candidates per batched evaluation); FME scans the 7x7
  * quarter-pel grid around the RIME winner, x offset outer, y inner. */
-#include "me_rk_rime.h"   /* rk_rime_kernel: RIME of a whole CTU from 8x8 block surfaces; uses RkArgs */
+#include "me_rk.h"   /* rk_rime_kernel (RIME of a whole CTU from 8x8 block surfaces; uses RkArgs), rk_fme_grid */
 
 /* HAVE_RIME: the full-pel stage was done by rk_rime_kernel, only FME runs here */
 template<typename P, bool HAVE_RIME>
@@ -441,11 +441,17 @@ __global__ __launch_bounds__(64) void rk_cu_kernel(RkArgs a)
         wave_sync();
     }
     {
-        /* the 7x7 grid in one batch: lane c -> (c / 7, c % 7) */
+        /* the 7x7 grid: distortions from rk_fme_grid, lambda * bits per position, then the first
+         * minimum in visit order, x offset outer (motion.cpp:1377-1401): lane c -> (c / 7, c % 7) */
         const int cx = (lane * 37) >> 8, cy = lane - cx * 7;
         const int qx = as_i16(BX + cx - 3), qy = as_i16(BY + cy - 3);
         S.put_lanes(lane < 49, qx, qy, qx, qy, 16, 0);
-        S.eval(49, 3, true);
+        wave_sync();
+        const int mvc = gather_mvcost(0, 49, 3, 1);
+        rk_fme_grid<P>(0, wave_lds_bytes<P>(64), RK_REGION_COLS(size), size, BX, BY, a.depth);
+        if (lane < 49) lds_i(0, L_COSTS)[lane] += mvc;
+        wave_sync();
+        S.nsub += 49;
         const int kb = S.fold_min(49, bcost);
         if (kb >= 0) { fx = S.mvx_of(kb); fy = S.mvy_of(kb); }
     }

@@ -1,4 +1,7 @@
-/* RIME of the Rockchip path for a whole CTU at once (8-bit planes).
+/* Rockchip path, stages after CIME: RIME for a whole CTU at once (8-bit planes) and the
+ * fractional stage FME for one CU per wave.
+ *
+ * RIME
  *
  * Reference: source/encoder/motion.cpp:1305-1361 (C-model twin hardwareC/inter.cpp:2521-2560).
  * Every CU of a CTU scans the same three windows of 16 x 12 full-pel positions -- the window
@@ -13,8 +16,8 @@
  *      (window, row, column; strict '<').
  * The 85 results go to x265amd_rk_result::rime; the fractional stage reads them from there.
  */
-#ifndef X265AMD_ME_RK_RIME_H
-#define X265AMD_ME_RK_RIME_H
+#ifndef X265AMD_ME_RK_H
+#define X265AMD_ME_RK_H
 
 #include "me_search.h"
 
@@ -199,6 +202,116 @@ __global__ __launch_bounds__(RIME_THREADS) void rk_rime_kernel(RkArgs a)
             res.rime[tid].cost = (int)(key >> 10);
         }
     }
+}
+
+
+/* ---- FME: the 7 x 7 quarter-pel grid around the RIME vector (motion.cpp:1364-1403; filters
+ * InterpHoriz / InterpVert / FilterHorizontal + FilterVertical with N = 4, :1495-1648) ----
+ *
+ * The grid has seven x offsets and seven y offsets. One lane owns a (x offset, 4x4 tile) pair:
+ * it runs the horizontal 4-tap pass once, over the eight reference rows the seven y offsets
+ * need between them, and then the vertical pass + Hadamard cost for each y offset. The
+ * reference region (RK_REGION_COLS x RK_REGION_ROWS samples, first sample at RIME vector
+ * - (2, 2)) and the source block are in LDS. costs[i * 7 + j] is left in the wave's L_COSTS
+ * array, i = x offset index (outer in the reference's visit order), j = y offset index. */
+template<typename P>
+__device__ __forceinline__ void rk_fme_grid(int base, int region, int pitch, int size, int bxq, int byq, int depth)
+{
+    const int lane = threadIdx.x & 63;
+    const int wt = size >> 2, T = wt * wt;
+    int lT = 0;
+    while ((1 << lT) < T) lT++;
+    const int lG = lT < 6 ? lT : 6;       /* lanes that share a candidate within one pass */
+    const int maxv = (1 << depth) - 1;
+    const int headRoom = 14 - depth;
+    const int shiftH = 6 - headRoom, offH = -(8192 << shiftH);
+    const int shiftV = 6 + headRoom, offV = (1 << (shiftV - 1)) + (8192 << 6);
+    if (lane < 49) lds_i(base, L_COSTS)[lane] = 0;
+    wave_sync();
+    for (int task0 = 0; task0 < 7 * T; task0 += 64)
+    {
+        const int task = task0 + lane;
+        const bool live = task < 7 * T;
+        const int i = live ? task >> lT : 0, t = task & (T - 1);
+        const int ty = t >> (lT >> 1), tx = t & (wt - 1);
+        const int qx = as_i16(bxq + i - 3), xf = qx & 3;
+        /* region column of the sample one to the left of the tile's first output */
+        const int col0 = ((qx >> 2) - (bxq >> 2) + 1) + tx * 4;
+        int ch[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) ch[k] = kRkTaps[xf][k];
+        /* horizontal pass over region rows ty*4 .. ty*4 + 7: raw sums, or the samples when xf == 0 */
+        int hr[8][4];
+#pragma unroll
+        for (int r = 0; r < 8; r++)
+        {
+            const int off = base + region + ((ty * 4 + r) * pitch + col0) * (int)sizeof(P);
+            int px[8];
+            Px<P>::unpack(Px<P>::load_lds(off), px);
+            Px<P>::unpack(Px<P>::load_lds(off + 4 * (int)sizeof(P)), px + 4);
+#pragma unroll
+            for (int x = 0; x < 4; x++)
+                hr[r][x] = xf ? px[x] * ch[0] + px[x + 1] * ch[1] + px[x + 2] * ch[2] + px[x + 3] * ch[3] : px[x + 1];
+        }
+        /* what the vertical filter reads: the 16-bit intermediates of the two-pass case, or samples */
+        int hv[8][4];
+#pragma unroll
+        for (int r = 0; r < 8; r++)
+#pragma unroll
+            for (int x = 0; x < 4; x++) hv[r][x] = xf ? as_i16((hr[r][x] + offH) >> shiftH) : hr[r][x];
+        int fv[4][4];
+#pragma unroll
+        for (int y = 0; y < 4; y++)
+            Px<P>::unpack(Px<P>::load_lds_aligned(base + L_FENC + ((ty * 4 + y) * 64 + tx * 4) * (int)sizeof(P)), fv[y]);
+        const int sv = xf ? shiftV : 6, ov = xf ? offV : 32;
+        for (int jj = 0; jj < 7; jj++)
+        {
+            const int yf = (jj + 1) & 3;
+            int d[4][4];
+            if (yf == 0)
+            {
+                /* integer row: luma-hpp style rounding of the raw horizontal sum, or the sample itself */
+#pragma unroll
+                for (int y = 0; y < 4; y++)
+#pragma unroll
+                    for (int x = 0; x < 4; x++)
+                        d[y][x] = fv[y][x] - (xf ? clip_pixel(as_i16((hr[y + 2][x] + 32) >> 6), maxv) : hr[y + 2][x]);
+            }
+            else
+            {
+                int cv[4];
+#pragma unroll
+                for (int k = 0; k < 4; k++) cv[k] = kRkTaps[yf][k];
+                if (jj < 3)
+                {
+#pragma unroll
+                    for (int y = 0; y < 4; y++)
+#pragma unroll
+                        for (int x = 0; x < 4; x++)
+                        {
+                            const int sum = hv[y][x] * cv[0] + hv[y + 1][x] * cv[1] + hv[y + 2][x] * cv[2] + hv[y + 3][x] * cv[3];
+                            d[y][x] = fv[y][x] - clip_pixel(as_i16((sum + ov) >> sv), maxv);
+                        }
+                }
+                else
+                {
+#pragma unroll
+                    for (int y = 0; y < 4; y++)
+#pragma unroll
+                        for (int x = 0; x < 4; x++)
+                        {
+                            const int sum = hv[y + 1][x] * cv[0] + hv[y + 2][x] * cv[1] + hv[y + 3][x] * cv[2] + hv[y + 4][x] * cv[3];
+                            d[y][x] = fv[y][x] - clip_pixel(as_i16((sum + ov) >> sv), maxv);
+                        }
+                }
+            }
+            int v = live ? had4x4_half(d) : 0;
+            v = seg_sum(v, lG);
+            if (live && (lane & ((1 << lG) - 1)) == 0) lds_i(base, L_COSTS)[i * 7 + jj] += v;
+            if (T > 64) wave_sync();   /* several passes add to the same entry */
+        }
+    }
+    wave_sync();
 }
 
 } // namespace x265amd
