@@ -1,0 +1,118 @@
+"""GPU: the BASELINE.json configurations at their full picture sizes.
+
+  configs[2]  4K 8-bit, --me full, merange 92, 3 references   -> exhaustive-search kernel
+  configs[3]  4K Main10, --subme 5                             -> 16-bit interpolation + SATD refinement
+  configs[4]  8K 8-bit lookahead                               -> one lowres MV field of a 7680x4320 frame
+
+A CPU replay of every PU at these sizes would take minutes, so each case checks (a) a seeded sample of
+the PUs against the oracle and (b) a size-independent property over all of them.
+"""
+import numpy as np
+import pytest
+
+from x265_amd.engine import METHODS, make_jobs
+from x265_amd.synth import make_clip, pad_plane
+from x265_amd import workload
+from util import oracle_search, host_lowres_planes
+
+pytestmark = pytest.mark.gpu
+
+
+def _sample(jobs, n, seed):
+    idx = np.sort(np.random.default_rng(seed).choice(len(jobs), n, replace=False))
+    return idx, jobs[idx]
+
+
+def test_4k_exhaustive_search_three_refs(engine8, oracle):
+    W, H, M, MR = 3840, 2160, 128, 92
+    clip = make_clip(W, H, 4, seed=41)
+    cur, org, stride = pad_plane(clip[3], M)
+    pc = engine8.upload_plane(cur, W, H, M, M, stride)
+    rng = np.random.default_rng(9)
+    wcu, hcu = (W // 2 + 7) // 8, (H // 2 + 7) // 8
+    la = rng.integers(-16, 17, (wcu * hcu, 2)).astype(np.int16)
+    jobs64 = workload.square_pu_jobs(W, H, la, wcu, hcu, MR, sizes=(64,))
+    jobs16 = workload.square_pu_jobs(W, H, la, wcu, hcu, MR, sizes=(16,))
+    for r in range(3):   # 3 reference pictures, one search batch each
+        ref, _, _ = pad_plane(clip[r], M)
+        pr = engine8.upload_plane(ref, W, H, M, M, stride)
+        for jobs, n in ((jobs64, 6), (jobs16, 24)):
+            res = engine8.search_batch(pc, pr, jobs, 32, METHODS["full"], 5)
+            idx, sub = _sample(jobs, n, 100 + r)
+            mv, cost, sc, qc = oracle_search(oracle, 8, cur, [ref], org, stride, sub, 32, METHODS["full"], 5)
+            assert np.array_equal(res["mv"][idx], mv) and np.array_equal(res["cost"][idx], cost), r
+            assert np.array_equal(res["sad_calls"][idx], sc) and np.array_equal(res["subpel_calls"][idx], qc), r
+            # every PU visited its whole range once, plus at most two start-up points
+            rngx = jobs["mvmax"][:, 0].astype(np.int64) - jobs["mvmin"][:, 0] + 1
+            rngy = jobs["mvmax"][:, 1].astype(np.int64) - jobs["mvmin"][:, 1] + 1
+            extra = res["sad_calls"].astype(np.int64) - rngx * rngy
+            assert (extra >= 0).all() and (extra <= 2).all()
+        engine8.free_plane(pr)
+    # property: against a copy of the source shifted by (+5, -7) the scan finds exactly that vector with SAD 0
+    img = make_clip(W, H, 1, seed=42, kind="noise")[0]
+    buf, _, _ = pad_plane(img, M)
+    sh, _, _ = pad_plane(np.roll(img, (-7, 5), axis=(0, 1)), M)
+    pn, ps = engine8.upload_plane(buf, W, H, M, M, stride), engine8.upload_plane(sh, W, H, M, M, stride)
+    xs, ys = np.meshgrid(np.arange(128, W - 192, 64), np.arange(128, H - 192, 64))
+    jobs = make_jobs(xs.size)
+    jobs["pu_x"], jobs["pu_y"], jobs["w"], jobs["h"] = xs.ravel(), ys.ravel(), 64, 64
+    jobs["mvmin"] = (-MR, -MR); jobs["mvmax"] = (MR, MR); jobs["merange"] = MR
+    res = engine8.search_batch(pn, ps, jobs, 30, METHODS["full"], 0)
+    t = engine8.cost_table(30).astype(np.int64)
+    assert (res["mv"] == (20, -28)).all()
+    assert (res["cost"] == ((t[32767 + 20] + t[32767 - 28]) & 0xffff)).all()
+    for p in (pc, pn, ps):
+        engine8.free_plane(p)
+
+
+def test_4k_main10_subpel_refine(engine10, oracle):
+    W, H, M = 3840, 2160, 96
+    clip = make_clip(W, H, 2, seed=43, depth=10)
+    cur, org, stride = pad_plane(clip[1], M)
+    ref, _, _ = pad_plane(clip[0], M)
+    pc = engine10.upload_plane(cur, W, H, M, M, stride)
+    pr = engine10.upload_plane(ref, W, H, M, M, stride)
+    rng = np.random.default_rng(10)
+    wcu, hcu = (W // 2 + 7) // 8, (H // 2 + 7) // 8
+    la = rng.integers(-20, 21, (wcu * hcu, 2)).astype(np.int16)
+    jobs = workload.square_pu_jobs(W, H, la, wcu, hcu, 57, clip_margin=70)
+    for mname in ("star", "hex"):
+        res = engine10.search_batch(pc, pr, jobs, 38, METHODS[mname], 5)
+        idx, sub = _sample(jobs, 160, 7)
+        mv, cost, sc, qc = oracle_search(oracle, 10, cur, [ref], org, stride, sub, 38, METHODS[mname], 5)
+        assert np.array_equal(res["mv"][idx], mv) and np.array_equal(res["cost"][idx], cost), mname
+        assert np.array_equal(res["sad_calls"][idx], sc) and np.array_equal(res["subpel_calls"][idx], qc), mname
+        # subme 5 measures the start-up predictor(s), then one half-pel and one quarter-pel round of
+        # 8 points with the centre re-measured once (motion.cpp:53-63, :1100-1141) unless the full-pel cost is 0
+        assert ((res["subpel_calls"] >= 1 + 9 + 8) | (res["cost"] == 0)).all()
+    # a picture searched against itself: every PU keeps MV 0 at cost 0 and skips the refinement
+    res = engine10.search_batch(pc, pc, jobs, 38, METHODS["star"], 5)
+    zero = (jobs["qmvp"] == 0).all(axis=1)
+    assert (res["cost"][zero] == 0).all() and (res["mv"][zero] == 0).all()
+    engine10.free_plane(pc)
+    engine10.free_plane(pr)
+
+
+def test_8k_lookahead_field(engine8, oracle):
+    from oracle.bindings import MEStats
+    W, H = 7680, 4320
+    clip = make_clip(W, H, 2, seed=44)
+    pa = host_lowres_planes(oracle, 8, clip[1], 64)
+    pb = host_lowres_planes(oracle, 8, clip[0], 64)
+    wcu, hcu = pa[3], pa[4]
+    assert (wcu, hcu) == (480, 270)
+    planes = []
+    for img in (clip[1], clip[0]):
+        buf, org, stride = pad_plane(img, 64)
+        p = engine8.upload_plane(buf, W, H, 64, 64, stride)
+        planes.append(engine8.lowres_init(p))
+        engine8.free_plane(p)
+    la, lb = planes
+    for k in range(4):
+        assert np.array_equal(engine8.download_plane(lb[k]).reshape(-1), pb[0][k])
+    ctx = oracle.make_ctx(8, pa[0][0], pa[1], pa[2], pb[0], pa[1], pa[2], True, 12, 1, 1)
+    st = MEStats()
+    mv, cost = oracle.lookahead_field(ctx, wcu, hcu, 16, st)
+    mvs, costs, stats = engine8.lookahead_fields([(la[0], lb)], wcu, hcu, 12, 1, 1, 16, want_stats=True)
+    assert np.array_equal(mvs[0], mv) and np.array_equal(costs[0], cost)
+    assert int(stats["sad_calls"].sum()) == st.sad_calls and int(stats["subpel_calls"].sum()) == st.subpel_calls
