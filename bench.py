@@ -47,6 +47,8 @@ def main():
     ap.add_argument("--launch", choices=("split", "single", "per-size"), default="split",
                     help="search launches per frame: split = 16/8 PUs and 64/32 PUs on two streams (LDS per PU sized "
                          "per class); single = one launch; per-size = four launches on one stream")
+    ap.add_argument("--no-other-paths", action="store_true",
+                    help="skip the exhaustive-search (4K) and Rockchip-path (1080p) measurements reported beside the headline")
     args = ap.parse_args()
 
     import torch
@@ -220,6 +222,28 @@ def main():
             "cpu_baseline": cpu,
             "fps_equiv": B * args.steps * world / elapsed,
         }
+        if not args.no_other_paths:
+            # the two other search paths of the reference, measured the same way (HIP events, inputs resident);
+            # reported beside the headline, never part of `value`
+            try:
+                from x265_amd import measure
+                rows, _ = measure.esa_per_size(es, dev)
+                ms = sum(r["ms"] for r in rows)
+                px = sum(r["pixel_sads"] for r in rows)
+                rk = measure.rk_picture(es, dev)
+                out["other_paths"] = {
+                    "esa_4k": {"workload": "3840x2160 8-bit, --me full --merange 92 --subme 5, all 64/32/16/8 square PUs of one "
+                                           "picture against one reference (BASELINE configs[2], per reference)",
+                               "ms_per_picture_reference": ms, "value": px / ms / 1e6, "unit": "Gpixel-SAD/s",
+                               "bound": "valu", "peak": measure.SAD_ISSUE_PEAK / 1e9,
+                               "frac": px / (ms * 1e-3) / measure.SAD_ISSUE_PEAK,
+                               "per_pu_size_ms": {str(r["size"]): r["ms"] for r in rows}},
+                    "rk_1080p": {"workload": "1920x1080 8-bit, Rockchip rd>=5 path: CIME + RIME + FME of all 510 CTUs (85 CUs each) "
+                                             "against one reference, default RK range",
+                                 "ms_per_picture_reference": rk["ms"], "ctus_per_s": rk["ctus"] / (rk["ms"] * 1e-3),
+                                 "value": rk["pixel_sads"] / rk["ms"] / 1e6, "unit": "Gpixel-SAD/s"}}
+            except Exception as ex:   # the headline line must survive a failure here
+                out["other_paths"] = {"error": repr(ex)}
         print(json.dumps(out))
     if world > 1:
         dist.barrier()

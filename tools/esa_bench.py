@@ -15,8 +15,6 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
-SAD_PEAK = 150e12
-
 
 def main():
     ap = argparse.ArgumentParser()
@@ -35,61 +33,35 @@ def main():
     if args.lib:
         import x265_amd.engine as eng
         eng.LIB_PATH = os.path.abspath(args.lib)
-    from x265_amd.engine import Engine, METHODS, RESULT_DTYPE
-    from x265_amd.synth import make_clip, pad_plane
-    from x265_amd import workload
+    from x265_amd.engine import Engine, METHODS
+    from x265_amd import measure
 
-    W, H, M = args.width, args.height, 128
     dev = torch.device("cuda", 0)
     e = Engine(0, 8)
     if args.window:
         e.set_esa_window_bytes(args.window)
-    clip = make_clip(W, H, 2, seed=99)
-    cur, org, stride = pad_plane(clip[1], M)
-    ref, _, _ = pad_plane(clip[0], M)
-    pc = e.upload_plane(cur, W, H, M, M, stride)
-    pr = e.upload_plane(ref, W, H, M, M, stride)
-    rng = np.random.default_rng(5)
-    wcu, hcu = (W // 2 + 7) // 8, (H // 2 + 7) // 8
-    la = rng.integers(-12, 13, (wcu * hcu, 2)).astype(np.int16)      # stand-in lookahead field
-    stream = torch.cuda.ExternalStream(e.stream(), device=dev)
+    rows, (cur, ref, org, stride) = measure.esa_per_size(e, dev, args.width, args.height, args.merange,
+                                                         [int(v) for v in args.sizes.split(",")], args.subme, args.reps)
     total_px, total_ms = 0, 0.0
-    for s in [int(v) for v in args.sizes.split(",")]:
-        jobs = workload.square_pu_jobs(W, H, la, wcu, hcu, args.merange, sizes=(s,))
-        n = len(jobs)
-        d_jobs = torch.from_numpy(jobs.view(np.uint8).reshape(n, -1).copy()).to(dev)
-        d_res = torch.zeros((n, RESULT_DTYPE.itemsize), dtype=torch.uint8, device=dev)
-        torch.cuda.synchronize()
-
-        def launch():
-            e.search_batch_dev(pc, pr, d_jobs.data_ptr(), n, d_res.data_ptr(), 32, METHODS["full"], args.subme, max_pu_dim=s)
-        launch()
-        e.sync()
-        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        ev0.record(stream)
-        for _ in range(args.reps):
-            launch()
-        ev1.record(stream)
-        e.sync()
-        ms = ev0.elapsed_time(ev1) / args.reps
-        res = d_res.cpu().numpy().view(RESULT_DTYPE).reshape(-1)
-        px = workload.pixel_sads(jobs, res)
-        total_px += px
-        total_ms += ms
+    for r in rows:
+        total_px += r["pixel_sads"]
+        total_ms += r["ms"]
         line = "%2dx%-2d  %6d PUs  %8.3f ms  %7.2f T pixel-SAD/s  %5.1f %% of SAD issue peak" % (
-            s, s, n, ms, px / ms / 1e9, 100.0 * px / (ms * 1e-3) / SAD_PEAK)
+            r["size"], r["size"], r["pus"], r["ms"], r["pixel_sads"] / r["ms"] / 1e9,
+            100.0 * r["pixel_sads"] / (r["ms"] * 1e-3) / measure.SAD_ISSUE_PEAK)
         if args.check:
             from oracle.bindings import Oracle   # checker only
-            from tests.util import oracle_search
-            orc = Oracle()
-            pick = np.linspace(0, n - 1, args.check).astype(int)
-            mv, cost, sc, qc = oracle_search(orc, 8, cur, [ref], org, stride, jobs[pick], 32, METHODS["full"], args.subme)
+            sys.path.insert(0, os.path.join(ROOT, "tests"))
+            from util import oracle_search
+            pick = np.linspace(0, r["pus"] - 1, args.check).astype(int)
+            mv, cost, sc, qc = oracle_search(Oracle(), 8, cur, [ref], org, stride, r["jobs"][pick], 32, METHODS["full"], args.subme)
+            res = r["results"]
             ok = (np.array_equal(res["mv"][pick], mv) and np.array_equal(res["cost"][pick], cost)
                   and np.array_equal(res["sad_calls"][pick], sc))
             line += "  oracle %s" % ("OK" if ok else "MISMATCH")
         print(line, flush=True)
     print("all     %8.3f ms  %7.2f T pixel-SAD/s  %5.1f %% of SAD issue peak" % (
-        total_ms, total_px / total_ms / 1e9, 100.0 * total_px / (total_ms * 1e-3) / SAD_PEAK))
+        total_ms, total_px / total_ms / 1e9, 100.0 * total_px / (total_ms * 1e-3) / measure.SAD_ISSUE_PEAK))
 
 
 if __name__ == "__main__":

@@ -9,6 +9,7 @@ RIME 576 x CU area + FME 49 x CU area, summed over the 85 CUs of a CTU).
 import argparse
 import os
 import sys
+import time
 
 import numpy as np
 
@@ -25,62 +26,25 @@ def main():
     args = ap.parse_args()
 
     import torch
-    from x265_amd.engine import Engine, RK_CTU_DTYPE, RK_RESULT_DTYPE
-    from x265_amd.synth import make_clip, pad_plane
-    from x265_amd import workload
+    from x265_amd.engine import Engine
+    from x265_amd import measure
 
-    W, H, M = args.width, args.height, 304
-    dev = torch.device("cuda", 0)
     e = Engine(0, 8)
-    clip = make_clip(W, H, 3, seed=5)
-    cur, org, stride = pad_plane(clip[2], M)
-    rorig, _, _ = pad_plane(clip[0], M)
-    noise = np.random.default_rng(5).integers(-2, 3, clip[0].shape)
-    recon, _, _ = pad_plane(np.clip(clip[0].astype(int) + noise, 0, 255).astype(np.uint8), M)
-    pc = e.upload_plane(cur, W, H, M, M, stride)
-    po = e.upload_plane(rorig, W, H, M, M, stride)
-    pr = e.upload_plane(recon, W, H, M, M, stride)
-    pds = e.rk_ds_plane(po)
-    rng = np.random.default_rng(6)
-    nctu = ((W + 63) // 64) * ((H + 63) // 64)
-    pmvs = (rng.integers(-12, 13, (nctu, 2, 2)) * 2).astype(np.int16)
-    mvps = (rng.integers(-12, 13, (nctu, 3, 2)) * 2).astype(np.int16)
-    jobs = workload.rk_ctu_jobs(W, H, pmvs, mvps, have_mvd=True)
-    d_jobs = torch.from_numpy(jobs.view(np.uint8).reshape(nctu, -1).copy()).to(dev)
-    d_res = torch.zeros((nctu, RK_RESULT_DTYPE.itemsize), dtype=torch.uint8, device=dev)
-    stream = torch.cuda.ExternalStream(e.stream(), device=dev)
-
-    def launch():
-        e.rk_ctu_batch_dev(pc, pr, pds, 30, d_jobs.data_ptr(), nctu, d_res.data_ptr())
-    launch()
-    e.sync()
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    ev0.record(stream)
-    for _ in range(args.reps):
-        launch()
-    ev1.record(stream)
-    e.sync()
-    ms = ev0.elapsed_time(ev1) / args.reps
-    res = d_res.cpu().numpy().view(RK_RESULT_DTYPE).reshape(-1)
-    nx = (jobs["mvmax"][:, 0].astype(np.int64) // 4) - (-(-jobs["mvmin"][:, 0].astype(np.int64) // 4)) + 1
-    ny = (jobs["mvmax"][:, 1].astype(np.int64) // 4) - (-(-jobs["mvmin"][:, 1].astype(np.int64) // 4)) + 1
-    cime_px = int((nx * ny * (jobs["valid_w"].astype(np.int64) // 4) * (jobs["valid_h"].astype(np.int64) // 4)).sum())
-    valid = res["rime"]["cost"] >= 0
-    area = np.array([64] * 64 + [256] * 16 + [1024] * 4 + [4096], np.int64)
-    cu_px = int((valid * area[None, :]).sum())
-    px = cime_px + cu_px * (576 + 49)
+    m = measure.rk_picture(e, torch.device("cuda", 0), args.width, args.height, args.reps)
     line = "%dx%d  %d CTUs  %.3f ms per picture-reference  %.1f kCTU/s  %.2f T pixel-SAD/s (CIME %.2f G, RIME+FME %.2f G per picture)" % (
-        W, H, nctu, ms, nctu / ms, px / ms / 1e9, cime_px / 1e9, cu_px * 625 / 1e9)
+        args.width, args.height, m["ctus"], m["ms"], m["ctus"] / m["ms"], m["pixel_sads"] / m["ms"] / 1e9,
+        m["cime_pixel_sads"] / 1e9, m["cu_pixel_sads"] / 1e9)
     if args.check:
         from oracle.bindings import Oracle   # checker only
         orc = Oracle()
-        ds, dorg, dstride = orc.rk_downsample(8, rorig, org, W, H, stride, M // 4)
-        ctx = orc.make_ctx(8, cur, org, stride, [recon], org, stride, False, 30, 0, 0)
-        pick = np.linspace(0, nctu - 1, args.check).astype(int)
-        import time
+        cur, rorig, recon, org, stride = m["planes"]
+        ds, dorg, dstride = orc.rk_downsample(8, rorig, org, args.width, args.height, stride, m["margin"] // 4)
+        ctx = orc.make_ctx(8, cur, org, stride, [recon], org, stride, False, m["qp"], 0, 0)
+        pick = np.linspace(0, m["ctus"] - 1, args.check).astype(int)
         t0 = time.perf_counter()
-        exp = orc.rk_ctu_batch(ctx, ds, dorg, dstride, W, H, jobs[pick])
+        exp = orc.rk_ctu_batch(ctx, ds, dorg, dstride, args.width, args.height, m["jobs"][pick])
         dt = time.perf_counter() - t0
+        res = m["results"]
         ok = all(np.array_equal(res[pick][k]["mv"], exp[k]["mv"]) and np.array_equal(res[pick][k]["cost"], exp[k]["cost"])
                  for k in ("cime", "rime", "fme"))
         line += "  oracle %s (%.1f ms per CTU on one host core)" % ("OK" if ok else "MISMATCH", dt / len(pick) * 1e3)
