@@ -786,6 +786,8 @@ static int plane_alloc(x265amd_ctx *c, int width, int height, int mx, int my, in
     HIPCHK(c, hipSetDevice(c->device));
     /* + slack: window staging reads whole 16-byte chunks and may run past the last row */
     HIPCHK(c, hipMalloc(&d, plane_bytes(c, height, my, stride) + 256));
+    /* samples between width + 2*margin and stride are written by no kernel: keep them defined */
+    HIPCHK(c, hipMemsetAsync(d, 0, plane_bytes(c, height, my, stride) + 256, c->stream));
     out->origin = (char*)d + ((size_t)my * stride + mx) * bpp;
     out->stride = stride; out->width = width; out->height = height; out->margin_x = mx; out->margin_y = my;
     return X265AMD_OK;
@@ -800,7 +802,8 @@ int x265amd_plane_upload(x265amd_ctx *c, const void *buf, int width, int height,
     if (rc) return rc;
     const int bpp = c->depth > 8 ? 2 : 1;
     void *base = (char*)out->origin - ((size_t)my * stride + mx) * bpp;
-    HIPCHK(c, hipMemcpy(base, buf, plane_bytes(c, height, my, stride), hipMemcpyHostToDevice));
+    HIPCHK(c, hipMemcpyAsync(base, buf, plane_bytes(c, height, my, stride), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
     return X265AMD_OK;
 }
 
