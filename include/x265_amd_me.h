@@ -163,6 +163,60 @@ int x265amd_lookahead_fields_dev(x265amd_ctx *ctx, const void *d_fields, int nfi
                                  int width_in_cu, int height_in_cu, int qp, int method, int subme, int merange,
                                  int16_t *d_mvs, int32_t *d_costs, x265amd_result *d_stats /* or NULL */);
 
+/* ---- lookahead frame cost ---- */
+
+/* Everything EstimateRow::estimateCUCost computes for the 8x8 CUs of frame b besides the
+ * searches (encoder/slicetype.cpp:1471-1581: the two bidirectional candidates through
+ * ReferencePlanes::lowresMC, common/lowres.h:56-76; the 35-mode intra estimate; the list /
+ * intra choice) and the sums CostEstimate::estimateFrameCost forms from its rows
+ * (:1193-1204), for p0 = b - d0 (list 0) and p1 = b + d1 (list 1). d0 = d1 = 0 is the
+ * intra-only call of :1145. The searches come first: mvs* / mv_costs* are the fields
+ * x265amd_lookahead_fields_dev wrote for (b, p0) and (b, p1) -- Lowres::lowresMvs[l][d - 1]
+ * and lowresMvCosts[l][d - 1] (common/lowres.h:124-125) -- whether searched now or kept from
+ * an earlier call (bDoSearch, :1150-1151). All arrays are DEVICE memory; ncu = wcu * hcu.
+ *   intra_calculated  Lowres::bIntraCalculated: 0 = compute intra_cost and row_satds_intra
+ *                     here (8-bit pictures only: the reference gathers its intra edges with
+ *                     byte counts, :1503-1512, so its result above 8 bits is undefined),
+ *                     1 = intra_cost holds an earlier call's result
+ *   inv_qscale        Lowres::invQscaleFactor or NULL (AQ off)
+ *   intra_cost        Lowres::intraCost[ncu]
+ *   lowres_costs      Lowres::lowresCosts[d0][d1][ncu]: min(cost, 16383) | lists used << 14
+ *   row_satds_intra   Lowres::rowSatds[0][0][hcu]
+ *   row_satds         Lowres::rowSatds[d0][d1][hcu] (unused when d0 = d1 = 0)
+ *   totals[5]         sums over the rows of costEst, costEstAq, costIntra, costIntraAq,
+ *                     intraMbs; the caller applies the B-frame scaling of :1208-1209 */
+typedef struct
+{
+    x265amd_plane fenc;        /* lowresPlane[0] of frames[b] */
+    x265amd_plane ref0[4];     /* hpel planes of frames[p0]; ignored when d0 == 0 */
+    x265amd_plane ref1[4];     /* hpel planes of frames[p1]; ignored when d1 == 0 */
+    int32_t d0, d1;
+    int32_t intra_calculated;
+    int32_t reserved;
+    const int16_t *mvs0; const int32_t *mv_costs0;
+    const int16_t *mvs1; const int32_t *mv_costs1;
+    const int32_t *inv_qscale;
+    int32_t  *intra_cost;
+    uint16_t *lowres_costs;
+    int32_t  *row_satds_intra;
+    int32_t  *row_satds;
+    int64_t  *totals;
+} x265amd_frame_cost;
+
+/* validates `nframes` descriptors and copies them to the device (release with
+ * x265amd_device_free); x265amd_lookahead_frame_costs_dev then evaluates them all in one
+ * go, asynchronously on the engine's stream (after the searches queued before it) */
+int x265amd_frame_costs_upload(x265amd_ctx *ctx, const x265amd_frame_cost *frames, int nframes,
+                               int width_in_cu, int height_in_cu, void **d_frames);
+int x265amd_lookahead_frame_costs_dev(x265amd_ctx *ctx, const void *d_frames, int nframes,
+                                      int width_in_cu, int height_in_cu);
+
+/* zero-filled device memory for the arrays above (release with x265amd_device_free), and a
+ * host-to-device copy that completes before it returns; stand for the buffers the encoder's
+ * Lowres::create allocates (common/lowres.cpp:59-96) */
+int x265amd_device_alloc(x265amd_ctx *ctx, size_t bytes, void **d_ptr);
+int x265amd_upload(x265amd_ctx *ctx, void *d_dst, const void *src, size_t bytes);
+
 /* ---- Rockchip path (rd >= 5): CIME + RIME + FME ---- */
 
 /* One 64x64 CTU against one reference picture: everything the 15-argument

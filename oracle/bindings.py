@@ -186,6 +186,24 @@ class Oracle:
                                    C.cast(C.pointer(stats), C.c_void_p) if stats is not None else None)
         return mvs, costs
 
+    def lookahead_frame_cost(self, depth, fenc, ref0, ref1, origin, stride, wcu, hcu, d0, d1, mvs0=None, mvcosts0=None,
+                             mvs1=None, mvcosts1=None, intra_cost=None, inv_qscale=None):
+        """Post-search part of estimateCUCost + the sums of estimateFrameCost. fenc: lowres full-pel plane of frame b;
+        ref0 / ref1: the four hpel planes of frames p0 / p1 (None when the list is unused). intra_cost=None computes
+        it (bIntraCalculated false). Returns a dict of the reference's output arrays."""
+        ncu = wcu * hcu
+        planes = lambda r: (C.c_void_p * 4)(*[p.ctypes.data + origin * p.itemsize for p in r]) if r is not None else None
+        calc = intra_cost is None
+        out = dict(intra_cost=np.zeros(ncu, np.int32) if calc else np.ascontiguousarray(intra_cost, np.int32).copy(),
+                   lowres_costs=np.zeros(ncu, np.uint16), row_satds_intra=np.zeros(hcu, np.int32),
+                   row_satds=np.zeros(hcu, np.int32), totals=np.zeros(5, np.int64))
+        opt = lambda a, dt: _p(np.ascontiguousarray(a, dt)) if a is not None else None
+        keep = [opt(inv_qscale, np.int32), opt(mvs0, np.int16), opt(mvcosts0, np.int32), opt(mvs1, np.int16), opt(mvcosts1, np.int32)]
+        self.L.orc_lookahead_frame_cost(depth, _p(fenc, origin), planes(ref0), planes(ref1), C.c_ssize_t(stride), wcu, hcu, d0, d1,
+                                        int(not calc), keep[0], keep[1], keep[2], keep[3], keep[4], _p(out["intra_cost"]),
+                                        _p(out["lowres_costs"]), _p(out["row_satds_intra"]), _p(out["row_satds"]), _p(out["totals"]))
+        return out
+
 
 def ref_available(depth=8):
     return os.path.exists(os.path.join(HERE, "_ref", "libx265ref%d.so" % (8 if depth <= 8 else 10)))
@@ -359,3 +377,24 @@ class Ref:
         costs = np.zeros(hcu * wcu, np.int32)
         self.L.ref_lookahead_field(_p(fenc, origin), planes, stride, wcu, hcu, qp, method, subme, merange, _p(mvs), _p(costs))
         return mvs, costs
+
+    def estimate_frame(self, fenc4, ref0, ref1, origin, stride, wcu, hcu, d0, d1, intra_cost=None, inv_qscale=None,
+                       mvs0=None, mvcosts0=None, mvs1=None, mvcosts1=None):
+        """The reference's own EstimateRow::estimateCUCost over a whole frame (serial processRow order) and the row sums
+        of estimateFrameCost. A list whose mvs are given is not searched again (bDoSearch false)."""
+        ncu = wcu * hcu
+        planes = lambda r: (C.c_void_p * 4)(*[p.ctypes.data + origin * p.itemsize for p in r]) if r is not None else None
+        calc = intra_cost is None
+        own = lambda a, dt, shape: np.zeros(shape, dt) if a is None else np.ascontiguousarray(a, dt).copy()
+        out = dict(mvs0=own(mvs0, np.int16, (ncu, 2)), mvcosts0=own(mvcosts0, np.int32, ncu),
+                   mvs1=own(mvs1, np.int16, (ncu, 2)), mvcosts1=own(mvcosts1, np.int32, ncu),
+                   intra_cost=own(intra_cost, np.int32, ncu), lowres_costs=np.zeros(ncu, np.uint16),
+                   row_satds_intra=np.zeros(hcu, np.int32), row_satds=np.zeros(hcu, np.int32), totals=np.zeros(5, np.int64))
+        q = np.ascontiguousarray(inv_qscale, np.int32) if inv_qscale is not None else None
+        self.L.ref_estimate_frame(planes(fenc4), planes(ref0), planes(ref1), stride, wcu, hcu, d0, d1,
+                                  int(d0 > 0 and mvs0 is None), int(d1 > 0 and mvs1 is None), int(not calc),
+                                  _p(q) if q is not None else None,
+                                  _p(out["mvs0"]), _p(out["mvcosts0"]), _p(out["mvs1"]), _p(out["mvcosts1"]),
+                                  _p(out["intra_cost"]), _p(out["lowres_costs"]), _p(out["row_satds_intra"]),
+                                  _p(out["row_satds"]), _p(out["totals"]))
+        return out

@@ -264,3 +264,18 @@ void orc_lookahead_field(const orc_me_ctx *c, int widthInCU, int heightInCU, int
         }
     }
 }
+
+
+void orc_lookahead_frame_cost(int depth, const void *fenc, const void *const ref0[4], const void *const ref1[4],
+                              intptr_t stride, int widthInCU, int heightInCU, int d0, int d1, int intra_calculated,
+                              const int32_t *inv_qscale, const orc_mv *mvs0, const int32_t *mvcosts0,
+                              const orc_mv *mvs1, const int32_t *mvcosts1, int32_t *intra_cost, uint16_t *lowres_costs,
+                              int32_t *row_satds_intra, int32_t *row_satds, int64_t totals[5])
+{
+    if (depth <= 8)
+        la_frame_cost_8(depth, fenc, ref0, ref1, stride, widthInCU, heightInCU, d0, d1, intra_calculated, inv_qscale,
+                        mvs0, mvcosts0, mvs1, mvcosts1, intra_cost, lowres_costs, row_satds_intra, row_satds, totals);
+    else
+        la_frame_cost_16(depth, fenc, ref0, ref1, stride, widthInCU, heightInCU, d0, d1, intra_calculated, inv_qscale,
+                         mvs0, mvcosts0, mvs1, mvcosts1, intra_cost, lowres_costs, row_satds_intra, row_satds, totals);
+}

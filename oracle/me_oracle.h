@@ -123,6 +123,22 @@ int orc_subpel_compare(const orc_me_ctx *c, intptr_t pu_offset, int w, int h, or
 void orc_lookahead_field(const orc_me_ctx *c, int widthInCU, int heightInCU, int merange,
                          orc_mv *mvs, int32_t *costs, orc_me_stats *stats);
 
+/* ---- lookahead frame cost: everything EstimateRow::estimateCUCost computes besides the
+ * searches (source/encoder/slicetype.cpp:1471-1581) plus the sums of estimateFrameCost
+ * (:1193-1204), for frame b against p0 = b - d0 (list 0) and p1 = b + d1 (list 1).
+ * Inputs: the MV fields and costs of the lists in use (orc_lookahead_field) and, when
+ * intra_calculated, intra_cost. Outputs: intra_cost (35-mode intra SATD per CU, only
+ * written when !intra_calculated; 8-bit only -- the reference copies its intra edges with
+ * byte counts, slicetype.cpp:1503,1511, so its >8-bit result is undefined), lowres_costs
+ * (Lowres::lowresCosts), row_satds_intra / row_satds (Lowres::rowSatds[0][0] and [d0][d1]),
+ * totals = { sum costEst, sum costEstAq, sum costIntra, sum costIntraAq, intraMbs }.
+ * inv_qscale (Lowres::invQscaleFactor) may be NULL. */
+void orc_lookahead_frame_cost(int depth, const void *fenc, const void *const ref0[4], const void *const ref1[4],
+                              intptr_t stride, int widthInCU, int heightInCU, int d0, int d1, int intra_calculated,
+                              const int32_t *inv_qscale, const orc_mv *mvs0, const int32_t *mvcosts0,
+                              const orc_mv *mvs1, const int32_t *mvcosts1, int32_t *intra_cost, uint16_t *lowres_costs,
+                              int32_t *row_satds_intra, int32_t *row_satds, int64_t totals[5]);
+
 #ifdef __cplusplus
 }
 #endif

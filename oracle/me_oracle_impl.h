@@ -1034,3 +1034,182 @@ static void FN(rk_ctu)(const orc_me_ctx *c, const int16_t *ds, intptr_t ds_strid
 #undef IN_RANGE
 #undef TRY_MV
 #undef TRY_MV_AT
+
+
+/* ---------------- lookahead frame cost: slicetype.cpp:1401-1582 besides the search ---------------- */
+
+/* The reference prediction edges of one 8x8 lowres CU (slicetype.cpp:1495-1524):
+ * e[0] = the 9 samples above / left of the block starting at the corner, the last one
+ * repeated up to index 16; e[1] = the same smoothed with [1 2 1], ends unfiltered. */
+static void FN(la_edges)(const PIXEL *cur, intptr_t stride, int above[2][17], int left[2][17])
+{
+    for (int i = 0; i <= 8; i++)
+    {
+        above[0][i] = cur[-1 - stride + i];
+        left[0][i] = cur[-1 - stride + i * stride];
+    }
+    for (int i = 9; i <= 16; i++) { above[0][i] = above[0][8]; left[0][i] = left[0][8]; }
+    above[1][0] = above[0][0]; above[1][16] = above[0][16];
+    left[1][0] = left[0][0]; left[1][16] = left[0][16];
+    for (int i = 1; i < 16; i++)
+    {
+        above[1][i] = (above[0][i - 1] + 2 * above[0][i] + above[0][i + 1] + 2) >> 2;
+        left[1][i] = (left[0][i - 1] + 2 * left[0][i] + left[0][i + 1] + 2) >> 2;
+    }
+}
+
+/* Sample (row k, column l) of entry `mode` of the reference's prediction buffer
+ * (slicetype.cpp:1529-1533): 0 = DC with edge smoothing (intrapred.cpp:45-104), 1 = planar
+ * from the smoothed edges (:106-154), 2..34 = angular (:156-259) in the orientation
+ * all_angs_pred_c leaves them in (:262-289): modes below 18 stay transposed. */
+static int FN(la_pred)(int mode, int k, int l, int above[2][17], int left[2][17], int depth)
+{
+    static const int angTable[9] = { 0, 2, 5, 9, 13, 17, 21, 26, 32 };
+    static const int invAngTable[9] = { 0, 4096, 1638, 910, 630, 482, 390, 315, 256 };
+    const int maxv = (1 << depth) - 1;
+    if (mode == 0)
+    {
+        int sum = 8;
+        for (int i = 1; i <= 8; i++) sum += above[0][i] + left[0][i];
+        const int dc = sum / 16;
+        if (k == 0 && l == 0) return (above[0][1] + left[0][1] + 2 * dc + 2) >> 2;
+        if (k == 0) return (above[0][l + 1] + 3 * dc + 2) >> 2;
+        if (l == 0) return (left[0][k + 1] + 3 * dc + 2) >> 2;
+        return dc;
+    }
+    if (mode == 1)
+    {
+        const int *a = above[1] + 1, *lf = left[1] + 1;
+        return ((lf[k] << 3) + 8 + (l + 1) * (int16_t)(a[8] - lf[k]) + (a[l] << 3) + (k + 1) * (int16_t)(lf[8] - a[l])) >> 4;
+    }
+    const int f = (mode == 2 || mode == 18 || mode == 34);   /* IntraFilterType, 8x8 row (intrapred.cpp:31-40) */
+    const int ver = mode >= 18;
+    const int *refMain = ver ? above[f] : left[f], *refSide = ver ? left[f] : above[f];
+    int ang = ver ? mode - 26 : -(mode - 10);
+    const int absIdx = abs(ang);
+    const int invAngle = invAngTable[absIdx];
+    ang = ang < 0 ? -angTable[absIdx] : angTable[absIdx];
+    if (ang == 0)
+    {
+        int v = refMain[l + 1];
+        if (l == 0) /* edge filter, bFilter = (cuSize <= 16) */
+        {
+            int16_t t = (int16_t)(v + ((refSide[k + 1] - refSide[0]) >> 1));
+            v = t < 0 ? 0 : (t > maxv ? maxv : t);
+        }
+        return v;
+    }
+    const int deltaPos = (k + 1) * ang, deltaInt = deltaPos >> 5, fract = deltaPos & 31;
+    /* negative indices of the main edge are projections of the side edge (:181-195) */
+#define MAINREF(i) ((i) >= 0 ? refMain[i] : refSide[(128 + -(i) * invAngle) >> 8])
+    const int i0 = l + deltaInt + 1;
+    if (!fract) return MAINREF(i0);
+    return ((32 - fract) * MAINREF(i0) + fract * MAINREF(i0 + 1) + 16) >> 5;
+#undef MAINREF
+}
+
+/* slicetype.cpp:1491-1551: least SATD over the 35 predictions of an 8x8 block */
+static int FN(la_intra_cost)(const PIXEL *cur, intptr_t stride, int depth)
+{
+    int above[2][17], left[2][17];
+    PIXEL src[64], srct[64], pred[64];
+    FN(la_edges)(cur, stride, above, left);
+    for (int y = 0; y < 8; y++)
+        for (int x = 0; x < 8; x++) { src[y * 8 + x] = cur[y * stride + x]; srct[x * 8 + y] = cur[y * stride + x]; }
+    int icost = 1 << 28;
+    for (int mode = 0; mode < 35; mode++)
+    {
+        for (int k = 0; k < 8; k++)
+            for (int l = 0; l < 8; l++) pred[k * 8 + l] = (PIXEL)FN(la_pred)(mode, k, l, above, left, depth);
+        const int cost = FN(satd)((mode >= 2 && mode < 18) ? srct : src, 8, pred, 8, 8, 8);
+        if (cost < icost) icost = cost;
+    }
+    return icost;
+}
+
+/* lowres.h:56-76 into an 8x8 buffer (always copied: the caller only averages it) */
+static void FN(la_mc)(const void *const planes[4], intptr_t off, intptr_t stride, int qx, int qy, PIXEL *buf)
+{
+    const int hpelA = (qy & 2) | ((qx & 2) >> 1);
+    const PIXEL *a = (const PIXEL*)planes[hpelA] + off + (qx >> 2) + (qy >> 2) * stride;
+    if ((qx | qy) & 1)
+    {
+        const int16_t bx = (int16_t)(qx + (qx & 1) * 2), by = (int16_t)(qy + (qy & 1) * 2);
+        const int hpelB = (by & 2) | ((bx & 2) >> 1);
+        const PIXEL *b = (const PIXEL*)planes[hpelB] + off + (bx >> 2) + (by >> 2) * stride;
+        FN(pixelavg)(buf, 8, a, stride, b, stride, 8, 8);
+    }
+    else
+        for (int y = 0; y < 8; y++)
+            for (int x = 0; x < 8; x++) buf[y * 8 + x] = a[y * stride + x];
+}
+
+static void FN(la_frame_cost)(int depth, const void *fenc0, const void *const ref0[4], const void *const ref1[4],
+                              intptr_t stride, int wcu, int hcu, int d0, int d1, int intra_calculated,
+                              const int32_t *inv_qscale, const orc_mv *mvs0, const int32_t *mvcosts0,
+                              const orc_mv *mvs1, const int32_t *mvcosts1, int32_t *intra_cost, uint16_t *lowres_costs,
+                              int32_t *row_satds_intra, int32_t *row_satds, int64_t totals[5])
+{
+    const PIXEL *fenc = (const PIXEL*)fenc0;
+    const int bidir = d1 > 0, inter = (d0 + d1) > 0;
+    uint64_t costEst = 0, costEstAq = 0, costIntraAq = 0;
+    int costIntra = 0, intraMbs = 0;
+    for (int cuy = hcu - 1; cuy >= 0; cuy--)
+    {
+        if (!intra_calculated) row_satds_intra[cuy] = 0;
+        if (inter) row_satds[cuy] = 0;
+        for (int cux = wcu - 1; cux >= 0; cux--)
+        {
+            const int cuXY = cux + cuy * wcu;
+            const intptr_t off = 8 * cux + 8 * cuy * stride;
+            const int scored = (cux > 0 && cux < wcu - 1 && cuy > 0 && cuy < hcu - 1) || wcu <= 2 || hcu <= 2;
+            int bcost = 1 << 28, listused = 0;   /* MotionEstimate::COST_MAX, motion.h:64 */
+            if (inter)
+            {
+                if (mvcosts0[cuXY] < bcost) { bcost = mvcosts0[cuXY]; listused = 1; }
+                if (bidir)
+                {
+                    if (mvcosts1[cuXY] < bcost) { bcost = mvcosts1[cuXY]; listused = 2; }
+                    PIXEL b0[64], b1[64], avg[64];
+                    FN(la_mc)(ref0, off, stride, mvs0[cuXY].x, mvs0[cuXY].y, b0);
+                    FN(la_mc)(ref1, off, stride, mvs1[cuXY].x, mvs1[cuXY].y, b1);
+                    FN(pixelavg)(avg, 8, b0, 8, b1, 8, 8, 8);
+                    int bicost = FN(satd)(fenc + off, stride, avg, 8, 8, 8);
+                    if (bicost < bcost) { bcost = bicost; listused = 3; }
+                    FN(pixelavg)(avg, 8, (const PIXEL*)ref0[0] + off, stride, (const PIXEL*)ref1[0] + off, stride, 8, 8);
+                    bicost = FN(satd)(fenc + off, stride, avg, 8, 8, 8);
+                    if (bicost < bcost) { bcost = bicost; listused = 3; }
+                }
+            }
+            if (!intra_calculated)
+            {
+                const int icost = FN(la_intra_cost)(fenc + off, stride, depth);
+                intra_cost[cuXY] = icost;
+                row_satds_intra[cuy] += icost;
+                if (scored)
+                {
+                    costIntra += icost;
+                    if (inv_qscale) costIntraAq += (icost * inv_qscale[cuXY] + 128) >> 8;
+                }
+            }
+            if (!bidir && intra_cost[cuXY] < bcost)
+            {
+                if (scored) intraMbs++;
+                bcost = intra_cost[cuXY];
+                listused = 0;
+            }
+            if (inter)
+            {
+                row_satds[cuy] += bcost;
+                if (scored)
+                {
+                    costEst += bcost;
+                    if (inv_qscale) costEstAq += (bcost * inv_qscale[cuXY] + 128) >> 8;
+                }
+            }
+            lowres_costs[cuXY] = (uint16_t)((bcost < 16383 ? bcost : 16383) | (listused << 14));
+        }
+    }
+    totals[0] = (int64_t)costEst; totals[1] = (int64_t)costEstAq; totals[2] = costIntra;
+    totals[3] = (int64_t)costIntraAq; totals[4] = intraMbs;
+}

@@ -14,6 +14,7 @@
  *   MotionEstimate API          source/encoder/motion.h:66-108
  *   lookahead CU driver         source/encoder/slicetype.cpp:1401-1470
  *   lowres plane generation     source/common/lowres.cpp:155-166
+ *   lookahead frame cost        source/encoder/slicetype.cpp:1132-1221, :1342-1387, :1401-1582
  */
 #include "TLibCommon/TComRom.h"
 #include "primitives.h"
@@ -24,6 +25,8 @@
 #include "mv.h"
 #include "reference.h"
 #include "hardwareC/inter.h"
+#include "TLibCommon/TComSlice.h"
+#include "slicetype.h"
 
 #include <string.h>
 #include <stdlib.h>
@@ -32,6 +35,7 @@
 namespace x265 {
 void Setup_C_PixelPrimitives(EncoderPrimitives &p);
 void Setup_C_IPFilterPrimitives(EncoderPrimitives &p);
+void Setup_C_IPredPrimitives(EncoderPrimitives &p);
 }
 
 using namespace x265;
@@ -65,6 +69,8 @@ void ref_setup(int bitDepth)
     if (g_ready) return;
     Setup_C_PixelPrimitives(primitives);
     Setup_C_IPFilterPrimitives(primitives);
+    Setup_C_IPredPrimitives(primitives);
+    initROM();                  /* g_convertToBit, read by estimateCUCost and the planar predictor */
     primitives.sa8d_inter[LUMA_4x4]   = primitives.satd[LUMA_4x4];
     primitives.sa8d_inter[LUMA_4x8]   = primitives.satd[LUMA_4x8];
     primitives.sa8d_inter[LUMA_4x16]  = primitives.satd[LUMA_4x16];
@@ -394,5 +400,78 @@ int ref_cmodel_cime(const unsigned char*, int, const unsigned char*, int, int, i
     return -1;
 }
 #endif
+
+/* ---- lookahead: cost of one frame b against (p0, p1): the reference's own
+ * EstimateRow::estimateCUCost (slicetype.cpp:1401-1582) called for every CU in the
+ * serial order of CostEstimate::processRow (:1344, :1356: rows bottom->top, CUs
+ * right->left), then the row sums added up as estimateFrameCost does (:1193-1204).
+ * Lowres objects are filled by hand with the planes and output arrays
+ * (lowres.h:101-140). d0 = b - p0, d1 = p1 - b. Arrays not used by the call may be
+ * NULL. out64: [0] sum of rows' costEst (the score before the b != p1 scaling of
+ * :1208-1209), [1] costEstAq, [2] costIntra, [3] costIntraAq, [4] intraMbs. ---- */
+void ref_estimate_frame(pixel **fencPlanes, pixel **ref0Planes, pixel **ref1Planes, int stride,
+                        int widthInCU, int heightInCU, int d0, int d1,
+                        int doSearch0, int doSearch1, int intraCalculated, int32_t *invQscale,
+                        int16_t *mvs0, int32_t *mvCosts0, int16_t *mvs1, int32_t *mvCosts1,
+                        int32_t *intraCost, uint16_t *lowresCosts, int32_t *rowSatdsIntra, int32_t *rowSatds,
+                        int64_t *out64)
+{
+    const int p0 = 0, b = d0, p1 = d0 + d1;
+    Lowres *frames[2 * X265_BFRAME_MAX + 4];
+    memset(frames, 0, sizeof(frames));
+    Lowres *lf[3] = { new Lowres, new Lowres, new Lowres };
+    pixel **pl[3] = { fencPlanes, ref0Planes, ref1Planes };
+    for (int k = 0; k < 3; k++)
+    {
+        if (!pl[k]) continue;
+        for (int i = 0; i < 4; i++) lf[k]->lowresPlane[i] = pl[k][i];
+        lf[k]->fpelPlane = pl[k][0];
+        lf[k]->lumaStride = stride;
+        lf[k]->isLowres = true;
+        lf[k]->width = widthInCU * 8;
+        lf[k]->lines = heightInCU * 8;
+    }
+    frames[b] = lf[0];
+    if (d0) frames[p0] = lf[1];
+    if (d1) frames[p1] = lf[2];
+    Lowres *fenc = frames[b];
+    fenc->bIntraCalculated = !!intraCalculated;
+    fenc->intraCost = intraCost;
+    fenc->invQscaleFactor = invQscale;
+    fenc->rowSatds[0][0] = rowSatdsIntra;
+    fenc->rowSatds[d0][d1] = (d0 || d1) ? rowSatds : rowSatdsIntra;
+    fenc->lowresCosts[d0][d1] = lowresCosts;
+    if (d0) { fenc->lowresMvs[0][d0 - 1] = (MV*)mvs0; fenc->lowresMvCosts[0][d0 - 1] = mvCosts0; }
+    if (d1) { fenc->lowresMvs[1][d1 - 1] = (MV*)mvs1; fenc->lowresMvCosts[1][d1 - 1] = mvCosts1; }
+    bool bDoSearch[2] = { !!doSearch0, !!doSearch1 };
+
+    EstimateRow *rows = new EstimateRow[heightInCU];
+    for (int i = 0; i < heightInCU; i++)
+    {
+        rows[i].widthInCU = widthInCU;
+        rows[i].heightInCU = heightInCU;
+        rows[i].init();
+        rows[i].me.setSourcePlane(fenc->lowresPlane[0], fenc->lumaStride);
+    }
+    for (int row = 0; row < heightInCU; row++)
+    {
+        const int realrow = heightInCU - 1 - row;
+        if (!fenc->bIntraCalculated) fenc->rowSatds[0][0][realrow] = 0;
+        fenc->rowSatds[d0][d1][realrow] = 0;
+        for (int i = widthInCU - 1; i >= 0; i--)
+            rows[row].estimateCUCost(frames, frames[p0], i, realrow, p0, p1, b, bDoSearch);
+    }
+    memset(out64, 0, 5 * sizeof(int64_t));
+    for (int row = 0; row < heightInCU; row++)
+    {
+        out64[0] += rows[row].costEst;
+        out64[1] += rows[row].costEstAq;
+        out64[2] += rows[row].costIntra;
+        out64[3] += rows[row].costIntraAq;
+        out64[4] += rows[row].intraMbs;
+    }
+    delete[] rows;
+    for (int k = 0; k < 3; k++) delete lf[k];
+}
 
 } // extern "C"

@@ -158,8 +158,53 @@ def main():
         rk[k + "_cost"] = np.stack([r[k]["cost"] for r in recs])
     np.savez_compressed(os.path.join(HERE, "rk_golden.npz"), **rk)
     make_cmodel(shas)
+    make_frame_cost(shas)
     json.dump(shas, open(os.path.join(HERE, "input_sha.json"), "w"), indent=0, sort_keys=True)
     print("golden vectors written to", HERE)
+
+
+class ref_as_orc:
+    """Gives host_lowres_planes the reference's own downscaler behind the oracle's call shape."""
+
+    def __init__(self, ref):
+        self.ref = ref
+
+    def lowres_core(self, depth, src, so, ss, w, h):
+        return self.ref.lowres_core(src, so, ss, w, h)
+
+
+FC_KEYS = ("mvs0", "mvcosts0", "mvs1", "mvcosts1", "intra_cost", "lowres_costs", "row_satds_intra", "row_satds", "totals")
+
+
+def frame_cost_cases():
+    """(name, clip kind, seed, b, d0, d1, with AQ factors) of the lookahead frame-cost vectors (416x240, 8-bit)."""
+    out = []
+    for kind, seed in (("texture", 3), ("noise", 11)):
+        for (b, d0, d1) in ((2, 0, 0), (2, 2, 0), (2, 1, 2), (1, 1, 3)):
+            for aq in (0, 1):
+                out.append(("%s_%d_%d_%d_%d" % (kind, b, d0, d1, aq), kind, seed, b, d0, d1, aq))
+    return out
+
+
+def frame_cost_inv_qscale(ncu):
+    return np.random.default_rng(77).integers(96, 520, ncu).astype(np.int32)
+
+
+def make_frame_cost(shas):
+    """The reference's own EstimateRow::estimateCUCost run over whole frames (slicetype.cpp:1401-1582, in the
+    serial order of processRow) and the row sums of estimateFrameCost (:1193-1204)."""
+    ref = Ref(8)
+    out = {}
+    for name, kind, seed, b, d0, d1, aq in frame_cost_cases():
+        clip = make_clip(LA_W, LA_H, 5, seed=seed, depth=8, kind=kind)
+        shas["fc_%s" % kind] = [sha(f) for f in clip]
+        P = [host_lowres_planes(ref_as_orc(ref), 8, f, 64) for f in clip]
+        org, stride, wcu, hcu = P[0][1], P[0][2], P[0][3], P[0][4]
+        r = ref.estimate_frame(P[b][0], P[b - d0][0] if d0 else None, P[b + d1][0] if d1 else None, org, stride, wcu, hcu,
+                               d0, d1, inv_qscale=frame_cost_inv_qscale(wcu * hcu) if aq else None)
+        for k in FC_KEYS:
+            out[name + "_" + k] = r[k]
+    np.savez_compressed(os.path.join(HERE, "framecost_golden.npz"), **out)
 
 
 def make_cmodel(shas):
@@ -188,11 +233,11 @@ def make_cmodel(shas):
 
 
 if __name__ == "__main__":
-    if sys.argv[1:] == ["cmodel"]:
-        # only (re)generate the C-model records, keeping the other files as they are
+    if sys.argv[1:] in (["cmodel"], ["framecost"]):
+        # only (re)generate the C-model / frame-cost records, keeping the other files as they are
         shas_path = os.path.join(HERE, "input_sha.json")
         shas_ = json.load(open(shas_path))
-        make_cmodel(shas_)
+        (make_cmodel if sys.argv[1] == "cmodel" else make_frame_cost)(shas_)
         json.dump(shas_, open(shas_path, "w"), indent=0, sort_keys=True)
     else:
         main()

@@ -82,3 +82,75 @@ def test_lowres_search_batch_vs_oracle(engine8, oracle):
         mv, cost, sc, qc = oracle_search(oracle, 8, pa[0][0], pb[0], pa[1], pa[2], jobs, 12, method, subme, is_lowres=True)
         assert np.array_equal(r["mv"], mv) and np.array_equal(r["cost"], cost)
         assert np.array_equal(r["sad_calls"], sc) and np.array_equal(r["subpel_calls"], qc)
+
+
+def test_frame_cost_golden(engine8):
+    """estimateFrameCost on the device (searches + intra + bidirectional candidates + choice + sums) against the
+    records of the reference's own estimateCUCost, all cases in one batch."""
+    g = G.frame_cost_golden()
+    cache, frames, names = {}, [], []
+    for name, kind, seed, b, d0, d1, aq in G.frame_cost_cases():
+        if kind not in cache:
+            clip = make_clip(G.LA_W, G.LA_H, 5, seed=seed, depth=8, kind=kind)
+            cache[kind] = [_device_lowres(engine8, f) for f in clip]
+        L = cache[kind]
+        frames.append(dict(fenc=L[b], ref0=L[b - d0] if d0 else None, ref1=L[b + d1] if d1 else None, d0=d0, d1=d1,
+                           inv_qscale=G.frame_cost_inv_qscale(26 * 15) if aq else None))
+        names.append((name, d0, d1))
+    res = engine8.estimate_frame_costs(frames, 26, 15, 12)
+    for (name, d0, d1), r in zip(names, res):
+        keys = ["intra_cost", "lowres_costs", "row_satds_intra", "totals"]
+        if d0:
+            keys += ["row_satds", "mvs0", "mvcosts0"]
+        if d1:
+            keys += ["mvs1", "mvcosts1"]
+        for k in keys:
+            assert np.array_equal(r[k.replace("mvcosts", "mv_costs")], g[name + "_" + k]), (name, k)
+
+
+def test_frame_cost_shapes_vs_oracle(engine8, oracle):
+    """Ragged and tiny CU grids, first call and repeat call (intra costs and MV fields handed back in)."""
+    for (w, h, kind) in ((16, 16, "texture"), (16, 144, "noise"), (144, 16, "texture"), (88, 56, "noise"), (300, 200, "texture")):
+        clip = make_clip(w, h, 4, seed=w + h, depth=8, kind=kind)
+        P = [host_lowres_planes(oracle, 8, f, 64) for f in clip]
+        L = [_device_lowres(engine8, f) for f in clip]
+        org, stride, wcu, hcu = P[0][1], P[0][2], P[0][3], P[0][4]
+        q = np.random.default_rng(w).integers(64, 700, wcu * hcu).astype(np.int32)
+        triples = ((1, 0, 0), (2, 2, 0), (1, 1, 2))
+        first = engine8.estimate_frame_costs([dict(fenc=L[b], ref0=L[b - d0] if d0 else None, ref1=L[b + d1] if d1 else None,
+                                                   d0=d0, d1=d1, inv_qscale=q) for b, d0, d1 in triples], wcu, hcu, 12)
+        again = engine8.estimate_frame_costs([dict(fenc=L[b], ref0=L[b - d0] if d0 else None, ref1=L[b + d1] if d1 else None,
+                                                   d0=d0, d1=d1, inv_qscale=q, intra_cost=r["intra_cost"],
+                                                   mvs0=r["mvs0"] if d0 else None, mv_costs0=r["mv_costs0"],
+                                                   mvs1=r["mvs1"] if d1 else None, mv_costs1=r["mv_costs1"])
+                                              for (b, d0, d1), r in zip(triples, first)], wcu, hcu, 12)
+        for (b, d0, d1), r, r2 in zip(triples, first, again):
+            exp = oracle.lookahead_frame_cost(8, P[b][0][0], P[b - d0][0] if d0 else None, P[b + d1][0] if d1 else None,
+                                              org, stride, wcu, hcu, d0, d1, r["mvs0"], r["mv_costs0"], r["mvs1"], r["mv_costs1"],
+                                              None, q)
+            for k in ("intra_cost", "lowres_costs", "row_satds_intra", "totals") + (("row_satds",) if d0 else ()):
+                assert np.array_equal(r[k], exp[k]), (w, h, b, d0, d1, k)
+            for k in ("lowres_costs", "totals") + (("row_satds",) if d0 else ()):
+                got, want = r2[k], exp[k].copy()
+                if k == "totals":
+                    want[2] = want[3] = 0     # the intra sums belong to the call that computed the intra costs
+                assert np.array_equal(got, want), (w, h, b, d0, d1, k, "repeat")
+
+
+def test_frame_cost_bidir_10bit(engine10, oracle):
+    """>8-bit pictures: the bidirectional / choice part with intra costs supplied by the caller."""
+    w, h = 200, 120
+    clip = make_clip(w, h, 4, seed=9, depth=10)
+    P = [host_lowres_planes(oracle, 10, f, 64) for f in clip]
+    L = [_device_lowres(engine10, f) for f in clip]
+    org, stride, wcu, hcu = P[0][1], P[0][2], P[0][3], P[0][4]
+    ic = np.random.default_rng(2).integers(200, 3000, wcu * hcu).astype(np.int32)
+    for (b, d0, d1) in ((2, 2, 0), (1, 1, 2)):
+        r = engine10.estimate_frame_costs([dict(fenc=L[b], ref0=L[b - d0], ref1=L[b + d1] if d1 else None, d0=d0, d1=d1,
+                                                intra_cost=ic)], wcu, hcu, 24)[0]
+        exp = oracle.lookahead_frame_cost(10, P[b][0][0], P[b - d0][0], P[b + d1][0] if d1 else None, org, stride, wcu, hcu,
+                                          d0, d1, r["mvs0"], r["mv_costs0"], r["mvs1"], r["mv_costs1"], ic, None)
+        for k in ("lowres_costs", "row_satds", "totals"):
+            assert np.array_equal(r[k], exp[k]), (b, d0, d1, k)
+    with pytest.raises(Exception):
+        engine10.estimate_frame_costs([dict(fenc=L[1], ref0=None, ref1=None, d0=0, d1=0)], wcu, hcu, 24)

@@ -99,3 +99,31 @@ def test_rk_matches_cmodel_records(oracle):
     got = oracle.rk_ctu_batch(ctx, ds, dorg, dstride, W, H, jobs)
     for k in ("cime", "rime", "fme"):
         assert np.array_equal(got[k]["mv"], g[k + "_mv"]) and np.array_equal(got[k]["cost"], g[k + "_cost"]), k
+
+
+def test_lookahead_frame_cost(oracle):
+    """Intra estimate, bidirectional candidates, list choice and the row / frame sums against the records of the
+    reference's own estimateCUCost; the MV fields the oracle searches itself must equal the reference's too."""
+    g = G.frame_cost_golden()
+    shas = G.input_shas()
+    cache = {}
+    for name, kind, seed, b, d0, d1, aq in G.frame_cost_cases():
+        if kind not in cache:
+            clip = make_clip(G.LA_W, G.LA_H, 5, seed=seed, depth=8, kind=kind)
+            assert [G.sha(f) for f in clip] == shas["fc_%s" % kind], "synthetic clip generator drifted"
+            cache[kind] = [host_lowres_planes(oracle, 8, f, 64) for f in clip]
+        P = cache[kind]
+        org, stride, wcu, hcu = P[0][1], P[0][2], P[0][3], P[0][4]
+        f, r0, r1 = P[b][0], (P[b - d0][0] if d0 else None), (P[b + d1][0] if d1 else None)
+        fields = {}
+        for l, (d, r) in enumerate(((d0, r0), (d1, r1))):
+            if d:
+                ctx = oracle.make_ctx(8, f[0], org, stride, r, org, stride, True, 12, 1, 1)
+                mv, cost = oracle.lookahead_field(ctx, wcu, hcu, 16)
+                assert np.array_equal(mv, g["%s_mvs%d" % (name, l)]) and np.array_equal(cost, g["%s_mvcosts%d" % (name, l)])
+                fields[l] = (mv, cost)
+        out = oracle.lookahead_frame_cost(8, f[0], r0, r1, org, stride, wcu, hcu, d0, d1,
+                                          *(fields.get(0, (None, None)) + fields.get(1, (None, None))),
+                                          inv_qscale=G.frame_cost_inv_qscale(wcu * hcu) if aq else None)
+        for k in ("intra_cost", "lowres_costs", "row_satds_intra", "totals") + (("row_satds",) if d0 else ()):
+            assert np.array_equal(out[k], g[name + "_" + k]), (name, k)

@@ -181,3 +181,32 @@ def test_cmodel_rime_fme_twin(oracle):
             assert (int(got["cime"]["mv"][0]), int(got["cime"]["mv"][1]), int(got["cime"]["cost"])) == (mv_c[0], mv_c[1], cost_c)
             assert np.array_equal(got["rime"]["mv"], rime[:, :2]) and np.array_equal(got["rime"]["cost"], rime[:, 2]), (W, H, addr)
             assert np.array_equal(got["fme"]["mv"], fme[:, :2]) and np.array_equal(got["fme"]["cost"], fme[:, 2]), (W, H, addr)
+
+
+def test_lookahead_frame_cost_vs_reference(oracle):
+    """The reference's EstimateRow::estimateCUCost run over whole frames against the oracle's post-search
+    restatement: intra-only, P and B triples, ragged and tiny CU grids, with and without AQ factors, first call
+    (intra computed) and repeat call (bIntraCalculated, lists not searched again)."""
+    from x265_amd.synth import make_clip
+    from util import host_lowres_planes
+    ref = Ref(8)
+    for (w, h, kind) in ((200, 120, "noise"), (32, 32, "texture"), (16, 144, "texture"), (144, 16, "noise"), (300, 200, "texture")):
+        clip = make_clip(w, h, 5, seed=w + 3, depth=8, kind=kind)
+        P = [host_lowres_planes(oracle, 8, f, 64) for f in clip]
+        org, stride, wcu, hcu = P[0][1], P[0][2], P[0][3], P[0][4]
+        q = np.random.default_rng(5).integers(100, 400, wcu * hcu).astype(np.int32)
+        for (b, d0, d1) in ((2, 0, 0), (2, 2, 0), (2, 1, 2), (1, 1, 3)):
+            f, r0, r1 = P[b][0], (P[b - d0][0] if d0 else None), (P[b + d1][0] if d1 else None)
+            for invq in (None, q):
+                R = ref.estimate_frame(f, r0, r1, org, stride, wcu, hcu, d0, d1, inv_qscale=invq)
+                O = oracle.lookahead_frame_cost(8, f[0], r0, r1, org, stride, wcu, hcu, d0, d1, R["mvs0"], R["mvcosts0"],
+                                                R["mvs1"], R["mvcosts1"], None, invq)
+                for k in O:
+                    assert np.array_equal(R[k], O[k]), (w, h, b, d0, d1, k)
+                R2 = ref.estimate_frame(f, r0, r1, org, stride, wcu, hcu, d0, d1, intra_cost=R["intra_cost"], inv_qscale=invq,
+                                        mvs0=R["mvs0"] if d0 else None, mvcosts0=R["mvcosts0"],
+                                        mvs1=R["mvs1"] if d1 else None, mvcosts1=R["mvcosts1"])
+                O2 = oracle.lookahead_frame_cost(8, f[0], r0, r1, org, stride, wcu, hcu, d0, d1, R["mvs0"], R["mvcosts0"],
+                                                 R["mvs1"], R["mvcosts1"], R["intra_cost"], invq)
+                for k in ("lowres_costs", "row_satds", "totals"):
+                    assert np.array_equal(R2[k], O2[k]), (w, h, b, d0, d1, k, "repeat")

@@ -63,6 +63,7 @@ __global__ __launch_bounds__(64) void search_kernel(SearchArgs a)
 }
 
 #include "me_esa.h"   /* esa_scan_kernel, esa_finish_kernel: use SearchArgs and xcd_remap */
+#include "me_lookahead_cost.h"
 
 /* subpelCompare for a batch of PUs (motion.cpp:1651-1689) */
 template<typename P>
@@ -1131,6 +1132,93 @@ int x265amd_lookahead_fields_dev(x265amd_ctx *c, const void *d_fields, int nfiel
     else
         hipLaunchKernelGGL(lookahead_kernel<uint16_t>, dim3(nfields), dim3(LA_WAVES * 64), LA_WAVES * wave_lds_bytes<uint16_t>(8), c->stream, a);
     HIPCHK(c, hipGetLastError());
+    return X265AMD_OK;
+}
+
+/* ---- lookahead frame cost ---- */
+
+static int frame_cost_check(x265amd_ctx *c, const x265amd_frame_cost *fr, int n, int wcu, int hcu, std::vector<FrameCostDev> &out)
+{
+    out.resize(n);
+    for (int i = 0; i < n; i++)
+    {
+        const x265amd_frame_cost &s = fr[i];
+        FrameCostDev &d = out[i];
+        if (s.d0 < 0 || s.d1 < 0 || (s.d1 > 0 && s.d0 == 0))
+            return fail(c, X265AMD_EINVAL, "frame cost: need d0 >= 0, d1 >= 0 and a list-0 reference for a bidirectional frame");
+        if (!s.fenc.origin || !s.lowres_costs || !s.intra_cost || !s.totals || (!s.intra_calculated && !s.row_satds_intra))
+            return fail(c, X265AMD_EINVAL, "frame cost: null output array");
+        if (!s.intra_calculated && c->depth > 8)
+            return fail(c, X265AMD_EINVAL, "frame cost: the intra estimate exists for 8-bit pictures only (pass intra_cost)");
+        if (s.fenc.margin_x < 16 || s.fenc.margin_y < 16 || s.fenc.width < wcu * 8 || s.fenc.height < hcu * 8)
+            return fail(c, X265AMD_EINVAL, "frame cost: lowres plane geometry does not cover the CU grid + 16 px");
+        if (s.d0 && (!s.ref0[0].origin || !s.mvs0 || !s.mv_costs0 || !s.row_satds))
+            return fail(c, X265AMD_EINVAL, "frame cost: list 0 needs planes, MVs, MV costs and row_satds");
+        if (s.d1 && (!s.ref1[0].origin || !s.mvs1 || !s.mv_costs1))
+            return fail(c, X265AMD_EINVAL, "frame cost: list 1 needs planes, MVs and MV costs");
+        d.fenc.origin = s.fenc.origin; d.fenc.stride = s.fenc.stride;
+        for (int k = 0; k < 4; k++)
+        {
+            d.ref0[k].origin = s.ref0[k].origin; d.ref0[k].stride = s.ref0[k].stride;
+            d.ref1[k].origin = s.ref1[k].origin; d.ref1[k].stride = s.ref1[k].stride;
+        }
+        d.d0 = s.d0; d.d1 = s.d1; d.intra_calculated = s.intra_calculated; d.pad = 0;
+        d.mvs0 = s.mvs0; d.mv_costs0 = s.mv_costs0; d.mvs1 = s.mvs1; d.mv_costs1 = s.mv_costs1;
+        d.inv_qscale = s.inv_qscale; d.intra_cost = s.intra_cost; d.lowres_costs = s.lowres_costs;
+        d.row_satds_intra = s.row_satds_intra; d.row_satds = s.row_satds; d.totals = (long long*)s.totals;
+    }
+    return X265AMD_OK;
+}
+
+int x265amd_frame_costs_upload(x265amd_ctx *c, const x265amd_frame_cost *frames, int nframes, int wcu, int hcu, void **d_frames)
+{
+    if (!c || !frames || nframes <= 0 || wcu <= 0 || hcu <= 0 || !d_frames) return fail(c, X265AMD_EINVAL, "null argument");
+    std::vector<FrameCostDev> hf;
+    int rc = frame_cost_check(c, frames, nframes, wcu, hcu, hf);
+    if (rc) return rc;
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipMalloc(d_frames, nframes * sizeof(FrameCostDev)));
+    HIPCHK(c, hipMemcpy(*d_frames, hf.data(), nframes * sizeof(FrameCostDev), hipMemcpyHostToDevice));
+    return X265AMD_OK;
+}
+
+int x265amd_lookahead_frame_costs_dev(x265amd_ctx *c, const void *d_frames, int nframes, int wcu, int hcu)
+{
+    if (!c || !d_frames || nframes < 0 || wcu <= 0 || hcu <= 0) return fail(c, X265AMD_EINVAL, "null argument");
+    if (!nframes) return X265AMD_OK;
+    HIPCHK(c, hipSetDevice(c->device));
+    const FrameCostDev *fr = (const FrameCostDev*)d_frames;
+    const int ncu = wcu * hcu;
+    hipLaunchKernelGGL(la_cost_init_kernel, dim3(nframes), dim3(256), 0, c->stream, fr, hcu);
+    if (c->depth <= 8)
+    {
+        hipLaunchKernelGGL(la_intra_kernel, dim3((ncu + LA_INTRA_WAVES - 1) / LA_INTRA_WAVES, nframes), dim3(LA_INTRA_WAVES * 64), 0,
+                           c->stream, fr, wcu, hcu);
+        hipLaunchKernelGGL(la_cost_kernel<uint8_t>, dim3((ncu + LA_COST_THREADS / 4 - 1) / (LA_COST_THREADS / 4), nframes),
+                           dim3(LA_COST_THREADS), 0, c->stream, fr, wcu, hcu);
+    }
+    else
+        hipLaunchKernelGGL(la_cost_kernel<uint16_t>, dim3((ncu + LA_COST_THREADS / 4 - 1) / (LA_COST_THREADS / 4), nframes),
+                           dim3(LA_COST_THREADS), 0, c->stream, fr, wcu, hcu);
+    HIPCHK(c, hipGetLastError());
+    return X265AMD_OK;
+}
+
+int x265amd_device_alloc(x265amd_ctx *c, size_t bytes, void **d_ptr)
+{
+    if (!c || !d_ptr || !bytes) return fail(c, X265AMD_EINVAL, "null argument");
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipMalloc(d_ptr, bytes));
+    HIPCHK(c, hipMemsetAsync(*d_ptr, 0, bytes, c->stream));
+    return X265AMD_OK;
+}
+
+int x265amd_upload(x265amd_ctx *c, void *d_dst, const void *src, size_t bytes)
+{
+    if (!c || !d_dst || !src) return fail(c, X265AMD_EINVAL, "null argument");
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipMemcpyAsync(d_dst, src, bytes, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
     return X265AMD_OK;
 }
 

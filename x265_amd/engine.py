@@ -48,6 +48,15 @@ class Field(C.Structure):
     _fields_ = [("fenc", Plane), ("ref", Plane * 4)]
 
 
+class FrameCost(C.Structure):
+    """x265amd_frame_cost: one estimateFrameCost evaluation; pointers are device addresses."""
+    _fields_ = [("fenc", Plane), ("ref0", Plane * 4), ("ref1", Plane * 4), ("d0", C.c_int32), ("d1", C.c_int32),
+                ("intra_calculated", C.c_int32), ("reserved", C.c_int32),
+                ("mvs0", C.c_void_p), ("mv_costs0", C.c_void_p), ("mvs1", C.c_void_p), ("mv_costs1", C.c_void_p),
+                ("inv_qscale", C.c_void_p), ("intra_cost", C.c_void_p), ("lowres_costs", C.c_void_p),
+                ("row_satds_intra", C.c_void_p), ("row_satds", C.c_void_p), ("totals", C.c_void_p)]
+
+
 class EngineError(RuntimeError):
     pass
 
@@ -209,6 +218,103 @@ class Engine:
         self._chk(self.L.x265amd_lookahead_fields_dev(self.ctx, d_fields, nfields, wcu, hcu, qp, method, subme, merange,
                                                       C.c_void_p(d_mvs), C.c_void_p(d_costs),
                                                       C.c_void_p(d_stats) if d_stats else None))
+
+    # ---- lookahead frame cost
+    def device_alloc(self, nbytes):
+        d = C.c_void_p()
+        self._chk(self.L.x265amd_device_alloc(self.ctx, C.c_size_t(nbytes), C.byref(d)))
+        return d.value
+
+    def upload(self, d_dst, arr):
+        arr = np.ascontiguousarray(arr)
+        self._chk(self.L.x265amd_upload(self.ctx, C.c_void_p(d_dst), C.c_void_p(arr.ctypes.data), C.c_size_t(arr.nbytes)))
+
+    def download(self, d_src, shape, dtype):
+        out = np.zeros(shape, dtype)
+        self._chk(self.L.x265amd_download(self.ctx, C.c_void_p(d_src), C.c_void_p(out.ctypes.data), C.c_size_t(out.nbytes)))
+        return out
+
+    def frame_costs_upload(self, descs, wcu, hcu):
+        arr = (FrameCost * len(descs))(*descs)
+        d = C.c_void_p()
+        self._chk(self.L.x265amd_frame_costs_upload(self.ctx, arr, len(descs), wcu, hcu, C.byref(d)))
+        return d
+
+    def lookahead_frame_costs_dev(self, d_frames, nframes, wcu, hcu):
+        self._chk(self.L.x265amd_lookahead_frame_costs_dev(self.ctx, d_frames, nframes, wcu, hcu))
+
+    def estimate_frame_costs(self, frames, wcu, hcu, qp, method=HEX, subme=1, merange=16):
+        """CostEstimate::estimateFrameCost (slicetype.cpp:1132-1221) for a batch of (b, p0, p1) triples in three
+        launches: the MV fields of every list that has none yet, then the intra / bidirectional / choice kernels.
+        frames: dicts with fenc (4 lowres planes of frame b), ref0 / ref1 (4 planes of frames p0 / p1 or None),
+        d0, d1, and optionally intra_cost (bIntraCalculated), inv_qscale, mvs0 / mv_costs0, mvs1 / mv_costs1 (lists
+        searched by an earlier call). Returns dicts of host arrays named like the reference's Lowres members."""
+        n, ncu = len(frames), wcu * hcu
+        todo = [(i, l) for i, f in enumerate(frames) for l in (0, 1)
+                if f["d%d" % l] > 0 and f.get("mvs%d" % l) is None]
+        d_mvs = self.device_alloc(max(1, 2 * n) * ncu * 4)
+        d_mvc = self.device_alloc(max(1, 2 * n) * ncu * 4)
+        sizes = (("intra_cost", ncu * 4), ("lowres_costs", ncu * 2), ("row_satds_intra", hcu * 4), ("row_satds", hcu * 4),
+                 ("totals", 40), ("inv_qscale", ncu * 4))
+        d_out = {k: self.device_alloc(n * sz) for k, sz in sizes}
+        owned = [d_mvs, d_mvc] + list(d_out.values())
+        try:
+            for i, f in enumerate(frames):
+                for l in (0, 1):
+                    if f["d%d" % l] > 0 and f.get("mvs%d" % l) is not None:
+                        self.upload(d_mvs + (2 * i + l) * ncu * 4, np.ascontiguousarray(f["mvs%d" % l], np.int16))
+                        self.upload(d_mvc + (2 * i + l) * ncu * 4, np.ascontiguousarray(f["mv_costs%d" % l], np.int32))
+                if f.get("intra_cost") is not None:
+                    self.upload(d_out["intra_cost"] + i * ncu * 4, np.ascontiguousarray(f["intra_cost"], np.int32))
+                if f.get("inv_qscale") is not None:
+                    self.upload(d_out["inv_qscale"] + i * ncu * 4, np.ascontiguousarray(f["inv_qscale"], np.int32))
+            # the searches: one launch per run of fields whose outputs are adjacent
+            k = 0
+            while k < len(todo):
+                m = k + 1
+                while m < len(todo) and 2 * todo[m][0] + todo[m][1] == 2 * todo[m - 1][0] + todo[m - 1][1] + 1:
+                    m += 1
+                d_f = self.fields_upload([(frames[i]["fenc"][0], frames[i]["ref%d" % l]) for i, l in todo[k:m]])
+                owned.append(d_f)
+                slot = 2 * todo[k][0] + todo[k][1]
+                self.lookahead_fields_dev(d_f, m - k, wcu, hcu, qp, method, subme, merange,
+                                          d_mvs + slot * ncu * 4, d_mvc + slot * ncu * 4)
+                k = m
+            descs = []
+            for i, f in enumerate(frames):
+                d = FrameCost()
+                d.fenc = f["fenc"][0]
+                for l in (0, 1):
+                    if f["d%d" % l] > 0:
+                        for q in range(4):
+                            getattr(d, "ref%d" % l)[q] = f["ref%d" % l][q]
+                        setattr(d, "mvs%d" % l, d_mvs + (2 * i + l) * ncu * 4)
+                        setattr(d, "mv_costs%d" % l, d_mvc + (2 * i + l) * ncu * 4)
+                d.d0, d.d1 = f["d0"], f["d1"]
+                d.intra_calculated = int(f.get("intra_cost") is not None)
+                d.inv_qscale = d_out["inv_qscale"] + i * ncu * 4 if f.get("inv_qscale") is not None else None
+                for key, sz in sizes[:5]:
+                    setattr(d, key, d_out[key] + i * sz)
+                descs.append(d)
+            d_desc = self.frame_costs_upload(descs, wcu, hcu)
+            owned.append(d_desc)
+            self.lookahead_frame_costs_dev(d_desc, n, wcu, hcu)
+            mvs = self.download(d_mvs, (n, 2, ncu, 2), np.int16)
+            mvc = self.download(d_mvc, (n, 2, ncu), np.int32)
+            res = []
+            for i in range(n):
+                r = dict(mvs0=mvs[i, 0], mv_costs0=mvc[i, 0], mvs1=mvs[i, 1], mv_costs1=mvc[i, 1])
+                r["intra_cost"] = self.download(d_out["intra_cost"] + i * ncu * 4, ncu, np.int32)
+                r["lowres_costs"] = self.download(d_out["lowres_costs"] + i * ncu * 2, ncu, np.uint16)
+                r["row_satds_intra"] = self.download(d_out["row_satds_intra"] + i * hcu * 4, hcu, np.int32)
+                r["row_satds"] = self.download(d_out["row_satds"] + i * hcu * 4, hcu, np.int32)
+                r["totals"] = self.download(d_out["totals"] + i * 40, 5, np.int64)
+                res.append(r)
+            return res
+        finally:
+            self.sync()
+            for d in owned:
+                self.device_free(C.c_void_p(d) if isinstance(d, int) else d)
 
     # ---- Rockchip path
     def rk_ds_plane(self, orig):
