@@ -104,6 +104,8 @@ struct LookaheadArgs
     int16_t *mvs;        /* nfields * ncu * 2 */
     int32_t *costs;      /* nfields * ncu */
     x265amd_result *stats; /* nfields * ncu or null */
+    int nfields;
+    int *ticket;         /* row hand-out counter of lookahead_rows_kernel, zero at launch */
 };
 
 __device__ __forceinline__ int median3(int a, int b, int c)
@@ -182,6 +184,103 @@ __global__ __launch_bounds__(LA_WAVES * 64) void lookahead_kernel(LookaheadArgs 
             }
         }
         __syncthreads();
+    }
+}
+
+/* Lookahead, row-parallel flavour: one wave per CU row, rows of all fields handed out bottom-up
+ * through a ticket counter, any number of workgroups. A row runs right to left like
+ * CostEstimate::processRow (slicetype.cpp:1342-1387) and, like the reference's wavefront rows,
+ * follows the row below it at a distance of two CUs. The MV array is the synchronisation: the
+ * launch presets every MV to x = 0x7FFF (the reference's own "not searched yet" mark,
+ * slicetype.cpp:1150), a CU's MV is published with one 32-bit device-scope store, and a wave
+ * polls the three MVs it needs from the row below (device-scope loads) until none carries the
+ * mark. Rows are taken in ticket order and a row only waits for a row with a smaller ticket,
+ * which a resident wave already holds, so every wait ends. A field of W x H CUs takes about
+ * W + 2H searches of latency instead of W * H / 16. */
+#define LA_MV_UNSET 0x7FFF7FFF
+template<typename P>
+__global__ __launch_bounds__(64) void lookahead_rows_kernel(LookaheadArgs a)
+{
+    __shared__ x265amd_job jobs[1];
+    __shared__ x265amd_result results[1];
+    const int lane = threadIdx.x & 63;
+    const int W = a.wcu, H = a.hcu, ncu = W * H;
+    const int nrows = a.nfields * H;
+    for (;;)
+    {
+        int t = 0;
+        if (lane == 0) t = atomicAdd(a.ticket, 1);
+        t = uni(t);
+        if (t >= nrows) break;
+        const int fi = t % a.nfields, cuy = H - 1 - t / a.nfields;
+        const FieldDev &f = a.fields[fi];
+        int *mvw = (int*)(a.mvs + (size_t)fi * ncu * 2);     /* one 32-bit word per MV: x low, y high */
+        int32_t *costs = a.costs + (size_t)fi * ncu;
+        int right = 0;                                         /* MV of (cux + 1, cuy): this wave's previous result */
+        for (int cux = W - 1; cux >= 0; cux--)
+        {
+            const int cuXY = cux + cuy * W;
+            /* lanes 0..2: below, below-left, below-right */
+            int nb = 0;
+            const int dx = lane == 0 ? 0 : (lane == 1 ? -1 : 1);
+            const bool want = lane < 3 && cuy < H - 1 && cux + dx >= 0 && cux + dx < W;
+            if (want)
+            {
+                const int *src = mvw + cuXY + W + dx;
+                nb = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                while ((nb & 0xffff) == 0x7FFF)
+                {
+                    __builtin_amdgcn_s_sleep(8);
+                    nb = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
+            const int below = __builtin_amdgcn_readlane(nb, 0), bleft = __builtin_amdgcn_readlane(nb, 1),
+                      bright = __builtin_amdgcn_readlane(nb, 2);
+            x265amd_job *job = &jobs[0];
+            if (lane == 0)
+            {
+                /* slicetype.cpp:1427-1466 */
+                job->pu_x = (int16_t)(cux * 8); job->pu_y = (int16_t)(cuy * 8);
+                job->w = 8; job->h = 8;
+                job->mvmin[0] = (int16_t)(uint16_t)(-cux * 8 - 8);
+                job->mvmin[1] = (int16_t)(uint16_t)(-cuy * 8 - 8);
+                job->mvmax[0] = (int16_t)(uint16_t)((W - cux - 1) * 8 + 8);
+                job->mvmax[1] = (int16_t)(uint16_t)((H - cuy - 1) * 8 + 8);
+                int numc = 0;
+                int16_t (*mvc)[2] = job->mvc;
+                for (int i = 0; i < 4; i++) { mvc[i][0] = 0; mvc[i][1] = 0; }
+#define MVC(word) do { mvc[numc][0] = (int16_t)((word) & 0xffff); mvc[numc][1] = (int16_t)((word) >> 16); numc++; } while (0)
+                if (cux < W - 1) MVC(right);
+                if (cuy < H - 1)
+                {
+                    MVC(below);
+                    if (cux > 0) MVC(bleft);
+                    if (cux < W - 1) MVC(bright);
+                }
+#undef MVC
+                if (numc <= 1) { job->qmvp[0] = mvc[0][0]; job->qmvp[1] = mvc[0][1]; }
+                else
+                {
+                    job->qmvp[0] = (int16_t)median3(mvc[0][0], mvc[1][0], mvc[2][0]);
+                    job->qmvp[1] = (int16_t)median3(mvc[0][1], mvc[1][1], mvc[2][1]);
+                }
+                job->numc = (uint8_t)numc;
+                job->merange = a.merange;
+            }
+            wave_sync();
+            Searcher<P, 8, true> S;
+            S.bind(0, f.fenc, f.ref, 4, a.ctab, a.depth, cux * 8, cuy * 8, 8, 8);
+            S.search(job, a.method, a.subme, &results[0]);
+            wave_sync();
+            right = uni(((int)(uint16_t)results[0].mv[0]) | ((int)(uint16_t)results[0].mv[1] << 16));
+            if (lane == 0)
+            {
+                costs[cuXY] = results[0].cost;
+                if (a.stats) a.stats[(size_t)fi * ncu + cuXY] = results[0];
+                __hip_atomic_store(mvw + cuXY, right, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            wave_sync();
+        }
     }
 }
 
@@ -633,6 +732,7 @@ struct x265amd_ctx
     void *d_results; size_t results_cap;
     void *d_stage; size_t stage_cap;   /* staging for the per-call primitives */
     int32_t *d_out;
+    int *d_ticket;                     /* row hand-out counter of the row-parallel lookahead kernel */
     int esa_window_bytes;              /* LDS the exhaustive search may use per PU for its window */
 };
 
@@ -689,6 +789,40 @@ static int launch_search(x265amd_ctx *c, const SearchArgs &a, int is_lowres)
     return X265AMD_OK;
 }
 
+/* Both lookahead kernels give the same fields. One workgroup per field keeps the launch free of
+ * global synchronisation and is enough when hundreds of fields are in flight; the row-parallel
+ * kernel spreads a field over up to min(H, W / 2) waves and wins whenever the fields alone cannot
+ * fill the chip. LA_ROWS_MAX_FIELDS is where a launch switches over. */
+#define LA_ROWS_MAX_FIELDS 512
+static int launch_lookahead(x265amd_ctx *c, LookaheadArgs &a, int nfields)
+{
+    const char *force = getenv("X265AMD_LOOKAHEAD_KERNEL");   /* "field" or "rows": measurements only */
+    const bool rows = force ? !strcmp(force, "rows") : nfields <= LA_ROWS_MAX_FIELDS;
+    a.nfields = nfields;
+    a.ticket = c->d_ticket;
+    if (!rows)
+    {
+        if (c->depth <= 8)
+            hipLaunchKernelGGL(lookahead_kernel<uint8_t>, dim3(nfields), dim3(LA_WAVES * 64), LA_WAVES * wave_lds_bytes<uint8_t>(8), c->stream, a);
+        else
+            hipLaunchKernelGGL(lookahead_kernel<uint16_t>, dim3(nfields), dim3(LA_WAVES * 64), LA_WAVES * wave_lds_bytes<uint16_t>(8), c->stream, a);
+    }
+    else
+    {
+        const size_t words = (size_t)nfields * a.wcu * a.hcu;
+        HIPCHK(c, hipMemsetD32Async((hipDeviceptr_t)a.mvs, LA_MV_UNSET, words, c->stream));
+        HIPCHK(c, hipMemsetAsync(c->d_ticket, 0, sizeof(int), c->stream));
+        long waves = (long)nfields * a.hcu;
+        if (waves > 8192) waves = 8192;     /* more than the chip holds at once; the rest of the rows go to waves that finish */
+        if (c->depth <= 8)
+            hipLaunchKernelGGL(lookahead_rows_kernel<uint8_t>, dim3((unsigned)waves), dim3(64), wave_lds_bytes<uint8_t>(8), c->stream, a);
+        else
+            hipLaunchKernelGGL(lookahead_rows_kernel<uint16_t>, dim3((unsigned)waves), dim3(64), wave_lds_bytes<uint16_t>(8), c->stream, a);
+    }
+    HIPCHK(c, hipGetLastError());
+    return X265AMD_OK;
+}
+
 extern "C" {
 
 int x265amd_partition_from_sizes(int w, int h)
@@ -705,10 +839,10 @@ int x265amd_create(int device, int bit_depth, x265amd_ctx **out)
     if (hipGetDeviceCount(&n) != hipSuccess || device < 0 || device >= n) return X265AMD_EHIP;
     x265amd_ctx *c = new x265amd_ctx();
     c->device = device; c->depth = bit_depth;
-    c->d_jobs = c->d_results = c->d_stage = 0; c->jobs_cap = c->results_cap = c->stage_cap = 0; c->d_out = 0;
+    c->d_jobs = c->d_results = c->d_stage = 0; c->d_ticket = 0; c->jobs_cap = c->results_cap = c->stage_cap = 0; c->d_out = 0;
     c->esa_window_bytes = ESA_WINDOW_DEFAULT;
     if (hipSetDevice(device) != hipSuccess || hipStreamCreate(&c->stream) != hipSuccess ||
-        hipMalloc((void**)&c->d_out, 64) != hipSuccess)
+        hipMalloc((void**)&c->d_out, 64) != hipSuccess || hipMalloc((void**)&c->d_ticket, 256) != hipSuccess)
     {
         delete c;
         return X265AMD_EHIP;
@@ -727,6 +861,7 @@ void x265amd_destroy(x265amd_ctx *c)
     if (c->d_results) (void)hipFree(c->d_results);
     if (c->d_stage) (void)hipFree(c->d_stage);
     if (c->d_out) (void)hipFree(c->d_out);
+    if (c->d_ticket) (void)hipFree(c->d_ticket);
     (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -1075,11 +1210,7 @@ int x265amd_lookahead_fields(x265amd_ctx *c, const x265amd_field *fields, int nf
     a.mvs = (int16_t*)c->d_results;
     a.costs = (int32_t*)((char*)c->d_results + mvbytes);
     a.stats = out_stats ? (x265amd_result*)((char*)c->d_results + mvbytes + cbytes) : 0;
-    if (c->depth <= 8)
-        hipLaunchKernelGGL(lookahead_kernel<uint8_t>, dim3(nfields), dim3(LA_WAVES * 64), LA_WAVES * wave_lds_bytes<uint8_t>(8), c->stream, a);
-    else
-        hipLaunchKernelGGL(lookahead_kernel<uint16_t>, dim3(nfields), dim3(LA_WAVES * 64), LA_WAVES * wave_lds_bytes<uint16_t>(8), c->stream, a);
-    HIPCHK(c, hipGetLastError());
+    if ((rc = launch_lookahead(c, a, nfields))) return rc;
     HIPCHK(c, hipMemcpyAsync(out_mvs, a.mvs, mvbytes, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipMemcpyAsync(out_costs, a.costs, cbytes, hipMemcpyDeviceToHost, c->stream));
     if (out_stats) HIPCHK(c, hipMemcpyAsync(out_stats, a.stats, sbytes, hipMemcpyDeviceToHost, c->stream));
@@ -1127,11 +1258,7 @@ int x265amd_lookahead_fields_dev(x265amd_ctx *c, const void *d_fields, int nfiel
     a.wcu = wcu; a.hcu = hcu; a.depth = c->depth; a.method = method; a.subme = subme; a.merange = merange;
     a.ctab = c->tables[qp] + 32768;
     a.mvs = d_mvs; a.costs = d_costs; a.stats = d_stats;
-    if (c->depth <= 8)
-        hipLaunchKernelGGL(lookahead_kernel<uint8_t>, dim3(nfields), dim3(LA_WAVES * 64), LA_WAVES * wave_lds_bytes<uint8_t>(8), c->stream, a);
-    else
-        hipLaunchKernelGGL(lookahead_kernel<uint16_t>, dim3(nfields), dim3(LA_WAVES * 64), LA_WAVES * wave_lds_bytes<uint16_t>(8), c->stream, a);
-    HIPCHK(c, hipGetLastError());
+    if ((rc = launch_lookahead(c, a, nfields))) return rc;
     return X265AMD_OK;
 }
 

@@ -87,3 +87,67 @@ def rk_picture(e, dev, width=1920, height=1080, reps=5, seed=5, qp=30):
     return {"ms": ms, "ctus": nctu, "cime_pixel_sads": cime_px, "cu_pixel_sads": cu_px * (576 + 49),
             "pixel_sads": cime_px + cu_px * (576 + 49), "jobs": jobs, "results": res,
             "planes": (cur, rorig, recon, org, stride), "margin": M, "qp": qp}
+
+
+def lookahead_costs(e, dev, width=1920, height=1080, nframes=16, reps=3, seed=21, qp=12):
+    """estimateFrameCost of `nframes` B-frame triples (b - 1, b, b + 1) of one clip: 2 * nframes MV fields (HEX,
+    subme 1, merange 16), then the intra / bidirectional / choice kernels, everything device resident.
+    Returns the per-stage times (ms per batch) and the first triple's results with its host planes for checking."""
+    import ctypes as C
+    import torch
+    from .engine import FrameCost, HEX
+    from .synth import lowres_dims
+    M = 64
+    clip = make_clip(width, height, nframes + 2, seed=seed)
+    low = []
+    for f in clip:
+        buf, org, stride = pad_plane(f, M)
+        p = e.upload_plane(buf, width, height, M, M, stride)
+        low.append(e.lowres_init(p))
+        e.free_plane(p)
+    lw, lh, wcu, hcu = lowres_dims(width, height)
+    ncu = wcu * hcu
+    n = nframes
+    fields = []
+    for b in range(1, n + 1):
+        fields += [(low[b][0], low[b - 1]), (low[b][0], low[b + 1])]
+    d_fields = e.fields_upload(fields)
+    d_mvs = torch.zeros((n, 2, ncu, 2), dtype=torch.int16, device=dev)
+    d_mvc = torch.zeros((n, 2, ncu), dtype=torch.int32, device=dev)
+    out = {"intra_cost": torch.zeros((n, ncu), dtype=torch.int32, device=dev),
+           "lowres_costs": torch.zeros((n, ncu), dtype=torch.int16, device=dev),
+           "row_satds_intra": torch.zeros((n, hcu), dtype=torch.int32, device=dev),
+           "row_satds": torch.zeros((n, hcu), dtype=torch.int32, device=dev),
+           "totals": torch.zeros((n, 5), dtype=torch.int64, device=dev)}
+    descs = []
+    for i in range(n):
+        d = FrameCost()
+        d.fenc = low[i + 1][0]
+        for q in range(4):
+            d.ref0[q] = low[i][q]
+            d.ref1[q] = low[i + 2][q]
+        d.d0 = d.d1 = 1
+        d.mvs0, d.mvs1 = d_mvs[i, 0].data_ptr(), d_mvs[i, 1].data_ptr()
+        d.mv_costs0, d.mv_costs1 = d_mvc[i, 0].data_ptr(), d_mvc[i, 1].data_ptr()
+        for k, t in out.items():
+            setattr(d, k, t[i].data_ptr())
+        descs.append(d)
+    d_desc = e.frame_costs_upload(descs, wcu, hcu)
+    torch.cuda.synchronize()
+    search = lambda: e.lookahead_fields_dev(d_fields, 2 * n, wcu, hcu, qp, HEX, 1, 16, d_mvs.data_ptr(), d_mvc.data_ptr())
+    costs = lambda: e.lookahead_frame_costs_dev(d_desc, n, wcu, hcu)
+    ms_search = _timed(torch, e, dev, search, reps)
+    ms_costs = _timed(torch, e, dev, costs, reps)
+    res = {k: t[0].cpu().numpy() for k, t in out.items()}
+    res["lowres_costs"] = res["lowres_costs"].view(np.uint16)
+    res["mvs"] = d_mvs[0].cpu().numpy()
+    res["mv_costs"] = d_mvc[0].cpu().numpy()
+    host = [[e.download_plane(p).reshape(-1) for p in low[k]] for k in range(3)]
+    geo = (low[0][0].margin_y * low[0][0].stride + low[0][0].margin_x, low[0][0].stride, wcu, hcu)
+    e.device_free(d_fields)
+    e.device_free(d_desc)
+    for l in low:
+        for p in l:
+            e.free_plane(p)
+    return {"frames": n, "fields": 2 * n, "cus": ncu, "ms_search": ms_search, "ms_costs": ms_costs, "first": res,
+            "host_planes": host, "geometry": geo}
