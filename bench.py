@@ -231,7 +231,18 @@ def main():
                 ms = sum(r["ms"] for r in rows)
                 px = sum(r["pixel_sads"] for r in rows)
                 rk = measure.rk_picture(es, dev)
+                la = {}
+                for (lw_, lh_, n_) in ((1920, 1080, 16), (7680, 4320, 4)):
+                    m = measure.lookahead_costs(el, dev, lw_, lh_, n_)
+                    la["%dx%d" % (lw_, lh_)] = {
+                        "b_frame_triples": m["frames"], "cus_per_field": m["cus"], "ms_search_of_%d_fields" % m["fields"]: m["ms_search"],
+                        "ms_intra_bidir_choice": m["ms_costs"],
+                        "frame_costs_per_s": m["frames"] / (m["ms_search"] + m["ms_costs"]) * 1e3,
+                        "searched_cus_per_s": m["fields"] * m["cus"] / (m["ms_search"] * 1e-3)}
                 out["other_paths"] = {
+                    "lookahead_frame_cost": dict(la, workload="estimateFrameCost of B-frame triples (b-1, b, b+1): two lowres HEX "
+                                                 "subme-1 merange-16 MV fields each, then 35-mode intra, bidirectional candidates, "
+                                                 "list choice and row / frame sums (BASELINE configs[4] at 7680x4320)"),
                     "esa_4k": {"workload": "3840x2160 8-bit, --me full --merange 92 --subme 5, all 64/32/16/8 square PUs of one "
                                            "picture against one reference (BASELINE configs[2], per reference)",
                                "ms_per_picture_reference": ms, "value": px / ms / 1e6, "unit": "Gpixel-SAD/s",

@@ -55,19 +55,37 @@ __global__ void la_cost_init_kernel(const FrameCostDev *frames, int hcu)
 }
 
 /* ---- intra: slicetype.cpp:1491-1559 ----
- * Per wave, LDS holds the block's reference edges the way the reference builds them
- * (:1495-1524): edge[f][s][0..16], f = 0 raw / 1 smoothed with [1 2 1] (ends kept),
- * s = 0 above / 1 left, index 0 the corner, 9..16 a repeat of index 8; and the 8x8 source. */
+ * Per wave, LDS holds
+ *   edge[f][s][0..16]  the block's reference edges as the reference builds them (:1495-1524):
+ *                      f = 0 raw / 1 smoothed with [1 2 1] (ends kept), s = 0 above / 1 left,
+ *                      index 0 the corner, 9..16 a repeat of index 8;
+ *   src, srcT          the 8x8 source and its transpose (horizontal modes are compared against
+ *                      the transpose, :1542-1543);
+ *   ext[m - 11]        for the 15 modes with a negative angle: the main edge with its eight
+ *                      projected side samples in front (intrapred.cpp:181-195), so that every
+ *                      angular mode reads its main edge through one base address with plain
+ *                      signed indexing. */
 #define LA_INTRA_WAVES 4
 #define LA_EDGE_BYTES 20
-#define LA_INTRA_LDS (4 * LA_EDGE_BYTES + 64)
+#define LA_EXT_BYTES 28
+#define LA_OFF_SRC (4 * LA_EDGE_BYTES)
+#define LA_OFF_SRCT (LA_OFF_SRC + 64)
+#define LA_OFF_EXT (LA_OFF_SRCT + 64)
+#define LA_INTRA_LDS (LA_OFF_EXT + 15 * LA_EXT_BYTES + 4)
 
-/* Sample (row k, column l) of prediction `mode` as the reference's cost loop sees it: 0 = DC
- * with edge smoothing (intrapred.cpp:45-104), 1 = planar from the smoothed edges (:106-154),
- * 2..34 angular (:156-259) with modes below 18 left transposed (:262-289). */
-__device__ __forceinline__ int la_pred(const uint8_t *e, int mode, int k, int l, int dc)
+/* 8192 / angle step of |mode - 10| or |mode - 26| (intrapred.cpp:167-170) */
+__constant__ static const int16_t kInvAngle[9] = { 0, 4096, 1638, 910, 630, 482, 390, 315, 256 };
+
+__device__ __forceinline__ int la_abs_angle(int idx)
 {
-    /* e + (f * 2 + s) * LA_EDGE_BYTES */
+    const unsigned long long angs = 0x1a15110d09050200ull;     /* 0 2 5 9 13 17 21 26 (a byte each), then 32 */
+    return idx == 8 ? 32 : (int)((angs >> (8 * idx)) & 0xff);
+}
+
+/* DC with edge smoothing (intrapred.cpp:45-104) and planar from the smoothed edges (:106-154),
+ * sample (row k, column l) */
+__device__ __forceinline__ int la_pred_dc_planar(const uint8_t *e, int mode, int k, int l, int dc)
+{
     if (mode == 0)
     {
         const uint8_t *a = e, *lf = e + LA_EDGE_BYTES;
@@ -76,47 +94,13 @@ __device__ __forceinline__ int la_pred(const uint8_t *e, int mode, int k, int l,
         if (l == 0) return (lf[k + 1] + 3 * dc + 2) >> 2;
         return dc;
     }
-    if (mode == 1)
-    {
-        const uint8_t *a = e + 2 * LA_EDGE_BYTES + 1, *lf = e + 3 * LA_EDGE_BYTES + 1;
-        return ((lf[k] << 3) + 8 + (l + 1) * ((int)a[8] - lf[k]) + (a[l] << 3) + (k + 1) * ((int)lf[8] - a[l])) >> 4;
-    }
-    /* angle steps of |mode - 10| / |mode - 26| = 0..8 and 8192 / step (intrapred.cpp:167-170), packed */
-    const int f = (mode == 2 || mode == 18 || mode == 34);   /* IntraFilterType of 8x8 blocks, intrapred.cpp:35 */
-    const int ver = mode >= 18;
-    const uint8_t *refMain = e + (f * 2 + (ver ? 0 : 1)) * LA_EDGE_BYTES;
-    const uint8_t *refSide = e + (f * 2 + (ver ? 1 : 0)) * LA_EDGE_BYTES;
-    int ang = ver ? mode - 26 : 10 - mode;
-    const int idx = ang < 0 ? -ang : ang;
-    const unsigned long long angs = 0x1a15110d09050200ull;             /* 0 2 5 9 13 17 21 26, a byte each; step 8 = 32 */
-    const int absAng = (idx == 8) ? 32 : (int)((angs >> (8 * idx)) & 0xff);
-    if (absAng == 0)
-    {
-        int v = refMain[l + 1];
-        if (l == 0)
-        {
-            v += ((int)refSide[k + 1] - (int)refSide[0]) >> 1;
-            v = v < 0 ? 0 : (v > 255 ? 255 : v);
-        }
-        return v;
-    }
-    int invAngle = 256;
-    switch (idx) { case 1: invAngle = 4096; break; case 2: invAngle = 1638; break; case 3: invAngle = 910; break;
-                   case 4: invAngle = 630; break; case 5: invAngle = 482; break; case 6: invAngle = 390; break;
-                   case 7: invAngle = 315; break; default: break; }
-    ang = ang < 0 ? -absAng : absAng;
-    const int deltaPos = (k + 1) * ang, deltaInt = deltaPos >> 5, fract = deltaPos & 31;
-    const int i0 = l + deltaInt + 1, i1 = i0 + 1;
-    /* negative indices of the main edge are projections of the side edge (intrapred.cpp:181-195) */
-    const int v0 = i0 >= 0 ? refMain[i0] : refSide[(128 - i0 * invAngle) >> 8];
-    if (!fract) return v0;
-    const int v1 = i1 >= 0 ? refMain[i1] : refSide[(128 - i1 * invAngle) >> 8];
-    return ((32 - fract) * v0 + fract * v1 + 16) >> 5;
+    const uint8_t *a = e + 2 * LA_EDGE_BYTES + 1, *lf = e + 3 * LA_EDGE_BYTES + 1;
+    return ((lf[k] << 3) + 8 + (l + 1) * ((int)a[8] - lf[k]) + (a[l] << 3) + (k + 1) * ((int)lf[8] - a[l])) >> 4;
 }
 
 __global__ __launch_bounds__(LA_INTRA_WAVES * 64) void la_intra_kernel(const FrameCostDev *frames, int W, int H)
 {
-    __shared__ uint8_t lds[LA_INTRA_WAVES][LA_INTRA_LDS];
+    __shared__ __attribute__((aligned(4))) uint8_t lds[LA_INTRA_WAVES][LA_INTRA_LDS];
     const FrameCostDev &f = frames[blockIdx.y];
     if (f.intra_calculated) return;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -125,13 +109,15 @@ __global__ __launch_bounds__(LA_INTRA_WAVES * 64) void la_intra_kernel(const Fra
     const int cuy = cu / W, cux = cu - cuy * W;
     const long stride = f.fenc.stride;
     const uint8_t AS1 *cur = (const uint8_t AS1*)f.fenc.origin + (long)(8 * cuy) * stride + 8 * cux;
-    uint8_t *e = lds[wave], *src = e + 4 * LA_EDGE_BYTES;
+    uint8_t *e = lds[wave], *src = e + LA_OFF_SRC, *srct = e + LA_OFF_SRCT, *ext = e + LA_OFF_EXT;
     /* raw edges: lanes 0-16 above, 32-48 left */
     {
         const int i = lane & 31, s = lane >> 5, j = i < 8 ? i : 8;
         if (i <= 16)
             e[s * LA_EDGE_BYTES + i] = s ? cur[-1 - stride + j * stride] : cur[-1 - stride + j];
-        src[lane] = cur[(lane >> 3) * stride + (lane & 7)];
+        const uint8_t px = cur[(lane >> 3) * stride + (lane & 7)];
+        src[lane] = px;
+        srct[(lane & 7) * 8 + (lane >> 3)] = px;
     }
     wave_sync();
     {
@@ -143,6 +129,24 @@ __global__ __launch_bounds__(LA_INTRA_WAVES * 64) void la_intra_kernel(const Fra
         }
     }
     wave_sync();
+    /* extended main edges of modes 11..25: entry j < 8 is main index j - 8 = side[(128 + (8 - j) * invAngle) >> 8];
+     * entries the mode never reads may project past the side edge and are clamped */
+    for (int t = lane; t < 15 * 25; t += 64)
+    {
+        const int m = t / 25, j = t - m * 25, mode = m + 11;
+        const int fl = mode == 18, ver = mode >= 18;
+        const uint8_t *main_ = e + (fl * 2 + (ver ? 0 : 1)) * LA_EDGE_BYTES, *side = e + (fl * 2 + (ver ? 1 : 0)) * LA_EDGE_BYTES;
+        const int idx = ver ? 26 - mode : mode - 10;
+        int v;
+        if (j >= 8) v = main_[j - 8];
+        else
+        {
+            int si = (128 + (8 - j) * kInvAngle[idx]) >> 8;
+            v = side[si > 16 ? 16 : si];
+        }
+        ext[m * LA_EXT_BYTES + j] = (uint8_t)v;
+    }
+    wave_sync();
     int dc = 8;
 #pragma unroll
     for (int i = 1; i <= 8; i++) dc += e[i] + e[LA_EDGE_BYTES + i];
@@ -151,22 +155,63 @@ __global__ __launch_bounds__(LA_INTRA_WAVES * 64) void la_intra_kernel(const Fra
     for (int pass = 0; pass < 3; pass++)
     {
         const int task = pass * 64 + lane, mode = task >> 2, ty = (task >> 1) & 1, tx = task & 1;
-        int v = LA_COST_MAX;
+        int v = 0;
         if (mode < 35)
         {
-            const bool hor = mode >= 2 && mode < 18;           /* compared with the transposed source, :1542-1543 */
+            int p[4][4];
+            if (mode < 2)
+            {
+#pragma unroll
+                for (int k = 0; k < 4; k++)
+#pragma unroll
+                    for (int l = 0; l < 4; l++) p[k][l] = la_pred_dc_planar(e, mode, 4 * ty + k, 4 * tx + l, dc);
+            }
+            else
+            {
+                /* angular (intrapred.cpp:156-259), modes below 18 left transposed as all_angs_pred_c
+                 * leaves them (:262-289) */
+                const int fl = (mode == 2 || mode == 18 || mode == 34);   /* IntraFilterType of 8x8 blocks, intrapred.cpp:35 */
+                const int ver = mode >= 18;
+                int ang = ver ? mode - 26 : 10 - mode;
+                const int absAng = la_abs_angle(ang < 0 ? -ang : ang);
+                const uint8_t *refMain = ang < 0 ? ext + (mode - 11) * LA_EXT_BYTES + 8 : e + (fl * 2 + (ver ? 0 : 1)) * LA_EDGE_BYTES;
+                ang = ang < 0 ? -absAng : absAng;
+#pragma unroll
+                for (int k = 0; k < 4; k++)
+                {
+                    const int dp = (4 * ty + k + 1) * ang, fr = dp & 31;
+                    const uint8_t *r = refMain + 4 * tx + (dp >> 5) + 1;
+                    const int r0 = r[0], r1 = r[1], r2 = r[2], r3 = r[3], r4 = r[4];
+                    /* with fr = 0 this is the plain copy of :233-240 */
+                    p[k][0] = ((32 - fr) * r0 + fr * r1 + 16) >> 5;
+                    p[k][1] = ((32 - fr) * r1 + fr * r2 + 16) >> 5;
+                    p[k][2] = ((32 - fr) * r2 + fr * r3 + 16) >> 5;
+                    p[k][3] = ((32 - fr) * r3 + fr * r4 + 16) >> 5;
+                }
+                if (absAng == 0 && tx == 0)
+                {
+                    /* edge filter of the pure horizontal / vertical modes, bFilter = (cuSize <= 16) (:203-209) */
+                    const uint8_t *refSide = e + (ver ? 1 : 0) * LA_EDGE_BYTES;
+#pragma unroll
+                    for (int k = 0; k < 4; k++)
+                    {
+                        const int t = p[k][0] + (((int)refSide[4 * ty + k + 1] - (int)refSide[0]) >> 1);
+                        p[k][0] = t < 0 ? 0 : (t > 255 ? 255 : t);
+                    }
+                }
+            }
+            const uint8_t *sp = ((mode >= 2 && mode < 18) ? srct : src) + (4 * ty) * 8 + 4 * tx;
             int d[4][4];
 #pragma unroll
             for (int k = 0; k < 4; k++)
-#pragma unroll
-                for (int l = 0; l < 4; l++)
-                {
-                    const int r = 4 * ty + k, c = 4 * tx + l;
-                    d[k][l] = (int)(hor ? src[c * 8 + r] : src[r * 8 + c]) - la_pred(e, mode, r, c, dc);
-                }
+            {
+                const uint32_t q = *(const uint32_t*)(sp + 8 * k);
+                d[k][0] = (int)(q & 0xff) - p[k][0]; d[k][1] = (int)((q >> 8) & 0xff) - p[k][1];
+                d[k][2] = (int)((q >> 16) & 0xff) - p[k][2]; d[k][3] = (int)(q >> 24) - p[k][3];
+            }
             v = had4x4_half(d);
         }
-        v = seg_sum(mode < 35 ? v : 0, 2);
+        v = seg_sum(v, 2);
         v = mode < 35 ? v : LA_COST_MAX;
         v = wave_min(v);
         icost = v < icost ? v : icost;
