@@ -42,6 +42,8 @@ def main():
     ap.add_argument("--pairs", type=int, default=32, help="frame pairs per GPU per step")
     ap.add_argument("--cpu-pairs", type=int, default=24,
                     help="frame pairs whose PU searches are re-run on one host core (parity gate + CPU baseline; 0 = skip)")
+    ap.add_argument("--ref-pairs", type=int, default=8,
+                    help="frame pairs re-run through the reference build (oracle/_ref) when it is present: the CPU baseline")
     ap.add_argument("--method", default="star")
     ap.add_argument("--subme", type=int, default=SUBME_DEFAULT, help="sub-pel refinement level (experiments only)")
     ap.add_argument("--launch", choices=("split", "single", "per-size"), default="split",
@@ -202,6 +204,31 @@ def main():
                    "sample": "all %d PU searches of %d of the %d frame pairs of one step (the lookahead fields are not "
                              "in the sample), oracle/me_oracle.c -O3 single thread, %.1f s; every result compared "
                              "with the GPU's" % (njobs * ncpu, ncpu, B, cpu_s)}
+            # where the reference's own code was built beforehand (oracle/_ref), it is the baseline: the same
+            # searches through its MotionEstimate::motionEstimate and C primitives, one thread, results compared too
+            from oracle.bindings import ref_available
+            nref = min(args.ref_pairs, ncpu)
+            if nref > 0 and ref_available(8):
+                from oracle.bindings import Ref
+                rf = Ref(8)
+                ref_s, ref_px = 0.0, 0
+                for i in range(nref):
+                    cur, org, stride = pad_plane(clip[i + 1], MARGIN)
+                    ref, _, _ = pad_plane(clip[i], MARGIN)
+                    rf.me_config(cur, org, stride, QP, method, SUBME)
+                    c0 = time.perf_counter()
+                    exp = rf.me_search_batch(ref, org, stride, host_jobs[i])
+                    ref_s += time.perf_counter() - c0
+                    if not (np.array_equal(res[i]["mv"], exp["mv"]) and np.array_equal(res[i]["cost"], exp["cost"])):
+                        print("PARITY FAILURE: GPU results of frame pair %d differ from the reference build" % i, file=sys.stderr)
+                        sys.exit(2)
+                    ref_px += workload.pixel_sads(host_jobs[i], res[i])
+                cpu = {"value": ref_px / ref_s / 1e9, "unit": "Gpixel-SAD/s", "cores": 1, "kind": "reference",
+                       "sample": "all %d PU searches of %d of the %d frame pairs of one step through the reference's own "
+                                 "MotionEstimate::motionEstimate + C primitives (oracle/_ref, g++ -O2 -ffast-math as the "
+                                 "reference builds, one thread, %.1f s); MVs and costs compared with the GPU's. The oracle "
+                                 "port ran %d pairs in %.1f s (also compared)" % (njobs * nref, nref, B, ref_s, ncpu, cpu_s),
+                       "port_value": cpu_px / cpu_s / 1e9}
         kernel = {"split": "search_kernel<uint8_t,false>, the launch over a frame's %d 16x16 + 8x8 PUs (its 64/32 PUs run "
                            "concurrently on a second stream)" % timed_cnt,
                   "single": "search_kernel<uint8_t,false>, one launch per frame (%d PUs)" % timed_cnt,

@@ -295,6 +295,14 @@ class Ref:
                                     i16(qmvp), len(mvc), cand, merange, out)
         return (out[0], out[1]), cost
 
+    def me_search_batch(self, plane, origin, stride, jobs):
+        """All jobs (40-byte records) against one full-pel reference plane; me_config first. Returns 16-byte records."""
+        res = np.zeros(len(jobs), np.dtype([("mv", "<i2", (2,)), ("cost", "<i4"), ("sad_calls", "<u4"), ("subpel_calls", "<u4")]))
+        jobs = np.ascontiguousarray(jobs)
+        assert jobs.dtype.itemsize == 40
+        self.L.ref_me_search_batch(self.h, _p(plane, origin), stride, _p(jobs), len(jobs), _p(res))
+        return res
+
     def subpel_compare(self, off, w, h, plane, origin, stride, qmv, cmp):
         return self.L.ref_me_subpel_compare(self.h, off, w, h, _p(plane, origin), stride, qmv[0], qmv[1], cmp)
 

@@ -155,6 +155,30 @@ int ref_me_search(void *h, int offset, int w, int hgt,
     return cost;
 }
 
+/* Batch form of ref_me_search for timing the reference without per-call binding overhead:
+ * jobs / results use the 40-byte / 16-byte records of include/x265_amd_me.h (sad_calls and
+ * subpel_calls are left 0: the reference does not count them). */
+struct HarnessJob { int16_t pu_x, pu_y; uint8_t w, h, numc, reserved; int16_t mvmin[2], mvmax[2], qmvp[2]; int16_t mvc[4][2]; int32_t merange; };
+struct HarnessResult { int16_t mv[2]; int32_t cost; uint32_t sad_calls, subpel_calls; };
+void ref_me_search_batch(void *h, pixel *plane, int stride, const HarnessJob *jobs, int n, HarnessResult *out)
+{
+    RefME *r = (RefME*)h;
+    r->ref.fpelPlane = plane;
+    r->ref.lumaStride = stride;
+    r->ref.isLowres = false;
+    for (int i = 0; i < n; i++)
+    {
+        const HarnessJob &j = jobs[i];
+        r->me.setSourcePU(j.pu_y * stride + j.pu_x, j.w, j.h);
+        MV cand[4], mv;
+        for (int k = 0; k < j.numc && k < 4; k++) cand[k] = MV(j.mvc[k][0], j.mvc[k][1]);
+        out[i].cost = r->me.motionEstimate(&r->ref, MV(j.mvmin[0], j.mvmin[1]), MV(j.mvmax[0], j.mvmax[1]),
+                                           MV(j.qmvp[0], j.qmvp[1]), j.numc, cand, j.merange, mv);
+        out[i].mv[0] = mv.x; out[i].mv[1] = mv.y;
+        out[i].sad_calls = out[i].subpel_calls = 0;
+    }
+}
+
 /* subpelCompare at one qpel MV with sad (cmp=0) or satd (cmp=1); motion.cpp:1651 */
 int ref_me_subpel_compare(void *h, int offset, int w, int hgt, pixel *plane, int stride,
                           int qx, int qy, int cmp)

@@ -1315,18 +1315,14 @@ int x265amd_lookahead_frame_costs_dev(x265amd_ctx *c, const void *d_frames, int 
     if (!nframes) return X265AMD_OK;
     HIPCHK(c, hipSetDevice(c->device));
     const FrameCostDev *fr = (const FrameCostDev*)d_frames;
-    const int ncu = wcu * hcu;
-    hipLaunchKernelGGL(la_cost_init_kernel, dim3(nframes), dim3(256), 0, c->stream, fr, hcu);
+    hipLaunchKernelGGL(la_cost_init_kernel, dim3(nframes), dim3(64), 0, c->stream, fr);
     if (c->depth <= 8)
     {
-        hipLaunchKernelGGL(la_intra_kernel, dim3((ncu + LA_INTRA_WAVES - 1) / LA_INTRA_WAVES, nframes), dim3(LA_INTRA_WAVES * 64), 0,
-                           c->stream, fr, wcu, hcu);
-        hipLaunchKernelGGL(la_cost_kernel<uint8_t>, dim3((ncu + LA_COST_THREADS / 4 - 1) / (LA_COST_THREADS / 4), nframes),
-                           dim3(LA_COST_THREADS), 0, c->stream, fr, wcu, hcu);
+        hipLaunchKernelGGL(la_intra_kernel, dim3(hcu, nframes), dim3(LA_INTRA_WAVES * 64), 0, c->stream, fr, wcu, hcu);
+        hipLaunchKernelGGL(la_cost_kernel<uint8_t>, dim3(hcu, nframes), dim3(LA_COST_THREADS), 0, c->stream, fr, wcu, hcu);
     }
     else
-        hipLaunchKernelGGL(la_cost_kernel<uint16_t>, dim3((ncu + LA_COST_THREADS / 4 - 1) / (LA_COST_THREADS / 4), nframes),
-                           dim3(LA_COST_THREADS), 0, c->stream, fr, wcu, hcu);
+        hipLaunchKernelGGL(la_cost_kernel<uint16_t>, dim3(hcu, nframes), dim3(LA_COST_THREADS), 0, c->stream, fr, wcu, hcu);
     HIPCHK(c, hipGetLastError());
     return X265AMD_OK;
 }

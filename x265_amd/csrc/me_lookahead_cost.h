@@ -2,14 +2,15 @@
  * 8x8 lowres CU besides the motion search, and the sums CostEstimate::estimateFrameCost
  * forms from it (reference: source/encoder/slicetype.cpp:1471-1581, :1193-1204).
  *
- * None of it depends on a neighbouring CU, so unlike the search (an anti-diagonal
- * wavefront) these kernels are flat over the CUs of all frames of a batch:
- *   la_cost_init_kernel   clears the accumulators of a frame
- *   la_intra_kernel       35-mode intra SATD of a CU: one wave per CU, one lane per
- *                         (mode, 4x4 tile), prediction and Hadamard in registers
- *   la_cost_kernel        bidirectional candidates, list / intra choice, row and frame
- *                         sums: four lanes per CU (one per 4x4 tile)
- * Sums are integer, so atomic accumulation gives the reference's totals in any order.
+ * None of it depends on a neighbouring CU, so unlike the search (a dependency wavefront)
+ * these kernels are flat: one workgroup per (frame, CU row), which also makes the row sums
+ * plain stores:
+ *   la_cost_init_kernel   clears the frame totals
+ *   la_intra_kernel       35-mode intra SATD: a wave takes every 8th CU of the row, one lane
+ *                         per (mode, 4x4 tile), prediction and Hadamard in registers
+ *   la_cost_kernel        bidirectional candidates, list / intra choice: four lanes per CU
+ *                         (one per 4x4 tile)
+ * Frame totals get one atomic add per row; sums are integer, so the order does not matter.
  */
 #ifndef X265AMD_ME_LOOKAHEAD_COST_H
 #define X265AMD_ME_LOOKAHEAD_COST_H
@@ -43,15 +44,28 @@ __device__ __forceinline__ bool la_scored(int cux, int cuy, int W, int H)
     return (cux > 0 && cux < W - 1 && cuy > 0 && cuy < H - 1) || W <= 2 || H <= 2;
 }
 
-__global__ void la_cost_init_kernel(const FrameCostDev *frames, int hcu)
+__global__ void la_cost_init_kernel(const FrameCostDev *frames)
 {
-    const FrameCostDev &f = frames[blockIdx.x];
-    for (int i = threadIdx.x; i < hcu; i += blockDim.x)
-    {
-        if (!f.intra_calculated) f.row_satds_intra[i] = 0;
-        if (f.d0 + f.d1 > 0) f.row_satds[i] = 0;
-    }
-    if (threadIdx.x < 5) f.totals[threadIdx.x] = 0;
+    if (threadIdx.x < 5) frames[blockIdx.x].totals[threadIdx.x] = 0;
+}
+
+/* Sum of up to three per-thread values over a workgroup of NW waves; the result is valid in
+ * thread 0. Per-wave partial sums stay below 2^31 (a wave adds at most a few hundred costs). */
+template<int NW>
+__device__ __forceinline__ void la_block_sum3(int a, int b, int c, long long out[3])
+{
+    __shared__ int part[NW][3];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    a = seg_sum(a, 6); b = seg_sum(b, 6); c = seg_sum(c, 6);
+    if (lane == 0) { part[wave][0] = a; part[wave][1] = b; part[wave][2] = c; }
+    __syncthreads();
+    if (threadIdx.x == 0)
+        for (int k = 0; k < 3; k++)
+        {
+            long long t = 0;
+            for (int w = 0; w < NW; w++) t += part[w][k];
+            out[k] = t;
+        }
 }
 
 /* ---- intra: slicetype.cpp:1491-1559 ----
@@ -65,7 +79,7 @@ __global__ void la_cost_init_kernel(const FrameCostDev *frames, int hcu)
  *                      projected side samples in front (intrapred.cpp:181-195), so that every
  *                      angular mode reads its main edge through one base address with plain
  *                      signed indexing. */
-#define LA_INTRA_WAVES 4
+#define LA_INTRA_WAVES 8
 #define LA_EDGE_BYTES 20
 #define LA_EXT_BYTES 28
 #define LA_OFF_SRC (4 * LA_EDGE_BYTES)
@@ -102,12 +116,14 @@ __global__ __launch_bounds__(LA_INTRA_WAVES * 64) void la_intra_kernel(const Fra
 {
     __shared__ __attribute__((aligned(4))) uint8_t lds[LA_INTRA_WAVES][LA_INTRA_LDS];
     const FrameCostDev &f = frames[blockIdx.y];
-    if (f.intra_calculated) return;
+    if (f.intra_calculated) return;                            /* block-uniform */
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int cu = blockIdx.x * LA_INTRA_WAVES + wave;
-    if (cu >= W * H) return;                                   /* wave-uniform; no block barrier below */
-    const int cuy = cu / W, cux = cu - cuy * W;
+    const int cuy = blockIdx.x;
     const long stride = f.fenc.stride;
+    int sum_cost = 0, sum_scored = 0, sum_aq = 0;              /* lane 0 of each wave accumulates */
+    for (int cux = wave; cux < W; cux += LA_INTRA_WAVES)
+    {
+    const int cu = cuy * W + cux;
     const uint8_t AS1 *cur = (const uint8_t AS1*)f.fenc.origin + (long)(8 * cuy) * stride + 8 * cux;
     uint8_t *e = lds[wave], *src = e + LA_OFF_SRC, *srct = e + LA_OFF_SRCT, *ext = e + LA_OFF_EXT;
     /* raw edges: lanes 0-16 above, 32-48 left */
@@ -219,13 +235,22 @@ __global__ __launch_bounds__(LA_INTRA_WAVES * 64) void la_intra_kernel(const Fra
     if (lane == 0)
     {
         f.intra_cost[cu] = icost;
-        atomicAdd(&f.row_satds_intra[cuy], icost);
+        sum_cost += icost;
         if (la_scored(cux, cuy, W, H))
         {
-            atomicAdd((unsigned long long*)&f.totals[2], (unsigned long long)icost);
-            if (f.inv_qscale)
-                atomicAdd((unsigned long long*)&f.totals[3], (unsigned long long)(long long)((int)((unsigned)icost * (unsigned)f.inv_qscale[cu] + 128u) >> 8));
+            sum_scored += icost;
+            if (f.inv_qscale) sum_aq += (int)((unsigned)icost * (unsigned)f.inv_qscale[cu] + 128u) >> 8;
         }
+    }
+    wave_sync();                                               /* the next CU overwrites this wave's LDS */
+    }
+    long long tot[3];
+    la_block_sum3<LA_INTRA_WAVES>(sum_cost, sum_scored, sum_aq, tot);
+    if (threadIdx.x == 0)
+    {
+        f.row_satds_intra[cuy] = (int)tot[0];
+        atomicAdd((unsigned long long*)&f.totals[2], (unsigned long long)tot[1]);
+        if (f.inv_qscale) atomicAdd((unsigned long long*)&f.totals[3], (unsigned long long)tot[2]);
     }
 }
 
@@ -254,61 +279,79 @@ template<typename P>
 __global__ __launch_bounds__(LA_COST_THREADS) void la_cost_kernel(const FrameCostDev *frames, int W, int H)
 {
     const FrameCostDev &f = frames[blockIdx.y];
-    const int ncu = W * H;
-    const int cu = blockIdx.x * (LA_COST_THREADS / 4) + (threadIdx.x >> 2), tile = threadIdx.x & 3;
-    const bool live = cu < ncu;
-    const int cuc = live ? cu : 0;
-    const int cuy = cuc / W, cux = cuc - cuy * W;
+    const int cuy = blockIdx.x, tile = threadIdx.x & 3;
     const bool bidir = f.d1 > 0, inter = f.d0 + f.d1 > 0;
-    int bcost = LA_COST_MAX, listused = 0;
-    if (inter)
+    int sum_cost = 0, sum_scored = 0, sum_aq = 0, sum_intra = 0;   /* tile-0 lanes accumulate */
+    for (int cx0 = 0; cx0 < W; cx0 += LA_COST_THREADS / 4)
     {
-        const int c0 = f.mv_costs0[cuc];
-        if (c0 < bcost) { bcost = c0; listused = 1; }
-    }
-    if (bidir)
-    {
-        const int c1 = f.mv_costs1[cuc];
-        if (c1 < bcost) { bcost = c1; listused = 2; }
-        const long off = (long)(8 * cuy + 4 * (tile >> 1)) * f.fenc.stride + 8 * cux + 4 * (tile & 1);
-        const int m0x = f.mvs0[2 * cuc], m0y = f.mvs0[2 * cuc + 1], m1x = f.mvs1[2 * cuc], m1y = f.mvs1[2 * cuc + 1];
-        typename Px<P>::quad s[4], q[4], z[4];
+        const int cux_ = cx0 + (threadIdx.x >> 2);
+        const bool live = cux_ < W;
+        const int cux = live ? cux_ : 0, cu = cuy * W + cux;
+        int bcost = LA_COST_MAX, listused = 0;
+        if (inter)
+        {
+            const int c0 = f.mv_costs0[cu];
+            if (c0 < bcost) { bcost = c0; listused = 1; }
+        }
+        if (bidir)
+        {
+            const int c1 = f.mv_costs1[cu];
+            if (c1 < bcost) { bcost = c1; listused = 2; }
+            const long off = (long)(8 * cuy + 4 * (tile >> 1)) * f.fenc.stride + 8 * cux + 4 * (tile & 1);
+            const int m0x = f.mvs0[2 * cu], m0y = f.mvs0[2 * cu + 1], m1x = f.mvs1[2 * cu], m1y = f.mvs1[2 * cu + 1];
+            typename Px<P>::quad s[4], q[4], z[4];
 #pragma unroll
-        for (int y = 0; y < 4; y++)
-        {
-            s[y] = Px<P>::load_g((const P AS1*)f.fenc.origin + off + (long)y * f.fenc.stride);
-            q[y] = Px<P>::avg(la_mc_quad<P>(f.ref0, off, m0x, m0y, y), la_mc_quad<P>(f.ref1, off, m1x, m1y, y));
-            z[y] = Px<P>::avg(Px<P>::load_g((const P AS1*)f.ref0[0].origin + off + (long)y * f.ref0[0].stride),
-                              Px<P>::load_g((const P AS1*)f.ref1[0].origin + off + (long)y * f.ref1[0].stride));
+            for (int y = 0; y < 4; y++)
+            {
+                s[y] = Px<P>::load_g((const P AS1*)f.fenc.origin + off + (long)y * f.fenc.stride);
+                q[y] = Px<P>::avg(la_mc_quad<P>(f.ref0, off, m0x, m0y, y), la_mc_quad<P>(f.ref1, off, m1x, m1y, y));
+                z[y] = Px<P>::avg(Px<P>::load_g((const P AS1*)f.ref0[0].origin + off + (long)y * f.ref0[0].stride),
+                                  Px<P>::load_g((const P AS1*)f.ref1[0].origin + off + (long)y * f.ref1[0].stride));
+            }
+            const int bi = seg_sum(tile_cost_quads<P>(s, q, true), 2);
+            const int bz = seg_sum(tile_cost_quads<P>(s, z, true), 2);
+            if (bi < bcost) { bcost = bi; listused = 3; }
+            if (bz < bcost) { bcost = bz; listused = 3; }
         }
-        const int bi = seg_sum(tile_cost_quads<P>(s, q, true), 2);
-        const int bz = seg_sum(tile_cost_quads<P>(s, z, true), 2);
-        if (bi < bcost) { bcost = bi; listused = 3; }
-        if (bz < bcost) { bcost = bz; listused = 3; }
+        if (live && !tile)
+        {
+            const bool scored = la_scored(cux, cuy, W, H);
+            if (!bidir)
+            {
+                const int ic = f.intra_cost[cu];
+                if (ic < bcost)
+                {
+                    if (scored) sum_intra++;
+                    bcost = ic;
+                    listused = 0;
+                }
+            }
+            if (inter)
+            {
+                sum_cost += bcost;
+                if (scored)
+                {
+                    sum_scored += bcost;
+                    if (f.inv_qscale) sum_aq += (int)((unsigned)bcost * (unsigned)f.inv_qscale[cu] + 128u) >> 8;
+                }
+            }
+            f.lowres_costs[cu] = (uint16_t)((bcost < 16383 ? bcost : 16383) | (listused << 14));
+        }
     }
-    if (!live || tile) return;
-    const bool scored = la_scored(cux, cuy, W, H);
-    if (!bidir)
+    long long tot[3], tot2[3];
+    la_block_sum3<LA_COST_THREADS / 64>(sum_cost, sum_scored, sum_aq, tot);
+    __syncthreads();
+    la_block_sum3<LA_COST_THREADS / 64>(sum_intra, 0, 0, tot2);
+    if (threadIdx.x == 0)
     {
-        const int ic = f.intra_cost[cu];
-        if (ic < bcost)
+        if (inter)
         {
-            if (scored) atomicAdd((unsigned long long*)&f.totals[4], 1ull);
-            bcost = ic;
-            listused = 0;
+            f.row_satds[cuy] = (int)tot[0];
+            atomicAdd((unsigned long long*)&f.totals[0], (unsigned long long)tot[1]);
+            if (f.inv_qscale) atomicAdd((unsigned long long*)&f.totals[1], (unsigned long long)tot[2]);
         }
+        if (tot2[0]) atomicAdd((unsigned long long*)&f.totals[4], (unsigned long long)tot2[0]);
     }
-    if (inter)
-    {
-        atomicAdd(&f.row_satds[cuy], bcost);
-        if (scored)
-        {
-            atomicAdd((unsigned long long*)&f.totals[0], (unsigned long long)bcost);
-            if (f.inv_qscale)
-                atomicAdd((unsigned long long*)&f.totals[1], (unsigned long long)(long long)((int)((unsigned)bcost * (unsigned)f.inv_qscale[cu] + 128u) >> 8));
-        }
-    }
-    f.lowres_costs[cu] = (uint16_t)((bcost < 16383 ? bcost : 16383) | (listused << 14));
 }
 
 } // namespace x265amd
