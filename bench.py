@@ -266,7 +266,14 @@ def main():
                         "ms_intra_bidir_choice": m["ms_costs"],
                         "frame_costs_per_s": m["frames"] / (m["ms_search"] + m["ms_costs"]) * 1e3,
                         "searched_cus_per_s": m["fields"] * m["cus"] / (m["ms_search"] * 1e-3)}
+                e10 = Engine(local_rank, 10)
+                m10 = measure.pattern_search_picture(e10, dev)
+                e10.close()
                 out["other_paths"] = {
+                    "main10_4k": {"workload": "3840x2160 10-bit, --me star --merange 57 --subme 5, all 64/32/16/8 square PUs of one "
+                                              "picture against one reference (BASELINE configs[3], per reference)",
+                                  "ms_per_picture_reference": m10["ms"], "pu_searches": m10["pus"],
+                                  "value": m10["pixel_sads"] / m10["ms"] / 1e6, "unit": "Gpixel-SAD/s"},
                     "lookahead_frame_cost": dict(la, workload="estimateFrameCost of B-frame triples (b-1, b, b+1): two lowres HEX "
                                                  "subme-1 merange-16 MV fields each, then 35-mode intra, bidirectional candidates, "
                                                  "list choice and row / frame sums (BASELINE configs[4] at 7680x4320)"),

@@ -217,6 +217,46 @@ int x265amd_lookahead_frame_costs_dev(x265amd_ctx *ctx, const void *d_frames, in
 int x265amd_device_alloc(x265amd_ctx *ctx, size_t bytes, void **d_ptr);
 int x265amd_upload(x265amd_ctx *ctx, void *d_dst, const void *src, size_t bytes);
 
+/* ---- explicit weighted prediction ---- */
+
+/* primitives.weight_pp (common/pixel.cpp:512-529) over a whole padded buffer, the way the
+ * lookahead weights Lowres::buffer[i] end to end (encoder/slicetype.cpp:1333-1337): every sample
+ * becomes clip(((w0 * (int16)(v << (14 - depth)) + round) >> shift) + offset). `dst` is
+ * allocated here with `src`'s geometry (release with x265amd_plane_free). Asynchronous on the
+ * engine's stream. */
+int x265amd_weight_buffer(x265amd_ctx *ctx, const x265amd_plane *src, int w0, int round, int shift, int offset,
+                          x265amd_plane *dst);
+
+/* MotionReference::init(pic, wp) + applyWeight over all CTU rows (encoder/reference.cpp:39-71,
+ * :211-256): the weighted copy of a reconstructed reference that motionEstimate then searches
+ * (weight = wp->inputWeight, shift = log2WeightDenom, offset = inputOffset << (depth - 8)), with
+ * its borders replicated from the weighted picture. `dst` is allocated here. Asynchronous. */
+int x265amd_apply_weight(x265amd_ctx *ctx, const x265amd_plane *recon, int input_weight, int log2_denom,
+                         int input_offset, x265amd_plane *dst);
+
+/* CostEstimate::weightCostLuma (encoder/slicetype.cpp:1223-1256): sum over the 8x8 CUs of
+ * min(satd(src block [weighted by (scale, denom, offset) when use_wp], fenc block), intraCost).
+ * fenc / src: lowres full-pel planes; d_intra_cost: DEVICE Lowres::intraCost; *cost: HOST. */
+int x265amd_lookahead_weight_cost(x265amd_ctx *ctx, const x265amd_plane *fenc, const x265amd_plane *src,
+                                  const int32_t *d_intra_cost, int width_in_cu, int height_in_cu,
+                                  int use_wp, int scale, int denom, int offset, uint32_t *cost);
+
+/* CostEstimate::weightsAnalyse (encoder/slicetype.cpp:1258-1340) for frame b (fenc = its
+ * lowresPlane[0]) against frame p0 (ref = its four hpel planes). stats = { fenc wp_ssd[0], fenc
+ * wp_sum[0], ref wp_ssd[0], ref wp_sum[0] } (encoder/ratecontrol.cpp:44-56, :185-192). When a
+ * weight is chosen (out->weighted, CostEstimate::weightedRef.isWeighted) `weighted` receives the
+ * four weighted planes (CostEstimate::wbuffer), to be passed as the list-0 reference of the
+ * lookahead searches and frame cost of (b, p0). Synchronous (two cost evaluations are read back). */
+typedef struct
+{
+    int32_t  weighted;          /* 0: the reference is used as it is */
+    int32_t  scale, denom, offset;  /* w.inputWeight, w.log2WeightDenom, w.inputOffset */
+    uint32_t orig_score, min_score;
+} x265amd_weight;
+int x265amd_weights_analyse(x265amd_ctx *ctx, const x265amd_plane *fenc, const x265amd_plane ref[4],
+                            const int32_t *d_intra_cost, int width_in_cu, int height_in_cu,
+                            const uint64_t stats[4], x265amd_weight *out, x265amd_plane weighted[4]);
+
 /* ---- Rockchip path (rd >= 5): CIME + RIME + FME ---- */
 
 /* One 64x64 CTU against one reference picture: everything the 15-argument

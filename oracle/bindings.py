@@ -204,6 +204,30 @@ class Oracle:
                                         _p(out["lowres_costs"]), _p(out["row_satds_intra"]), _p(out["row_satds"]), _p(out["totals"]))
         return out
 
+    def weight_pp(self, depth, src, so, dst, do, ss, ds, width, height, w0, rnd, shift, offset):
+        self.L.orc_weight_pp(depth, _p(src, so), _p(dst, do), C.c_ssize_t(ss), C.c_ssize_t(ds), width, height, w0, rnd, shift, offset)
+
+    def apply_weight(self, depth, src, origin, stride, width, height, mx, my, weight, denom, offset):
+        dst = np.zeros_like(src)
+        self.L.orc_apply_weight(depth, _p(src, origin), _p(dst, origin), C.c_ssize_t(stride), width, height, mx, my, weight, denom, offset)
+        return dst
+
+    def weight_cost_luma(self, depth, fenc, src, origin, stride, wcu, hcu, intra_cost, wp=None):
+        ic = np.ascontiguousarray(intra_cost, np.int32)
+        self.L.orc_weight_cost_luma.restype = C.c_uint32
+        s, d, o = wp if wp else (0, 0, 0)
+        return self.L.orc_weight_cost_luma(depth, _p(fenc, origin), _p(src, origin), C.c_ssize_t(stride), wcu, hcu, _p(ic),
+                                           int(wp is not None), s, d, o)
+
+    def weights_analyse(self, depth, fenc, ref, origin, stride, wcu, hcu, intra_cost, stats):
+        """Returns (weighted, (scale, denom, offset), (origscore, minscore))."""
+        ic = np.ascontiguousarray(intra_cost, np.int32)
+        st = np.ascontiguousarray(stats, np.uint64)
+        out = np.zeros(3, np.int32)
+        sc = np.zeros(2, np.uint32)
+        w = self.L.orc_weights_analyse(depth, _p(fenc, origin), _p(ref, origin), C.c_ssize_t(stride), wcu, hcu, _p(ic), _p(st), _p(out), _p(sc))
+        return bool(w), tuple(int(v) for v in out), tuple(int(v) for v in sc)
+
 
 def ref_available(depth=8):
     return os.path.exists(os.path.join(HERE, "_ref", "libx265ref%d.so" % (8 if depth <= 8 else 10)))
@@ -406,3 +430,34 @@ class Ref:
                                   _p(out["intra_cost"]), _p(out["lowres_costs"]), _p(out["row_satds_intra"]),
                                   _p(out["row_satds"]), _p(out["totals"]))
         return out
+
+    def weight_pp(self, src, so, dst, do, ss, ds, width, height, w0, rnd, shift, offset):
+        self.L.ref_weight_pp(_p(src, so), _p(dst, do), C.c_ssize_t(ss), C.c_ssize_t(ds), width, height, w0, rnd, shift, offset)
+
+    def apply_weight(self, buf, width, height, mx, my, stride, weight, denom, offset):
+        """MotionReference::init(pic, wp) + applyWeight row by row, by the reference itself; the weighted padded plane."""
+        out = np.zeros_like(buf)
+        assert self.L.ref_apply_weight(_p(buf), width, height, mx, my, stride, weight, denom, offset, _p(out)) == 0
+        return out
+
+    def weight_cost_luma(self, fenc, src, origin, stride, wcu, hcu, intra_cost, wp=None):
+        ic = np.ascontiguousarray(intra_cost, np.int32)
+        scratch = np.zeros(stride * hcu * 8 + 64, fenc.dtype)
+        self.L.ref_weight_cost_luma.restype = C.c_uint32
+        s, d, o = wp if wp else (0, 0, 0)
+        return self.L.ref_weight_cost_luma(_p(fenc, origin), _p(src, origin), stride, wcu, hcu, _p(ic), int(wp is not None), s, d, o,
+                                           _p(scratch))
+
+    def weights_analyse(self, fenc4, ref4, origin, stride, padded_lines, wcu, hcu, intra_cost, stats, delta_index=1):
+        """CostEstimate::weightsAnalyse by the reference itself. ref4: the four padded lowres buffers of the reference
+        (flat arrays whose pixel (0,0) is at `origin`). Returns (weighted, (scale, denom, offset), weighted buffers, delta)."""
+        ic = np.ascontiguousarray(intra_cost, np.int32)
+        st = np.ascontiguousarray(stats, np.uint64)
+        pl = lambda r: (C.c_void_p * 4)(*[p.ctypes.data + origin * p.itemsize for p in r])
+        bufs = (C.c_void_p * 4)(*[p.ctypes.data for p in ref4])
+        wbuf = np.zeros(4 * stride * padded_lines, ref4[0].dtype)
+        out = np.zeros(4, np.int32)
+        delta = C.c_double(0)
+        self.L.ref_weights_analyse(pl(fenc4), pl(ref4), bufs, stride, padded_lines, origin, wcu, hcu, _p(ic), _p(st), delta_index,
+                                   _p(wbuf), _p(out), C.byref(delta))
+        return bool(out[0]), (int(out[1]), int(out[2]), int(out[3])), wbuf.reshape(4, -1), delta.value

@@ -279,3 +279,69 @@ void orc_lookahead_frame_cost(int depth, const void *fenc, const void *const ref
         la_frame_cost_16(depth, fenc, ref0, ref1, stride, widthInCU, heightInCU, d0, d1, intra_calculated, inv_qscale,
                          mvs0, mvcosts0, mvs1, mvcosts1, intra_cost, lowres_costs, row_satds_intra, row_satds, totals);
 }
+
+
+void orc_weight_pp(int depth, const void *src, void *dst, intptr_t ss, intptr_t ds, int width, int height,
+                   int w0, int round, int shift, int offset)
+{
+    if (depth <= 8) weight_pp_8((const uint8_t*)src, (uint8_t*)dst, ss, ds, width, height, w0, round, shift, offset, depth);
+    else weight_pp_16((const uint16_t*)src, (uint16_t*)dst, ss, ds, width, height, w0, round, shift, offset, depth);
+}
+
+void orc_apply_weight(int depth, const void *src_origin, void *dst_origin, intptr_t stride, int width, int height,
+                      int mx, int my, int inputWeight, int log2Denom, int inputOffset)
+{
+    if (depth <= 8) apply_weight_8((const uint8_t*)src_origin, (uint8_t*)dst_origin, stride, width, height, mx, my, inputWeight, log2Denom, inputOffset, depth);
+    else apply_weight_16((const uint16_t*)src_origin, (uint16_t*)dst_origin, stride, width, height, mx, my, inputWeight, log2Denom, inputOffset, depth);
+}
+
+uint32_t orc_weight_cost_luma(int depth, const void *fenc, const void *src, intptr_t stride, int wcu, int hcu,
+                              const int32_t *intra_cost, int use_wp, int scale, int denom, int offset)
+{
+    if (depth <= 8) return weight_cost_luma_8((const uint8_t*)fenc, (const uint8_t*)src, stride, wcu, hcu, intra_cost, use_wp, scale, denom, offset, depth);
+    return weight_cost_luma_16((const uint16_t*)fenc, (const uint16_t*)src, stride, wcu, hcu, intra_cost, use_wp, scale, denom, offset, depth);
+}
+
+/* CostEstimate::weightsAnalyse, slicetype.cpp:1258-1340. Returns 1 when a weight was chosen
+ * (weightedRef.isWeighted); out = { inputWeight, log2WeightDenom, inputOffset }, scores =
+ * { origscore, minscore }. The caller weights the four planes with orc_weight_pp as :1333-1337
+ * do (scale, 1 << (denom - 1 + correction), denom + correction, offset << (depth - 8)). */
+int orc_weights_analyse(int depth, const void *fenc, const void *ref, intptr_t stride, int wcu, int hcu,
+                        const int32_t *intra_cost, const uint64_t stats[4], int out[3], uint32_t scores[2])
+{
+    const float epsilon = 1.f / 128.f;
+    const int lines = hcu * 8, width = wcu * 8;
+    float guessScale, fencMean, refMean;
+    if (stats[0] && stats[2]) guessScale = sqrtf((float)stats[0] / stats[2]);
+    else guessScale = 1.0f;
+    fencMean = (float)stats[1] / (lines * width) / (1 << (depth - 8));
+    refMean = (float)stats[3] / (lines * width) / (1 << (depth - 8));
+    scores[0] = 1; scores[1] = 0;
+    if (fabsf(refMean - fencMean) < 0.5f && fabsf(1.f - guessScale) < epsilon) return 0;
+
+    /* wpScalingParam::setFromWeightAndOffset, TComSlice.h:1274-1286 */
+    int mindenom = 7, minscale = (int)(guessScale * 128 + 0.5f), minoff = 0, found = 0;
+    while (mindenom > 0 && minscale > 127) { mindenom--; minscale >>= 1; }
+    if (minscale > 127) minscale = 127;
+
+    unsigned int minscore, origscore;
+    origscore = minscore = orc_weight_cost_luma(depth, fenc, ref, stride, wcu, hcu, intra_cost, 0, 0, 0, 0);
+    scores[0] = origscore; scores[1] = minscore;
+    if (!minscore) return 0;
+
+    int curScale = minscale;
+    int curOffset = (int)(fencMean - refMean * curScale / (1 << mindenom) + 0.5f);
+    if (curOffset < -128 || curOffset > 127)
+    {
+        curOffset = curOffset < -128 ? -128 : 127;
+        curScale = (int)((1 << mindenom) * (fencMean - curOffset) / refMean + 0.5f);
+        curScale = curScale < 0 ? 0 : (curScale > 127 ? 127 : curScale);
+    }
+    const unsigned int s = orc_weight_cost_luma(depth, fenc, ref, stride, wcu, hcu, intra_cost, 1, curScale, mindenom, curOffset);
+    if (s < minscore) { minscore = s; minscale = curScale; minoff = curOffset; found = 1; }
+    while (mindenom > 0 && !(minscale & 1)) { mindenom--; minscale >>= 1; }
+    scores[1] = minscore;
+    if (!found || (minscale == 1 << mindenom && minoff == 0) || (float)minscore / origscore > 0.998f) return 0;
+    out[0] = minscale; out[1] = mindenom; out[2] = minoff;
+    return 1;
+}

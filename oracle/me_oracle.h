@@ -139,6 +139,20 @@ void orc_lookahead_frame_cost(int depth, const void *fenc, const void *const ref
                               const orc_mv *mvs1, const int32_t *mvcosts1, int32_t *intra_cost, uint16_t *lowres_costs,
                               int32_t *row_satds_intra, int32_t *row_satds, int64_t totals[5]);
 
+/* ---- explicit weighted prediction ----
+ * weight_pp_c (source/common/pixel.cpp:512-529); MotionReference::init + applyWeight over a whole
+ * picture (source/encoder/reference.cpp:39-71, :211-256); CostEstimate::weightCostLuma and
+ * weightsAnalyse of the lookahead (source/encoder/slicetype.cpp:1223-1340; stats = { fenc wp_ssd[0],
+ * fenc wp_sum[0], ref wp_ssd[0], ref wp_sum[0] }). */
+void orc_weight_pp(int depth, const void *src, void *dst, intptr_t ss, intptr_t ds, int width, int height,
+                   int w0, int round, int shift, int offset);
+void orc_apply_weight(int depth, const void *src_origin, void *dst_origin, intptr_t stride, int width, int height,
+                      int mx, int my, int inputWeight, int log2Denom, int inputOffset);
+uint32_t orc_weight_cost_luma(int depth, const void *fenc, const void *src, intptr_t stride, int wcu, int hcu,
+                              const int32_t *intra_cost, int use_wp, int scale, int denom, int offset);
+int orc_weights_analyse(int depth, const void *fenc, const void *ref, intptr_t stride, int wcu, int hcu,
+                        const int32_t *intra_cost, const uint64_t stats[4], int out[3], uint32_t scores[2]);
+
 #ifdef __cplusplus
 }
 #endif

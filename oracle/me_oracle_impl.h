@@ -1213,3 +1213,67 @@ static void FN(la_frame_cost)(int depth, const void *fenc0, const void *const re
     totals[0] = (int64_t)costEst; totals[1] = (int64_t)costEstAq; totals[2] = costIntra;
     totals[3] = (int64_t)costIntraAq; totals[4] = intraMbs;
 }
+
+
+/* ---------------- explicit weighted prediction ---------------- */
+
+/* weight_pp_c, pixel.cpp:512-529: the sample goes through the 14-bit intermediate as an int16 */
+static inline PIXEL FN(weight_px)(PIXEL v, int w0, int round, int shift, int offset, int depth)
+{
+    const int16_t val = (int16_t)(v << (14 - depth));
+    int r = ((w0 * val + round) >> shift) + offset;
+    const int maxv = (1 << depth) - 1;
+    return (PIXEL)(r < 0 ? 0 : (r > maxv ? maxv : r));
+}
+
+static void FN(weight_pp)(const PIXEL *src, PIXEL *dst, intptr_t ss, intptr_t ds, int width, int height,
+                          int w0, int round, int shift, int offset, int depth)
+{
+    for (int y = 0; y < height; y++, src += ss, dst += ds)
+        for (int x = 0; x < width; x++) dst[x] = FN(weight_px)(src[x], w0, round, shift, offset, depth);
+}
+
+/* MotionReference::init + applyWeight over a whole picture (reference.cpp:39-71, :211-256): the
+ * picture area weighted, then replicated into the margins on all sides */
+static void FN(apply_weight)(const PIXEL *src_origin, PIXEL *dst_origin, intptr_t stride, int width, int height,
+                             int mx, int my, int inputWeight, int log2Denom, int inputOffset, int depth)
+{
+    const int offset = inputOffset * (1 << (depth - 8));
+    const int shift = log2Denom + (14 - depth);
+    const int round = shift ? 1 << (shift - 1) : 0;
+    FN(weight_pp)(src_origin, dst_origin, stride, stride, width, height, inputWeight, round, shift, offset, depth);
+    for (int y = 0; y < height; y++)
+    {
+        PIXEL *r = dst_origin + y * stride;
+        for (int x = 1; x <= mx; x++) { r[-x] = r[0]; r[width - 1 + x] = r[width - 1]; }
+    }
+    for (int y = 1; y <= my; y++)
+    {
+        memcpy(dst_origin - mx - y * stride, dst_origin - mx, (width + 2 * mx) * sizeof(PIXEL));
+        memcpy(dst_origin - mx + (height - 1 + y) * stride, dst_origin - mx + (height - 1) * stride, (width + 2 * mx) * sizeof(PIXEL));
+    }
+}
+
+/* CostEstimate::weightCostLuma, slicetype.cpp:1223-1256 */
+static uint32_t FN(weight_cost_luma)(const PIXEL *fenc, const PIXEL *src, intptr_t stride, int wcu, int hcu,
+                                     const int32_t *intra_cost, int use_wp, int scale, int denom, int inputOffset, int depth)
+{
+    const int correction = 14 - depth;
+    uint32_t cost = 0;
+    int mb = 0;
+    for (int y = 0; y < hcu * 8; y += 8)
+        for (int x = 0; x < wcu * 8; x += 8, mb++)
+        {
+            PIXEL blk[64];
+            for (int j = 0; j < 8; j++)
+                for (int i = 0; i < 8; i++)
+                {
+                    const PIXEL v = src[(y + j) * stride + x + i];
+                    blk[j * 8 + i] = use_wp ? FN(weight_px)(v, scale, 1 << (denom - 1 + correction), denom + correction,
+                                                            inputOffset << (depth - 8), depth) : v;
+                }
+            const int satd = FN(satd)(blk, 8, fenc + y * stride + x, stride, 8, 8);
+            cost += satd < intra_cost[mb] ? satd : intra_cost[mb];
+        }
+    return cost;
+}

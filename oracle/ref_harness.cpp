@@ -26,6 +26,7 @@
 #include "reference.h"
 #include "hardwareC/inter.h"
 #include "TLibCommon/TComSlice.h"
+#include "TLibCommon/TComPicYuv.h"
 #include "slicetype.h"
 
 #include <string.h>
@@ -496,6 +497,103 @@ void ref_estimate_frame(pixel **fencPlanes, pixel **ref0Planes, pixel **ref1Plan
     }
     delete[] rows;
     for (int k = 0; k < 3; k++) delete lf[k];
+}
+
+/* ---- lookahead weighted prediction: the reference's own CostEstimate::weightsAnalyse and
+ * weightCostLuma (slicetype.cpp:1223-1340), reached through a subclass because they are
+ * protected. The object is used the way CostEstimate::init leaves it when weightp is on
+ * (:1112-1130): four weighted buffers of stride x paddedLines samples and weightedRef pointing
+ * at their origins; no thread pool, no TEncCfg (neither function reads it).
+ * fencPlanes / refPlanes: origins of the 4 lowres planes of frames b and p0; refBuffers: the
+ * start of the ref's padded buffers (Lowres::buffer[i]). stats = { fenc wp_ssd[0], fenc
+ * wp_sum[0], ref wp_ssd[0], ref wp_sum[0] } (ratecontrol.cpp:44-56, :185-192).
+ * out: [0] isWeighted, [1] inputWeight, [2] log2WeightDenom, [3] inputOffset.
+ * wbuf: 4 * stride * paddedLines samples, the weighted buffers when isWeighted. ---- */
+namespace {
+struct ProbeCE : public CostEstimate
+{
+    ProbeCE() : CostEstimate(NULL) {}
+    void analyse(Lowres **frames, int b, int p0) { weightsAnalyse(frames, b, p0); }
+    uint32_t cost(Lowres **frames, int b, pixel *src, wpScalingParam *wp) { return weightCostLuma(frames, b, src, wp); }
+};
+}
+
+uint32_t ref_weight_cost_luma(pixel *fencPlane0, pixel *src, int stride, int widthInCU, int heightInCU, int32_t *intraCost,
+                              int useWp, int scale, int denom, int offset, pixel *scratch /* stride * lines */)
+{
+    ProbeCE ce;
+    Lowres fenc;
+    fenc.fpelPlane = fenc.lowresPlane[0] = fencPlane0;
+    fenc.lumaStride = stride; fenc.width = widthInCU * 8; fenc.lines = heightInCU * 8;
+    fenc.intraCost = intraCost;
+    Lowres *frames[1] = { &fenc };
+    ce.weightedRef.fpelPlane = scratch;
+    wpScalingParam wp;
+    SET_WEIGHT(wp, 1, scale, denom, offset);
+    return ce.cost(frames, 0, src, useWp ? &wp : NULL);
+}
+
+void ref_weights_analyse(pixel **fencPlanes, pixel **refPlanes, pixel **refBuffers, int stride, int paddedLines, int padOffset,
+                         int widthInCU, int heightInCU, int32_t *intraCost, const uint64_t *stats, int deltaIndex,
+                         pixel *wbuf, int32_t *out, double *costDelta)
+{
+    ProbeCE ce;
+    Lowres fenc, ref;
+    for (int i = 0; i < 4; i++)
+    {
+        fenc.lowresPlane[i] = fencPlanes[i]; ref.lowresPlane[i] = refPlanes[i];
+        ref.buffer[i] = refBuffers[i];
+        ce.wbuffer[i] = wbuf + (size_t)i * stride * paddedLines;
+        ce.weightedRef.lowresPlane[i] = ce.wbuffer[i] + padOffset;
+    }
+    fenc.fpelPlane = fencPlanes[0]; ref.fpelPlane = refPlanes[0];
+    fenc.lumaStride = ref.lumaStride = stride;
+    fenc.width = ref.width = widthInCU * 8; fenc.lines = ref.lines = heightInCU * 8;
+    fenc.intraCost = intraCost;
+    fenc.wp_ssd[0] = stats[0]; fenc.wp_sum[0] = stats[1]; ref.wp_ssd[0] = stats[2]; ref.wp_sum[0] = stats[3];
+    fenc.frameNum = deltaIndex; ref.frameNum = 0;
+    for (int i = 0; i < X265_BFRAME_MAX + 2; i++) fenc.weightedCostDelta[i] = -1.0;
+    ce.weightedRef.fpelPlane = ce.weightedRef.lowresPlane[0];
+    ce.weightedRef.lumaStride = stride;
+    ce.weightedRef.isLowres = true;
+    ce.weightedRef.isWeighted = false;
+    ce.paddedLines = paddedLines;
+    Lowres *frames[2] = { &ref, &fenc };
+    ce.analyse(frames, 1, 0);
+    out[0] = ce.weightedRef.isWeighted; out[1] = ce.w.inputWeight; out[2] = ce.w.log2WeightDenom; out[3] = ce.w.inputOffset;
+    *costDelta = fenc.weightedCostDelta[deltaIndex];
+    for (int i = 0; i < 4; i++) ce.wbuffer[i] = NULL;   /* not the object's to free */
+}
+
+void ref_weight_pp(pixel *src, pixel *dst, intptr_t srcStride, intptr_t dstStride, int width, int height,
+                   int w0, int round, int shift, int offset)
+{
+    primitives.weight_pp(src, dst, srcStride, dstStride, width, height, w0, round, shift, offset);
+}
+
+/* MotionReference::init + applyWeight (reference.cpp:39-71, :211-256) over all CTU rows of a
+ * reconstructed picture described by hand in a TComPicYuv (buffer with margins, stride):
+ * the weighted, border-extended plane comes back in outBuf (same geometry). */
+int ref_apply_weight(pixel *buf, int width, int height, int marginX, int marginY, int stride,
+                     int inputWeight, int log2Denom, int inputOffset, pixel *outBuf)
+{
+    TComPicYuv pic;
+    pic.m_picBufY = buf;
+    pic.m_picOrgY = buf + (size_t)marginY * stride + marginX;
+    pic.m_picWidth = width; pic.m_picHeight = height; pic.m_stride = stride;
+    pic.m_lumaMarginX = marginX; pic.m_lumaMarginY = marginY;
+    pic.m_numCuInHeight = (height + g_maxCUHeight - 1) / g_maxCUHeight;
+    wpScalingParam wp;
+    SET_WEIGHT(wp, 1, inputWeight, log2Denom, inputOffset);
+    MotionReference mref;
+    if (mref.init(&pic, &wp)) return -1;
+    /* CTU row by CTU row, as the frame encoder asks for reference rows (the last row's height is
+     * only right when it is weighted on its own, reference.cpp:221-223) */
+    const int numRows = pic.m_numCuInHeight;
+    for (int r = 1; r <= numRows; r++) mref.applyWeight(r, numRows);
+    const size_t rows = (size_t)height + 2 * marginY;
+    memcpy(outBuf, mref.fpelPlane - ((size_t)marginY * stride + marginX), rows * stride * sizeof(pixel));
+    return 0;
 }
 
 } // extern "C"

@@ -159,6 +159,7 @@ def main():
     np.savez_compressed(os.path.join(HERE, "rk_golden.npz"), **rk)
     make_cmodel(shas)
     make_frame_cost(shas)
+    make_wp(shas)
     json.dump(shas, open(os.path.join(HERE, "input_sha.json"), "w"), indent=0, sort_keys=True)
     print("golden vectors written to", HERE)
 
@@ -207,6 +208,56 @@ def make_frame_cost(shas):
     np.savez_compressed(os.path.join(HERE, "framecost_golden.npz"), **out)
 
 
+def wp_stats(img):
+    """wp_sum / wp_ssd of a plane as the rate control computes them (ratecontrol.cpp:44-56, :185-192)."""
+    p = img.astype(np.uint64)
+    n, s, q = p.size, int(p.sum()), int((p * p).sum())
+    return q - (s * s + n // 2) // n, s
+
+
+WP_WEIGHTS = ((64, 6, 0), (50, 6, 7), (127, 7, -20), (33, 5, 100), (1, 0, 3), (90, 6, -128))
+WP_FADES = ((1.0, 0), (0.8, 10), (0.6, -5), (1.3, 0), (1.0, 30))
+
+
+def wp_fade_frames(depth, fade, off):
+    """(faded frame b, reference frame p0) of the weighted-prediction vectors."""
+    clip = make_clip(LA_W, LA_H, 2, seed=3, depth=depth)
+    maxv = (1 << depth) - 1
+    f = np.clip(clip[1].astype(np.float64) * fade + off * (1 << (depth - 8)), 0, maxv).astype(clip[1].dtype)
+    return f, clip[0]
+
+
+def wp_intra_costs(ncu):
+    return np.random.default_rng(123).integers(300, 4000, ncu).astype(np.int32)
+
+
+def make_wp(shas):
+    """MotionReference::applyWeight, CostEstimate::weightCostLuma and weightsAnalyse run by the reference itself."""
+    out = {}
+    for depth in (8, 10):
+        ref = Ref(depth)
+        img = make_clip(200, 136, 1, seed=5, depth=depth)[0]
+        buf, org, stride = pad_plane(img, 48, 32)
+        shas["wp_apply_%d" % depth] = sha(buf)
+        for (w, d, o) in WP_WEIGHTS:
+            out["%d_apply_%d_%d_%d" % (depth, w, d, o)] = np.frombuffer(bytes.fromhex(sha(ref.apply_weight(buf, 200, 136, 48, 32, stride, w, d, o))), np.uint8)
+        for fade, off in WP_FADES:
+            f, r = wp_fade_frames(depth, fade, off)
+            PF = host_lowres_planes(ref_as_orc(ref), depth, f, 64)
+            PR = host_lowres_planes(ref_as_orc(ref), depth, r, 64)
+            org, stride, wcu, hcu = PF[1], PF[2], PF[3], PF[4]
+            ic = wp_intra_costs(wcu * hcu)
+            padded = PF[6] + 128
+            key = "%d_fade_%g_%d" % (depth, fade, off)
+            weighted, w, wbuf, _ = ref.weights_analyse(PF[0], PR[0], org, stride, padded, wcu, hcu, ic, wp_stats(f) + wp_stats(r))
+            out[key + "_decision"] = np.array([int(weighted)] + (list(w) if weighted else [0, 0, 0]), np.int32)
+            out[key + "_cost_plain"] = np.array([ref.weight_cost_luma(PF[0][0], PR[0][0], org, stride, wcu, hcu, ic)], np.uint32)
+            out[key + "_cost_wp"] = np.array([ref.weight_cost_luma(PF[0][0], PR[0][0], org, stride, wcu, hcu, ic, (50, 6, 7))], np.uint32)
+            if weighted:
+                out[key + "_planes"] = np.stack([np.frombuffer(bytes.fromhex(sha(wbuf[i])), np.uint8) for i in range(4)])
+    np.savez_compressed(os.path.join(HERE, "wp_golden.npz"), **out)
+
+
 def make_cmodel(shas):
     """Records of the reference's hardware C-model: coarse stage (CoarseIntMotionEstimation::CIME,
     hardwareC/inter.cpp:679-734), refine + fractional stages for the 85 CUs of each CTU
@@ -233,11 +284,11 @@ def make_cmodel(shas):
 
 
 if __name__ == "__main__":
-    if sys.argv[1:] in (["cmodel"], ["framecost"]):
+    if sys.argv[1:] in (["cmodel"], ["framecost"], ["wp"]):
         # only (re)generate the C-model / frame-cost records, keeping the other files as they are
         shas_path = os.path.join(HERE, "input_sha.json")
         shas_ = json.load(open(shas_path))
-        (make_cmodel if sys.argv[1] == "cmodel" else make_frame_cost)(shas_)
+        {"cmodel": make_cmodel, "framecost": make_frame_cost, "wp": make_wp}[sys.argv[1]](shas_)
         json.dump(shas_, open(shas_path, "w"), indent=0, sort_keys=True)
     else:
         main()

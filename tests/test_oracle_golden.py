@@ -127,3 +127,33 @@ def test_lookahead_frame_cost(oracle):
                                           inv_qscale=G.frame_cost_inv_qscale(wcu * hcu) if aq else None)
         for k in ("intra_cost", "lowres_costs", "row_satds_intra", "totals") + (("row_satds",) if d0 else ()):
             assert np.array_equal(out[k], g[name + "_" + k]), (name, k)
+
+
+@pytest.mark.parametrize("depth", [8, 10])
+def test_weighted_prediction(oracle, depth):
+    """applyWeight, weightCostLuma and weightsAnalyse against the reference's own records."""
+    from x265_amd.synth import pad_plane
+    g = G.wp_golden()
+    img = make_clip(200, 136, 1, seed=5, depth=depth)[0]
+    buf, org, stride = pad_plane(img, 48, 32)
+    assert G.sha(buf) == G.input_shas()["wp_apply_%d" % depth]
+    for (w, d, o) in G.WP_WEIGHTS:
+        got = oracle.apply_weight(depth, buf, org, stride, 200, 136, 48, 32, w, d, o)
+        assert np.array_equal(G.sha_bytes(got), g["%d_apply_%d_%d_%d" % (depth, w, d, o)]), (w, d, o)
+    for fade, off in G.WP_FADES:
+        f, r = G.wp_fade_frames(depth, fade, off)
+        PF, PR = host_lowres_planes(oracle, depth, f, 64), host_lowres_planes(oracle, depth, r, 64)
+        org, stride, wcu, hcu = PF[1], PF[2], PF[3], PF[4]
+        ic = G.wp_intra_costs(wcu * hcu)
+        key = "%d_fade_%g_%d" % (depth, fade, off)
+        assert oracle.weight_cost_luma(depth, PF[0][0], PR[0][0], org, stride, wcu, hcu, ic) == g[key + "_cost_plain"][0]
+        assert oracle.weight_cost_luma(depth, PF[0][0], PR[0][0], org, stride, wcu, hcu, ic, (50, 6, 7)) == g[key + "_cost_wp"][0]
+        weighted, w, _ = oracle.weights_analyse(depth, PF[0][0], PR[0][0], org, stride, wcu, hcu, ic, G.wp_stats(f) + G.wp_stats(r))
+        assert [int(weighted)] + (list(w) if weighted else [0, 0, 0]) == list(g[key + "_decision"]), key
+        if weighted:
+            corr, padded = 14 - depth, PF[6] + 128
+            for i in range(4):
+                out = np.zeros_like(PR[0][i])
+                oracle.weight_pp(depth, PR[0][i], 0, out, 0, stride, stride, stride, padded, w[0], 1 << (w[1] - 1 + corr), w[1] + corr,
+                                 w[2] << (depth - 8))
+                assert np.array_equal(G.sha_bytes(out[:stride * padded]), g[key + "_planes"][i]), (key, i)

@@ -210,3 +210,34 @@ def test_lookahead_frame_cost_vs_reference(oracle):
                                                  R["mvs1"], R["mvcosts1"], R["intra_cost"], invq)
                 for k in ("lowres_costs", "row_satds", "totals"):
                     assert np.array_equal(R2[k], O2[k]), (w, h, b, d0, d1, k, "repeat")
+
+
+def test_weighted_prediction_vs_reference(oracle, ref):
+    """Randomised weights through MotionReference::applyWeight and CostEstimate::weightCostLuma, and fades through
+    CostEstimate::weightsAnalyse, reference against oracle."""
+    from x265_amd.synth import make_clip, pad_plane
+    from util import host_lowres_planes
+    import golden_util as G
+    depth = ref.depth
+    rng = np.random.default_rng(31)
+    img = make_clip(180, 100, 1, seed=9, depth=depth)[0]     # width not a multiple of 16, two CTU rows
+    buf, org, stride = pad_plane(img, 40, 24)
+    for _ in range(12):
+        w, d, o = int(rng.integers(0, 128)), int(rng.integers(0, 8)), int(rng.integers(-128, 128))
+        assert np.array_equal(ref.apply_weight(buf, 180, 100, 40, 24, stride, w, d, o),
+                              oracle.apply_weight(depth, buf, org, stride, 180, 100, 40, 24, w, d, o)), (w, d, o)
+    maxv = (1 << depth) - 1
+    clip = make_clip(200, 120, 2, seed=4, depth=depth)
+    for fade, off in ((0.5, 0), (0.7, 20), (0.9, -12), (1.1, 5), (1.5, -30), (1.0, 1), (0.3, 60)):
+        f = np.clip(clip[1].astype(np.float64) * fade + off * (1 << (depth - 8)), 0, maxv).astype(clip[1].dtype)
+        PF, PR = host_lowres_planes(oracle, depth, f, 64), host_lowres_planes(oracle, depth, clip[0], 64)
+        org, stride, wcu, hcu = PF[1], PF[2], PF[3], PF[4]
+        ic = rng.integers(200, 6000, wcu * hcu).astype(np.int32)
+        stats = G.wp_stats(f) + G.wp_stats(clip[0])
+        R = ref.weights_analyse(PF[0], PR[0], org, stride, PF[6] + 128, wcu, hcu, ic, stats)
+        O = oracle.weights_analyse(depth, PF[0][0], PR[0][0], org, stride, wcu, hcu, ic, stats)
+        assert R[0] == O[0] and (not R[0] or R[1] == O[1]), (fade, off, R[:2], O)
+        wp = (int(rng.integers(1, 128)), int(rng.integers(1, 8)), int(rng.integers(-128, 128)))
+        for p in (None, wp):
+            assert ref.weight_cost_luma(PF[0][0], PR[0][0], org, stride, wcu, hcu, ic, p) == \
+                oracle.weight_cost_luma(depth, PF[0][0], PR[0][0], org, stride, wcu, hcu, ic, p), (fade, off, p)

@@ -1345,6 +1345,144 @@ int x265amd_upload(x265amd_ctx *c, void *d_dst, const void *src, size_t bytes)
     return X265AMD_OK;
 }
 
+/* ---- explicit weighted prediction ---- */
+
+static int weight_args_ok(int w0, int shift)
+{
+    return w0 >= -128 && w0 <= 255 && shift >= 0 && shift <= 20;
+}
+
+int x265amd_weight_buffer(x265amd_ctx *c, const x265amd_plane *src, int w0, int round, int shift, int offset, x265amd_plane *dst)
+{
+    if (!c || !src || !src->origin || !dst) return fail(c, X265AMD_EINVAL, "null plane");
+    if (!weight_args_ok(w0, shift)) return fail(c, X265AMD_EINVAL, "weight / shift out of range");
+    int rc = plane_alloc(c, src->width, src->height, src->margin_x, src->margin_y, src->stride, dst);
+    if (rc) return rc;
+    const int bpp = c->depth > 8 ? 2 : 1;
+    const size_t pad = ((size_t)src->margin_y * src->stride + src->margin_x) * bpp;
+    const long nvec = (long)((plane_bytes(c, src->height, src->margin_y, src->stride) + 15) / 16);
+    const uint4 *s = (const uint4*)((const char*)src->origin - pad);
+    if ((uintptr_t)s & 15) return fail(c, X265AMD_EINVAL, "source buffer is not 16-byte aligned (planes made by this library are)");
+    uint4 *d = (uint4*)((char*)dst->origin - pad);
+    if (c->depth <= 8)
+        hipLaunchKernelGGL(weight_buffer_kernel<uint8_t>, dim3((unsigned)((nvec + 255) / 256)), dim3(256), 0, c->stream, s, d, nvec, w0, round, shift, offset, c->depth);
+    else
+        hipLaunchKernelGGL(weight_buffer_kernel<uint16_t>, dim3((unsigned)((nvec + 255) / 256)), dim3(256), 0, c->stream, s, d, nvec, w0, round, shift, offset, c->depth);
+    HIPCHK(c, hipGetLastError());
+    return X265AMD_OK;
+}
+
+int x265amd_apply_weight(x265amd_ctx *c, const x265amd_plane *recon, int input_weight, int log2_denom, int input_offset, x265amd_plane *dst)
+{
+    if (!c || !recon || !recon->origin || !dst) return fail(c, X265AMD_EINVAL, "null plane");
+    /* reference.cpp:60-63, :226-228 */
+    const int offset = input_offset * (1 << (c->depth - 8));
+    const int shift = log2_denom + (14 - c->depth);
+    const int round = shift ? 1 << (shift - 1) : 0;
+    if (log2_denom < 0 || !weight_args_ok(input_weight, shift)) return fail(c, X265AMD_EINVAL, "weight / denominator out of range");
+    const int padwidth = (recon->width + 15) & ~15;
+    if (padwidth - recon->width > recon->margin_x) return fail(c, X265AMD_EINVAL, "margin_x smaller than the 16-column rounding of the width");
+    int rc = plane_alloc(c, recon->width, recon->height, recon->margin_x, recon->margin_y, recon->stride, dst);
+    if (rc) return rc;
+    dim3 blk(64, 4), grd((padwidth / 4 + 63) / 64, (recon->height + 3) / 4);
+    dim3 grd2((recon->width + 2 * recon->margin_x + 63) / 64, (recon->height + 2 * recon->margin_y + 3) / 4);
+    if (c->depth <= 8)
+    {
+        hipLaunchKernelGGL(weight_picture_kernel<uint8_t>, grd, blk, 0, c->stream, (const uint8_t*)recon->origin, (uint8_t*)dst->origin,
+                           (long)recon->stride, padwidth / 4, recon->height, input_weight, round, shift, offset, c->depth);
+        hipLaunchKernelGGL(extend_border_kernel<uint8_t>, grd2, blk, 0, c->stream, (uint8_t*)dst->origin, (long)recon->stride,
+                           recon->width, recon->height, recon->margin_x, recon->margin_y);
+    }
+    else
+    {
+        hipLaunchKernelGGL(weight_picture_kernel<uint16_t>, grd, blk, 0, c->stream, (const uint16_t*)recon->origin, (uint16_t*)dst->origin,
+                           (long)recon->stride, padwidth / 4, recon->height, input_weight, round, shift, offset, c->depth);
+        hipLaunchKernelGGL(extend_border_kernel<uint16_t>, grd2, blk, 0, c->stream, (uint16_t*)dst->origin, (long)recon->stride,
+                           recon->width, recon->height, recon->margin_x, recon->margin_y);
+    }
+    HIPCHK(c, hipGetLastError());
+    return X265AMD_OK;
+}
+
+int x265amd_lookahead_weight_cost(x265amd_ctx *c, const x265amd_plane *fenc, const x265amd_plane *src, const int32_t *d_intra_cost,
+                                  int wcu, int hcu, int use_wp, int scale, int denom, int offset, uint32_t *cost)
+{
+    if (!c || !fenc || !src || !fenc->origin || !src->origin || !d_intra_cost || !cost || wcu <= 0 || hcu <= 0)
+        return fail(c, X265AMD_EINVAL, "null argument");
+    if (fenc->width < wcu * 8 || fenc->height < hcu * 8 || src->width < wcu * 8 || src->height < hcu * 8)
+        return fail(c, X265AMD_EINVAL, "planes smaller than the CU grid");
+    /* slicetype.cpp:1230-1237 */
+    const int correction = 14 - c->depth;
+    const int shift = denom + correction, round = use_wp ? 1 << (denom - 1 + correction) : 0;
+    if (use_wp && (denom < 0 || shift < 1 || !weight_args_ok(scale, shift))) return fail(c, X265AMD_EINVAL, "weight / denominator out of range");
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipMemsetAsync(c->d_out, 0, sizeof(uint32_t), c->stream));
+    PlaneDev f = { fenc->origin, fenc->stride }, s = { src->origin, src->stride };
+    if (c->depth <= 8)
+        hipLaunchKernelGGL(la_weight_cost_kernel<uint8_t>, dim3(hcu), dim3(LA_COST_THREADS), 0, c->stream, f, s, d_intra_cost, wcu,
+                           use_wp, scale, round, shift, offset << (c->depth - 8), c->depth, (unsigned int*)c->d_out);
+    else
+        hipLaunchKernelGGL(la_weight_cost_kernel<uint16_t>, dim3(hcu), dim3(LA_COST_THREADS), 0, c->stream, f, s, d_intra_cost, wcu,
+                           use_wp, scale, round, shift, offset << (c->depth - 8), c->depth, (unsigned int*)c->d_out);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipMemcpyAsync(cost, c->d_out, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return X265AMD_OK;
+}
+
+/* CostEstimate::weightsAnalyse (slicetype.cpp:1258-1340): the float bookkeeping runs here on the
+ * host exactly as the reference's, the two cost evaluations and the weighting of the four planes
+ * on the device */
+int x265amd_weights_analyse(x265amd_ctx *c, const x265amd_plane *fenc, const x265amd_plane ref[4], const int32_t *d_intra_cost,
+                            int wcu, int hcu, const uint64_t stats[4], x265amd_weight *out, x265amd_plane weighted[4])
+{
+    if (!c || !fenc || !ref || !d_intra_cost || !stats || !out || !weighted) return fail(c, X265AMD_EINVAL, "null argument");
+    const float epsilon = 1.f / 128.f;
+    const int lines = hcu * 8, width = wcu * 8, depth = c->depth;
+    memset(out, 0, sizeof(*out));
+    out->orig_score = 1;
+    float guessScale, fencMean, refMean;
+    if (stats[0] && stats[2]) guessScale = sqrtf((float)stats[0] / stats[2]);
+    else guessScale = 1.0f;
+    fencMean = (float)stats[1] / (lines * width) / (1 << (depth - 8));
+    refMean = (float)stats[3] / (lines * width) / (1 << (depth - 8));
+    if (fabsf(refMean - fencMean) < 0.5f && fabsf(1.f - guessScale) < epsilon) return X265AMD_OK;
+
+    /* wpScalingParam::setFromWeightAndOffset (TComSlice.h:1274-1286) */
+    int mindenom = 7, minscale = (int)(guessScale * 128 + 0.5f), minoff = 0, found = 0;
+    while (mindenom > 0 && minscale > 127) { mindenom--; minscale >>= 1; }
+    if (minscale > 127) minscale = 127;
+
+    uint32_t minscore = 0, origscore = 1, s = 0;
+    int rc = x265amd_lookahead_weight_cost(c, fenc, &ref[0], d_intra_cost, wcu, hcu, 0, 0, 0, 0, &minscore);
+    if (rc) return rc;
+    origscore = minscore;
+    out->orig_score = origscore; out->min_score = minscore;
+    if (!minscore) return X265AMD_OK;
+
+    int curScale = minscale;
+    int curOffset = (int)(fencMean - refMean * curScale / (1 << mindenom) + 0.5f);
+    if (curOffset < -128 || curOffset > 127)
+    {
+        curOffset = curOffset < -128 ? -128 : 127;
+        curScale = (int)((1 << mindenom) * (fencMean - curOffset) / refMean + 0.5f);
+        curScale = curScale < 0 ? 0 : (curScale > 127 ? 127 : curScale);
+    }
+    if ((rc = x265amd_lookahead_weight_cost(c, fenc, &ref[0], d_intra_cost, wcu, hcu, 1, curScale, mindenom, curOffset, &s))) return rc;
+    if (s < minscore) { minscore = s; minscale = curScale; minoff = curOffset; found = 1; }
+    while (mindenom > 0 && !(minscale & 1)) { mindenom--; minscale >>= 1; }
+    out->min_score = minscore;
+    if (!found || (minscale == 1 << mindenom && minoff == 0) || (float)minscore / origscore > 0.998f) return X265AMD_OK;
+
+    const int correction = 14 - depth;
+    for (int i = 0; i < 4; i++)
+        if ((rc = x265amd_weight_buffer(c, &ref[i], minscale, 1 << (mindenom - 1 + correction), mindenom + correction,
+                                        minoff << (depth - 8), &weighted[i])))
+            return rc;
+    out->weighted = 1; out->scale = minscale; out->denom = mindenom; out->offset = minoff;
+    return X265AMD_OK;
+}
+
 int x265amd_rk_ds_plane(x265amd_ctx *c, const x265amd_plane *orig, x265amd_plane *out)
 {
     if (!c || !orig || !orig->origin || !out) return fail(c, X265AMD_EINVAL, "null plane");

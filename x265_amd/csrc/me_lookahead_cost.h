@@ -354,5 +354,111 @@ __global__ __launch_bounds__(LA_COST_THREADS) void la_cost_kernel(const FrameCos
     }
 }
 
+/* ---- explicit weighted prediction ---- */
+
+/* weight_pp_c (pixel.cpp:512-529) on four packed samples: through the 14-bit intermediate as
+ * int16, (w0 * v + round) >> shift, + offset, clipped to the sample range */
+template<typename P>
+__device__ __forceinline__ typename Px<P>::quad weight_quad(typename Px<P>::quad q, int w0, int round, int shift, int offset, int depth)
+{
+    int v[4];
+    Px<P>::unpack(q, v);
+    const int maxv = (1 << depth) - 1;
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+    {
+        int r = ((w0 * as_i16(v[i] << (14 - depth)) + round) >> shift) + offset;
+        v[i] = r < 0 ? 0 : (r > maxv ? maxv : r);
+    }
+    if constexpr (sizeof(P) == 1)
+        return (uint32_t)v[0] | ((uint32_t)v[1] << 8) | ((uint32_t)v[2] << 16) | ((uint32_t)v[3] << 24);
+    else
+        return make_uint2((uint32_t)v[0] | ((uint32_t)v[1] << 16), (uint32_t)v[2] | ((uint32_t)v[3] << 16));
+}
+
+/* A whole padded buffer (the lookahead weights Lowres::buffer[i] end to end, slicetype.cpp:1333-1337):
+ * flat, 16 bytes per thread. Both buffers start 16-byte aligned and are padded to a multiple of 16. */
+template<typename P>
+__global__ void weight_buffer_kernel(const uint4 *src, uint4 *dst, long nvec, int w0, int round, int shift, int offset, int depth)
+{
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nvec) return;
+    const uint4 a = src[i];
+    uint4 o;
+    if constexpr (sizeof(P) == 1)
+    {
+        o.x = weight_quad<P>(a.x, w0, round, shift, offset, depth); o.y = weight_quad<P>(a.y, w0, round, shift, offset, depth);
+        o.z = weight_quad<P>(a.z, w0, round, shift, offset, depth); o.w = weight_quad<P>(a.w, w0, round, shift, offset, depth);
+    }
+    else
+    {
+        const uint2 lo = weight_quad<P>(make_uint2(a.x, a.y), w0, round, shift, offset, depth);
+        const uint2 hi = weight_quad<P>(make_uint2(a.z, a.w), w0, round, shift, offset, depth);
+        o = make_uint4(lo.x, lo.y, hi.x, hi.y);
+    }
+    dst[i] = o;
+}
+
+/* The picture area of a reference (MotionReference::applyWeight weights (width + 15) & ~15 columns
+ * of every row, reference.cpp:227-229; the overshoot lands in the margin and is overwritten by the
+ * border extension that follows). One thread per four samples. */
+template<typename P>
+__global__ void weight_picture_kernel(const P *src, P *dst, long stride, int quads, int height, int w0, int round, int shift, int offset, int depth)
+{
+    const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y * blockDim.y + threadIdx.y;
+    if (x >= quads || y >= height) return;
+    const long o = (long)y * stride + 4 * x;
+    const typename Px<P>::quad q = weight_quad<P>(Px<P>::load(src + o), w0, round, shift, offset, depth);
+    if constexpr (sizeof(P) == 1)
+    {
+        typedef uint32_t __attribute__((aligned(1))) u32u;
+        *(u32u*)(dst + o) = q;
+    }
+    else
+    {
+        typedef uint32_t __attribute__((aligned(2))) u32u;
+        ((u32u*)(dst + o))[0] = q.x;
+        ((u32u*)(dst + o))[1] = q.y;
+    }
+}
+
+/* CostEstimate::weightCostLuma (slicetype.cpp:1223-1256): sum over the 8x8 blocks of
+ * min(SATD(weighted reference block, source block), intraCost). One workgroup per CU row, four
+ * lanes per block, the weighting applied to the loaded samples instead of a weighted copy. */
+template<typename P>
+__global__ __launch_bounds__(LA_COST_THREADS) void la_weight_cost_kernel(PlaneDev fenc, PlaneDev srcp, const int32_t *intra_cost, int W,
+                                                                         int use_wp, int w0, int round, int shift, int offset, int depth,
+                                                                         unsigned int *out)
+{
+    const int cuy = blockIdx.x, tile = threadIdx.x & 3;
+    int sum = 0;
+    for (int cx0 = 0; cx0 < W; cx0 += LA_COST_THREADS / 4)
+    {
+        const int cux_ = cx0 + (threadIdx.x >> 2);
+        const bool live = cux_ < W;
+        const int cux = live ? cux_ : 0;
+        const long off = (long)(8 * cuy + 4 * (tile >> 1)) * fenc.stride + 8 * cux + 4 * (tile & 1);
+        typename Px<P>::quad s[4], q[4];
+#pragma unroll
+        for (int y = 0; y < 4; y++)
+        {
+            s[y] = Px<P>::load_g((const P AS1*)fenc.origin + off + (long)y * fenc.stride);
+            q[y] = Px<P>::load_g((const P AS1*)srcp.origin + off + (long)y * srcp.stride);
+            if (use_wp) q[y] = weight_quad<P>(q[y], w0, round, shift, offset, depth);
+        }
+        /* satd(src, fenc): the Hadamard abs-sum does not depend on the sign of the difference */
+        const int satd = seg_sum(tile_cost_quads<P>(s, q, true), 2);
+        if (live && !tile)
+        {
+            const int ic = intra_cost[cuy * W + cux];
+            sum += satd < ic ? satd : ic;
+        }
+    }
+    long long tot[3];
+    la_block_sum3<LA_COST_THREADS / 64>(sum, 0, 0, tot);
+    if (threadIdx.x == 0) atomicAdd(out, (unsigned int)tot[0]);
+}
+
 } // namespace x265amd
+
 #endif

@@ -57,6 +57,12 @@ class FrameCost(C.Structure):
                 ("row_satds_intra", C.c_void_p), ("row_satds", C.c_void_p), ("totals", C.c_void_p)]
 
 
+class Weight(C.Structure):
+    """x265amd_weight: outcome of weightsAnalyse."""
+    _fields_ = [("weighted", C.c_int32), ("scale", C.c_int32), ("denom", C.c_int32), ("offset", C.c_int32),
+                ("orig_score", C.c_uint32), ("min_score", C.c_uint32)]
+
+
 class EngineError(RuntimeError):
     pass
 
@@ -212,7 +218,7 @@ class Engine:
         return d
 
     def device_free(self, d):
-        self._chk(self.L.x265amd_device_free(self.ctx, d))
+        self._chk(self.L.x265amd_device_free(self.ctx, C.c_void_p(d) if isinstance(d, int) else d))
 
     def lookahead_fields_dev(self, d_fields, nfields, wcu, hcu, qp, method, subme, merange, d_mvs, d_costs, d_stats=None):
         self._chk(self.L.x265amd_lookahead_fields_dev(self.ctx, d_fields, nfields, wcu, hcu, qp, method, subme, merange,
@@ -314,7 +320,34 @@ class Engine:
         finally:
             self.sync()
             for d in owned:
-                self.device_free(C.c_void_p(d) if isinstance(d, int) else d)
+                self.device_free(d)
+
+    # ---- explicit weighted prediction
+    def weight_buffer(self, src, w0, rnd, shift, offset):
+        out = Plane()
+        self._chk(self.L.x265amd_weight_buffer(self.ctx, C.byref(src), w0, rnd, shift, offset, C.byref(out)))
+        return out
+
+    def apply_weight(self, recon, input_weight, log2_denom, input_offset):
+        out = Plane()
+        self._chk(self.L.x265amd_apply_weight(self.ctx, C.byref(recon), input_weight, log2_denom, input_offset, C.byref(out)))
+        return out
+
+    def lookahead_weight_cost(self, fenc, src, d_intra_cost, wcu, hcu, wp=None):
+        cost = C.c_uint32(0)
+        s, d, o = wp if wp else (0, 0, 0)
+        self._chk(self.L.x265amd_lookahead_weight_cost(self.ctx, C.byref(fenc), C.byref(src), C.c_void_p(d_intra_cost), wcu, hcu,
+                                                       int(wp is not None), s, d, o, C.byref(cost)))
+        return cost.value
+
+    def weights_analyse(self, fenc, ref4, d_intra_cost, wcu, hcu, stats):
+        """Returns (Weight, [4 weighted planes] or None)."""
+        st = (C.c_uint64 * 4)(*[int(v) for v in stats])
+        out = Weight()
+        planes = (Plane * 4)()
+        self._chk(self.L.x265amd_weights_analyse(self.ctx, C.byref(fenc), (Plane * 4)(*ref4), C.c_void_p(d_intra_cost), wcu, hcu,
+                                                 st, C.byref(out), planes))
+        return out, ([planes[i] for i in range(4)] if out.weighted else None)
 
     # ---- Rockchip path
     def rk_ds_plane(self, orig):
