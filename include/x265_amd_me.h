@@ -221,8 +221,11 @@ int x265amd_upload(x265amd_ctx *ctx, void *d_dst, const void *src, size_t bytes)
 
 /* primitives.weight_pp (common/pixel.cpp:512-529) over a whole padded buffer, the way the
  * lookahead weights Lowres::buffer[i] end to end (encoder/slicetype.cpp:1333-1337): every sample
- * becomes clip(((w0 * (int16)(v << (14 - depth)) + round) >> shift) + offset). `dst` is
- * allocated here with `src`'s geometry (release with x265amd_plane_free). Asynchronous on the
+ * becomes clip(((w0 * (int16)(v << (14 - depth)) + round) >> shift) + offset). If dst->origin
+ * is NULL the output plane is allocated here with `src`'s geometry (release with
+ * x265amd_plane_free); otherwise `dst` must be another plane of that geometry and is overwritten
+ * (the reference keeps one weight buffer per reference and reuses it). The same holds for
+ * x265amd_apply_weight and for the planes of x265amd_weights_analyse. Asynchronous on the
  * engine's stream. */
 int x265amd_weight_buffer(x265amd_ctx *ctx, const x265amd_plane *src, int w0, int round, int shift, int offset,
                           x265amd_plane *dst);
@@ -230,7 +233,7 @@ int x265amd_weight_buffer(x265amd_ctx *ctx, const x265amd_plane *src, int w0, in
 /* MotionReference::init(pic, wp) + applyWeight over all CTU rows (encoder/reference.cpp:39-71,
  * :211-256): the weighted copy of a reconstructed reference that motionEstimate then searches
  * (weight = wp->inputWeight, shift = log2WeightDenom, offset = inputOffset << (depth - 8)), with
- * its borders replicated from the weighted picture. `dst` is allocated here. Asynchronous. */
+ * its borders replicated from the weighted picture. Asynchronous. */
 int x265amd_apply_weight(x265amd_ctx *ctx, const x265amd_plane *recon, int input_weight, int log2_denom,
                          int input_offset, x265amd_plane *dst);
 

@@ -1352,11 +1352,25 @@ static int weight_args_ok(int w0, int shift)
     return w0 >= -128 && w0 <= 255 && shift >= 0 && shift <= 20;
 }
 
+/* output plane of a weighting call: the caller's (dst->origin set, same geometry as src: the
+ * reference keeps one weight buffer per reference and reuses it) or a fresh one */
+static int weight_dst(x265amd_ctx *c, const x265amd_plane *src, x265amd_plane *dst)
+{
+    if (dst->origin)
+    {
+        if (dst->stride != src->stride || dst->width != src->width || dst->height != src->height ||
+            dst->margin_x != src->margin_x || dst->margin_y != src->margin_y || dst->origin == src->origin)
+            return fail(c, X265AMD_EINVAL, "output plane must be another plane of the source's geometry");
+        return X265AMD_OK;
+    }
+    return plane_alloc(c, src->width, src->height, src->margin_x, src->margin_y, src->stride, dst);
+}
+
 int x265amd_weight_buffer(x265amd_ctx *c, const x265amd_plane *src, int w0, int round, int shift, int offset, x265amd_plane *dst)
 {
     if (!c || !src || !src->origin || !dst) return fail(c, X265AMD_EINVAL, "null plane");
     if (!weight_args_ok(w0, shift)) return fail(c, X265AMD_EINVAL, "weight / shift out of range");
-    int rc = plane_alloc(c, src->width, src->height, src->margin_x, src->margin_y, src->stride, dst);
+    int rc = weight_dst(c, src, dst);
     if (rc) return rc;
     const int bpp = c->depth > 8 ? 2 : 1;
     const size_t pad = ((size_t)src->margin_y * src->stride + src->margin_x) * bpp;
@@ -1382,24 +1396,22 @@ int x265amd_apply_weight(x265amd_ctx *c, const x265amd_plane *recon, int input_w
     if (log2_denom < 0 || !weight_args_ok(input_weight, shift)) return fail(c, X265AMD_EINVAL, "weight / denominator out of range");
     const int padwidth = (recon->width + 15) & ~15;
     if (padwidth - recon->width > recon->margin_x) return fail(c, X265AMD_EINVAL, "margin_x smaller than the 16-column rounding of the width");
-    int rc = plane_alloc(c, recon->width, recon->height, recon->margin_x, recon->margin_y, recon->stride, dst);
+    int rc = weight_dst(c, recon, dst);
     if (rc) return rc;
-    dim3 blk(64, 4), grd((padwidth / 4 + 63) / 64, (recon->height + 3) / 4);
-    dim3 grd2((recon->width + 2 * recon->margin_x + 63) / 64, (recon->height + 2 * recon->margin_y + 3) / 4);
+    if (recon->stride < 16) return fail(c, X265AMD_EINVAL, "stride too small");
+    const int bpp = c->depth > 8 ? 2 : 1;
+    const size_t pad = ((size_t)recon->margin_y * recon->stride + recon->margin_x) * bpp;
+    const long nvec = (long)((plane_bytes(c, recon->height, recon->margin_y, recon->stride) + 15) / 16);
+    const char *sb = (const char*)recon->origin - pad;
+    char *db = (char*)dst->origin - pad;
+    if (((uintptr_t)sb | (uintptr_t)db) & 15) return fail(c, X265AMD_EINVAL, "plane buffers are not 16-byte aligned (planes made by this library are)");
+    const dim3 grd((unsigned)((nvec + 255) / 256)), blk(256);
     if (c->depth <= 8)
-    {
-        hipLaunchKernelGGL(weight_picture_kernel<uint8_t>, grd, blk, 0, c->stream, (const uint8_t*)recon->origin, (uint8_t*)dst->origin,
-                           (long)recon->stride, padwidth / 4, recon->height, input_weight, round, shift, offset, c->depth);
-        hipLaunchKernelGGL(extend_border_kernel<uint8_t>, grd2, blk, 0, c->stream, (uint8_t*)dst->origin, (long)recon->stride,
-                           recon->width, recon->height, recon->margin_x, recon->margin_y);
-    }
+        hipLaunchKernelGGL(apply_weight_kernel<uint8_t>, grd, blk, 0, c->stream, (const uint8_t*)sb, (uint8_t*)db, nvec, recon->stride,
+                           recon->width, recon->height, recon->margin_x, recon->margin_y, input_weight, round, shift, offset, c->depth);
     else
-    {
-        hipLaunchKernelGGL(weight_picture_kernel<uint16_t>, grd, blk, 0, c->stream, (const uint16_t*)recon->origin, (uint16_t*)dst->origin,
-                           (long)recon->stride, padwidth / 4, recon->height, input_weight, round, shift, offset, c->depth);
-        hipLaunchKernelGGL(extend_border_kernel<uint16_t>, grd2, blk, 0, c->stream, (uint16_t*)dst->origin, (long)recon->stride,
-                           recon->width, recon->height, recon->margin_x, recon->margin_y);
-    }
+        hipLaunchKernelGGL(apply_weight_kernel<uint16_t>, grd, blk, 0, c->stream, (const uint16_t*)sb, (uint16_t*)db, nvec, recon->stride,
+                           recon->width, recon->height, recon->margin_x, recon->margin_y, input_weight, round, shift, offset, c->depth);
     HIPCHK(c, hipGetLastError());
     return X265AMD_OK;
 }

@@ -399,27 +399,62 @@ __global__ void weight_buffer_kernel(const uint4 *src, uint4 *dst, long nvec, in
     dst[i] = o;
 }
 
-/* The picture area of a reference (MotionReference::applyWeight weights (width + 15) & ~15 columns
- * of every row, reference.cpp:227-229; the overshoot lands in the margin and is overwritten by the
- * border extension that follows). One thread per four samples. */
+/* MotionReference::applyWeight over a whole picture (reference.cpp:211-256) in one pass. The
+ * reference weights the picture rows and then replicates the weighted edge samples into the
+ * margins; weighting is pointwise, so the padded output is weight(source sample at the clamped
+ * position). Flat over the padded buffer, 16 bytes per thread, all stores aligned; a chunk that
+ * lies inside one picture row reads its 16 source bytes at once. Columns between width + 2 *
+ * margin and the stride are cleared. src and dst have the same geometry. */
 template<typename P>
-__global__ void weight_picture_kernel(const P *src, P *dst, long stride, int quads, int height, int w0, int round, int shift, int offset, int depth)
+__global__ void apply_weight_kernel(const P *src_base, P *dst_base, long nvec, int stride, int width, int height, int mx, int my,
+                                    int w0, int round, int shift, int offset, int depth)
 {
-    const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y * blockDim.y + threadIdx.y;
-    if (x >= quads || y >= height) return;
-    const long o = (long)y * stride + 4 * x;
-    const typename Px<P>::quad q = weight_quad<P>(Px<P>::load(src + o), w0, round, shift, offset, depth);
-    if constexpr (sizeof(P) == 1)
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nvec) return;
+    constexpr int N = 16 / (int)sizeof(P);
+    const long e0 = i * N;
+    const int row = (int)(e0 / stride), col = (int)(e0 - (long)row * stride);
+    const int y = row - my, x = col - mx;
+    uint4 o;
+    if (y >= 0 && y < height && x >= 0 && x + N <= width)
     {
-        typedef uint32_t __attribute__((aligned(1))) u32u;
-        *(u32u*)(dst + o) = q;
+        const uint4 a = *(const uint4*)(src_base + e0);
+        if constexpr (sizeof(P) == 1)
+        {
+            o.x = weight_quad<P>(a.x, w0, round, shift, offset, depth); o.y = weight_quad<P>(a.y, w0, round, shift, offset, depth);
+            o.z = weight_quad<P>(a.z, w0, round, shift, offset, depth); o.w = weight_quad<P>(a.w, w0, round, shift, offset, depth);
+        }
+        else
+        {
+            const uint2 lo = weight_quad<P>(make_uint2(a.x, a.y), w0, round, shift, offset, depth);
+            const uint2 hi = weight_quad<P>(make_uint2(a.z, a.w), w0, round, shift, offset, depth);
+            o = make_uint4(lo.x, lo.y, hi.x, hi.y);
+        }
     }
     else
     {
-        typedef uint32_t __attribute__((aligned(2))) u32u;
-        ((u32u*)(dst + o))[0] = q.x;
-        ((u32u*)(dst + o))[1] = q.y;
+        const int maxv = (1 << depth) - 1, rows = height + 2 * my;
+        uint32_t w[4] = { 0, 0, 0, 0 };
+#pragma unroll
+        for (int k = 0; k < N; k++)
+        {
+            int c = col + k, r = row;
+            if (c >= stride) { c -= stride; r++; }
+            int v = 0;
+            if (c < width + 2 * mx && r < rows)
+            {
+                int sx = c - mx, sy = r - my;
+                sx = sx < 0 ? 0 : (sx >= width ? width - 1 : sx);
+                sy = sy < 0 ? 0 : (sy >= height ? height - 1 : sy);
+                const int p = src_base[(long)(sy + my) * stride + sx + mx];
+                v = ((w0 * as_i16(p << (14 - depth)) + round) >> shift) + offset;
+                v = v < 0 ? 0 : (v > maxv ? maxv : v);
+            }
+            w[k * (int)sizeof(P) / 4] |= (uint32_t)v << (8 * ((k * (int)sizeof(P)) & 3));
+        }
+        o = make_uint4(w[0], w[1], w[2], w[3]);
     }
+    *(uint4*)(dst_base + e0) = o;
 }
 
 /* CostEstimate::weightCostLuma (slicetype.cpp:1223-1256): sum over the 8x8 blocks of

@@ -323,13 +323,13 @@ class Engine:
                 self.device_free(d)
 
     # ---- explicit weighted prediction
-    def weight_buffer(self, src, w0, rnd, shift, offset):
-        out = Plane()
+    def weight_buffer(self, src, w0, rnd, shift, offset, out=None):
+        out = out if out is not None else Plane()
         self._chk(self.L.x265amd_weight_buffer(self.ctx, C.byref(src), w0, rnd, shift, offset, C.byref(out)))
         return out
 
-    def apply_weight(self, recon, input_weight, log2_denom, input_offset):
-        out = Plane()
+    def apply_weight(self, recon, input_weight, log2_denom, input_offset, out=None):
+        out = out if out is not None else Plane()
         self._chk(self.L.x265amd_apply_weight(self.ctx, C.byref(recon), input_weight, log2_denom, input_offset, C.byref(out)))
         return out
 
@@ -340,11 +340,11 @@ class Engine:
                                                        int(wp is not None), s, d, o, C.byref(cost)))
         return cost.value
 
-    def weights_analyse(self, fenc, ref4, d_intra_cost, wcu, hcu, stats):
-        """Returns (Weight, [4 weighted planes] or None)."""
+    def weights_analyse(self, fenc, ref4, d_intra_cost, wcu, hcu, stats, reuse=None):
+        """Returns (Weight, [4 weighted planes] or None); `reuse`: four planes to write into instead of new ones."""
         st = (C.c_uint64 * 4)(*[int(v) for v in stats])
         out = Weight()
-        planes = (Plane * 4)()
+        planes = (Plane * 4)(*reuse) if reuse else (Plane * 4)()
         self._chk(self.L.x265amd_weights_analyse(self.ctx, C.byref(fenc), (Plane * 4)(*ref4), C.c_void_p(d_intra_cost), wcu, hcu,
                                                  st, C.byref(out), planes))
         return out, ([planes[i] for i in range(4)] if out.weighted else None)
