@@ -22,6 +22,7 @@ def main():
     ap.add_argument("--reps", type=int, default=10)
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
+    ap.add_argument("--lib", default=None, help="another build of the engine library, e.g. a -DX265AMD_STAGE_STOP=n timing build")
     args = ap.parse_args()
     import torch
     from x265_amd.engine import Engine, METHODS, RESULT_DTYPE
@@ -29,6 +30,10 @@ def main():
     from x265_amd import workload
     from x265_amd.measure import _timed
     dev = torch.device("cuda", 0)
+    e0 = Engine(0, 8)                       # the product build: makes the predictors (lookahead field)
+    if args.lib:
+        import x265_amd.engine as eng
+        eng.LIB_PATH = os.path.abspath(args.lib)
     e = Engine(0, 8)
     W, H, M = args.width, args.height, 128
     clip = make_clip(W, H, 2, seed=1234)
@@ -36,9 +41,9 @@ def main():
     for f in clip:
         buf, org, stride = pad_plane(f, M)
         planes.append(e.upload_plane(buf, W, H, M, M, stride))
-    low = [e.lowres_init(p) for p in planes]
+    low = [e0.lowres_init(p) for p in planes]
     lw, lh, wcu, hcu = lowres_dims(W, H)
-    la_mvs, _, _ = e.lookahead_fields([(low[1][0], low[0])], wcu, hcu, 12)
+    la_mvs, _, _ = e0.lookahead_fields([(low[1][0], low[0])], wcu, hcu, 12)
     for s in (8, 16, 32, 64):
         jobs = workload.square_pu_jobs(W, H, la_mvs[0], wcu, hcu, 57, sizes=(s,))
         n = len(jobs)

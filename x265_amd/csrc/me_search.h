@@ -1114,9 +1114,20 @@ struct Searcher
         JobRegs J;
         J.load(job);
         SearchState st;
+#ifdef X265AMD_STAGE_STOP
+        /* timing builds only (tools/search_bench.py --lib): leave after the set-up (1), the start-up
+         * batch (2) or the integer stage (3); results are then meaningless */
+        if (X265AMD_STAGE_STOP == 1) { if (lane == 0) res->cost = J.pux; return; }
+        startup(J, st);
+        if (X265AMD_STAGE_STOP == 2) { if (lane == 0) res->cost = st.bcost; return; }
+        integer(J, method, st);
+        if (X265AMD_STAGE_STOP == 3) { if (lane == 0) res->cost = st.bcost; return; }
+        finish(subme, st, res);
+#else
         startup(J, st);
         integer(J, method, st);
         finish(subme, st, res);
+#endif
     }
 
     /* motion.cpp:562-621: predictor, MV(0,0) and the qpel candidates */
