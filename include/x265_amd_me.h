@@ -260,6 +260,29 @@ int x265amd_weights_analyse(x265amd_ctx *ctx, const x265amd_plane *fenc, const x
                             const int32_t *d_intra_cost, int width_in_cu, int height_in_cu,
                             const uint64_t stats[4], x265amd_weight *out, x265amd_plane weighted[4]);
 
+/* ---- bi-prediction estimate ---- */
+
+/* The distortion part of the bi-directional check of TEncSearch::predInterSearch
+ * (Lib/TLibEncoder/TEncSearch.cpp:4346-4368) for a batch of PUs: each PU is predicted from both
+ * references at its best list-0 / list-1 quarter-pel MVs (TComPrediction::xPredInterLumaBlk,
+ * Lib/TLibCommon/TComPrediction.cpp:405-438), the predictions are averaged (pixelavg_pp) and
+ * compared with the source by SATD; satd_zero is the same for the two co-located blocks
+ * (:4362-4368). The bit costs around it (:4359-4360, :4370-4378) stay with the caller. */
+typedef struct
+{
+    int16_t pu_x, pu_y;
+    uint8_t w, h;              /* an HEVC luma partition */
+    uint8_t reserved[2];
+    int16_t mv0[2], mv1[2];    /* quarter-pel MVs into ref0 / ref1 */
+} x265amd_bipred_job;
+typedef struct { int32_t satd, satd_zero; } x265amd_bipred_result;
+/* jobs / results are HOST arrays */
+int x265amd_bipred_batch(x265amd_ctx *ctx, const x265amd_plane *fenc, const x265amd_plane *ref0, const x265amd_plane *ref1,
+                         const x265amd_bipred_job *jobs, int njobs, x265amd_bipred_result *results);
+/* device-resident, asynchronous on the engine's stream; the jobs are not validated */
+int x265amd_bipred_batch_dev(x265amd_ctx *ctx, const x265amd_plane *fenc, const x265amd_plane *ref0, const x265amd_plane *ref1,
+                             const x265amd_bipred_job *d_jobs, int njobs, x265amd_bipred_result *d_results);
+
 /* ---- Rockchip path (rd >= 5): CIME + RIME + FME ---- */
 
 /* One 64x64 CTU against one reference picture: everything the 15-argument

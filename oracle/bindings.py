@@ -50,6 +50,11 @@ RK_RESULT_DTYPE = np.dtype([("cime", RK_MV_DTYPE), ("rime", RK_MV_DTYPE, (85,)),
 assert RK_CTU_DTYPE.itemsize == 40 and RK_RESULT_DTYPE.itemsize == 171 * 8
 
 
+BIPRED_JOB_DTYPE = np.dtype([("pu_x", "<i2"), ("pu_y", "<i2"), ("w", "u1"), ("h", "u1"), ("reserved", "u1", (2,)),
+                             ("mv0", "<i2", (2,)), ("mv1", "<i2", (2,))], align=True)
+assert BIPRED_JOB_DTYPE.itemsize == 16
+
+
 def build_oracle():
     import subprocess
     subprocess.check_call(["make", "-C", HERE, "libme_oracle.so"], stdout=subprocess.DEVNULL)
@@ -227,6 +232,14 @@ class Oracle:
         sc = np.zeros(2, np.uint32)
         w = self.L.orc_weights_analyse(depth, _p(fenc, origin), _p(ref, origin), C.c_ssize_t(stride), wcu, hcu, _p(ic), _p(st), _p(out), _p(sc))
         return bool(w), tuple(int(v) for v in out), tuple(int(v) for v in sc)
+
+    def bipred_batch(self, depth, fenc, ref0, ref1, origin, stride, jobs):
+        """jobs: BIPRED_JOB_DTYPE records; returns int32 [n, 2] = (satd of the averaged predictions, of the zero-MV pair)."""
+        jobs = np.ascontiguousarray(jobs, BIPRED_JOB_DTYPE)
+        out = np.zeros((len(jobs), 2), np.int32)
+        self.L.orc_bipred_batch(depth, _p(fenc, origin), C.c_ssize_t(stride), _p(ref0, origin), _p(ref1, origin), C.c_ssize_t(stride),
+                                _p(jobs), len(jobs), _p(out))
+        return out
 
 
 def ref_available(depth=8):
@@ -461,3 +474,15 @@ class Ref:
         self.L.ref_weights_analyse(pl(fenc4), pl(ref4), bufs, stride, padded_lines, origin, wcu, hcu, _p(ic), _p(st), delta_index,
                                    _p(wbuf), _p(out), C.byref(delta))
         return bool(out[0]), (int(out[1]), int(out[2]), int(out[3])), wbuf.reshape(4, -1), delta.value
+
+    def bipred_batch(self, fenc, ref0, ref1, origin, stride, jobs):
+        out = np.zeros((len(jobs), 2), np.int32)
+        for i, j in enumerate(jobs):
+            off = origin + int(j["pu_y"]) * stride + int(j["pu_x"])
+            mv0 = (C.c_int16 * 2)(int(j["mv0"][0]), int(j["mv0"][1]))
+            mv1 = (C.c_int16 * 2)(int(j["mv1"][0]), int(j["mv1"][1]))
+            r = (C.c_int32 * 2)()
+            self.L.ref_bipred_cost(_p(fenc, off), C.c_ssize_t(stride), _p(ref0, off), _p(ref1, off), C.c_ssize_t(stride),
+                                   int(j["w"]), int(j["h"]), mv0, mv1, r)
+            out[i] = (r[0], r[1])
+        return out

@@ -345,3 +345,20 @@ int orc_weights_analyse(int depth, const void *fenc, const void *ref, intptr_t s
     out[0] = minscale; out[1] = mindenom; out[2] = minoff;
     return 1;
 }
+
+
+void orc_bipred_batch(int depth, const void *fenc, intptr_t fstride, const void *ref0, const void *ref1, intptr_t rstride,
+                      const orc_bipred_job *jobs, int n, int32_t *out /* 2 per job */)
+{
+    for (int i = 0; i < n; i++)
+    {
+        const orc_bipred_job *j = jobs + i;
+        const intptr_t fo = (intptr_t)j->pu_y * fstride + j->pu_x, ro = (intptr_t)j->pu_y * rstride + j->pu_x;
+        if (depth <= 8)
+            bipred_cost_8((const uint8_t*)fenc + fo, fstride, (const uint8_t*)ref0 + ro, (const uint8_t*)ref1 + ro, rstride,
+                          j->w, j->h, depth, j->mv0[0], j->mv0[1], j->mv1[0], j->mv1[1], out + 2 * i);
+        else
+            bipred_cost_16((const uint16_t*)fenc + fo, fstride, (const uint16_t*)ref0 + ro, (const uint16_t*)ref1 + ro, rstride,
+                           j->w, j->h, depth, j->mv0[0], j->mv0[1], j->mv1[0], j->mv1[1], out + 2 * i);
+    }
+}

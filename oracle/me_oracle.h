@@ -153,6 +153,16 @@ uint32_t orc_weight_cost_luma(int depth, const void *fenc, const void *src, intp
 int orc_weights_analyse(int depth, const void *fenc, const void *ref, intptr_t stride, int wcu, int hcu,
                         const int32_t *intra_cost, const uint64_t stats[4], int out[3], uint32_t scores[2]);
 
+/* ---- bi-prediction estimate of TEncSearch::predInterSearch (source/Lib/TLibEncoder/TEncSearch.cpp:
+ * 4346-4368): each PU is predicted from both references at its two quarter-pel MVs
+ * (xPredInterLumaBlk, source/Lib/TLibCommon/TComPrediction.cpp:405-438), the predictions are
+ * averaged (pixelavg_pp) and compared with the source by SATD; out[2i] is that cost, out[2i+1]
+ * the same for the two co-located (zero-MV) blocks. Planes are origins; both references share
+ * one stride. Job layout = x265amd_bipred_job. */
+typedef struct { int16_t pu_x, pu_y; uint8_t w, h, reserved[2]; int16_t mv0[2], mv1[2]; } orc_bipred_job;
+void orc_bipred_batch(int depth, const void *fenc, intptr_t fstride, const void *ref0, const void *ref1, intptr_t rstride,
+                      const orc_bipred_job *jobs, int n, int32_t *out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1277,3 +1277,40 @@ static uint32_t FN(weight_cost_luma)(const PIXEL *fenc, const PIXEL *src, intptr
         }
     return cost;
 }
+
+
+/* ---------------- bi-prediction estimate of predInterSearch ---------------- */
+
+/* TComPrediction::xPredInterLumaBlk (TComPrediction.cpp:405-438): the PU predicted from `ref`
+ * at quarter-pel MV (qx, qy) into buf (pitch 64) */
+static void FN(mc_luma)(const PIXEL *ref_pu, intptr_t stride, int qx, int qy, int w, int h, int depth, PIXEL *buf)
+{
+    const int xFrac = qx & 3, yFrac = qy & 3;
+    const PIXEL *src = ref_pu + (qx >> 2) + (qy >> 2) * stride;
+    if ((xFrac | yFrac) == 0)
+        for (int y = 0; y < h; y++) memcpy(buf + 64 * y, src + y * stride, w * sizeof(PIXEL));
+    else if (yFrac == 0)
+        FN(luma_hpp)(src, stride, buf, 64, xFrac, w, h, depth);
+    else if (xFrac == 0)
+        FN(luma_vpp)(src, stride, buf, 64, yFrac, w, h, depth);
+    else
+    {
+        int16_t immed[64 * (64 + 8)];
+        FN(luma_hps)(src, stride, immed, w, xFrac, 1, w, h, depth);
+        FN(luma_vsp)(immed + 3 * w, w, buf, 64, yFrac, w, h, depth);
+    }
+}
+
+/* TEncSearch.cpp:4346-4368: SATD of the PU against the average of its two predictions, and
+ * against the average of the two co-located reference blocks */
+static void FN(bipred_cost)(const PIXEL *fenc_pu, intptr_t fstride, const PIXEL *ref0_pu, const PIXEL *ref1_pu, intptr_t rstride,
+                            int w, int h, int depth, int mv0x, int mv0y, int mv1x, int mv1y, int32_t out[2])
+{
+    PIXEL p0[64 * 64], p1[64 * 64], avg[64 * 64];
+    FN(mc_luma)(ref0_pu, rstride, mv0x, mv0y, w, h, depth, p0);
+    FN(mc_luma)(ref1_pu, rstride, mv1x, mv1y, w, h, depth, p1);
+    FN(pixelavg)(avg, 64, p0, 64, p1, 64, w, h);
+    out[0] = FN(satd)(fenc_pu, fstride, avg, 64, w, h);
+    FN(pixelavg)(avg, 64, ref0_pu, rstride, ref1_pu, rstride, w, h);
+    out[1] = FN(satd)(fenc_pu, fstride, avg, 64, w, h);
+}

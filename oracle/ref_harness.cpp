@@ -596,4 +596,40 @@ int ref_apply_weight(pixel *buf, int width, int height, int marginX, int marginY
     return 0;
 }
 
+/* ---- bi-prediction estimate: the primitive calls of TEncSearch::predInterSearch
+ * (TEncSearch.cpp:4346-4368) and of TComPrediction::xPredInterLumaBlk (TComPrediction.cpp:
+ * 405-438) that it makes, issued in their order on the reference's own primitives. out[0] =
+ * satd against the averaged predictions, out[1] = against the averaged co-located blocks. ---- */
+static void harness_pred_luma(pixel *refPU, intptr_t stride, int qx, int qy, int part, int width, pixel *dst, intptr_t dstStride,
+                              int16_t *immed)
+{
+    pixel *src = refPU + (qx >> 2) + (qy >> 2) * stride;
+    const int xFrac = qx & 3, yFrac = qy & 3;
+    if ((yFrac | xFrac) == 0) primitives.luma_copy_pp[part](dst, dstStride, src, stride);
+    else if (yFrac == 0) primitives.luma_hpp[part](src, stride, dst, dstStride, xFrac);
+    else if (xFrac == 0) primitives.luma_vpp[part](src, stride, dst, dstStride, yFrac);
+    else
+    {
+        primitives.luma_hps[part](src, stride, immed, width, xFrac, 1);
+        primitives.luma_vsp[part](immed + 3 * width, width, dst, dstStride, yFrac);
+    }
+}
+
+void ref_bipred_cost(pixel *fencPU, intptr_t fencStride, pixel *ref0PU, pixel *ref1PU, intptr_t refStride, int w, int h,
+                     const int16_t *mv0, const int16_t *mv1, int32_t *out)
+{
+    const int part = partitionFromSizes(w, h);
+    pixel *p0 = (pixel*)malloc(sizeof(pixel) * 64 * 64 * 3);
+    pixel *p1 = p0 + 64 * 64, *avg = p1 + 64 * 64;
+    int16_t *immed = (int16_t*)malloc(sizeof(int16_t) * 64 * (64 + 8));
+    harness_pred_luma(ref0PU, refStride, mv0[0], mv0[1], part, w, p0, 64, immed);
+    harness_pred_luma(ref1PU, refStride, mv1[0], mv1[1], part, w, p1, 64, immed);
+    primitives.pixelavg_pp[part](avg, w, p0, 64, p1, 64, 32);
+    out[0] = primitives.satd[part](fencPU, fencStride, avg, w);
+    primitives.pixelavg_pp[part](avg, w, ref0PU, refStride, ref1PU, refStride, 32);
+    out[1] = primitives.satd[part](fencPU, fencStride, avg, w);
+    free(immed);
+    free(p0);
+}
+
 } // extern "C"

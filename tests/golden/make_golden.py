@@ -160,6 +160,7 @@ def main():
     make_cmodel(shas)
     make_frame_cost(shas)
     make_wp(shas)
+    make_bipred(shas)
     json.dump(shas, open(os.path.join(HERE, "input_sha.json"), "w"), indent=0, sort_keys=True)
     print("golden vectors written to", HERE)
 
@@ -258,6 +259,40 @@ def make_wp(shas):
     np.savez_compressed(os.path.join(HERE, "wp_golden.npz"), **out)
 
 
+def bipred_case(depth):
+    """(fenc, ref0, ref1 padded buffers, origin, stride, jobs) of the bi-prediction vectors."""
+    from oracle.bindings import BIPRED_JOB_DTYPE
+    clip = make_clip(ME_W, ME_H, 3, seed=8, depth=depth)
+    f, org, stride = pad_plane(clip[1], 96)
+    r0, _, _ = pad_plane(clip[0], 96)
+    r1, _, _ = pad_plane(clip[2], 96)
+    rng = np.random.default_rng(3)
+    parts = PARTITIONS[1:]
+    jobs = np.zeros(12 * len(parts), BIPRED_JOB_DTYPE)
+    for i in range(len(jobs)):
+        w, h = parts[i % len(parts)]
+        j = jobs[i]
+        j["pu_x"], j["pu_y"] = int(rng.integers(0, (ME_W - w) // 4 + 1)) * 4, int(rng.integers(0, (ME_H - h) // 4 + 1)) * 4
+        j["w"], j["h"] = w, h
+        j["mv0"], j["mv1"] = rng.integers(-120, 121, 2), rng.integers(-120, 121, 2)
+        if i % 7 == 0:
+            j["mv0"] = (j["mv0"] // 4) * 4
+        if i % 11 == 0:
+            j["mv1"] = 0
+        if i % 13 == 0:
+            j["mv0"][1] = (j["mv0"][1] // 4) * 4
+    return f, r0, r1, org, stride, jobs
+
+
+def make_bipred(shas):
+    out = {}
+    for depth in (8, 10):
+        f, r0, r1, org, stride, jobs = bipred_case(depth)
+        shas["bipred_%d" % depth] = [sha(f), sha(r0), sha(r1), sha(jobs)]
+        out["%d" % depth] = Ref(depth).bipred_batch(f, r0, r1, org, stride, jobs)
+    np.savez_compressed(os.path.join(HERE, "bipred_golden.npz"), **out)
+
+
 def make_cmodel(shas):
     """Records of the reference's hardware C-model: coarse stage (CoarseIntMotionEstimation::CIME,
     hardwareC/inter.cpp:679-734), refine + fractional stages for the 85 CUs of each CTU
@@ -284,11 +319,11 @@ def make_cmodel(shas):
 
 
 if __name__ == "__main__":
-    if sys.argv[1:] in (["cmodel"], ["framecost"], ["wp"]):
+    if sys.argv[1:] in (["cmodel"], ["framecost"], ["wp"], ["bipred"]):
         # only (re)generate the C-model / frame-cost records, keeping the other files as they are
         shas_path = os.path.join(HERE, "input_sha.json")
         shas_ = json.load(open(shas_path))
-        {"cmodel": make_cmodel, "framecost": make_frame_cost, "wp": make_wp}[sys.argv[1]](shas_)
+        {"cmodel": make_cmodel, "framecost": make_frame_cost, "wp": make_wp, "bipred": make_bipred}[sys.argv[1]](shas_)
         json.dump(shas_, open(shas_path, "w"), indent=0, sort_keys=True)
     else:
         main()

@@ -157,3 +157,10 @@ def test_weighted_prediction(oracle, depth):
                 oracle.weight_pp(depth, PR[0][i], 0, out, 0, stride, stride, stride, padded, w[0], 1 << (w[1] - 1 + corr), w[1] + corr,
                                  w[2] << (depth - 8))
                 assert np.array_equal(G.sha_bytes(out[:stride * padded]), g[key + "_planes"][i]), (key, i)
+
+
+@pytest.mark.parametrize("depth", [8, 10])
+def test_bipred_cost(oracle, depth):
+    f, r0, r1, org, stride, jobs = G.bipred_case(depth)
+    assert [G.sha(f), G.sha(r0), G.sha(r1), G.sha(jobs)] == G.input_shas()["bipred_%d" % depth]
+    assert np.array_equal(oracle.bipred_batch(depth, f, r0, r1, org, stride, jobs), G.bipred_golden()[depth])

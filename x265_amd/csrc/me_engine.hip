@@ -1495,6 +1495,61 @@ int x265amd_weights_analyse(x265amd_ctx *c, const x265amd_plane *fenc, const x26
     return X265AMD_OK;
 }
 
+/* ---- bi-prediction estimate ---- */
+
+int x265amd_bipred_batch_dev(x265amd_ctx *c, const x265amd_plane *fenc, const x265amd_plane *ref0, const x265amd_plane *ref1,
+                             const x265amd_bipred_job *d_jobs, int njobs, x265amd_bipred_result *d_results)
+{
+    if (!c || !fenc || !ref0 || !ref1 || !fenc->origin || !ref0->origin || !ref1->origin || !d_jobs || !d_results || njobs < 0)
+        return fail(c, X265AMD_EINVAL, "null argument");
+    if (!njobs) return X265AMD_OK;
+    HIPCHK(c, hipSetDevice(c->device));
+    BipredArgs a;
+    a.fenc.origin = fenc->origin; a.fenc.stride = fenc->stride;
+    a.ref0.origin = ref0->origin; a.ref0.stride = ref0->stride;
+    a.ref1.origin = ref1->origin; a.ref1.stride = ref1->stride;
+    a.depth = c->depth; a.njobs = njobs; a.jobs = d_jobs; a.results = d_results;
+    if (c->depth <= 8) hipLaunchKernelGGL(bipred_kernel<uint8_t>, dim3(njobs), dim3(64), 0, c->stream, a);
+    else hipLaunchKernelGGL(bipred_kernel<uint16_t>, dim3(njobs), dim3(64), 0, c->stream, a);
+    HIPCHK(c, hipGetLastError());
+    return X265AMD_OK;
+}
+
+int x265amd_bipred_batch(x265amd_ctx *c, const x265amd_plane *fenc, const x265amd_plane *ref0, const x265amd_plane *ref1,
+                         const x265amd_bipred_job *jobs, int njobs, x265amd_bipred_result *results)
+{
+    if (!c || !fenc || !ref0 || !ref1 || !jobs || !results || njobs < 0) return fail(c, X265AMD_EINVAL, "null argument");
+    if (!njobs) return X265AMD_OK;
+    const x265amd_plane *refs[2] = { ref0, ref1 };
+    for (int i = 0; i < njobs; i++)
+    {
+        const x265amd_bipred_job &j = jobs[i];
+        if (x265amd_partition_from_sizes(j.w, j.h) < 0) return fail(c, X265AMD_EINVAL, "job: not a luma partition");
+        if (j.pu_x < 0 || j.pu_y < 0 || j.pu_x + j.w > fenc->width + fenc->margin_x || j.pu_y + j.h > fenc->height + fenc->margin_y)
+            return fail(c, X265AMD_EINVAL, "job: PU outside the source plane");
+        for (int l = 0; l < 2; l++)
+        {
+            const int16_t *mv = l ? j.mv1 : j.mv0;
+            /* the 8-tap footprint of the prediction: 3 samples before, 4 after, tiles read as whole quads */
+            const int x0 = j.pu_x + (mv[0] >> 2) - 3, x1 = j.pu_x + j.w + (mv[0] >> 2) + 8;
+            const int y0 = j.pu_y + (mv[1] >> 2) - 3, y1 = j.pu_y + j.h + (mv[1] >> 2) + 4;
+            const x265amd_plane *r = refs[l];
+            if (x0 < -r->margin_x || y0 < -r->margin_y || x1 > r->width + r->margin_x || y1 > r->height + r->margin_y)
+                return fail(c, X265AMD_EINVAL, "job: prediction block leaves the padded reference plane");
+        }
+    }
+    HIPCHK(c, hipSetDevice(c->device));
+    int rc;
+    if ((rc = ensure(c, &c->d_jobs, &c->jobs_cap, (size_t)njobs * sizeof(x265amd_bipred_job)))) return rc;
+    if ((rc = ensure(c, &c->d_results, &c->results_cap, (size_t)njobs * sizeof(x265amd_bipred_result)))) return rc;
+    HIPCHK(c, hipMemcpyAsync(c->d_jobs, jobs, (size_t)njobs * sizeof(x265amd_bipred_job), hipMemcpyHostToDevice, c->stream));
+    if ((rc = x265amd_bipred_batch_dev(c, fenc, ref0, ref1, (const x265amd_bipred_job*)c->d_jobs, njobs, (x265amd_bipred_result*)c->d_results)))
+        return rc;
+    HIPCHK(c, hipMemcpyAsync(results, c->d_results, (size_t)njobs * sizeof(x265amd_bipred_result), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return X265AMD_OK;
+}
+
 int x265amd_rk_ds_plane(x265amd_ctx *c, const x265amd_plane *orig, x265amd_plane *out)
 {
     if (!c || !orig || !orig->origin || !out) return fail(c, X265AMD_EINVAL, "null plane");

@@ -494,6 +494,73 @@ __global__ __launch_bounds__(LA_COST_THREADS) void la_weight_cost_kernel(PlaneDe
     if (threadIdx.x == 0) atomicAdd(out, (unsigned int)tot[0]);
 }
 
+/* ---- bi-prediction estimate of predInterSearch (TEncSearch.cpp:4346-4368) ----
+ * One wave per PU, a lane per 4x4 tile (lanes loop when the PU has more than 64 tiles): both
+ * predictions of the tile are interpolated in registers from global memory
+ * (xPredInterLumaBlk = the luma_hpp / vpp / hps+vsp chain of interp_tile), averaged with
+ * rounding, and the 4x4 Hadamard of the difference to the source is summed over the tiles. */
+struct BipredArgs
+{
+    PlaneDev fenc, ref0, ref1;
+    int depth, njobs;
+    const x265amd_bipred_job *jobs;
+    x265amd_bipred_result *results;
+};
+
+template<typename P>
+__device__ __forceinline__ void bipred_tile(const P AS1 *r, int stride, int qx, int qy, int depth, int o[4][4])
+{
+    const int xf = qx & 3, yf = qy & 3;
+    GlobalLoader<P> ld = { r + (long)(qy >> 2) * stride + (qx >> 2), stride };
+    if ((xf | yf) == 0)
+    {
+#pragma unroll
+        for (int y = 0; y < 4; y++) Px<P>::unpack(ld(0, y), o[y]);
+    }
+    else
+        interp_tile<P>(ld, xf, yf, depth, o);
+}
+
+template<typename P>
+__global__ __launch_bounds__(64) void bipred_kernel(BipredArgs a)
+{
+    const int j = blockIdx.x;
+    if (j >= a.njobs) return;
+    const x265amd_bipred_job *job = a.jobs + j;
+    const int lane = threadIdx.x & 63;
+    const int w = uni(job->w), h = uni(job->h), pux = uni(job->pu_x), puy = uni(job->pu_y);
+    const int m0x = uni(job->mv0[0]), m0y = uni(job->mv0[1]), m1x = uni(job->mv1[0]), m1y = uni(job->mv1[1]);
+    const int wt = w >> 2, T = wt * (h >> 2);
+    int bi = 0, zero = 0;
+    for (int t = lane; t < T; t += 64)
+    {
+        const int ty = t / wt, tx = t - ty * wt;
+        const long fo = (long)(puy + 4 * ty) * a.fenc.stride + pux + 4 * tx;
+        const long r0o = (long)(puy + 4 * ty) * a.ref0.stride + pux + 4 * tx, r1o = (long)(puy + 4 * ty) * a.ref1.stride + pux + 4 * tx;
+        typename Px<P>::quad f[4], z[4];
+#pragma unroll
+        for (int y = 0; y < 4; y++)
+        {
+            f[y] = Px<P>::load_g((const P AS1*)a.fenc.origin + fo + (long)y * a.fenc.stride);
+            z[y] = Px<P>::avg(Px<P>::load_g((const P AS1*)a.ref0.origin + r0o + (long)y * a.ref0.stride),
+                              Px<P>::load_g((const P AS1*)a.ref1.origin + r1o + (long)y * a.ref1.stride));
+        }
+        zero += tile_cost_quads<P>(f, z, true);
+        int o0[4][4], o1[4][4];
+        bipred_tile<P>((const P AS1*)a.ref0.origin + r0o, a.ref0.stride, m0x, m0y, a.depth, o0);
+        bipred_tile<P>((const P AS1*)a.ref1.origin + r1o, a.ref1.stride, m1x, m1y, a.depth, o1);
+#pragma unroll
+        for (int y = 0; y < 4; y++)
+#pragma unroll
+            for (int x = 0; x < 4; x++) o0[y][x] = (o0[y][x] + o1[y][x] + 1) >> 1;
+        bi += tile_cost_px<P>(f, o0, true);
+    }
+    bi = seg_sum(bi, 6);
+    zero = seg_sum(zero, 6);
+    if (lane == 0) { a.results[j].satd = bi; a.results[j].satd_zero = zero; }
+}
+
 } // namespace x265amd
+
 
 #endif

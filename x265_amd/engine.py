@@ -38,6 +38,12 @@ RK_RESULT_DTYPE = np.dtype([("cime", RK_MV_DTYPE), ("rime", RK_MV_DTYPE, (85,)),
 assert RK_CTU_DTYPE.itemsize == 40 and RK_RESULT_DTYPE.itemsize == 171 * 8
 
 
+BIPRED_JOB_DTYPE = np.dtype([("pu_x", "<i2"), ("pu_y", "<i2"), ("w", "u1"), ("h", "u1"), ("reserved", "u1", (2,)),
+                             ("mv0", "<i2", (2,)), ("mv1", "<i2", (2,))], align=True)
+BIPRED_RESULT_DTYPE = np.dtype([("satd", "<i4"), ("satd_zero", "<i4")], align=True)
+assert BIPRED_JOB_DTYPE.itemsize == 16 and BIPRED_RESULT_DTYPE.itemsize == 8
+
+
 class Plane(C.Structure):
     """x265amd_plane: a padded picture plane in device memory."""
     _fields_ = [("origin", C.c_void_p), ("stride", C.c_int32), ("width", C.c_int32), ("height", C.c_int32),
@@ -348,6 +354,18 @@ class Engine:
         self._chk(self.L.x265amd_weights_analyse(self.ctx, C.byref(fenc), (Plane * 4)(*ref4), C.c_void_p(d_intra_cost), wcu, hcu,
                                                  st, C.byref(out), planes))
         return out, ([planes[i] for i in range(4)] if out.weighted else None)
+
+    # ---- bi-prediction estimate
+    def bipred_batch(self, fenc, ref0, ref1, jobs):
+        jobs = np.ascontiguousarray(jobs, BIPRED_JOB_DTYPE)
+        res = np.zeros(len(jobs), BIPRED_RESULT_DTYPE)
+        self._chk(self.L.x265amd_bipred_batch(self.ctx, C.byref(fenc), C.byref(ref0), C.byref(ref1), C.c_void_p(jobs.ctypes.data),
+                                              len(jobs), C.c_void_p(res.ctypes.data)))
+        return res
+
+    def bipred_batch_dev(self, fenc, ref0, ref1, d_jobs, njobs, d_results):
+        self._chk(self.L.x265amd_bipred_batch_dev(self.ctx, C.byref(fenc), C.byref(ref0), C.byref(ref1), C.c_void_p(d_jobs), njobs,
+                                                  C.c_void_p(d_results)))
 
     # ---- Rockchip path
     def rk_ds_plane(self, orig):
