@@ -154,3 +154,23 @@ def test_frame_cost_bidir_10bit(engine10, oracle):
             assert np.array_equal(r[k], exp[k]), (b, d0, d1, k)
     with pytest.raises(Exception):
         engine10.estimate_frame_costs([dict(fenc=L[1], ref0=None, ref1=None, d0=0, d1=0)], wcu, hcu, 24)
+
+
+def test_both_lookahead_kernels_agree(engine8, oracle, monkeypatch):
+    """The workgroup-per-field kernel and the row-parallel kernel give the same fields (the library picks by batch
+    size; X265AMD_LOOKAHEAD_KERNEL forces one), for a batch larger than the number of rows a launch starts with."""
+    clip = make_clip(416, 240, 5, seed=23, depth=8)
+    L = [_device_lowres(engine8, f) for f in clip]
+    fields = [(L[i][0], L[j]) for i in range(5) for j in range(5) if i != j] * 3        # 60 fields
+    out = {}
+    for which in ("field", "rows"):
+        monkeypatch.setenv("X265AMD_LOOKAHEAD_KERNEL", which)
+        out[which] = engine8.lookahead_fields(fields, 26, 15, 12, 1, 1, 16, want_stats=True)
+    monkeypatch.delenv("X265AMD_LOOKAHEAD_KERNEL")
+    for a, b in zip(out["field"], out["rows"]):
+        assert np.array_equal(a, b)
+    pa = host_lowres_planes(oracle, 8, clip[0], 64)
+    pb = host_lowres_planes(oracle, 8, clip[1], 64)
+    ctx = oracle.make_ctx(8, pa[0][0], pa[1], pa[2], pb[0], pa[1], pa[2], True, 12, 1, 1)
+    mv, cost = oracle.lookahead_field(ctx, 26, 15, 16)
+    assert np.array_equal(out["rows"][0][0], mv) and np.array_equal(out["rows"][1][0], cost)
