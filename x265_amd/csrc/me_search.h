@@ -565,7 +565,12 @@ __device__ __noinline__ void eval_planes(int base, int K, int mode, int addmv)
         if (cm == 0) { qx <<= 2; qy <<= 2; }   /* full-pel member of a mixed batch */
     }
     const int yf = qy & 3, Y = qy >> 2;
-    const int key = (qx << 1) | ((qx & 3) && yf ? 1 : 0);
+    /* With 8-bit samples the luma_hps intermediate keeps every bit (shift 0), and luma_vsp with the
+     * phase-0 taps on it gives exactly (sum + 32) >> 6; likewise phase-0 luma_hps of a sample is
+     * 64 * sample - 8192 and luma_vsp on that equals luma_vpp. So all candidates of one qpel x can
+     * share one plane of hps intermediates, whatever their fractions. Deeper samples lose two bits
+     * in the intermediate and keep the three plane kinds. */
+    const int key = (qx << 1) | (sizeof(P) == 1 ? 1 : ((qx & 3) && yf ? 1 : 0));
     int pkey = 0, pymin = 0, pymax = 0, papron = 0, mypl = 0, np = 0;
     for (int k = 0; k < K; k++)
     {
