@@ -727,6 +727,7 @@ struct x265amd_ctx
     int depth;
     hipStream_t stream;
     std::map<int, uint16_t*> tables; /* qp -> device table, 65536 entries, index mvd + 32768 */
+    std::map<int, int> table_nowrap; /* qp -> 1 when no two entries of the table add up to 2^16 or more */
     std::string err;
     void *d_jobs; size_t jobs_cap;
     void *d_results; size_t results_cap;
@@ -761,7 +762,7 @@ static int ensure(x265amd_ctx *c, void **p, size_t *cap, size_t need)
 
 /* X265_FULL_SEARCH on 8-bit planes: workgroup-per-PU scan through an LDS window, then the
  * one-wave stages around it */
-static int launch_esa(x265amd_ctx *c, const SearchArgs &a, int window_bytes)
+static int launch_esa(x265amd_ctx *c, const SearchArgs &a, int window_bytes, int nowrap)
 {
     static bool lds_raised = false;
     if (!lds_raised)
@@ -771,7 +772,7 @@ static int launch_esa(x265amd_ctx *c, const SearchArgs &a, int window_bytes)
         lds_raised = true;
     }
     hipLaunchKernelGGL(esa_scan_kernel<uint8_t>, dim3(a.njobs), dim3(ESA_THREADS), esa_fixed_lds(a.max_dim) + window_bytes,
-                       c->stream, a, window_bytes);
+                       c->stream, a, window_bytes, nowrap);
     hipLaunchKernelGGL(esa_finish_kernel<uint8_t>, dim3(a.njobs), dim3(64), wave_lds_bytes<uint8_t>(a.max_dim, true),
                        c->stream, a, window_bytes);
     HIPCHK(c, hipGetLastError());
@@ -898,6 +899,7 @@ int x265amd_set_qp(x265amd_ctx *c, int qp)
     HIPCHK(c, hipMalloc((void**)&d, 65536 * sizeof(uint16_t)));
     HIPCHK(c, hipMemcpy(d, tab.data(), 65536 * sizeof(uint16_t), hipMemcpyHostToDevice));
     c->tables[qp] = d;
+    c->table_nowrap[qp] = 2 * (int)tab[65535] < 65536;   /* the table grows with |mvd|: its last entry is the largest */
     return X265AMD_OK;
 }
 
@@ -1088,7 +1090,7 @@ static int search_dev(x265amd_ctx *c, const x265amd_plane *fenc, const x265amd_p
     fill_args(c, a, fenc, ref, is_lowres, qp, method, subme);
     a.jobs = d_jobs; a.results = d_results; a.njobs = njobs;
     if (!is_lowres) a.max_dim = max_pu_dim;
-    if (method == X265AMD_FULL && !is_lowres && c->depth <= 8) return launch_esa(c, a, esa_window);
+    if (method == X265AMD_FULL && !is_lowres && c->depth <= 8) return launch_esa(c, a, esa_window, c->table_nowrap[qp]);
     return c->depth <= 8 ? launch_search<uint8_t>(c, a, is_lowres) : launch_search<uint16_t>(c, a, is_lowres);
 }
 

@@ -179,7 +179,7 @@ __device__ __forceinline__ bool esa_job_ok(const JobRegs &J, int w, int h, int m
  * (SAD + lambda * bits, raster index) of the range into results[j].cost / .sad_calls, where
  * esa_finish_kernel picks it up. */
 template<typename P>
-__global__ __launch_bounds__(ESA_THREADS) void esa_scan_kernel(SearchArgs a, int win_budget)
+__global__ __launch_bounds__(ESA_THREADS) void esa_scan_kernel(SearchArgs a, int win_budget, int nowrap)
 {
     static_assert(sizeof(P) == 1, "the packed quad-SAD path is for 8-bit samples");
     const int j = xcd_remap(blockIdx.x, a.njobs);
@@ -297,6 +297,30 @@ __global__ __launch_bounds__(ESA_THREADS) void esa_scan_kernel(SearchArgs a, int
 #pragma unroll
                 for (int i = 0; i < 4; i++) cx[i] = lds_i(0, g.off_cx)[xg * 4 + i];
                 uint32_t best = 0xffffffffu;
+                if (nowrap)
+                {
+                    /* No two entries of this QP's table add up to 2^16 (the host checked), so the
+                     * uint16 wrap of bitcost.h:46 never acts and cost = SAD + cx + cy. The key
+                     * (cost << 5 | patch index) then splits into a per-column and a per-row term,
+                     * and adding the row term after the minimum over a row's four columns keeps
+                     * the order: two instructions per position instead of five. */
+                    uint32_t kx[4];
+#pragma unroll
+                    for (int i = 0; i < 4; i++) kx[i] = ((uint32_t)cx[i] << 5) | (uint32_t)i;
+#pragma unroll
+                    for (int c = 0; c < ESA_R; c++)
+                    {
+                        const uint32_t ky = ((uint32_t)lds_i(0, g.off_cy)[yg * ESA_R + c] << 5) | (uint32_t)(c * 4);
+                        const uint32_t k0 = (tot[c][0] << 5) + kx[0], k1 = (tot[c][1] << 5) + kx[1];
+                        const uint32_t k2 = (tot[c][2] << 5) + kx[2], k3 = (tot[c][3] << 5) + kx[3];
+                        uint32_t m = k0 < k1 ? k0 : k1;
+                        m = k2 < m ? k2 : m;
+                        m = k3 < m ? k3 : m;
+                        m += ky;
+                        best = m < best ? m : best;
+                    }
+                }
+                else
 #pragma unroll
                 for (int c = 0; c < ESA_R; c++)
                 {
