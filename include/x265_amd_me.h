@@ -283,6 +283,28 @@ int x265amd_bipred_batch(x265amd_ctx *ctx, const x265amd_plane *fenc, const x265
 int x265amd_bipred_batch_dev(x265amd_ctx *ctx, const x265amd_plane *fenc, const x265amd_plane *ref0, const x265amd_plane *ref1,
                              const x265amd_bipred_job *d_jobs, int njobs, x265amd_bipred_result *d_results);
 
+/* ---- merge-candidate estimate ---- */
+
+/* The distortion of the merge candidates of a 2Nx2N CU (encoder/compress.cpp:248-271): luma motion
+ * compensation of the candidate (TComPrediction::motionCompensation with bLuma only,
+ * Lib/TLibCommon/TComPrediction.cpp:214-283 -- dir 1 / 2: one list through xPredInterLumaBlk's
+ * pixel path, :405-438; dir 3: both lists through its 14-bit path, :441-476, and TComYuv::addAvg,
+ * Lib/TLibCommon/TComYuv.cpp:573-612) and primitives.sa8d against the source CU (:265). The
+ * caller has clipped the MVs (TComDataCU::clipMv) and turned a candidate whose two lists are the
+ * same picture and MV into dir 1 (xCheckIdenticalMotion, TComPrediction.cpp:276). Weighted
+ * prediction flavours (:252-268) are not covered. */
+typedef struct
+{
+    int16_t pu_x, pu_y;
+    uint8_t size;              /* 8, 16, 32 or 64 */
+    uint8_t dir;               /* interDir: 1 = list 0, 2 = list 1, 3 = both */
+    uint8_t ref0, ref1;        /* indices into `refs` */
+    int16_t mv0[2], mv1[2];    /* quarter-pel */
+} x265amd_merge_job;
+/* refs: nrefs (<= 32) reconstructed reference planes; jobs / sa8d: HOST arrays */
+int x265amd_merge_sa8d_batch(x265amd_ctx *ctx, const x265amd_plane *fenc, const x265amd_plane *refs, int nrefs,
+                             const x265amd_merge_job *jobs, int njobs, int32_t *sa8d);
+
 /* ---- Rockchip path (rd >= 5): CIME + RIME + FME ---- */
 
 /* One 64x64 CTU against one reference picture: everything the 15-argument

@@ -55,6 +55,11 @@ BIPRED_JOB_DTYPE = np.dtype([("pu_x", "<i2"), ("pu_y", "<i2"), ("w", "u1"), ("h"
 assert BIPRED_JOB_DTYPE.itemsize == 16
 
 
+MERGE_JOB_DTYPE = np.dtype([("pu_x", "<i2"), ("pu_y", "<i2"), ("size", "u1"), ("dir", "u1"), ("ref0", "u1"), ("ref1", "u1"),
+                            ("mv0", "<i2", (2,)), ("mv1", "<i2", (2,))], align=True)
+assert MERGE_JOB_DTYPE.itemsize == 16
+
+
 def build_oracle():
     import subprocess
     subprocess.check_call(["make", "-C", HERE, "libme_oracle.so"], stdout=subprocess.DEVNULL)
@@ -239,6 +244,15 @@ class Oracle:
         out = np.zeros((len(jobs), 2), np.int32)
         self.L.orc_bipred_batch(depth, _p(fenc, origin), C.c_ssize_t(stride), _p(ref0, origin), _p(ref1, origin), C.c_ssize_t(stride),
                                 _p(jobs), len(jobs), _p(out))
+        return out
+
+    def merge_sa8d_batch(self, depth, fenc, refs, origin, stride, jobs):
+        """jobs: MERGE_JOB_DTYPE records; refs: list of padded reference buffers (same geometry). Returns int32 [n]."""
+        jobs = np.ascontiguousarray(jobs, MERGE_JOB_DTYPE)
+        out = np.zeros(len(jobs), np.int32)
+        ptrs = (C.c_void_p * len(refs))(*[r.ctypes.data + origin * r.itemsize for r in refs])
+        strides = (C.c_ssize_t * len(refs))(*[stride] * len(refs))
+        self.L.orc_merge_sa8d_batch(depth, _p(fenc, origin), C.c_ssize_t(stride), ptrs, strides, _p(jobs), len(jobs), _p(out))
         return out
 
 
@@ -485,4 +499,14 @@ class Ref:
             self.L.ref_bipred_cost(_p(fenc, off), C.c_ssize_t(stride), _p(ref0, off), _p(ref1, off), C.c_ssize_t(stride),
                                    int(j["w"]), int(j["h"]), mv0, mv1, r)
             out[i] = (r[0], r[1])
+        return out
+
+    def merge_sa8d_batch(self, fenc, refs, origin, stride, jobs):
+        out = np.zeros(len(jobs), np.int32)
+        for i, j in enumerate(jobs):
+            off = origin + int(j["pu_y"]) * stride + int(j["pu_x"])
+            mv0 = (C.c_int16 * 2)(int(j["mv0"][0]), int(j["mv0"][1]))
+            mv1 = (C.c_int16 * 2)(int(j["mv1"][0]), int(j["mv1"][1]))
+            out[i] = self.L.ref_merge_sa8d(_p(fenc, off), C.c_ssize_t(stride), _p(refs[int(j["ref0"])], off), C.c_ssize_t(stride),
+                                           _p(refs[int(j["ref1"])], off), C.c_ssize_t(stride), int(j["size"]), int(j["dir"]), mv0, mv1)
         return out

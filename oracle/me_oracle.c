@@ -362,3 +362,22 @@ void orc_bipred_batch(int depth, const void *fenc, intptr_t fstride, const void 
                            j->w, j->h, depth, j->mv0[0], j->mv0[1], j->mv1[0], j->mv1[1], out + 2 * i);
     }
 }
+
+
+void orc_merge_sa8d_batch(int depth, const void *fenc, intptr_t fstride, const void *const *refs, const intptr_t *rstrides,
+                          const orc_merge_job *jobs, int n, int32_t *out)
+{
+    for (int i = 0; i < n; i++)
+    {
+        const orc_merge_job *j = jobs + i;
+        const intptr_t fo = (intptr_t)j->pu_y * fstride + j->pu_x;
+        const intptr_t s0 = rstrides[j->ref0], s1 = rstrides[j->ref1];
+        const intptr_t o0 = (intptr_t)j->pu_y * s0 + j->pu_x, o1 = (intptr_t)j->pu_y * s1 + j->pu_x;
+        if (depth <= 8)
+            out[i] = merge_sa8d_8((const uint8_t*)fenc + fo, fstride, (const uint8_t*)refs[j->ref0] + o0, s0,
+                                  (const uint8_t*)refs[j->ref1] + o1, s1, j->size, depth, j->dir, j->mv0[0], j->mv0[1], j->mv1[0], j->mv1[1]);
+        else
+            out[i] = merge_sa8d_16((const uint16_t*)fenc + fo, fstride, (const uint16_t*)refs[j->ref0] + o0, s0,
+                                   (const uint16_t*)refs[j->ref1] + o1, s1, j->size, depth, j->dir, j->mv0[0], j->mv0[1], j->mv1[0], j->mv1[1]);
+    }
+}

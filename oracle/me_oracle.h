@@ -163,6 +163,15 @@ typedef struct { int16_t pu_x, pu_y; uint8_t w, h, reserved[2]; int16_t mv0[2], 
 void orc_bipred_batch(int depth, const void *fenc, intptr_t fstride, const void *ref0, const void *ref1, intptr_t rstride,
                       const orc_bipred_job *jobs, int n, int32_t *out);
 
+/* ---- merge-candidate estimate of the CU analysis (source/encoder/compress.cpp:248-271): luma motion
+ * compensation of each candidate (TComPrediction::motionCompensation, source/Lib/TLibCommon/
+ * TComPrediction.cpp:214-283: one list through the pixel path, two lists through the 14-bit path
+ * and TComYuv::addAvg) and primitives.sa8d against the source CU. Job layout = x265amd_merge_job;
+ * refs / rstrides: plane origins and strides indexed by job.ref0 / ref1. */
+typedef struct { int16_t pu_x, pu_y; uint8_t size, dir, ref0, ref1; int16_t mv0[2], mv1[2]; } orc_merge_job;
+void orc_merge_sa8d_batch(int depth, const void *fenc, intptr_t fstride, const void *const *refs, const intptr_t *rstrides,
+                          const orc_merge_job *jobs, int n, int32_t *out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1314,3 +1314,72 @@ static void FN(bipred_cost)(const PIXEL *fenc_pu, intptr_t fstride, const PIXEL 
     FN(pixelavg)(avg, 64, ref0_pu, rstride, ref1_pu, rstride, w, h);
     out[1] = FN(satd)(fenc_pu, fstride, avg, 64, w, h);
 }
+
+
+/* ---------------- merge-candidate estimate (compress.cpp:248-271) ---------------- */
+
+/* TComPrediction::xPredInterLumaBlk into 14-bit intermediates (TComPrediction.cpp:441-476):
+ * luma_p2s (ipfilter.cpp:155-172), luma_hps, filterVertical_ps_c (:122-153) or luma_hps with row
+ * extension + filterVertical_ss_c (:84-119); buf pitch 64 */
+static void FN(mc_short)(const PIXEL *ref_pu, intptr_t stride, int qx, int qy, int w, int h, int depth, int16_t *buf)
+{
+    const int xFrac = qx & 3, yFrac = qy & 3, headRoom = 14 - depth;
+    const int shift = 6 - headRoom, offset = -(8192 << shift);
+    const PIXEL *src = ref_pu + (qx >> 2) + (qy >> 2) * stride;
+    if ((xFrac | yFrac) == 0)
+    {
+        for (int y = 0; y < h; y++)
+            for (int x = 0; x < w; x++) buf[y * 64 + x] = (int16_t)((int16_t)(src[y * stride + x] << headRoom) - (int16_t)8192);
+    }
+    else if (yFrac == 0)
+        FN(luma_hps)(src, stride, buf, 64, xFrac, 0, w, h, depth);
+    else if (xFrac == 0)
+    {
+        const int16_t *c = orc_luma_filter[yFrac];
+        for (int y = 0; y < h; y++)
+            for (int x = 0; x < w; x++)
+            {
+                int sum = 0;
+                for (int k = 0; k < 8; k++) sum += (int)src[(y - 3 + k) * stride + x] * c[k];
+                buf[y * 64 + x] = (int16_t)((sum + offset) >> shift);
+            }
+    }
+    else
+    {
+        int16_t immed[64 * (64 + 8)];
+        const int16_t *c = orc_luma_filter[yFrac];
+        FN(luma_hps)(src, stride, immed, w, xFrac, 1, w, h, depth);
+        for (int y = 0; y < h; y++)
+            for (int x = 0; x < w; x++)
+            {
+                int sum = 0;
+                for (int k = 0; k < 8; k++) sum += (int)immed[(y + k) * w + x] * c[k];
+                buf[y * 64 + x] = (int16_t)(sum >> 6);
+            }
+    }
+}
+
+/* Luma motion compensation of one merge candidate of a size x size CU and its sa8d against the
+ * source: dir 1 / 2 = one list through the pixel path (xPredInterUni), 3 = both lists through
+ * the 14-bit path and TComYuv::addAvg (TComYuv.cpp:573-612) */
+static int FN(merge_sa8d)(const PIXEL *fenc_pu, intptr_t fstride, const PIXEL *ref0_pu, intptr_t r0stride, const PIXEL *ref1_pu,
+                          intptr_t r1stride, int size, int depth, int dir, int mv0x, int mv0y, int mv1x, int mv1y)
+{
+    PIXEL pred[64 * 64];
+    if (dir == 1) FN(mc_luma)(ref0_pu, r0stride, mv0x, mv0y, size, size, depth, pred);
+    else if (dir == 2) FN(mc_luma)(ref1_pu, r1stride, mv1x, mv1y, size, size, depth, pred);
+    else
+    {
+        int16_t s0[64 * 64], s1[64 * 64];
+        FN(mc_short)(ref0_pu, r0stride, mv0x, mv0y, size, size, depth, s0);
+        FN(mc_short)(ref1_pu, r1stride, mv1x, mv1y, size, size, depth, s1);
+        const int shiftNum = 15 - depth, offset = (1 << (shiftNum - 1)) + 2 * 8192, maxv = (1 << depth) - 1;
+        for (int y = 0; y < size; y++)
+            for (int x = 0; x < size; x++)
+            {
+                const int v = (s0[y * 64 + x] + s1[y * 64 + x] + offset) >> shiftNum;
+                pred[y * 64 + x] = (PIXEL)(v < 0 ? 0 : (v > maxv ? maxv : v));
+            }
+    }
+    return FN(sa8d_inter)(fenc_pu, fstride, pred, 64, size, size);
+}

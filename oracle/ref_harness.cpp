@@ -632,4 +632,54 @@ void ref_bipred_cost(pixel *fencPU, intptr_t fencStride, pixel *ref0PU, pixel *r
     free(p0);
 }
 
+/* ---- merge-candidate estimate (compress.cpp:248-271): the primitive calls that
+ * TComPrediction::motionCompensation makes for the luma of one candidate (xPredInterUni ->
+ * xPredInterLumaBlk, TComPrediction.cpp:405-476; two lists: the TShortYUV flavour and
+ * TComYuv::addAvg, TComYuv.cpp:573-612, whose loop is repeated here because TComYuv needs a whole
+ * CU buffer set), then primitives.sa8d[log2 size - 3] as compress.cpp:265 calls it. ---- */
+static void harness_pred_luma_short(pixel *refPU, intptr_t stride, int qx, int qy, int part, int width, int height, int16_t *dst,
+                                    int16_t *immed)
+{
+    pixel *ref = refPU + (qx >> 2) + (qy >> 2) * stride;
+    const int xFrac = qx & 3, yFrac = qy & 3;
+    if ((yFrac | xFrac) == 0) primitives.luma_p2s(ref, stride, dst, width, height);
+    else if (yFrac == 0) primitives.luma_hps[part](ref, stride, dst, MAX_CU_SIZE, xFrac, 0);
+    else if (xFrac == 0) primitives.ipfilter_ps[FILTER_V_P_S_8](ref, stride, dst, MAX_CU_SIZE, width, height, g_lumaFilter[yFrac]);
+    else
+    {
+        primitives.luma_hps[part](ref, stride, immed, width, xFrac, 1);
+        primitives.ipfilter_ss[FILTER_V_S_S_8](immed + 3 * width, width, dst, MAX_CU_SIZE, width, height, yFrac);
+    }
+}
+
+int ref_merge_sa8d(pixel *fencPU, intptr_t fencStride, pixel *ref0PU, intptr_t ref0Stride, pixel *ref1PU, intptr_t ref1Stride,
+                   int size, int dir, const int16_t *mv0, const int16_t *mv1)
+{
+    const int part = partitionFromSizes(size, size);
+    pixel *pred = (pixel*)malloc(sizeof(pixel) * 64 * 64);
+    int16_t *immed = (int16_t*)malloc(sizeof(int16_t) * 64 * (64 + 8));
+    if (dir == 1) harness_pred_luma(ref0PU, ref0Stride, mv0[0], mv0[1], part, size, pred, 64, immed);
+    else if (dir == 2) harness_pred_luma(ref1PU, ref1Stride, mv1[0], mv1[1], part, size, pred, 64, immed);
+    else
+    {
+        int16_t *s0 = (int16_t*)malloc(sizeof(int16_t) * 64 * 64 * 2), *s1 = s0 + 64 * 64;
+        harness_pred_luma_short(ref0PU, ref0Stride, mv0[0], mv0[1], part, size, size, s0, immed);
+        harness_pred_luma_short(ref1PU, ref1Stride, mv1[0], mv1[1], part, size, size, s1, immed);
+        const int shiftNum = IF_INTERNAL_PREC + 1 - X265_DEPTH;
+        const int offset = (1 << (shiftNum - 1)) + 2 * IF_INTERNAL_OFFS;
+        const int maxv = (1 << X265_DEPTH) - 1;
+        for (int y = 0; y < size; y++)
+            for (int x = 0; x < size; x++)
+            {
+                int v = (s0[y * 64 + x] + s1[y * 64 + x] + offset) >> shiftNum;
+                pred[y * 64 + x] = (pixel)(v < 0 ? 0 : (v > maxv ? maxv : v));
+            }
+        free(s0);
+    }
+    const int cost = primitives.sa8d[g_convertToBit[size]](fencPU, fencStride, pred, 64);
+    free(immed);
+    free(pred);
+    return cost;
+}
+
 } // extern "C"

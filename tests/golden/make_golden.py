@@ -161,6 +161,7 @@ def main():
     make_frame_cost(shas)
     make_wp(shas)
     make_bipred(shas)
+    make_merge(shas)
     json.dump(shas, open(os.path.join(HERE, "input_sha.json"), "w"), indent=0, sort_keys=True)
     print("golden vectors written to", HERE)
 
@@ -293,6 +294,37 @@ def make_bipred(shas):
     np.savez_compressed(os.path.join(HERE, "bipred_golden.npz"), **out)
 
 
+def merge_case(depth):
+    """(fenc, [3 refs] padded buffers, origin, stride, jobs) of the merge-candidate vectors."""
+    from oracle.bindings import MERGE_JOB_DTYPE
+    clip = make_clip(ME_W, ME_H, 4, seed=8, depth=depth)
+    f, org, stride = pad_plane(clip[1], 96)
+    refs = [pad_plane(clip[k], 96)[0] for k in (0, 2, 3)]
+    rng = np.random.default_rng(3)
+    jobs = np.zeros(240, MERGE_JOB_DTYPE)
+    for i, j in enumerate(jobs):
+        s = (8, 16, 32, 64)[i % 4]
+        j["pu_x"], j["pu_y"], j["size"] = int(rng.integers(0, (ME_W - s) // 8 + 1)) * 8, int(rng.integers(0, (ME_H - s) // 8 + 1)) * 8, s
+        j["dir"], j["ref0"], j["ref1"] = 1 + i % 3, int(rng.integers(0, 3)), int(rng.integers(0, 3))
+        j["mv0"], j["mv1"] = rng.integers(-120, 121, 2), rng.integers(-120, 121, 2)
+        if i % 5 == 0:
+            j["mv0"] = (j["mv0"] // 4) * 4
+        if i % 7 == 0:
+            j["mv1"][0] = (j["mv1"][0] // 4) * 4
+        if i % 11 == 0:
+            j["mv1"][1] = (j["mv1"][1] // 4) * 4
+    return f, refs, org, stride, jobs
+
+
+def make_merge(shas):
+    out = {}
+    for depth in (8, 10):
+        f, refs, org, stride, jobs = merge_case(depth)
+        shas["merge_%d" % depth] = [sha(f)] + [sha(r) for r in refs] + [sha(jobs)]
+        out["%d" % depth] = Ref(depth).merge_sa8d_batch(f, refs, org, stride, jobs)
+    np.savez_compressed(os.path.join(HERE, "merge_golden.npz"), **out)
+
+
 def make_cmodel(shas):
     """Records of the reference's hardware C-model: coarse stage (CoarseIntMotionEstimation::CIME,
     hardwareC/inter.cpp:679-734), refine + fractional stages for the 85 CUs of each CTU
@@ -319,11 +351,11 @@ def make_cmodel(shas):
 
 
 if __name__ == "__main__":
-    if sys.argv[1:] in (["cmodel"], ["framecost"], ["wp"], ["bipred"]):
+    if sys.argv[1:] in (["cmodel"], ["framecost"], ["wp"], ["bipred"], ["merge"]):
         # only (re)generate the C-model / frame-cost records, keeping the other files as they are
         shas_path = os.path.join(HERE, "input_sha.json")
         shas_ = json.load(open(shas_path))
-        {"cmodel": make_cmodel, "framecost": make_frame_cost, "wp": make_wp, "bipred": make_bipred}[sys.argv[1]](shas_)
+        {"cmodel": make_cmodel, "framecost": make_frame_cost, "wp": make_wp, "bipred": make_bipred, "merge": make_merge}[sys.argv[1]](shas_)
         json.dump(shas_, open(shas_path, "w"), indent=0, sort_keys=True)
     else:
         main()

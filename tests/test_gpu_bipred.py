@@ -47,3 +47,41 @@ def test_bipred_unaligned_and_edges_vs_oracle(engine8, oracle):
     bad["w"] = 20
     with pytest.raises(Exception):
         engine8.bipred_batch(pf, p0, p1, bad)
+
+
+@pytest.mark.parametrize("depth", [8, 10])
+def test_merge_sa8d_golden(request, depth):
+    e = request.getfixturevalue("engine8" if depth == 8 else "engine10")
+    f, refs, org, stride, jobs = G.merge_case(depth)
+    pf = e.upload_plane(f, G.ME_W, G.ME_H, 96, 96, stride)
+    pr = [e.upload_plane(r, G.ME_W, G.ME_H, 96, 96, stride) for r in refs]
+    assert np.array_equal(e.merge_sa8d_batch(pf, pr, jobs), G.merge_golden()[depth])
+    for p in [pf] + pr:
+        e.free_plane(p)
+
+
+def test_merge_sa8d_fractions_vs_oracle(engine8, oracle):
+    """All 256 fraction pairs of bi-predicted candidates on noise, unaligned CU positions, rejected jobs."""
+    from x265_amd.engine import MERGE_JOB_DTYPE
+    W, H, M = 160, 96, 80
+    clip = make_clip(W, H, 3, seed=14, depth=8, kind="noise")
+    f, org, stride = pad_plane(clip[1], M)
+    refs = [pad_plane(clip[0], M)[0], pad_plane(clip[2], M)[0]]
+    pf = engine8.upload_plane(f, W, H, M, M, stride)
+    pr = [engine8.upload_plane(r, W, H, M, M, stride) for r in refs]
+    rng = np.random.default_rng(16)
+    jobs = np.zeros(256 + 60, MERGE_JOB_DTYPE)
+    for i, j in enumerate(jobs):
+        s = (8, 16, 32, 64)[i % 4]
+        j["pu_x"], j["pu_y"], j["size"] = int(rng.integers(0, W - s + 1)), int(rng.integers(0, H - s + 1)), s
+        j["dir"], j["ref0"], j["ref1"] = (3 if i < 256 else 1 + i % 2), i % 2, (i // 2) % 2
+        j["mv0"], j["mv1"] = rng.integers(-150, 151, 2), rng.integers(-150, 151, 2)
+        if i < 256:
+            j["mv0"] = ((j["mv0"][0] & ~3) | (i & 3), (j["mv0"][1] & ~3) | ((i >> 2) & 3))
+            j["mv1"] = ((j["mv1"][0] & ~3) | ((i >> 4) & 3), (j["mv1"][1] & ~3) | ((i >> 6) & 3))
+    assert np.array_equal(engine8.merge_sa8d_batch(pf, pr, jobs), oracle.merge_sa8d_batch(8, f, refs, org, stride, jobs))
+    for field, val in (("size", 12), ("dir", 0), ("ref1", 2)):
+        bad = jobs[:1].copy()
+        bad[field] = val
+        with pytest.raises(Exception):
+            engine8.merge_sa8d_batch(pf, pr, bad)

@@ -164,3 +164,10 @@ def test_bipred_cost(oracle, depth):
     f, r0, r1, org, stride, jobs = G.bipred_case(depth)
     assert [G.sha(f), G.sha(r0), G.sha(r1), G.sha(jobs)] == G.input_shas()["bipred_%d" % depth]
     assert np.array_equal(oracle.bipred_batch(depth, f, r0, r1, org, stride, jobs), G.bipred_golden()[depth])
+
+
+@pytest.mark.parametrize("depth", [8, 10])
+def test_merge_sa8d(oracle, depth):
+    f, refs, org, stride, jobs = G.merge_case(depth)
+    assert [G.sha(f)] + [G.sha(r) for r in refs] + [G.sha(jobs)] == G.input_shas()["merge_%d" % depth]
+    assert np.array_equal(oracle.merge_sa8d_batch(depth, f, refs, org, stride, jobs), G.merge_golden()[depth])

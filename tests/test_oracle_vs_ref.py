@@ -259,3 +259,24 @@ def test_bipred_vs_reference(oracle, ref):
         j["pu_x"], j["pu_y"], j["w"], j["h"] = int(rng.integers(0, 160 - w + 1)), int(rng.integers(0, 96 - h + 1)), w, h
         j["mv0"], j["mv1"] = rng.integers(-200, 201, 2), rng.integers(-200, 201, 2)
     assert np.array_equal(ref.bipred_batch(f, r0, r1, org, stride, jobs), oracle.bipred_batch(depth, f, r0, r1, org, stride, jobs))
+
+
+def test_merge_sa8d_vs_reference(oracle, ref):
+    """Uni- and bi-predicted merge candidates on noise (every fraction pair, clipping at both ends of the range)."""
+    from oracle.bindings import MERGE_JOB_DTYPE
+    from x265_amd.synth import make_clip, pad_plane
+    depth = ref.depth
+    clip = make_clip(160, 96, 3, seed=14, depth=depth, kind="noise")
+    f, org, stride = pad_plane(clip[1], 80)
+    refs = [pad_plane(clip[0], 80)[0], pad_plane(clip[2], 80)[0]]
+    rng = np.random.default_rng(16)
+    jobs = np.zeros(16 * 16 + 60, MERGE_JOB_DTYPE)
+    for i, j in enumerate(jobs):
+        s = (8, 16, 32, 64)[i % 4]
+        j["pu_x"], j["pu_y"], j["size"] = int(rng.integers(0, 160 - s + 1)), int(rng.integers(0, 96 - s + 1)), s
+        j["dir"], j["ref0"], j["ref1"] = (3 if i < 256 else 1 + i % 2), i % 2, (i // 2) % 2
+        j["mv0"], j["mv1"] = rng.integers(-150, 151, 2), rng.integers(-150, 151, 2)
+        if i < 256:   # all 16 x 16 fraction pairs of the two lists
+            j["mv0"] = ((j["mv0"][0] & ~3) | (i & 3), (j["mv0"][1] & ~3) | ((i >> 2) & 3))
+            j["mv1"] = ((j["mv1"][0] & ~3) | ((i >> 4) & 3), (j["mv1"][1] & ~3) | ((i >> 6) & 3))
+    assert np.array_equal(ref.merge_sa8d_batch(f, refs, org, stride, jobs), oracle.merge_sa8d_batch(depth, f, refs, org, stride, jobs))

@@ -1552,6 +1552,53 @@ int x265amd_bipred_batch(x265amd_ctx *c, const x265amd_plane *fenc, const x265am
     return X265AMD_OK;
 }
 
+/* ---- merge-candidate estimate ---- */
+
+int x265amd_merge_sa8d_batch(x265amd_ctx *c, const x265amd_plane *fenc, const x265amd_plane *refs, int nrefs,
+                             const x265amd_merge_job *jobs, int njobs, int32_t *sa8d)
+{
+    if (!c || !fenc || !fenc->origin || !refs || nrefs <= 0 || nrefs > 32 || !jobs || !sa8d || njobs < 0)
+        return fail(c, X265AMD_EINVAL, "null argument");
+    if (!njobs) return X265AMD_OK;
+    for (int i = 0; i < njobs; i++)
+    {
+        const x265amd_merge_job &j = jobs[i];
+        if (!(j.size == 8 || j.size == 16 || j.size == 32 || j.size == 64)) return fail(c, X265AMD_EINVAL, "job: CU size must be 8, 16, 32 or 64");
+        if (j.dir < 1 || j.dir > 3 || j.ref0 >= nrefs || j.ref1 >= nrefs) return fail(c, X265AMD_EINVAL, "job: bad direction or reference index");
+        if (j.pu_x < 0 || j.pu_y < 0 || j.pu_x + j.size > fenc->width + fenc->margin_x || j.pu_y + j.size > fenc->height + fenc->margin_y)
+            return fail(c, X265AMD_EINVAL, "job: CU outside the source plane");
+        for (int l = 0; l < 2; l++)
+        {
+            if (!(j.dir & (1 << l))) continue;
+            const int16_t *mv = l ? j.mv1 : j.mv0;
+            const x265amd_plane *r = &refs[l ? j.ref1 : j.ref0];
+            const int x0 = j.pu_x + (mv[0] >> 2) - 3, x1 = j.pu_x + j.size + (mv[0] >> 2) + 8;
+            const int y0 = j.pu_y + (mv[1] >> 2) - 3, y1 = j.pu_y + j.size + (mv[1] >> 2) + 4;
+            if (!r->origin || x0 < -r->margin_x || y0 < -r->margin_y || x1 > r->width + r->margin_x || y1 > r->height + r->margin_y)
+                return fail(c, X265AMD_EINVAL, "job: prediction block leaves the padded reference plane");
+        }
+    }
+    HIPCHK(c, hipSetDevice(c->device));
+    int rc;
+    PlaneDev hp[32];
+    for (int i = 0; i < nrefs; i++) { hp[i].origin = refs[i].origin; hp[i].stride = refs[i].stride; }
+    const size_t jb = (size_t)njobs * sizeof(x265amd_merge_job), pb = sizeof(PlaneDev) * 32;
+    if ((rc = ensure(c, &c->d_jobs, &c->jobs_cap, jb + pb))) return rc;
+    if ((rc = ensure(c, &c->d_results, &c->results_cap, (size_t)njobs * sizeof(int32_t)))) return rc;
+    HIPCHK(c, hipMemcpyAsync(c->d_jobs, hp, sizeof(PlaneDev) * nrefs, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync((char*)c->d_jobs + pb, jobs, jb, hipMemcpyHostToDevice, c->stream));
+    MergeArgs a;
+    a.fenc.origin = fenc->origin; a.fenc.stride = fenc->stride;
+    a.refs = (const PlaneDev*)c->d_jobs; a.depth = c->depth; a.njobs = njobs;
+    a.jobs = (const x265amd_merge_job*)((char*)c->d_jobs + pb); a.out = (int32_t*)c->d_results;
+    if (c->depth <= 8) hipLaunchKernelGGL(merge_sa8d_kernel<uint8_t>, dim3(njobs), dim3(64), 0, c->stream, a);
+    else hipLaunchKernelGGL(merge_sa8d_kernel<uint16_t>, dim3(njobs), dim3(64), 0, c->stream, a);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipMemcpyAsync(sa8d, c->d_results, (size_t)njobs * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return X265AMD_OK;
+}
+
 int x265amd_rk_ds_plane(x265amd_ctx *c, const x265amd_plane *orig, x265amd_plane *out)
 {
     if (!c || !orig || !orig->origin || !out) return fail(c, X265AMD_EINVAL, "null plane");

@@ -560,7 +560,194 @@ __global__ __launch_bounds__(64) void bipred_kernel(BipredArgs a)
     if (lane == 0) { a.results[j].satd = bi; a.results[j].satd_zero = zero; }
 }
 
+/* ---- merge-candidate estimate of the CU analysis (compress.cpp:248-271) ----
+ * One wave per candidate, a lane per 4x4 tile. Lanes are ordered so that a quad of lanes is an
+ * 8x8 block (2 x 2 tiles) and sixteen lanes a 16x16 block: the 8x8 Hadamard of sa8d is the 4x4
+ * Hadamard of each tile followed by sum / difference steps across the quad (DPP), and the 16x16
+ * rounding of sa8d_16x16 (pixel.cpp:332-342) is a sum over sixteen lanes. */
+struct MergeArgs
+{
+    PlaneDev fenc;
+    const PlaneDev *refs;      /* device array of nrefs planes */
+    int depth, njobs;
+    const x265amd_merge_job *jobs;
+    int32_t *out;
+};
+
+/* xPredInterLumaBlk into 14-bit intermediates (TComPrediction.cpp:441-476): luma_p2s, luma_hps,
+ * filterVertical_ps or luma_hps + filterVertical_ss (ipfilter.cpp:84-172), one 4x4 tile */
+template<typename P>
+__device__ __forceinline__ void mc_short_tile(const P AS1 *r, int stride, int qx, int qy, int depth, int o[4][4])
+{
+    const int xf = qx & 3, yf = qy & 3, headRoom = 14 - depth;
+    const int shift = 6 - headRoom, off = -(8192 << shift);
+    GlobalLoader<P> ld = { r + (long)(qy >> 2) * stride + (qx >> 2), stride };
+    int ch[8], cv[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) { ch[k] = kLumaTaps[xf][k]; cv[k] = kLumaTaps[yf][k]; }
+    if (yf == 0)
+    {
+#pragma unroll
+        for (int y = 0; y < 4; y++)
+        {
+            int px[12];
+            Px<P>::unpack(ld(-3, y), px);
+            Px<P>::unpack(ld(1, y), px + 4);
+            Px<P>::unpack(ld(5, y), px + 8);
+#pragma unroll
+            for (int x = 0; x < 4; x++)
+            {
+                int sum = 0;
+#pragma unroll
+                for (int k = 0; k < 8; k++) sum += px[x + k] * ch[k];
+                /* with xf = 0 the taps are {0,0,0,64,..}: (64 p - 8192 << shift) >> shift = (p << headRoom) - 8192 */
+                o[y][x] = as_i16((sum + off) >> shift);
+            }
+        }
+        return;
+    }
+    int win[8][4];
+#pragma unroll
+    for (int k = 0; k < 8; k++)
+#pragma unroll
+        for (int x = 0; x < 4; x++) win[k][x] = 0;
+    auto feed = [&](int row)
+    {
+#pragma unroll
+        for (int k = 0; k < 7; k++)
+#pragma unroll
+            for (int x = 0; x < 4; x++) win[k][x] = win[k + 1][x];
+        if (xf == 0)
+            Px<P>::unpack(ld(0, row), win[7]);
+        else
+        {
+            int px[12];
+            Px<P>::unpack(ld(-3, row), px);
+            Px<P>::unpack(ld(1, row), px + 4);
+            Px<P>::unpack(ld(5, row), px + 8);
+#pragma unroll
+            for (int x = 0; x < 4; x++)
+            {
+                int sum = 0;
+#pragma unroll
+                for (int k = 0; k < 8; k++) sum += px[x + k] * ch[k];
+                win[7][x] = as_i16((sum + off) >> shift);
+            }
+        }
+    };
+#pragma unroll 1
+    for (int rr = -3; rr < 4; rr++) feed(rr);
+#pragma unroll
+    for (int y = 0; y < 4; y++)
+    {
+        feed(y + 4);
+#pragma unroll
+        for (int x = 0; x < 4; x++)
+        {
+            int sum = 0;
+#pragma unroll
+            for (int k = 0; k < 8; k++) sum += win[k][x] * cv[k];
+            o[y][x] = xf == 0 ? as_i16((sum + off) >> shift) : as_i16(sum >> 6);
+        }
+    }
+}
+
+template<typename P>
+__global__ __launch_bounds__(64) void merge_sa8d_kernel(MergeArgs a)
+{
+    const int j = blockIdx.x;
+    if (j >= a.njobs) return;
+    const x265amd_merge_job *job = a.jobs + j;
+    const int lane = threadIdx.x & 63;
+    const int size = uni(job->size), dir = uni(job->dir), pux = uni(job->pu_x), puy = uni(job->pu_y);
+    const int m0x = uni(job->mv0[0]), m0y = uni(job->mv0[1]), m1x = uni(job->mv1[0]), m1y = uni(job->mv1[1]);
+    const PlaneDev r0 = a.refs[uni(job->ref0)], r1 = a.refs[uni(job->ref1)];
+    const int T = (size >> 2) * (size >> 2), g16 = size >> 4;       /* tiles; 16x16 blocks per row (0 for an 8x8 CU) */
+    const int maxv = (1 << a.depth) - 1;
+    int total = 0;
+    for (int t0 = 0; t0 < T; t0 += 64)
+    {
+        const int t = t0 + lane;
+        const bool live = t < T;
+        /* lane -> tile: bits 0-1 the tile inside its 8x8 block, bits 2-3 the 8x8 block inside its 16x16 block */
+        const int tt = live ? t : 0, g = tt >> 4;
+        const int gy = g16 ? g / g16 : 0, gx = g16 ? g - gy * g16 : 0;
+        const int ty = gy * 4 + ((tt >> 3) & 1) * 2 + ((tt >> 1) & 1), tx = gx * 4 + ((tt >> 2) & 1) * 2 + (tt & 1);
+        const long fo = (long)(puy + 4 * ty) * a.fenc.stride + pux + 4 * tx;
+        const long o0 = (long)(puy + 4 * ty) * r0.stride + pux + 4 * tx, o1 = (long)(puy + 4 * ty) * r1.stride + pux + 4 * tx;
+        int p[4][4];
+        if (dir == 3)
+        {
+            int s1[4][4];
+            mc_short_tile<P>((const P AS1*)r0.origin + o0, r0.stride, m0x, m0y, a.depth, p);
+            mc_short_tile<P>((const P AS1*)r1.origin + o1, r1.stride, m1x, m1y, a.depth, s1);
+            /* TComYuv::addAvg, TComYuv.cpp:596-606 */
+            const int shiftNum = 15 - a.depth, offset = (1 << (shiftNum - 1)) + 2 * 8192;
+#pragma unroll
+            for (int y = 0; y < 4; y++)
+#pragma unroll
+                for (int x = 0; x < 4; x++)
+                {
+                    const int v = (p[y][x] + s1[y][x] + offset) >> shiftNum;
+                    p[y][x] = v < 0 ? 0 : (v > maxv ? maxv : v);
+                }
+        }
+        else if (dir == 2)
+            bipred_tile<P>((const P AS1*)r1.origin + o1, r1.stride, m1x, m1y, a.depth, p);
+        else
+            bipred_tile<P>((const P AS1*)r0.origin + o0, r0.stride, m0x, m0y, a.depth, p);
+        int d[4][4];
+#pragma unroll
+        for (int y = 0; y < 4; y++)
+        {
+            int fv[4];
+            Px<P>::unpack(Px<P>::load_g((const P AS1*)a.fenc.origin + fo + (long)y * a.fenc.stride), fv);
+#pragma unroll
+            for (int x = 0; x < 4; x++) d[y][x] = fv[x] - p[y][x];
+        }
+        /* 4x4 Hadamard of the tile, rows then columns */
+#pragma unroll
+        for (int y = 0; y < 4; y++)
+        {
+            const int a0 = d[y][0] + d[y][1], a1 = d[y][0] - d[y][1], a2 = d[y][2] + d[y][3], a3 = d[y][2] - d[y][3];
+            d[y][0] = a0 + a2; d[y][1] = a1 + a3; d[y][2] = a0 - a2; d[y][3] = a1 - a3;
+        }
+        int s = 0;
+        const int n1 = -(lane & 1), n2 = -((lane >> 1) & 1);
+#pragma unroll
+        for (int x = 0; x < 4; x++)
+        {
+            const int a0 = d[0][x] + d[1][x], a1 = d[0][x] - d[1][x], a2 = d[2][x] + d[3][x], a3 = d[2][x] - d[3][x];
+            int c[4] = { a0 + a2, a1 + a3, a0 - a2, a1 - a3 };
+#pragma unroll
+            for (int i = 0; i < 4; i++)
+            {
+                /* the 8-point steps across the 2 x 2 tiles of the block: the lower lane of a pair
+                 * keeps the sum, the upper one the difference */
+                int v = c[i];
+                v = ((v ^ n1) - n1) + __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xf, 0xf, false);
+                v = ((v ^ n2) - n2) + __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xf, 0xf, false);
+                s += abs(v);
+            }
+        }
+        s = live ? s : 0;
+        if (g16)
+        {
+            s = seg_sum(s, 4);                                   /* sa8d_16x16: four 8x8 sums, rounded once */
+            total += (live && (lane & 15) == 0) ? (s + 2) >> 2 : 0;
+        }
+        else
+        {
+            s = seg_sum(s, 2);                                   /* sa8d_8x8 */
+            total += (live && (lane & 3) == 0) ? (s + 2) >> 2 : 0;
+        }
+    }
+    total = seg_sum(total, 6);
+    if (lane == 0) a.out[j] = total;
+}
+
 } // namespace x265amd
+
 
 
 #endif

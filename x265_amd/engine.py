@@ -40,6 +40,9 @@ assert RK_CTU_DTYPE.itemsize == 40 and RK_RESULT_DTYPE.itemsize == 171 * 8
 
 BIPRED_JOB_DTYPE = np.dtype([("pu_x", "<i2"), ("pu_y", "<i2"), ("w", "u1"), ("h", "u1"), ("reserved", "u1", (2,)),
                              ("mv0", "<i2", (2,)), ("mv1", "<i2", (2,))], align=True)
+MERGE_JOB_DTYPE = np.dtype([("pu_x", "<i2"), ("pu_y", "<i2"), ("size", "u1"), ("dir", "u1"), ("ref0", "u1"), ("ref1", "u1"),
+                            ("mv0", "<i2", (2,)), ("mv1", "<i2", (2,))], align=True)
+assert MERGE_JOB_DTYPE.itemsize == 16
 BIPRED_RESULT_DTYPE = np.dtype([("satd", "<i4"), ("satd_zero", "<i4")], align=True)
 assert BIPRED_JOB_DTYPE.itemsize == 16 and BIPRED_RESULT_DTYPE.itemsize == 8
 
@@ -366,6 +369,14 @@ class Engine:
     def bipred_batch_dev(self, fenc, ref0, ref1, d_jobs, njobs, d_results):
         self._chk(self.L.x265amd_bipred_batch_dev(self.ctx, C.byref(fenc), C.byref(ref0), C.byref(ref1), C.c_void_p(d_jobs), njobs,
                                                   C.c_void_p(d_results)))
+
+    # ---- merge-candidate estimate
+    def merge_sa8d_batch(self, fenc, refs, jobs):
+        jobs = np.ascontiguousarray(jobs, MERGE_JOB_DTYPE)
+        out = np.zeros(len(jobs), np.int32)
+        self._chk(self.L.x265amd_merge_sa8d_batch(self.ctx, C.byref(fenc), (Plane * len(refs))(*refs), len(refs),
+                                                  C.c_void_p(jobs.ctypes.data), len(jobs), C.c_void_p(out.ctypes.data)))
+        return out
 
     # ---- Rockchip path
     def rk_ds_plane(self, orig):
