@@ -476,7 +476,15 @@ __global__ __launch_bounds__(CIME_THREADS) void rk_cime_kernel(RkArgs a)
 template<typename P, bool HAVE_RIME>
 __global__ __launch_bounds__(64) void rk_cu_kernel(RkArgs a)
 {
-    const int ctuIdx = blockIdx.x / 85, idx = blockIdx.x % 85;
+    /* Longest work first: a 64x64 CU is 28 passes of the fractional grid, an 8x8 CU one. Workgroups
+     * start in index order, so all 64x64 CUs of the batch come first, then the 32x32, 16x16 and 8x8
+     * ones, and the launch ends on short waves instead of waiting for a last large CU. */
+    const int n = a.nctus, b = blockIdx.x;
+    int ctuIdx, idx;
+    if (b < n) { ctuIdx = b; idx = 84; }
+    else if (b < 5 * n) { ctuIdx = (b - n) >> 2; idx = 80 + ((b - n) & 3); }
+    else if (b < 21 * n) { ctuIdx = (b - 5 * n) >> 4; idx = 64 + ((b - 5 * n) & 15); }
+    else { ctuIdx = (b - 21 * n) >> 6; idx = (b - 21 * n) & 63; }
     const x265amd_rk_ctu &j = a.ctus[ctuIdx];
     x265amd_rk_result &res = a.results[ctuIdx];
     const int lane = threadIdx.x & 63;
