@@ -199,7 +199,7 @@ __global__ __launch_bounds__(LA_WAVES * 64) void lookahead_kernel(LookaheadArgs 
  * W + 2H searches of latency instead of W * H / 16. */
 #define LA_MV_UNSET 0x7FFF7FFF
 template<typename P>
-__global__ __launch_bounds__(64) void lookahead_rows_kernel(LookaheadArgs a)
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void lookahead_rows_kernel(LookaheadArgs a)
 {
     __shared__ x265amd_job jobs[1];
     __shared__ x265amd_result results[1];
