@@ -137,7 +137,8 @@ def main():
         el.sync()
         if world > 1:
             # hand the MV / cost records to the rank that feeds the host encoder
-            sharding.gather_records(torch.cat(d_res).view(-1), dist, dst=0)
+            # what the host encoder reads back: outQMv and the cost (8 of a record's 16 bytes; the rest are counters)
+            sharding.gather_records(torch.cat(d_res)[:, :8].contiguous().view(-1), dist, dst=0)
             sharding.gather_records(d_la_mvs.view(torch.uint8).view(-1), dist, dst=0)
 
     for _ in range(args.warmup):
