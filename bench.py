@@ -49,6 +49,9 @@ def main():
     ap.add_argument("--launch", choices=("split", "single", "per-size"), default="split",
                     help="search launches per frame: split = 16/8 PUs and 64/32 PUs on two streams (LDS per PU sized "
                          "per class); single = one launch; per-size = four launches on one stream")
+    ap.add_argument("--rehearse-one-gpu", action="store_true",
+                    help="rehearsal of the N > 1 control flow on a box with one GPU: every rank uses cuda:0 and the "
+                         "collectives go over gloo through host memory (RCCL wants one GPU per rank); not a measurement")
     ap.add_argument("--no-other-paths", action="store_true",
                     help="skip the exhaustive-search (4K) and Rockchip-path (1080p) measurements reported beside the headline")
     args = ap.parse_args()
@@ -62,10 +65,16 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.rehearse_one_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    cdev = torch.device("cpu") if args.rehearse_one_gpu else dev      # where collectives take their tensors
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        if args.rehearse_one_gpu:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
     method = METHODS[args.method]
     SUBME = args.subme
 
@@ -138,8 +147,8 @@ def main():
         if world > 1:
             # hand the MV / cost records to the rank that feeds the host encoder
             # what the host encoder reads back: outQMv and the cost (8 of a record's 16 bytes; the rest are counters)
-            sharding.gather_records(torch.cat(d_res)[:, :8].contiguous().view(-1), dist, dst=0)
-            sharding.gather_records(d_la_mvs.view(torch.uint8).view(-1), dist, dst=0)
+            sharding.gather_records(torch.cat(d_res)[:, :8].contiguous().view(-1).to(cdev), dist, dst=0)
+            sharding.gather_records(d_la_mvs.view(torch.uint8).view(-1).to(cdev), dist, dst=0)
 
     for _ in range(args.warmup):
         step()
@@ -156,7 +165,7 @@ def main():
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
@@ -164,7 +173,7 @@ def main():
     res = [r.cpu().numpy().view(RESULT_DTYPE).reshape(-1) for r in d_res]
     px_search = sum(workload.pixel_sads(host_jobs[i], res[i]) for i in range(B))
     px_step = px_search + la_pixel_sads
-    total_px = torch.tensor([float(px_step) * args.steps], dtype=torch.float64, device=dev)
+    total_px = torch.tensor([float(px_step) * args.steps], dtype=torch.float64, device=cdev)
     if world > 1:
         dist.all_reduce(total_px, op=dist.ReduceOp.SUM)
     value = float(total_px.item()) / elapsed / 1e9
