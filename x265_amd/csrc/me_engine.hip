@@ -503,9 +503,13 @@ __global__ __launch_bounds__(64) void rk_cu_kernel(RkArgs a)
         return;
     }
     Searcher<P, 64, false, true> S;
-    S.bind(0, a.fenc, &a.recon, 1, a.ctab, a.depth, j.ctu_x + ox, j.ctu_y + oy, size, size);
+    /* with the full-pel stage done elsewhere only the fractional grid reads the source block, one
+     * tile per lane straight from global memory: no LDS copy, and the reference region sits where
+     * the copy would be, which lets five waves instead of three share a SIMD's LDS */
+    S.bind(0, a.fenc, &a.recon, 1, a.ctab, a.depth, j.ctu_x + ox, j.ctu_y + oy, size, size, 64, 0, !HAVE_RIME);
     S.nsad = S.nsub = 0;
     S.set_rk_predictors(j.mvp, j.have_mvd);
+    const int woff = HAVE_RIME ? L_FENC : wave_lds_bytes<P>(64);
     int bcost = 0x7fffffff, bx = 0, by = 0;
     if (HAVE_RIME)
     {
@@ -533,7 +537,6 @@ __global__ __launch_bounds__(64) void rk_cu_kernel(RkArgs a)
         /* the reference region of the 49 fractional positions, copied once into LDS (the
          * reference copies the same neighbourhood into pfref, motion.cpp:1382-1389) */
         const int cols = RK_REGION_COLS(size), rows = RK_REGION_ROWS(size), rx0 = bx - 2, ry0 = by - 2;
-        const int woff = wave_lds_bytes<P>(64);
         const P AS1 *src = (const P AS1*)a.recon.origin + (long)(j.ctu_y + oy + ry0) * a.recon.stride + j.ctu_x + ox + rx0;
         const int qd = cols >> 2;
         for (int i = lane; i < rows * qd; i += 64)
@@ -556,7 +559,8 @@ __global__ __launch_bounds__(64) void rk_cu_kernel(RkArgs a)
         S.put_lanes(lane < 49, qx, qy, qx, qy, 16, 0);
         wave_sync();
         const int mvc = gather_mvcost(0, 49, 3, 1);
-        rk_fme_grid<P>(0, wave_lds_bytes<P>(64), RK_REGION_COLS(size), size, BX, BY, a.depth);
+        rk_fme_grid<P, HAVE_RIME>(0, woff, RK_REGION_COLS(size), size, BX, BY, a.depth,
+                                  (const P AS1*)a.fenc.origin + (long)(j.ctu_y + oy) * a.fenc.stride + j.ctu_x + ox, a.fenc.stride);
         if (lane < 49) lds_i(0, L_COSTS)[lane] += mvc;
         wave_sync();
         S.nsub += 49;
@@ -1659,7 +1663,7 @@ int x265amd_rk_ctu_batch_dev(x265amd_ctx *c, const x265amd_plane *fenc, const x2
         }
         hipLaunchKernelGGL(rk_cime_kernel<uint8_t>, dim3(nctus), dim3(CIME_THREADS), lds, c->stream, a);
         hipLaunchKernelGGL(rk_rime_kernel<uint8_t>, dim3(nctus), dim3(RIME_THREADS), RL_TOTAL, c->stream, a);
-        hipLaunchKernelGGL((rk_cu_kernel<uint8_t, true>), dim3(nctus * 85), dim3(64), wave_lds_bytes<uint8_t>(64) + rk_region_bytes<uint8_t>(64), c->stream, a);
+        hipLaunchKernelGGL((rk_cu_kernel<uint8_t, true>), dim3(nctus * 85), dim3(64), L_FENC + rk_region_bytes<uint8_t>(64), c->stream, a);
     }
     else
     {

@@ -214,8 +214,9 @@ __global__ __launch_bounds__(RIME_THREADS) void rk_rime_kernel(RkArgs a)
  * reference region (RK_REGION_COLS x RK_REGION_ROWS samples, first sample at RIME vector
  * - (2, 2)) and the source block are in LDS. costs[i * 7 + j] is left in the wave's L_COSTS
  * array, i = x offset index (outer in the reference's visit order), j = y offset index. */
-template<typename P>
-__device__ __forceinline__ void rk_fme_grid(int base, int region, int pitch, int size, int bxq, int byq, int depth)
+template<typename P, bool FENC_GLOBAL>
+__device__ __forceinline__ void rk_fme_grid(int base, int region, int pitch, int size, int bxq, int byq, int depth,
+                                            const P AS1 *fenc_g, int fenc_stride)
 {
     const int lane = threadIdx.x & 63;
     const int wt = size >> 2, T = wt * wt;
@@ -262,7 +263,8 @@ __device__ __forceinline__ void rk_fme_grid(int base, int region, int pitch, int
         int fv[4][4];
 #pragma unroll
         for (int y = 0; y < 4; y++)
-            Px<P>::unpack(Px<P>::load_lds_aligned(base + L_FENC + ((ty * 4 + y) * 64 + tx * 4) * (int)sizeof(P)), fv[y]);
+            Px<P>::unpack(FENC_GLOBAL ? Px<P>::load_g(fenc_g + (long)(ty * 4 + y) * fenc_stride + tx * 4)
+                                      : Px<P>::load_lds_aligned(base + L_FENC + ((ty * 4 + y) * 64 + tx * 4) * (int)sizeof(P)), fv[y]);
         const int sv = xf ? shiftV : 6, ov = xf ? offV : 32;
         for (int jj = 0; jj < 7; jj++)
         {

@@ -1438,7 +1438,7 @@ struct Searcher
      * reserved for source blocks; the interpolation planes follow them. */
     __device__ __forceinline__ void bind(int lds_base, const PlaneDev &fencPl, const PlaneDev *refPl, int nref,
                                          const uint16_t *costTab, int depth_, int pu_x, int pu_y, int w_, int h_,
-                                         int fenc_rows = ROWS, int budget = 0)
+                                         int fenc_rows = ROWS, int budget = 0, bool copy_fenc = true)
     {
         base = lds_base;
         lane = threadIdx.x & 63;
@@ -1463,7 +1463,8 @@ struct Searcher
         }
         if (!LOWRES && !RK && lane < 48) lds_i(base, L_TAPS)[lane] = kTapWords.w[lane];
         const P AS1 *src = (const P AS1*)fencPl.origin + (long)pu_y * fencPl.stride + pu_x;
-        for (int t = lane; t < T; t += 64)
+        /* a caller that reads the source block from global memory itself reserves no LDS for it */
+        for (int t = lane; copy_fenc && t < T; t += 64)
         {
             const int ty = (t * inv_wt) >> 16, tx = t - ty * wt;
 #pragma unroll
