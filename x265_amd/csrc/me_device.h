@@ -45,6 +45,13 @@ __device__ __forceinline__ void wave_sync()
 
 __device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
 
+/* v of the lane a DPP control word selects (quad permutes, row mirrors: patterns in which every
+ * lane has a source, so no previous value of the result needs to be kept) */
+template<int CTRL> __device__ __forceinline__ int dpp_all(int v)
+{
+    return __builtin_amdgcn_mov_dpp(v, CTRL, 0xf, 0xf, true);
+}
+
 /* ---- 4 horizontally adjacent pixels ---- */
 template<typename P> struct Px;
 

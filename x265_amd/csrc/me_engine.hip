@@ -797,7 +797,10 @@ static int launch_search(x265amd_ctx *c, const SearchArgs &a, int is_lowres)
     if (is_lowres)
         hipLaunchKernelGGL((search_kernel<P, true>), dim3(a.njobs), dim3(64), wave_lds_bytes<P>(8), c->stream, a);
     else
-        hipLaunchKernelGGL((search_kernel<P, false>), dim3(a.njobs), dim3(64), wave_lds_bytes<P>(a.max_dim, true), c->stream, a);
+    {
+        static const int pad = getenv("X265AMD_LDS_PAD") ? atoi(getenv("X265AMD_LDS_PAD")) : 0;   /* occupancy experiments */
+        hipLaunchKernelGGL((search_kernel<P, false>), dim3(a.njobs), dim3(64), wave_lds_bytes<P>(a.max_dim, true) + pad, c->stream, a);
+    }
     HIPCHK(c, hipGetLastError());
     return X265AMD_OK;
 }

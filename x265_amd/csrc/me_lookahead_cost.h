@@ -725,8 +725,8 @@ __global__ __launch_bounds__(64) void merge_sa8d_kernel(MergeArgs a)
                 /* the 8-point steps across the 2 x 2 tiles of the block: the lower lane of a pair
                  * keeps the sum, the upper one the difference */
                 int v = c[i];
-                v = ((v ^ n1) - n1) + __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xf, 0xf, false);
-                v = ((v ^ n2) - n2) + __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xf, 0xf, false);
+                v = ((v ^ n1) - n1) + dpp_all<0xB1>(v);
+                v = ((v ^ n2) - n2) + dpp_all<0x4E>(v);
                 s += abs(v);
             }
         }

@@ -134,10 +134,10 @@ template<typename P> constexpr int wave_lds_bytes(int rows, bool planes = false)
 /* sum over each group of 2^l adjacent lanes, left in every lane of the group */
 __device__ __forceinline__ int seg_sum(int v, int l)
 {
-    if (l >= 1) v += __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xf, 0xf, false);  /* quad_perm [1,0,3,2] */
-    if (l >= 2) v += __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xf, 0xf, false);  /* quad_perm [2,3,0,1] */
-    if (l >= 3) v += __builtin_amdgcn_update_dpp(0, v, 0x141, 0xf, 0xf, false); /* row_half_mirror */
-    if (l >= 4) v += __builtin_amdgcn_update_dpp(0, v, 0x140, 0xf, 0xf, false); /* row_mirror */
+    if (l >= 1) v += dpp_all<0xB1>(v);  /* quad_perm [1,0,3,2] */
+    if (l >= 2) v += dpp_all<0x4E>(v);  /* quad_perm [2,3,0,1] */
+    if (l >= 3) v += dpp_all<0x141>(v); /* row_half_mirror */
+    if (l >= 4) v += dpp_all<0x140>(v); /* row_mirror */
     if (l >= 5) v += __shfl_xor(v, 16);
     if (l >= 6) v += __shfl_xor(v, 32);
     return v;
@@ -147,10 +147,10 @@ __device__ __forceinline__ int seg_sum(int v, int l)
 __device__ __forceinline__ int row_min16(int v)
 {
     int o;
-    o = __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xf, 0xf, false); v = o < v ? o : v;
-    o = __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xf, 0xf, false); v = o < v ? o : v;
-    o = __builtin_amdgcn_update_dpp(0, v, 0x141, 0xf, 0xf, false); v = o < v ? o : v;
-    o = __builtin_amdgcn_update_dpp(0, v, 0x140, 0xf, 0xf, false); v = o < v ? o : v;
+    o = dpp_all<0xB1>(v); v = o < v ? o : v;
+    o = dpp_all<0x4E>(v); v = o < v ? o : v;
+    o = dpp_all<0x141>(v); v = o < v ? o : v;
+    o = dpp_all<0x140>(v); v = o < v ? o : v;
     return v;
 }
 
@@ -244,7 +244,7 @@ struct Geo
 template<typename P, bool LOWRES, bool RK>
 __device__ __forceinline__ int tile_cost(int base, const Geo &c, int k, int t, int mode)
 {
-    const int ty = (t * c.inv_wt) >> 16, tx = t - ty * c.wt;
+    const int ty = __umul24(t, c.inv_wt) >> 16, tx = t - __mul24(ty, c.wt);
     typename Px<P>::quad f[4], q[4];
 #pragma unroll
     for (int y = 0; y < 4; y++) f[y] = Px<P>::load_lds_aligned(base + L_FENC + ((ty * 4 + y) * 64 + tx * 4) * (int)sizeof(P));
@@ -252,7 +252,7 @@ __device__ __forceinline__ int tile_cost(int base, const Geo &c, int k, int t, i
     const P AS1 *ref0 = (const P AS1*)c.ref[0];
     if (mode == 0)
     {
-        const P AS1 *r = ref0 + c.roff + (long)(cy + ty * 4) * c.rstride + cx + tx * 4;
+        const P AS1 *r = ref0 + c.roff + (long)__mul24(cy + ty * 4, c.rstride) + cx + tx * 4;
 #pragma unroll
         for (int y = 0; y < 4; y++) q[y] = Px<P>::load_g(r + y * c.rstride);
         return tile_cost_quads<P>(f, q, false);
@@ -262,14 +262,14 @@ __device__ __forceinline__ int tile_cost(int base, const Geo &c, int k, int t, i
         /* lowres.h:78-97: pick the hpel plane; odd qpel = average with the next one */
         const bool satd = mode == 2;
         const int hpelA = (cy & 2) | ((cx & 2) >> 1);
-        const P AS1 *ra = (const P AS1*)c.pick(hpelA) + c.roff + (long)((cy >> 2) + ty * 4) * c.rstride + (cx >> 2) + tx * 4;
+        const P AS1 *ra = (const P AS1*)c.pick(hpelA) + c.roff + (long)__mul24((cy >> 2) + ty * 4, c.rstride) + (cx >> 2) + tx * 4;
 #pragma unroll
         for (int y = 0; y < 4; y++) q[y] = Px<P>::load_g(ra + y * c.rstride);
         if ((cx | cy) & 1)
         {
             const int bx = as_i16(cx + (cx & 1) * 2), by = as_i16(cy + (cy & 1) * 2);
             const int hpelB = (by & 2) | ((bx & 2) >> 1);
-            const P AS1 *rb = (const P AS1*)c.pick(hpelB) + c.roff + (long)((by >> 2) + ty * 4) * c.rstride + (bx >> 2) + tx * 4;
+            const P AS1 *rb = (const P AS1*)c.pick(hpelB) + c.roff + (long)__mul24((by >> 2) + ty * 4, c.rstride) + (bx >> 2) + tx * 4;
 #pragma unroll
             for (int y = 0; y < 4; y++) q[y] = Px<P>::avg(q[y], Px<P>::load_g(rb + y * c.rstride));
         }
@@ -280,7 +280,7 @@ __device__ __forceinline__ int tile_cost(int base, const Geo &c, int k, int t, i
         const int xf = cx & 3, yf = cy & 3;
         const EvalCtx *ec = lds_ctx(base);
         const int pitch = uni(ec->rk_pitch);
-        LdsLoader<P> ld = { base + uni(ec->rk_win) + (((cy >> 2) - uni(ec->rk_y0) + ty * 4) * pitch + (cx >> 2) - uni(ec->rk_x0) + tx * 4) * (int)sizeof(P), pitch };
+        LdsLoader<P> ld = { base + uni(ec->rk_win) + (__mul24((cy >> 2) - uni(ec->rk_y0) + ty * 4, pitch) + (cx >> 2) - uni(ec->rk_x0) + tx * 4) * (int)sizeof(P), pitch };
         if ((xf | yf) == 0)
         {
 #pragma unroll
@@ -318,11 +318,11 @@ __device__ __noinline__ void eval_batch(int base, int K, int mode, int addmv)
             /* full-pel SAD: the lane's source tile is loaded once; two passes are issued back
              * to back so that their reference loads are in flight together */
             const int tt = t < c.T ? t : 0;
-            const int ty = (tt * c.inv_wt) >> 16, tx = tt - ty * c.wt;
+            const int ty = __umul24(tt, c.inv_wt) >> 16, tx = tt - __mul24(ty, c.wt);
             typename Px<P>::quad f[4];
 #pragma unroll
             for (int y = 0; y < 4; y++) f[y] = Px<P>::load_lds_aligned(base + L_FENC + ((ty * 4 + y) * 64 + tx * 4) * (int)sizeof(P));
-            const P AS1 *r0 = (const P AS1*)c.ref[0] + c.roff + (long)(ty * 4) * c.rstride + tx * 4;
+            const P AS1 *r0 = (const P AS1*)c.ref[0] + c.roff + (long)__mul24(ty * 4, c.rstride) + tx * 4;
             for (int k0 = 0; k0 < K; k0 += 2 * cpp)
             {
                 typename Px<P>::quad q[2][4];
@@ -332,7 +332,7 @@ __device__ __noinline__ void eval_batch(int base, int K, int mode, int addmv)
                 {
                     kk[u] = k0 + u * cpp + g;
                     const int kc = kk[u] < K ? kk[u] : K - 1;
-                    const P AS1 *r = r0 + (long)lds_i(base, L_SY)[kc] * c.rstride + lds_i(base, L_SX)[kc];
+                    const P AS1 *r = r0 + (long)__mul24(lds_i(base, L_SY)[kc], c.rstride) + lds_i(base, L_SX)[kc];
 #pragma unroll
                     for (int y = 0; y < 4; y++) q[u][y] = Px<P>::load_g(r + y * c.rstride);
                 }
@@ -368,8 +368,8 @@ __device__ __noinline__ void eval_batch(int base, int K, int mode, int addmv)
         for (int i = 0; i < 4; i++)
         {
             const int t = lane + 64 * i < c.T ? lane + 64 * i : lane;
-            const int ty = (t * c.inv_wt) >> 16, tx = t - ty * c.wt;
-            toff[i] = (long)(ty * 4) * c.rstride + tx * 4;
+            const int ty = __umul24(t, c.inv_wt) >> 16, tx = t - __mul24(ty, c.wt);
+            toff[i] = (long)__mul24(ty * 4, c.rstride) + tx * 4;
 #pragma unroll
             for (int y = 0; y < 4; y++) f[i][y] = Px<P>::load_lds_aligned(base + L_FENC + ((ty * 4 + y) * 64 + tx * 4) * (int)sizeof(P));
         }
@@ -481,12 +481,12 @@ struct ColCand
      * and the packed taps of its vertical phase */
     int poff, prow, R0, shiftV, offV, satd;
     uint32_t ev[4], od[5];
-    template<bool UNIFORM> __device__ __forceinline__ void load(int base, int k, int depth)
+    template<bool UNIFORM> __device__ __forceinline__ void load(int base, int k, int depth, bool all_ps)
     {
 #define U_(v) (UNIFORM ? uni(v) : (v))
         const int cpl = U_(lds_i(base, L_CPL)[k]);
         const int *d = lds_i(base, L_PDESC + (cpl & 255) * 32);
-        const int ps = (U_(d[1]) >> 2) & 1, headRoom = 14 - depth;
+        const int ps = all_ps ? 1 : (U_(d[1]) >> 2) & 1, headRoom = 14 - depth;
         poff = U_(d[3]); prow = U_(d[4]);
         R0 = ((cpl >> 8) & 255) - 16;
         satd = (cpl >> 18) & 1;
@@ -501,15 +501,29 @@ struct ColCand
     }
 };
 
+/* where tile t of a column block sits, and the lane's column of the source tile */
 template<typename P>
-__device__ __forceinline__ int plane_column_cost(int base, const ColCand &cc, int t, int x, int wt, int inv_wt, int cb, int depth)
+struct ColTile
+{
+    int ty, col, f[4];
+    __device__ __forceinline__ void load(int base, int t, int x, int wt, int inv_wt, int cb)
+    {
+        ty = __umul24(t, inv_wt) >> 16;
+        col = (t - __mul24(ty, wt)) * 4 + x;
+        const P *s = (const P*)(x265amd_smem + base + L_FENC) + (ty * 4) * 64 + cb + col;
+#pragma unroll
+        for (int y = 0; y < 4; y++) f[y] = (int)s[y * 64];
+    }
+};
+
+template<typename P>
+__device__ __forceinline__ int plane_column_cost(int base, const ColCand &cc, const ColTile<P> &ct, int x, int depth)
 {
     const int poff = cc.poff, prow = cc.prow, shiftV = cc.shiftV, offV = cc.offV, maxv = (1 << depth) - 1;
     const uint32_t *ev = cc.ev, *od = cc.od;
-    const int ty = (t * inv_wt) >> 16, tx = t - ty * wt;
-    const int R = cc.R0 + 4 * ty;
+    const int R = cc.R0 + 4 * ct.ty;
     const uint32_t sh16 = (R & 1) * 16;
-    const uint32_t *col = (const uint32_t*)(x265amd_smem + base + poff + ((tx * 4 + x) * prow + (R & ~1)) * 2);
+    const uint32_t *col = (const uint32_t*)(x265amd_smem + base + poff + (__mul24(ct.col, prow) + (R & ~1)) * 2);
     uint32_t E[7], e[6];
 #pragma unroll
     for (int i = 0; i < 7; i++) E[i] = col[i];
@@ -520,26 +534,22 @@ __device__ __forceinline__ int plane_column_cost(int base, const ColCand &cc, in
     o[1] = dot2(e[0], od[0], dot2(e[1], od[1], dot2(e[2], od[2], dot2(e[3], od[3], dot2(e[4], od[4], offV)))));
     o[2] = dot2(e[1], ev[0], dot2(e[2], ev[1], dot2(e[3], ev[2], dot2(e[4], ev[3], offV))));
     o[3] = dot2(e[1], od[0], dot2(e[2], od[1], dot2(e[3], od[2], dot2(e[4], od[3], dot2(e[5], od[4], offV)))));
-    const P *f = (const P*)(x265amd_smem + base + L_FENC) + (ty * 4) * 64 + cb + tx * 4 + x;
     int dv[4];
 #pragma unroll
-    for (int y = 0; y < 4; y++) dv[y] = (int)f[y * 64] - clip_pixel(as_i16(o[y] >> shiftV), maxv);
+    for (int y = 0; y < 4; y++) dv[y] = ct.f[y] - clip_pixel(as_i16(o[y] >> shiftV), maxv);
     if (!cc.satd)
         return abs(dv[0]) + abs(dv[1]) + abs(dv[2]) + abs(dv[3]);
     const int a0 = dv[0] + dv[1], a1 = dv[0] - dv[1], a2 = dv[2] + dv[3], a3 = dv[2] - dv[3];
     int c[4] = { a0 + a2, a1 + a3, a0 - a2, a1 - a3 };
-    const int n1 = -(x & 1), n2 = -((x >> 1) & 1);
-    int s = 0;
+    /* butterfly with the lane one column over, then two columns over: the lower lane of a pair
+     * keeps the sum, the upper one the difference (own value times -1, 24-bit multiply-add) */
+    const int s1 = 1 - 2 * (x & 1), s2 = 1 - (x & 2);
+    /* stage by stage over the four values, so that no DPP read waits on the write before it */
 #pragma unroll
-    for (int i = 0; i < 4; i++)
-    {
-        /* butterfly with the lane one column over, then two columns over: the lower lane of a
-         * pair keeps the sum, the upper one the difference */
-        int v = c[i];
-        v = ((v ^ n1) - n1) + __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xf, 0xf, false);
-        v = ((v ^ n2) - n2) + __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xf, 0xf, false);
-        s += abs(v);
-    }
+    for (int i = 0; i < 4; i++) c[i] = __mul24(c[i], s1) + dpp_all<0xB1>(c[i]);
+#pragma unroll
+    for (int i = 0; i < 4; i++) c[i] = __mul24(c[i], s2) + dpp_all<0x4E>(c[i]);
+    const int s = abs(c[0]) + abs(c[1]) + abs(c[2]) + abs(c[3]);
     return s;
 }
 
@@ -552,7 +562,8 @@ __device__ __noinline__ void eval_planes(int base, int K, int mode, int addmv)
     const EvalCtx *cx = lds_ctx(base);
     const int mvc = gather_mvcost(base, K, mode, addmv);
     const P AS1 *ref0 = (const P AS1*)uni64(cx->ref[0]) + (long)uni64((unsigned long long)cx->roff);
-    const int rstride = uni(cx->rstride), w = uni(cx->w), h = uni(cx->h), depth = uni(cx->depth);
+    /* 8-bit planes always hold 8-bit samples: shifts, offsets and clamps become constants */
+    const int rstride = uni(cx->rstride), w = uni(cx->w), h = uni(cx->h), depth = sizeof(P) == 1 ? 8 : uni(cx->depth);
     const int T = uni(cx->T), lTp = uni(cx->lTp), wt = uni(cx->wt), inv_wt = uni(cx->inv_wt);
     const int planes_off = uni(cx->planes_off), budget = uni(cx->plane_budget);
 
@@ -571,22 +582,35 @@ __device__ __noinline__ void eval_planes(int base, int K, int mode, int addmv)
      * share one plane of hps intermediates, whatever their fractions. Deeper samples lose two bits
      * in the intermediate and keep the three plane kinds. */
     const int key = (qx << 1) | (sizeof(P) == 1 ? 1 : ((qx & 3) && yf ? 1 : 0));
+    /* Candidates share a plane when they have the same key and their first rows fall into the
+     * same pair (base + 2g, base + 2g + 1), base being the smallest first row of the batch: the
+     * candidates of a refinement round span two rows at most, so each of their columns gets one
+     * plane. One pass per plane: the lowest unplaced candidate names the plane, a ballot finds
+     * its companions. Which candidates share a plane changes the work, never the costs. */
     int pkey = 0, pymin = 0, pymax = 0, papron = 0, mypl = 0, np = 0;
-    for (int k = 0; k < K; k++)
     {
-        const int kk = __builtin_amdgcn_readlane(key, k), kY = __builtin_amdgcn_readlane(Y, k);
-        const int kap = __builtin_amdgcn_readlane(yf, k) != 0;
-        const int nmin = pymin < kY ? pymin : kY, nmax = pymax > kY ? pymax : kY;
-        /* candidates share a plane when its rows grow by at most one */
-        const unsigned long long m = __ballot(lane < np && pkey == kk && nmax - nmin <= 1);
-        const int p = m ? (int)__builtin_ctzll(m) : np;
-        if (lane == p)
+        const bool isc = lane < K;
+        const int ybase = wave_min(isc ? Y : 0x7fffffff);
+        const int grp = (Y - ybase) >> 1, odd = (Y - ybase) & 1;
+        unsigned long long rem = __ballot(isc);
+        while (rem)
         {
-            if (m) { pymin = nmin; pymax = nmax; papron |= kap; }
-            else { pkey = kk; pymin = pymax = kY; papron = kap; }
+            const int lead = (int)__builtin_ctzll(rem);
+            const int kk = __builtin_amdgcn_readlane(key, lead), kg = __builtin_amdgcn_readlane(grp, lead);
+            const bool mine = isc && key == kk && grp == kg;
+            const unsigned long long m = __ballot(mine);
+            const bool lo = __ballot(mine && !odd) != 0, hi = __ballot(mine && odd) != 0, ap = __ballot(mine && yf != 0) != 0;
+            if (mine) mypl = np;
+            if (lane == np)
+            {
+                pkey = kk;
+                pymin = ybase + 2 * kg + (lo ? 0 : 1);
+                pymax = ybase + 2 * kg + (hi ? 1 : 0);
+                papron = ap;
+            }
+            rem &= ~m;
+            np++;
         }
-        if (!m) np++;
-        if (lane == k) mypl = p;
     }
     const int pY0 = pymin - (papron ? 3 : 0);
     const int pnrows = pymax - pymin + h + (papron ? 7 : 0);
@@ -624,7 +648,7 @@ __device__ __noinline__ void eval_planes(int base, int K, int mode, int addmv)
             {
                 int *d = lds_i(base, L_PDESC + lane * 32);
                 const int pqx = pkey >> 1;
-                d[0] = pY0 * rstride + (pqx >> 2) - 3 + cb;
+                d[0] = __mul24(pY0, rstride) + (pqx >> 2) - 3 + cb;
                 d[1] = (pqx & 3) | ((pkey & 1) << 2);
                 d[2] = my_istart; d[3] = planes_off + my_poff; d[4] = pprow;
             }
@@ -644,16 +668,16 @@ __device__ __noinline__ void eval_planes(int base, int K, int mode, int addmv)
                 int taps[11];
 #pragma unroll
                 for (int i = 0; i < 11; i++) taps[i] = uni(tp[i]);
-                const bool ps = xfps & 4;
+                const bool ps = sizeof(P) == 1 || (xfps & 4);   /* 8-bit: every plane holds hps intermediates */
                 const int off = ps ? offH : 32, sh = ps ? shiftH : 6, lo = ps ? -32768 : 0, hi = ps ? 32767 : maxv;
                 for (int i0 = 0; i0 < items; i0 += 64)
                 {
                     const bool act = i0 + lane < items;
                     const int i = act ? i0 + lane : items - 1;
-                    const int r = (i * inv_wtb) >> 16, q4 = i - r * wtb;
+                    const int r = __umul24(i, inv_wtb) >> 16, q4 = i - __mul24(r, wtb);
                     int sum[4];
-                    HFilter<P>::run(ref0 + src + (long)r * rstride + 4 * q4, taps, sum);
-                    int16_t *dst = (int16_t*)(x265amd_smem + base + poff) + (4 * q4) * prow + r;
+                    HFilter<P>::run(ref0 + src + (long)__mul24(r, rstride) + 4 * q4, taps, sum);
+                    int16_t *dst = (int16_t*)(x265amd_smem + base + poff) + __mul24(4 * q4, prow) + r;
                     if (act)
 #pragma unroll
                         for (int x = 0; x < 4; x++)
@@ -670,15 +694,15 @@ __device__ __noinline__ void eval_planes(int base, int K, int mode, int addmv)
                     const bool act = i0 + lane < items;
                     const int i = act ? i0 + lane : items - 1;
                     int p = p0;
-                    for (int q = p0 + 1; q < p1; q++) p += i >= lds_i(base, L_PDESC + q * 32)[2] ? 1 : 0;
+                    for (int q = p0 + 1; q < p1; q++) p += i >= __builtin_amdgcn_readlane(my_istart, q) ? 1 : 0;
                     const int *d = lds_i(base, L_PDESC + p * 32);
                     const int xfps = d[1], li = i - d[2], poff = d[3], prow = d[4];
-                    const int r = (li * inv_wtb) >> 16, q4 = li - r * wtb;
+                    const int r = __umul24(li, inv_wtb) >> 16, q4 = li - __mul24(r, wtb);
                     int sum[4];
-                    HFilter<P>::run(ref0 + d[0] + (long)r * rstride + 4 * q4, lds_i(base, L_TAPS + (xfps & 3) * 48), sum);
-                    const bool ps = xfps & 4;
+                    HFilter<P>::run(ref0 + d[0] + (long)__mul24(r, rstride) + 4 * q4, lds_i(base, L_TAPS + (xfps & 3) * 48), sum);
+                    const bool ps = sizeof(P) == 1 || (xfps & 4);   /* 8-bit: every plane holds hps intermediates */
                     const int off = ps ? offH : 32, sh = ps ? shiftH : 6, lo = ps ? -32768 : 0, hi = ps ? 32767 : maxv;
-                    int16_t *dst = (int16_t*)(x265amd_smem + base + poff) + (4 * q4) * prow + r;
+                    int16_t *dst = (int16_t*)(x265amd_smem + base + poff) + __mul24(4 * q4, prow) + r;
                     if (act)
 #pragma unroll
                         for (int x = 0; x < 4; x++)
@@ -694,14 +718,17 @@ __device__ __noinline__ void eval_planes(int base, int K, int mode, int addmv)
             if (lTb <= 4)
             {
                 const int l4 = lTb + 2, g = lane >> l4, t = (lane >> 2) & ((1 << lTb) - 1), cpp = 64 >> l4;
+                /* the lane keeps its tile and source column over all passes */
+                ColTile<P> ct;
+                ct.load(base, t < Tb ? t : 0, lane & 3, wtb, inv_wtb, cb);
                 for (int j0 = 0; j0 < nc; j0 += cpp)
                 {
                     const int j = j0 + g;
                     const bool act = j < nc && t < Tb;
                     const int k = lds_i(base, L_CLIST)[act ? j : 0];
                     ColCand cc;
-                    cc.load<false>(base, k, depth);
-                    int v = plane_column_cost<P>(base, cc, act ? t : 0, lane & 3, wtb, inv_wtb, cb, depth);
+                    cc.load<false>(base, k, depth, sizeof(P) == 1);
+                    int v = plane_column_cost<P>(base, cc, ct, lane & 3, depth);
                     v = seg_sum(act ? v : 0, l4);
                     if (act && (lane & ((1 << l4) - 1)) == 0) lds_i(base, L_COSTS)[k] = (cb ? lds_i(base, L_COSTS)[k] : 0) + v;
                 }
@@ -712,12 +739,14 @@ __device__ __noinline__ void eval_planes(int base, int K, int mode, int addmv)
                 {
                     const int k = uni(lds_i(base, L_CLIST)[j]);
                     ColCand cc;   /* the same for every lane: kept in scalar registers */
-                    cc.load<true>(base, k, depth);
+                    cc.load<true>(base, k, depth, sizeof(P) == 1);
                     int v = 0;
                     for (int t0 = 0; t0 < Tb; t0 += 16)
                     {
                         const int t = t0 + (lane >> 2);
-                        const int c = plane_column_cost<P>(base, cc, t < Tb ? t : 0, lane & 3, wtb, inv_wtb, cb, depth);
+                        ColTile<P> ct;
+                        ct.load(base, t < Tb ? t : 0, lane & 3, wtb, inv_wtb, cb);
+                        const int c = plane_column_cost<P>(base, cc, ct, lane & 3, depth);
                         v += t < Tb ? c : 0;
                     }
                     v = seg_sum(v, 6);
