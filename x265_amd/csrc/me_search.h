@@ -131,6 +131,14 @@ template<typename P> constexpr int wave_lds_bytes(int rows, bool planes = false)
     return L_FENC + rows * 64 * (int)sizeof(P) + (planes ? plane_budget(rows) + 16 : 0);
 }
 
+/* ceil(65536 / wt) for the tile counts a PU row can have (widths 4 .. 64), so that
+ * (t * inv) >> 16 == t / wt for every tile index; a division costs some twenty instructions */
+__device__ __forceinline__ int inv_tiles(int wt)
+{
+    return wt == 1 ? 65536 : wt == 2 ? 32768 : wt == 3 ? 21846 : wt == 4 ? 16384 : wt == 6 ? 10923 : wt == 8 ? 8192
+         : wt == 12 ? 5462 : wt == 16 ? 4096 : (65536 + wt - 1) / wt;
+}
+
 /* sum over each group of 2^l adjacent lanes, left in every lane of the group */
 __device__ __forceinline__ int seg_sum(int v, int l)
 {
@@ -534,9 +542,37 @@ __device__ __forceinline__ int plane_column_cost(int base, const ColCand &cc, co
     o[1] = dot2(e[0], od[0], dot2(e[1], od[1], dot2(e[2], od[2], dot2(e[3], od[3], dot2(e[4], od[4], offV)))));
     o[2] = dot2(e[1], ev[0], dot2(e[2], ev[1], dot2(e[3], ev[2], dot2(e[4], ev[3], offV))));
     o[3] = dot2(e[1], od[0], dot2(e[2], od[1], dot2(e[3], od[2], dot2(e[4], od[3], dot2(e[5], od[4], offV)))));
+    int pr[4];
+#pragma unroll
+    for (int y = 0; y < 4; y++) pr[y] = clip_pixel(as_i16(o[y] >> shiftV), maxv);
+    if constexpr (sizeof(P) == 1)
+    {
+        /* 8-bit samples: differences and every Hadamard stage fit int16 (16 * 255), so rows
+         * (0, 1) and (2, 3) travel as packed pairs through v_pk_* instructions */
+        const s16x2 one = { 1, 1 };
+        const s16x2 d01 = __builtin_bit_cast(s16x2, (uint32_t)(ct.f[0] | (ct.f[1] << 16))) - __builtin_bit_cast(s16x2, (uint32_t)(pr[0] | (pr[1] << 16)));
+        const s16x2 d23 = __builtin_bit_cast(s16x2, (uint32_t)(ct.f[2] | (ct.f[3] << 16))) - __builtin_bit_cast(s16x2, (uint32_t)(pr[2] | (pr[3] << 16)));
+        if (!cc.satd)
+        {
+            const s16x2 a = __builtin_elementwise_max(d01, -d01), b = __builtin_elementwise_max(d23, -d23);
+            return __builtin_amdgcn_sdot2(a, one, __builtin_amdgcn_sdot2(b, one, 0, false), false);
+        }
+        const s16x2 S = d01 + d23, D = d01 - d23;                       /* (r0+r2, r1+r3), (r0-r2, r1-r3) */
+        const s16x2 A = __builtin_shufflevector(S, D, 0, 2), B = __builtin_shufflevector(S, D, 1, 3);
+        s16x2 U = A + B, W = A - B;                                     /* vertical coefficients (c0, c2), (c1, c3) */
+        const short m1 = (short)(1 - 2 * (x & 1)), m2 = (short)(1 - (x & 2));
+        const s16x2 s1 = { m1, m1 }, s2 = { m2, m2 };
+        U = U * s1 + __builtin_bit_cast(s16x2, dpp_all<0xB1>(__builtin_bit_cast(int, U)));
+        W = W * s1 + __builtin_bit_cast(s16x2, dpp_all<0xB1>(__builtin_bit_cast(int, W)));
+        U = U * s2 + __builtin_bit_cast(s16x2, dpp_all<0x4E>(__builtin_bit_cast(int, U)));
+        W = W * s2 + __builtin_bit_cast(s16x2, dpp_all<0x4E>(__builtin_bit_cast(int, W)));
+        U = __builtin_elementwise_max(U, -U);
+        W = __builtin_elementwise_max(W, -W);
+        return __builtin_amdgcn_sdot2(U, one, __builtin_amdgcn_sdot2(W, one, 0, false), false);
+    }
     int dv[4];
 #pragma unroll
-    for (int y = 0; y < 4; y++) dv[y] = ct.f[y] - clip_pixel(as_i16(o[y] >> shiftV), maxv);
+    for (int y = 0; y < 4; y++) dv[y] = ct.f[y] - pr[y];
     if (!cc.satd)
         return abs(dv[0]) + abs(dv[1]) + abs(dv[2]) + abs(dv[3]);
     const int a0 = dv[0] + dv[1], a1 = dv[0] - dv[1], a2 = dv[2] + dv[3], a3 = dv[2] - dv[3];
@@ -627,7 +663,7 @@ __device__ __noinline__ void eval_planes(int base, int K, int mode, int addmv)
     for (int cb = 0; cb < w; cb += PLANE_COLS)
     {
         const int cw = w - cb < PLANE_COLS ? w - cb : PLANE_COLS;
-        const int wtb = cw >> 2, inv_wtb = (65536 + wtb - 1) / wtb, Tb = wtb * (h >> 2);
+        const int wtb = cw >> 2, inv_wtb = wtb == 4 ? 16384 : (wtb == 2 ? 32768 : (wtb == 1 ? 65536 : 21846)), Tb = wtb * (h >> 2);
         int lTb = 0;
         while ((1 << lTb) < Tb) lTb++;
         const int pbytes = cw * pprow * 2, pitems = pnrows * wtb;
@@ -635,6 +671,17 @@ __device__ __noinline__ void eval_planes(int base, int K, int mode, int addmv)
         {
             /* ---- the planes that fit in LDS together ---- */
             int acc = 0, items = 0, p1 = p0, my_poff = 0, my_istart = 0;
+            const int b0 = __builtin_amdgcn_readlane(pbytes, p0), n0 = __builtin_amdgcn_readlane(pitems, p0);
+            if (__ballot(lane >= p0 && lane < np && (pbytes != b0 || pitems != n0)) == 0)
+            {
+                /* planes of one size (every refinement round): no running sums needed */
+                int n = 1;
+                while (p0 + n < np && (n + 1) * b0 <= budget) n++;
+                p1 = p0 + n;
+                items = n * n0;
+                my_poff = __mul24(lane - p0, b0); my_istart = __mul24(lane - p0, n0);
+            }
+            else
             while (p1 < np)
             {
                 const int b = __builtin_amdgcn_readlane(pbytes, p1);
@@ -1476,7 +1523,7 @@ struct Searcher
         const int wt = w >> 2, T = wt * (h >> 2);
         int lTp = 0;
         while ((1 << lTp) < T) lTp++;
-        const int inv_wt = (65536 + wt - 1) / wt;
+        const int inv_wt = inv_tiles(wt);
         const int rstride = refPl[0].stride;
         const long roff = (long)pu_y * rstride + pu_x;
         wave_sync();
