@@ -169,6 +169,39 @@ __device__ __forceinline__ int had4x4_half(const int d[4][4])
     return s >> 1;
 }
 
+/* The same for differences of 8-bit samples, on packed int16 pairs: E[r] = (d[r][0], d[r][2]),
+ * O[r] = (d[r][1], d[r][3]). Every intermediate stays below 2^12. The two vertical stages and
+ * the first horizontal one are whole-register v_pk_add / v_pk_sub; the last stage pairs the two
+ * halves of a register, and |a + b| + |a - b| = 2 max(|a|, |b|) turns it into a maximum, which
+ * is also where the halving goes. */
+typedef short pk16 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ int had4x4_half_pk(const pk16 E[4], const pk16 O[4])
+{
+    pk16 v[2][4];
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+    {
+        const pk16 *X = i ? O : E;
+        const pk16 a0 = X[0] + X[1], a1 = X[0] - X[1], a2 = X[2] + X[3], a3 = X[2] - X[3];
+        v[i][0] = a0 + a2; v[i][1] = a1 + a3; v[i][2] = a0 - a2; v[i][3] = a1 - a3;
+    }
+    pk16 acc = { 0, 0 };
+#pragma unroll
+    for (int r = 0; r < 4; r++)
+#pragma unroll
+        for (int i = 0; i < 2; i++)
+        {
+            pk16 t = i ? v[0][r] - v[1][r] : v[0][r] + v[1][r];
+            t = __builtin_elementwise_max(t, -t);
+            const uint32_t u = __builtin_bit_cast(uint32_t, t);
+            acc += __builtin_elementwise_max(t, __builtin_bit_cast(pk16, __builtin_amdgcn_alignbit(u, u, 16)));
+        }
+    return (int)(unsigned short)acc.x;
+}
+/* even / odd samples of four packed bytes as int16 pairs */
+__device__ __forceinline__ pk16 even_bytes(uint32_t q) { return __builtin_bit_cast(pk16, __builtin_amdgcn_perm(q, q, 0x0c020c00u)); }
+__device__ __forceinline__ pk16 odd_bytes(uint32_t q) { return __builtin_bit_cast(pk16, __builtin_amdgcn_perm(q, q, 0x0c030c01u)); }
+
 __device__ __forceinline__ int clip_pixel(int v16, int maxv)
 {
     /* v16 already passed through the reference's int16_t cast */
@@ -342,6 +375,18 @@ __device__ __forceinline__ void rk_interp_tile(const LD &ld, int xf, int yf, int
 template<typename P>
 __device__ __forceinline__ int tile_cost_px(const typename Px<P>::quad f[4], const int o[4][4], bool satd)
 {
+    if constexpr (sizeof(P) == 1)
+        if (satd)
+        {
+            pk16 E[4], O[4];
+#pragma unroll
+            for (int y = 0; y < 4; y++)
+            {
+                E[y] = even_bytes(f[y]) - __builtin_bit_cast(pk16, (uint32_t)(o[y][0] | (o[y][2] << 16)));
+                O[y] = odd_bytes(f[y]) - __builtin_bit_cast(pk16, (uint32_t)(o[y][1] | (o[y][3] << 16)));
+            }
+            return had4x4_half_pk(E, O);
+        }
     int d[4][4];
 #pragma unroll
     for (int y = 0; y < 4; y++)
@@ -371,6 +416,17 @@ __device__ __forceinline__ int tile_cost_quads(const typename Px<P>::quad f[4], 
 #pragma unroll
         for (int y = 0; y < 4; y++) s = Px<P>::sad(f[y], q[y], s);
         return s;
+    }
+    if constexpr (sizeof(P) == 1)
+    {
+        pk16 E[4], O[4];
+#pragma unroll
+        for (int y = 0; y < 4; y++)
+        {
+            E[y] = even_bytes(f[y]) - even_bytes(q[y]);
+            O[y] = odd_bytes(f[y]) - odd_bytes(q[y]);
+        }
+        return had4x4_half_pk(E, O);
     }
     int o[4][4];
 #pragma unroll

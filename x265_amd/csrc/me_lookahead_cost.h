@@ -217,15 +217,10 @@ __global__ __launch_bounds__(LA_INTRA_WAVES * 64) void la_intra_kernel(const Fra
                 }
             }
             const uint8_t *sp = ((mode >= 2 && mode < 18) ? srct : src) + (4 * ty) * 8 + 4 * tx;
-            int d[4][4];
+            uint32_t q[4];
 #pragma unroll
-            for (int k = 0; k < 4; k++)
-            {
-                const uint32_t q = *(const uint32_t*)(sp + 8 * k);
-                d[k][0] = (int)(q & 0xff) - p[k][0]; d[k][1] = (int)((q >> 8) & 0xff) - p[k][1];
-                d[k][2] = (int)((q >> 16) & 0xff) - p[k][2]; d[k][3] = (int)(q >> 24) - p[k][3];
-            }
-            v = had4x4_half(d);
+            for (int k = 0; k < 4; k++) q[k] = *(const uint32_t*)(sp + 8 * k);
+            v = tile_cost_px<uint8_t>(q, p, true);
         }
         v = seg_sum(v, 2);
         v = mode < 35 ? v : LA_COST_MAX;

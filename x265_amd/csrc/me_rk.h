@@ -260,16 +260,16 @@ __device__ __forceinline__ void rk_fme_grid(int base, int region, int pitch, int
         for (int r = 0; r < 8; r++)
 #pragma unroll
             for (int x = 0; x < 4; x++) hv[r][x] = xf ? as_i16((hr[r][x] + offH) >> shiftH) : hr[r][x];
-        int fv[4][4];
+        typename Px<P>::quad fq[4];
 #pragma unroll
         for (int y = 0; y < 4; y++)
-            Px<P>::unpack(FENC_GLOBAL ? Px<P>::load_g(fenc_g + (long)(ty * 4 + y) * fenc_stride + tx * 4)
-                                      : Px<P>::load_lds_aligned(base + L_FENC + ((ty * 4 + y) * 64 + tx * 4) * (int)sizeof(P)), fv[y]);
+            fq[y] = FENC_GLOBAL ? Px<P>::load_g(fenc_g + (long)(ty * 4 + y) * fenc_stride + tx * 4)
+                                : Px<P>::load_lds_aligned(base + L_FENC + ((ty * 4 + y) * 64 + tx * 4) * (int)sizeof(P));
         const int sv = xf ? shiftV : 6, ov = xf ? offV : 32;
         for (int jj = 0; jj < 7; jj++)
         {
             const int yf = (jj + 1) & 3;
-            int d[4][4];
+            int pr[4][4];   /* the predicted tile */
             if (yf == 0)
             {
                 /* integer row: luma-hpp style rounding of the raw horizontal sum, or the sample itself */
@@ -277,7 +277,7 @@ __device__ __forceinline__ void rk_fme_grid(int base, int region, int pitch, int
                 for (int y = 0; y < 4; y++)
 #pragma unroll
                     for (int x = 0; x < 4; x++)
-                        d[y][x] = fv[y][x] - (xf ? clip_pixel(as_i16((hr[y + 2][x] + 32) >> 6), maxv) : hr[y + 2][x]);
+                        pr[y][x] = xf ? clip_pixel(as_i16((hr[y + 2][x] + 32) >> 6), maxv) : hr[y + 2][x];
             }
             else
             {
@@ -292,7 +292,7 @@ __device__ __forceinline__ void rk_fme_grid(int base, int region, int pitch, int
                         for (int x = 0; x < 4; x++)
                         {
                             const int sum = hv[y][x] * cv[0] + hv[y + 1][x] * cv[1] + hv[y + 2][x] * cv[2] + hv[y + 3][x] * cv[3];
-                            d[y][x] = fv[y][x] - clip_pixel(as_i16((sum + ov) >> sv), maxv);
+                            pr[y][x] = clip_pixel(as_i16((sum + ov) >> sv), maxv);
                         }
                 }
                 else
@@ -303,11 +303,11 @@ __device__ __forceinline__ void rk_fme_grid(int base, int region, int pitch, int
                         for (int x = 0; x < 4; x++)
                         {
                             const int sum = hv[y + 1][x] * cv[0] + hv[y + 2][x] * cv[1] + hv[y + 3][x] * cv[2] + hv[y + 4][x] * cv[3];
-                            d[y][x] = fv[y][x] - clip_pixel(as_i16((sum + ov) >> sv), maxv);
+                            pr[y][x] = clip_pixel(as_i16((sum + ov) >> sv), maxv);
                         }
                 }
             }
-            int v = live ? had4x4_half(d) : 0;
+            int v = live ? tile_cost_px<P>(fq, pr, true) : 0;
             v = seg_sum(v, lG);
             if (live && (lane & ((1 << lG) - 1)) == 0) lds_i(base, L_COSTS)[i * 7 + jj] += v;
             if (T > 64) wave_sync();   /* several passes add to the same entry */
