@@ -58,7 +58,7 @@ __global__ __launch_bounds__(64) void search_kernel(SearchArgs a)
         }
         return;
     }
-    S.bind(0, a.fenc, a.ref, a.nref, a.ctab, a.depth, job->pu_x, job->pu_y, w, h, a.max_dim, plane_budget(a.max_dim));
+    S.bind(0, a.fenc, a.ref, a.nref, a.ctab, a.depth, job->pu_x, job->pu_y, w, h, a.max_dim, plane_budget(a.max_dim, (int)sizeof(P)));
     S.search(job, a.method, a.subme, a.results + j);
 }
 
@@ -73,7 +73,7 @@ __global__ __launch_bounds__(64) void subpel_compare_kernel(SearchArgs a, int cm
     if (j >= a.njobs) return;
     const x265amd_job *job = a.jobs + j;
     Searcher<P, 64> S;
-    S.bind(0, a.fenc, a.ref, a.nref, a.ctab, a.depth, job->pu_x, job->pu_y, job->w, job->h, 64, plane_budget(64));
+    S.bind(0, a.fenc, a.ref, a.nref, a.ctab, a.depth, job->pu_x, job->pu_y, job->w, job->h, 64, plane_budget(64, (int)sizeof(P)));
     S.nsad = S.nsub = 0;
     S.put(0, job->qmvp[0], job->qmvp[1], job->qmvp[0], job->qmvp[1], 0, 0);
     S.eval(1, cmp ? 2 : 1, false);

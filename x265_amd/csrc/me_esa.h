@@ -386,7 +386,7 @@ __global__ __launch_bounds__(64) void esa_finish_kernel(SearchArgs a, int win_bu
     const uint32_t bc = (uint32_t)uni(a.results[j].cost), bi = (uint32_t)uni((int)a.results[j].sad_calls);
     Searcher<P, 64> S;
     SearchState st;
-    S.bind(0, a.fenc, a.ref, a.nref, a.ctab, a.depth, J.pux, J.puy, w, h, a.max_dim, plane_budget(a.max_dim));
+    S.bind(0, a.fenc, a.ref, a.nref, a.ctab, a.depth, J.pux, J.puy, w, h, a.max_dim, plane_budget(a.max_dim, (int)sizeof(P)));
     S.startup(J, st);
     if (bc < (uint32_t)st.bcost)
     {

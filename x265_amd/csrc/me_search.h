@@ -118,17 +118,21 @@ __device__ __forceinline__ unsigned long long uni64(unsigned long long v)
 }
 
 /* LDS bytes of the interpolation planes for PUs up to dim x dim. One plane is at most
- * PLANE_COLS columns of (h + 10) int16 rows (wider PUs go block by block); the budget holds
- * the six planes a refinement round of a 16x16 PU can need, or two blocks of a 64-row PU. */
+ * PLANE_COLS columns of (h + 10) int16 rows (wider PUs go block by block). A refinement round
+ * needs one plane per qpel x of its candidates when the samples are 8-bit (three planes), and up
+ * to six with deeper samples, where the kind of the first pass splits them further; batches with
+ * more planes go through in several chunks. Launches of small 8-bit PUs get exactly those three
+ * planes, which lets a CU hold six waves per SIMD; larger launches have fewer waves than the
+ * chip has room for and keep room for two planes of a 64-row PU. */
 #define PLANE_COLS 16
-constexpr int plane_budget(int dim)
+constexpr int plane_budget(int dim, int sample_bytes)
 {
-    return 6 * (dim < PLANE_COLS ? dim : PLANE_COLS) * (((dim < PLANE_COLS ? dim : PLANE_COLS) + 10) & ~1) * 2;
+    return (dim <= PLANE_COLS && sample_bytes == 1 ? 3 : 6) * (dim < PLANE_COLS ? dim : PLANE_COLS) * (((dim < PLANE_COLS ? dim : PLANE_COLS) + 10) & ~1) * 2;
 }
 /* per-wave LDS: candidate arrays + context + source block of `rows` rows [+ planes] */
 template<typename P> constexpr int wave_lds_bytes(int rows, bool planes = false)
 {
-    return L_FENC + rows * 64 * (int)sizeof(P) + (planes ? plane_budget(rows) + 16 : 0);
+    return L_FENC + rows * 64 * (int)sizeof(P) + (planes ? plane_budget(rows, (int)sizeof(P)) + 16 : 0);
 }
 
 /* ceil(65536 / wt) for the tile counts a PU row can have (widths 4 .. 64), so that
@@ -371,13 +375,13 @@ __device__ __noinline__ void eval_batch(int base, int K, int mode, int addmv)
         /* more than 64 tiles (T is 128, 192 or 256): the lane's up to four source tiles stay in
          * registers across candidates and all loads of a candidate are issued together */
         typename Px<P>::quad f[4][4];
-        long toff[4];
+        int toff[4];
 #pragma unroll
         for (int i = 0; i < 4; i++)
         {
             const int t = lane + 64 * i < c.T ? lane + 64 * i : lane;
             const int ty = __umul24(t, c.inv_wt) >> 16, tx = t - __mul24(ty, c.wt);
-            toff[i] = (long)__mul24(ty * 4, c.rstride) + tx * 4;
+            toff[i] = __mul24(ty * 4, c.rstride) + tx * 4;
 #pragma unroll
             for (int y = 0; y < 4; y++) f[i][y] = Px<P>::load_lds_aligned(base + L_FENC + ((ty * 4 + y) * 64 + tx * 4) * (int)sizeof(P));
         }
@@ -386,19 +390,25 @@ __device__ __noinline__ void eval_batch(int base, int K, int mode, int addmv)
         for (int k = 0; k < K; k++)
         {
             const P AS1 *r = r0 + (long)uni(lds_i(base, L_SY)[k]) * c.rstride + uni(lds_i(base, L_SX)[k]);
-            typename Px<P>::quad q[4][4];
-#pragma unroll
-            for (int i = 0; i < 4; i++)
-#pragma unroll
-                for (int y = 0; y < 4; y++) q[i][y] = Px<P>::load_g(r + toff[i] + y * c.rstride);
             int v = 0;
+            /* two tiles (eight loads) at a time: the registers of all sixteen rows would set the
+             * kernel's register count, and with it how many waves a SIMD holds */
 #pragma unroll
-            for (int i = 0; i < 4; i++)
+            for (int i0 = 0; i0 < 4; i0 += 2)
             {
-                int s = 0;
+                typename Px<P>::quad q[2][4];
 #pragma unroll
-                for (int y = 0; y < 4; y++) s = Px<P>::sad(f[i][y], q[i][y], s);
-                v += i < nt ? s : 0;
+                for (int i = 0; i < 2; i++)
+#pragma unroll
+                    for (int y = 0; y < 4; y++) q[i][y] = Px<P>::load_g(r + toff[i0 + i] + y * c.rstride);
+#pragma unroll
+                for (int i = 0; i < 2; i++)
+                {
+                    int s = 0;
+#pragma unroll
+                    for (int y = 0; y < 4; y++) s = Px<P>::sad(f[i0 + i][y], q[i][y], s);
+                    v += i0 + i < nt ? s : 0;
+                }
             }
             v = seg_sum(v, 6);
             if (lane == 0) lds_i(base, L_COSTS)[k] = v;
