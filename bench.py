@@ -46,7 +46,7 @@ def main():
                     help="frame pairs re-run through the reference build (oracle/_ref) when it is present: the CPU baseline")
     ap.add_argument("--method", default="star")
     ap.add_argument("--subme", type=int, default=SUBME_DEFAULT, help="sub-pel refinement level (experiments only)")
-    ap.add_argument("--launch", choices=("split", "single", "per-size"), default="split",
+    ap.add_argument("--launch", choices=("split", "split3", "single", "per-size"), default="split3",
                     help="search launches per frame: split = 16/8 PUs and 64/32 PUs on two streams (LDS per PU sized "
                          "per class); single = one launch; per-size = four launches on one stream")
     ap.add_argument("--rehearse-one-gpu", action="store_true",
@@ -81,7 +81,9 @@ def main():
     # ---------------- setup (untimed): planes, lookahead fields, job lists, all on the device
     es = Engine(local_rank, 8)      # search stream (all launches, or the 16/8 class)
     el = Engine(local_rank, 8)      # lookahead stream
-    eb = Engine(local_rank, 8) if args.launch == "split" else es   # stream of the 64/32 class
+    split = args.launch in ("split", "split3")
+    eb = Engine(local_rank, 8) if split else es   # stream of the 64/32 class
+    em = Engine(local_rank, 8) if args.launch == "split3" else es   # split3: stream of the 16x16 class
     B = args.pairs
     clip = make_clip(W, H, B + 1, seed=1234 + rank)
     planes, lowres = [], []
@@ -107,6 +109,8 @@ def main():
                 return (int(idx[0]), len(idx), dim, eng)
             if args.launch == "split":
                 segs = [seg(jobs["w"] <= 16, 16, es), seg(jobs["w"] >= 32, 64, eb)]
+            elif args.launch == "split3":
+                segs = [seg(jobs["w"] == 8, 8, es), seg(jobs["w"] == 16, 16, em), seg(jobs["w"] >= 32, 64, eb)]
             elif args.launch == "single":
                 segs = [seg(jobs["w"] > 0, 64, es)]
             else:
@@ -129,20 +133,21 @@ def main():
     def step(k=None):
         el.lookahead_fields_dev(d_fields, B, wcu, hcu, LA_QP, HEX, 1, LA_MERANGE,
                                 d_la_mvs.data_ptr(), d_la_costs.data_ptr())
-        for (first, cnt, dim, eng) in segs[1:] if args.launch == "split" else ():
+        for (first, cnt, dim, eng) in segs[1:] if split else ():
             for i in range(B):
                 eng.search_batch_dev(planes[i + 1], planes[i], d_jobs[i].data_ptr() + first * 40, cnt,
                                      d_res[i].data_ptr() + first * 16, QP, method, SUBME, max_pu_dim=dim)
         if k is not None:
             ev0[k].record(s_search)
         for i in range(B):
-            for (first, cnt, dim, eng) in segs if args.launch != "split" else segs[:1]:
+            for (first, cnt, dim, eng) in segs if not split else segs[:1]:
                 eng.search_batch_dev(planes[i + 1], planes[i], d_jobs[i].data_ptr() + first * 40, cnt,
                                      d_res[i].data_ptr() + first * 16, QP, method, SUBME, max_pu_dim=dim)
         if k is not None:
             ev1[k].record(s_search)
         es.sync()
         eb.sync()
+        em.sync()
         el.sync()
         if world > 1:
             # hand the MV / cost records to the rank that feeds the host encoder
@@ -241,6 +246,8 @@ def main():
                        "port_value": cpu_px / cpu_s / 1e9}
         kernel = {"split": "search_kernel<uint8_t,false>, the launch over a frame's %d 16x16 + 8x8 PUs (its 64/32 PUs run "
                            "concurrently on a second stream)" % timed_cnt,
+                  "split3": "search_kernel<uint8_t,false>, the launch over a frame's %d 8x8 PUs (its 16x16 and its 64/32 PUs "
+                            "run concurrently on two more streams)" % timed_cnt,
                   "single": "search_kernel<uint8_t,false>, one launch per frame (%d PUs)" % timed_cnt,
                   "per-size": "search_kernel<uint8_t,false>, average of the 4 per-size launches of a frame"}[args.launch]
         out = {

@@ -622,6 +622,60 @@ __device__ __noinline__ void eval_planes(int base, int K, int mode, int addmv)
         if (cm == 0) { qx <<= 2; qy <<= 2; }   /* full-pel member of a mixed batch */
     }
     const int yf = qy & 3, Y = qy >> 2;
+
+    /* ---- SAD candidates at integer positions (the rounded predictor, MV(0,0), a refinement
+     * point that lands on a sample) need no interpolation: one lane per (candidate, tile) reads
+     * the reference itself, and the planes below are built for the others only ---- */
+    const bool direct = lane < K && cm != 2 && ((qx | qy) & 3) == 0;
+    {
+        const unsigned long long dmask = __ballot(direct);
+        if (dmask)
+        {
+            const int nd = (int)__builtin_popcountll(dmask);
+            if (direct) lds_i(base, L_CLIST)[__builtin_popcountll(dmask & ((1ull << lane) - 1))] = lane;
+            wave_sync();
+            if (T <= 64)
+            {
+                const int g = lane >> lTp, t = lane & ((1 << lTp) - 1), cpp = 64 >> lTp, tt = t < T ? t : 0;
+                const int ty = __umul24(tt, inv_wt) >> 16, tx = tt - __mul24(ty, wt);
+                typename Px<P>::quad f[4];
+#pragma unroll
+                for (int y = 0; y < 4; y++) f[y] = Px<P>::load_lds_aligned(base + L_FENC + ((ty * 4 + y) * 64 + tx * 4) * (int)sizeof(P));
+                const P AS1 *r0 = ref0 + __mul24(ty * 4, rstride) + tx * 4;
+                for (int j0 = 0; j0 < nd; j0 += cpp)
+                {
+                    const int j = j0 + g;
+                    const bool act = j < nd && t < T;
+                    const int k = lds_i(base, L_CLIST)[act ? j : 0];
+                    const P AS1 *r = r0 + __mul24(__shfl(Y, k), rstride) + __shfl(qx >> 2, k);
+                    int v = 0;
+#pragma unroll
+                    for (int y = 0; y < 4; y++) v = Px<P>::sad(f[y], Px<P>::load_g(r + y * rstride), v);
+                    v = seg_sum(act ? v : 0, lTp);
+                    if (act && t == 0) lds_i(base, L_COSTS)[k] = v;
+                }
+            }
+            else
+                for (int j = 0; j < nd; j++)
+                {
+                    const int k = uni(lds_i(base, L_CLIST)[j]);
+                    const P AS1 *r0 = ref0 + (long)__builtin_amdgcn_readlane(Y, k) * rstride + __builtin_amdgcn_readlane(qx >> 2, k);
+                    int v = 0;
+                    for (int t = lane; t < T; t += 64)
+                    {
+                        const int ty = __umul24(t, inv_wt) >> 16, tx = t - __mul24(ty, wt);
+                        const P AS1 *r = r0 + __mul24(ty * 4, rstride) + tx * 4;
+#pragma unroll
+                        for (int y = 0; y < 4; y++)
+                            v = Px<P>::sad(Px<P>::load_lds_aligned(base + L_FENC + ((ty * 4 + y) * 64 + tx * 4) * (int)sizeof(P)), Px<P>::load_g(r + y * rstride), v);
+                    }
+                    v = seg_sum(v, 6);
+                    if (lane == 0) lds_i(base, L_COSTS)[k] = v;
+                }
+            wave_sync();
+        }
+    }
+
     /* With 8-bit samples the luma_hps intermediate keeps every bit (shift 0), and luma_vsp with the
      * phase-0 taps on it gives exactly (sum + 32) >> 6; likewise phase-0 luma_hps of a sample is
      * 64 * sample - 8192 and luma_vsp on that equals luma_vpp. So all candidates of one qpel x can
@@ -635,7 +689,7 @@ __device__ __noinline__ void eval_planes(int base, int K, int mode, int addmv)
      * its companions. Which candidates share a plane changes the work, never the costs. */
     int pkey = 0, pymin = 0, pymax = 0, papron = 0, mypl = 0, np = 0;
     {
-        const bool isc = lane < K;
+        const bool isc = lane < K && !direct;
         const int ybase = wave_min(isc ? Y : 0x7fffffff);
         const int grp = (Y - ybase) >> 1, odd = (Y - ybase) & 1;
         unsigned long long rem = __ballot(isc);
@@ -663,7 +717,7 @@ __device__ __noinline__ void eval_planes(int base, int K, int mode, int addmv)
     const int pprow = (pnrows + 2) & ~1;
     {
         const int Y0 = __shfl(pY0, mypl);
-        if (lane < K) lds_i(base, L_CPL)[lane] = mypl | ((Y - 3 - Y0 + 16) << 8) | (yf << 16) | ((cm == 2 ? 1 : 0) << 18);
+        if (lane < K) lds_i(base, L_CPL)[lane] = direct ? 0 : mypl | ((Y - 3 - Y0 + 16) << 8) | (yf << 16) | ((cm == 2 ? 1 : 0) << 18);
     }
 
     const int headRoom = 14 - depth, maxv = (1 << depth) - 1;
@@ -709,7 +763,7 @@ __device__ __noinline__ void eval_planes(int base, int K, int mode, int addmv)
                 d[1] = (pqx & 3) | ((pkey & 1) << 2);
                 d[2] = my_istart; d[3] = planes_off + my_poff; d[4] = pprow;
             }
-            const bool inch = lane < K && mypl >= p0 && mypl < p1;
+            const bool inch = lane < K && !direct && mypl >= p0 && mypl < p1;
             const unsigned long long cmask = __ballot(inch);
             const int nc = __builtin_popcountll(cmask);
             if (inch) lds_i(base, L_CLIST)[__builtin_popcountll(cmask & ((1ull << lane) - 1))] = lane;
