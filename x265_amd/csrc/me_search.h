@@ -623,10 +623,12 @@ __device__ __noinline__ void eval_planes(int base, int K, int mode, int addmv)
     }
     const int yf = qy & 3, Y = qy >> 2;
 
-    /* ---- SAD candidates at integer positions (the rounded predictor, MV(0,0), a refinement
-     * point that lands on a sample) need no interpolation: one lane per (candidate, tile) reads
-     * the reference itself, and the planes below are built for the others only ---- */
-    const bool direct = lane < K && cm != 2 && ((qx | qy) & 3) == 0;
+    /* ---- candidates at integer positions (the rounded predictor, MV(0,0), the centre of the
+     * first refinement round, a refinement point that lands on a sample) need no interpolation:
+     * one lane per (candidate, tile) reads the reference itself, and the planes below are built
+     * for the others only. SATD is halved per tile here, which equals halving the sum; the lone
+     * SATD candidate of a small PU (the centre) stays with the planes, where it rides along ---- */
+    const bool direct = lane < K && ((qx | qy) & 3) == 0 && (cm != 2 || T > 16);   /* a small PU's SATD costs no more in the planes */
     {
         const unsigned long long dmask = __ballot(direct);
         if (dmask)
@@ -648,9 +650,10 @@ __device__ __noinline__ void eval_planes(int base, int K, int mode, int addmv)
                     const bool act = j < nd && t < T;
                     const int k = lds_i(base, L_CLIST)[act ? j : 0];
                     const P AS1 *r = r0 + __mul24(__shfl(Y, k), rstride) + __shfl(qx >> 2, k);
-                    int v = 0;
+                    typename Px<P>::quad q[4];
 #pragma unroll
-                    for (int y = 0; y < 4; y++) v = Px<P>::sad(f[y], Px<P>::load_g(r + y * rstride), v);
+                    for (int y = 0; y < 4; y++) q[y] = Px<P>::load_g(r + y * rstride);
+                    int v = tile_cost_quads<P>(f, q, __shfl(cm, k) == 2);
                     v = seg_sum(act ? v : 0, lTp);
                     if (act && t == 0) lds_i(base, L_COSTS)[k] = v;
                 }
@@ -660,14 +663,20 @@ __device__ __noinline__ void eval_planes(int base, int K, int mode, int addmv)
                 {
                     const int k = uni(lds_i(base, L_CLIST)[j]);
                     const P AS1 *r0 = ref0 + (long)__builtin_amdgcn_readlane(Y, k) * rstride + __builtin_amdgcn_readlane(qx >> 2, k);
+                    const bool satd = __builtin_amdgcn_readlane(cm, k) == 2;
                     int v = 0;
                     for (int t = lane; t < T; t += 64)
                     {
                         const int ty = __umul24(t, inv_wt) >> 16, tx = t - __mul24(ty, wt);
                         const P AS1 *r = r0 + __mul24(ty * 4, rstride) + tx * 4;
+                        typename Px<P>::quad f[4], q[4];
 #pragma unroll
                         for (int y = 0; y < 4; y++)
-                            v = Px<P>::sad(Px<P>::load_lds_aligned(base + L_FENC + ((ty * 4 + y) * 64 + tx * 4) * (int)sizeof(P)), Px<P>::load_g(r + y * rstride), v);
+                        {
+                            f[y] = Px<P>::load_lds_aligned(base + L_FENC + ((ty * 4 + y) * 64 + tx * 4) * (int)sizeof(P));
+                            q[y] = Px<P>::load_g(r + y * rstride);
+                        }
+                        v += tile_cost_quads<P>(f, q, satd);
                     }
                     v = seg_sum(v, 6);
                     if (lane == 0) lds_i(base, L_COSTS)[k] = v;
