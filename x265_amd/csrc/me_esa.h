@@ -79,9 +79,14 @@ __device__ __forceinline__ uint64_t lds_pair(int off)
 }
 
 /* SADs of the 4 x ESA_R candidates whose first one has its top-left reference pixel at LDS byte
- * `org`; the source block (w x h) sits at `fenc` with a pitch of 64 bytes */
-__device__ __forceinline__ void esa_patch(int org, int pitch, int fenc, int w, int h, uint32_t tot[ESA_R][4])
+ * `org`; the source block (w x h) sits at `fenc` with a pitch of 64 bytes. W, H != 0 fix the PU
+ * size at compile time: the loops unroll, the accumulators start from the instruction's zero
+ * operand and the single widening needs no running totals (8x8 PUs spend more instructions on
+ * that bookkeeping than on SADs otherwise). */
+template<int W, int H>
+__device__ __forceinline__ void esa_patch(int org, int pitch, int fenc, int w_, int h_, uint32_t tot[ESA_R][4])
 {
+    const int w = W ? W : w_, h = H ? H : h_;
     static_assert(ESA_R == 8, "the row bookkeeping below is written for 8 candidate rows");
     uint64_t a16[ESA_R];
 #pragma unroll
@@ -93,6 +98,7 @@ __device__ __forceinline__ void esa_patch(int org, int pitch, int fenc, int w, i
     }
     int cnt = 0;
     const int ncol = w >> 2;
+#pragma unroll
     for (int j = 0; j < ncol; j++)
     {
         const int col = org + 4 * j, fcol = fenc + 4 * j;
@@ -106,6 +112,7 @@ __device__ __forceinline__ void esa_patch(int org, int pitch, int fenc, int w, i
          * start at once and its own loads have the first seven SADs to arrive in */
         uint32_t f0 = *(const uint32_t*)(x265amd_smem + fcol);
         int y0 = 0;
+#pragma unroll
         for (; y0 + 8 <= h; y0 += 8)
         {
             uint64_t nw[8];
@@ -179,7 +186,7 @@ __device__ __forceinline__ bool esa_job_ok(const JobRegs &J, int w, int h, int m
  * (SAD + lambda * bits, raster index) of the range into results[j].cost / .sad_calls, where
  * esa_finish_kernel picks it up. */
 template<typename P>
-__global__ __launch_bounds__(ESA_THREADS) void esa_scan_kernel(SearchArgs a, int win_budget, int nowrap)
+__global__ __launch_bounds__(ESA_THREADS) __attribute__((amdgpu_waves_per_eu(4))) void esa_scan_kernel(SearchArgs a, int win_budget, int nowrap)
 {
     static_assert(sizeof(P) == 1, "the packed quad-SAD path is for 8-bit samples");
     const int j = xcd_remap(blockIdx.x, a.njobs);
@@ -254,6 +261,10 @@ __global__ __launch_bounds__(ESA_THREADS) void esa_scan_kernel(SearchArgs a, int
                 const int rlast = (ny - 1 - ys0 * ESA_R) + h - 1;
                 const int dlast = (nx - 1 - xs0 * 4 + w - 1 + 4) >> 2;
                 const char AS1 *src0 = (const char AS1*)(ref + (long)(J.mny + ys0 * ESA_R) * rstride + J.mnx + xs0 * 4);
+#ifdef X265AMD_ESA_SKIP
+                /* timing builds only: 1 = no window staging, 2 = no scan; results are then meaningless */
+                if (X265AMD_ESA_SKIP != 1)
+#endif
                 for (int d0 = 0; d0 < pd; d0 += 64)
                 {
                     const int d = d0 + lane;
@@ -281,7 +292,11 @@ __global__ __launch_bounds__(ESA_THREADS) void esa_scan_kernel(SearchArgs a, int
             if (tid == 0) *lds_i(0, ESA_L_CNT) = 0;
             __syncthreads();
 
+#ifdef X265AMD_ESA_SKIP
+            const int ni = X265AMD_ESA_SKIP == 2 ? 0 : xgc * ygc, inv = (65536 + xgc - 1) / xgc;
+#else
             const int ni = xgc * ygc, inv = (65536 + xgc - 1) / xgc;
+#endif
             for (;;)
             {
                 int i0 = 0;
@@ -292,7 +307,10 @@ __global__ __launch_bounds__(ESA_THREADS) void esa_scan_kernel(SearchArgs a, int
                 const int it = live ? i0 + lane : ni - 1;
                 const int yg = (it * inv) >> 16, xg = it - yg * xgc;
                 uint32_t tot[ESA_R][4];
-                esa_patch(g.off_win + yg * ESA_R * g.pitch + xg * 4, g.pitch, ESA_L_FENC, w, h, tot);
+                const int porg = g.off_win + yg * ESA_R * g.pitch + xg * 4;
+                if (w == 8 && h == 8) esa_patch<8, 8>(porg, g.pitch, ESA_L_FENC, w, h, tot);
+                else if (w == 16 && h == 16) esa_patch<16, 16>(porg, g.pitch, ESA_L_FENC, w, h, tot);
+                else esa_patch<0, 0>(porg, g.pitch, ESA_L_FENC, w, h, tot);
                 int cx[4];
 #pragma unroll
                 for (int i = 0; i < 4; i++) cx[i] = lds_i(0, g.off_cx)[xg * 4 + i];
