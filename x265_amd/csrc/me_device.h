@@ -302,6 +302,14 @@ __device__ __forceinline__ void interp_tile(const LD &ld, int xf, int yf, int de
 /* 4-tap kernels of the Rockchip fractional search: g_chromaFilter[frac * 2]
  * (motion.cpp:1455-1490; table TComRom.cpp:183-193) */
 __constant__ static const int16_t kRkTaps[4][4] = { { 0, 64, 0, 0 }, { -4, 54, 16, -2 }, { -4, 36, 36, -4 }, { -2, 16, 54, -4 } };
+/* the same taps as four signed bytes (tap 0 lowest) and as two int16 pairs (taps 0-1, taps 2-3) */
+#define RK_B(a, b, c, d) ((uint32_t)((a) & 0xff) | ((uint32_t)((b) & 0xff) << 8) | ((uint32_t)((c) & 0xff) << 16) | ((uint32_t)((d) & 0xff) << 24))
+#define RK_H(a, b) ((uint32_t)((a) & 0xffff) | ((uint32_t)((b) & 0xffff) << 16))
+__constant__ static const uint32_t kRkTapBytes[4] = { RK_B(0, 64, 0, 0), RK_B(-4, 54, 16, -2), RK_B(-4, 36, 36, -4), RK_B(-2, 16, 54, -4) };
+__constant__ static const uint32_t kRkTapPairs[4][2] = { { RK_H(0, 64), RK_H(0, 0) }, { RK_H(-4, 54), RK_H(16, -2) },
+                                                         { RK_H(-4, 36), RK_H(36, -4) }, { RK_H(-2, 16), RK_H(54, -4) } };
+#undef RK_B
+#undef RK_H
 
 /* RK flavour of interp_tile: InterpHoriz / InterpVert / FilterHorizontal + FilterVertical
  * with N = 4 (motion.cpp:1495-1648), phase (xf, yf) != (0, 0) */

@@ -238,6 +238,61 @@ __device__ __forceinline__ void rk_fme_grid(int base, int region, int pitch, int
         const int qx = as_i16(bxq + i - 3), xf = qx & 3;
         /* region column of the sample one to the left of the tile's first output */
         const int col0 = ((qx >> 2) - (bxq >> 2) + 1) + tx * 4;
+        typename Px<P>::quad fq[4];
+#pragma unroll
+        for (int y = 0; y < 4; y++)
+            fq[y] = FENC_GLOBAL ? Px<P>::load_g(fenc_g + (long)(ty * 4 + y) * fenc_stride + tx * 4)
+                                : Px<P>::load_lds_aligned(base + L_FENC + ((ty * 4 + y) * 64 + tx * 4) * (int)sizeof(P));
+        if constexpr (sizeof(P) == 1)
+        {
+            /* 8-bit samples. Horizontal pass on v_dot4_i32_i8: samples biased to signed bytes, and as
+             * the taps of every phase (phase 0 = {0, 64, 0, 0} included) add up to 64, the result is
+             * D = sum - 8192, which is the reference's 16-bit intermediate (shift 0 at this depth).
+             * Everything else follows from D without telling the phases apart:
+             *   yf != 0: (sum_k cv[k] * D[k] + offV) >> 12 -- for xf == 0 that is (64 S + 2048) >> 12
+             *            = (S + 32) >> 6 with S the vertical sum over samples, the one-pass rounding;
+             *   yf == 0: (D + 8192 + 32) >> 6, the one-pass horizontal rounding (the sample for xf == 0).
+             * The vertical pass takes rows in pairs through v_dot2_i32_i16. */
+            const uint32_t tH = kRkTapBytes[xf];
+            const int off0 = base + region + (ty * 4 * pitch + col0);
+            const uint32_t sh = (uint32_t)(off0 & 3);     /* the pitch is a multiple of 4: the same for every row */
+            int D[8][4];
+#pragma unroll
+            for (int r = 0; r < 8; r++)
+            {
+                const uint32_t *q = (const uint32_t*)(x265amd_smem + ((off0 + r * pitch) & ~3));
+                const uint32_t q0 = q[0], q1 = q[1], q2 = q[2];
+                const uint32_t d0 = __builtin_amdgcn_alignbyte(q1, q0, sh) ^ 0x80808080u, d1 = __builtin_amdgcn_alignbyte(q2, q1, sh) ^ 0x80808080u;
+                D[r][0] = __builtin_amdgcn_sdot4(d0, tH, 0, false);
+#pragma unroll
+                for (int x = 1; x < 4; x++) D[r][x] = __builtin_amdgcn_sdot4(__builtin_amdgcn_alignbyte(d1, d0, x), tH, 0, false);
+            }
+            uint32_t pk[7][4];
+#pragma unroll
+            for (int r = 0; r < 7; r++)
+#pragma unroll
+                for (int x = 0; x < 4; x++) pk[r][x] = __builtin_amdgcn_perm((uint32_t)D[r + 1][x], (uint32_t)D[r][x], 0x05040100u);
+#pragma unroll
+            for (int jj = 0; jj < 7; jj++)
+            {
+                const int yf = (jj + 1) & 3, o = jj < 3 ? 0 : 1;
+                int pr[4][4];
+#pragma unroll
+                for (int y = 0; y < 4; y++)
+#pragma unroll
+                    for (int x = 0; x < 4; x++)
+                    {
+                        const int sum = yf ? dot2(pk[y + o][x], kRkTapPairs[yf][0], dot2(pk[y + o + 2][x], kRkTapPairs[yf][1], offV)) >> shiftV
+                                           : (D[y + 2][x] + 8192 + 32) >> 6;
+                        pr[y][x] = clip_pixel(sum, maxv);
+                    }
+                int v = live ? tile_cost_px<P>(fq, pr, true) : 0;
+                v = seg_sum(v, lG);
+                if (live && (lane & ((1 << lG) - 1)) == 0) lds_i(base, L_COSTS)[i * 7 + jj] += v;
+                if (T > 64) wave_sync();   /* several passes add to the same entry */
+            }
+            continue;
+        }
         int ch[4];
 #pragma unroll
         for (int k = 0; k < 4; k++) ch[k] = kRkTaps[xf][k];
@@ -260,11 +315,6 @@ __device__ __forceinline__ void rk_fme_grid(int base, int region, int pitch, int
         for (int r = 0; r < 8; r++)
 #pragma unroll
             for (int x = 0; x < 4; x++) hv[r][x] = xf ? as_i16((hr[r][x] + offH) >> shiftH) : hr[r][x];
-        typename Px<P>::quad fq[4];
-#pragma unroll
-        for (int y = 0; y < 4; y++)
-            fq[y] = FENC_GLOBAL ? Px<P>::load_g(fenc_g + (long)(ty * 4 + y) * fenc_stride + tx * 4)
-                                : Px<P>::load_lds_aligned(base + L_FENC + ((ty * 4 + y) * 64 + tx * 4) * (int)sizeof(P));
         const int sv = xf ? shiftV : 6, ov = xf ? offV : 32;
         for (int jj = 0; jj < 7; jj++)
         {
