@@ -305,6 +305,40 @@ typedef struct
 int x265amd_merge_sa8d_batch(x265amd_ctx *ctx, const x265amd_plane *fenc, const x265amd_plane *refs, int nrefs,
                              const x265amd_merge_job *jobs, int njobs, int32_t *sa8d);
 
+/* ---- motion compensation ---- */
+
+/* TComPrediction::motionCompensation without weighted prediction (Lib/TLibCommon/TComPrediction.cpp:
+ * 201-286) for a batch of PUs, luma and 4:2:0 chroma, written into a prediction picture at each PU's
+ * own position (the reference writes the CU-local TComYuv predYuv; one picture-sized buffer stands
+ * for all of them). dir 1 / 2: one list through the pixel flavours of xPredInterLumaBlk (:405-438)
+ * and xPredInterChromaBlk (:491-540); dir 3: both lists through the 14-bit flavours (:441-478,
+ * :543-593) and TComYuv::addAvg (Lib/TLibCommon/TComYuv.cpp:573-650). flags bit 0 = bLuma, bit 1 =
+ * bChroma. The luma quarter-pel MV addresses chroma in eighth-pel units (:496, :504-505). The caller
+ * has clipped the MVs (TComDataCU::clipMv) and turned identical motion of both lists into dir 1
+ * (xCheckIdenticalMotion, :183-198). PUs of one call must not overlap (they never do inside a frame's
+ * final partitioning); weighted prediction (:212-226, :334-376) is not covered. */
+typedef struct
+{
+    int16_t pu_x, pu_y;        /* luma position, a multiple of 4 */
+    uint8_t w, h;              /* an HEVC luma partition, not 4x4 */
+    uint8_t dir;               /* 1 = list 0, 2 = list 1, 3 = both */
+    uint8_t flags;             /* 1 = luma, 2 = chroma, 3 = both */
+    uint8_t ref0, ref1;        /* indices into `refs` */
+    uint8_t reserved[2];
+    int16_t mv0[2], mv1[2];    /* quarter-pel */
+} x265amd_mc_job;
+/* A 4:2:0 picture resident in device memory (TComPicYuv): cb / cr are half size in both directions */
+typedef struct { x265amd_plane y, cb, cr; } x265amd_picture;
+/* refs: nrefs (<= 32) reconstructed reference pictures; pred: the output picture (margins may be 0);
+ * jobs: HOST array. Returns when the prediction samples are in `pred`. */
+int x265amd_mc_batch(x265amd_ctx *ctx, const x265amd_picture *refs, int nrefs, const x265amd_picture *pred,
+                     const x265amd_mc_job *jobs, int njobs);
+/* device-resident jobs, asynchronous on the engine's stream; the jobs are not validated.
+ * d_ref_planes: device array from x265amd_pictures_upload. */
+int x265amd_pictures_upload(x265amd_ctx *ctx, const x265amd_picture *refs, int nrefs, void **d_ref_planes);
+int x265amd_mc_batch_dev(x265amd_ctx *ctx, const void *d_ref_planes, const x265amd_picture *pred,
+                         const x265amd_mc_job *d_jobs, int njobs);
+
 /* ---- Rockchip path (rd >= 5): CIME + RIME + FME ---- */
 
 /* One 64x64 CTU against one reference picture: everything the 15-argument

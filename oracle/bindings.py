@@ -60,6 +60,11 @@ MERGE_JOB_DTYPE = np.dtype([("pu_x", "<i2"), ("pu_y", "<i2"), ("size", "u1"), ("
 assert MERGE_JOB_DTYPE.itemsize == 16
 
 
+MC_JOB_DTYPE = np.dtype([("pu_x", "<i2"), ("pu_y", "<i2"), ("w", "u1"), ("h", "u1"), ("dir", "u1"), ("flags", "u1"),
+                         ("ref0", "u1"), ("ref1", "u1"), ("reserved", "u1", (2,)), ("mv0", "<i2", (2,)), ("mv1", "<i2", (2,))], align=True)
+assert MC_JOB_DTYPE.itemsize == 20
+
+
 def build_oracle():
     import subprocess
     subprocess.check_call(["make", "-C", HERE, "libme_oracle.so"], stdout=subprocess.DEVNULL)
@@ -254,6 +259,16 @@ class Oracle:
         strides = (C.c_ssize_t * len(refs))(*[stride] * len(refs))
         self.L.orc_merge_sa8d_batch(depth, _p(fenc, origin), C.c_ssize_t(stride), ptrs, strides, _p(jobs), len(jobs), _p(out))
         return out
+
+    def mc_batch(self, depth, refs, pred, jobs):
+        """Motion compensation of MC_JOB_DTYPE records. refs: list of pictures, a picture = [(buf, origin, stride)] * 3 for
+        Y, Cb, Cr (both chroma planes share a geometry); pred: one such picture, written in place."""
+        jobs = np.ascontiguousarray(jobs, MC_JOB_DTYPE)
+        planes = (C.c_void_p * (3 * len(refs)))(*[b.ctypes.data + o * b.itemsize for pic in refs for (b, o, _) in pic])
+        strides = (C.c_ssize_t * (2 * len(refs)))(*[pic[k][2] for pic in refs for k in (0, 1)])
+        pp = (C.c_void_p * 3)(*[b.ctypes.data + o * b.itemsize for (b, o, _) in pred])
+        ps = (C.c_ssize_t * 2)(pred[0][2], pred[1][2])
+        self.L.orc_mc_batch(depth, planes, strides, pp, ps, _p(jobs), len(jobs))
 
 
 def ref_available(depth=8):
@@ -510,3 +525,19 @@ class Ref:
             out[i] = self.L.ref_merge_sa8d(_p(fenc, off), C.c_ssize_t(stride), _p(refs[int(j["ref0"])], off), C.c_ssize_t(stride),
                                            _p(refs[int(j["ref1"])], off), C.c_ssize_t(stride), int(j["size"]), int(j["dir"]), mv0, mv1)
         return out
+
+    def mc_batch(self, refs, pred, jobs):
+        """TComPrediction::motionCompensation's primitive calls per PU (ref_mc_pu); arguments as Oracle.mc_batch."""
+        def at(pic, px, py):
+            ptrs = [pic[0][0].ctypes.data + (pic[0][1] + py * pic[0][2] + px) * pic[0][0].itemsize]
+            for k in (1, 2):
+                ptrs.append(pic[k][0].ctypes.data + (pic[k][1] + (py >> 1) * pic[k][2] + (px >> 1)) * pic[k][0].itemsize)
+            return (C.c_void_p * 3)(*ptrs), (C.c_ssize_t * 2)(pic[0][2], pic[1][2])
+        for j in jobs:
+            px, py = int(j["pu_x"]), int(j["pu_y"])
+            p0, s0 = at(refs[int(j["ref0"])], px, py)
+            p1, s1 = at(refs[int(j["ref1"])], px, py)
+            pd, sd = at(pred, px, py)
+            mv0 = (C.c_int16 * 2)(int(j["mv0"][0]), int(j["mv0"][1]))
+            mv1 = (C.c_int16 * 2)(int(j["mv1"][0]), int(j["mv1"][1]))
+            self.L.ref_mc_pu(p0, s0, p1, s1, pd, sd, int(j["w"]), int(j["h"]), int(j["dir"]), int(j["flags"]), mv0, mv1)

@@ -14,6 +14,12 @@ static const int16_t orc_luma_filter[4][8] = {
     {  0, 1,  -5, 17, 58, -10, 4, -1 },
 };
 
+/* HEVC 4-tap chroma interpolation taps (eighth-pel); source/Lib/TLibCommon/TComRom.cpp:183-193 */
+static const int16_t orc_chroma_filter[8][4] = {
+    {  0, 64,  0,  0 }, { -2, 58, 10, -2 }, { -4, 54, 16, -2 }, { -6, 46, 28, -4 },
+    { -4, 36, 36, -4 }, { -4, 28, 46, -6 }, { -2, 16, 54, -4 }, { -2, 10, 58, -2 },
+};
+
 /* lambda^2 for non-I slices per QP; source/Lib/TLibCommon/TComRom.cpp:529-541 */
 static const double orc_lambda2_non_I[70] = {
     0.05231, 0.060686, 0.07646, 0.096333333, 0.151715667, 0.15292, 0.192666667, 0.242745, 0.382299,
@@ -379,5 +385,23 @@ void orc_merge_sa8d_batch(int depth, const void *fenc, intptr_t fstride, const v
         else
             out[i] = merge_sa8d_16((const uint16_t*)fenc + fo, fstride, (const uint16_t*)refs[j->ref0] + o0, s0,
                                    (const uint16_t*)refs[j->ref1] + o1, s1, j->size, depth, j->dir, j->mv0[0], j->mv0[1], j->mv1[0], j->mv1[1]);
+    }
+}
+
+
+void orc_mc_batch(int depth, const void *const *ref_planes, const intptr_t *ref_strides, void *const pred[3],
+                  const intptr_t pred_strides[2], const orc_mc_job *jobs, int n)
+{
+    for (int i = 0; i < n; i++)
+    {
+        const orc_mc_job *j = jobs + i;
+        const void *const *p0 = ref_planes + 3 * j->ref0, *const *p1 = ref_planes + 3 * j->ref1;
+        const intptr_t *s0 = ref_strides + 2 * j->ref0, *s1 = ref_strides + 2 * j->ref1;
+        if (depth <= 8)
+            mc_pu_8((const uint8_t *const *)p0, s0, (const uint8_t *const *)p1, s1, (uint8_t *const *)pred, pred_strides,
+                    j->pu_x, j->pu_y, j->w, j->h, depth, j->dir, j->flags, j->mv0[0], j->mv0[1], j->mv1[0], j->mv1[1]);
+        else
+            mc_pu_16((const uint16_t *const *)p0, s0, (const uint16_t *const *)p1, s1, (uint16_t *const *)pred, pred_strides,
+                     j->pu_x, j->pu_y, j->w, j->h, depth, j->dir, j->flags, j->mv0[0], j->mv0[1], j->mv1[0], j->mv1[1]);
     }
 }

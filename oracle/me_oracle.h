@@ -172,6 +172,16 @@ typedef struct { int16_t pu_x, pu_y; uint8_t size, dir, ref0, ref1; int16_t mv0[
 void orc_merge_sa8d_batch(int depth, const void *fenc, intptr_t fstride, const void *const *refs, const intptr_t *rstrides,
                           const orc_merge_job *jobs, int n, int32_t *out);
 
+/* ---- motion compensation of a batch of PUs into a prediction picture, luma and 4:2:0 chroma
+ * (TComPrediction::motionCompensation without weighted prediction, source/Lib/TLibCommon/
+ * TComPrediction.cpp:201-286 with xPredInterLumaBlk :405-478 and xPredInterChromaBlk :491-593).
+ * ref_planes: 3 origins (Y, Cb, Cr) per reference picture; ref_strides: 2 per picture (luma, chroma);
+ * pred / pred_strides likewise for the output picture. Job layout = x265amd_mc_job; flags bit 0 =
+ * bLuma, bit 1 = bChroma; dir 1 / 2 / 3 = list 0, list 1, both. */
+typedef struct { int16_t pu_x, pu_y; uint8_t w, h, dir, flags, ref0, ref1, reserved[2]; int16_t mv0[2], mv1[2]; } orc_mc_job;
+void orc_mc_batch(int depth, const void *const *ref_planes, const intptr_t *ref_strides, void *const pred[3],
+                  const intptr_t pred_strides[2], const orc_mc_job *jobs, int n);
+
 #ifdef __cplusplus
 }
 #endif

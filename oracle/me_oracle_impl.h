@@ -1383,3 +1383,159 @@ static int FN(merge_sa8d)(const PIXEL *fenc_pu, intptr_t fstride, const PIXEL *r
     }
     return FN(sa8d_inter)(fenc_pu, fstride, pred, 64, size, size);
 }
+
+
+/* ---------------- motion compensation into prediction samples, luma + 4:2:0 chroma ---------------- */
+
+/* The 4-tap chroma chain of TComPrediction::xPredInterChromaBlk, pixel flavour (TComPrediction.cpp:
+ * 491-540): copy_pp, chroma filter_hpp / filter_vpp (ipfilter.cpp:194-233, :280-319 with N = 4), or
+ * filter_hps with row extension + chroma_vsp (ipfilter.cpp:235-278, :40-81). (ex, ey) is the MV in
+ * eighth-pel chroma units (= the luma quarter-pel MV); cw x ch the chroma block; dst pitch ds */
+static void FN(mc_chroma)(const PIXEL *ref_blk, intptr_t stride, int ex, int ey, int cw, int ch, int depth, PIXEL *dst, intptr_t ds)
+{
+    const int xFrac = ex & 7, yFrac = ey & 7, maxv = (1 << depth) - 1, headRoom = 14 - depth;
+    const PIXEL *src = ref_blk + (ex >> 3) + (ey >> 3) * stride;
+    if ((xFrac | yFrac) == 0)
+    {
+        for (int y = 0; y < ch; y++) memcpy(dst + ds * y, src + y * stride, cw * sizeof(PIXEL));
+        return;
+    }
+    if (yFrac == 0 || xFrac == 0)
+    {
+        const int16_t *c = orc_chroma_filter[yFrac == 0 ? xFrac : yFrac];
+        const intptr_t step = yFrac == 0 ? 1 : stride;
+        for (int y = 0; y < ch; y++)
+            for (int x = 0; x < cw; x++)
+            {
+                int sum = 0;
+                for (int k = 0; k < 4; k++) sum += (int)src[y * stride + x + (k - 1) * step] * c[k];
+                int16_t val = (int16_t)((sum + 32) >> 6);
+                if (val < 0) val = 0;
+                if (val > maxv) val = (int16_t)maxv;
+                dst[y * ds + x] = (PIXEL)val;
+            }
+        return;
+    }
+    int16_t immed[32 * (32 + 3)];
+    const int16_t *cx = orc_chroma_filter[xFrac], *cy = orc_chroma_filter[yFrac];
+    const int shiftH = 6 - headRoom, offH = -(8192 << shiftH);
+    const int shiftV = 6 + headRoom, offV = (1 << (shiftV - 1)) + (8192 << 6);
+    for (int y = 0; y < ch + 3; y++)
+        for (int x = 0; x < cw; x++)
+        {
+            int sum = 0;
+            for (int k = 0; k < 4; k++) sum += (int)src[(y - 1) * stride + x - 1 + k] * cx[k];
+            immed[y * cw + x] = (int16_t)((sum + offH) >> shiftH);
+        }
+    for (int y = 0; y < ch; y++)
+        for (int x = 0; x < cw; x++)
+        {
+            int sum = 0;
+            for (int k = 0; k < 4; k++) sum += (int)immed[(y + k) * cw + x] * cy[k];
+            int16_t val = (int16_t)((sum + offV) >> shiftV);
+            if (val < 0) val = 0;
+            if (val > maxv) val = (int16_t)maxv;
+            dst[y * ds + x] = (PIXEL)val;
+        }
+}
+
+/* xPredInterChromaBlk into 14-bit intermediates (TComPrediction.cpp:543-593): chroma_p2s
+ * (ipfilter.cpp:155-172), filter_hps, filterVertical_ps_c<4> (:118-153), or filter_hps with row
+ * extension + filterVertical_ss_c<4> (:83-116); buf pitch 32 */
+static void FN(mc_chroma_short)(const PIXEL *ref_blk, intptr_t stride, int ex, int ey, int cw, int ch, int depth, int16_t *buf)
+{
+    const int xFrac = ex & 7, yFrac = ey & 7, headRoom = 14 - depth;
+    const int shift = 6 - headRoom, offset = -(8192 << shift);
+    const PIXEL *src = ref_blk + (ex >> 3) + (ey >> 3) * stride;
+    if ((xFrac | yFrac) == 0)
+    {
+        for (int y = 0; y < ch; y++)
+            for (int x = 0; x < cw; x++) buf[y * 32 + x] = (int16_t)((int16_t)(src[y * stride + x] << headRoom) - (int16_t)8192);
+    }
+    else if (yFrac == 0 || xFrac == 0)
+    {
+        const int16_t *c = orc_chroma_filter[yFrac == 0 ? xFrac : yFrac];
+        const intptr_t step = yFrac == 0 ? 1 : stride;
+        for (int y = 0; y < ch; y++)
+            for (int x = 0; x < cw; x++)
+            {
+                int sum = 0;
+                for (int k = 0; k < 4; k++) sum += (int)src[y * stride + x + (k - 1) * step] * c[k];
+                buf[y * 32 + x] = (int16_t)((sum + offset) >> shift);
+            }
+    }
+    else
+    {
+        int16_t immed[32 * (32 + 3)];
+        const int16_t *cx = orc_chroma_filter[xFrac], *cy = orc_chroma_filter[yFrac];
+        for (int y = 0; y < ch + 3; y++)
+            for (int x = 0; x < cw; x++)
+            {
+                int sum = 0;
+                for (int k = 0; k < 4; k++) sum += (int)src[(y - 1) * stride + x - 1 + k] * cx[k];
+                immed[y * cw + x] = (int16_t)((sum + offset) >> shift);
+            }
+        for (int y = 0; y < ch; y++)
+            for (int x = 0; x < cw; x++)
+            {
+                int sum = 0;
+                for (int k = 0; k < 4; k++) sum += (int)immed[(y + k) * cw + x] * cy[k];
+                buf[y * 32 + x] = (int16_t)(sum >> 6);
+            }
+    }
+}
+
+/* TComYuv::addAvg (TComYuv.cpp:573-650): rounded, clipped average of two 14-bit blocks */
+static void FN(add_avg)(const int16_t *s0, const int16_t *s1, int pitch, int w, int h, int depth, PIXEL *dst, intptr_t ds)
+{
+    const int shiftNum = 15 - depth, offset = (1 << (shiftNum - 1)) + 2 * 8192, maxv = (1 << depth) - 1;
+    for (int y = 0; y < h; y++)
+        for (int x = 0; x < w; x++)
+        {
+            const int v = (s0[y * pitch + x] + s1[y * pitch + x] + offset) >> shiftNum;
+            dst[y * ds + x] = (PIXEL)(v < 0 ? 0 : (v > maxv ? maxv : v));
+        }
+}
+
+/* TComPrediction::motionCompensation of one PU without weighted prediction (TComPrediction.cpp:
+ * 201-286): dir 1 / 2 = xPredInterUni into the prediction picture, 3 = xPredInterBi's first branch
+ * (both lists into TShortYUV, then addAvg). planes: [0] luma, [1] Cb, [2] Cr of the two references
+ * and of the prediction picture, all as origins; the PU sits at (px, py) luma samples. */
+static void FN(mc_pu)(const PIXEL *const r0[3], const intptr_t r0s[2], const PIXEL *const r1[3], const intptr_t r1s[2],
+                      PIXEL *const pred[3], const intptr_t ps[2], int px, int py, int w, int h, int depth, int dir, int flags,
+                      int mv0x, int mv0y, int mv1x, int mv1y)
+{
+    const int cw = w >> 1, ch = h >> 1, cx = px >> 1, cy = py >> 1;
+    if (flags & 1)
+    {
+        PIXEL *d = pred[0] + (intptr_t)py * ps[0] + px;
+        if (dir == 3)
+        {
+            int16_t s0[64 * 64], s1[64 * 64];
+            FN(mc_short)(r0[0] + (intptr_t)py * r0s[0] + px, r0s[0], mv0x, mv0y, w, h, depth, s0);
+            FN(mc_short)(r1[0] + (intptr_t)py * r1s[0] + px, r1s[0], mv1x, mv1y, w, h, depth, s1);
+            FN(add_avg)(s0, s1, 64, w, h, depth, d, ps[0]);
+        }
+        else
+        {
+            PIXEL tmp[64 * 64];
+            if (dir == 1) FN(mc_luma)(r0[0] + (intptr_t)py * r0s[0] + px, r0s[0], mv0x, mv0y, w, h, depth, tmp);
+            else FN(mc_luma)(r1[0] + (intptr_t)py * r1s[0] + px, r1s[0], mv1x, mv1y, w, h, depth, tmp);
+            for (int y = 0; y < h; y++) memcpy(d + y * ps[0], tmp + 64 * y, w * sizeof(PIXEL));
+        }
+    }
+    if (flags & 2)
+        for (int c = 1; c < 3; c++)
+        {
+            PIXEL *d = pred[c] + (intptr_t)cy * ps[1] + cx;
+            if (dir == 3)
+            {
+                int16_t s0[32 * 32], s1[32 * 32];
+                FN(mc_chroma_short)(r0[c] + (intptr_t)cy * r0s[1] + cx, r0s[1], mv0x, mv0y, cw, ch, depth, s0);
+                FN(mc_chroma_short)(r1[c] + (intptr_t)cy * r1s[1] + cx, r1s[1], mv1x, mv1y, cw, ch, depth, s1);
+                FN(add_avg)(s0, s1, 32, cw, ch, depth, d, ps[1]);
+            }
+            else if (dir == 1) FN(mc_chroma)(r0[c] + (intptr_t)cy * r0s[1] + cx, r0s[1], mv0x, mv0y, cw, ch, depth, d, ps[1]);
+            else FN(mc_chroma)(r1[c] + (intptr_t)cy * r1s[1] + cx, r1s[1], mv1x, mv1y, cw, ch, depth, d, ps[1]);
+        }
+}

@@ -682,4 +682,85 @@ int ref_merge_sa8d(pixel *fencPU, intptr_t fencStride, pixel *ref0PU, intptr_t r
     return cost;
 }
 
+/* ---- motion compensation into prediction samples, luma + 4:2:0 chroma: the primitive calls of
+ * TComPrediction::motionCompensation without weighted prediction (TComPrediction.cpp:201-286) for
+ * one PU, issued as xPredInterLumaBlk (:405-478) and xPredInterChromaBlk (:491-593) issue them --
+ * the chroma tables indexed by the luma partition -- and TComYuv::addAvg's arithmetic
+ * (TComYuv.cpp:573-650; the loop is repeated because TComYuv / TComDataCU need a whole encoder
+ * around them). refs / pred hold the PU's own sample in each plane (Y, Cb, Cr). ---- */
+static void harness_pred_chroma(pixel *refBlk, intptr_t stride, int ex, int ey, int part, int cw, int ch, pixel *dst, intptr_t dstStride,
+                                int16_t *immed)
+{
+    pixel *src = refBlk + (ex >> 3) + (ey >> 3) * stride;
+    const int xFrac = ex & 7, yFrac = ey & 7, csp = X265_CSP_I420;
+    if ((yFrac | xFrac) == 0) primitives.chroma[csp].copy_pp[part](dst, dstStride, src, stride);
+    else if (yFrac == 0) primitives.chroma[csp].filter_hpp[part](src, stride, dst, dstStride, xFrac);
+    else if (xFrac == 0) primitives.chroma[csp].filter_vpp[part](src, stride, dst, dstStride, yFrac);
+    else
+    {
+        primitives.chroma[csp].filter_hps[part](src, stride, immed, cw, xFrac, 1);
+        primitives.chroma_vsp(immed + (NTAPS_CHROMA / 2 - 1) * cw, cw, dst, dstStride, cw, ch, yFrac);
+    }
+}
+
+static void harness_pred_chroma_short(pixel *refBlk, intptr_t stride, int ex, int ey, int part, int cw, int ch, int16_t *dst, int16_t *immed)
+{
+    pixel *src = refBlk + (ex >> 3) + (ey >> 3) * stride;
+    const int xFrac = ex & 7, yFrac = ey & 7, csp = X265_CSP_I420, dstStride = MAX_CU_SIZE / 2;
+    if ((yFrac | xFrac) == 0) primitives.chroma_p2s(src, stride, dst, cw, ch);
+    else if (yFrac == 0) primitives.chroma[csp].filter_hps[part](src, stride, dst, dstStride, xFrac, 0);
+    else if (xFrac == 0) primitives.ipfilter_ps[FILTER_V_P_S_4](src, stride, dst, dstStride, cw, ch, g_chromaFilter[yFrac]);
+    else
+    {
+        primitives.chroma[csp].filter_hps[part](src, stride, immed, cw, xFrac, 1);
+        primitives.ipfilter_ss[FILTER_V_S_S_4](immed + (NTAPS_CHROMA / 2 - 1) * cw, cw, dst, dstStride, cw, ch, yFrac);
+    }
+}
+
+static void harness_add_avg(const int16_t *s0, const int16_t *s1, int pitch, int w, int h, pixel *dst, intptr_t dstStride)
+{
+    const int shiftNum = IF_INTERNAL_PREC + 1 - X265_DEPTH;
+    const int offset = (1 << (shiftNum - 1)) + 2 * IF_INTERNAL_OFFS;
+    const int maxv = (1 << X265_DEPTH) - 1;
+    for (int y = 0; y < h; y++)
+        for (int x = 0; x < w; x++)
+        {
+            int v = (s0[y * pitch + x] + s1[y * pitch + x] + offset) >> shiftNum;
+            dst[y * dstStride + x] = (pixel)(v < 0 ? 0 : (v > maxv ? maxv : v));
+        }
+}
+
+void ref_mc_pu(pixel **ref0, const intptr_t *ref0Strides, pixel **ref1, const intptr_t *ref1Strides, pixel **pred,
+               const intptr_t *predStrides, int w, int h, int dir, int flags, const int16_t *mv0, const int16_t *mv1)
+{
+    const int part = partitionFromSizes(w, h), cw = w >> 1, ch = h >> 1;
+    int16_t *immed = (int16_t*)malloc(sizeof(int16_t) * 64 * (64 + 8));
+    int16_t *s0 = (int16_t*)malloc(sizeof(int16_t) * 64 * 64 * 2), *s1 = s0 + 64 * 64;
+    if (flags & 1)
+    {
+        if (dir == 3)
+        {
+            harness_pred_luma_short(ref0[0], ref0Strides[0], mv0[0], mv0[1], part, w, h, s0, immed);
+            harness_pred_luma_short(ref1[0], ref1Strides[0], mv1[0], mv1[1], part, w, h, s1, immed);
+            harness_add_avg(s0, s1, MAX_CU_SIZE, w, h, pred[0], predStrides[0]);
+        }
+        else if (dir == 1) harness_pred_luma(ref0[0], ref0Strides[0], mv0[0], mv0[1], part, w, pred[0], predStrides[0], immed);
+        else harness_pred_luma(ref1[0], ref1Strides[0], mv1[0], mv1[1], part, w, pred[0], predStrides[0], immed);
+    }
+    if (flags & 2)
+        for (int c = 1; c < 3; c++)
+        {
+            if (dir == 3)
+            {
+                harness_pred_chroma_short(ref0[c], ref0Strides[1], mv0[0], mv0[1], part, cw, ch, s0, immed);
+                harness_pred_chroma_short(ref1[c], ref1Strides[1], mv1[0], mv1[1], part, cw, ch, s1, immed);
+                harness_add_avg(s0, s1, MAX_CU_SIZE / 2, cw, ch, pred[c], predStrides[1]);
+            }
+            else if (dir == 1) harness_pred_chroma(ref0[c], ref0Strides[1], mv0[0], mv0[1], part, cw, ch, pred[c], predStrides[1], immed);
+            else harness_pred_chroma(ref1[c], ref1Strides[1], mv1[0], mv1[1], part, cw, ch, pred[c], predStrides[1], immed);
+        }
+    free(s0);
+    free(immed);
+}
+
 } // extern "C"

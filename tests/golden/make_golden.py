@@ -162,6 +162,7 @@ def main():
     make_wp(shas)
     make_bipred(shas)
     make_merge(shas)
+    make_mc(shas)
     json.dump(shas, open(os.path.join(HERE, "input_sha.json"), "w"), indent=0, sort_keys=True)
     print("golden vectors written to", HERE)
 
@@ -325,6 +326,30 @@ def make_merge(shas):
     np.savez_compressed(os.path.join(HERE, "merge_golden.npz"), **out)
 
 
+def mc_case(depth):
+    """(reference pictures, job batches) of the motion-compensation vectors: pictures as [(buffer, origin, stride)] * 3."""
+    from oracle.bindings import MC_JOB_DTYPE
+    from util import mc_pictures, mc_job_batches
+    return mc_pictures(depth, 31, nrefs=3), mc_job_batches(np.random.default_rng(32), MC_JOB_DTYPE, 14, nrefs=3)
+
+
+def make_mc(shas):
+    """SHA-256 of the three planes of the prediction picture after each batch, computed by the reference's primitives in
+    TComPrediction::motionCompensation's order (Ref.mc_batch)."""
+    from util import mc_blank_pred
+    out = {}
+    for depth in (8, 10):
+        refs, batches = mc_case(depth)
+        shas["mc_%d" % depth] = [sha(pl[0]) for pic in refs for pl in pic] + [sha(np.concatenate(batches))]
+        digests = []
+        for jobs in batches:
+            pred = mc_blank_pred(depth)
+            Ref(depth).mc_batch(refs, pred, jobs)
+            digests.append([np.frombuffer(bytes.fromhex(sha(pl[0])), np.uint8) for pl in pred])
+        out["%d" % depth] = np.array(digests, np.uint8)
+    np.savez_compressed(os.path.join(HERE, "mc_golden.npz"), **out)
+
+
 def make_cmodel(shas):
     """Records of the reference's hardware C-model: coarse stage (CoarseIntMotionEstimation::CIME,
     hardwareC/inter.cpp:679-734), refine + fractional stages for the 85 CUs of each CTU
@@ -351,11 +376,11 @@ def make_cmodel(shas):
 
 
 if __name__ == "__main__":
-    if sys.argv[1:] in (["cmodel"], ["framecost"], ["wp"], ["bipred"], ["merge"]):
+    if sys.argv[1:] in (["cmodel"], ["framecost"], ["wp"], ["bipred"], ["merge"], ["mc"]):
         # only (re)generate the C-model / frame-cost records, keeping the other files as they are
         shas_path = os.path.join(HERE, "input_sha.json")
         shas_ = json.load(open(shas_path))
-        {"cmodel": make_cmodel, "framecost": make_frame_cost, "wp": make_wp, "bipred": make_bipred, "merge": make_merge}[sys.argv[1]](shas_)
+        {"cmodel": make_cmodel, "framecost": make_frame_cost, "wp": make_wp, "bipred": make_bipred, "merge": make_merge, "mc": make_mc}[sys.argv[1]](shas_)
         json.dump(shas_, open(shas_path, "w"), indent=0, sort_keys=True)
     else:
         main()

@@ -54,13 +54,14 @@ def test_header_is_plain_c(tmp_path):
     """include/x265_amd_me.h compiles as C99 and as C++ on its own, and its struct sizes match the Python mirrors."""
     import subprocess
     src = tmp_path / "t.c"
-    src.write_text('#include "x265_amd_me.h"\n#include <stdio.h>\nint main(void) { printf("%zu %zu %zu %zu %zu %zu %zu %zu\\n", '
+    src.write_text('#include "x265_amd_me.h"\n#include <stdio.h>\nint main(void) { printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu %zu\\n", '
                    'sizeof(x265amd_plane), sizeof(x265amd_job), sizeof(x265amd_result), sizeof(x265amd_field), '
-                   'sizeof(x265amd_frame_cost), sizeof(x265amd_weight), sizeof(x265amd_bipred_job), sizeof(x265amd_rk_result)); return 0; }\n')
+                   'sizeof(x265amd_frame_cost), sizeof(x265amd_weight), sizeof(x265amd_bipred_job), sizeof(x265amd_rk_result), sizeof(x265amd_mc_job), sizeof(x265amd_picture)); return 0; }\n')
     exe = tmp_path / "t"
     inc = os.path.join(ROOT, "include")
     subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Werror", "-pedantic", "-I", inc, "-o", str(exe), str(src)])
     sizes = [int(v) for v in subprocess.check_output([str(exe)]).split()]
     assert sizes == [C.sizeof(E.Plane), E.JOB_DTYPE.itemsize, E.RESULT_DTYPE.itemsize, C.sizeof(E.Field), C.sizeof(E.FrameCost),
-                     C.sizeof(E.Weight), E.BIPRED_JOB_DTYPE.itemsize, E.RK_RESULT_DTYPE.itemsize]
+                     C.sizeof(E.Weight), E.BIPRED_JOB_DTYPE.itemsize, E.RK_RESULT_DTYPE.itemsize, E.MC_JOB_DTYPE.itemsize,
+                     C.sizeof(E.Picture)]
     subprocess.check_call(["g++", "-std=c++11", "-Wall", "-Werror", "-fsyntax-only", "-x", "c++", "-I", inc, str(src)])

@@ -280,3 +280,20 @@ def test_merge_sa8d_vs_reference(oracle, ref):
             j["mv0"] = ((j["mv0"][0] & ~3) | (i & 3), (j["mv0"][1] & ~3) | ((i >> 2) & 3))
             j["mv1"] = ((j["mv1"][0] & ~3) | ((i >> 4) & 3), (j["mv1"][1] & ~3) | ((i >> 6) & 3))
     assert np.array_equal(ref.merge_sa8d_batch(f, refs, org, stride, jobs), oracle.merge_sa8d_batch(depth, f, refs, org, stride, jobs))
+
+
+def test_motion_compensation_vs_reference(oracle, ref):
+    """TComPrediction::motionCompensation's primitive calls (luma 8-tap, chroma 4-tap, pixel and 14-bit paths, addAvg) on the
+    reference's own primitives vs the oracle: every partition, direction and chroma fraction pair, whole prediction picture."""
+    from oracle.bindings import MC_JOB_DTYPE
+    from util import mc_pictures, mc_blank_pred, mc_job_batches
+    depth = ref.depth
+    refs = mc_pictures(depth, 21)
+    for jobs in mc_job_batches(np.random.default_rng(22), MC_JOB_DTYPE, 26):
+        a, b = mc_blank_pred(depth), mc_blank_pred(depth)
+        ref.mc_batch(refs, a, jobs)
+        oracle.mc_batch(depth, refs, b, jobs)
+        for k in range(3):
+            assert np.array_equal(a[k][0], b[k][0]), "plane %d" % k
+        assert (a[0][0] != 0x5A).any()
+

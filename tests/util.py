@@ -80,3 +80,57 @@ def host_lowres_planes(orc, depth, img, margin=64):
     outs = orc.lowres_core(depth, src, so, ss, lw, lh)
     padded = [pad_plane(o, margin, stride_align=32) for o in outs]
     return [p[0] for p in padded], padded[0][1], padded[0][2], wcu, hcu, lw, lh
+
+
+MC_W, MC_H, MC_MARGIN = 320, 192, 80
+
+
+def mc_pictures(depth, seed, nrefs=2):
+    """Reference pictures for the motion-compensation tests: a picture = [(buffer, origin, stride)] * 3 for Y, Cb, Cr,
+    noise so that every filter tap and the clipping at both ends of the range matter."""
+    from x265_amd.synth import make_chroma
+    y = make_clip(MC_W, MC_H, nrefs, seed=seed, depth=depth, kind="noise")
+    rng = np.random.default_rng(seed + 1)
+    pics = []
+    for i in range(nrefs):
+        dt = y[i].dtype
+        cb = rng.integers(0, 1 << depth, size=(MC_H // 2, MC_W // 2)).astype(dt)
+        cr = rng.integers(0, 1 << depth, size=(MC_H // 2, MC_W // 2)).astype(dt)
+        pics.append([pad_plane(y[i], MC_MARGIN), pad_plane(cb, MC_MARGIN // 2), pad_plane(cr, MC_MARGIN // 2)])
+    return pics
+
+
+def mc_blank_pred(depth, fill=0x5A):
+    """An unpadded prediction picture filled with a sentinel (so writes outside a PU show up)."""
+    dt = np.uint8 if depth <= 8 else np.uint16
+    return [(np.full(MC_W * MC_H, fill, dt), 0, MC_W), (np.full(MC_W * MC_H // 4, fill, dt), 0, MC_W // 2),
+            (np.full(MC_W * MC_H // 4, fill, dt), 0, MC_W // 2)]
+
+
+def mc_job_batches(rng, dtype, nbatches, nrefs=2):
+    """Batches of non-overlapping PUs (one per 64x64 cell, at a random multiple of 4 inside it): every partition, the three
+    directions, luma-only / chroma-only / both, and all 64 eighth-pel chroma fraction pairs many times over."""
+    parts = PARTITIONS[1:]
+    batches, k = [], 0
+    for b in range(nbatches):
+        jobs = np.zeros((MC_W // 64) * (MC_H // 64), dtype)
+        for c, j in enumerate(jobs):
+            w, h = parts[k % len(parts)]
+            cx, cy = c % (MC_W // 64), c // (MC_W // 64)
+            j["pu_x"] = cx * 64 + int(rng.integers(0, (64 - w) // 4 + 1)) * 4
+            j["pu_y"] = cy * 64 + int(rng.integers(0, (64 - h) // 4 + 1)) * 4
+            j["w"], j["h"] = w, h
+            j["dir"] = 1 + k % 3
+            j["flags"] = (3, 3, 3, 1, 2)[(k // 3) % 5]
+            j["ref0"], j["ref1"] = k % nrefs, (k // nrefs) % nrefs
+            mv0, mv1 = rng.integers(-150, 151, 2), rng.integers(-150, 151, 2)
+            # walk the 8 x 8 fraction pairs of list 0; list 1 runs through them at another pace
+            mv0 = ((mv0[0] & ~7) | (k & 7), (mv0[1] & ~7) | ((k >> 3) & 7))
+            mv1 = ((mv1[0] & ~7) | ((k // 5) & 7), (mv1[1] & ~7) | ((k // 7) & 7))
+            if k % 11 == 0:
+                mv0, mv1 = (mv0[0] & ~7, mv0[1] & ~7), (0, 0)
+            j["mv0"], j["mv1"] = mv0, mv1
+            k += 1
+        batches.append(jobs)
+    return batches
+

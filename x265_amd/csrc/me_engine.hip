@@ -1614,6 +1614,111 @@ int x265amd_merge_sa8d_batch(x265amd_ctx *c, const x265amd_plane *fenc, const x2
     return X265AMD_OK;
 }
 
+/* ---- motion compensation ---- */
+
+int x265amd_pictures_upload(x265amd_ctx *c, const x265amd_picture *refs, int nrefs, void **d_ref_planes)
+{
+    if (!c || !refs || nrefs <= 0 || nrefs > 32 || !d_ref_planes) return fail(c, X265AMD_EINVAL, "null argument");
+    PlaneDev hp[96];
+    for (int i = 0; i < nrefs; i++)
+    {
+        const x265amd_plane *pl[3] = { &refs[i].y, &refs[i].cb, &refs[i].cr };
+        for (int k = 0; k < 3; k++)
+        {
+            if (!pl[k]->origin) return fail(c, X265AMD_EINVAL, "picture: null plane");
+            hp[3 * i + k].origin = pl[k]->origin; hp[3 * i + k].stride = pl[k]->stride;
+        }
+    }
+    HIPCHK(c, hipSetDevice(c->device));
+    void *d = 0;
+    HIPCHK(c, hipMalloc(&d, sizeof(PlaneDev) * 3 * nrefs));
+    hipError_t e = hipMemcpyAsync(d, hp, sizeof(PlaneDev) * 3 * nrefs, hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    if (e != hipSuccess) { (void)hipFree(d); HIPCHK(c, e); }
+    *d_ref_planes = d;
+    return X265AMD_OK;
+}
+
+int x265amd_mc_batch_dev(x265amd_ctx *c, const void *d_ref_planes, const x265amd_picture *pred, const x265amd_mc_job *d_jobs, int njobs)
+{
+    if (!c || !d_ref_planes || !pred || !pred->y.origin || !pred->cb.origin || !pred->cr.origin || !d_jobs || njobs < 0)
+        return fail(c, X265AMD_EINVAL, "null argument");
+    if (!njobs) return X265AMD_OK;
+    HIPCHK(c, hipSetDevice(c->device));
+    McArgs a;
+    a.refs = (const PlaneDev*)d_ref_planes;
+    a.pred[0].origin = pred->y.origin; a.pred[0].stride = pred->y.stride;
+    a.pred[1].origin = pred->cb.origin; a.pred[1].stride = pred->cb.stride;
+    a.pred[2].origin = pred->cr.origin; a.pred[2].stride = pred->cr.stride;
+    a.depth = c->depth; a.njobs = njobs; a.jobs = d_jobs;
+    if (c->depth <= 8) hipLaunchKernelGGL(mc_kernel<uint8_t>, dim3(njobs), dim3(64), 0, c->stream, a);
+    else hipLaunchKernelGGL(mc_kernel<uint16_t>, dim3(njobs), dim3(64), 0, c->stream, a);
+    HIPCHK(c, hipGetLastError());
+    return X265AMD_OK;
+}
+
+int x265amd_mc_batch(x265amd_ctx *c, const x265amd_picture *refs, int nrefs, const x265amd_picture *pred,
+                     const x265amd_mc_job *jobs, int njobs)
+{
+    if (!c || !refs || nrefs <= 0 || nrefs > 32 || !pred || !jobs || njobs < 0) return fail(c, X265AMD_EINVAL, "null argument");
+    if (!pred->y.origin || !pred->cb.origin || !pred->cr.origin) return fail(c, X265AMD_EINVAL, "null prediction plane");
+    if (!njobs) return X265AMD_OK;
+    for (int i = 0; i < nrefs; i++)
+        if (!refs[i].y.origin || !refs[i].cb.origin || !refs[i].cr.origin) return fail(c, X265AMD_EINVAL, "picture: null plane");
+    for (int i = 0; i < njobs; i++)
+    {
+        const x265amd_mc_job &j = jobs[i];
+        if (x265amd_partition_from_sizes(j.w, j.h) < 1) return fail(c, X265AMD_EINVAL, "job: not a luma partition above 4x4");
+        if (j.dir < 1 || j.dir > 3 || !(j.flags & 3) || j.ref0 >= nrefs || j.ref1 >= nrefs)
+            return fail(c, X265AMD_EINVAL, "job: bad direction, flags or reference index");
+        if (j.pu_x < 0 || j.pu_y < 0 || (j.pu_x & 3) || (j.pu_y & 3)) return fail(c, X265AMD_EINVAL, "job: PU position must be a multiple of 4");
+        if (((j.flags & 1) && (j.pu_x + j.w > pred->y.width || j.pu_y + j.h > pred->y.height)) ||
+            ((j.flags & 2) && ((j.pu_x + j.w) / 2 > pred->cb.width || (j.pu_y + j.h) / 2 > pred->cb.height ||
+                               (j.pu_x + j.w) / 2 > pred->cr.width || (j.pu_y + j.h) / 2 > pred->cr.height)))
+            return fail(c, X265AMD_EINVAL, "job: PU outside the prediction picture");
+        for (int l = 0; l < 2; l++)
+        {
+            if (!(j.dir & (1 << l))) continue;
+            const int16_t *mv = l ? j.mv1 : j.mv0;
+            const x265amd_picture *r = &refs[l ? j.ref1 : j.ref0];
+            if (j.flags & 1)
+            {
+                /* 8-tap footprint, tiles read as whole quads */
+                const int x0 = j.pu_x + (mv[0] >> 2) - 3, x1 = j.pu_x + j.w + (mv[0] >> 2) + 8;
+                const int y0 = j.pu_y + (mv[1] >> 2) - 3, y1 = j.pu_y + j.h + (mv[1] >> 2) + 4;
+                if (x0 < -r->y.margin_x || y0 < -r->y.margin_y || x1 > r->y.width + r->y.margin_x || y1 > r->y.height + r->y.margin_y)
+                    return fail(c, X265AMD_EINVAL, "job: luma prediction block leaves the padded reference plane");
+            }
+            if (j.flags & 2)
+                for (int k = 0; k < 2; k++)
+                {
+                    /* 4-tap footprint; a 2x2 block reads its rows as two quads from one sample to the left */
+                    const x265amd_plane *p = k ? &r->cr : &r->cb;
+                    const int x0 = j.pu_x / 2 + (mv[0] >> 3) - 1, x1 = (j.pu_x + j.w) / 2 + (mv[0] >> 3) + 5;
+                    const int y0 = j.pu_y / 2 + (mv[1] >> 3) - 1, y1 = (j.pu_y + j.h) / 2 + (mv[1] >> 3) + 2;
+                    if (x0 < -p->margin_x || y0 < -p->margin_y || x1 > p->width + p->margin_x || y1 > p->height + p->margin_y)
+                        return fail(c, X265AMD_EINVAL, "job: chroma prediction block leaves the padded reference plane");
+                }
+        }
+    }
+    HIPCHK(c, hipSetDevice(c->device));
+    int rc;
+    PlaneDev hp[96];
+    for (int i = 0; i < nrefs; i++)
+    {
+        hp[3 * i].origin = refs[i].y.origin; hp[3 * i].stride = refs[i].y.stride;
+        hp[3 * i + 1].origin = refs[i].cb.origin; hp[3 * i + 1].stride = refs[i].cb.stride;
+        hp[3 * i + 2].origin = refs[i].cr.origin; hp[3 * i + 2].stride = refs[i].cr.stride;
+    }
+    const size_t jb = (size_t)njobs * sizeof(x265amd_mc_job), pb = sizeof(PlaneDev) * 96;
+    if ((rc = ensure(c, &c->d_jobs, &c->jobs_cap, jb + pb))) return rc;
+    HIPCHK(c, hipMemcpyAsync(c->d_jobs, hp, sizeof(PlaneDev) * 3 * nrefs, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync((char*)c->d_jobs + pb, jobs, jb, hipMemcpyHostToDevice, c->stream));
+    if ((rc = x265amd_mc_batch_dev(c, c->d_jobs, pred, (const x265amd_mc_job*)((char*)c->d_jobs + pb), njobs))) return rc;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return X265AMD_OK;
+}
+
 int x265amd_rk_ds_plane(x265amd_ctx *c, const x265amd_plane *orig, x265amd_plane *out)
 {
     if (!c || !orig || !orig->origin || !out) return fail(c, X265AMD_EINVAL, "null plane");

@@ -741,7 +741,194 @@ __global__ __launch_bounds__(64) void merge_sa8d_kernel(MergeArgs a)
     if (lane == 0) a.out[j] = total;
 }
 
+/* ---- motion compensation into a prediction picture, luma + 4:2:0 chroma ----
+ * TComPrediction::motionCompensation without weighted prediction (TComPrediction.cpp:201-286).
+ * One wave per PU, a lane per 4x4 luma tile (looping above 64 tiles); the lane also owns the 2x2
+ * block of Cb and of Cr under its tile (chroma blocks of every HEVC partition are even-sized).
+ * All samples are interpolated in registers from global memory and stored once; phases are
+ * uniform over the wave, so no branch diverges. */
+__constant__ static const int16_t kChromaTaps[8][4] = {        /* g_chromaFilter, TComRom.cpp:183-193 */
+    {  0, 64,  0,  0 }, { -2, 58, 10, -2 }, { -4, 54, 16, -2 }, { -6, 46, 28, -4 },
+    { -4, 36, 36, -4 }, { -4, 28, 46, -6 }, { -2, 16, 54, -4 }, { -2, 10, 58, -2 } };
+
+struct McArgs
+{
+    const PlaneDev *refs;      /* device array: Y, Cb, Cr of each reference picture */
+    PlaneDev pred[3];
+    int depth, njobs;
+    const x265amd_mc_job *jobs;
+};
+
+/* One 2x2 chroma block of xPredInterChromaBlk at eighth-pel MV (ex, ey); `r` is the block's own
+ * position in the reference plane. SHORT = false, the pixel flavour (TComPrediction.cpp:491-540):
+ * copy, filter_hpp / filter_vpp, or filter_hps with row extension + chroma_vsp (ipfilter.cpp:194-319
+ * with N = 4, :40-81). SHORT = true, the 14-bit flavour (:543-593): chroma_p2s, filter_hps,
+ * filterVertical_ps_c<4> or filter_hps + filterVertical_ss_c<4> (ipfilter.cpp:83-172). */
+template<typename P, bool SHORT>
+__device__ __forceinline__ void chroma_block(const P AS1 *r, int stride, int ex, int ey, int depth, int o[2][2])
+{
+    const int xf = ex & 7, yf = ey & 7, headRoom = 14 - depth, maxv = (1 << depth) - 1;
+    const int shiftH = 6 - headRoom, offH = -(8192 << shiftH);
+    const int shiftV = 6 + headRoom, offV = (1 << (shiftV - 1)) + (8192 << 6);
+    GlobalLoader<P> ld = { r + (long)(ey >> 3) * stride + (ex >> 3), stride };
+    int cx[4], cy[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) { cx[k] = kChromaTaps[xf][k]; cy[k] = kChromaTaps[yf][k]; }
+    int hrow[5][2];
+    const int first = yf ? -1 : 0, nrows = yf ? 5 : 2;
+#pragma unroll
+    for (int i = 0; i < 5; i++)
+    {
+        if (i >= nrows) { hrow[i][0] = hrow[i][1] = 0; continue; }
+        if (xf == 0)
+        {
+            int px[4];
+            Px<P>::unpack(ld(0, first + i), px);
+            hrow[i][0] = px[0]; hrow[i][1] = px[1];
+        }
+        else
+        {
+            int px[8];
+            Px<P>::unpack(ld(-1, first + i), px);
+            Px<P>::unpack(ld(3, first + i), px + 4);
+#pragma unroll
+            for (int x = 0; x < 2; x++)
+            {
+                int sum = 0;
+#pragma unroll
+                for (int k = 0; k < 4; k++) sum += px[x + k] * cx[k];
+                hrow[i][x] = (yf == 0 && !SHORT) ? clip_pixel(as_i16((sum + 32) >> 6), maxv) : as_i16((sum + offH) >> shiftH);
+            }
+        }
+    }
+#pragma unroll
+    for (int y = 0; y < 2; y++)
+#pragma unroll
+        for (int x = 0; x < 2; x++)
+        {
+            if (yf == 0)
+                o[y][x] = xf ? hrow[y][x] : (SHORT ? as_i16((hrow[y][x] << headRoom) - 8192) : hrow[y][x]);
+            else
+            {
+                int sum = 0;
+#pragma unroll
+                for (int k = 0; k < 4; k++) sum += hrow[y + k][x] * cy[k];
+                if (xf == 0) o[y][x] = SHORT ? as_i16((sum + offH) >> shiftH) : clip_pixel(as_i16((sum + 32) >> 6), maxv);
+                else o[y][x] = SHORT ? as_i16(sum >> 6) : clip_pixel(as_i16((sum + offV) >> shiftV), maxv);
+            }
+        }
+}
+
+template<typename P> struct PxStore;
+template<> struct PxStore<uint8_t>
+{
+    static __device__ __forceinline__ void four(uint8_t AS1 *d, const int v[4])
+    {
+        typedef uint32_t __attribute__((aligned(1))) u32u;
+        *(u32u AS1*)d = (uint32_t)v[0] | ((uint32_t)v[1] << 8) | ((uint32_t)v[2] << 16) | ((uint32_t)v[3] << 24);
+    }
+    static __device__ __forceinline__ void two(uint8_t AS1 *d, int a, int b)
+    {
+        typedef uint16_t __attribute__((aligned(1))) u16u;
+        *(u16u AS1*)d = (uint16_t)(a | (b << 8));
+    }
+};
+template<> struct PxStore<uint16_t>
+{
+    static __device__ __forceinline__ void four(uint16_t AS1 *d, const int v[4])
+    {
+        typedef uint32_t __attribute__((aligned(2))) u32u;
+        ((u32u AS1*)d)[0] = (uint32_t)v[0] | ((uint32_t)v[1] << 16);
+        ((u32u AS1*)d)[1] = (uint32_t)v[2] | ((uint32_t)v[3] << 16);
+    }
+    static __device__ __forceinline__ void two(uint16_t AS1 *d, int a, int b)
+    {
+        typedef uint32_t __attribute__((aligned(2))) u32u;
+        *(u32u AS1*)d = (uint32_t)a | ((uint32_t)b << 16);
+    }
+};
+
+template<typename P>
+__global__ __launch_bounds__(64) void mc_kernel(McArgs a)
+{
+    const int j = blockIdx.x;
+    if (j >= a.njobs) return;
+    const x265amd_mc_job *job = a.jobs + j;
+    const int lane = threadIdx.x & 63;
+    const int w = uni(job->w), h = uni(job->h), dir = uni(job->dir), flags = uni(job->flags);
+    const int pux = uni(job->pu_x), puy = uni(job->pu_y);
+    const int m0x = uni(job->mv0[0]), m0y = uni(job->mv0[1]), m1x = uni(job->mv1[0]), m1y = uni(job->mv1[1]);
+    const PlaneDev *p0 = a.refs + 3 * uni(job->ref0), *p1 = a.refs + 3 * uni(job->ref1);
+    const int wt = w >> 2, T = wt * (h >> 2);
+    const int maxv = (1 << a.depth) - 1;
+    /* TComYuv::addAvg, TComYuv.cpp:596-606 and :616-650 */
+    const int shiftNum = 15 - a.depth, offset = (1 << (shiftNum - 1)) + 2 * 8192;
+    for (int t = lane; t < T; t += 64)
+    {
+        const int ty = t / wt, tx = t - ty * wt;
+        if (flags & 1)
+        {
+            const PlaneDev r0 = p0[0], r1 = p1[0];
+            const int x = pux + 4 * tx, y = puy + 4 * ty;
+            const P AS1 *s0 = (const P AS1*)r0.origin + (long)y * r0.stride + x;
+            const P AS1 *s1 = (const P AS1*)r1.origin + (long)y * r1.stride + x;
+            int p[4][4];
+            if (dir == 3)
+            {
+                int q[4][4];
+                mc_short_tile<P>(s0, r0.stride, m0x, m0y, a.depth, p);
+                mc_short_tile<P>(s1, r1.stride, m1x, m1y, a.depth, q);
+#pragma unroll
+                for (int yy = 0; yy < 4; yy++)
+#pragma unroll
+                    for (int xx = 0; xx < 4; xx++)
+                    {
+                        const int v = (p[yy][xx] + q[yy][xx] + offset) >> shiftNum;
+                        p[yy][xx] = v < 0 ? 0 : (v > maxv ? maxv : v);
+                    }
+            }
+            else if (dir == 2) bipred_tile<P>(s1, r1.stride, m1x, m1y, a.depth, p);
+            else bipred_tile<P>(s0, r0.stride, m0x, m0y, a.depth, p);
+            P AS1 *d = (P AS1*)a.pred[0].origin + (long)y * a.pred[0].stride + x;
+#pragma unroll
+            for (int yy = 0; yy < 4; yy++) PxStore<P>::four(d + (long)yy * a.pred[0].stride, p[yy]);
+        }
+        if (flags & 2)
+        {
+            const int x = (pux >> 1) + 2 * tx, y = (puy >> 1) + 2 * ty;
+#pragma unroll 1
+            for (int c = 1; c < 3; c++)
+            {
+                const PlaneDev r0 = p0[c], r1 = p1[c];
+                const P AS1 *s0 = (const P AS1*)r0.origin + (long)y * r0.stride + x;
+                const P AS1 *s1 = (const P AS1*)r1.origin + (long)y * r1.stride + x;
+                int p[2][2];
+                if (dir == 3)
+                {
+                    int q[2][2];
+                    chroma_block<P, true>(s0, r0.stride, m0x, m0y, a.depth, p);
+                    chroma_block<P, true>(s1, r1.stride, m1x, m1y, a.depth, q);
+#pragma unroll
+                    for (int yy = 0; yy < 2; yy++)
+#pragma unroll
+                        for (int xx = 0; xx < 2; xx++)
+                        {
+                            const int v = (p[yy][xx] + q[yy][xx] + offset) >> shiftNum;
+                            p[yy][xx] = v < 0 ? 0 : (v > maxv ? maxv : v);
+                        }
+                }
+                else if (dir == 2) chroma_block<P, false>(s1, r1.stride, m1x, m1y, a.depth, p);
+                else chroma_block<P, false>(s0, r0.stride, m0x, m0y, a.depth, p);
+                P AS1 *d = (P AS1*)a.pred[c].origin + (long)y * a.pred[c].stride + x;
+                PxStore<P>::two(d, p[0][0], p[0][1]);
+                PxStore<P>::two(d + a.pred[c].stride, p[1][0], p[1][1]);
+            }
+        }
+    }
+}
+
 } // namespace x265amd
+
 
 
 

@@ -43,6 +43,9 @@ BIPRED_JOB_DTYPE = np.dtype([("pu_x", "<i2"), ("pu_y", "<i2"), ("w", "u1"), ("h"
 MERGE_JOB_DTYPE = np.dtype([("pu_x", "<i2"), ("pu_y", "<i2"), ("size", "u1"), ("dir", "u1"), ("ref0", "u1"), ("ref1", "u1"),
                             ("mv0", "<i2", (2,)), ("mv1", "<i2", (2,))], align=True)
 assert MERGE_JOB_DTYPE.itemsize == 16
+MC_JOB_DTYPE = np.dtype([("pu_x", "<i2"), ("pu_y", "<i2"), ("w", "u1"), ("h", "u1"), ("dir", "u1"), ("flags", "u1"),
+                         ("ref0", "u1"), ("ref1", "u1"), ("reserved", "u1", (2,)), ("mv0", "<i2", (2,)), ("mv1", "<i2", (2,))], align=True)
+assert MC_JOB_DTYPE.itemsize == 20
 BIPRED_RESULT_DTYPE = np.dtype([("satd", "<i4"), ("satd_zero", "<i4")], align=True)
 assert BIPRED_JOB_DTYPE.itemsize == 16 and BIPRED_RESULT_DTYPE.itemsize == 8
 
@@ -51,6 +54,11 @@ class Plane(C.Structure):
     """x265amd_plane: a padded picture plane in device memory."""
     _fields_ = [("origin", C.c_void_p), ("stride", C.c_int32), ("width", C.c_int32), ("height", C.c_int32),
                 ("margin_x", C.c_int32), ("margin_y", C.c_int32)]
+
+
+class Picture(C.Structure):
+    """x265amd_picture: the three planes of a 4:2:0 picture in device memory."""
+    _fields_ = [("y", Plane), ("cb", Plane), ("cr", Plane)]
 
 
 class Field(C.Structure):
@@ -377,6 +385,32 @@ class Engine:
         self._chk(self.L.x265amd_merge_sa8d_batch(self.ctx, C.byref(fenc), (Plane * len(refs))(*refs), len(refs),
                                                   C.c_void_p(jobs.ctypes.data), len(jobs), C.c_void_p(out.ctypes.data)))
         return out
+
+    # ---- motion compensation
+    def upload_picture(self, planes):
+        """planes: [(padded buffer, origin, stride, width, height, margin)] for Y, Cb, Cr -> Picture."""
+        pic = Picture()
+        for name, (buf, _, stride, w, h, m) in zip(("y", "cb", "cr"), planes):
+            setattr(pic, name, self.upload_plane(buf, w, h, m, m, stride))
+        return pic
+
+    def free_picture(self, pic):
+        for p in (pic.y, pic.cb, pic.cr):
+            self.free_plane(p)
+
+    def mc_batch(self, refs, pred, jobs):
+        """TComPrediction::motionCompensation for MC_JOB_DTYPE records: refs = list of Picture, pred = output Picture."""
+        jobs = np.ascontiguousarray(jobs, MC_JOB_DTYPE)
+        self._chk(self.L.x265amd_mc_batch(self.ctx, (Picture * len(refs))(*refs), len(refs), C.byref(pred),
+                                          C.c_void_p(jobs.ctypes.data), len(jobs)))
+
+    def pictures_upload(self, refs):
+        d = C.c_void_p()
+        self._chk(self.L.x265amd_pictures_upload(self.ctx, (Picture * len(refs))(*refs), len(refs), C.byref(d)))
+        return d.value
+
+    def mc_batch_dev(self, d_ref_planes, pred, d_jobs, njobs):
+        self._chk(self.L.x265amd_mc_batch_dev(self.ctx, C.c_void_p(d_ref_planes), C.byref(pred), C.c_void_p(d_jobs), njobs))
 
     # ---- Rockchip path
     def rk_ds_plane(self, orig):

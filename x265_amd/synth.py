@@ -1,4 +1,4 @@
-"""Deterministic synthetic luma clips and padded-plane helpers (host side, numpy).
+"""Deterministic synthetic clips (luma; 4:2:0 chroma for motion compensation) and padded-plane helpers (host side, numpy).
 
 The clips follow the recipe the reference numbers were measured on: a 5x5
 box-smoothed uniform random texture translated by (3i mod 32, 2i mod 32) pixels per
@@ -37,6 +37,13 @@ def make_clip(width, height, nframes, seed=1234, depth=8, kind="texture"):
         y = np.clip((b[dy:dy + height, dx:dx + width] + noise) * scale, 0, maxv)
         frames.append(y.astype(dt))
     return frames
+
+
+def make_chroma(width, height, nframes, seed=1234, depth=8):
+    """Cb / Cr planes of a 4:2:0 clip ((height/2, width/2) each): the luma recipe at half size with other seeds."""
+    cb = make_clip(width // 2, height // 2, nframes, seed + 7001, depth)
+    cr = make_clip(width // 2, height // 2, nframes, seed + 9001, depth)
+    return cb, cr
 
 
 def pad_plane(img, margin_x=LUMA_MARGIN, margin_y=None, stride_align=1):
