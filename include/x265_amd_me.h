@@ -333,11 +333,16 @@ typedef struct { x265amd_plane y, cb, cr; } x265amd_picture;
  * jobs: HOST array. Returns when the prediction samples are in `pred`. */
 int x265amd_mc_batch(x265amd_ctx *ctx, const x265amd_picture *refs, int nrefs, const x265amd_picture *pred,
                      const x265amd_mc_job *jobs, int njobs);
-/* device-resident jobs, asynchronous on the engine's stream; the jobs are not validated.
- * d_ref_planes: device array from x265amd_pictures_upload. */
+/* Device-resident variant, asynchronous on the engine's stream. x265amd_pictures_upload puts the plane
+ * descriptors of `refs` on the device (free with x265amd_device_free); x265amd_mc_list_create checks the
+ * jobs as x265amd_mc_batch does, numbers their 4x4 tiles for the launch and uploads both (a list can be
+ * launched any number of times, e.g. one list per frame); x265amd_mc_batch_dev only launches. */
+typedef struct x265amd_mc_list x265amd_mc_list;
 int x265amd_pictures_upload(x265amd_ctx *ctx, const x265amd_picture *refs, int nrefs, void **d_ref_planes);
-int x265amd_mc_batch_dev(x265amd_ctx *ctx, const void *d_ref_planes, const x265amd_picture *pred,
-                         const x265amd_mc_job *d_jobs, int njobs);
+int x265amd_mc_list_create(x265amd_ctx *ctx, const x265amd_picture *refs, int nrefs, const x265amd_picture *pred,
+                           const x265amd_mc_job *jobs, int njobs, x265amd_mc_list **out);
+int x265amd_mc_list_free(x265amd_ctx *ctx, x265amd_mc_list *list);
+int x265amd_mc_batch_dev(x265amd_ctx *ctx, const void *d_ref_planes, const x265amd_picture *pred, const x265amd_mc_list *list);
 
 /* ---- Rockchip path (rd >= 5): CIME + RIME + FME ---- */
 

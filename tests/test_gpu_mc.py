@@ -69,20 +69,22 @@ def test_mc_vs_oracle(request, oracle, depth):
     # device-resident jobs, asynchronous
     jobs = batches[3]
     d_planes = e.pictures_upload(drefs)
-    d_jobs = C.c_void_p()
-    e._chk(e.L.x265amd_device_alloc(e.ctx, C.c_size_t(jobs.nbytes), C.byref(d_jobs)))
-    e._chk(e.L.x265amd_upload(e.ctx, d_jobs, C.c_void_p(jobs.ctypes.data), C.c_size_t(jobs.nbytes)))
     dpred = upload_pictures(e, [mc_blank_pred(depth)], margin=0)[0]
-    e.mc_batch_dev(d_planes, dpred, d_jobs.value, len(jobs))
+    lst = e.mc_list_create(drefs, dpred, jobs)
+    e.mc_batch_dev(d_planes, dpred, lst)
     e._chk(e.L.x265amd_sync(e.ctx))
     exp = mc_blank_pred(depth)
     oracle.mc_batch(depth, refs, exp, jobs)
     for k, got in enumerate(download_picture(e, dpred)):
         assert np.array_equal(got, exp[k][0])
-    e._chk(e.L.x265amd_device_free(e.ctx, d_jobs))
-    e._chk(e.L.x265amd_device_free(e.ctx, C.c_void_p(d_planes)))
+    e.mc_list_free(lst)
     # empty batch leaves the picture alone
     e.mc_batch(drefs, dpred, jobs[:0])
+    empty = e.mc_list_create(drefs, dpred, jobs[:0])
+    e.mc_batch_dev(d_planes, dpred, empty)
+    e.mc_list_free(empty)
+    with pytest.raises(Exception):
+        e.mc_list_create(drefs, dpred, np.zeros(1, MC_JOB_DTYPE))
     for bad_field, bad_value in (("w", 20), ("dir", 0), ("flags", 0), ("ref1", 7), ("pu_x", 2), ("mv0", (8 * (MC_W + MC_MARGIN), 0)),
                                  ("pu_y", MC_H)):
         bad = jobs[:1].copy()
@@ -90,6 +92,7 @@ def test_mc_vs_oracle(request, oracle, depth):
         bad[bad_field] = bad_value
         with pytest.raises(Exception):
             e.mc_batch(drefs, dpred, bad)
+    e._chk(e.L.x265amd_device_free(e.ctx, C.c_void_p(d_planes)))
     e.free_picture(dpred)
     for p in drefs:
         e.free_picture(p)

@@ -1639,30 +1639,18 @@ int x265amd_pictures_upload(x265amd_ctx *c, const x265amd_picture *refs, int nre
     return X265AMD_OK;
 }
 
-int x265amd_mc_batch_dev(x265amd_ctx *c, const void *d_ref_planes, const x265amd_picture *pred, const x265amd_mc_job *d_jobs, int njobs)
+struct x265amd_mc_list
 {
-    if (!c || !d_ref_planes || !pred || !pred->y.origin || !pred->cb.origin || !pred->cr.origin || !d_jobs || njobs < 0)
-        return fail(c, X265AMD_EINVAL, "null argument");
-    if (!njobs) return X265AMD_OK;
-    HIPCHK(c, hipSetDevice(c->device));
-    McArgs a;
-    a.refs = (const PlaneDev*)d_ref_planes;
-    a.pred[0].origin = pred->y.origin; a.pred[0].stride = pred->y.stride;
-    a.pred[1].origin = pred->cb.origin; a.pred[1].stride = pred->cb.stride;
-    a.pred[2].origin = pred->cr.origin; a.pred[2].stride = pred->cr.stride;
-    a.depth = c->depth; a.njobs = njobs; a.jobs = d_jobs;
-    if (c->depth <= 8) hipLaunchKernelGGL(mc_kernel<uint8_t>, dim3(njobs), dim3(64), 0, c->stream, a);
-    else hipLaunchKernelGGL(mc_kernel<uint16_t>, dim3(njobs), dim3(64), 0, c->stream, a);
-    HIPCHK(c, hipGetLastError());
-    return X265AMD_OK;
-}
+    void *d_blob;              /* jobs | first[njobs + 64] | chunk_job[nchunks] */
+    size_t first_off, chunk_off;
+    int njobs, nchunks;
+};
 
-int x265amd_mc_batch(x265amd_ctx *c, const x265amd_picture *refs, int nrefs, const x265amd_picture *pred,
-                     const x265amd_mc_job *jobs, int njobs)
+static int mc_validate(x265amd_ctx *c, const x265amd_picture *refs, int nrefs, const x265amd_picture *pred,
+                       const x265amd_mc_job *jobs, int njobs)
 {
     if (!c || !refs || nrefs <= 0 || nrefs > 32 || !pred || !jobs || njobs < 0) return fail(c, X265AMD_EINVAL, "null argument");
     if (!pred->y.origin || !pred->cb.origin || !pred->cr.origin) return fail(c, X265AMD_EINVAL, "null prediction plane");
-    if (!njobs) return X265AMD_OK;
     for (int i = 0; i < nrefs; i++)
         if (!refs[i].y.origin || !refs[i].cb.origin || !refs[i].cr.origin) return fail(c, X265AMD_EINVAL, "picture: null plane");
     for (int i = 0; i < njobs; i++)
@@ -1701,8 +1689,100 @@ int x265amd_mc_batch(x265amd_ctx *c, const x265amd_picture *refs, int nrefs, con
                 }
         }
     }
+    return X265AMD_OK;
+}
+
+/* Numbers the 4x4 tiles of the jobs consecutively and lays jobs | first[] | chunk_job[] out in `blob` */
+static void mc_plan(const x265amd_mc_job *jobs, int njobs, std::vector<char> &blob, x265amd_mc_list *l)
+{
+    long total = 0;
+    for (int i = 0; i < njobs; i++) total += (jobs[i].w >> 2) * (jobs[i].h >> 2);
+    l->njobs = njobs;
+    l->nchunks = (int)((total + 63) / 64);
+    l->first_off = ((size_t)njobs * sizeof(x265amd_mc_job) + 15) & ~(size_t)15;
+    l->chunk_off = l->first_off + ((size_t)njobs + 64) * sizeof(int32_t);
+    blob.assign(l->chunk_off + (size_t)l->nchunks * sizeof(int32_t), 0);
+    memcpy(blob.data(), jobs, (size_t)njobs * sizeof(x265amd_mc_job));
+    int32_t *first = (int32_t*)(blob.data() + l->first_off), *chunk = (int32_t*)(blob.data() + l->chunk_off);
+    int32_t run = 0;
+    for (int i = 0; i < njobs; i++)
+    {
+        const int t = (jobs[i].w >> 2) * (jobs[i].h >> 2);
+        first[i] = run;
+        for (int k = (run + 63) / 64; 64 * k < run + t; k++) chunk[k] = i;
+        run += t;
+    }
+    for (int i = 0; i < 64; i++) first[njobs + i] = run;
+}
+
+static int mc_launch(x265amd_ctx *c, const void *d_ref_planes, const x265amd_picture *pred, const void *d_blob, const x265amd_mc_list *l)
+{
+    McArgs a;
+    a.refs = (const PlaneDev*)d_ref_planes;
+    a.pred[0].origin = pred->y.origin; a.pred[0].stride = pred->y.stride;
+    a.pred[1].origin = pred->cb.origin; a.pred[1].stride = pred->cb.stride;
+    a.pred[2].origin = pred->cr.origin; a.pred[2].stride = pred->cr.stride;
+    a.depth = c->depth; a.njobs = l->njobs; a.nchunks = l->nchunks;
+    a.jobs = (const x265amd_mc_job*)d_blob;
+    a.first = (const int32_t*)((const char*)d_blob + l->first_off);
+    a.chunk_job = (const int32_t*)((const char*)d_blob + l->chunk_off);
+    if (c->depth <= 8) hipLaunchKernelGGL(mc_kernel<uint8_t>, dim3(l->nchunks), dim3(64), 0, c->stream, a);
+    else hipLaunchKernelGGL(mc_kernel<uint16_t>, dim3(l->nchunks), dim3(64), 0, c->stream, a);
+    HIPCHK(c, hipGetLastError());
+    return X265AMD_OK;
+}
+
+int x265amd_mc_list_create(x265amd_ctx *c, const x265amd_picture *refs, int nrefs, const x265amd_picture *pred,
+                           const x265amd_mc_job *jobs, int njobs, x265amd_mc_list **out)
+{
+    if (!out) return fail(c, X265AMD_EINVAL, "null argument");
+    int rc = mc_validate(c, refs, nrefs, pred, jobs, njobs);
+    if (rc) return rc;
+    x265amd_mc_list *l = new x265amd_mc_list();
+    std::vector<char> blob;
+    mc_plan(jobs, njobs, blob, l);
+    hipError_t e = hipSetDevice(c->device);
+    if (e == hipSuccess) e = hipMalloc(&l->d_blob, blob.size() + 16);
+    if (e == hipSuccess) e = hipMemcpyAsync(l->d_blob, blob.data(), blob.size(), hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    if (e != hipSuccess)
+    {
+        if (l->d_blob) (void)hipFree(l->d_blob);
+        delete l;
+        HIPCHK(c, e);
+    }
+    *out = l;
+    return X265AMD_OK;
+}
+
+int x265amd_mc_list_free(x265amd_ctx *c, x265amd_mc_list *l)
+{
+    if (!c) return X265AMD_EINVAL;
+    if (!l) return X265AMD_OK;
     HIPCHK(c, hipSetDevice(c->device));
-    int rc;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    hipError_t e = hipFree(l->d_blob);
+    delete l;
+    HIPCHK(c, e);
+    return X265AMD_OK;
+}
+
+int x265amd_mc_batch_dev(x265amd_ctx *c, const void *d_ref_planes, const x265amd_picture *pred, const x265amd_mc_list *l)
+{
+    if (!c || !d_ref_planes || !pred || !pred->y.origin || !pred->cb.origin || !pred->cr.origin || !l)
+        return fail(c, X265AMD_EINVAL, "null argument");
+    if (!l->njobs) return X265AMD_OK;
+    HIPCHK(c, hipSetDevice(c->device));
+    return mc_launch(c, d_ref_planes, pred, l->d_blob, l);
+}
+
+int x265amd_mc_batch(x265amd_ctx *c, const x265amd_picture *refs, int nrefs, const x265amd_picture *pred,
+                     const x265amd_mc_job *jobs, int njobs)
+{
+    int rc = mc_validate(c, refs, nrefs, pred, jobs, njobs);
+    if (rc) return rc;
+    if (!njobs) return X265AMD_OK;
+    HIPCHK(c, hipSetDevice(c->device));
     PlaneDev hp[96];
     for (int i = 0; i < nrefs; i++)
     {
@@ -1710,11 +1790,14 @@ int x265amd_mc_batch(x265amd_ctx *c, const x265amd_picture *refs, int nrefs, con
         hp[3 * i + 1].origin = refs[i].cb.origin; hp[3 * i + 1].stride = refs[i].cb.stride;
         hp[3 * i + 2].origin = refs[i].cr.origin; hp[3 * i + 2].stride = refs[i].cr.stride;
     }
-    const size_t jb = (size_t)njobs * sizeof(x265amd_mc_job), pb = sizeof(PlaneDev) * 96;
-    if ((rc = ensure(c, &c->d_jobs, &c->jobs_cap, jb + pb))) return rc;
+    x265amd_mc_list l;
+    std::vector<char> blob;
+    mc_plan(jobs, njobs, blob, &l);
+    const size_t pb = sizeof(PlaneDev) * 96;
+    if ((rc = ensure(c, &c->d_jobs, &c->jobs_cap, pb + blob.size()))) return rc;
     HIPCHK(c, hipMemcpyAsync(c->d_jobs, hp, sizeof(PlaneDev) * 3 * nrefs, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, hipMemcpyAsync((char*)c->d_jobs + pb, jobs, jb, hipMemcpyHostToDevice, c->stream));
-    if ((rc = x265amd_mc_batch_dev(c, c->d_jobs, pred, (const x265amd_mc_job*)((char*)c->d_jobs + pb), njobs))) return rc;
+    HIPCHK(c, hipMemcpyAsync((char*)c->d_jobs + pb, blob.data(), blob.size(), hipMemcpyHostToDevice, c->stream));
+    if ((rc = mc_launch(c, c->d_jobs, pred, (char*)c->d_jobs + pb, &l))) return rc;
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return X265AMD_OK;
 }

@@ -743,10 +743,13 @@ __global__ __launch_bounds__(64) void merge_sa8d_kernel(MergeArgs a)
 
 /* ---- motion compensation into a prediction picture, luma + 4:2:0 chroma ----
  * TComPrediction::motionCompensation without weighted prediction (TComPrediction.cpp:201-286).
- * One wave per PU, a lane per 4x4 luma tile (looping above 64 tiles); the lane also owns the 2x2
- * block of Cb and of Cr under its tile (chroma blocks of every HEVC partition are even-sized).
- * All samples are interpolated in registers from global memory and stored once; phases are
- * uniform over the wave, so no branch diverges. */
+ * The unit of work is a 4x4 luma tile together with the 2x2 block of Cb and of Cr under it (chroma
+ * blocks of every HEVC partition are even-sized). The tiles of all PUs of a launch are numbered
+ * consecutively (PU j owns tiles [first[j], first[j+1])); a wave takes 64 consecutive tiles, whatever
+ * PUs they belong to, so 8x8 PUs fill a wave as well as 64x64 ones do. The host supplies first[] and,
+ * per wave, the PU its first tile belongs to; the lanes find their own PU from the 64 entries of
+ * first[] that follow (a flag per tile where a PU starts, one ballot, a bit count).
+ * All samples are interpolated in registers from global memory and stored once. */
 __constant__ static const int16_t kChromaTaps[8][4] = {        /* g_chromaFilter, TComRom.cpp:183-193 */
     {  0, 64,  0,  0 }, { -2, 58, 10, -2 }, { -4, 54, 16, -2 }, { -6, 46, 28, -4 },
     { -4, 36, 36, -4 }, { -4, 28, 46, -6 }, { -2, 16, 54, -4 }, { -2, 10, 58, -2 } };
@@ -755,8 +758,10 @@ struct McArgs
 {
     const PlaneDev *refs;      /* device array: Y, Cb, Cr of each reference picture */
     PlaneDev pred[3];
-    int depth, njobs;
+    int depth, njobs, nchunks;
     const x265amd_mc_job *jobs;
+    const int32_t *first;      /* njobs + 64 entries: first tile of each PU, then the tile total repeated */
+    const int32_t *chunk_job;  /* nchunks entries: the PU that tile 64 * k belongs to */
 };
 
 /* One 2x2 chroma block of xPredInterChromaBlk at eighth-pel MV (ex, ey); `r` is the block's own
@@ -851,20 +856,36 @@ template<> struct PxStore<uint16_t>
 template<typename P>
 __global__ __launch_bounds__(64) void mc_kernel(McArgs a)
 {
-    const int j = blockIdx.x;
-    if (j >= a.njobs) return;
-    const x265amd_mc_job *job = a.jobs + j;
+    __shared__ int32_t starts[64];
+    __shared__ int32_t flags[64];
+    const int k = xcd_remap(blockIdx.x, a.nchunks);
+    if (k >= a.nchunks) return;
     const int lane = threadIdx.x & 63;
-    const int w = uni(job->w), h = uni(job->h), dir = uni(job->dir), flags = uni(job->flags);
-    const int pux = uni(job->pu_x), puy = uni(job->pu_y);
-    const int m0x = uni(job->mv0[0]), m0y = uni(job->mv0[1]), m1x = uni(job->mv1[0]), m1y = uni(job->mv1[1]);
-    const PlaneDev *p0 = a.refs + 3 * uni(job->ref0), *p1 = a.refs + 3 * uni(job->ref1);
-    const int wt = w >> 2, T = wt * (h >> 2);
+    const int j0 = uni(a.chunk_job[k]), g = 64 * k + lane;
+    const int my_start = a.first[j0 + lane];
+    starts[lane] = my_start;
+    flags[lane] = 0;
+    wave_sync();
+    /* PU j0 holds tile 64 k, so the PUs after it start inside (64 k, ...) */
+    if (lane > 0 && (unsigned)(my_start - 64 * k) < 64u) flags[my_start - 64 * k] = 1;
+    wave_sync();
+    const int f = flags[lane];
+    const unsigned long long m = __ballot(f);
+    const int off = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0)) + f;
+    const int j = j0 + off;
+    if (j >= a.njobs) return;                 /* tiles past the last PU (only in the last wave) */
+    const int t = g - starts[off];
+    const x265amd_mc_job *job = a.jobs + j;
+    const int w = job->w, dir = job->dir, flags_lc = job->flags;
+    const int pux = job->pu_x, puy = job->pu_y;
+    const int m0x = job->mv0[0], m0y = job->mv0[1], m1x = job->mv1[0], m1y = job->mv1[1];
+    const PlaneDev *p0 = a.refs + 3 * job->ref0, *p1 = a.refs + 3 * job->ref1;
+    const int wt = w >> 2;
     const int maxv = (1 << a.depth) - 1;
     /* TComYuv::addAvg, TComYuv.cpp:596-606 and :616-650 */
     const int shiftNum = 15 - a.depth, offset = (1 << (shiftNum - 1)) + 2 * 8192;
-    for (int t = lane; t < T; t += 64)
     {
+        const int flags = flags_lc;
         const int ty = t / wt, tx = t - ty * wt;
         if (flags & 1)
         {

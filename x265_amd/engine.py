@@ -409,8 +409,19 @@ class Engine:
         self._chk(self.L.x265amd_pictures_upload(self.ctx, (Picture * len(refs))(*refs), len(refs), C.byref(d)))
         return d.value
 
-    def mc_batch_dev(self, d_ref_planes, pred, d_jobs, njobs):
-        self._chk(self.L.x265amd_mc_batch_dev(self.ctx, C.c_void_p(d_ref_planes), C.byref(pred), C.c_void_p(d_jobs), njobs))
+    def mc_list_create(self, refs, pred, jobs):
+        """Checks the jobs against the pictures, numbers their tiles and uploads them; returns the list handle."""
+        jobs = np.ascontiguousarray(jobs, MC_JOB_DTYPE)
+        h = C.c_void_p()
+        self._chk(self.L.x265amd_mc_list_create(self.ctx, (Picture * len(refs))(*refs), len(refs), C.byref(pred),
+                                                C.c_void_p(jobs.ctypes.data), len(jobs), C.byref(h)))
+        return h
+
+    def mc_list_free(self, h):
+        self._chk(self.L.x265amd_mc_list_free(self.ctx, h))
+
+    def mc_batch_dev(self, d_ref_planes, pred, mc_list):
+        self._chk(self.L.x265amd_mc_batch_dev(self.ctx, C.c_void_p(d_ref_planes), C.byref(pred), mc_list))
 
     # ---- Rockchip path
     def rk_ds_plane(self, orig):
