@@ -316,31 +316,46 @@ int x265amd_merge_sa8d_batch(x265amd_ctx *ctx, const x265amd_plane *fenc, const 
  * bChroma. The luma quarter-pel MV addresses chroma in eighth-pel units (:496, :504-505). The caller
  * has clipped the MVs (TComDataCU::clipMv) and turned identical motion of both lists into dir 1
  * (xCheckIdenticalMotion, :183-198). PUs of one call must not overlap (they never do inside a frame's
- * final partitioning); weighted prediction (:212-226, :334-376) is not covered. */
+ * final partitioning).
+ * flags bit 2 = explicit weighted prediction for this PU (PPS getUseWP / getWPBiPred): every used list
+ * goes through the 14-bit flavour, then xWeightedPredictionUni (:212-226, :357-376; addWeightUni with
+ * weight_sp, Lib/TLibCommon/TComWeightPrediction.cpp:433-485) or xWeightedPredictionBi (:334-356;
+ * addWeightBi, TComWeightPrediction.cpp:203-313) with the parameters getWpScaling derives (:534-560)
+ * from the `weights` entry of each reference picture. */
 typedef struct
 {
     int16_t pu_x, pu_y;        /* luma position, a multiple of 4 */
     uint8_t w, h;              /* an HEVC luma partition, not 4x4 */
     uint8_t dir;               /* 1 = list 0, 2 = list 1, 3 = both */
-    uint8_t flags;             /* 1 = luma, 2 = chroma, 3 = both */
+    uint8_t flags;             /* 1 = luma, 2 = chroma, 3 = both; + 4 = weighted */
     uint8_t ref0, ref1;        /* indices into `refs` */
     uint8_t reserved[2];
     int16_t mv0[2], mv1[2];    /* quarter-pel */
 } x265amd_mc_job;
 /* A 4:2:0 picture resident in device memory (TComPicYuv): cb / cr are half size in both directions */
 typedef struct { x265amd_plane y, cb, cr; } x265amd_picture;
-/* refs: nrefs (<= 32) reconstructed reference pictures; pred: the output picture (margins may be 0);
- * jobs: HOST array. Returns when the prediction samples are in `pred`. */
-int x265amd_mc_batch(x265amd_ctx *ctx, const x265amd_picture *refs, int nrefs, const x265amd_picture *pred,
-                     const x265amd_mc_job *jobs, int njobs);
+/* wpScalingParam of one reference picture per component Y, Cb, Cr (Lib/TLibCommon/TComSlice.h:
+ * inputWeight, inputOffset at 8-bit scale, log2WeightDenom 0..7). A picture used with different weights
+ * in the two lists is listed twice in `refs`. */
+typedef struct
+{
+    int16_t w[3], offset[3];
+    uint8_t log2denom[3], reserved;
+} x265amd_mc_weight;
+/* refs: nrefs (<= 32) reconstructed reference pictures; weights: nrefs entries, or NULL when no job is
+ * weighted; pred: the output picture (margins may be 0); jobs: HOST array. Returns when the prediction
+ * samples are in `pred`. */
+int x265amd_mc_batch(x265amd_ctx *ctx, const x265amd_picture *refs, const x265amd_mc_weight *weights, int nrefs,
+                     const x265amd_picture *pred, const x265amd_mc_job *jobs, int njobs);
 /* Device-resident variant, asynchronous on the engine's stream. x265amd_pictures_upload puts the plane
- * descriptors of `refs` on the device (free with x265amd_device_free); x265amd_mc_list_create checks the
+ * descriptors and weights of `refs` on the device (free with x265amd_device_free); x265amd_mc_list_create checks the
  * jobs as x265amd_mc_batch does, numbers their 4x4 tiles for the launch and uploads both (a list can be
  * launched any number of times, e.g. one list per frame); x265amd_mc_batch_dev only launches. */
 typedef struct x265amd_mc_list x265amd_mc_list;
-int x265amd_pictures_upload(x265amd_ctx *ctx, const x265amd_picture *refs, int nrefs, void **d_ref_planes);
-int x265amd_mc_list_create(x265amd_ctx *ctx, const x265amd_picture *refs, int nrefs, const x265amd_picture *pred,
-                           const x265amd_mc_job *jobs, int njobs, x265amd_mc_list **out);
+int x265amd_pictures_upload(x265amd_ctx *ctx, const x265amd_picture *refs, const x265amd_mc_weight *weights, int nrefs,
+                            void **d_ref_planes);
+int x265amd_mc_list_create(x265amd_ctx *ctx, const x265amd_picture *refs, const x265amd_mc_weight *weights, int nrefs,
+                           const x265amd_picture *pred, const x265amd_mc_job *jobs, int njobs, x265amd_mc_list **out);
 int x265amd_mc_list_free(x265amd_ctx *ctx, x265amd_mc_list *list);
 int x265amd_mc_batch_dev(x265amd_ctx *ctx, const void *d_ref_planes, const x265amd_picture *pred, const x265amd_mc_list *list);
 

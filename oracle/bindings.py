@@ -63,6 +63,8 @@ assert MERGE_JOB_DTYPE.itemsize == 16
 MC_JOB_DTYPE = np.dtype([("pu_x", "<i2"), ("pu_y", "<i2"), ("w", "u1"), ("h", "u1"), ("dir", "u1"), ("flags", "u1"),
                          ("ref0", "u1"), ("ref1", "u1"), ("reserved", "u1", (2,)), ("mv0", "<i2", (2,)), ("mv1", "<i2", (2,))], align=True)
 assert MC_JOB_DTYPE.itemsize == 20
+MC_WEIGHT_DTYPE = np.dtype([("w", "<i2", (3,)), ("offset", "<i2", (3,)), ("log2denom", "u1", (3,)), ("reserved", "u1")], align=True)
+assert MC_WEIGHT_DTYPE.itemsize == 16
 
 
 def build_oracle():
@@ -260,15 +262,17 @@ class Oracle:
         self.L.orc_merge_sa8d_batch(depth, _p(fenc, origin), C.c_ssize_t(stride), ptrs, strides, _p(jobs), len(jobs), _p(out))
         return out
 
-    def mc_batch(self, depth, refs, pred, jobs):
+    def mc_batch(self, depth, refs, pred, jobs, weights=None):
         """Motion compensation of MC_JOB_DTYPE records. refs: list of pictures, a picture = [(buf, origin, stride)] * 3 for
-        Y, Cb, Cr (both chroma planes share a geometry); pred: one such picture, written in place."""
+        Y, Cb, Cr (both chroma planes share a geometry); pred: one such picture, written in place; weights: one
+        MC_WEIGHT_DTYPE record per reference picture, for jobs with flags bit 2."""
         jobs = np.ascontiguousarray(jobs, MC_JOB_DTYPE)
+        wts = None if weights is None else np.ascontiguousarray(weights, MC_WEIGHT_DTYPE)
         planes = (C.c_void_p * (3 * len(refs)))(*[b.ctypes.data + o * b.itemsize for pic in refs for (b, o, _) in pic])
         strides = (C.c_ssize_t * (2 * len(refs)))(*[pic[k][2] for pic in refs for k in (0, 1)])
         pp = (C.c_void_p * 3)(*[b.ctypes.data + o * b.itemsize for (b, o, _) in pred])
         ps = (C.c_ssize_t * 2)(pred[0][2], pred[1][2])
-        self.L.orc_mc_batch(depth, planes, strides, pp, ps, _p(jobs), len(jobs))
+        self.L.orc_mc_batch(depth, planes, strides, None if wts is None else _p(wts), pp, ps, _p(jobs), len(jobs))
 
 
 def ref_available(depth=8):
@@ -526,8 +530,10 @@ class Ref:
                                            _p(refs[int(j["ref1"])], off), C.c_ssize_t(stride), int(j["size"]), int(j["dir"]), mv0, mv1)
         return out
 
-    def mc_batch(self, refs, pred, jobs):
+    def mc_batch(self, refs, pred, jobs, weights=None):
         """TComPrediction::motionCompensation's primitive calls per PU (ref_mc_pu); arguments as Oracle.mc_batch."""
+        wts = None if weights is None else np.ascontiguousarray(weights, MC_WEIGHT_DTYPE)
+        wp = lambda r: None if wts is None else _p(wts, r)
         def at(pic, px, py):
             ptrs = [pic[0][0].ctypes.data + (pic[0][1] + py * pic[0][2] + px) * pic[0][0].itemsize]
             for k in (1, 2):
@@ -540,4 +546,5 @@ class Ref:
             pd, sd = at(pred, px, py)
             mv0 = (C.c_int16 * 2)(int(j["mv0"][0]), int(j["mv0"][1]))
             mv1 = (C.c_int16 * 2)(int(j["mv1"][0]), int(j["mv1"][1]))
-            self.L.ref_mc_pu(p0, s0, p1, s1, pd, sd, int(j["w"]), int(j["h"]), int(j["dir"]), int(j["flags"]), mv0, mv1)
+            self.L.ref_mc_pu(p0, s0, p1, s1, pd, sd, int(j["w"]), int(j["h"]), int(j["dir"]), int(j["flags"]), mv0, mv1,
+                             wp(int(j["ref0"])), wp(int(j["ref1"])))

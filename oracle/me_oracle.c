@@ -389,19 +389,20 @@ void orc_merge_sa8d_batch(int depth, const void *fenc, intptr_t fstride, const v
 }
 
 
-void orc_mc_batch(int depth, const void *const *ref_planes, const intptr_t *ref_strides, void *const pred[3],
-                  const intptr_t pred_strides[2], const orc_mc_job *jobs, int n)
+void orc_mc_batch(int depth, const void *const *ref_planes, const intptr_t *ref_strides, const orc_mc_weight *weights,
+                  void *const pred[3], const intptr_t pred_strides[2], const orc_mc_job *jobs, int n)
 {
     for (int i = 0; i < n; i++)
     {
         const orc_mc_job *j = jobs + i;
         const void *const *p0 = ref_planes + 3 * j->ref0, *const *p1 = ref_planes + 3 * j->ref1;
         const intptr_t *s0 = ref_strides + 2 * j->ref0, *s1 = ref_strides + 2 * j->ref1;
+        const orc_mc_weight *w0 = weights ? weights + j->ref0 : 0, *w1 = weights ? weights + j->ref1 : 0;
         if (depth <= 8)
             mc_pu_8((const uint8_t *const *)p0, s0, (const uint8_t *const *)p1, s1, (uint8_t *const *)pred, pred_strides,
-                    j->pu_x, j->pu_y, j->w, j->h, depth, j->dir, j->flags, j->mv0[0], j->mv0[1], j->mv1[0], j->mv1[1]);
+                    j->pu_x, j->pu_y, j->w, j->h, depth, j->dir, j->flags, j->mv0[0], j->mv0[1], j->mv1[0], j->mv1[1], w0, w1);
         else
             mc_pu_16((const uint16_t *const *)p0, s0, (const uint16_t *const *)p1, s1, (uint16_t *const *)pred, pred_strides,
-                     j->pu_x, j->pu_y, j->w, j->h, depth, j->dir, j->flags, j->mv0[0], j->mv0[1], j->mv1[0], j->mv1[1]);
+                     j->pu_x, j->pu_y, j->w, j->h, depth, j->dir, j->flags, j->mv0[0], j->mv0[1], j->mv1[0], j->mv1[1], w0, w1);
     }
 }

@@ -179,8 +179,12 @@ void orc_merge_sa8d_batch(int depth, const void *fenc, intptr_t fstride, const v
  * pred / pred_strides likewise for the output picture. Job layout = x265amd_mc_job; flags bit 0 =
  * bLuma, bit 1 = bChroma; dir 1 / 2 / 3 = list 0, list 1, both. */
 typedef struct { int16_t pu_x, pu_y; uint8_t w, h, dir, flags, ref0, ref1, reserved[2]; int16_t mv0[2], mv1[2]; } orc_mc_job;
-void orc_mc_batch(int depth, const void *const *ref_planes, const intptr_t *ref_strides, void *const pred[3],
-                  const intptr_t pred_strides[2], const orc_mc_job *jobs, int n);
+/* explicit weights of one reference picture per component (wpScalingParam inputWeight, inputOffset at 8-bit scale,
+ * log2WeightDenom; TComSlice.h:1260-1290); layout = x265amd_mc_weight. Used by jobs with flags bit 2 (weights may be
+ * NULL when no job has it): TComWeightPrediction.cpp:203-313, :433-485, :534-560. */
+typedef struct { int16_t w[3], offset[3]; uint8_t log2denom[3], reserved; } orc_mc_weight;
+void orc_mc_batch(int depth, const void *const *ref_planes, const intptr_t *ref_strides, const orc_mc_weight *weights,
+                  void *const pred[3], const intptr_t pred_strides[2], const orc_mc_job *jobs, int n);
 
 #ifdef __cplusplus
 }

@@ -1497,24 +1497,59 @@ static void FN(add_avg)(const int16_t *s0, const int16_t *s1, int pitch, int w, 
         }
 }
 
-/* TComPrediction::motionCompensation of one PU without weighted prediction (TComPrediction.cpp:
- * 201-286): dir 1 / 2 = xPredInterUni into the prediction picture, 3 = xPredInterBi's first branch
- * (both lists into TShortYUV, then addAvg). planes: [0] luma, [1] Cb, [2] Cr of the two references
+/* TComWeightPrediction::addWeightUni on a 14-bit block (TComWeightPrediction.cpp:433-485 with weight_sp_c,
+ * pixel.cpp:494-510) and addWeightBi (:203-313, :46-54); the parameters are getWpScaling's (:534-560) */
+static void FN(add_weight)(const int16_t *s0, const int16_t *s1, int pitch, int w, int h, int depth, const orc_mc_weight *wp0,
+                           const orc_mc_weight *wp1, int comp, PIXEL *dst, intptr_t ds)
+{
+    const int maxv = (1 << depth) - 1, shiftNum = 14 - depth;
+    if (!s1)
+    {
+        const int w0 = wp0->w[comp], offset = wp0->offset[comp] * (1 << (depth - 8)), shift = wp0->log2denom[comp] + shiftNum;
+        const int round = shift ? (1 << (shift - 1)) : 0;
+        for (int y = 0; y < h; y++)
+            for (int x = 0; x < w; x++)
+            {
+                const int v = ((w0 * (s0[y * pitch + x] + 8192) + round) >> shift) + offset;
+                dst[y * ds + x] = (PIXEL)(v < 0 ? 0 : (v > maxv ? maxv : v));
+            }
+        return;
+    }
+    const int w0 = wp0->w[comp], w1 = wp1->w[comp];
+    const int offset = (wp0->offset[comp] + wp1->offset[comp]) * (1 << (depth - 8));
+    const int shift = wp0->log2denom[comp] + 1 + shiftNum, round = 1 << (shift - 1);
+    for (int y = 0; y < h; y++)
+        for (int x = 0; x < w; x++)
+        {
+            const int v = (w0 * (s0[y * pitch + x] + 8192) + w1 * (s1[y * pitch + x] + 8192) + round + offset * (1 << (shift - 1))) >> shift;
+            dst[y * ds + x] = (PIXEL)(v < 0 ? 0 : (v > maxv ? maxv : v));
+        }
+}
+
+/* TComPrediction::motionCompensation of one PU (TComPrediction.cpp:201-286). Without weights: dir 1 / 2 =
+ * xPredInterUni into the prediction picture, 3 = xPredInterBi's first branch (both lists into TShortYUV,
+ * then addAvg). With weights (flags bit 2; getUseWP / getWPBiPred): every used list goes through the
+ * 14-bit flavour, then xWeightedPredictionUni (:212-226) or xWeightedPredictionBi (:334-356).
+ * planes: [0] luma, [1] Cb, [2] Cr of the two references
  * and of the prediction picture, all as origins; the PU sits at (px, py) luma samples. */
 static void FN(mc_pu)(const PIXEL *const r0[3], const intptr_t r0s[2], const PIXEL *const r1[3], const intptr_t r1s[2],
                       PIXEL *const pred[3], const intptr_t ps[2], int px, int py, int w, int h, int depth, int dir, int flags,
-                      int mv0x, int mv0y, int mv1x, int mv1y)
+                      int mv0x, int mv0y, int mv1x, int mv1y, const orc_mc_weight *wp0, const orc_mc_weight *wp1)
 {
     const int cw = w >> 1, ch = h >> 1, cx = px >> 1, cy = py >> 1;
+    const int weighted = flags & 4;
     if (flags & 1)
     {
         PIXEL *d = pred[0] + (intptr_t)py * ps[0] + px;
-        if (dir == 3)
+        if (dir == 3 || weighted)
         {
             int16_t s0[64 * 64], s1[64 * 64];
-            FN(mc_short)(r0[0] + (intptr_t)py * r0s[0] + px, r0s[0], mv0x, mv0y, w, h, depth, s0);
-            FN(mc_short)(r1[0] + (intptr_t)py * r1s[0] + px, r1s[0], mv1x, mv1y, w, h, depth, s1);
-            FN(add_avg)(s0, s1, 64, w, h, depth, d, ps[0]);
+            if (dir & 1) FN(mc_short)(r0[0] + (intptr_t)py * r0s[0] + px, r0s[0], mv0x, mv0y, w, h, depth, s0);
+            if (dir & 2) FN(mc_short)(r1[0] + (intptr_t)py * r1s[0] + px, r1s[0], mv1x, mv1y, w, h, depth, s1);
+            if (!weighted) FN(add_avg)(s0, s1, 64, w, h, depth, d, ps[0]);
+            else if (dir == 3) FN(add_weight)(s0, s1, 64, w, h, depth, wp0, wp1, 0, d, ps[0]);
+            else if (dir == 1) FN(add_weight)(s0, 0, 64, w, h, depth, wp0, 0, 0, d, ps[0]);
+            else FN(add_weight)(s1, 0, 64, w, h, depth, wp1, 0, 0, d, ps[0]);
         }
         else
         {
@@ -1528,12 +1563,15 @@ static void FN(mc_pu)(const PIXEL *const r0[3], const intptr_t r0s[2], const PIX
         for (int c = 1; c < 3; c++)
         {
             PIXEL *d = pred[c] + (intptr_t)cy * ps[1] + cx;
-            if (dir == 3)
+            if (dir == 3 || weighted)
             {
                 int16_t s0[32 * 32], s1[32 * 32];
-                FN(mc_chroma_short)(r0[c] + (intptr_t)cy * r0s[1] + cx, r0s[1], mv0x, mv0y, cw, ch, depth, s0);
-                FN(mc_chroma_short)(r1[c] + (intptr_t)cy * r1s[1] + cx, r1s[1], mv1x, mv1y, cw, ch, depth, s1);
-                FN(add_avg)(s0, s1, 32, cw, ch, depth, d, ps[1]);
+                if (dir & 1) FN(mc_chroma_short)(r0[c] + (intptr_t)cy * r0s[1] + cx, r0s[1], mv0x, mv0y, cw, ch, depth, s0);
+                if (dir & 2) FN(mc_chroma_short)(r1[c] + (intptr_t)cy * r1s[1] + cx, r1s[1], mv1x, mv1y, cw, ch, depth, s1);
+                if (!weighted) FN(add_avg)(s0, s1, 32, cw, ch, depth, d, ps[1]);
+                else if (dir == 3) FN(add_weight)(s0, s1, 32, cw, ch, depth, wp0, wp1, c, d, ps[1]);
+                else if (dir == 1) FN(add_weight)(s0, 0, 32, cw, ch, depth, wp0, 0, c, d, ps[1]);
+                else FN(add_weight)(s1, 0, 32, cw, ch, depth, wp1, 0, c, d, ps[1]);
             }
             else if (dir == 1) FN(mc_chroma)(r0[c] + (intptr_t)cy * r0s[1] + cx, r0s[1], mv0x, mv0y, cw, ch, depth, d, ps[1]);
             else FN(mc_chroma)(r1[c] + (intptr_t)cy * r1s[1] + cx, r1s[1], mv1x, mv1y, cw, ch, depth, d, ps[1]);

@@ -730,19 +730,58 @@ static void harness_add_avg(const int16_t *s0, const int16_t *s1, int pitch, int
         }
 }
 
+/* addWeightBi on two 14-bit blocks (TComWeightPrediction.cpp:203-313; weightBidirY / weightBidirC :46-54 are
+ * file-static there, so the expression is repeated) with getWpScaling's bi-directional parameters (:534-549) */
+static void harness_add_weight_bi(const int16_t *s0, const int16_t *s1, int pitch, int w, int h, int w0, int w1, int offset, int shift,
+                                  pixel *dst, intptr_t dstStride)
+{
+    const int round = shift ? (1 << (shift - 1)) : 0;
+    const int maxv = (1 << X265_DEPTH) - 1;
+    for (int y = 0; y < h; y++)
+        for (int x = 0; x < w; x++)
+        {
+            int v = (w0 * (s0[y * pitch + x] + IF_INTERNAL_OFFS) + w1 * (s1[y * pitch + x] + IF_INTERNAL_OFFS) + round + (offset << (shift - 1))) >> shift;
+            dst[y * dstStride + x] = (pixel)(v < 0 ? 0 : (v > maxv ? maxv : v));
+        }
+}
+
+struct HarnessWeight { int16_t w[3], offset[3]; uint8_t log2denom[3], reserved; };
+
+/* one component of xWeightedPredictionUni / xWeightedPredictionBi on 14-bit blocks: the uni-directional case through
+ * the reference's weight_sp primitive as addWeightUni calls it (:433-485) */
+static void harness_weight(int16_t *s0, int16_t *s1, int pitch, int w, int h, int dir, const HarnessWeight *wp0, const HarnessWeight *wp1,
+                           int comp, pixel *dst, intptr_t dstStride)
+{
+    const int shiftNum = IF_INTERNAL_PREC - X265_DEPTH;
+    if (dir == 3)
+        harness_add_weight_bi(s0, s1, pitch, w, h, wp0->w[comp], wp1->w[comp],
+                              wp0->offset[comp] * (1 << (X265_DEPTH - 8)) + wp1->offset[comp] * (1 << (X265_DEPTH - 8)),
+                              wp0->log2denom[comp] + 1 + shiftNum, dst, dstStride);
+    else
+    {
+        const HarnessWeight *wp = dir == 1 ? wp0 : wp1;
+        const int shift = wp->log2denom[comp] + shiftNum, round = shift ? (1 << (shift - 1)) : 0;
+        primitives.weight_sp(dir == 1 ? s0 : s1, dst, pitch, dstStride, w, h, wp->w[comp], round, shift,
+                             wp->offset[comp] * (1 << (X265_DEPTH - 8)));
+    }
+}
+
 void ref_mc_pu(pixel **ref0, const intptr_t *ref0Strides, pixel **ref1, const intptr_t *ref1Strides, pixel **pred,
-               const intptr_t *predStrides, int w, int h, int dir, int flags, const int16_t *mv0, const int16_t *mv1)
+               const intptr_t *predStrides, int w, int h, int dir, int flags, const int16_t *mv0, const int16_t *mv1,
+               const HarnessWeight *wp0, const HarnessWeight *wp1)
 {
     const int part = partitionFromSizes(w, h), cw = w >> 1, ch = h >> 1;
+    const bool weighted = (flags & 4) != 0;
     int16_t *immed = (int16_t*)malloc(sizeof(int16_t) * 64 * (64 + 8));
     int16_t *s0 = (int16_t*)malloc(sizeof(int16_t) * 64 * 64 * 2), *s1 = s0 + 64 * 64;
     if (flags & 1)
     {
-        if (dir == 3)
+        if (dir == 3 || weighted)
         {
-            harness_pred_luma_short(ref0[0], ref0Strides[0], mv0[0], mv0[1], part, w, h, s0, immed);
-            harness_pred_luma_short(ref1[0], ref1Strides[0], mv1[0], mv1[1], part, w, h, s1, immed);
-            harness_add_avg(s0, s1, MAX_CU_SIZE, w, h, pred[0], predStrides[0]);
+            if (dir & 1) harness_pred_luma_short(ref0[0], ref0Strides[0], mv0[0], mv0[1], part, w, h, s0, immed);
+            if (dir & 2) harness_pred_luma_short(ref1[0], ref1Strides[0], mv1[0], mv1[1], part, w, h, s1, immed);
+            if (weighted) harness_weight(s0, s1, MAX_CU_SIZE, w, h, dir, wp0, wp1, 0, pred[0], predStrides[0]);
+            else harness_add_avg(s0, s1, MAX_CU_SIZE, w, h, pred[0], predStrides[0]);
         }
         else if (dir == 1) harness_pred_luma(ref0[0], ref0Strides[0], mv0[0], mv0[1], part, w, pred[0], predStrides[0], immed);
         else harness_pred_luma(ref1[0], ref1Strides[0], mv1[0], mv1[1], part, w, pred[0], predStrides[0], immed);
@@ -750,11 +789,12 @@ void ref_mc_pu(pixel **ref0, const intptr_t *ref0Strides, pixel **ref1, const in
     if (flags & 2)
         for (int c = 1; c < 3; c++)
         {
-            if (dir == 3)
+            if (dir == 3 || weighted)
             {
-                harness_pred_chroma_short(ref0[c], ref0Strides[1], mv0[0], mv0[1], part, cw, ch, s0, immed);
-                harness_pred_chroma_short(ref1[c], ref1Strides[1], mv1[0], mv1[1], part, cw, ch, s1, immed);
-                harness_add_avg(s0, s1, MAX_CU_SIZE / 2, cw, ch, pred[c], predStrides[1]);
+                if (dir & 1) harness_pred_chroma_short(ref0[c], ref0Strides[1], mv0[0], mv0[1], part, cw, ch, s0, immed);
+                if (dir & 2) harness_pred_chroma_short(ref1[c], ref1Strides[1], mv1[0], mv1[1], part, cw, ch, s1, immed);
+                if (weighted) harness_weight(s0, s1, MAX_CU_SIZE / 2, cw, ch, dir, wp0, wp1, c, pred[c], predStrides[1]);
+                else harness_add_avg(s0, s1, MAX_CU_SIZE / 2, cw, ch, pred[c], predStrides[1]);
             }
             else if (dir == 1) harness_pred_chroma(ref0[c], ref0Strides[1], mv0[0], mv0[1], part, cw, ch, pred[c], predStrides[1], immed);
             else harness_pred_chroma(ref1[c], ref1Strides[1], mv1[0], mv1[1], part, cw, ch, pred[c], predStrides[1], immed);

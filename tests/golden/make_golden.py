@@ -326,11 +326,16 @@ def make_merge(shas):
     np.savez_compressed(os.path.join(HERE, "merge_golden.npz"), **out)
 
 
-def mc_case(depth):
-    """(reference pictures, job batches) of the motion-compensation vectors: pictures as [(buffer, origin, stride)] * 3."""
-    from oracle.bindings import MC_JOB_DTYPE
-    from util import mc_pictures, mc_job_batches
-    return mc_pictures(depth, 31, nrefs=3), mc_job_batches(np.random.default_rng(32), MC_JOB_DTYPE, 14, nrefs=3)
+def mc_case(depth, weighted=False):
+    """(reference pictures, job batches, weights) of the motion-compensation vectors: pictures as [(buffer, origin,
+    stride)] * 3; the weighted set mixes explicit weighted prediction (flags bit 2) into three PUs of four."""
+    from oracle.bindings import MC_JOB_DTYPE, MC_WEIGHT_DTYPE
+    from util import mc_pictures, mc_job_batches, mc_weights
+    if not weighted:
+        return mc_pictures(depth, 31, nrefs=3), mc_job_batches(np.random.default_rng(32), MC_JOB_DTYPE, 14, nrefs=3), None
+    rng = np.random.default_rng(34)
+    return (mc_pictures(depth, 33, nrefs=3), mc_job_batches(rng, MC_JOB_DTYPE, 14, nrefs=3, weighted=True),
+            mc_weights(rng, MC_WEIGHT_DTYPE, 3))
 
 
 def make_mc(shas):
@@ -339,14 +344,16 @@ def make_mc(shas):
     from util import mc_blank_pred
     out = {}
     for depth in (8, 10):
-        refs, batches = mc_case(depth)
-        shas["mc_%d" % depth] = [sha(pl[0]) for pic in refs for pl in pic] + [sha(np.concatenate(batches))]
-        digests = []
-        for jobs in batches:
-            pred = mc_blank_pred(depth)
-            Ref(depth).mc_batch(refs, pred, jobs)
-            digests.append([np.frombuffer(bytes.fromhex(sha(pl[0])), np.uint8) for pl in pred])
-        out["%d" % depth] = np.array(digests, np.uint8)
+        for weighted in (False, True):
+            refs, batches, wts = mc_case(depth, weighted)
+            key = "%d%s" % (depth, "w" if weighted else "")
+            shas["mc_" + key] = [sha(pl[0]) for pic in refs for pl in pic] + [sha(np.concatenate(batches))] + ([sha(wts)] if weighted else [])
+            digests = []
+            for jobs in batches:
+                pred = mc_blank_pred(depth)
+                Ref(depth).mc_batch(refs, pred, jobs, wts)
+                digests.append([np.frombuffer(bytes.fromhex(sha(pl[0])), np.uint8) for pl in pred])
+            out[key] = np.array(digests, np.uint8)
     np.savez_compressed(os.path.join(HERE, "mc_golden.npz"), **out)
 
 

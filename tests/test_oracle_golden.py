@@ -173,16 +173,18 @@ def test_merge_sa8d(oracle, depth):
     assert np.array_equal(oracle.merge_sa8d_batch(depth, f, refs, org, stride, jobs), G.merge_golden()[depth])
 
 
+@pytest.mark.parametrize("weighted", [False, True])
 @pytest.mark.parametrize("depth", [8, 10])
-def test_motion_compensation(oracle, depth):
+def test_motion_compensation(oracle, depth, weighted):
     """Luma + chroma prediction pictures of the oracle vs the digests recorded from the reference's primitives."""
     from util import mc_blank_pred
-    refs, batches = G.mc_case(depth)
-    assert [G.sha(pl[0]) for pic in refs for pl in pic] + [G.sha(np.concatenate(batches))] == G.input_shas()["mc_%d" % depth]
-    exp = G.mc_golden()[depth]
+    refs, batches, wts = G.mc_case(depth, weighted)
+    key = "%d%s" % (depth, "w" if weighted else "")
+    assert [G.sha(pl[0]) for pic in refs for pl in pic] + [G.sha(np.concatenate(batches))] + ([G.sha(wts)] if weighted else []) \
+        == G.input_shas()["mc_" + key]
+    exp = G.mc_golden()[key]
     for b, jobs in enumerate(batches):
         pred = mc_blank_pred(depth)
-        oracle.mc_batch(depth, refs, pred, jobs)
+        oracle.mc_batch(depth, refs, pred, jobs, wts)
         for k in range(3):
             assert np.array_equal(G.sha_bytes(pred[k][0]), exp[b, k]), "batch %d plane %d" % (b, k)
-

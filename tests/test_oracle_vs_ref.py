@@ -297,3 +297,20 @@ def test_motion_compensation_vs_reference(oracle, ref):
             assert np.array_equal(a[k][0], b[k][0]), "plane %d" % k
         assert (a[0][0] != 0x5A).any()
 
+
+def test_weighted_motion_compensation_vs_reference(oracle, ref):
+    """The weighted flavours (xWeightedPredictionUni through the reference's weight_sp, xWeightedPredictionBi) mixed with
+    unweighted PUs in the same batches."""
+    from oracle.bindings import MC_JOB_DTYPE, MC_WEIGHT_DTYPE
+    from util import mc_pictures, mc_blank_pred, mc_job_batches, mc_weights
+    depth = ref.depth
+    refs = mc_pictures(depth, 23)
+    rng = np.random.default_rng(24)
+    for jobs in mc_job_batches(rng, MC_JOB_DTYPE, 26, weighted=True):
+        wts = mc_weights(rng, MC_WEIGHT_DTYPE, 2)
+        a, b = mc_blank_pred(depth), mc_blank_pred(depth)
+        ref.mc_batch(refs, a, jobs, wts)
+        oracle.mc_batch(depth, refs, b, jobs, wts)
+        for k in range(3):
+            assert np.array_equal(a[k][0], b[k][0]), "plane %d" % k
+

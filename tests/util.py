@@ -107,7 +107,22 @@ def mc_blank_pred(depth, fill=0x5A):
             (np.full(MC_W * MC_H // 4, fill, dt), 0, MC_W // 2)]
 
 
-def mc_job_batches(rng, dtype, nbatches, nrefs=2):
+def mc_weights(rng, dtype, nrefs):
+    """Explicit weights per reference picture and component: denominators 0..7, weights on both sides of 1.0 (a few
+    negative), offsets over the whole signed 8-bit range."""
+    wts = np.zeros(nrefs, dtype)
+    for r in wts:
+        den = rng.integers(0, 8, 3)
+        den[2] = den[1]
+        r["log2denom"] = den
+        r["w"] = [int(np.clip(round((1 << int(d)) * rng.uniform(0.4, 1.8)), -128, 127)) for d in den]
+        if rng.random() < 0.25:
+            r["w"][int(rng.integers(0, 3))] *= -1
+        r["offset"] = rng.integers(-128, 128, 3)
+    return wts
+
+
+def mc_job_batches(rng, dtype, nbatches, nrefs=2, weighted=False):
     """Batches of non-overlapping PUs (one per 64x64 cell, at a random multiple of 4 inside it): every partition, the three
     directions, luma-only / chroma-only / both, and all 64 eighth-pel chroma fraction pairs many times over."""
     parts = PARTITIONS[1:]
@@ -121,7 +136,7 @@ def mc_job_batches(rng, dtype, nbatches, nrefs=2):
             j["pu_y"] = cy * 64 + int(rng.integers(0, (64 - h) // 4 + 1)) * 4
             j["w"], j["h"] = w, h
             j["dir"] = 1 + k % 3
-            j["flags"] = (3, 3, 3, 1, 2)[(k // 3) % 5]
+            j["flags"] = (3, 3, 3, 1, 2)[(k // 3) % 5] | (4 if weighted and k % 4 else 0)
             j["ref0"], j["ref1"] = k % nrefs, (k // nrefs) % nrefs
             mv0, mv1 = rng.integers(-150, 151, 2), rng.integers(-150, 151, 2)
             # walk the 8 x 8 fraction pairs of list 0; list 1 runs through them at another pace

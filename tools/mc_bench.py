@@ -93,7 +93,7 @@ def main():
             jobs["dir"], jobs["flags"], jobs["ref0"], jobs["ref1"] = dir_, 3, 0, 1
             jobs["mv0"] = rng.integers(-64, 65, (len(jobs), 2))
             jobs["mv1"] = rng.integers(-64, 65, (len(jobs), 2))
-            lst = e.mc_list_create(dpics, dpred, jobs)
+            lst = e.mc_list_create(dpics, dpred, jobs)  # unweighted
             e.mc_batch_dev(d_planes, dpred, lst)
             e.sync()
             if not args.no_check and size in (8, 64):

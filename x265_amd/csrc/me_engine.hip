@@ -1616,23 +1616,39 @@ int x265amd_merge_sa8d_batch(x265amd_ctx *c, const x265amd_plane *fenc, const x2
 
 /* ---- motion compensation ---- */
 
-int x265amd_pictures_upload(x265amd_ctx *c, const x265amd_picture *refs, int nrefs, void **d_ref_planes)
+static int mc_ref_table(x265amd_ctx *c, const x265amd_picture *refs, const x265amd_mc_weight *weights, int nrefs, McRef *hp)
 {
-    if (!c || !refs || nrefs <= 0 || nrefs > 32 || !d_ref_planes) return fail(c, X265AMD_EINVAL, "null argument");
-    PlaneDev hp[96];
+    memset(hp, 0, sizeof(McRef) * nrefs);
     for (int i = 0; i < nrefs; i++)
     {
         const x265amd_plane *pl[3] = { &refs[i].y, &refs[i].cb, &refs[i].cr };
         for (int k = 0; k < 3; k++)
         {
             if (!pl[k]->origin) return fail(c, X265AMD_EINVAL, "picture: null plane");
-            hp[3 * i + k].origin = pl[k]->origin; hp[3 * i + k].stride = pl[k]->stride;
+            hp[i].pl[k].origin = pl[k]->origin; hp[i].pl[k].stride = pl[k]->stride;
+        }
+        if (weights)
+        {
+            for (int k = 0; k < 3; k++)
+                if (weights[i].log2denom[k] > 7 || weights[i].w[k] < -128 || weights[i].w[k] > 255 || weights[i].offset[k] < -128 ||
+                    weights[i].offset[k] > 127)
+                    return fail(c, X265AMD_EINVAL, "weight: log2denom is 0..7, weight -128..255, offset -128..127");
+            hp[i].wp = weights[i];
         }
     }
+    return X265AMD_OK;
+}
+
+int x265amd_pictures_upload(x265amd_ctx *c, const x265amd_picture *refs, const x265amd_mc_weight *weights, int nrefs, void **d_ref_planes)
+{
+    if (!c || !refs || nrefs <= 0 || nrefs > 32 || !d_ref_planes) return fail(c, X265AMD_EINVAL, "null argument");
+    McRef hp[32];
+    int rc = mc_ref_table(c, refs, weights, nrefs, hp);
+    if (rc) return rc;
     HIPCHK(c, hipSetDevice(c->device));
     void *d = 0;
-    HIPCHK(c, hipMalloc(&d, sizeof(PlaneDev) * 3 * nrefs));
-    hipError_t e = hipMemcpyAsync(d, hp, sizeof(PlaneDev) * 3 * nrefs, hipMemcpyHostToDevice, c->stream);
+    HIPCHK(c, hipMalloc(&d, sizeof(McRef) * nrefs));
+    hipError_t e = hipMemcpyAsync(d, hp, sizeof(McRef) * nrefs, hipMemcpyHostToDevice, c->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
     if (e != hipSuccess) { (void)hipFree(d); HIPCHK(c, e); }
     *d_ref_planes = d;
@@ -1646,8 +1662,8 @@ struct x265amd_mc_list
     int njobs, nchunks;
 };
 
-static int mc_validate(x265amd_ctx *c, const x265amd_picture *refs, int nrefs, const x265amd_picture *pred,
-                       const x265amd_mc_job *jobs, int njobs)
+static int mc_validate(x265amd_ctx *c, const x265amd_picture *refs, const x265amd_mc_weight *weights, int nrefs,
+                       const x265amd_picture *pred, const x265amd_mc_job *jobs, int njobs)
 {
     if (!c || !refs || nrefs <= 0 || nrefs > 32 || !pred || !jobs || njobs < 0) return fail(c, X265AMD_EINVAL, "null argument");
     if (!pred->y.origin || !pred->cb.origin || !pred->cr.origin) return fail(c, X265AMD_EINVAL, "null prediction plane");
@@ -1657,8 +1673,9 @@ static int mc_validate(x265amd_ctx *c, const x265amd_picture *refs, int nrefs, c
     {
         const x265amd_mc_job &j = jobs[i];
         if (x265amd_partition_from_sizes(j.w, j.h) < 1) return fail(c, X265AMD_EINVAL, "job: not a luma partition above 4x4");
-        if (j.dir < 1 || j.dir > 3 || !(j.flags & 3) || j.ref0 >= nrefs || j.ref1 >= nrefs)
+        if (j.dir < 1 || j.dir > 3 || !(j.flags & 3) || (j.flags & ~7) || j.ref0 >= nrefs || j.ref1 >= nrefs)
             return fail(c, X265AMD_EINVAL, "job: bad direction, flags or reference index");
+        if ((j.flags & 4) && !weights) return fail(c, X265AMD_EINVAL, "job: weighted, but no weights were given");
         if (j.pu_x < 0 || j.pu_y < 0 || (j.pu_x & 3) || (j.pu_y & 3)) return fail(c, X265AMD_EINVAL, "job: PU position must be a multiple of 4");
         if (((j.flags & 1) && (j.pu_x + j.w > pred->y.width || j.pu_y + j.h > pred->y.height)) ||
             ((j.flags & 2) && ((j.pu_x + j.w) / 2 > pred->cb.width || (j.pu_y + j.h) / 2 > pred->cb.height ||
@@ -1718,7 +1735,7 @@ static void mc_plan(const x265amd_mc_job *jobs, int njobs, std::vector<char> &bl
 static int mc_launch(x265amd_ctx *c, const void *d_ref_planes, const x265amd_picture *pred, const void *d_blob, const x265amd_mc_list *l)
 {
     McArgs a;
-    a.refs = (const PlaneDev*)d_ref_planes;
+    a.refs = (const McRef*)d_ref_planes;
     a.pred[0].origin = pred->y.origin; a.pred[0].stride = pred->y.stride;
     a.pred[1].origin = pred->cb.origin; a.pred[1].stride = pred->cb.stride;
     a.pred[2].origin = pred->cr.origin; a.pred[2].stride = pred->cr.stride;
@@ -1732,11 +1749,11 @@ static int mc_launch(x265amd_ctx *c, const void *d_ref_planes, const x265amd_pic
     return X265AMD_OK;
 }
 
-int x265amd_mc_list_create(x265amd_ctx *c, const x265amd_picture *refs, int nrefs, const x265amd_picture *pred,
-                           const x265amd_mc_job *jobs, int njobs, x265amd_mc_list **out)
+int x265amd_mc_list_create(x265amd_ctx *c, const x265amd_picture *refs, const x265amd_mc_weight *weights, int nrefs,
+                           const x265amd_picture *pred, const x265amd_mc_job *jobs, int njobs, x265amd_mc_list **out)
 {
     if (!out) return fail(c, X265AMD_EINVAL, "null argument");
-    int rc = mc_validate(c, refs, nrefs, pred, jobs, njobs);
+    int rc = mc_validate(c, refs, weights, nrefs, pred, jobs, njobs);
     if (rc) return rc;
     x265amd_mc_list *l = new x265amd_mc_list();
     std::vector<char> blob;
@@ -1776,26 +1793,21 @@ int x265amd_mc_batch_dev(x265amd_ctx *c, const void *d_ref_planes, const x265amd
     return mc_launch(c, d_ref_planes, pred, l->d_blob, l);
 }
 
-int x265amd_mc_batch(x265amd_ctx *c, const x265amd_picture *refs, int nrefs, const x265amd_picture *pred,
-                     const x265amd_mc_job *jobs, int njobs)
+int x265amd_mc_batch(x265amd_ctx *c, const x265amd_picture *refs, const x265amd_mc_weight *weights, int nrefs,
+                     const x265amd_picture *pred, const x265amd_mc_job *jobs, int njobs)
 {
-    int rc = mc_validate(c, refs, nrefs, pred, jobs, njobs);
+    int rc = mc_validate(c, refs, weights, nrefs, pred, jobs, njobs);
     if (rc) return rc;
     if (!njobs) return X265AMD_OK;
+    McRef hp[32];
+    if ((rc = mc_ref_table(c, refs, weights, nrefs, hp))) return rc;
     HIPCHK(c, hipSetDevice(c->device));
-    PlaneDev hp[96];
-    for (int i = 0; i < nrefs; i++)
-    {
-        hp[3 * i].origin = refs[i].y.origin; hp[3 * i].stride = refs[i].y.stride;
-        hp[3 * i + 1].origin = refs[i].cb.origin; hp[3 * i + 1].stride = refs[i].cb.stride;
-        hp[3 * i + 2].origin = refs[i].cr.origin; hp[3 * i + 2].stride = refs[i].cr.stride;
-    }
     x265amd_mc_list l;
     std::vector<char> blob;
     mc_plan(jobs, njobs, blob, &l);
-    const size_t pb = sizeof(PlaneDev) * 96;
+    const size_t pb = sizeof(McRef) * 32;
     if ((rc = ensure(c, &c->d_jobs, &c->jobs_cap, pb + blob.size()))) return rc;
-    HIPCHK(c, hipMemcpyAsync(c->d_jobs, hp, sizeof(PlaneDev) * 3 * nrefs, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->d_jobs, hp, sizeof(McRef) * nrefs, hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipMemcpyAsync((char*)c->d_jobs + pb, blob.data(), blob.size(), hipMemcpyHostToDevice, c->stream));
     if ((rc = mc_launch(c, c->d_jobs, pred, (char*)c->d_jobs + pb, &l))) return rc;
     HIPCHK(c, hipStreamSynchronize(c->stream));

@@ -754,9 +754,15 @@ __constant__ static const int16_t kChromaTaps[8][4] = {        /* g_chromaFilter
     {  0, 64,  0,  0 }, { -2, 58, 10, -2 }, { -4, 54, 16, -2 }, { -6, 46, 28, -4 },
     { -4, 36, 36, -4 }, { -4, 28, 46, -6 }, { -2, 16, 54, -4 }, { -2, 10, 58, -2 } };
 
+struct McRef                   /* one reference picture: Y, Cb, Cr planes and its explicit weights */
+{
+    PlaneDev pl[3];
+    x265amd_mc_weight wp;
+};
+
 struct McArgs
 {
-    const PlaneDev *refs;      /* device array: Y, Cb, Cr of each reference picture */
+    const McRef *refs;         /* device array, one entry per reference picture */
     PlaneDev pred[3];
     int depth, njobs, nchunks;
     const x265amd_mc_job *jobs;
@@ -824,6 +830,41 @@ __device__ __forceinline__ void chroma_block(const P AS1 *r, int stride, int ex,
         }
 }
 
+/* Parameters of explicit weighted prediction for one component, as getWpScaling derives them
+ * (TComWeightPrediction.cpp:534-560), and the sample formulas weightUnidir / weightBidir (:46-64) */
+struct McWeights
+{
+    int w0, w1, shift, round, offset;
+    __device__ __forceinline__ int apply(int s0, int s1, int dir, int maxv) const
+    {
+        int v;
+        if (dir == 3) v = (w0 * (s0 + 8192) + w1 * (s1 + 8192) + round + offset) >> shift;
+        else v = ((w0 * ((dir == 1 ? s0 : s1) + 8192) + round) >> shift) + offset;
+        return v < 0 ? 0 : (v > maxv ? maxv : v);
+    }
+};
+__device__ __forceinline__ McWeights mc_weights(const x265amd_mc_weight &a, const x265amd_mc_weight &b, int comp, int dir, int depth)
+{
+    McWeights W;
+    const int scale = 1 << (depth - 8), shiftNum = 14 - depth;
+    if (dir == 3)
+    {
+        W.w0 = a.w[comp]; W.w1 = b.w[comp];
+        W.shift = a.log2denom[comp] + 1 + shiftNum;
+        W.round = 1 << (W.shift - 1);
+        W.offset = (a.offset[comp] + b.offset[comp]) * scale * (1 << (W.shift - 1));   /* added before the shift */
+    }
+    else
+    {
+        const x265amd_mc_weight &u = dir == 1 ? a : b;
+        W.w0 = W.w1 = u.w[comp];
+        W.shift = u.log2denom[comp] + shiftNum;
+        W.round = W.shift ? 1 << (W.shift - 1) : 0;
+        W.offset = u.offset[comp] * scale;                                              /* added after the shift */
+    }
+    return W;
+}
+
 template<typename P> struct PxStore;
 template<> struct PxStore<uint8_t>
 {
@@ -879,8 +920,9 @@ __global__ __launch_bounds__(64) void mc_kernel(McArgs a)
     const int w = job->w, dir = job->dir, flags_lc = job->flags;
     const int pux = job->pu_x, puy = job->pu_y;
     const int m0x = job->mv0[0], m0y = job->mv0[1], m1x = job->mv1[0], m1y = job->mv1[1];
-    const PlaneDev *p0 = a.refs + 3 * job->ref0, *p1 = a.refs + 3 * job->ref1;
+    const McRef *p0 = a.refs + job->ref0, *p1 = a.refs + job->ref1;
     const int wt = w >> 2;
+    const bool weighted = (flags_lc & 4) != 0;
     const int maxv = (1 << a.depth) - 1;
     /* TComYuv::addAvg, TComYuv.cpp:596-606 and :616-650 */
     const int shiftNum = 15 - a.depth, offset = (1 << (shiftNum - 1)) + 2 * 8192;
@@ -889,12 +931,23 @@ __global__ __launch_bounds__(64) void mc_kernel(McArgs a)
         const int ty = t / wt, tx = t - ty * wt;
         if (flags & 1)
         {
-            const PlaneDev r0 = p0[0], r1 = p1[0];
+            const PlaneDev r0 = p0->pl[0], r1 = p1->pl[0];
             const int x = pux + 4 * tx, y = puy + 4 * ty;
             const P AS1 *s0 = (const P AS1*)r0.origin + (long)y * r0.stride + x;
             const P AS1 *s1 = (const P AS1*)r1.origin + (long)y * r1.stride + x;
             int p[4][4];
-            if (dir == 3)
+            if (weighted)
+            {
+                const McWeights W = mc_weights(p0->wp, p1->wp, 0, dir, a.depth);
+                int q[4][4];
+                if (dir & 1) mc_short_tile<P>(s0, r0.stride, m0x, m0y, a.depth, p);
+                if (dir & 2) mc_short_tile<P>(s1, r1.stride, m1x, m1y, a.depth, q);
+#pragma unroll
+                for (int yy = 0; yy < 4; yy++)
+#pragma unroll
+                    for (int xx = 0; xx < 4; xx++) p[yy][xx] = W.apply(p[yy][xx], q[yy][xx], dir, maxv);
+            }
+            else if (dir == 3)
             {
                 int q[4][4];
                 mc_short_tile<P>(s0, r0.stride, m0x, m0y, a.depth, p);
@@ -920,11 +973,22 @@ __global__ __launch_bounds__(64) void mc_kernel(McArgs a)
 #pragma unroll 1
             for (int c = 1; c < 3; c++)
             {
-                const PlaneDev r0 = p0[c], r1 = p1[c];
+                const PlaneDev r0 = p0->pl[c], r1 = p1->pl[c];
                 const P AS1 *s0 = (const P AS1*)r0.origin + (long)y * r0.stride + x;
                 const P AS1 *s1 = (const P AS1*)r1.origin + (long)y * r1.stride + x;
                 int p[2][2];
-                if (dir == 3)
+                if (weighted)
+                {
+                    const McWeights W = mc_weights(p0->wp, p1->wp, c, dir, a.depth);
+                    int q[2][2];
+                    if (dir & 1) chroma_block<P, true>(s0, r0.stride, m0x, m0y, a.depth, p);
+                    if (dir & 2) chroma_block<P, true>(s1, r1.stride, m1x, m1y, a.depth, q);
+#pragma unroll
+                    for (int yy = 0; yy < 2; yy++)
+#pragma unroll
+                        for (int xx = 0; xx < 2; xx++) p[yy][xx] = W.apply(p[yy][xx], q[yy][xx], dir, maxv);
+                }
+                else if (dir == 3)
                 {
                     int q[2][2];
                     chroma_block<P, true>(s0, r0.stride, m0x, m0y, a.depth, p);

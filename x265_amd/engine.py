@@ -46,6 +46,8 @@ assert MERGE_JOB_DTYPE.itemsize == 16
 MC_JOB_DTYPE = np.dtype([("pu_x", "<i2"), ("pu_y", "<i2"), ("w", "u1"), ("h", "u1"), ("dir", "u1"), ("flags", "u1"),
                          ("ref0", "u1"), ("ref1", "u1"), ("reserved", "u1", (2,)), ("mv0", "<i2", (2,)), ("mv1", "<i2", (2,))], align=True)
 assert MC_JOB_DTYPE.itemsize == 20
+MC_WEIGHT_DTYPE = np.dtype([("w", "<i2", (3,)), ("offset", "<i2", (3,)), ("log2denom", "u1", (3,)), ("reserved", "u1")], align=True)
+assert MC_WEIGHT_DTYPE.itemsize == 16
 BIPRED_RESULT_DTYPE = np.dtype([("satd", "<i4"), ("satd_zero", "<i4")], align=True)
 assert BIPRED_JOB_DTYPE.itemsize == 16 and BIPRED_RESULT_DTYPE.itemsize == 8
 
@@ -398,22 +400,34 @@ class Engine:
         for p in (pic.y, pic.cb, pic.cr):
             self.free_plane(p)
 
-    def mc_batch(self, refs, pred, jobs):
-        """TComPrediction::motionCompensation for MC_JOB_DTYPE records: refs = list of Picture, pred = output Picture."""
+    @staticmethod
+    def _weights(weights, nrefs):
+        if weights is None:
+            return None, None
+        w = np.ascontiguousarray(weights, MC_WEIGHT_DTYPE)
+        assert len(w) == nrefs
+        return w, C.c_void_p(w.ctypes.data)
+
+    def mc_batch(self, refs, pred, jobs, weights=None):
+        """TComPrediction::motionCompensation for MC_JOB_DTYPE records: refs = list of Picture, pred = output Picture,
+        weights = one MC_WEIGHT_DTYPE record per reference (for jobs with flags bit 2)."""
         jobs = np.ascontiguousarray(jobs, MC_JOB_DTYPE)
-        self._chk(self.L.x265amd_mc_batch(self.ctx, (Picture * len(refs))(*refs), len(refs), C.byref(pred),
+        keep, wp = self._weights(weights, len(refs))
+        self._chk(self.L.x265amd_mc_batch(self.ctx, (Picture * len(refs))(*refs), wp, len(refs), C.byref(pred),
                                           C.c_void_p(jobs.ctypes.data), len(jobs)))
 
-    def pictures_upload(self, refs):
+    def pictures_upload(self, refs, weights=None):
         d = C.c_void_p()
-        self._chk(self.L.x265amd_pictures_upload(self.ctx, (Picture * len(refs))(*refs), len(refs), C.byref(d)))
+        keep, wp = self._weights(weights, len(refs))
+        self._chk(self.L.x265amd_pictures_upload(self.ctx, (Picture * len(refs))(*refs), wp, len(refs), C.byref(d)))
         return d.value
 
-    def mc_list_create(self, refs, pred, jobs):
+    def mc_list_create(self, refs, pred, jobs, weights=None):
         """Checks the jobs against the pictures, numbers their tiles and uploads them; returns the list handle."""
         jobs = np.ascontiguousarray(jobs, MC_JOB_DTYPE)
         h = C.c_void_p()
-        self._chk(self.L.x265amd_mc_list_create(self.ctx, (Picture * len(refs))(*refs), len(refs), C.byref(pred),
+        keep, wp = self._weights(weights, len(refs))
+        self._chk(self.L.x265amd_mc_list_create(self.ctx, (Picture * len(refs))(*refs), wp, len(refs), C.byref(pred),
                                                 C.c_void_p(jobs.ctypes.data), len(jobs), C.byref(h)))
         return h
 
