@@ -283,6 +283,7 @@ def main():
                         "ms_intra_bidir_choice": m["ms_costs"],
                         "frame_costs_per_s": m["frames"] / (m["ms_search"] + m["ms_costs"]) * 1e3,
                         "searched_cus_per_s": m["fields"] * m["cus"] / (m["ms_search"] * 1e-3)}
+                mc = measure.mc_picture(es, dev)
                 e10 = Engine(local_rank, 10)
                 m10 = measure.pattern_search_picture(e10, dev)
                 e10.close()
@@ -300,6 +301,12 @@ def main():
                                "bound": "valu", "peak": measure.SAD_ISSUE_PEAK / 1e9,
                                "frac": px / (ms * 1e-3) / measure.SAD_ISSUE_PEAK,
                                "per_pu_size_ms": {str(r["size"]): r["ms"] for r in rows}},
+                    "mc_4k": {"workload": "3840x2160 8-bit TComPrediction::motionCompensation of every PU of a picture (mixed quadtree "
+                                          "partitioning, luma + 4:2:0 chroma, random quarter-pel MVs), device-resident job list",
+                              "bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                              **{k: {"ms_per_picture": v["ms"], "pus": v["pus"], "achieved": v["algorithmic_bytes"] / v["ms"] / 1e6,
+                                     "frac": v["algorithmic_bytes"] / v["ms"] / 1e6 / HBM_PEAK_GBS,
+                                     "Gsample_per_s": v["samples"] / v["ms"] / 1e6} for k, v in mc.items()}},
                     "rk_1080p": {"workload": "1920x1080 8-bit, Rockchip rd>=5 path: CIME + RIME + FME of all 510 CTUs (85 CUs each) "
                                              "against one reference, default RK range",
                                  "ms_per_picture_reference": rk["ms"], "ctus_per_s": rk["ctus"] / (rk["ms"] * 1e-3),

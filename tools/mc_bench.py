@@ -17,41 +17,6 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 
-def mixed_partition(rng, W, H, dtype):
-    """A frame's final partitioning as mode decision leaves it: every 64x64 CTU split at random down the quadtree, leaf CUs
-    as 2Nx2N, 2NxN, Nx2N or an asymmetric pair."""
-    pus = []
-
-    def leaf(x, y, s):
-        m = int(rng.integers(0, 6)) if s > 8 else int(rng.integers(0, 3))
-        if m == 0 or m > 4:
-            pus.append((x, y, s, s))
-        elif m == 1:
-            pus.extend([(x, y, s, s // 2), (x, y + s // 2, s, s // 2)])
-        elif m == 2:
-            pus.extend([(x, y, s // 2, s), (x + s // 2, y, s // 2, s)])
-        elif m == 3:
-            pus.extend([(x, y, s, s // 4), (x, y + s // 4, s, 3 * s // 4)])
-        else:
-            pus.extend([(x, y, 3 * s // 4, s), (x + 3 * s // 4, y, s // 4, s)])
-
-    def cu(x, y, s):
-        if s > 8 and rng.random() < 0.55:
-            for dy in (0, s // 2):
-                for dx in (0, s // 2):
-                    cu(x + dx, y + dy, s // 2)
-        else:
-            leaf(x, y, s)
-
-    for y in range(0, H - 63, 64):
-        for x in range(0, W - 63, 64):
-            cu(x, y, 64)
-    jobs = np.zeros(len(pus), dtype)
-    a = np.array(pus)
-    jobs["pu_x"], jobs["pu_y"], jobs["w"], jobs["h"] = a[:, 0], a[:, 1], a[:, 2], a[:, 3]
-    return jobs
-
-
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--width", type=int, default=1920)
@@ -63,6 +28,7 @@ def main():
     import torch
     from x265_amd.engine import Engine, MC_JOB_DTYPE, Picture
     from x265_amd.synth import make_clip, make_chroma, pad_plane
+    from x265_amd.measure import mixed_partition
     dev = torch.device("cuda", 0)
     e = Engine(0, args.depth)
     W, H, M = args.width, args.height, 304

@@ -188,3 +188,77 @@ def pattern_search_picture(e, dev, width=3840, height=2160, depth=10, method="st
     for p in planes:
         e.free_plane(p)
     return {"ms": ms, "pus": n, "pixel_sads": workload.pixel_sads(jobs, res), "jobs": jobs, "results": res}
+
+
+def mixed_partition(rng, W, H, dtype):
+    """A frame's final partitioning as mode decision leaves it: every 64x64 CTU split at random down the quadtree, leaf CUs
+    as 2Nx2N, 2NxN, Nx2N or an asymmetric pair."""
+    pus = []
+
+    def leaf(x, y, s):
+        m = int(rng.integers(0, 6)) if s > 8 else int(rng.integers(0, 3))
+        if m == 0 or m > 4:
+            pus.append((x, y, s, s))
+        elif m == 1:
+            pus.extend([(x, y, s, s // 2), (x, y + s // 2, s, s // 2)])
+        elif m == 2:
+            pus.extend([(x, y, s // 2, s), (x + s // 2, y, s // 2, s)])
+        elif m == 3:
+            pus.extend([(x, y, s, s // 4), (x, y + s // 4, s, 3 * s // 4)])
+        else:
+            pus.extend([(x, y, 3 * s // 4, s), (x + 3 * s // 4, y, s // 4, s)])
+
+    def cu(x, y, s):
+        if s > 8 and rng.random() < 0.55:
+            for dy in (0, s // 2):
+                for dx in (0, s // 2):
+                    cu(x + dx, y + dy, s // 2)
+        else:
+            leaf(x, y, s)
+
+    for y in range(0, H - 63, 64):
+        for x in range(0, W - 63, 64):
+            cu(x, y, 64)
+    jobs = np.zeros(len(pus), dtype)
+    a = np.array(pus)
+    jobs["pu_x"], jobs["pu_y"], jobs["w"], jobs["h"] = a[:, 0], a[:, 1], a[:, 2], a[:, 3]
+    return jobs
+
+
+def mc_picture(e, dev, width=3840, height=2160, reps=10, seed=5):
+    """TComPrediction::motionCompensation of every PU of one picture (a mixed quadtree partitioning, luma + 4:2:0 chroma,
+    random quarter-pel MVs) from device-resident pictures and job lists; uni- and bi-predicted."""
+    import torch
+    from .engine import MC_JOB_DTYPE
+    from .synth import make_chroma
+    W, H, M = width, height, 304
+    bpp = 1 if e.depth <= 8 else 2
+    ys = make_clip(W, H, 2, seed=seed, depth=e.depth)
+    cbs, crs = make_chroma(W, H, 2, seed=seed, depth=e.depth)
+    dims = ((W, H, M), (W // 2, H // 2, M // 2), (W // 2, H // 2, M // 2))
+    dpics = []
+    for i in range(2):
+        planes = [pad_plane(ys[i], M), pad_plane(cbs[i], M // 2), pad_plane(crs[i], M // 2)]
+        dpics.append(e.upload_picture([(b, o, s, w, h, m) for (b, o, s), (w, h, m) in zip(planes, dims)]))
+    dpred = e.upload_picture([(np.zeros(w * h, e.dtype), 0, w, w, h, 0) for (w, h, _) in dims])
+    d_planes = e.pictures_upload(dpics)
+    rng = np.random.default_rng(seed)
+    out = {}
+    for name, dir_ in (("uni", 1), ("bi", 3)):
+        jobs = mixed_partition(rng, W, H, MC_JOB_DTYPE)
+        jobs["dir"], jobs["flags"], jobs["ref0"], jobs["ref1"] = dir_, 3, 0, 1
+        jobs["mv0"] = rng.integers(-64, 65, (len(jobs), 2))
+        jobs["mv1"] = rng.integers(-64, 65, (len(jobs), 2))
+        lst = e.mc_list_create(dpics, dpred, jobs)
+        ms = _timed(torch, e, dev, lambda: e.mc_batch_dev(d_planes, dpred, lst), reps)
+        e.mc_list_free(lst)
+        jw, jh = jobs["w"].astype(np.int64), jobs["h"].astype(np.int64)
+        lists = 2 if dir_ == 3 else 1
+        nbytes = int((bpp * (lists * ((jw + 7) * (jh + 7) + 2 * (jw // 2 + 3) * (jh // 2 + 3)) + jw * jh * 3 // 2)).sum())
+        out[name] = {"ms": ms, "pus": len(jobs), "algorithmic_bytes": nbytes, "samples": int((jw * jh).sum()) * 3 // 2}
+    e.device_free(d_planes)
+    e.free_picture(dpred)
+    for p_ in dpics:
+        e.free_picture(p_)
+    return out
+
