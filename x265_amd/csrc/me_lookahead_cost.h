@@ -831,38 +831,230 @@ __device__ __forceinline__ void chroma_block(const P AS1 *r, int stride, int ex,
 }
 
 /* Parameters of explicit weighted prediction for one component, as getWpScaling derives them
- * (TComWeightPrediction.cpp:534-560), and the sample formulas weightUnidir / weightBidir (:46-64) */
+ * (TComWeightPrediction.cpp:534-560), and the sample formulas weightUnidir / weightBidir (:46-64).
+ * Samples are the 14-bit intermediates (value - 8192); `bias` adds the 8192 back. With weights (1, 1),
+ * bias 0 and round = 1 << (shift - 1) the two-list formula is TComYuv::addAvg's, whose offset
+ * 2 * 8192 stands for the same bias. */
 struct McWeights
 {
-    int w0, w1, shift, round, offset;
-    __device__ __forceinline__ int apply(int s0, int s1, int dir, int maxv) const
+    int w0, w1, shift, round, offset, bias;
+    __device__ __forceinline__ int apply(int s0, int s1, bool two, int maxv) const
     {
         int v;
-        if (dir == 3) v = (w0 * (s0 + 8192) + w1 * (s1 + 8192) + round + offset) >> shift;
-        else v = ((w0 * ((dir == 1 ? s0 : s1) + 8192) + round) >> shift) + offset;
+        if (two) v = (w0 * (s0 + bias) + w1 * (s1 + bias) + round + offset) >> shift;
+        else v = ((w0 * (s0 + bias) + round) >> shift) + offset;
         return v < 0 ? 0 : (v > maxv ? maxv : v);
     }
 };
-__device__ __forceinline__ McWeights mc_weights(const x265amd_mc_weight &a, const x265amd_mc_weight &b, int comp, int dir, int depth)
+/* a: the weights of list A (the only list, or list 0), b: of list 1 */
+__device__ __forceinline__ McWeights mc_weights(const x265amd_mc_weight &a, const x265amd_mc_weight &b, int comp, bool two, int depth)
 {
     McWeights W;
     const int scale = 1 << (depth - 8), shiftNum = 14 - depth;
-    if (dir == 3)
+    W.bias = 8192;
+    W.w0 = a.w[comp]; W.w1 = b.w[comp];
+    if (two)
     {
-        W.w0 = a.w[comp]; W.w1 = b.w[comp];
         W.shift = a.log2denom[comp] + 1 + shiftNum;
         W.round = 1 << (W.shift - 1);
         W.offset = (a.offset[comp] + b.offset[comp]) * scale * (1 << (W.shift - 1));   /* added before the shift */
     }
     else
     {
-        const x265amd_mc_weight &u = dir == 1 ? a : b;
-        W.w0 = W.w1 = u.w[comp];
-        W.shift = u.log2denom[comp] + shiftNum;
+        W.shift = a.log2denom[comp] + shiftNum;
         W.round = W.shift ? 1 << (W.shift - 1) : 0;
-        W.offset = u.offset[comp] * scale;                                              /* added after the shift */
+        W.offset = a.offset[comp] * scale;                                              /* added after the shift */
     }
     return W;
+}
+
+/* N consecutive samples starting at p, as one wide load (any alignment) */
+template<typename P, int N> struct RowLoad;
+typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x3_t __attribute__((ext_vector_type(3)));
+typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+template<> struct RowLoad<uint8_t, 12>
+{
+    u32x3_t v;
+    __device__ __forceinline__ void load(const uint8_t AS1 *p) { typedef u32x3_t __attribute__((aligned(1))) T; v = *(const T AS1*)p; }
+    __device__ __forceinline__ void zero() { v = (u32x3_t)(0u); }
+    __device__ __forceinline__ int px(int i) const { return (int)((v[i >> 2] >> (8 * (i & 3))) & 0xff); }
+};
+template<> struct RowLoad<uint8_t, 8>
+{
+    u32x2_t v;
+    __device__ __forceinline__ void load(const uint8_t AS1 *p) { typedef u32x2_t __attribute__((aligned(1))) T; v = *(const T AS1*)p; }
+    __device__ __forceinline__ void zero() { v = (u32x2_t)(0u); }
+    __device__ __forceinline__ int px(int i) const { return (int)((v[i >> 2] >> (8 * (i & 3))) & 0xff); }
+};
+template<> struct RowLoad<uint16_t, 12>
+{
+    u32x4_t lo; u32x2_t hi;
+    __device__ __forceinline__ void load(const uint16_t AS1 *p)
+    {
+        typedef u32x4_t __attribute__((aligned(2))) T4;
+        typedef u32x2_t __attribute__((aligned(2))) T2;
+        lo = *(const T4 AS1*)p; hi = *(const T2 AS1*)(p + 8);
+    }
+    __device__ __forceinline__ void zero() { lo = (u32x4_t)(0u); hi = (u32x2_t)(0u); }
+    __device__ __forceinline__ int px(int i) const { const uint32_t d = i < 8 ? lo[i >> 1] : hi[(i - 8) >> 1]; return (int)((d >> (16 * (i & 1))) & 0xffff); }
+};
+template<> struct RowLoad<uint16_t, 8>        /* six samples are enough for the chroma footprint */
+{
+    u32x3_t v;
+    __device__ __forceinline__ void load(const uint16_t AS1 *p) { typedef u32x3_t __attribute__((aligned(2))) T; v = *(const T AS1*)p; }
+    __device__ __forceinline__ void zero() { v = (u32x3_t)(0u); }
+    __device__ __forceinline__ int px(int i) const { return (int)((v[i >> 1] >> (16 * (i & 1))) & 0xffff); }
+};
+
+/* Predictions of one tile from one list: luma 4x4, Cb and Cr 2x2 */
+struct McTile
+{
+    int y[4][4], c[2][2][2];
+};
+
+/* xPredInterLumaBlk + xPredInterChromaBlk for one tile and one list (TComPrediction.cpp:405-593), pixel flavour or
+ * (inter14) 14-bit flavour, chosen per lane. Every row the filters can touch is fetched first -- one wide load per row,
+ * apron rows only where the vertical phase needs them -- so the loads of a tile are all in flight together; then the
+ * separable filters run on registers. Phases differ between lanes, so the formulas are selected, not branched:
+ *   H = sum of 8 (4) taps over the row; with a zero horizontal phase the row sample itself is used instead
+ *   no vertical phase:  pixel = clip((H + 32) >> 6) or the sample;   14-bit = (H + offH) >> shiftH
+ *   vertical phase on samples (xf = 0): pixel = clip((V + 32) >> 6); 14-bit = (V + offH) >> shiftH
+ *   vertical phase on intermediates:    pixel = clip((V + offV) >> shiftV); 14-bit = V >> 6
+ * each through the reference's int16 cast (ipfilter.cpp:40-172, :194-435). */
+template<typename P>
+__device__ __forceinline__ void mc_predict(const McRef *ref, int lx, int ly, int cx, int cy, int mvx, int mvy, int depth, bool inter14,
+                                           bool luma, bool chroma, McTile &o)
+{
+    const int maxv = (1 << depth) - 1, headRoom = 14 - depth;
+    const int shiftH = 6 - headRoom, offH = -(8192 << shiftH);
+    const int shiftV = 6 + headRoom, offV = (1 << (shiftV - 1)) + (8192 << 6);
+    const int xf = mvx & 3, yf = mvy & 3, cxf = mvx & 7, cyf = mvy & 7;
+    /* plane descriptors and filter taps first: nothing below has to wait for them behind the row loads */
+    const PlaneDev pls[3] = { ref->pl[0], ref->pl[1], ref->pl[2] };
+    int lh[8], lv[8], kh[4], kv[4];
+#pragma unroll
+    for (int k = 0; k < 8; k++) { lh[k] = kLumaTaps[xf][k]; lv[k] = kLumaTaps[yf][k]; }
+#pragma unroll
+    for (int k = 0; k < 4; k++) { kh[k] = kChromaTaps[cxf][k]; kv[k] = kChromaTaps[cyf][k]; }
+    RowLoad<P, 12> L[11];
+    RowLoad<P, 8> C[2][5];
+    {
+        const PlaneDev pl = pls[0];
+        const P AS1 *base = (const P AS1*)pl.origin + (long)(ly + (mvy >> 2) - 3) * pl.stride + lx + (mvx >> 2) - 3;
+#pragma unroll
+        for (int r = 0; r < 11; r++) L[r].zero();
+        if (luma)
+        {
+#pragma unroll
+            for (int r = 3; r < 7; r++) L[r].load(base + (long)r * pl.stride);
+            if (yf)
+            {
+#pragma unroll
+                for (int r = 0; r < 3; r++) L[r].load(base + (long)r * pl.stride);
+#pragma unroll
+                for (int r = 7; r < 11; r++) L[r].load(base + (long)r * pl.stride);
+            }
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < 2; c++)
+    {
+        const PlaneDev pl = pls[1 + c];
+        const P AS1 *base = (const P AS1*)pl.origin + (long)(cy + (mvy >> 3) - 1) * pl.stride + cx + (mvx >> 3) - 1;
+#pragma unroll
+        for (int r = 0; r < 5; r++) C[c][r].zero();
+        if (chroma)
+        {
+            C[c][1].load(base + pl.stride);
+            C[c][2].load(base + 2L * pl.stride);
+            if (cyf)
+            {
+                C[c][0].load(base);
+                C[c][3].load(base + 3L * pl.stride);
+                C[c][4].load(base + 4L * pl.stride);
+            }
+        }
+    }
+    /* ---- luma ---- */
+    {
+        const int (&ch)[8] = lh, (&cv)[8] = lv;
+        int im[11][4];          /* rows -3 .. 7: samples (xf = 0) or 14-bit horizontal intermediates */
+        auto hrow = [&](int r)
+        {
+#pragma unroll
+            for (int x = 0; x < 4; x++)
+            {
+                int H = 0;
+#pragma unroll
+                for (int k = 0; k < 8; k++) H += L[r].px(x + k) * ch[k];
+                const int hp = clip_pixel(as_i16((H + 32) >> 6), maxv), hs = as_i16((H + offH) >> shiftH);
+                /* rows 3..6 with no vertical phase are the result; elsewhere the vertical filter's input */
+                if (r >= 3 && r < 7) o.y[r - 3][x] = inter14 ? hs : (xf ? hp : L[r].px(x + 3));
+                im[r][x] = xf ? hs : L[r].px(x + 3);
+            }
+        };
+#pragma unroll
+        for (int r = 3; r < 7; r++) hrow(r);
+        if (yf)
+        {
+#pragma unroll
+            for (int r = 0; r < 3; r++) hrow(r);
+#pragma unroll
+            for (int r = 7; r < 11; r++) hrow(r);
+#pragma unroll
+            for (int y = 0; y < 4; y++)
+#pragma unroll
+                for (int x = 0; x < 4; x++)
+                {
+                    int V = 0;
+#pragma unroll
+                    for (int k = 0; k < 8; k++) V += im[y + k][x] * cv[k];
+                    const int a = xf ? as_i16(V >> 6) : as_i16((V + offH) >> shiftH);
+                    const int b = xf ? clip_pixel(as_i16((V + offV) >> shiftV), maxv) : clip_pixel(as_i16((V + 32) >> 6), maxv);
+                    o.y[y][x] = inter14 ? a : b;
+                }
+        }
+    }
+    /* ---- chroma ---- */
+    {
+        const int (&ch)[4] = kh, (&cv)[4] = kv;
+#pragma unroll
+        for (int c = 0; c < 2; c++)
+        {
+            int im[5][2];
+            auto hrow = [&](int r)
+            {
+#pragma unroll
+                for (int x = 0; x < 2; x++)
+                {
+                    int H = 0;
+#pragma unroll
+                    for (int k = 0; k < 4; k++) H += C[c][r].px(x + k) * ch[k];
+                    const int hp = clip_pixel(as_i16((H + 32) >> 6), maxv), hs = as_i16((H + offH) >> shiftH);
+                    if (r >= 1 && r < 3) o.c[c][r - 1][x] = inter14 ? hs : (cxf ? hp : C[c][r].px(x + 1));
+                    im[r][x] = cxf ? hs : C[c][r].px(x + 1);
+                }
+            };
+            hrow(1); hrow(2);
+            if (cyf)
+            {
+                hrow(0); hrow(3); hrow(4);
+#pragma unroll
+                for (int y = 0; y < 2; y++)
+#pragma unroll
+                    for (int x = 0; x < 2; x++)
+                    {
+                        int V = 0;
+#pragma unroll
+                        for (int k = 0; k < 4; k++) V += im[y + k][x] * cv[k];
+                        const int a = cxf ? as_i16(V >> 6) : as_i16((V + offH) >> shiftH);
+                        const int b = cxf ? clip_pixel(as_i16((V + offV) >> shiftV), maxv) : clip_pixel(as_i16((V + 32) >> 6), maxv);
+                        o.c[c][y][x] = inter14 ? a : b;
+                    }
+            }
+        }
+    }
 }
 
 template<typename P> struct PxStore;
@@ -922,94 +1114,56 @@ __global__ __launch_bounds__(64) void mc_kernel(McArgs a)
     const int m0x = job->mv0[0], m0y = job->mv0[1], m1x = job->mv1[0], m1y = job->mv1[1];
     const McRef *p0 = a.refs + job->ref0, *p1 = a.refs + job->ref1;
     const int wt = w >> 2;
-    const bool weighted = (flags_lc & 4) != 0;
+    const bool weighted = (flags_lc & 4) != 0, two = dir == 3, inter14 = two || weighted;
     const int maxv = (1 << a.depth) - 1;
-    /* TComYuv::addAvg, TComYuv.cpp:596-606 and :616-650 */
-    const int shiftNum = 15 - a.depth, offset = (1 << (shiftNum - 1)) + 2 * 8192;
+    const int ty = t / wt, tx = t - ty * wt;
+    const int lx = pux + 4 * tx, ly = puy + 4 * ty, cx = (pux >> 1) + 2 * tx, cy = (puy >> 1) + 2 * ty;
+    const bool luma = flags_lc & 1, chroma = flags_lc & 2;
+    /* list A = the only list of a uni-predicted PU, or list 0; list B = list 1 of a bi-predicted PU */
+    const McRef *pa = dir == 2 ? p1 : p0;
+    McTile A, B;
+    mc_predict<P>(pa, lx, ly, cx, cy, dir == 2 ? m1x : m0x, dir == 2 ? m1y : m0y, a.depth, inter14, luma, chroma, A);
+    if (two) mc_predict<P>(p1, lx, ly, cx, cy, m1x, m1y, a.depth, true, luma, chroma, B);
+    if (inter14)
     {
-        const int flags = flags_lc;
-        const int ty = t / wt, tx = t - ty * wt;
-        if (flags & 1)
+        /* TComYuv::addAvg (TComYuv.cpp:596-606, :616-650) as weights (1, 1), or the explicit weights */
+        const int shiftNum = 15 - a.depth;
+#pragma unroll
+        for (int c = 0; c < 3; c++)
         {
-            const PlaneDev r0 = p0->pl[0], r1 = p1->pl[0];
-            const int x = pux + 4 * tx, y = puy + 4 * ty;
-            const P AS1 *s0 = (const P AS1*)r0.origin + (long)y * r0.stride + x;
-            const P AS1 *s1 = (const P AS1*)r1.origin + (long)y * r1.stride + x;
-            int p[4][4];
-            if (weighted)
+            McWeights W;
+            if (weighted) W = mc_weights(pa->wp, p1->wp, c, two, a.depth);
+            else { W.w0 = W.w1 = 1; W.shift = shiftNum; W.round = 1 << (shiftNum - 1); W.offset = 0; W.bias = 8192; }
+            if (c == 0)
             {
-                const McWeights W = mc_weights(p0->wp, p1->wp, 0, dir, a.depth);
-                int q[4][4];
-                if (dir & 1) mc_short_tile<P>(s0, r0.stride, m0x, m0y, a.depth, p);
-                if (dir & 2) mc_short_tile<P>(s1, r1.stride, m1x, m1y, a.depth, q);
 #pragma unroll
                 for (int yy = 0; yy < 4; yy++)
 #pragma unroll
-                    for (int xx = 0; xx < 4; xx++) p[yy][xx] = W.apply(p[yy][xx], q[yy][xx], dir, maxv);
+                    for (int xx = 0; xx < 4; xx++) A.y[yy][xx] = W.apply(A.y[yy][xx], B.y[yy][xx], two, maxv);
             }
-            else if (dir == 3)
+            else
             {
-                int q[4][4];
-                mc_short_tile<P>(s0, r0.stride, m0x, m0y, a.depth, p);
-                mc_short_tile<P>(s1, r1.stride, m1x, m1y, a.depth, q);
 #pragma unroll
-                for (int yy = 0; yy < 4; yy++)
+                for (int yy = 0; yy < 2; yy++)
 #pragma unroll
-                    for (int xx = 0; xx < 4; xx++)
-                    {
-                        const int v = (p[yy][xx] + q[yy][xx] + offset) >> shiftNum;
-                        p[yy][xx] = v < 0 ? 0 : (v > maxv ? maxv : v);
-                    }
-            }
-            else if (dir == 2) bipred_tile<P>(s1, r1.stride, m1x, m1y, a.depth, p);
-            else bipred_tile<P>(s0, r0.stride, m0x, m0y, a.depth, p);
-            P AS1 *d = (P AS1*)a.pred[0].origin + (long)y * a.pred[0].stride + x;
-#pragma unroll
-            for (int yy = 0; yy < 4; yy++) PxStore<P>::four(d + (long)yy * a.pred[0].stride, p[yy]);
-        }
-        if (flags & 2)
-        {
-            const int x = (pux >> 1) + 2 * tx, y = (puy >> 1) + 2 * ty;
-#pragma unroll 1
-            for (int c = 1; c < 3; c++)
-            {
-                const PlaneDev r0 = p0->pl[c], r1 = p1->pl[c];
-                const P AS1 *s0 = (const P AS1*)r0.origin + (long)y * r0.stride + x;
-                const P AS1 *s1 = (const P AS1*)r1.origin + (long)y * r1.stride + x;
-                int p[2][2];
-                if (weighted)
-                {
-                    const McWeights W = mc_weights(p0->wp, p1->wp, c, dir, a.depth);
-                    int q[2][2];
-                    if (dir & 1) chroma_block<P, true>(s0, r0.stride, m0x, m0y, a.depth, p);
-                    if (dir & 2) chroma_block<P, true>(s1, r1.stride, m1x, m1y, a.depth, q);
-#pragma unroll
-                    for (int yy = 0; yy < 2; yy++)
-#pragma unroll
-                        for (int xx = 0; xx < 2; xx++) p[yy][xx] = W.apply(p[yy][xx], q[yy][xx], dir, maxv);
-                }
-                else if (dir == 3)
-                {
-                    int q[2][2];
-                    chroma_block<P, true>(s0, r0.stride, m0x, m0y, a.depth, p);
-                    chroma_block<P, true>(s1, r1.stride, m1x, m1y, a.depth, q);
-#pragma unroll
-                    for (int yy = 0; yy < 2; yy++)
-#pragma unroll
-                        for (int xx = 0; xx < 2; xx++)
-                        {
-                            const int v = (p[yy][xx] + q[yy][xx] + offset) >> shiftNum;
-                            p[yy][xx] = v < 0 ? 0 : (v > maxv ? maxv : v);
-                        }
-                }
-                else if (dir == 2) chroma_block<P, false>(s1, r1.stride, m1x, m1y, a.depth, p);
-                else chroma_block<P, false>(s0, r0.stride, m0x, m0y, a.depth, p);
-                P AS1 *d = (P AS1*)a.pred[c].origin + (long)y * a.pred[c].stride + x;
-                PxStore<P>::two(d, p[0][0], p[0][1]);
-                PxStore<P>::two(d + a.pred[c].stride, p[1][0], p[1][1]);
+                    for (int xx = 0; xx < 2; xx++) A.c[c - 1][yy][xx] = W.apply(A.c[c - 1][yy][xx], B.c[c - 1][yy][xx], two, maxv);
             }
         }
     }
+    if (luma)
+    {
+        P AS1 *d = (P AS1*)a.pred[0].origin + (long)ly * a.pred[0].stride + lx;
+#pragma unroll
+        for (int yy = 0; yy < 4; yy++) PxStore<P>::four(d + (long)yy * a.pred[0].stride, A.y[yy]);
+    }
+    if (chroma)
+#pragma unroll
+        for (int c = 0; c < 2; c++)
+        {
+            P AS1 *d = (P AS1*)a.pred[1 + c].origin + (long)cy * a.pred[1 + c].stride + cx;
+            PxStore<P>::two(d, A.c[c][0][0], A.c[c][0][1]);
+            PxStore<P>::two(d + a.pred[1 + c].stride, A.c[c][1][0], A.c[c][1][1]);
+        }
 }
 
 } // namespace x265amd
