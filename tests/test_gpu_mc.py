@@ -105,3 +105,46 @@ def test_mc_vs_oracle(request, oracle, depth, weighted):
     e.free_picture(dpred)
     for p in drefs:
         e.free_picture(p)
+
+
+def test_mc_full_size_properties(engine8):
+    """3840x2160, every 32x32 PU of the picture in one launch. Whole-sample MVs (multiples of 8 quarter-pels, so chroma is
+    whole-sample too) must reproduce the displaced reference exactly, uni-predicted; bi-predicting from one picture with
+    equal MVs must give the same samples (addAvg of two equal 14-bit copies); and weights of exactly 1.0 with offset 0
+    must change nothing, whatever the denominator."""
+    from x265_amd.synth import make_clip, make_chroma, pad_plane
+    from x265_amd.engine import MC_WEIGHT_DTYPE
+    e = engine8
+    W, H, M = 3840, 2160, 96
+    y = make_clip(W, H, 1, seed=77)[0]
+    cb, cr = (c[0] for c in make_chroma(W, H, 1, seed=77))
+    dims = ((W, H, M), (W // 2, H // 2, M // 2), (W // 2, H // 2, M // 2))
+    host = [pad_plane(y, M), pad_plane(cb, M // 2), pad_plane(cr, M // 2)]
+    dref = e.upload_picture([(b, o, s, w, h, m) for (b, o, s), (w, h, m) in zip(host, dims)])
+    dpred = e.upload_picture([(np.zeros(w * h, np.uint8), 0, w, w, h, 0) for (w, h, _) in dims])
+    xs, ys = np.meshgrid(np.arange(0, W - 31, 32), np.arange(0, H - 31, 32))
+    jobs = np.zeros(xs.size, MC_JOB_DTYPE)
+    jobs["pu_x"], jobs["pu_y"], jobs["w"], jobs["h"] = xs.ravel(), ys.ravel(), 32, 32
+    rng = np.random.default_rng(78)
+    mv = rng.integers(-6, 7, (len(jobs), 2)) * 8
+    jobs["mv0"], jobs["mv1"], jobs["flags"] = mv, mv, 3
+    padded = [np.pad(p, m, mode="edge") for p, m in ((y, M), (cb, M // 2), (cr, M // 2))]
+    exp = [np.zeros((H, W), np.uint8), np.zeros((H // 2, W // 2), np.uint8), np.zeros((H // 2, W // 2), np.uint8)]
+    for j in jobs:
+        px, py, dx, dy = int(j["pu_x"]), int(j["pu_y"]), int(j["mv0"][0]) // 4, int(j["mv0"][1]) // 4
+        exp[0][py:py + 32, px:px + 32] = padded[0][M + py + dy:M + py + dy + 32, M + px + dx:M + px + dx + 32]
+        for k in (1, 2):
+            exp[k][py // 2:py // 2 + 16, px // 2:px // 2 + 16] = \
+                padded[k][M // 2 + (py + dy) // 2:M // 2 + (py + dy) // 2 + 16, M // 2 + (px + dx) // 2:M // 2 + (px + dx) // 2 + 16]
+    wts = np.zeros(1, MC_WEIGHT_DTYPE)
+    wts["log2denom"], wts["w"] = (5, 3, 3), (32, 8, 8)
+    for dir_, extra, w_ in ((1, 0, None), (3, 0, None), (1, 4, wts), (3, 4, wts)):
+        jobs["dir"], jobs["flags"] = dir_, 3 | extra
+        e.mc_batch([dref], dpred, jobs, w_)
+        for k, p in enumerate((dpred.y, dpred.cb, dpred.cr)):
+            got = e.download_plane(p)
+            rows = (H // 32 * 32) >> (k > 0)      # the PUs cover 2144 of the 2160 luma rows
+            assert np.array_equal(got[:rows], exp[k][:rows]), "dir %d flags %d plane %d" % (dir_, 3 | extra, k)
+    e.free_picture(dpred)
+    e.free_picture(dref)
+

@@ -770,66 +770,6 @@ struct McArgs
     const int32_t *chunk_job;  /* nchunks entries: the PU that tile 64 * k belongs to */
 };
 
-/* One 2x2 chroma block of xPredInterChromaBlk at eighth-pel MV (ex, ey); `r` is the block's own
- * position in the reference plane. SHORT = false, the pixel flavour (TComPrediction.cpp:491-540):
- * copy, filter_hpp / filter_vpp, or filter_hps with row extension + chroma_vsp (ipfilter.cpp:194-319
- * with N = 4, :40-81). SHORT = true, the 14-bit flavour (:543-593): chroma_p2s, filter_hps,
- * filterVertical_ps_c<4> or filter_hps + filterVertical_ss_c<4> (ipfilter.cpp:83-172). */
-template<typename P, bool SHORT>
-__device__ __forceinline__ void chroma_block(const P AS1 *r, int stride, int ex, int ey, int depth, int o[2][2])
-{
-    const int xf = ex & 7, yf = ey & 7, headRoom = 14 - depth, maxv = (1 << depth) - 1;
-    const int shiftH = 6 - headRoom, offH = -(8192 << shiftH);
-    const int shiftV = 6 + headRoom, offV = (1 << (shiftV - 1)) + (8192 << 6);
-    GlobalLoader<P> ld = { r + (long)(ey >> 3) * stride + (ex >> 3), stride };
-    int cx[4], cy[4];
-#pragma unroll
-    for (int k = 0; k < 4; k++) { cx[k] = kChromaTaps[xf][k]; cy[k] = kChromaTaps[yf][k]; }
-    int hrow[5][2];
-    const int first = yf ? -1 : 0, nrows = yf ? 5 : 2;
-#pragma unroll
-    for (int i = 0; i < 5; i++)
-    {
-        if (i >= nrows) { hrow[i][0] = hrow[i][1] = 0; continue; }
-        if (xf == 0)
-        {
-            int px[4];
-            Px<P>::unpack(ld(0, first + i), px);
-            hrow[i][0] = px[0]; hrow[i][1] = px[1];
-        }
-        else
-        {
-            int px[8];
-            Px<P>::unpack(ld(-1, first + i), px);
-            Px<P>::unpack(ld(3, first + i), px + 4);
-#pragma unroll
-            for (int x = 0; x < 2; x++)
-            {
-                int sum = 0;
-#pragma unroll
-                for (int k = 0; k < 4; k++) sum += px[x + k] * cx[k];
-                hrow[i][x] = (yf == 0 && !SHORT) ? clip_pixel(as_i16((sum + 32) >> 6), maxv) : as_i16((sum + offH) >> shiftH);
-            }
-        }
-    }
-#pragma unroll
-    for (int y = 0; y < 2; y++)
-#pragma unroll
-        for (int x = 0; x < 2; x++)
-        {
-            if (yf == 0)
-                o[y][x] = xf ? hrow[y][x] : (SHORT ? as_i16((hrow[y][x] << headRoom) - 8192) : hrow[y][x]);
-            else
-            {
-                int sum = 0;
-#pragma unroll
-                for (int k = 0; k < 4; k++) sum += hrow[y + k][x] * cy[k];
-                if (xf == 0) o[y][x] = SHORT ? as_i16((sum + offH) >> shiftH) : clip_pixel(as_i16((sum + 32) >> 6), maxv);
-                else o[y][x] = SHORT ? as_i16(sum >> 6) : clip_pixel(as_i16((sum + offV) >> shiftV), maxv);
-            }
-        }
-}
-
 /* Parameters of explicit weighted prediction for one component, as getWpScaling derives them
  * (TComWeightPrediction.cpp:534-560), and the sample formulas weightUnidir / weightBidir (:46-64).
  * Samples are the 14-bit intermediates (value - 8192); `bias` adds the 8192 back. With weights (1, 1),
