@@ -350,7 +350,8 @@ int x265amd_mc_batch(x265amd_ctx *ctx, const x265amd_picture *refs, const x265am
 /* Device-resident variant, asynchronous on the engine's stream. x265amd_pictures_upload puts the plane
  * descriptors and weights of `refs` on the device (free with x265amd_device_free); x265amd_mc_list_create checks the
  * jobs as x265amd_mc_batch does, numbers their 4x4 tiles for the launch and uploads both (a list can be
- * launched any number of times, e.g. one list per frame); x265amd_mc_batch_dev only launches. */
+ * launched any number of times, e.g. one list per frame); x265amd_mc_batch_dev only launches: the pictures it is
+ * given must have the geometry the list was checked against. */
 typedef struct x265amd_mc_list x265amd_mc_list;
 int x265amd_pictures_upload(x265amd_ctx *ctx, const x265amd_picture *refs, const x265amd_mc_weight *weights, int nrefs,
                             void **d_ref_planes);
