@@ -24,8 +24,12 @@ def main():
     ap.add_argument("--depth", type=int, default=8)
     ap.add_argument("--reps", type=int, default=20)
     ap.add_argument("--no-check", action="store_true")
+    ap.add_argument("--lib", default=None, help="another build of the engine library, e.g. one with -DX265AMD_MC_WAVES=n")
     args = ap.parse_args()
     import torch
+    if args.lib:
+        import x265_amd.engine as eng
+        eng.LIB_PATH = os.path.abspath(args.lib)
     from x265_amd.engine import Engine, MC_JOB_DTYPE, Picture
     from x265_amd.synth import make_clip, make_chroma, pad_plane
     from x265_amd.measure import mixed_partition
