@@ -359,6 +359,15 @@ int x265amd_mc_list_create(x265amd_ctx *ctx, const x265amd_picture *refs, const 
                            const x265amd_picture *pred, const x265amd_mc_job *jobs, int njobs, x265amd_mc_list **out);
 int x265amd_mc_list_free(x265amd_ctx *ctx, x265amd_mc_list *list);
 int x265amd_mc_batch_dev(x265amd_ctx *ctx, const void *d_ref_planes, const x265amd_picture *pred, const x265amd_mc_list *list);
+/* Prediction straight from search results: as x265amd_mc_batch_dev, but job i takes its list-0 MV from
+ * d_results0[i].mv and its list-1 MV from d_results1[i].mv -- device-resident outputs of
+ * x265amd_search_batch_dev for the same PUs in the same order, launched earlier on the engine's stream --
+ * instead of from the job record (the encoder's motionEstimate -> motionCompensation sequence,
+ * Lib/TLibEncoder/TEncSearch.cpp:4303 then :4790-4803, without a host round trip). Either pointer may be
+ * NULL: that list keeps the job's MV. These MVs are not validated; the search ranges must keep the 8-tap /
+ * 4-tap footprints inside the padded reference planes. */
+int x265amd_mc_batch_dev_mv(x265amd_ctx *ctx, const void *d_ref_planes, const x265amd_picture *pred, const x265amd_mc_list *list,
+                            const x265amd_result *d_results0, const x265amd_result *d_results1);
 
 /* ---- Rockchip path (rd >= 5): CIME + RIME + FME ---- */
 

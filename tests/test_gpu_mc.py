@@ -148,3 +148,52 @@ def test_mc_full_size_properties(engine8):
     e.free_picture(dpred)
     e.free_picture(dref)
 
+
+def test_search_then_mc_on_device(engine8, oracle):
+    """motionEstimate -> motionCompensation without a host round trip: two device-resident searches (two references) feed a
+    bi-predicted MC launch through their result arrays; the prediction equals the oracle's for the downloaded MVs."""
+    from x265_amd.engine import JOB_DTYPE, RESULT_DTYPE, STAR
+    from x265_amd.synth import make_clip, make_chroma, pad_plane
+    e = engine8
+    W, H, M = 320, 192, 96
+    ys = make_clip(W, H, 3, seed=91)
+    cbs, crs = make_chroma(W, H, 3, seed=91)
+    dims = ((W, H, M), (W // 2, H // 2, M // 2), (W // 2, H // 2, M // 2))
+    host = [[pad_plane(ys[i], M), pad_plane(cbs[i], M // 2), pad_plane(crs[i], M // 2)] for i in range(3)]
+    pics = [e.upload_picture([(b, o, s, w, h, m) for (b, o, s), (w, h, m) in zip(p, dims)]) for p in host]
+    xs, yy = np.meshgrid(np.arange(0, W, 16), np.arange(0, H, 16))
+    jobs = np.zeros(xs.size, JOB_DTYPE)
+    jobs["pu_x"], jobs["pu_y"], jobs["w"], jobs["h"] = xs.ravel(), yy.ravel(), 16, 16
+    jobs["mvmin"], jobs["mvmax"], jobs["merange"] = (-24, -24), (24, 24), 24
+    d_jobs = e.device_alloc(jobs.nbytes)
+    e.upload(d_jobs, jobs)
+    d_res = [e.device_alloc(len(jobs) * RESULT_DTYPE.itemsize) for _ in range(2)]
+    for k, ref in enumerate((0, 2)):        # frame 1 searched in frames 0 and 2
+        e.search_batch_dev(pics[1].y, pics[ref].y, d_jobs, len(jobs), d_res[k], 30, STAR, 5)
+    mj = np.zeros(len(jobs), MC_JOB_DTYPE)
+    for f in ("pu_x", "pu_y", "w", "h"):
+        mj[f] = jobs[f]
+    mj["dir"], mj["flags"], mj["ref0"], mj["ref1"] = 3, 3, 0, 1
+    refs = [pics[0], pics[2]]
+    dpred = e.upload_picture([(np.zeros(w * h, np.uint8), 0, w, w, h, 0) for (w, h, _) in dims])
+    lst = e.mc_list_create(refs, dpred, mj)
+    d_planes = e.pictures_upload(refs)
+    e.mc_batch_dev(d_planes, dpred, lst, d_res[0], d_res[1])
+    e.sync()
+    res = []
+    for d in d_res:
+        r = np.zeros(len(jobs), RESULT_DTYPE)
+        e._chk(e.L.x265amd_download(e.ctx, C.c_void_p(d), C.c_void_p(r.ctypes.data), C.c_size_t(r.nbytes)))
+        res.append(r)
+    assert (res[0]["mv"] != 0).any() and (res[1]["mv"] != 0).any()
+    mj["mv0"], mj["mv1"] = res[0]["mv"], res[1]["mv"]
+    exp = [(np.zeros(w * h, np.uint8), 0, w) for (w, h, _) in dims]
+    oracle.mc_batch(8, [host[0], host[2]], exp, mj)
+    for got, (ex, _, _) in zip((dpred.y, dpred.cb, dpred.cr), exp):
+        assert np.array_equal(e.download_plane(got).reshape(-1), ex)
+    e.mc_list_free(lst)
+    for d in [d_jobs, d_planes] + d_res:
+        e.device_free(d)
+    for p in pics + [dpred]:
+        e.free_picture(p)
+

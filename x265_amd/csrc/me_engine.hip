@@ -1732,9 +1732,11 @@ static void mc_plan(const x265amd_mc_job *jobs, int njobs, std::vector<char> &bl
     for (int i = 0; i < 64; i++) first[njobs + i] = run;
 }
 
-static int mc_launch(x265amd_ctx *c, const void *d_ref_planes, const x265amd_picture *pred, const void *d_blob, const x265amd_mc_list *l)
+static int mc_launch(x265amd_ctx *c, const void *d_ref_planes, const x265amd_picture *pred, const void *d_blob, const x265amd_mc_list *l,
+                     const x265amd_result *res0 = 0, const x265amd_result *res1 = 0)
 {
     McArgs a;
+    a.res0 = res0; a.res1 = res1;
     a.refs = (const McRef*)d_ref_planes;
     a.pred[0].origin = pred->y.origin; a.pred[0].stride = pred->y.stride;
     a.pred[1].origin = pred->cb.origin; a.pred[1].stride = pred->cb.stride;
@@ -1784,13 +1786,19 @@ int x265amd_mc_list_free(x265amd_ctx *c, x265amd_mc_list *l)
     return X265AMD_OK;
 }
 
-int x265amd_mc_batch_dev(x265amd_ctx *c, const void *d_ref_planes, const x265amd_picture *pred, const x265amd_mc_list *l)
+int x265amd_mc_batch_dev_mv(x265amd_ctx *c, const void *d_ref_planes, const x265amd_picture *pred, const x265amd_mc_list *l,
+                            const x265amd_result *d_results0, const x265amd_result *d_results1)
 {
     if (!c || !d_ref_planes || !pred || !pred->y.origin || !pred->cb.origin || !pred->cr.origin || !l)
         return fail(c, X265AMD_EINVAL, "null argument");
     if (!l->njobs) return X265AMD_OK;
     HIPCHK(c, hipSetDevice(c->device));
-    return mc_launch(c, d_ref_planes, pred, l->d_blob, l);
+    return mc_launch(c, d_ref_planes, pred, l->d_blob, l, d_results0, d_results1);
+}
+
+int x265amd_mc_batch_dev(x265amd_ctx *c, const void *d_ref_planes, const x265amd_picture *pred, const x265amd_mc_list *l)
+{
+    return x265amd_mc_batch_dev_mv(c, d_ref_planes, pred, l, 0, 0);
 }
 
 int x265amd_mc_batch(x265amd_ctx *c, const x265amd_picture *refs, const x265amd_mc_weight *weights, int nrefs,

@@ -768,6 +768,7 @@ struct McArgs
     const x265amd_mc_job *jobs;
     const int32_t *first;      /* njobs + 64 entries: first tile of each PU, then the tile total repeated */
     const int32_t *chunk_job;  /* nchunks entries: the PU that tile 64 * k belongs to */
+    const x265amd_result *res0, *res1;   /* optional: search results that supply the MVs of list 0 / list 1 */
 };
 
 /* Parameters of explicit weighted prediction for one component, as getWpScaling derives them
@@ -1053,7 +1054,9 @@ __global__ __launch_bounds__(64) void mc_kernel(McArgs a)
     const x265amd_mc_job *job = a.jobs + j;
     const int w = job->w, dir = job->dir, flags_lc = job->flags;
     const int pux = job->pu_x, puy = job->pu_y;
-    const int m0x = job->mv0[0], m0y = job->mv0[1], m1x = job->mv1[0], m1y = job->mv1[1];
+    int m0x = job->mv0[0], m0y = job->mv0[1], m1x = job->mv1[0], m1y = job->mv1[1];
+    if (a.res0) { m0x = a.res0[j].mv[0]; m0y = a.res0[j].mv[1]; }
+    if (a.res1) { m1x = a.res1[j].mv[0]; m1y = a.res1[j].mv[1]; }
     const McRef *p0 = a.refs + job->ref0, *p1 = a.refs + job->ref1;
     const int wt = w >> 2;
     const bool weighted = (flags_lc & 4) != 0, two = dir == 3, inter14 = two || weighted;

@@ -434,8 +434,11 @@ class Engine:
     def mc_list_free(self, h):
         self._chk(self.L.x265amd_mc_list_free(self.ctx, h))
 
-    def mc_batch_dev(self, d_ref_planes, pred, mc_list):
-        self._chk(self.L.x265amd_mc_batch_dev(self.ctx, C.c_void_p(d_ref_planes), C.byref(pred), mc_list))
+    def mc_batch_dev(self, d_ref_planes, pred, mc_list, d_results0=None, d_results1=None):
+        """Launches a list; d_results0 / d_results1: device arrays of search results whose MVs replace the jobs' list-0 /
+        list-1 MVs (x265amd_mc_batch_dev_mv)."""
+        self._chk(self.L.x265amd_mc_batch_dev_mv(self.ctx, C.c_void_p(d_ref_planes), C.byref(pred), mc_list,
+                                                 C.c_void_p(d_results0), C.c_void_p(d_results1)))
 
     # ---- Rockchip path
     def rk_ds_plane(self, orig):
