@@ -292,7 +292,11 @@ int x265amd_bipred_batch_dev(x265amd_ctx *ctx, const x265amd_plane *fenc, const 
  * Lib/TLibCommon/TComYuv.cpp:573-612) and primitives.sa8d against the source CU (:265). The
  * caller has clipped the MVs (TComDataCU::clipMv) and turned a candidate whose two lists are the
  * same picture and MV into dir 1 (xCheckIdenticalMotion, TComPrediction.cpp:276). Weighted
- * prediction flavours (:252-268) are not covered. */
+ * prediction flavours (:252-268) are not covered here (x265amd_mc_batch has them).
+ * The distortion of an inter mode whose prediction already exists (TEncCu::xComputeCostInter,
+ * encoder/compress.cpp:209-212: sa8d of the source CU against predYuv) is the same call with the
+ * prediction picture's luma plane as the only reference, dir 1 and MV (0, 0): a whole-sample MV of a
+ * single list reads exactly the block, so the plane needs no margins. */
 typedef struct
 {
     int16_t pu_x, pu_y;

@@ -191,6 +191,16 @@ def test_search_then_mc_on_device(engine8, oracle):
     oracle.mc_batch(8, [host[0], host[2]], exp, mj)
     for got, (ex, _, _) in zip((dpred.y, dpred.cb, dpred.cr), exp):
         assert np.array_equal(e.download_plane(got).reshape(-1), ex)
+    # the inter-mode distortion of xComputeCostInter (compress.cpp:209-212): sa8d of each source CU against the prediction
+    # picture, taken through the merge entry point with the picture as reference and MV 0 (no margins needed)
+    from x265_amd.engine import MERGE_JOB_DTYPE
+    cj = np.zeros(len(jobs), MERGE_JOB_DTYPE)
+    cj["pu_x"], cj["pu_y"], cj["size"], cj["dir"] = jobs["pu_x"], jobs["pu_y"], 16, 1
+    got = e.merge_sa8d_batch(pics[1].y, [dpred.y], cj)
+    fe, fo, fs = host[1][0]
+    want = np.array([oracle.sa8d_inter(8, fe, fo + int(j["pu_y"]) * fs + int(j["pu_x"]), fs, exp[0][0], int(j["pu_y"]) * W + int(j["pu_x"]), W, 16, 16)
+                     for j in cj], np.int32)
+    assert np.array_equal(got, want) and got.min() >= 0 and got.max() > 0
     e.mc_list_free(lst)
     for d in [d_jobs, d_planes] + d_res:
         e.device_free(d)

@@ -1587,8 +1587,12 @@ int x265amd_merge_sa8d_batch(x265amd_ctx *c, const x265amd_plane *fenc, const x2
             if (!(j.dir & (1 << l))) continue;
             const int16_t *mv = l ? j.mv1 : j.mv0;
             const x265amd_plane *r = &refs[l ? j.ref1 : j.ref0];
-            const int x0 = j.pu_x + (mv[0] >> 2) - 3, x1 = j.pu_x + j.size + (mv[0] >> 2) + 8;
-            const int y0 = j.pu_y + (mv[1] >> 2) - 3, y1 = j.pu_y + j.size + (mv[1] >> 2) + 4;
+            /* a whole-sample MV of a single list reads the block itself (this is how the distortion of a finished
+             * prediction picture, which has no margins, is taken: the picture as reference, MV 0); everything else
+             * reads the 8-tap footprint, tiles as whole quads */
+            const bool copy = j.dir != 3 && ((mv[0] | mv[1]) & 3) == 0;
+            const int x0 = j.pu_x + (mv[0] >> 2) - (copy ? 0 : 3), x1 = j.pu_x + j.size + (mv[0] >> 2) + (copy ? 0 : 8);
+            const int y0 = j.pu_y + (mv[1] >> 2) - (copy ? 0 : 3), y1 = j.pu_y + j.size + (mv[1] >> 2) + (copy ? 0 : 4);
             if (!r->origin || x0 < -r->margin_x || y0 < -r->margin_y || x1 > r->width + r->margin_x || y1 > r->height + r->margin_y)
                 return fail(c, X265AMD_EINVAL, "job: prediction block leaves the padded reference plane");
         }
