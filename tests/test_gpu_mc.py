@@ -207,3 +207,24 @@ def test_search_then_mc_on_device(engine8, oracle):
     for p in pics + [dpred]:
         e.free_picture(p)
 
+
+def test_mc_12bit_vs_oracle(oracle):
+    """12-bit samples (headroom 2: the lossy end of the 14-bit intermediates), weighted and unweighted PUs mixed."""
+    from x265_amd.engine import Engine
+    e = Engine(0, 12)
+    try:
+        refs = mc_pictures(12, 51)
+        drefs = upload_pictures(e, refs)
+        rng = np.random.default_rng(52)
+        wts = mc_weights(rng, MC_WEIGHT_DTYPE, 2)
+        for jobs in mc_job_batches(rng, MC_JOB_DTYPE, 10, weighted=True):
+            exp = mc_blank_pred(12)
+            oracle.mc_batch(12, refs, exp, jobs, wts)
+            got = run_batch(e, drefs, jobs, 12, wts)
+            for k in range(3):
+                assert np.array_equal(got[k], exp[k][0]), "plane %d" % k
+        for p in drefs:
+            e.free_picture(p)
+    finally:
+        e.close()
+
