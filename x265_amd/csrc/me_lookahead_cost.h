@@ -814,9 +814,58 @@ template<typename P, int N> struct RowLoad;
 typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
 typedef uint32_t u32x3_t __attribute__((ext_vector_type(3)));
 typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+/* Horizontal filter sums of a loaded row on the dot-product instructions. 8-bit samples are biased to signed bytes for
+ * v_dot4_i32_i8; the taps of every phase add up to 64, so the bias comes back as + 128 * 64. 16-bit samples (at most 12
+ * bits) are signed halves for v_dot2_i32_i16 as they are. */
+__device__ __forceinline__ int mc_dot2(uint32_t a, uint32_t b, int c)
+{
+    typedef short h2 __attribute__((ext_vector_type(2)));
+    return __builtin_amdgcn_sdot2(__builtin_bit_cast(h2, a), __builtin_bit_cast(h2, b), c, false);
+}
+#define MC_B(a, b, c, d) ((uint32_t)((a) & 0xff) | ((uint32_t)((b) & 0xff) << 8) | ((uint32_t)((c) & 0xff) << 16) | ((uint32_t)((d) & 0xff) << 24))
+#define MC_H(a, b) ((uint32_t)((a) & 0xffff) | ((uint32_t)((b) & 0xffff) << 16))
+#define MC_L8(a, b, c, d, e, f, g, h) { MC_B(a, b, c, d), MC_B(e, f, g, h) }
+#define MC_L16(a, b, c, d, e, f, g, h) { MC_H(a, b), MC_H(c, d), MC_H(e, f), MC_H(g, h) }
+__constant__ static const uint32_t kMcLuma8[4][2] = { MC_L8(0, 0, 0, 64, 0, 0, 0, 0), MC_L8(-1, 4, -10, 58, 17, -5, 1, 0),
+                                                      MC_L8(-1, 4, -11, 40, 40, -11, 4, -1), MC_L8(0, 1, -5, 17, 58, -10, 4, -1) };
+__constant__ static const uint32_t kMcLuma16[4][4] = { MC_L16(0, 0, 0, 64, 0, 0, 0, 0), MC_L16(-1, 4, -10, 58, 17, -5, 1, 0),
+                                                       MC_L16(-1, 4, -11, 40, 40, -11, 4, -1), MC_L16(0, 1, -5, 17, 58, -10, 4, -1) };
+__constant__ static const uint32_t kMcChroma8[8] = { MC_B(0, 64, 0, 0), MC_B(-2, 58, 10, -2), MC_B(-4, 54, 16, -2), MC_B(-6, 46, 28, -4),
+                                                     MC_B(-4, 36, 36, -4), MC_B(-4, 28, 46, -6), MC_B(-2, 16, 54, -4), MC_B(-2, 10, 58, -2) };
+__constant__ static const uint32_t kMcChroma16[8][2] = { { MC_H(0, 64), MC_H(0, 0) }, { MC_H(-2, 58), MC_H(10, -2) }, { MC_H(-4, 54), MC_H(16, -2) },
+                                                         { MC_H(-6, 46), MC_H(28, -4) }, { MC_H(-4, 36), MC_H(36, -4) }, { MC_H(-4, 28), MC_H(46, -6) },
+                                                         { MC_H(-2, 16), MC_H(54, -4) }, { MC_H(-2, 10), MC_H(58, -2) } };
+/* packed taps of a lane's horizontal phases: l = luma (2 or 4 words), c = chroma (1 or 2 words) */
+template<typename P> struct McTaps;
+template<> struct McTaps<uint8_t>
+{
+    uint32_t l[2], c[1];
+    __device__ __forceinline__ void load(int xf, int cxf) { l[0] = kMcLuma8[xf][0]; l[1] = kMcLuma8[xf][1]; c[0] = kMcChroma8[cxf]; }
+};
+template<> struct McTaps<uint16_t>
+{
+    uint32_t l[4], c[2];
+    __device__ __forceinline__ void load(int xf, int cxf)
+    {
+#pragma unroll
+        for (int i = 0; i < 4; i++) l[i] = kMcLuma16[xf][i];
+        c[0] = kMcChroma16[cxf][0]; c[1] = kMcChroma16[cxf][1];
+    }
+};
+
 template<> struct RowLoad<uint8_t, 12>
 {
     u32x3_t v;
+    /* H[x] = sum over k < 8 of sample(x + k) * tap[k], x < 4 */
+    __device__ __forceinline__ void hsum(const McTaps<uint8_t> &t, int H[4]) const
+    {
+        const uint32_t d0 = v[0] ^ 0x80808080u, d1 = v[1] ^ 0x80808080u, d2 = v[2] ^ 0x80808080u;
+        H[0] = __builtin_amdgcn_sdot4(d0, t.l[0], __builtin_amdgcn_sdot4(d1, t.l[1], 8192, false), false);
+#pragma unroll
+        for (int x = 1; x < 4; x++)
+            H[x] = __builtin_amdgcn_sdot4(__builtin_amdgcn_alignbyte(d1, d0, x), t.l[0],
+                                          __builtin_amdgcn_sdot4(__builtin_amdgcn_alignbyte(d2, d1, x), t.l[1], 8192, false), false);
+    }
     __device__ __forceinline__ void load(const uint8_t AS1 *p) { typedef u32x3_t __attribute__((aligned(1))) T; v = *(const T AS1*)p; }
     __device__ __forceinline__ void zero() { v = (u32x3_t)(0u); }
     __device__ __forceinline__ int px(int i) const { return (int)((v[i >> 2] >> (8 * (i & 3))) & 0xff); }
@@ -824,6 +873,13 @@ template<> struct RowLoad<uint8_t, 12>
 template<> struct RowLoad<uint8_t, 8>
 {
     u32x2_t v;
+    /* H[x] = sum over k < 4 of sample(x + k) * tap[k], x < 2 */
+    __device__ __forceinline__ void hsum(const McTaps<uint8_t> &t, int H[2]) const
+    {
+        const uint32_t d0 = v[0] ^ 0x80808080u, d1 = v[1] ^ 0x80808080u;
+        H[0] = __builtin_amdgcn_sdot4(d0, t.c[0], 8192, false);
+        H[1] = __builtin_amdgcn_sdot4(__builtin_amdgcn_alignbyte(d1, d0, 1), t.c[0], 8192, false);
+    }
     __device__ __forceinline__ void load(const uint8_t AS1 *p) { typedef u32x2_t __attribute__((aligned(1))) T; v = *(const T AS1*)p; }
     __device__ __forceinline__ void zero() { v = (u32x2_t)(0u); }
     __device__ __forceinline__ int px(int i) const { return (int)((v[i >> 2] >> (8 * (i & 3))) & 0xff); }
@@ -831,6 +887,17 @@ template<> struct RowLoad<uint8_t, 8>
 template<> struct RowLoad<uint16_t, 12>
 {
     u32x4_t lo; u32x2_t hi;
+    __device__ __forceinline__ void hsum(const McTaps<uint16_t> &t, int H[4]) const
+    {
+        const uint32_t D[6] = { lo[0], lo[1], lo[2], lo[3], hi[0], hi[1] };
+        uint32_t A[5];
+#pragma unroll
+        for (int i = 0; i < 5; i++) A[i] = __builtin_amdgcn_alignbit(D[i + 1], D[i], 16);
+        H[0] = mc_dot2(D[0], t.l[0], mc_dot2(D[1], t.l[1], mc_dot2(D[2], t.l[2], mc_dot2(D[3], t.l[3], 0))));
+        H[1] = mc_dot2(A[0], t.l[0], mc_dot2(A[1], t.l[1], mc_dot2(A[2], t.l[2], mc_dot2(A[3], t.l[3], 0))));
+        H[2] = mc_dot2(D[1], t.l[0], mc_dot2(D[2], t.l[1], mc_dot2(D[3], t.l[2], mc_dot2(D[4], t.l[3], 0))));
+        H[3] = mc_dot2(A[1], t.l[0], mc_dot2(A[2], t.l[1], mc_dot2(A[3], t.l[2], mc_dot2(A[4], t.l[3], 0))));
+    }
     __device__ __forceinline__ void load(const uint16_t AS1 *p)
     {
         typedef u32x4_t __attribute__((aligned(2))) T4;
@@ -843,6 +910,11 @@ template<> struct RowLoad<uint16_t, 12>
 template<> struct RowLoad<uint16_t, 8>        /* six samples are enough for the chroma footprint */
 {
     u32x3_t v;
+    __device__ __forceinline__ void hsum(const McTaps<uint16_t> &t, int H[2]) const
+    {
+        H[0] = mc_dot2(v[0], t.c[0], mc_dot2(v[1], t.c[1], 0));
+        H[1] = mc_dot2(__builtin_amdgcn_alignbit(v[1], v[0], 16), t.c[0], mc_dot2(__builtin_amdgcn_alignbit(v[2], v[1], 16), t.c[1], 0));
+    }
     __device__ __forceinline__ void load(const uint16_t AS1 *p) { typedef u32x3_t __attribute__((aligned(2))) T; v = *(const T AS1*)p; }
     __device__ __forceinline__ void zero() { v = (u32x3_t)(0u); }
     __device__ __forceinline__ int px(int i) const { return (int)((v[i >> 1] >> (16 * (i & 1))) & 0xffff); }
@@ -873,11 +945,13 @@ __device__ __forceinline__ void mc_predict(const McRef *ref, int lx, int ly, int
     const int xf = mvx & 3, yf = mvy & 3, cxf = mvx & 7, cyf = mvy & 7;
     /* plane descriptors and filter taps first: nothing below has to wait for them behind the row loads */
     const PlaneDev pls[3] = { ref->pl[0], ref->pl[1], ref->pl[2] };
-    int lh[8], lv[8], kh[4], kv[4];
+    McTaps<P> th;
+    th.load(xf, cxf);
+    int lv[8], kv[4];
 #pragma unroll
-    for (int k = 0; k < 8; k++) { lh[k] = kLumaTaps[xf][k]; lv[k] = kLumaTaps[yf][k]; }
+    for (int k = 0; k < 8; k++) lv[k] = kLumaTaps[yf][k];
 #pragma unroll
-    for (int k = 0; k < 4; k++) { kh[k] = kChromaTaps[cxf][k]; kv[k] = kChromaTaps[cyf][k]; }
+    for (int k = 0; k < 4; k++) kv[k] = kChromaTaps[cyf][k];
     RowLoad<P, 12> L[11];
     RowLoad<P, 8> C[2][5];
     {
@@ -919,16 +993,16 @@ __device__ __forceinline__ void mc_predict(const McRef *ref, int lx, int ly, int
     }
     /* ---- luma ---- */
     {
-        const int (&ch)[8] = lh, (&cv)[8] = lv;
+        const int (&cv)[8] = lv;
         int im[11][4];          /* rows -3 .. 7: samples (xf = 0) or 14-bit horizontal intermediates */
         auto hrow = [&](int r)
         {
+            int Hs[4];
+            L[r].hsum(th, Hs);
 #pragma unroll
             for (int x = 0; x < 4; x++)
             {
-                int H = 0;
-#pragma unroll
-                for (int k = 0; k < 8; k++) H += L[r].px(x + k) * ch[k];
+                const int H = Hs[x];
                 const int hp = clip_pixel(as_i16((H + 32) >> 6), maxv), hs = as_i16((H + offH) >> shiftH);
                 /* rows 3..6 with no vertical phase are the result; elsewhere the vertical filter's input */
                 if (r >= 3 && r < 7) o.y[r - 3][x] = inter14 ? hs : (xf ? hp : L[r].px(x + 3));
@@ -959,19 +1033,19 @@ __device__ __forceinline__ void mc_predict(const McRef *ref, int lx, int ly, int
     }
     /* ---- chroma ---- */
     {
-        const int (&ch)[4] = kh, (&cv)[4] = kv;
+        const int (&cv)[4] = kv;
 #pragma unroll
         for (int c = 0; c < 2; c++)
         {
             int im[5][2];
             auto hrow = [&](int r)
             {
+                int Hs[2];
+                C[c][r].hsum(th, Hs);
 #pragma unroll
                 for (int x = 0; x < 2; x++)
                 {
-                    int H = 0;
-#pragma unroll
-                    for (int k = 0; k < 4; k++) H += C[c][r].px(x + k) * ch[k];
+                    const int H = Hs[x];
                     const int hp = clip_pixel(as_i16((H + 32) >> 6), maxv), hs = as_i16((H + offH) >> shiftH);
                     if (r >= 1 && r < 3) o.c[c][r - 1][x] = inter14 ? hs : (cxf ? hp : C[c][r].px(x + 1));
                     im[r][x] = cxf ? hs : C[c][r].px(x + 1);
