@@ -1514,6 +1514,9 @@ int x265amd_weights_analyse(x265amd_ctx *c, const x265amd_plane *fenc, const x26
 
 /* ---- bi-prediction estimate ---- */
 
+static void flat_plan(const void *jobs, size_t job_size, int njobs, const std::vector<int> &tiles, std::vector<char> &blob,
+                      size_t &first_off, size_t &chunk_off, int &nchunks);
+
 int x265amd_bipred_batch_dev(x265amd_ctx *c, const x265amd_plane *fenc, const x265amd_plane *ref0, const x265amd_plane *ref1,
                              const x265amd_bipred_job *d_jobs, int njobs, x265amd_bipred_result *d_results)
 {
@@ -1557,11 +1560,28 @@ int x265amd_bipred_batch(x265amd_ctx *c, const x265amd_plane *fenc, const x265am
     }
     HIPCHK(c, hipSetDevice(c->device));
     int rc;
-    if ((rc = ensure(c, &c->d_jobs, &c->jobs_cap, (size_t)njobs * sizeof(x265amd_bipred_job)))) return rc;
+    /* host job arrays show their sizes: tiles are numbered here and waves take 64 of them at a time, whatever PUs they
+     * belong to (the device-resident entry point above cannot see the sizes and runs one wave per PU) */
+    std::vector<int> tiles(njobs);
+    for (int i = 0; i < njobs; i++) tiles[i] = (jobs[i].w >> 2) * (jobs[i].h >> 2);
+    std::vector<char> blob;
+    BipredFlatArgs fa;
+    size_t first_off, chunk_off;
+    flat_plan(jobs, sizeof(x265amd_bipred_job), njobs, tiles, blob, first_off, chunk_off, fa.nchunks);
+    if ((rc = ensure(c, &c->d_jobs, &c->jobs_cap, blob.size()))) return rc;
     if ((rc = ensure(c, &c->d_results, &c->results_cap, (size_t)njobs * sizeof(x265amd_bipred_result)))) return rc;
-    HIPCHK(c, hipMemcpyAsync(c->d_jobs, jobs, (size_t)njobs * sizeof(x265amd_bipred_job), hipMemcpyHostToDevice, c->stream));
-    if ((rc = x265amd_bipred_batch_dev(c, fenc, ref0, ref1, (const x265amd_bipred_job*)c->d_jobs, njobs, (x265amd_bipred_result*)c->d_results)))
-        return rc;
+    HIPCHK(c, hipMemcpyAsync(c->d_jobs, blob.data(), blob.size(), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemsetAsync(c->d_results, 0, (size_t)njobs * sizeof(x265amd_bipred_result), c->stream));
+    fa.b.fenc.origin = fenc->origin; fa.b.fenc.stride = fenc->stride;
+    fa.b.ref0.origin = ref0->origin; fa.b.ref0.stride = ref0->stride;
+    fa.b.ref1.origin = ref1->origin; fa.b.ref1.stride = ref1->stride;
+    fa.b.depth = c->depth; fa.b.njobs = njobs;
+    fa.b.jobs = (const x265amd_bipred_job*)c->d_jobs; fa.b.results = (x265amd_bipred_result*)c->d_results;
+    fa.first = (const int32_t*)((const char*)c->d_jobs + first_off);
+    fa.chunk_job = (const int32_t*)((const char*)c->d_jobs + chunk_off);
+    if (c->depth <= 8) hipLaunchKernelGGL(bipred_flat_kernel<uint8_t>, dim3(fa.nchunks), dim3(64), 0, c->stream, fa);
+    else hipLaunchKernelGGL(bipred_flat_kernel<uint16_t>, dim3(fa.nchunks), dim3(64), 0, c->stream, fa);
+    HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipMemcpyAsync(results, c->d_results, (size_t)njobs * sizeof(x265amd_bipred_result), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return X265AMD_OK;
@@ -1713,27 +1733,35 @@ static int mc_validate(x265amd_ctx *c, const x265amd_picture *refs, const x265am
     return X265AMD_OK;
 }
 
-/* Numbers the 4x4 tiles of the jobs consecutively and lays jobs | first[] | chunk_job[] out in `blob` */
-static void mc_plan(const x265amd_mc_job *jobs, int njobs, std::vector<char> &blob, x265amd_mc_list *l)
+/* Numbers the 4x4 tiles of `njobs` records (tiles[i] each) consecutively and lays records | first[] | chunk_job[] out in
+ * `blob`: first[] has njobs + 64 entries (the tail repeats the total), chunk_job[k] is the record tile 64 k belongs to */
+static void flat_plan(const void *jobs, size_t job_size, int njobs, const std::vector<int> &tiles, std::vector<char> &blob,
+                      size_t &first_off, size_t &chunk_off, int &nchunks)
 {
     long total = 0;
-    for (int i = 0; i < njobs; i++) total += (jobs[i].w >> 2) * (jobs[i].h >> 2);
-    l->njobs = njobs;
-    l->nchunks = (int)((total + 63) / 64);
-    l->first_off = ((size_t)njobs * sizeof(x265amd_mc_job) + 15) & ~(size_t)15;
-    l->chunk_off = l->first_off + ((size_t)njobs + 64) * sizeof(int32_t);
-    blob.assign(l->chunk_off + (size_t)l->nchunks * sizeof(int32_t), 0);
-    memcpy(blob.data(), jobs, (size_t)njobs * sizeof(x265amd_mc_job));
-    int32_t *first = (int32_t*)(blob.data() + l->first_off), *chunk = (int32_t*)(blob.data() + l->chunk_off);
+    for (int i = 0; i < njobs; i++) total += tiles[i];
+    nchunks = (int)((total + 63) / 64);
+    first_off = ((size_t)njobs * job_size + 15) & ~(size_t)15;
+    chunk_off = first_off + ((size_t)njobs + 64) * sizeof(int32_t);
+    blob.assign(chunk_off + (size_t)nchunks * sizeof(int32_t), 0);
+    memcpy(blob.data(), jobs, (size_t)njobs * job_size);
+    int32_t *first = (int32_t*)(blob.data() + first_off), *chunk = (int32_t*)(blob.data() + chunk_off);
     int32_t run = 0;
     for (int i = 0; i < njobs; i++)
     {
-        const int t = (jobs[i].w >> 2) * (jobs[i].h >> 2);
         first[i] = run;
-        for (int k = (run + 63) / 64; 64 * k < run + t; k++) chunk[k] = i;
-        run += t;
+        for (int k = (run + 63) / 64; 64 * k < run + tiles[i]; k++) chunk[k] = i;
+        run += tiles[i];
     }
     for (int i = 0; i < 64; i++) first[njobs + i] = run;
+}
+
+static void mc_plan(const x265amd_mc_job *jobs, int njobs, std::vector<char> &blob, x265amd_mc_list *l)
+{
+    std::vector<int> tiles(njobs);
+    for (int i = 0; i < njobs; i++) tiles[i] = (jobs[i].w >> 2) * (jobs[i].h >> 2);
+    l->njobs = njobs;
+    flat_plan(jobs, sizeof(x265amd_mc_job), njobs, tiles, blob, l->first_off, l->chunk_off, l->nchunks);
 }
 
 static int mc_launch(x265amd_ctx *c, const void *d_ref_planes, const x265amd_picture *pred, const void *d_blob, const x265amd_mc_list *l,

@@ -1101,18 +1101,19 @@ template<> struct PxStore<uint16_t>
     }
 };
 
-/* 133 VGPRs (8-bit) / 164 (16-bit): three waves per SIMD. Asking for four or five (amdgpu_waves_per_eu) makes the
- * compiler spill the row registers and was measured equal (8-bit, four) or slower (all other cases). */
-template<typename P>
-__global__ __launch_bounds__(64) void mc_kernel(McArgs a)
+/* Lane -> (PU, tile) for kernels whose waves take 64 consecutive tiles of a launch, whatever PUs they belong to.
+ * first[j] = first tile of PU j (njobs + 64 entries, the tail repeating the tile total); chunk_job[k] = the PU that tile
+ * 64 k belongs to. The lanes find their PU from the 64 entries of first[] after the chunk's PU: a flag in LDS where a PU
+ * starts, one ballot, a bit count. Returns false for lanes past the last tile. */
+__device__ __forceinline__ bool flat_tile_of_lane(const int32_t *first, const int32_t *chunk_job, int nchunks, int njobs, int &j, int &t)
 {
     __shared__ int32_t starts[64];
     __shared__ int32_t flags[64];
-    const int k = xcd_remap(blockIdx.x, a.nchunks);
-    if (k >= a.nchunks) return;
+    const int k = xcd_remap(blockIdx.x, nchunks);
+    if (k >= nchunks) return false;
     const int lane = threadIdx.x & 63;
-    const int j0 = uni(a.chunk_job[k]), g = 64 * k + lane;
-    const int my_start = a.first[j0 + lane];
+    const int j0 = uni(chunk_job[k]), g = 64 * k + lane;
+    const int my_start = first[j0 + lane];
     starts[lane] = my_start;
     flags[lane] = 0;
     wave_sync();
@@ -1122,9 +1123,19 @@ __global__ __launch_bounds__(64) void mc_kernel(McArgs a)
     const int f = flags[lane];
     const unsigned long long m = __ballot(f);
     const int off = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0)) + f;
-    const int j = j0 + off;
-    if (j >= a.njobs) return;                 /* tiles past the last PU (only in the last wave) */
-    const int t = g - starts[off];
+    j = j0 + off;
+    if (j >= njobs) return false;             /* tiles past the last PU (only in the last wave) */
+    t = g - starts[off];
+    return true;
+}
+
+/* 125 VGPRs (8-bit) / 160 (16-bit): four / three waves per SIMD. Asking for more (amdgpu_waves_per_eu) makes the
+ * compiler spill the row registers and was measured slower. */
+template<typename P>
+__global__ __launch_bounds__(64) void mc_kernel(McArgs a)
+{
+    int j, t;
+    if (!flat_tile_of_lane(a.first, a.chunk_job, a.nchunks, a.njobs, j, t)) return;
     const x265amd_mc_job *job = a.jobs + j;
     const int w = job->w, dir = job->dir, flags_lc = job->flags;
     const int pux = job->pu_x, puy = job->pu_y;
@@ -1185,7 +1196,64 @@ __global__ __launch_bounds__(64) void mc_kernel(McArgs a)
         }
 }
 
+/* The bi-prediction estimate with 64 consecutive tiles per wave (flat_tile_of_lane): every lane adds its tile's two
+ * SATDs to its PU's result, which the launch zeroed first. SATD is halved per tile, which equals halving the sum. */
+struct BipredFlatArgs
+{
+    BipredArgs b;
+    const int32_t *first, *chunk_job;
+    int nchunks;
+};
+
+template<typename P>
+__global__ __launch_bounds__(64) void bipred_flat_kernel(BipredFlatArgs fa)
+{
+    const BipredArgs &a = fa.b;
+    int j, t;
+    if (!flat_tile_of_lane(fa.first, fa.chunk_job, fa.nchunks, a.njobs, j, t)) return;
+    const x265amd_bipred_job *job = a.jobs + j;
+    const int wt = job->w >> 2, pux = job->pu_x, puy = job->pu_y;
+    const int ty = t / wt, tx = t - ty * wt;
+    const long fo = (long)(puy + 4 * ty) * a.fenc.stride + pux + 4 * tx;
+    const long r0o = (long)(puy + 4 * ty) * a.ref0.stride + pux + 4 * tx, r1o = (long)(puy + 4 * ty) * a.ref1.stride + pux + 4 * tx;
+    typename Px<P>::quad f[4], z[4];
+#pragma unroll
+    for (int y = 0; y < 4; y++)
+    {
+        f[y] = Px<P>::load_g((const P AS1*)a.fenc.origin + fo + (long)y * a.fenc.stride);
+        z[y] = Px<P>::avg(Px<P>::load_g((const P AS1*)a.ref0.origin + r0o + (long)y * a.ref0.stride),
+                          Px<P>::load_g((const P AS1*)a.ref1.origin + r1o + (long)y * a.ref1.stride));
+    }
+    const int zero = tile_cost_quads<P>(f, z, true);
+    int o0[4][4], o1[4][4];
+    bipred_tile<P>((const P AS1*)a.ref0.origin + r0o, a.ref0.stride, job->mv0[0], job->mv0[1], a.depth, o0);
+    bipred_tile<P>((const P AS1*)a.ref1.origin + r1o, a.ref1.stride, job->mv1[0], job->mv1[1], a.depth, o1);
+#pragma unroll
+    for (int y = 0; y < 4; y++)
+#pragma unroll
+        for (int x = 0; x < 4; x++) o0[y][x] = (o0[y][x] + o1[y][x] + 1) >> 1;
+    int bi = tile_cost_px<P>(f, o0, true), zr = zero;
+    /* the lanes of one PU are neighbours: sum them down to the PU's first lane in the wave (a lane adds its partner's
+     * partial sum when the partner belongs to the same PU), then one atomic per PU and wave */
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1)
+    {
+        const int pj = __shfl_down(j, d), pb = __shfl_down(bi, d), pz = __shfl_down(zr, d);
+        const bool same = lane + d < 64 && pj == j;
+        bi += same ? pb : 0;
+        zr += same ? pz : 0;
+    }
+    const int prev = __shfl_up(j, 1);
+    if (lane == 0 || prev != j)
+    {
+        atomicAdd(&a.results[j].satd, bi);
+        atomicAdd(&a.results[j].satd_zero, zr);
+    }
+}
+
 } // namespace x265amd
+
 
 
 
