@@ -1515,7 +1515,7 @@ int x265amd_weights_analyse(x265amd_ctx *c, const x265amd_plane *fenc, const x26
 /* ---- bi-prediction estimate ---- */
 
 static void flat_plan(const void *jobs, size_t job_size, int njobs, const std::vector<int> &tiles, std::vector<char> &blob,
-                      size_t &first_off, size_t &chunk_off, int &nchunks);
+                      size_t &first_off, size_t &chunk_off, int &nchunks, int align16 = 0);
 
 int x265amd_bipred_batch_dev(x265amd_ctx *c, const x265amd_plane *fenc, const x265amd_plane *ref0, const x265amd_plane *ref1,
                              const x265amd_bipred_job *d_jobs, int njobs, x265amd_bipred_result *d_results)
@@ -1621,17 +1621,27 @@ int x265amd_merge_sa8d_batch(x265amd_ctx *c, const x265amd_plane *fenc, const x2
     int rc;
     PlaneDev hp[32];
     for (int i = 0; i < nrefs; i++) { hp[i].origin = refs[i].origin; hp[i].stride = refs[i].stride; }
-    const size_t jb = (size_t)njobs * sizeof(x265amd_merge_job), pb = sizeof(PlaneDev) * 32;
-    if ((rc = ensure(c, &c->d_jobs, &c->jobs_cap, jb + pb))) return rc;
+    /* tiles numbered on the host (CU sizes are visible here); waves take 64 of them at a time */
+    std::vector<int> tiles(njobs);
+    for (int i = 0; i < njobs; i++) tiles[i] = (jobs[i].size >> 2) * (jobs[i].size >> 2);
+    std::vector<char> blob;
+    MergeFlatArgs fa;
+    size_t first_off, chunk_off;
+    flat_plan(jobs, sizeof(x265amd_merge_job), njobs, tiles, blob, first_off, chunk_off, fa.nchunks, 1);
+    const size_t pb = sizeof(PlaneDev) * 32;
+    if ((rc = ensure(c, &c->d_jobs, &c->jobs_cap, pb + blob.size()))) return rc;
     if ((rc = ensure(c, &c->d_results, &c->results_cap, (size_t)njobs * sizeof(int32_t)))) return rc;
     HIPCHK(c, hipMemcpyAsync(c->d_jobs, hp, sizeof(PlaneDev) * nrefs, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, hipMemcpyAsync((char*)c->d_jobs + pb, jobs, jb, hipMemcpyHostToDevice, c->stream));
-    MergeArgs a;
+    HIPCHK(c, hipMemcpyAsync((char*)c->d_jobs + pb, blob.data(), blob.size(), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemsetAsync(c->d_results, 0, (size_t)njobs * sizeof(int32_t), c->stream));
+    MergeArgs &a = fa.m;
     a.fenc.origin = fenc->origin; a.fenc.stride = fenc->stride;
     a.refs = (const PlaneDev*)c->d_jobs; a.depth = c->depth; a.njobs = njobs;
     a.jobs = (const x265amd_merge_job*)((char*)c->d_jobs + pb); a.out = (int32_t*)c->d_results;
-    if (c->depth <= 8) hipLaunchKernelGGL(merge_sa8d_kernel<uint8_t>, dim3(njobs), dim3(64), 0, c->stream, a);
-    else hipLaunchKernelGGL(merge_sa8d_kernel<uint16_t>, dim3(njobs), dim3(64), 0, c->stream, a);
+    fa.first = (const int32_t*)((const char*)a.jobs + first_off);
+    fa.chunk_job = (const int32_t*)((const char*)a.jobs + chunk_off);
+    if (c->depth <= 8) hipLaunchKernelGGL(merge_flat_kernel<uint8_t>, dim3(fa.nchunks), dim3(64), 0, c->stream, fa);
+    else hipLaunchKernelGGL(merge_flat_kernel<uint16_t>, dim3(fa.nchunks), dim3(64), 0, c->stream, fa);
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipMemcpyAsync(sa8d, c->d_results, (size_t)njobs * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -1734,26 +1744,36 @@ static int mc_validate(x265amd_ctx *c, const x265amd_picture *refs, const x265am
 }
 
 /* Numbers the 4x4 tiles of `njobs` records (tiles[i] each) consecutively and lays records | first[] | chunk_job[] out in
- * `blob`: first[] has njobs + 64 entries (the tail repeats the total), chunk_job[k] is the record tile 64 k belongs to */
+ * `blob`: first[] has njobs + 64 entries (the tail repeats the total), chunk_job[k] is the record tile 64 k belongs to.
+ * With align16 a record starts at a multiple of min(its tiles, 16); the tiles skipped belong to the record before. */
 static void flat_plan(const void *jobs, size_t job_size, int njobs, const std::vector<int> &tiles, std::vector<char> &blob,
-                      size_t &first_off, size_t &chunk_off, int &nchunks)
+                      size_t &first_off, size_t &chunk_off, int &nchunks, int align16)
 {
-    long total = 0;
-    for (int i = 0; i < njobs; i++) total += tiles[i];
-    nchunks = (int)((total + 63) / 64);
+    std::vector<int32_t> start(njobs + 1);
+    long run = 0;
+    for (int i = 0; i < njobs; i++)
+    {
+        if (align16)
+        {
+            const int al = tiles[i] < 16 ? tiles[i] : 16;
+            run = (run + al - 1) / al * al;
+        }
+        start[i] = (int32_t)run;
+        run += tiles[i];
+    }
+    start[njobs] = (int32_t)run;
+    nchunks = (int)((run + 63) / 64);
     first_off = ((size_t)njobs * job_size + 15) & ~(size_t)15;
     chunk_off = first_off + ((size_t)njobs + 64) * sizeof(int32_t);
     blob.assign(chunk_off + (size_t)nchunks * sizeof(int32_t), 0);
     memcpy(blob.data(), jobs, (size_t)njobs * job_size);
     int32_t *first = (int32_t*)(blob.data() + first_off), *chunk = (int32_t*)(blob.data() + chunk_off);
-    int32_t run = 0;
     for (int i = 0; i < njobs; i++)
     {
-        first[i] = run;
-        for (int k = (run + 63) / 64; 64 * k < run + tiles[i]; k++) chunk[k] = i;
-        run += tiles[i];
+        first[i] = start[i];
+        for (int k = (start[i] + 63) / 64; 64 * k < start[i + 1]; k++) chunk[k] = i;
     }
-    for (int i = 0; i < 64; i++) first[njobs + i] = run;
+    for (int i = 0; i < 64; i++) first[njobs + i] = start[njobs];
 }
 
 static void mc_plan(const x265amd_mc_job *jobs, int njobs, std::vector<char> &blob, x265amd_mc_list *l)

@@ -556,7 +556,7 @@ __global__ __launch_bounds__(64) void bipred_kernel(BipredArgs a)
 }
 
 /* ---- merge-candidate estimate of the CU analysis (compress.cpp:248-271) ----
- * One wave per candidate, a lane per 4x4 tile. Lanes are ordered so that a quad of lanes is an
+ * A lane per 4x4 tile (merge_flat_kernel, further down). Lanes are ordered so that a quad of lanes is an
  * 8x8 block (2 x 2 tiles) and sixteen lanes a 16x16 block: the 8x8 Hadamard of sa8d is the 4x4
  * Hadamard of each tile followed by sum / difference steps across the quad (DPP), and the 16x16
  * rounding of sa8d_16x16 (pixel.cpp:332-342) is a sum over sixteen lanes. */
@@ -645,100 +645,6 @@ __device__ __forceinline__ void mc_short_tile(const P AS1 *r, int stride, int qx
             o[y][x] = xf == 0 ? as_i16((sum + off) >> shift) : as_i16(sum >> 6);
         }
     }
-}
-
-template<typename P>
-__global__ __launch_bounds__(64) void merge_sa8d_kernel(MergeArgs a)
-{
-    const int j = blockIdx.x;
-    if (j >= a.njobs) return;
-    const x265amd_merge_job *job = a.jobs + j;
-    const int lane = threadIdx.x & 63;
-    const int size = uni(job->size), dir = uni(job->dir), pux = uni(job->pu_x), puy = uni(job->pu_y);
-    const int m0x = uni(job->mv0[0]), m0y = uni(job->mv0[1]), m1x = uni(job->mv1[0]), m1y = uni(job->mv1[1]);
-    const PlaneDev r0 = a.refs[uni(job->ref0)], r1 = a.refs[uni(job->ref1)];
-    const int T = (size >> 2) * (size >> 2), g16 = size >> 4;       /* tiles; 16x16 blocks per row (0 for an 8x8 CU) */
-    const int maxv = (1 << a.depth) - 1;
-    int total = 0;
-    for (int t0 = 0; t0 < T; t0 += 64)
-    {
-        const int t = t0 + lane;
-        const bool live = t < T;
-        /* lane -> tile: bits 0-1 the tile inside its 8x8 block, bits 2-3 the 8x8 block inside its 16x16 block */
-        const int tt = live ? t : 0, g = tt >> 4;
-        const int gy = g16 ? g / g16 : 0, gx = g16 ? g - gy * g16 : 0;
-        const int ty = gy * 4 + ((tt >> 3) & 1) * 2 + ((tt >> 1) & 1), tx = gx * 4 + ((tt >> 2) & 1) * 2 + (tt & 1);
-        const long fo = (long)(puy + 4 * ty) * a.fenc.stride + pux + 4 * tx;
-        const long o0 = (long)(puy + 4 * ty) * r0.stride + pux + 4 * tx, o1 = (long)(puy + 4 * ty) * r1.stride + pux + 4 * tx;
-        int p[4][4];
-        if (dir == 3)
-        {
-            int s1[4][4];
-            mc_short_tile<P>((const P AS1*)r0.origin + o0, r0.stride, m0x, m0y, a.depth, p);
-            mc_short_tile<P>((const P AS1*)r1.origin + o1, r1.stride, m1x, m1y, a.depth, s1);
-            /* TComYuv::addAvg, TComYuv.cpp:596-606 */
-            const int shiftNum = 15 - a.depth, offset = (1 << (shiftNum - 1)) + 2 * 8192;
-#pragma unroll
-            for (int y = 0; y < 4; y++)
-#pragma unroll
-                for (int x = 0; x < 4; x++)
-                {
-                    const int v = (p[y][x] + s1[y][x] + offset) >> shiftNum;
-                    p[y][x] = v < 0 ? 0 : (v > maxv ? maxv : v);
-                }
-        }
-        else if (dir == 2)
-            bipred_tile<P>((const P AS1*)r1.origin + o1, r1.stride, m1x, m1y, a.depth, p);
-        else
-            bipred_tile<P>((const P AS1*)r0.origin + o0, r0.stride, m0x, m0y, a.depth, p);
-        int d[4][4];
-#pragma unroll
-        for (int y = 0; y < 4; y++)
-        {
-            int fv[4];
-            Px<P>::unpack(Px<P>::load_g((const P AS1*)a.fenc.origin + fo + (long)y * a.fenc.stride), fv);
-#pragma unroll
-            for (int x = 0; x < 4; x++) d[y][x] = fv[x] - p[y][x];
-        }
-        /* 4x4 Hadamard of the tile, rows then columns */
-#pragma unroll
-        for (int y = 0; y < 4; y++)
-        {
-            const int a0 = d[y][0] + d[y][1], a1 = d[y][0] - d[y][1], a2 = d[y][2] + d[y][3], a3 = d[y][2] - d[y][3];
-            d[y][0] = a0 + a2; d[y][1] = a1 + a3; d[y][2] = a0 - a2; d[y][3] = a1 - a3;
-        }
-        int s = 0;
-        const int n1 = -(lane & 1), n2 = -((lane >> 1) & 1);
-#pragma unroll
-        for (int x = 0; x < 4; x++)
-        {
-            const int a0 = d[0][x] + d[1][x], a1 = d[0][x] - d[1][x], a2 = d[2][x] + d[3][x], a3 = d[2][x] - d[3][x];
-            int c[4] = { a0 + a2, a1 + a3, a0 - a2, a1 - a3 };
-#pragma unroll
-            for (int i = 0; i < 4; i++)
-            {
-                /* the 8-point steps across the 2 x 2 tiles of the block: the lower lane of a pair
-                 * keeps the sum, the upper one the difference */
-                int v = c[i];
-                v = ((v ^ n1) - n1) + dpp_all<0xB1>(v);
-                v = ((v ^ n2) - n2) + dpp_all<0x4E>(v);
-                s += abs(v);
-            }
-        }
-        s = live ? s : 0;
-        if (g16)
-        {
-            s = seg_sum(s, 4);                                   /* sa8d_16x16: four 8x8 sums, rounded once */
-            total += (live && (lane & 15) == 0) ? (s + 2) >> 2 : 0;
-        }
-        else
-        {
-            s = seg_sum(s, 2);                                   /* sa8d_8x8 */
-            total += (live && (lane & 3) == 0) ? (s + 2) >> 2 : 0;
-        }
-    }
-    total = seg_sum(total, 6);
-    if (lane == 0) a.out[j] = total;
 }
 
 /* ---- motion compensation into a prediction picture, luma + 4:2:0 chroma ----
@@ -1104,13 +1010,15 @@ template<> struct PxStore<uint16_t>
 /* Lane -> (PU, tile) for kernels whose waves take 64 consecutive tiles of a launch, whatever PUs they belong to.
  * first[j] = first tile of PU j (njobs + 64 entries, the tail repeating the tile total); chunk_job[k] = the PU that tile
  * 64 k belongs to. The lanes find their PU from the 64 entries of first[] after the chunk's PU: a flag in LDS where a PU
- * starts, one ballot, a bit count. Returns false for lanes past the last tile. */
-__device__ __forceinline__ bool flat_tile_of_lane(const int32_t *first, const int32_t *chunk_job, int nchunks, int njobs, int &j, int &t)
+ * starts, one ballot, a bit count. Returns false for lanes past the last tile; with may_leave = false those lanes get the
+ * last PU and tile 0, so that a kernel with cross-lane steps can keep the whole wave running. */
+__device__ __forceinline__ bool flat_tile_of_lane(const int32_t *first, const int32_t *chunk_job, int nchunks, int njobs, int &j, int &t,
+                                                  bool may_leave = true)
 {
     __shared__ int32_t starts[64];
     __shared__ int32_t flags[64];
     const int k = xcd_remap(blockIdx.x, nchunks);
-    if (k >= nchunks) return false;
+    if (k >= nchunks) { j = njobs - 1; t = 0; return false; }       /* never taken: the grid is nchunks */
     const int lane = threadIdx.x & 63;
     const int j0 = uni(chunk_job[k]), g = 64 * k + lane;
     const int my_start = first[j0 + lane];
@@ -1124,7 +1032,11 @@ __device__ __forceinline__ bool flat_tile_of_lane(const int32_t *first, const in
     const unsigned long long m = __ballot(f);
     const int off = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0)) + f;
     j = j0 + off;
-    if (j >= njobs) return false;             /* tiles past the last PU (only in the last wave) */
+    if (j >= njobs)                           /* tiles past the last PU (only in the last wave) */
+    {
+        j = njobs - 1; t = 0;
+        return false;
+    }
     t = g - starts[off];
     return true;
 }
@@ -1252,7 +1164,105 @@ __global__ __launch_bounds__(64) void bipred_flat_kernel(BipredFlatArgs fa)
     }
 }
 
+/* The merge-candidate estimate with 64 consecutive tiles per wave. The plan starts every CU at a multiple of 4 tiles
+ * (8x8 CUs) or 16 tiles (larger ones), so a quad of lanes is still an 8x8 block and sixteen lanes a 16x16 block, as the
+ * sa8d butterflies across lanes need; lanes in the padding between two CUs compute a dummy tile and add nothing. The
+ * launch zeroes the results; per CU and wave the block sums are added up by neighbours and one lane adds them in. */
+struct MergeFlatArgs
+{
+    MergeArgs m;
+    const int32_t *first, *chunk_job;
+    int nchunks;
+};
+
+template<typename P>
+__global__ __launch_bounds__(64) void merge_flat_kernel(MergeFlatArgs fa)
+{
+    const MergeArgs &a = fa.m;
+    const int lane = threadIdx.x & 63;
+    int j, t;
+    bool live = flat_tile_of_lane(fa.first, fa.chunk_job, fa.nchunks, a.njobs, j, t, false);
+    const x265amd_merge_job *job = a.jobs + j;
+    const int size = job->size, dir = job->dir, pux = job->pu_x, puy = job->pu_y;
+    const int m0x = job->mv0[0], m0y = job->mv0[1], m1x = job->mv1[0], m1y = job->mv1[1];
+    const PlaneDev r0 = a.refs[job->ref0], r1 = a.refs[job->ref1];
+    const int T = (size >> 2) * (size >> 2), g16 = size >> 4;
+    live = live && t < T;
+    const int maxv = (1 << a.depth) - 1;
+    /* tile number -> tile: bits 0-1 the tile inside its 8x8 block, bits 2-3 the 8x8 block inside its 16x16 block */
+    const int tt = live ? t : 0, g = tt >> 4;
+    const int gy = g16 ? g / g16 : 0, gx = g16 ? g - gy * g16 : 0;
+    const int ty = gy * 4 + ((tt >> 3) & 1) * 2 + ((tt >> 1) & 1), tx = gx * 4 + ((tt >> 2) & 1) * 2 + (tt & 1);
+    const long fo = (long)(puy + 4 * ty) * a.fenc.stride + pux + 4 * tx;
+    const long o0 = (long)(puy + 4 * ty) * r0.stride + pux + 4 * tx, o1 = (long)(puy + 4 * ty) * r1.stride + pux + 4 * tx;
+    int p[4][4];
+    if (dir == 3)
+    {
+        int s1[4][4];
+        mc_short_tile<P>((const P AS1*)r0.origin + o0, r0.stride, m0x, m0y, a.depth, p);
+        mc_short_tile<P>((const P AS1*)r1.origin + o1, r1.stride, m1x, m1y, a.depth, s1);
+        const int shiftNum = 15 - a.depth, offset = (1 << (shiftNum - 1)) + 2 * 8192;
+#pragma unroll
+        for (int y = 0; y < 4; y++)
+#pragma unroll
+            for (int x = 0; x < 4; x++)
+            {
+                const int v = (p[y][x] + s1[y][x] + offset) >> shiftNum;
+                p[y][x] = v < 0 ? 0 : (v > maxv ? maxv : v);
+            }
+    }
+    else if (dir == 2)
+        bipred_tile<P>((const P AS1*)r1.origin + o1, r1.stride, m1x, m1y, a.depth, p);
+    else
+        bipred_tile<P>((const P AS1*)r0.origin + o0, r0.stride, m0x, m0y, a.depth, p);
+    int d[4][4];
+#pragma unroll
+    for (int y = 0; y < 4; y++)
+    {
+        int fv[4];
+        Px<P>::unpack(Px<P>::load_g((const P AS1*)a.fenc.origin + fo + (long)y * a.fenc.stride), fv);
+#pragma unroll
+        for (int x = 0; x < 4; x++) d[y][x] = fv[x] - p[y][x];
+    }
+#pragma unroll
+    for (int y = 0; y < 4; y++)
+    {
+        const int a0 = d[y][0] + d[y][1], a1 = d[y][0] - d[y][1], a2 = d[y][2] + d[y][3], a3 = d[y][2] - d[y][3];
+        d[y][0] = a0 + a2; d[y][1] = a1 + a3; d[y][2] = a0 - a2; d[y][3] = a1 - a3;
+    }
+    int s = 0;
+    const int n1 = -(lane & 1), n2 = -((lane >> 1) & 1);
+#pragma unroll
+    for (int x = 0; x < 4; x++)
+    {
+        const int a0 = d[0][x] + d[1][x], a1 = d[0][x] - d[1][x], a2 = d[2][x] + d[3][x], a3 = d[2][x] - d[3][x];
+        int c[4] = { a0 + a2, a1 + a3, a0 - a2, a1 - a3 };
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+        {
+            int v = c[i];
+            v = ((v ^ n1) - n1) + dpp_all<0xB1>(v);
+            v = ((v ^ n2) - n2) + dpp_all<0x4E>(v);
+            s += abs(v);
+        }
+    }
+    s = live ? s : 0;
+    /* sa8d_8x8 rounds per 8x8 block, sa8d_16x16 once per 16x16 block (pixel.cpp:290-342) */
+    const int s4 = seg_sum(s, 2), s16 = seg_sum(s, 4);
+    int total = g16 ? ((live && (lane & 15) == 0) ? (s16 + 2) >> 2 : 0) : ((live && (lane & 3) == 0) ? (s4 + 2) >> 2 : 0);
+    const int key = live ? j : -1 - lane;
+#pragma unroll
+    for (int dd = 1; dd < 64; dd <<= 1)
+    {
+        const int pk = __shfl_down(key, dd), pv = __shfl_down(total, dd);
+        total += (lane + dd < 64 && pk == key) ? pv : 0;
+    }
+    const int prev = __shfl_up(key, 1);
+    if (live && (lane == 0 || prev != key)) atomicAdd(&a.out[j], total);
+}
+
 } // namespace x265amd
+
 
 
 
