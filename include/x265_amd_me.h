@@ -283,6 +283,20 @@ int x265amd_bipred_batch(x265amd_ctx *ctx, const x265amd_plane *fenc, const x265
 int x265amd_bipred_batch_dev(x265amd_ctx *ctx, const x265amd_plane *fenc, const x265amd_plane *ref0, const x265amd_plane *ref1,
                              const x265amd_bipred_job *d_jobs, int njobs, x265amd_bipred_result *d_results);
 
+/* The same estimate for a list of PUs that is checked and laid out once and launched asynchronously on the engine's
+ * stream (x265amd_bipred_batch_dev cannot see the PU sizes and runs one wave per PU; a list knows them and fills its
+ * waves with 4x4 tiles of neighbouring PUs). d_results0 / d_results1, when not NULL, are device-resident outputs of
+ * x265amd_search_batch_dev for the same PUs in the same order, launched earlier on the stream: PU i then takes its
+ * list-0 / list-1 MV from them instead of from its job record (predInterSearch's sequence, TEncSearch.cpp:4303 then
+ * :4346-4368, without a host round trip; such MVs are not validated). d_out: njobs device records. */
+typedef struct x265amd_bipred_list x265amd_bipred_list;
+int x265amd_bipred_list_create(x265amd_ctx *ctx, const x265amd_plane *fenc, const x265amd_plane *ref0, const x265amd_plane *ref1,
+                               const x265amd_bipred_job *jobs, int njobs, x265amd_bipred_list **out);
+int x265amd_bipred_list_free(x265amd_ctx *ctx, x265amd_bipred_list *list);
+int x265amd_bipred_batch_list(x265amd_ctx *ctx, const x265amd_plane *fenc, const x265amd_plane *ref0, const x265amd_plane *ref1,
+                              const x265amd_bipred_list *list, const x265amd_result *d_results0, const x265amd_result *d_results1,
+                              x265amd_bipred_result *d_out);
+
 /* ---- merge-candidate estimate ---- */
 
 /* The distortion of the merge candidates of a 2Nx2N CU (encoder/compress.cpp:248-271): luma motion

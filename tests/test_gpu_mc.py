@@ -201,6 +201,21 @@ def test_search_then_mc_on_device(engine8, oracle):
     want = np.array([oracle.sa8d_inter(8, fe, fo + int(j["pu_y"]) * fs + int(j["pu_x"]), fs, exp[0][0], int(j["pu_y"]) * W + int(j["pu_x"]), W, 16, 16)
                      for j in cj], np.int32)
     assert np.array_equal(got, want) and got.min() >= 0 and got.max() > 0
+    # the bi-prediction estimate of the same PUs, MVs again straight from the two result arrays
+    from x265_amd.engine import BIPRED_JOB_DTYPE, BIPRED_RESULT_DTYPE
+    bj = np.zeros(len(jobs), BIPRED_JOB_DTYPE)
+    for f in ("pu_x", "pu_y", "w", "h"):
+        bj[f] = jobs[f]
+    bl = e.bipred_list_create(pics[1].y, pics[0].y, pics[2].y, bj)
+    d_bi = e.device_alloc(len(bj) * BIPRED_RESULT_DTYPE.itemsize)
+    e.bipred_batch_list(pics[1].y, pics[0].y, pics[2].y, bl, d_bi, d_res[0], d_res[1])
+    e.bipred_batch_list(pics[1].y, pics[0].y, pics[2].y, bl, d_bi, d_res[0], d_res[1])      # a list can be launched again
+    got_bi = e.download(d_bi, len(bj), BIPRED_RESULT_DTYPE)
+    bj["mv0"], bj["mv1"] = res[0]["mv"], res[1]["mv"]
+    exp_bi = oracle.bipred_batch(8, host[1][0][0], host[0][0][0], host[2][0][0], host[1][0][1], host[1][0][2], bj)
+    assert np.array_equal(got_bi["satd"], exp_bi[:, 0]) and np.array_equal(got_bi["satd_zero"], exp_bi[:, 1])
+    e.bipred_list_free(bl)
+    e.device_free(d_bi)
     e.mc_list_free(lst)
     for d in [d_jobs, d_planes] + d_res:
         e.device_free(d)

@@ -1535,11 +1535,11 @@ int x265amd_bipred_batch_dev(x265amd_ctx *c, const x265amd_plane *fenc, const x2
     return X265AMD_OK;
 }
 
-int x265amd_bipred_batch(x265amd_ctx *c, const x265amd_plane *fenc, const x265amd_plane *ref0, const x265amd_plane *ref1,
-                         const x265amd_bipred_job *jobs, int njobs, x265amd_bipred_result *results)
+static int bipred_validate(x265amd_ctx *c, const x265amd_plane *fenc, const x265amd_plane *ref0, const x265amd_plane *ref1,
+                           const x265amd_bipred_job *jobs, int njobs)
 {
-    if (!c || !fenc || !ref0 || !ref1 || !jobs || !results || njobs < 0) return fail(c, X265AMD_EINVAL, "null argument");
-    if (!njobs) return X265AMD_OK;
+    if (!c || !fenc || !ref0 || !ref1 || !fenc->origin || !ref0->origin || !ref1->origin || !jobs || njobs < 0)
+        return fail(c, X265AMD_EINVAL, "null argument");
     const x265amd_plane *refs[2] = { ref0, ref1 };
     for (int i = 0; i < njobs; i++)
     {
@@ -1558,33 +1558,112 @@ int x265amd_bipred_batch(x265amd_ctx *c, const x265amd_plane *fenc, const x265am
                 return fail(c, X265AMD_EINVAL, "job: prediction block leaves the padded reference plane");
         }
     }
-    HIPCHK(c, hipSetDevice(c->device));
-    int rc;
-    /* host job arrays show their sizes: tiles are numbered here and waves take 64 of them at a time, whatever PUs they
-     * belong to (the device-resident entry point above cannot see the sizes and runs one wave per PU) */
-    std::vector<int> tiles(njobs);
-    for (int i = 0; i < njobs; i++) tiles[i] = (jobs[i].w >> 2) * (jobs[i].h >> 2);
-    std::vector<char> blob;
-    BipredFlatArgs fa;
+    return X265AMD_OK;
+}
+
+struct x265amd_bipred_list
+{
+    void *d_blob;              /* jobs | first[njobs + 64] | chunk_job[nchunks] */
     size_t first_off, chunk_off;
-    flat_plan(jobs, sizeof(x265amd_bipred_job), njobs, tiles, blob, first_off, chunk_off, fa.nchunks);
-    if ((rc = ensure(c, &c->d_jobs, &c->jobs_cap, blob.size()))) return rc;
-    if ((rc = ensure(c, &c->d_results, &c->results_cap, (size_t)njobs * sizeof(x265amd_bipred_result)))) return rc;
-    HIPCHK(c, hipMemcpyAsync(c->d_jobs, blob.data(), blob.size(), hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, hipMemsetAsync(c->d_results, 0, (size_t)njobs * sizeof(x265amd_bipred_result), c->stream));
+    int njobs, nchunks;
+};
+
+/* zeroes d_out and launches the 64-tiles-per-wave kernel on the engine's stream */
+static int bipred_flat_launch(x265amd_ctx *c, const x265amd_plane *fenc, const x265amd_plane *ref0, const x265amd_plane *ref1,
+                              const void *d_blob, const x265amd_bipred_list *l, const x265amd_result *res0, const x265amd_result *res1,
+                              x265amd_bipred_result *d_out)
+{
+    HIPCHK(c, hipMemsetAsync(d_out, 0, (size_t)l->njobs * sizeof(x265amd_bipred_result), c->stream));
+    BipredFlatArgs fa;
     fa.b.fenc.origin = fenc->origin; fa.b.fenc.stride = fenc->stride;
     fa.b.ref0.origin = ref0->origin; fa.b.ref0.stride = ref0->stride;
     fa.b.ref1.origin = ref1->origin; fa.b.ref1.stride = ref1->stride;
-    fa.b.depth = c->depth; fa.b.njobs = njobs;
-    fa.b.jobs = (const x265amd_bipred_job*)c->d_jobs; fa.b.results = (x265amd_bipred_result*)c->d_results;
-    fa.first = (const int32_t*)((const char*)c->d_jobs + first_off);
-    fa.chunk_job = (const int32_t*)((const char*)c->d_jobs + chunk_off);
+    fa.b.depth = c->depth; fa.b.njobs = l->njobs;
+    fa.b.jobs = (const x265amd_bipred_job*)d_blob; fa.b.results = d_out;
+    fa.first = (const int32_t*)((const char*)d_blob + l->first_off);
+    fa.chunk_job = (const int32_t*)((const char*)d_blob + l->chunk_off);
+    fa.nchunks = l->nchunks;
+    fa.res0 = res0; fa.res1 = res1;
     if (c->depth <= 8) hipLaunchKernelGGL(bipred_flat_kernel<uint8_t>, dim3(fa.nchunks), dim3(64), 0, c->stream, fa);
     else hipLaunchKernelGGL(bipred_flat_kernel<uint16_t>, dim3(fa.nchunks), dim3(64), 0, c->stream, fa);
     HIPCHK(c, hipGetLastError());
+    return X265AMD_OK;
+}
+
+static void bipred_plan(const x265amd_bipred_job *jobs, int njobs, std::vector<char> &blob, x265amd_bipred_list *l)
+{
+    /* host job arrays show their sizes: tiles are numbered here and waves take 64 of them at a time, whatever PUs they
+     * belong to (x265amd_bipred_batch_dev cannot see the sizes and runs one wave per PU) */
+    std::vector<int> tiles(njobs);
+    for (int i = 0; i < njobs; i++) tiles[i] = (jobs[i].w >> 2) * (jobs[i].h >> 2);
+    l->njobs = njobs;
+    flat_plan(jobs, sizeof(x265amd_bipred_job), njobs, tiles, blob, l->first_off, l->chunk_off, l->nchunks);
+}
+
+int x265amd_bipred_batch(x265amd_ctx *c, const x265amd_plane *fenc, const x265amd_plane *ref0, const x265amd_plane *ref1,
+                         const x265amd_bipred_job *jobs, int njobs, x265amd_bipred_result *results)
+{
+    if (!results) return fail(c, X265AMD_EINVAL, "null argument");
+    int rc = bipred_validate(c, fenc, ref0, ref1, jobs, njobs);
+    if (rc) return rc;
+    if (!njobs) return X265AMD_OK;
+    HIPCHK(c, hipSetDevice(c->device));
+    x265amd_bipred_list l;
+    std::vector<char> blob;
+    bipred_plan(jobs, njobs, blob, &l);
+    if ((rc = ensure(c, &c->d_jobs, &c->jobs_cap, blob.size()))) return rc;
+    if ((rc = ensure(c, &c->d_results, &c->results_cap, (size_t)njobs * sizeof(x265amd_bipred_result)))) return rc;
+    HIPCHK(c, hipMemcpyAsync(c->d_jobs, blob.data(), blob.size(), hipMemcpyHostToDevice, c->stream));
+    if ((rc = bipred_flat_launch(c, fenc, ref0, ref1, c->d_jobs, &l, 0, 0, (x265amd_bipred_result*)c->d_results))) return rc;
     HIPCHK(c, hipMemcpyAsync(results, c->d_results, (size_t)njobs * sizeof(x265amd_bipred_result), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return X265AMD_OK;
+}
+
+int x265amd_bipred_list_create(x265amd_ctx *c, const x265amd_plane *fenc, const x265amd_plane *ref0, const x265amd_plane *ref1,
+                               const x265amd_bipred_job *jobs, int njobs, x265amd_bipred_list **out)
+{
+    if (!out) return fail(c, X265AMD_EINVAL, "null argument");
+    int rc = bipred_validate(c, fenc, ref0, ref1, jobs, njobs);
+    if (rc) return rc;
+    x265amd_bipred_list *l = new x265amd_bipred_list();
+    std::vector<char> blob;
+    bipred_plan(jobs, njobs, blob, l);
+    hipError_t e = hipSetDevice(c->device);
+    if (e == hipSuccess) e = hipMalloc(&l->d_blob, blob.size() + 16);
+    if (e == hipSuccess) e = hipMemcpyAsync(l->d_blob, blob.data(), blob.size(), hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    if (e != hipSuccess)
+    {
+        if (l->d_blob) (void)hipFree(l->d_blob);
+        delete l;
+        HIPCHK(c, e);
+    }
+    *out = l;
+    return X265AMD_OK;
+}
+
+int x265amd_bipred_list_free(x265amd_ctx *c, x265amd_bipred_list *l)
+{
+    if (!c) return X265AMD_EINVAL;
+    if (!l) return X265AMD_OK;
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    hipError_t e = hipFree(l->d_blob);
+    delete l;
+    HIPCHK(c, e);
+    return X265AMD_OK;
+}
+
+int x265amd_bipred_batch_list(x265amd_ctx *c, const x265amd_plane *fenc, const x265amd_plane *ref0, const x265amd_plane *ref1,
+                              const x265amd_bipred_list *l, const x265amd_result *d_results0, const x265amd_result *d_results1,
+                              x265amd_bipred_result *d_out)
+{
+    if (!c || !fenc || !ref0 || !ref1 || !fenc->origin || !ref0->origin || !ref1->origin || !l || !d_out)
+        return fail(c, X265AMD_EINVAL, "null argument");
+    if (!l->njobs) return X265AMD_OK;
+    HIPCHK(c, hipSetDevice(c->device));
+    return bipred_flat_launch(c, fenc, ref0, ref1, l->d_blob, l, d_results0, d_results1, d_out);
 }
 
 /* ---- merge-candidate estimate ---- */

@@ -1115,6 +1115,7 @@ struct BipredFlatArgs
     BipredArgs b;
     const int32_t *first, *chunk_job;
     int nchunks;
+    const x265amd_result *res0, *res1;   /* optional: search results that supply the MVs of list 0 / list 1 */
 };
 
 template<typename P>
@@ -1138,8 +1139,11 @@ __global__ __launch_bounds__(64) void bipred_flat_kernel(BipredFlatArgs fa)
     }
     const int zero = tile_cost_quads<P>(f, z, true);
     int o0[4][4], o1[4][4];
-    bipred_tile<P>((const P AS1*)a.ref0.origin + r0o, a.ref0.stride, job->mv0[0], job->mv0[1], a.depth, o0);
-    bipred_tile<P>((const P AS1*)a.ref1.origin + r1o, a.ref1.stride, job->mv1[0], job->mv1[1], a.depth, o1);
+    int m0x = job->mv0[0], m0y = job->mv0[1], m1x = job->mv1[0], m1y = job->mv1[1];
+    if (fa.res0) { m0x = fa.res0[j].mv[0]; m0y = fa.res0[j].mv[1]; }
+    if (fa.res1) { m1x = fa.res1[j].mv[0]; m1y = fa.res1[j].mv[1]; }
+    bipred_tile<P>((const P AS1*)a.ref0.origin + r0o, a.ref0.stride, m0x, m0y, a.depth, o0);
+    bipred_tile<P>((const P AS1*)a.ref1.origin + r1o, a.ref1.stride, m1x, m1y, a.depth, o1);
 #pragma unroll
     for (int y = 0; y < 4; y++)
 #pragma unroll

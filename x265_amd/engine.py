@@ -380,6 +380,21 @@ class Engine:
         self._chk(self.L.x265amd_bipred_batch_dev(self.ctx, C.byref(fenc), C.byref(ref0), C.byref(ref1), C.c_void_p(d_jobs), njobs,
                                                   C.c_void_p(d_results)))
 
+    def bipred_list_create(self, fenc, ref0, ref1, jobs):
+        jobs = np.ascontiguousarray(jobs, BIPRED_JOB_DTYPE)
+        h = C.c_void_p()
+        self._chk(self.L.x265amd_bipred_list_create(self.ctx, C.byref(fenc), C.byref(ref0), C.byref(ref1), C.c_void_p(jobs.ctypes.data),
+                                                    len(jobs), C.byref(h)))
+        return h
+
+    def bipred_list_free(self, h):
+        self._chk(self.L.x265amd_bipred_list_free(self.ctx, h))
+
+    def bipred_batch_list(self, fenc, ref0, ref1, blist, d_out, d_results0=None, d_results1=None):
+        """Launches a list asynchronously; d_results0 / d_results1: device search results that supply the MVs."""
+        self._chk(self.L.x265amd_bipred_batch_list(self.ctx, C.byref(fenc), C.byref(ref0), C.byref(ref1), blist,
+                                                   C.c_void_p(d_results0), C.c_void_p(d_results1), C.c_void_p(d_out)))
+
     # ---- merge-candidate estimate
     def merge_sa8d_batch(self, fenc, refs, jobs):
         jobs = np.ascontiguousarray(jobs, MERGE_JOB_DTYPE)
