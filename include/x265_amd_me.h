@@ -387,6 +387,14 @@ int x265amd_mc_batch_dev(x265amd_ctx *ctx, const void *d_ref_planes, const x265a
 int x265amd_mc_batch_dev_mv(x265amd_ctx *ctx, const void *d_ref_planes, const x265amd_picture *pred, const x265amd_mc_list *list,
                             const x265amd_result *d_results0, const x265amd_result *d_results1);
 
+/* The launch plan behind x265amd_mc_*, x265amd_bipred_batch / _list and x265amd_merge_sa8d_batch, as a pure host
+ * function (no counterpart in the reference; exported so that it can be checked without a GPU): the 4x4 tiles of n
+ * records with tiles[i] tiles each are numbered consecutively; first[i] (n + 64 entries, the tail repeating the total)
+ * is the first tile of record i, chunk_job[k] (*nchunks entries, capacity total / 64 + n / 4 + 2 is always enough) the
+ * record that tile 64 k belongs to. With align16 a record starts at a multiple of min(tiles[i], 16) and the tiles
+ * skipped belong to the record before. Needs no context; returns X265AMD_EINVAL for a tile count below 1. */
+int x265amd_tile_plan(const int32_t *tiles, int n, int align16, int32_t *first, int32_t *chunk_job, int *nchunks);
+
 /* ---- Rockchip path (rd >= 5): CIME + RIME + FME ---- */
 
 /* One 64x64 CTU against one reference picture: everything the 15-argument

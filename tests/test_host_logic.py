@@ -118,3 +118,36 @@ def test_two_rank_gather_over_gloo(tmp_path):
     outs = [p.communicate(timeout=240)[0] for p in procs]
     assert all(p.returncode == 0 for p in procs), outs
     assert "GATHER_OK" in outs[0]
+
+
+def test_tile_plan_properties():
+    """The launch plan of the tile-per-lane kernels (host code inside the library, no GPU needed): every record's tiles are
+    consecutive, records follow each other without overlap, aligned records start where the cross-lane steps need them,
+    and each 64-tile chunk names the record that owns its first tile (or the padding in front of the next one)."""
+    import ctypes as C
+    from x265_amd.engine import load_library
+    L = load_library()
+    rng = np.random.default_rng(3)
+    for align16 in (0, 1):
+        for n in (0, 1, 2, 63, 64, 65, 1000):
+            choices = np.array([4, 16, 64, 256]) if align16 else np.array([2, 3, 4, 6, 8, 12, 16, 24, 32, 48, 64, 96, 128, 192, 256])
+            tiles = rng.choice(choices, n).astype(np.int32)
+            first = np.zeros(n + 64, np.int32)
+            chunk = np.zeros(int(tiles.sum()) // 64 + n // 4 + 2, np.int32)
+            nch = C.c_int(-1)
+            assert L.x265amd_tile_plan(C.c_void_p(tiles.ctypes.data), n, align16, C.c_void_p(first.ctypes.data),
+                                       C.c_void_p(chunk.ctypes.data), C.byref(nch)) == 0
+            total = int(first[n])
+            assert (first[n:] == total).all() and nch.value == (total + 63) // 64
+            ends = first[:n] + tiles
+            assert (first[1:n] >= ends[:-1]).all() and (n == 0 or first[0] == 0) and (n == 0 or total == ends[-1])
+            if align16:
+                assert (first[:n] % np.minimum(tiles, 16) == 0).all() and (first[1:n] - ends[:-1] < 16).all()
+            else:
+                assert (first[1:n] == ends[:-1]).all()
+            for k in range(nch.value):
+                j = int(chunk[k])
+                assert first[j] <= 64 * k < first[j + 1] if j + 1 < n else first[j] <= 64 * k < total
+    bad = np.array([4, 0, 4], np.int32)
+    assert L.x265amd_tile_plan(C.c_void_p(bad.ctypes.data), 3, 0, C.c_void_p(first.ctypes.data), C.c_void_p(chunk.ctypes.data), C.byref(nch)) == -1
+

@@ -1855,6 +1855,20 @@ static void flat_plan(const void *jobs, size_t job_size, int njobs, const std::v
     for (int i = 0; i < 64; i++) first[njobs + i] = start[njobs];
 }
 
+int x265amd_tile_plan(const int32_t *tiles, int n, int align16, int32_t *first, int32_t *chunk_job, int *nchunks)
+{
+    if (!tiles || n < 0 || !first || !chunk_job || !nchunks) return X265AMD_EINVAL;
+    std::vector<int> t(tiles, tiles + n);
+    for (int i = 0; i < n; i++)
+        if (t[i] < 1) return X265AMD_EINVAL;
+    std::vector<char> blob, none(1);
+    size_t fo, co;
+    flat_plan(none.data(), 0, n, t, blob, fo, co, *nchunks, align16);
+    memcpy(first, blob.data() + fo, ((size_t)n + 64) * sizeof(int32_t));
+    memcpy(chunk_job, blob.data() + co, (size_t)*nchunks * sizeof(int32_t));
+    return X265AMD_OK;
+}
+
 static void mc_plan(const x265amd_mc_job *jobs, int njobs, std::vector<char> &blob, x265amd_mc_list *l)
 {
     std::vector<int> tiles(njobs);
