@@ -835,12 +835,12 @@ struct McTile
 /* xPredInterLumaBlk + xPredInterChromaBlk for one tile and one list (TComPrediction.cpp:405-593), pixel flavour or
  * (inter14) 14-bit flavour, chosen per lane. Every row the filters can touch is fetched first -- one wide load per row,
  * apron rows only where the vertical phase needs them -- so the loads of a tile are all in flight together; then the
- * separable filters run on registers. Phases differ between lanes, so the formulas are selected, not branched:
- *   H = sum of 8 (4) taps over the row; with a zero horizontal phase the row sample itself is used instead
- *   no vertical phase:  pixel = clip((H + 32) >> 6) or the sample;   14-bit = (H + offH) >> shiftH
+ * separable filters run on registers. Phases and flavours differ between lanes; the reference's formulas
+ *   no vertical phase:  pixel = clip((H + 32) >> 6) or a copy;       14-bit = (H + offH) >> shiftH or p2s
  *   vertical phase on samples (xf = 0): pixel = clip((V + 32) >> 6); 14-bit = (V + offH) >> shiftH
  *   vertical phase on intermediates:    pixel = clip((V + offV) >> shiftV); 14-bit = V >> 6
- * each through the reference's int16 cast (ipfilter.cpp:40-172, :194-435). */
+ * (each through an int16 cast; ipfilter.cpp:40-172, :194-435) differ only in offset, shift and clamp, which become
+ * per-lane parameters of one code path. */
 template<typename P>
 __device__ __forceinline__ void mc_predict(const McRef *ref, int lx, int ly, int cx, int cy, int mvx, int mvy, int depth, bool inter14,
                                            bool luma, bool chroma, McTile &o)
@@ -897,23 +897,25 @@ __device__ __forceinline__ void mc_predict(const McRef *ref, int lx, int ly, int
             }
         }
     }
+    /* Every stage is value = int16((sum + off) >> shift), then a clamp for finished samples; which flavour and which phases a
+     * lane has only changes off, shift and the clamp bounds, so they are per-lane parameters and the code is one formula.
+     * A zero horizontal phase runs through the phase-0 taps {.., 64, ..}: (64 p + 32) >> 6 = p, (64 p) >> 6 = p and
+     * (64 p + offH) >> shiftH = (p << headRoom) - 8192 are the copy, the vertical filter's sample input and p2s exactly. */
+    const int lo = inter14 ? -32768 : 0, hi = inter14 ? 32767 : maxv;
+    const int offR = inter14 ? offH : 32, shR = inter14 ? shiftH : 6;            /* result of the horizontal stage alone */
     /* ---- luma ---- */
     {
         const int (&cv)[8] = lv;
-        int im[11][4];          /* rows -3 .. 7: samples (xf = 0) or 14-bit horizontal intermediates */
+        const int offI = xf ? offH : 0, shI = xf ? shiftH : 6;                  /* input of the vertical stage */
+        const int offA = yf ? offI : offR, shA = yf ? shI : shR;
+        const int offB = xf ? (inter14 ? 0 : offV) : offR, shB = xf ? (inter14 ? 6 : shiftV) : shR;   /* vertical stage */
+        int im[11][4];          /* rows -3 .. 7 after the horizontal stage */
         auto hrow = [&](int r)
         {
             int Hs[4];
             L[r].hsum(th, Hs);
 #pragma unroll
-            for (int x = 0; x < 4; x++)
-            {
-                const int H = Hs[x];
-                const int hp = clip_pixel(as_i16((H + 32) >> 6), maxv), hs = as_i16((H + offH) >> shiftH);
-                /* rows 3..6 with no vertical phase are the result; elsewhere the vertical filter's input */
-                if (r >= 3 && r < 7) o.y[r - 3][x] = inter14 ? hs : (xf ? hp : L[r].px(x + 3));
-                im[r][x] = xf ? hs : L[r].px(x + 3);
-            }
+            for (int x = 0; x < 4; x++) im[r][x] = as_i16((Hs[x] + offA) >> shA);
         };
 #pragma unroll
         for (int r = 3; r < 7; r++) hrow(r);
@@ -931,15 +933,22 @@ __device__ __forceinline__ void mc_predict(const McRef *ref, int lx, int ly, int
                     int V = 0;
 #pragma unroll
                     for (int k = 0; k < 8; k++) V += im[y + k][x] * cv[k];
-                    const int a = xf ? as_i16(V >> 6) : as_i16((V + offH) >> shiftH);
-                    const int b = xf ? clip_pixel(as_i16((V + offV) >> shiftV), maxv) : clip_pixel(as_i16((V + 32) >> 6), maxv);
-                    o.y[y][x] = inter14 ? a : b;
+                    const int v = as_i16((V + offB) >> shB);
+                    o.y[y][x] = v < lo ? lo : (v > hi ? hi : v);
                 }
         }
+        else
+#pragma unroll
+            for (int y = 0; y < 4; y++)
+#pragma unroll
+                for (int x = 0; x < 4; x++) { const int v = im[y + 3][x]; o.y[y][x] = v < lo ? lo : (v > hi ? hi : v); }
     }
     /* ---- chroma ---- */
     {
         const int (&cv)[4] = kv;
+        const int offI = cxf ? offH : 0, shI = cxf ? shiftH : 6;
+        const int offA = cyf ? offI : offR, shA = cyf ? shI : shR;
+        const int offB = cxf ? (inter14 ? 0 : offV) : offR, shB = cxf ? (inter14 ? 6 : shiftV) : shR;
 #pragma unroll
         for (int c = 0; c < 2; c++)
         {
@@ -949,13 +958,7 @@ __device__ __forceinline__ void mc_predict(const McRef *ref, int lx, int ly, int
                 int Hs[2];
                 C[c][r].hsum(th, Hs);
 #pragma unroll
-                for (int x = 0; x < 2; x++)
-                {
-                    const int H = Hs[x];
-                    const int hp = clip_pixel(as_i16((H + 32) >> 6), maxv), hs = as_i16((H + offH) >> shiftH);
-                    if (r >= 1 && r < 3) o.c[c][r - 1][x] = inter14 ? hs : (cxf ? hp : C[c][r].px(x + 1));
-                    im[r][x] = cxf ? hs : C[c][r].px(x + 1);
-                }
+                for (int x = 0; x < 2; x++) im[r][x] = as_i16((Hs[x] + offA) >> shA);
             };
             hrow(1); hrow(2);
             if (cyf)
@@ -969,11 +972,15 @@ __device__ __forceinline__ void mc_predict(const McRef *ref, int lx, int ly, int
                         int V = 0;
 #pragma unroll
                         for (int k = 0; k < 4; k++) V += im[y + k][x] * cv[k];
-                        const int a = cxf ? as_i16(V >> 6) : as_i16((V + offH) >> shiftH);
-                        const int b = cxf ? clip_pixel(as_i16((V + offV) >> shiftV), maxv) : clip_pixel(as_i16((V + 32) >> 6), maxv);
-                        o.c[c][y][x] = inter14 ? a : b;
+                        const int v = as_i16((V + offB) >> shB);
+                        o.c[c][y][x] = v < lo ? lo : (v > hi ? hi : v);
                     }
             }
+            else
+#pragma unroll
+                for (int y = 0; y < 2; y++)
+#pragma unroll
+                    for (int x = 0; x < 2; x++) { const int v = im[y + 1][x]; o.c[c][y][x] = v < lo ? lo : (v > hi ? hi : v); }
         }
     }
 }
