@@ -841,16 +841,15 @@ struct McTile
  *   vertical phase on intermediates:    pixel = clip((V + offV) >> shiftV); 14-bit = V >> 6
  * (each through an int16 cast; ipfilter.cpp:40-172, :194-435) differ only in offset, shift and clamp, which become
  * per-lane parameters of one code path. */
-template<typename P>
-__device__ __forceinline__ void mc_predict(const McRef *ref, int lx, int ly, int cx, int cy, int mvx, int mvy, int depth, bool inter14,
+template<typename P, bool CHROMA>
+__device__ __forceinline__ void mc_predict(const PlaneDev (&pls)[3], int lx, int ly, int cx, int cy, int mvx, int mvy, int depth, bool inter14,
                                            bool luma, bool chroma, McTile &o)
 {
     const int maxv = (1 << depth) - 1, headRoom = 14 - depth;
     const int shiftH = 6 - headRoom, offH = -(8192 << shiftH);
     const int shiftV = 6 + headRoom, offV = (1 << (shiftV - 1)) + (8192 << 6);
     const int xf = mvx & 3, yf = mvy & 3, cxf = mvx & 7, cyf = mvy & 7;
-    /* plane descriptors and filter taps first: nothing below has to wait for them behind the row loads */
-    const PlaneDev pls[3] = { ref->pl[0], ref->pl[1], ref->pl[2] };
+    /* filter taps first: nothing below has to wait for them behind the row loads */
     McTaps<P> th;
     th.load(xf, cxf);
     int lv[8], kv[4];
@@ -879,7 +878,7 @@ __device__ __forceinline__ void mc_predict(const McRef *ref, int lx, int ly, int
         }
     }
 #pragma unroll
-    for (int c = 0; c < 2; c++)
+    for (int c = 0; CHROMA && c < 2; c++)
     {
         const PlaneDev pl = pls[1 + c];
         const P AS1 *base = (const P AS1*)pl.origin + (long)(cy + (mvy >> 3) - 1) * pl.stride + cx + (mvx >> 3) - 1;
@@ -944,6 +943,7 @@ __device__ __forceinline__ void mc_predict(const McRef *ref, int lx, int ly, int
                 for (int x = 0; x < 4; x++) { const int v = im[y + 3][x]; o.y[y][x] = v < lo ? lo : (v > hi ? hi : v); }
     }
     /* ---- chroma ---- */
+    if (CHROMA)
     {
         const int (&cv)[4] = kv;
         const int offI = cxf ? offH : 0, shI = cxf ? shiftH : 6;
@@ -1071,8 +1071,16 @@ __global__ __launch_bounds__(64) void mc_kernel(McArgs a)
     /* list A = the only list of a uni-predicted PU, or list 0; list B = list 1 of a bi-predicted PU */
     const McRef *pa = dir == 2 ? p1 : p0;
     McTile A, B;
-    mc_predict<P>(pa, lx, ly, cx, cy, dir == 2 ? m1x : m0x, dir == 2 ? m1y : m0y, a.depth, inter14, luma, chroma, A);
-    if (two) mc_predict<P>(p1, lx, ly, cx, cy, m1x, m1y, a.depth, true, luma, chroma, B);
+    {
+        /* plane descriptors before anything that waits on the row loads */
+        const PlaneDev pla[3] = { pa->pl[0], pa->pl[1], pa->pl[2] };
+        mc_predict<P, true>(pla, lx, ly, cx, cy, dir == 2 ? m1x : m0x, dir == 2 ? m1y : m0y, a.depth, inter14, luma, chroma, A);
+    }
+    if (two)
+    {
+        const PlaneDev plb[3] = { p1->pl[0], p1->pl[1], p1->pl[2] };
+        mc_predict<P, true>(plb, lx, ly, cx, cy, m1x, m1y, a.depth, true, luma, chroma, B);
+    }
     if (inter14)
     {
         /* TComYuv::addAvg (TComYuv.cpp:596-606, :616-650) as weights (1, 1), or the explicit weights */
@@ -1145,16 +1153,21 @@ __global__ __launch_bounds__(64) void bipred_flat_kernel(BipredFlatArgs fa)
                           Px<P>::load_g((const P AS1*)a.ref1.origin + r1o + (long)y * a.ref1.stride));
     }
     const int zero = tile_cost_quads<P>(f, z, true);
-    int o0[4][4], o1[4][4];
     int m0x = job->mv0[0], m0y = job->mv0[1], m1x = job->mv1[0], m1y = job->mv1[1];
     if (fa.res0) { m0x = fa.res0[j].mv[0]; m0y = fa.res0[j].mv[1]; }
     if (fa.res1) { m1x = fa.res1[j].mv[0]; m1y = fa.res1[j].mv[1]; }
-    bipred_tile<P>((const P AS1*)a.ref0.origin + r0o, a.ref0.stride, m0x, m0y, a.depth, o0);
-    bipred_tile<P>((const P AS1*)a.ref1.origin + r1o, a.ref1.stride, m1x, m1y, a.depth, o1);
+    /* xPredInterLumaBlk's pixel flavour through the one-formula predictor: lanes of different phases do not diverge */
+    McTile A, B;
+    {
+        const PlaneDev p0[3] = { a.ref0, a.ref0, a.ref0 }, p1[3] = { a.ref1, a.ref1, a.ref1 };
+        mc_predict<P, false>(p0, pux + 4 * tx, puy + 4 * ty, 0, 0, m0x, m0y, a.depth, false, true, false, A);
+        mc_predict<P, false>(p1, pux + 4 * tx, puy + 4 * ty, 0, 0, m1x, m1y, a.depth, false, true, false, B);
+    }
+    int (&o0)[4][4] = A.y;
 #pragma unroll
     for (int y = 0; y < 4; y++)
 #pragma unroll
-        for (int x = 0; x < 4; x++) o0[y][x] = (o0[y][x] + o1[y][x] + 1) >> 1;
+        for (int x = 0; x < 4; x++) o0[y][x] = (A.y[y][x] + B.y[y][x] + 1) >> 1;
     int bi = tile_cost_px<P>(f, o0, true), zr = zero;
     /* the lanes of one PU are neighbours: sum them down to the PU's first lane in the wave (a lane adds its partner's
      * partial sum when the partner belongs to the same PU), then one atomic per PU and wave */
@@ -1206,26 +1219,35 @@ __global__ __launch_bounds__(64) void merge_flat_kernel(MergeFlatArgs fa)
     const int ty = gy * 4 + ((tt >> 3) & 1) * 2 + ((tt >> 1) & 1), tx = gx * 4 + ((tt >> 2) & 1) * 2 + (tt & 1);
     const long fo = (long)(puy + 4 * ty) * a.fenc.stride + pux + 4 * tx;
     const long o0 = (long)(puy + 4 * ty) * r0.stride + pux + 4 * tx, o1 = (long)(puy + 4 * ty) * r1.stride + pux + 4 * tx;
-    int p[4][4];
-    if (dir == 3)
+    /* list A = the only list of a uni-predicted candidate, or list 0; list B = list 1 of a bi-predicted one */
+    McTile A, B;
     {
-        int s1[4][4];
-        mc_short_tile<P>((const P AS1*)r0.origin + o0, r0.stride, m0x, m0y, a.depth, p);
-        mc_short_tile<P>((const P AS1*)r1.origin + o1, r1.stride, m1x, m1y, a.depth, s1);
-        const int shiftNum = 15 - a.depth, offset = (1 << (shiftNum - 1)) + 2 * 8192;
+        const bool two = dir == 3;
+        const PlaneDev ra = dir == 2 ? r1 : r0;
+        const PlaneDev pa[3] = { ra, ra, ra }, pb[3] = { r1, r1, r1 };
+        const int max_ = dir == 2 ? m1x : m0x, may_ = dir == 2 ? m1y : m0y;
+        if (!two && ((max_ | may_) & 3) == 0)
+            /* a whole-sample MV of a single list reads the block itself and nothing around it: the host lets such a
+             * candidate use a reference without margins (the distortion of a finished prediction picture) */
+            bipred_tile<P>((const P AS1*)ra.origin + (long)(puy + 4 * ty) * ra.stride + pux + 4 * tx, ra.stride, max_, may_, a.depth, A.y);
+        else
+            mc_predict<P, false>(pa, pux + 4 * tx, puy + 4 * ty, 0, 0, max_, may_, a.depth, two, true, false, A);
+        if (two)
+        {
+            mc_predict<P, false>(pb, pux + 4 * tx, puy + 4 * ty, 0, 0, m1x, m1y, a.depth, true, true, false, B);
+            /* TComYuv::addAvg, TComYuv.cpp:596-606 */
+            const int shiftNum = 15 - a.depth, offset = (1 << (shiftNum - 1)) + 2 * 8192;
 #pragma unroll
-        for (int y = 0; y < 4; y++)
+            for (int y = 0; y < 4; y++)
 #pragma unroll
-            for (int x = 0; x < 4; x++)
-            {
-                const int v = (p[y][x] + s1[y][x] + offset) >> shiftNum;
-                p[y][x] = v < 0 ? 0 : (v > maxv ? maxv : v);
-            }
+                for (int x = 0; x < 4; x++)
+                {
+                    const int v = (A.y[y][x] + B.y[y][x] + offset) >> shiftNum;
+                    A.y[y][x] = v < 0 ? 0 : (v > maxv ? maxv : v);
+                }
+        }
     }
-    else if (dir == 2)
-        bipred_tile<P>((const P AS1*)r1.origin + o1, r1.stride, m1x, m1y, a.depth, p);
-    else
-        bipred_tile<P>((const P AS1*)r0.origin + o0, r0.stride, m0x, m0y, a.depth, p);
+    int (&p)[4][4] = A.y;
     int d[4][4];
 #pragma unroll
     for (int y = 0; y < 4; y++)
