@@ -65,26 +65,6 @@ __global__ __launch_bounds__(64) void search_kernel(SearchArgs a)
 #include "me_esa.h"   /* esa_scan_kernel, esa_finish_kernel: use SearchArgs and xcd_remap */
 #include "me_lookahead_cost.h"
 
-/* subpelCompare for a batch of PUs (motion.cpp:1651-1689) */
-template<typename P>
-__global__ __launch_bounds__(64) void subpel_compare_kernel(SearchArgs a, int cmp)
-{
-    const int j = blockIdx.x;
-    if (j >= a.njobs) return;
-    const x265amd_job *job = a.jobs + j;
-    Searcher<P, 64> S;
-    S.bind(0, a.fenc, a.ref, a.nref, a.ctab, a.depth, job->pu_x, job->pu_y, job->w, job->h, 64, plane_budget(64, (int)sizeof(P)));
-    S.nsad = S.nsub = 0;
-    S.put(0, job->qmvp[0], job->qmvp[1], job->qmvp[0], job->qmvp[1], 0, 0);
-    S.eval(1, cmp ? 2 : 1, false);
-    const int c = S.cost_of(0);
-    if ((threadIdx.x & 63) == 0)
-    {
-        a.results[j].mv[0] = job->qmvp[0]; a.results[j].mv[1] = job->qmvp[1];
-        a.results[j].cost = c; a.results[j].sad_calls = 0; a.results[j].subpel_calls = 1;
-    }
-}
-
 /* Lookahead: one workgroup per lowres field, LA_WAVES waves walking the reverse-raster
  * dependency wavefront. CU (x, y) needs the final MVs of (x+1, y) and of
  * (x-1 .. x+1, y+1) (slicetype.cpp:1450-1459), so all CUs with equal
@@ -1161,6 +1141,9 @@ int x265amd_search_batch(x265amd_ctx *c, const x265amd_plane *fenc, const x265am
     return X265AMD_OK;
 }
 
+static void flat_plan(const void *jobs, size_t job_size, int njobs, const std::vector<int> &tiles, std::vector<char> &blob,
+                      size_t &first_off, size_t &chunk_off, int &nchunks, int align16 = 0);
+
 int x265amd_subpel_compare_batch(x265amd_ctx *c, const x265amd_plane *fenc, const x265amd_plane *ref, int cmp,
                                  const x265amd_job *jobs, int njobs, x265amd_result *results)
 {
@@ -1171,16 +1154,25 @@ int x265amd_subpel_compare_batch(x265amd_ctx *c, const x265amd_plane *fenc, cons
     for (int i = 0; i < njobs; i++)
         if (x265amd_partition_from_sizes(jobs[i].w, jobs[i].h) < 0) return fail(c, X265AMD_EINVAL, "job: not a luma partition");
     HIPCHK(c, hipSetDevice(c->device));
-    if ((rc = ensure(c, &c->d_jobs, &c->jobs_cap, (size_t)njobs * sizeof(x265amd_job)))) return rc;
+    /* tiles numbered here (the PU sizes are visible), 64 per wave whatever PUs they belong to */
+    std::vector<int> tiles(njobs);
+    for (int i = 0; i < njobs; i++) tiles[i] = (jobs[i].w >> 2) * (jobs[i].h >> 2);
+    std::vector<char> blob;
+    SubpelFlatArgs a;
+    size_t first_off, chunk_off;
+    flat_plan(jobs, sizeof(x265amd_job), njobs, tiles, blob, first_off, chunk_off, a.nchunks);
+    if ((rc = ensure(c, &c->d_jobs, &c->jobs_cap, blob.size()))) return rc;
     if ((rc = ensure(c, &c->d_results, &c->results_cap, (size_t)njobs * sizeof(x265amd_result)))) return rc;
-    HIPCHK(c, hipMemcpyAsync(c->d_jobs, jobs, (size_t)njobs * sizeof(x265amd_job), hipMemcpyHostToDevice, c->stream));
-    SearchArgs a;
-    fill_args(c, a, fenc, ref, 0, 12, 0, 0);
-    a.jobs = (const x265amd_job*)c->d_jobs; a.results = (x265amd_result*)c->d_results; a.njobs = njobs;
-    if (c->depth <= 8)
-        hipLaunchKernelGGL(subpel_compare_kernel<uint8_t>, dim3(njobs), dim3(64), wave_lds_bytes<uint8_t>(64, true), c->stream, a, cmp);
-    else
-        hipLaunchKernelGGL(subpel_compare_kernel<uint16_t>, dim3(njobs), dim3(64), wave_lds_bytes<uint16_t>(64, true), c->stream, a, cmp);
+    HIPCHK(c, hipMemcpyAsync(c->d_jobs, blob.data(), blob.size(), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemsetAsync(c->d_results, 0, (size_t)njobs * sizeof(x265amd_result), c->stream));
+    a.fenc.origin = fenc->origin; a.fenc.stride = fenc->stride;
+    a.ref.origin = ref->origin; a.ref.stride = ref->stride;
+    a.depth = c->depth; a.njobs = njobs; a.satd = cmp;
+    a.jobs = (const x265amd_job*)c->d_jobs; a.results = (x265amd_result*)c->d_results;
+    a.first = (const int32_t*)((const char*)c->d_jobs + first_off);
+    a.chunk_job = (const int32_t*)((const char*)c->d_jobs + chunk_off);
+    if (c->depth <= 8) hipLaunchKernelGGL(subpel_flat_kernel<uint8_t>, dim3(a.nchunks), dim3(64), 0, c->stream, a);
+    else hipLaunchKernelGGL(subpel_flat_kernel<uint16_t>, dim3(a.nchunks), dim3(64), 0, c->stream, a);
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipMemcpyAsync(results, c->d_results, (size_t)njobs * sizeof(x265amd_result), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -1514,8 +1506,6 @@ int x265amd_weights_analyse(x265amd_ctx *c, const x265amd_plane *fenc, const x26
 
 /* ---- bi-prediction estimate ---- */
 
-static void flat_plan(const void *jobs, size_t job_size, int njobs, const std::vector<int> &tiles, std::vector<char> &blob,
-                      size_t &first_off, size_t &chunk_off, int &nchunks, int align16 = 0);
 
 int x265amd_bipred_batch_dev(x265amd_ctx *c, const x265amd_plane *fenc, const x265amd_plane *ref0, const x265amd_plane *ref1,
                              const x265amd_bipred_job *d_jobs, int njobs, x265amd_bipred_result *d_results)

@@ -1294,7 +1294,52 @@ __global__ __launch_bounds__(64) void merge_flat_kernel(MergeFlatArgs fa)
     if (live && (lane == 0 || prev != key)) atomicAdd(&a.out[j], total);
 }
 
+/* subpelCompare (motion.cpp:1651-1689) for a batch of PUs with 64 consecutive tiles per wave: the PU interpolated at
+ * its quarter-pel MV (pixel flavour of the one-formula predictor; a whole-sample MV is the copy the reference compares
+ * directly) against the source, SAD or SATD per tile, summed per PU as in the bi-prediction estimate. */
+struct SubpelFlatArgs
+{
+    PlaneDev fenc, ref;
+    int depth, njobs, satd;
+    const x265amd_job *jobs;
+    x265amd_result *results;   /* zeroed by the launch */
+    const int32_t *first, *chunk_job;
+    int nchunks;
+};
+
+template<typename P>
+__global__ __launch_bounds__(64) void subpel_flat_kernel(SubpelFlatArgs a)
+{
+    int j, t;
+    if (!flat_tile_of_lane(a.first, a.chunk_job, a.nchunks, a.njobs, j, t)) return;
+    const x265amd_job *job = a.jobs + j;
+    const int wt = job->w >> 2, ty = t / wt, tx = t - ty * wt;
+    const int x = job->pu_x + 4 * tx, y = job->pu_y + 4 * ty, qx = job->qmvp[0], qy = job->qmvp[1];
+    typename Px<P>::quad f[4];
+#pragma unroll
+    for (int r = 0; r < 4; r++) f[r] = Px<P>::load_g((const P AS1*)a.fenc.origin + (long)(y + r) * a.fenc.stride + x);
+    McTile A;
+    const PlaneDev pl[3] = { a.ref, a.ref, a.ref };
+    mc_predict<P, false>(pl, x, y, 0, 0, qx, qy, a.depth, false, true, false, A);
+    int v = tile_cost_px<P>(f, A.y, a.satd != 0);
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1)
+    {
+        const int pj = __shfl_down(j, d), pv = __shfl_down(v, d);
+        v += (lane + d < 64 && pj == j) ? pv : 0;
+    }
+    const int prev = __shfl_up(j, 1);
+    if (lane == 0 || prev != j)
+    {
+        atomicAdd(&a.results[j].cost, v);
+        a.results[j].mv[0] = (int16_t)qx; a.results[j].mv[1] = (int16_t)qy;
+        a.results[j].subpel_calls = 1;
+    }
+}
+
 } // namespace x265amd
+
 
 
 
