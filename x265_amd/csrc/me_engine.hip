@@ -1151,8 +1151,20 @@ int x265amd_subpel_compare_batch(x265amd_ctx *c, const x265amd_plane *fenc, cons
     if (!njobs) return X265AMD_OK;
     int rc = x265amd_set_qp(c, 12);
     if (rc) return rc;
+    if (!fenc->origin || !ref->origin) return fail(c, X265AMD_EINVAL, "null plane");
     for (int i = 0; i < njobs; i++)
-        if (x265amd_partition_from_sizes(jobs[i].w, jobs[i].h) < 0) return fail(c, X265AMD_EINVAL, "job: not a luma partition");
+    {
+        const x265amd_job &j = jobs[i];
+        if (x265amd_partition_from_sizes(j.w, j.h) < 0) return fail(c, X265AMD_EINVAL, "job: not a luma partition");
+        if (j.pu_x < -fenc->margin_x || j.pu_y < -fenc->margin_y || j.pu_x + j.w > fenc->width + fenc->margin_x ||
+            j.pu_y + j.h > fenc->height + fenc->margin_y)
+            return fail(c, X265AMD_EINVAL, "job: PU outside the source plane");
+        /* the 8-tap footprint of the prediction, rows read 12 samples wide */
+        const int x0 = j.pu_x + (j.qmvp[0] >> 2) - 3, x1 = j.pu_x + j.w + (j.qmvp[0] >> 2) + 5;
+        const int y0 = j.pu_y + (j.qmvp[1] >> 2) - 3, y1 = j.pu_y + j.h + (j.qmvp[1] >> 2) + 4;
+        if (x0 < -ref->margin_x || y0 < -ref->margin_y || x1 > ref->width + ref->margin_x || y1 > ref->height + ref->margin_y)
+            return fail(c, X265AMD_EINVAL, "job: prediction block leaves the padded reference plane");
+    }
     HIPCHK(c, hipSetDevice(c->device));
     /* tiles numbered here (the PU sizes are visible), 64 per wave whatever PUs they belong to */
     std::vector<int> tiles(njobs);
