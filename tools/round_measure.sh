@@ -13,3 +13,4 @@ timeout -k 10 200 python -u tools/mc_bench.py --width 3840 --height 2160 --no-ch
 timeout -k 10 200 python -u tools/mc_bench.py --width 3840 --height 2160 --depth 10 --no-check >> gpurun_out/mc_bench_final.txt 2>&1
 cd /tmp
 timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/prof_mc -- python3 $GRAFT_REPO_ROOT/tools/mc_bench.py --width 3840 --height 2160 --no-check > $GRAFT_REPO_ROOT/gpurun_out/prof_mc.log 2>&1
+timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/prof_bipred_final -- python3 $GRAFT_REPO_ROOT/tools/bipred_bench.py > $GRAFT_REPO_ROOT/gpurun_out/bipred_bench_final.txt 2>&1
