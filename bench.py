@@ -284,6 +284,7 @@ def main():
                         "frame_costs_per_s": m["frames"] / (m["ms_search"] + m["ms_costs"]) * 1e3,
                         "searched_cus_per_s": m["fields"] * m["cus"] / (m["ms_search"] * 1e-3)}
                 mc = measure.mc_picture(es, dev)
+                bp = measure.bipred_picture(es, dev)
                 e10 = Engine(local_rank, 10)
                 m10 = measure.pattern_search_picture(e10, dev)
                 e10.close()
@@ -307,6 +308,11 @@ def main():
                               **{k: {"ms_per_picture": v["ms"], "pus": v["pus"], "achieved": v["algorithmic_bytes"] / v["ms"] / 1e6,
                                      "frac": v["algorithmic_bytes"] / v["ms"] / 1e6 / HBM_PEAK_GBS,
                                      "Gsample_per_s": v["samples"] / v["ms"] / 1e6} for k, v in mc.items()}},
+                    "bipred_4k": {"workload": "3840x2160 8-bit bi-prediction estimate of predInterSearch for every PU of a picture (mixed quadtree "
+                                              "partitioning, random quarter-pel MVs), device-resident list",
+                                  "ms_per_picture": bp["ms"], "pus": bp["pus"], "bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                  "achieved": bp["algorithmic_bytes"] / bp["ms"] / 1e6,
+                                  "frac": bp["algorithmic_bytes"] / bp["ms"] / 1e6 / HBM_PEAK_GBS},
                     "rk_1080p": {"workload": "1920x1080 8-bit, Rockchip rd>=5 path: CIME + RIME + FME of all 510 CTUs (85 CUs each) "
                                              "against one reference, default RK range",
                                  "ms_per_picture_reference": rk["ms"], "ctus_per_s": rk["ctus"] / (rk["ms"] * 1e-3),

@@ -262,3 +262,30 @@ def mc_picture(e, dev, width=3840, height=2160, reps=10, seed=5):
         e.free_picture(p_)
     return out
 
+
+def bipred_picture(e, dev, width=3840, height=2160, reps=10, seed=6):
+    """The bi-prediction estimate of every PU of one picture (mixed quadtree partitioning, random quarter-pel MVs) as a
+    device-resident list (x265amd_bipred_batch_list)."""
+    import torch
+    from .engine import BIPRED_JOB_DTYPE, BIPRED_RESULT_DTYPE
+    W, H, M = width, height, 96
+    bpp = 1 if e.depth <= 8 else 2
+    clip = make_clip(W, H, 3, seed=seed, depth=e.depth)
+    planes = []
+    for f in clip:
+        buf, _, stride = pad_plane(f, M)
+        planes.append(e.upload_plane(buf, W, H, M, M, stride))
+    rng = np.random.default_rng(seed)
+    jobs = mixed_partition(rng, W, H, BIPRED_JOB_DTYPE)
+    jobs["mv0"] = rng.integers(-64, 65, (len(jobs), 2))
+    jobs["mv1"] = rng.integers(-64, 65, (len(jobs), 2))
+    lst = e.bipred_list_create(planes[1], planes[0], planes[2], jobs)
+    d_out = e.device_alloc(len(jobs) * BIPRED_RESULT_DTYPE.itemsize)
+    ms = _timed(torch, e, dev, lambda: e.bipred_batch_list(planes[1], planes[0], planes[2], lst, d_out), reps)
+    e.bipred_list_free(lst)
+    e.device_free(d_out)
+    for p_ in planes:
+        e.free_plane(p_)
+    jw, jh = jobs["w"].astype(np.int64), jobs["h"].astype(np.int64)
+    return {"ms": ms, "pus": len(jobs), "algorithmic_bytes": int((bpp * (jw * jh + 2 * (jw + 7) * (jh + 7)) + 8).sum())}
+
