@@ -118,7 +118,7 @@ def main():
         d_jobs.append(torch.from_numpy(jobs.view(np.uint8).reshape(len(jobs), -1).copy()).to(dev))
         d_res.append(torch.zeros((len(jobs), RESULT_DTYPE.itemsize), dtype=torch.uint8, device=dev))
     njobs = len(host_jobs[0])
-    d_fields = el.fields_upload(fields)
+    d_fields = el.fields_upload(fields, wcu, hcu, HEX, LA_MERANGE)
     d_la_mvs = torch.zeros((B, ncu, 2), dtype=torch.int16, device=dev)
     d_la_costs = torch.zeros((B, ncu), dtype=torch.int32, device=dev)
     torch.cuda.synchronize()

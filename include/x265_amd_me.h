@@ -77,8 +77,8 @@ const char *x265amd_last_error(const x265amd_ctx *ctx);
 void *x265amd_stream(x265amd_ctx *ctx);
 
 /* BitCost::setQP (encoder/bitcost.cpp:34-59): builds (once) and selects the
- * lambda-scaled MVD cost table of `qp`; x265amd_cost_table copies the 65535
- * entries [-32767, 32767] of that table to `out` (host). */
+ * lambda-scaled MVD cost table of `qp` (0..69); x265amd_cost_table copies the 65535
+ * entries [-32767, 32767] of the device-resident table the kernels read to `out` (host). */
 int x265amd_set_qp(x265amd_ctx *ctx, int qp);
 int x265amd_cost_table(x265amd_ctx *ctx, int qp, uint16_t *out);
 
@@ -89,6 +89,9 @@ int x265amd_cost_table(x265amd_ctx *ctx, int qp, uint16_t *out);
  * Stands for the pictures the encoder already owns (TComPicYuv, Lowres::buffer). */
 int x265amd_plane_upload(x265amd_ctx *ctx, const void *buf, int width, int height,
                          int margin_x, int margin_y, int stride, x265amd_plane *out);
+/* Releases a plane made by this context: x265amd_plane_upload, x265amd_lowres_init, the weighting calls, and the
+ * int16 plane of x265amd_rk_ds_plane alike (the allocation is looked up by `origin`, so the sample size does not
+ * matter). Waits for the engine's stream first. X265AMD_EINVAL for a plane this context did not make. */
 int x265amd_plane_free(x265amd_ctx *ctx, x265amd_plane *plane);
 /* Lowres::init (common/lowres.cpp:121-166): frame_init_lowres_core + border
  * extension, on device. `src` is a full-resolution padded plane; produces the four
@@ -148,16 +151,26 @@ int x265amd_subpel_compare_batch(x265amd_ctx *ctx, const x265amd_plane *fenc, co
 typedef struct
 {
     x265amd_plane fenc;        /* lowresPlane[0] of the frame being searched */
-    x265amd_plane ref[4];      /* the four hpel planes of the reference frame */
+    x265amd_plane ref[4];      /* the four hpel planes of the reference frame (one stride) */
 } x265amd_field;
+/* Geometry checked before anything is launched (X265AMD_EINVAL otherwise): every plane covers the CU grid, and the
+ * reference planes have margins of at least 12 samples -- the range reaches 8 samples outside the grid
+ * (slicetype.cpp:1427-1430), hexagon / square steps 3 more without a range check, the quarter-pel average one more.
+ * X265AMD_UMH reads much further (motion.cpp:732, :301-303: its cross is measured from the start block, the vertical one
+ * at x = omv.x + omv.y) and needs margin_x >= 32 + 8 * (height_in_cu - 1) + 6 * merange / 4 + 6 and
+ * margin_y >= 30 + 6 * merange / 4; the reference's own lookahead only ever uses X265_HEX_SEARCH (slicetype.h:65-72). */
 int x265amd_lookahead_fields(x265amd_ctx *ctx, const x265amd_field *fields, int nfields,
                              int width_in_cu, int height_in_cu, int qp, int method, int subme, int merange,
                              int16_t *out_mvs, int32_t *out_costs, x265amd_result *out_stats /* nfields*ncu or NULL */);
 
 /* Device-resident variant: `d_fields` comes from x265amd_fields_upload (release it with
  * x265amd_device_free), outputs are DEVICE arrays of the sizes above; asynchronous on
- * the engine's stream. Same reference path as x265amd_lookahead_fields. */
-int x265amd_fields_upload(x265amd_ctx *ctx, const x265amd_field *fields, int nfields, void **d_fields);
+ * the engine's stream. Same reference path as x265amd_lookahead_fields. x265amd_fields_upload makes the
+ * geometry checks above for the grid, method and merange it is given; x265amd_lookahead_fields_dev cannot
+ * see the planes and must be called with that grid, that method (or any other than UMH) and a merange no
+ * larger. */
+int x265amd_fields_upload(x265amd_ctx *ctx, const x265amd_field *fields, int nfields,
+                          int width_in_cu, int height_in_cu, int method, int merange, void **d_fields);
 int x265amd_device_free(x265amd_ctx *ctx, void *d_ptr);
 int x265amd_lookahead_fields_dev(x265amd_ctx *ctx, const void *d_fields, int nfields,
                                  int width_in_cu, int height_in_cu, int qp, int method, int subme, int merange,
@@ -456,7 +469,10 @@ int x265amd_rk_ctu_batch_dev(x265amd_ctx *ctx, const x265amd_plane *fenc, const 
  * the HIP kernel and returns the result, so the table can be checked call by call
  * against the C primitives the way test/pixelharness.cpp and
  * test/ipfilterharness.cpp do. Indexed by the LumaPartitions enum (:65-73).
- * `pixel` is uint8_t or uint16_t according to the context's bit depth. */
+ * `pixel` is uint8_t or uint16_t according to the context's bit depth.
+ * One table is live per process: its entries serve the context of the latest x265amd_setup_primitives call
+ * (depth, stream, staging buffer), are not thread-safe, and abort with a message once that context has been
+ * destroyed. */
 #define X265AMD_NUM_LUMA_PARTITIONS 25
 typedef int  (*x265amd_pixelcmp_t)(const void *fenc, intptr_t fencstride, const void *fref, intptr_t frefstride);
 typedef void (*x265amd_pixelcmp_x3_t)(const void *fenc, const void *fref0, const void *fref1, const void *fref2,

@@ -26,7 +26,7 @@ from x265_amd.synth import make_clip, pad_plane  # noqa: E402
 
 ME_W, ME_H = 192, 128
 LA_W, LA_H = 416, 240
-QPS = [0, 12, 20, 24, 30, 37, 51, 69]
+QPS = list(range(70))     # every QP BitCost::setQP accepts (bitcost.cpp:34-59, MAX_QP 69)
 
 
 def sha(a):
@@ -70,9 +70,7 @@ def prim_offsets(part_index):
 
 def main():
     out = {}
-    # ---- cost tables
-    ref8 = Ref(8)
-    np.savez_compressed(os.path.join(HERE, "cost_tables.npz"), **{"qp%d" % qp: ref8.cost_table(qp) for qp in QPS})
+    make_cost_tables(None)
 
     # ---- primitives
     prim = {}
@@ -165,6 +163,20 @@ def main():
     make_mc(shas)
     json.dump(shas, open(os.path.join(HERE, "input_sha.json"), "w"), indent=0, sort_keys=True)
     print("golden vectors written to", HERE)
+
+
+def make_cost_tables(shas):
+    """BitCost::setQP tables (bitcost.cpp:34-83) of the reference build. The tables are symmetric in the MVD and grow
+    with |mvd|, so only the non-negative half is stored, as run lengths: entry v of `steps` is the first |mvd| whose
+    cost is at least v (golden_util.cost_tables expands them again)."""
+    ref8 = Ref(8)
+    out = {}
+    for qp in QPS:
+        t = ref8.cost_table(qp)                      # 65535 entries, mvd -32767 .. 32767
+        half = t[32767:].astype(np.int64)
+        assert np.array_equal(t[:32768][::-1], t[32767:]) and (np.diff(half) >= 0).all()
+        out["qp%d" % qp] = np.searchsorted(half, np.arange(int(half[-1]) + 2), side="left").astype(np.int32)
+    np.savez_compressed(os.path.join(HERE, "cost_tables.npz"), **out)
 
 
 class ref_as_orc:
@@ -383,11 +395,11 @@ def make_cmodel(shas):
 
 
 if __name__ == "__main__":
-    if sys.argv[1:] in (["cmodel"], ["framecost"], ["wp"], ["bipred"], ["merge"], ["mc"]):
+    if sys.argv[1:] in (["costtables"], ["cmodel"], ["framecost"], ["wp"], ["bipred"], ["merge"], ["mc"]):
         # only (re)generate the C-model / frame-cost records, keeping the other files as they are
         shas_path = os.path.join(HERE, "input_sha.json")
         shas_ = json.load(open(shas_path))
-        {"cmodel": make_cmodel, "framecost": make_frame_cost, "wp": make_wp, "bipred": make_bipred, "merge": make_merge, "mc": make_mc}[sys.argv[1]](shas_)
+        {"costtables": make_cost_tables, "cmodel": make_cmodel, "framecost": make_frame_cost, "wp": make_wp, "bipred": make_bipred, "merge": make_merge, "mc": make_mc}[sys.argv[1]](shas_)
         json.dump(shas_, open(shas_path, "w"), indent=0, sort_keys=True)
     else:
         main()

@@ -1,5 +1,6 @@
 """GPU: the BASELINE.json configurations at their full picture sizes.
 
+  configs[1]  1080p 8-bit, --me star --merange 57           -> lookahead field + full-encode pattern search
   configs[2]  4K 8-bit, --me full, merange 92, 3 references   -> exhaustive-search kernel
   configs[3]  4K Main10, --subme 5                             -> 16-bit interpolation + SATD refinement
   configs[4]  8K 8-bit lookahead                               -> one lowres MV field of a 7680x4320 frame
@@ -21,6 +22,51 @@ pytestmark = pytest.mark.gpu
 def _sample(jobs, n, seed):
     idx = np.sort(np.random.default_rng(seed).choice(len(jobs), n, replace=False))
     return idx, jobs[idx]
+
+
+def test_1080p_star_merange57_and_lookahead(engine8, oracle):
+    """The benchmark's own workload: the 120x68 HEX lookahead field of a 1080p frame pair (whole field against the
+    oracle), then STAR / merange 57 / subme 5 over all 42 900 square PUs with predictors from that field; a seeded sample
+    of every PU size plus the PUs on the four picture borders against the oracle."""
+    from oracle.bindings import MEStats
+    W, H, M, MR, QP = 1920, 1080, 128, 57, 32
+    clip = make_clip(W, H, 2, seed=1234)
+    cur, org, stride = pad_plane(clip[1], M)
+    ref, _, _ = pad_plane(clip[0], M)
+    pc = engine8.upload_plane(cur, W, H, M, M, stride)
+    pr = engine8.upload_plane(ref, W, H, M, M, stride)
+    lc, lr = engine8.lowres_init(pc), engine8.lowres_init(pr)
+    wcu, hcu = 120, 68
+    mvs, costs, stats = engine8.lookahead_fields([(lc[0], lr)], wcu, hcu, 12, METHODS["hex"], 1, 16, want_stats=True)
+    hc = engine8.download_plane(lc[0]).reshape(-1)
+    hr = [engine8.download_plane(p).reshape(-1) for p in lr]
+    lorg = lc[0].margin_y * lc[0].stride + lc[0].margin_x
+    lctx = oracle.make_ctx(8, hc, lorg, lc[0].stride, hr, lorg, lc[0].stride, True, 12, METHODS["hex"], 1)
+    st = MEStats()
+    emv, ecost = oracle.lookahead_field(lctx, wcu, hcu, 16, st)
+    assert np.array_equal(mvs[0], emv) and np.array_equal(costs[0], ecost)
+    assert int(stats["sad_calls"].sum()) == st.sad_calls and int(stats["subpel_calls"].sum()) == st.subpel_calls
+    jobs = workload.square_pu_jobs(W, H, mvs[0], wcu, hcu, MR)
+    assert len(jobs) == 42900
+    res = engine8.search_batch(pc, pr, jobs, QP, METHODS["star"], 5)
+    pick = []
+    rng = np.random.default_rng(57)
+    for s in (64, 32, 16, 8):
+        of_size = np.flatnonzero(jobs["w"] == s)
+        border = of_size[(jobs["pu_x"][of_size] == 0) | (jobs["pu_y"][of_size] == 0) |
+                         (jobs["pu_x"][of_size] + s >= W - (W % s)) | (jobs["pu_y"][of_size] + s >= H - (H % s))]
+        pick += list(rng.choice(of_size, 45, replace=False)) + list(rng.choice(border, 15, replace=False))
+    idx = np.unique(np.array(pick))
+    assert len(idx) >= 200
+    mv, cost, sc, qc = oracle_search(oracle, 8, cur, [ref], org, stride, jobs[idx], QP, METHODS["star"], 5)
+    assert np.array_equal(res["mv"][idx], mv) and np.array_equal(res["cost"][idx], cost)
+    assert np.array_equal(res["sad_calls"][idx], sc) and np.array_equal(res["subpel_calls"][idx], qc)
+    # every result lies inside its range (quarter-pel) and was refined at least once unless its cost is 0
+    q = res["mv"].astype(np.int32)
+    assert (q >= jobs["mvmin"].astype(np.int32) * 4 - 3).all() and (q <= jobs["mvmax"].astype(np.int32) * 4 + 3).all()
+    assert ((res["subpel_calls"] >= 1 + 9 + 8) | (res["cost"] == 0)).all()
+    for p in [pc, pr] + lc + lr:
+        engine8.free_plane(p)
 
 
 def test_4k_exhaustive_search_three_refs(engine8, oracle):
@@ -58,7 +104,8 @@ def test_4k_exhaustive_search_three_refs(engine8, oracle):
     jobs["pu_x"], jobs["pu_y"], jobs["w"], jobs["h"] = xs.ravel(), ys.ravel(), 64, 64
     jobs["mvmin"] = (-MR, -MR); jobs["mvmax"] = (MR, MR); jobs["merange"] = MR
     res = engine8.search_batch(pn, ps, jobs, 30, METHODS["full"], 0)
-    t = engine8.cost_table(30).astype(np.int64)
+    import golden_util as G
+    t = G.cost_tables()[30].astype(np.int64)      # the reference's own BitCost table
     assert (res["mv"] == (20, -28)).all()
     assert (res["cost"] == ((t[32767 + 20] + t[32767 - 28]) & 0xffff)).all()
     for p in (pc, pn, ps):

@@ -34,13 +34,37 @@ def test_golden_fields(request, depth):
     e = request.getfixturevalue("engine8" if depth == 8 else "engine10")
     g = G.lookahead_golden()
     clip = make_clip(G.LA_W, G.LA_H, 4, seed=3, depth=depth)
-    la, lb = _device_lowres(e, clip[3]), _device_lowres(e, clip[1])
     wcu, hcu = 26, 15
     for (method, subme) in ((1, 1), (3, 2), (0, 0), (2, 5)):
+        # UMH measures far outside its range (the entry point demands 32 + 8 * 14 + 30 samples of margin for it)
+        margin = 192 if method == 2 else 64
+        la, lb = _device_lowres(e, clip[3], margin), _device_lowres(e, clip[1], margin)
         mvs, costs, _ = e.lookahead_fields([(la[0], lb), (la[0], lb)], wcu, hcu, 12 + 6 * (depth - 8), method, subme, 16)
         for i in range(2):
             assert np.array_equal(mvs[i], g["%d_%d_%d_mvs" % (depth, method, subme)]), (method, subme)
             assert np.array_equal(costs[i], g["%d_%d_%d_costs" % (depth, method, subme)]), (method, subme)
+
+
+def test_field_geometry_is_checked(engine8):
+    """Planes whose margins cannot hold what the search method reads are refused before anything is launched."""
+    from x265_amd.engine import EngineError, Plane
+    clip = make_clip(G.LA_W, G.LA_H, 2, seed=3, depth=8)
+    la, lb = _device_lowres(engine8, clip[1], 16), _device_lowres(engine8, clip[0], 16)
+    engine8.lookahead_fields([(la[0], lb)], 26, 15, 12, 1, 1, 16)                 # HEX: 12 samples are enough
+    with pytest.raises(EngineError):
+        engine8.lookahead_fields([(la[0], lb)], 26, 15, 12, 2, 1, 16)             # UMH reads far outside its range
+    with pytest.raises(EngineError):
+        engine8.fields_upload([(la[0], lb)], 26, 15, 2, 16)
+    with pytest.raises(EngineError):
+        engine8.lookahead_fields([(la[0], lb)], 27, 15, 12, 1, 1, 16)             # grid wider than the planes
+    small = _device_lowres(engine8, clip[0], 8)
+    with pytest.raises(EngineError):
+        engine8.lookahead_fields([(la[0], small)], 26, 15, 12, 1, 1, 16)          # margins below 12 samples
+    mixed = [lb[0], lb[1], small[2], lb[3]]
+    with pytest.raises(EngineError):
+        engine8.lookahead_fields([(la[0], mixed)], 26, 15, 12, 1, 1, 16)          # one half-pel plane with another stride
+    with pytest.raises(EngineError):
+        engine8.lookahead_fields([(Plane(), lb)], 26, 15, 12, 1, 1, 16)           # null source plane
 
 
 def test_field_shapes_vs_oracle(engine8, oracle):

@@ -147,6 +147,19 @@ def test_motion_estimate_class_mirror(engine8, oracle):
             assert me.subpelCompare(pr, q, cmp) == oracle.subpel_compare(ctx, 32 * stride + 64, 32, 32, q, cmp)
 
 
+def test_cost_tables_vs_reference(engine8, engine10):
+    """x265amd_cost_table returns the table the kernels read (device copy): equal to the reference's BitCost::setQP table
+    for every QP (bitcost.cpp:34-83; golden tables made by the reference build with its own -ffast-math flags)."""
+    gold = G.cost_tables()
+    assert sorted(gold) == list(range(70))
+    for qp, tab in gold.items():
+        assert np.array_equal(engine8.cost_table(qp), tab), qp
+    for qp in (0, 24, 51, 69):
+        assert np.array_equal(engine10.cost_table(qp), gold[qp]), qp
+    with pytest.raises(EngineError):
+        engine8.cost_table(70)
+
+
 def test_full_size_properties(engine8):
     """1080p, every 16x16 PU: size-independent properties instead of a CPU replay.
     (a) searching a frame against itself finds MV 0 with cost 0 everywhere;
@@ -169,7 +182,7 @@ def test_full_size_properties(engine8):
     assert (r["cost"] == 0).all() and (r["mv"] == 0).all()
     r = engine8.search_batch(pf, ps, jobs, 30, METHODS["full"], 5)
     assert (r["mv"] == (12, -8)).all()
-    t = engine8.cost_table(30).astype(np.int64)
+    t = G.cost_tables()[30].astype(np.int64)      # the reference's own BitCost table
     assert (r["cost"] == t[32767 + 12] + t[32767 - 8]).all()
     assert (r["sad_calls"] == 81).all()   # the 9x9 raster; the zero predictor itself is measured through subpelCompare
 

@@ -727,7 +727,12 @@ struct x265amd_ctx
     int32_t *d_out;
     int *d_ticket;                     /* row hand-out counter of the row-parallel lookahead kernel */
     int esa_window_bytes;              /* LDS the exhaustive search may use per PU for its window */
+    bool esa_lds_raised, rime_lds_raised; /* dynamic-LDS limits raised on this context's device (the attribute is per device) */
+    std::map<const void*, void*> plane_base; /* plane origin -> start of its allocation, whatever the sample size */
 };
+
+static x265amd_ctx *g_prim_ctx = 0;    /* context behind the per-call primitives table (me_primitives.inc) */
+
 
 #define ESA_WINDOW_DEFAULT 36864
 #define ESA_WINDOW_MIN 8192
@@ -756,12 +761,11 @@ static int ensure(x265amd_ctx *c, void **p, size_t *cap, size_t need)
  * one-wave stages around it */
 static int launch_esa(x265amd_ctx *c, const SearchArgs &a, int window_bytes, int nowrap)
 {
-    static bool lds_raised = false;
-    if (!lds_raised)
+    if (!c->esa_lds_raised)
     {
         HIPCHK(c, hipFuncSetAttribute((const void*)esa_scan_kernel<uint8_t>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                       esa_fixed_lds(64) + ESA_WINDOW_MAX));
-        lds_raised = true;
+        c->esa_lds_raised = true;
     }
     hipLaunchKernelGGL(esa_scan_kernel<uint8_t>, dim3(a.njobs), dim3(ESA_THREADS), esa_fixed_lds(a.max_dim) + window_bytes,
                        c->stream, a, window_bytes, nowrap);
@@ -790,12 +794,15 @@ static int launch_search(x265amd_ctx *c, const SearchArgs &a, int is_lowres)
  * kernel spreads a field over up to min(H, W / 2) waves and wins whenever the fields alone cannot
  * fill the chip. LA_ROWS_MAX_FIELDS is where a launch switches over. */
 #define LA_ROWS_MAX_FIELDS 512
-static int launch_lookahead(x265amd_ctx *c, LookaheadArgs &a, int nfields)
+static int launch_lookahead(x265amd_ctx *c, LookaheadArgs &a, int nfields, int *d_ticket)
 {
     const char *force = getenv("X265AMD_LOOKAHEAD_KERNEL");   /* "field" or "rows": measurements only */
-    const bool rows = force ? !strcmp(force, "rows") : nfields <= LA_ROWS_MAX_FIELDS;
+    bool rows = force ? !strcmp(force, "rows") : nfields <= LA_ROWS_MAX_FIELDS;
+    /* the row-parallel kernel marks unfinished CUs with MV x = 0x7FFF: a grid wide enough for a real quarter-pel MV
+     * of that value (range end (wcu * 8 + 8) * 4 + 3) goes to the kernel that needs no mark */
+    if ((a.wcu * 8 + 8) * 4 + 3 >= 0x7FFF) rows = false;
     a.nfields = nfields;
-    a.ticket = c->d_ticket;
+    a.ticket = d_ticket;
     if (!rows)
     {
         if (c->depth <= 8)
@@ -807,7 +814,7 @@ static int launch_lookahead(x265amd_ctx *c, LookaheadArgs &a, int nfields)
     {
         const size_t words = (size_t)nfields * a.wcu * a.hcu;
         HIPCHK(c, hipMemsetD32Async((hipDeviceptr_t)a.mvs, LA_MV_UNSET, words, c->stream));
-        HIPCHK(c, hipMemsetAsync(c->d_ticket, 0, sizeof(int), c->stream));
+        HIPCHK(c, hipMemsetAsync(d_ticket, 0, sizeof(int), c->stream));
         long waves = (long)nfields * a.hcu;
         if (waves > 8192) waves = 8192;     /* more than the chip holds at once; the rest of the rows go to waves that finish */
         if (c->depth <= 8)
@@ -837,6 +844,7 @@ int x265amd_create(int device, int bit_depth, x265amd_ctx **out)
     c->device = device; c->depth = bit_depth;
     c->d_jobs = c->d_results = c->d_stage = 0; c->d_ticket = 0; c->jobs_cap = c->results_cap = c->stage_cap = 0; c->d_out = 0;
     c->esa_window_bytes = ESA_WINDOW_DEFAULT;
+    c->esa_lds_raised = c->rime_lds_raised = false;
     if (hipSetDevice(device) != hipSuccess || hipStreamCreate(&c->stream) != hipSuccess ||
         hipMalloc((void**)&c->d_out, 64) != hipSuccess || hipMalloc((void**)&c->d_ticket, 256) != hipSuccess)
     {
@@ -850,6 +858,7 @@ int x265amd_create(int device, int bit_depth, x265amd_ctx **out)
 void x265amd_destroy(x265amd_ctx *c)
 {
     if (!c) return;
+    if (g_prim_ctx == c) g_prim_ctx = 0;   /* the primitives table it served now fails loudly instead of reading freed memory */
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
     for (std::map<int, uint16_t*>::iterator it = c->tables.begin(); it != c->tables.end(); ++it) (void)hipFree(it->second);
@@ -901,9 +910,11 @@ int x265amd_set_qp(x265amd_ctx *c, int qp)
 int x265amd_cost_table(x265amd_ctx *c, int qp, uint16_t *out)
 {
     if (!c || !out || qp < 0 || qp >= 70) return fail(c, X265AMD_EINVAL, "bad argument");
-    std::vector<uint16_t> tab(65536);
-    build_cost_table(qp, tab.data());
-    memcpy(out, tab.data() + 1, 65535 * sizeof(uint16_t));
+    /* the device copy, i.e. what the kernels read */
+    int rc = x265amd_set_qp(c, qp);
+    if (rc) return rc;
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipMemcpy(out, c->tables[qp] + 1, 65535 * sizeof(uint16_t), hipMemcpyDeviceToHost));
     return X265AMD_OK;
 }
 
@@ -923,6 +934,7 @@ static int plane_alloc(x265amd_ctx *c, int width, int height, int mx, int my, in
     HIPCHK(c, hipMemsetAsync(d, 0, plane_bytes(c, height, my, stride) + 256, c->stream));
     out->origin = (char*)d + ((size_t)my * stride + mx) * bpp;
     out->stride = stride; out->width = width; out->height = height; out->margin_x = mx; out->margin_y = my;
+    c->plane_base[out->origin] = d;
     return X265AMD_OK;
 }
 
@@ -943,9 +955,14 @@ int x265amd_plane_upload(x265amd_ctx *c, const void *buf, int width, int height,
 int x265amd_plane_free(x265amd_ctx *c, x265amd_plane *p)
 {
     if (!c || !p || !p->origin) return fail(c, X265AMD_EINVAL, "null plane");
-    const int bpp = c->depth > 8 ? 2 : 1;
+    /* the allocation is looked up, not derived from the geometry: the int16 plane of x265amd_rk_ds_plane has
+     * another sample size than the context's pictures */
+    std::map<const void*, void*>::iterator it = c->plane_base.find(p->origin);
+    if (it == c->plane_base.end()) return fail(c, X265AMD_EINVAL, "plane was not made by this context (or was freed already)");
     HIPCHK(c, hipSetDevice(c->device));
-    HIPCHK(c, hipFree((char*)p->origin - ((size_t)p->margin_y * p->stride + p->margin_x) * bpp));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipFree(it->second));
+    c->plane_base.erase(it);
     p->origin = 0;
     return X265AMD_OK;
 }
@@ -1191,6 +1208,46 @@ int x265amd_subpel_compare_batch(x265amd_ctx *c, const x265amd_plane *fenc, cons
     return X265AMD_OK;
 }
 
+/* Every sample a lookahead search of the wcu x hcu grid can touch must lie inside the padded planes. The search range
+ * of a CU reaches 8 samples outside the grid (slicetype.cpp:1427-1430); hexagon / square / diamond steps go up to 3
+ * further without a range check (motion.cpp:635, :673-678, :711-721) and the quarter-pel average reads one more sample.
+ * UMH measures its cross relative to the block it started from, up to the rescaled range (x 6/4) away, and its vertical
+ * cross at x = omv.x + omv.y (motion.cpp:732, :301-303): the same bound validate_jobs applies per job, taken over the
+ * corner CUs of the grid. Fills the device descriptors on success. */
+static int lookahead_fields_check(x265amd_ctx *c, const x265amd_field *fields, int nfields, int wcu, int hcu, int method,
+                                  int merange, FieldDev *hf /* nfields entries */)
+{
+    if (method < 0 || method > X265AMD_FULL) return fail(c, X265AMD_EINVAL, "bad method");
+    if (merange < 0 || merange > 4096) return fail(c, X265AMD_EINVAL, "merange out of range");
+    int need_x = 8 + 3 + 1, need_y = 8 + 3 + 1;
+    if (method == X265AMD_UMH)
+    {
+        const int b = ((merange * 6) >> 2) + 6, apron = 8;
+        need_x = 16 + (hcu - 1) * 8 + 8 + b + apron;
+        need_y = 16 + b + apron;
+    }
+    for (int i = 0; i < nfields; i++)
+    {
+        const x265amd_plane &f = fields[i].fenc;
+        if (!f.origin || f.width < wcu * 8 || f.height < hcu * 8 || f.stride < f.width)
+            return fail(c, X265AMD_EINVAL, "lookahead field: source plane does not cover the CU grid");
+        hf[i].fenc.origin = f.origin; hf[i].fenc.stride = f.stride;
+        for (int k = 0; k < 4; k++)
+        {
+            const x265amd_plane &p = fields[i].ref[k];
+            if (!p.origin || p.width < wcu * 8 || p.height < hcu * 8)
+                return fail(c, X265AMD_EINVAL, "lookahead field: reference plane does not cover the CU grid");
+            if (p.stride != fields[i].ref[0].stride)
+                return fail(c, X265AMD_EINVAL, "lookahead field: the four half-pel planes of a reference must share one stride");
+            if (p.margin_x < need_x || p.margin_y < need_y || p.stride < p.width + 2 * p.margin_x)
+                return fail(c, X265AMD_EINVAL, "lookahead field: reference margins too small for this search method "
+                                               "(12 samples; UMH: 32 + 8 * (height_in_cu - 1) + 6 * merange / 4 + 6 wide, 30 + 6 * merange / 4 high)");
+            hf[i].ref[k].origin = p.origin; hf[i].ref[k].stride = p.stride;
+        }
+    }
+    return X265AMD_OK;
+}
+
 int x265amd_lookahead_fields(x265amd_ctx *c, const x265amd_field *fields, int nfields, int wcu, int hcu,
                              int qp, int method, int subme, int merange,
                              int16_t *out_mvs, int32_t *out_costs, x265amd_result *out_stats)
@@ -1200,24 +1257,12 @@ int x265amd_lookahead_fields(x265amd_ctx *c, const x265amd_field *fields, int nf
     if (method < 0 || method > X265AMD_FULL || subme < 0 || subme > 7)
         return fail(c, X265AMD_EINVAL, "bad method / subme");
     if (!nfields) return X265AMD_OK;
-    for (int i = 0; i < nfields; i++)
-    {
-        const x265amd_plane &p = fields[i].ref[0];
-        /* slicetype.cpp:1427-1430: MVs may reach 8 px outside the frame, +3 unchecked
-         * hexagon steps, + the 8x8 block itself on the far side */
-        if (p.margin_x < 16 || p.margin_y < 16 || p.width < wcu * 8 || p.height < hcu * 8)
-            return fail(c, X265AMD_EINVAL, "lowres plane geometry does not cover the CU grid + 16 px");
-    }
-    int rc = x265amd_set_qp(c, qp);
+    std::vector<FieldDev> hf(nfields);
+    int rc = lookahead_fields_check(c, fields, nfields, wcu, hcu, method, merange, hf.data());
     if (rc) return rc;
+    if ((rc = x265amd_set_qp(c, qp))) return rc;
     HIPCHK(c, hipSetDevice(c->device));
     const size_t ncu = (size_t)wcu * hcu;
-    std::vector<FieldDev> hf(nfields);
-    for (int i = 0; i < nfields; i++)
-    {
-        hf[i].fenc.origin = fields[i].fenc.origin; hf[i].fenc.stride = fields[i].fenc.stride;
-        for (int k = 0; k < 4; k++) { hf[i].ref[k].origin = fields[i].ref[k].origin; hf[i].ref[k].stride = fields[i].ref[k].stride; }
-    }
     const size_t fbytes = nfields * sizeof(FieldDev), mvbytes = nfields * ncu * 4, cbytes = nfields * ncu * 4;
     const size_t sbytes = out_stats ? nfields * ncu * sizeof(x265amd_result) : 0;
     if ((rc = ensure(c, &c->d_jobs, &c->jobs_cap, fbytes))) return rc;
@@ -1231,7 +1276,7 @@ int x265amd_lookahead_fields(x265amd_ctx *c, const x265amd_field *fields, int nf
     a.mvs = (int16_t*)c->d_results;
     a.costs = (int32_t*)((char*)c->d_results + mvbytes);
     a.stats = out_stats ? (x265amd_result*)((char*)c->d_results + mvbytes + cbytes) : 0;
-    if ((rc = launch_lookahead(c, a, nfields))) return rc;
+    if ((rc = launch_lookahead(c, a, nfields, c->d_ticket))) return rc;
     HIPCHK(c, hipMemcpyAsync(out_mvs, a.mvs, mvbytes, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipMemcpyAsync(out_costs, a.costs, cbytes, hipMemcpyDeviceToHost, c->stream));
     if (out_stats) HIPCHK(c, hipMemcpyAsync(out_stats, a.stats, sbytes, hipMemcpyDeviceToHost, c->stream));
@@ -1239,15 +1284,13 @@ int x265amd_lookahead_fields(x265amd_ctx *c, const x265amd_field *fields, int nf
     return X265AMD_OK;
 }
 
-int x265amd_fields_upload(x265amd_ctx *c, const x265amd_field *fields, int nfields, void **d_fields)
+int x265amd_fields_upload(x265amd_ctx *c, const x265amd_field *fields, int nfields, int wcu, int hcu, int method, int merange,
+                          void **d_fields)
 {
-    if (!c || !fields || nfields <= 0 || !d_fields) return fail(c, X265AMD_EINVAL, "null argument");
+    if (!c || !fields || nfields <= 0 || wcu <= 0 || hcu <= 0 || !d_fields) return fail(c, X265AMD_EINVAL, "null argument");
     std::vector<FieldDev> hf(nfields);
-    for (int i = 0; i < nfields; i++)
-    {
-        hf[i].fenc.origin = fields[i].fenc.origin; hf[i].fenc.stride = fields[i].fenc.stride;
-        for (int k = 0; k < 4; k++) { hf[i].ref[k].origin = fields[i].ref[k].origin; hf[i].ref[k].stride = fields[i].ref[k].stride; }
-    }
+    int rc = lookahead_fields_check(c, fields, nfields, wcu, hcu, method, merange, hf.data());
+    if (rc) return rc;
     HIPCHK(c, hipSetDevice(c->device));
     HIPCHK(c, hipMalloc(d_fields, nfields * sizeof(FieldDev)));
     HIPCHK(c, hipMemcpy(*d_fields, hf.data(), nfields * sizeof(FieldDev), hipMemcpyHostToDevice));
@@ -1279,7 +1322,7 @@ int x265amd_lookahead_fields_dev(x265amd_ctx *c, const void *d_fields, int nfiel
     a.wcu = wcu; a.hcu = hcu; a.depth = c->depth; a.method = method; a.subme = subme; a.merange = merange;
     a.ctab = c->tables[qp] + 32768;
     a.mvs = d_mvs; a.costs = d_costs; a.stats = d_stats;
-    if ((rc = launch_lookahead(c, a, nfields))) return rc;
+    if ((rc = launch_lookahead(c, a, nfields, c->d_ticket))) return rc;
     return X265AMD_OK;
 }
 
@@ -1978,8 +2021,12 @@ int x265amd_rk_ds_plane(x265amd_ctx *c, const x265amd_plane *orig, x265amd_plane
     const int stride = w4 + 2 * m4;
     void *d = 0;
     HIPCHK(c, hipSetDevice(c->device));
-    HIPCHK(c, hipMalloc(&d, (size_t)(h4 + 2 * m4) * stride * sizeof(int16_t)));
+    /* + slack, as for every plane: window staging reads whole 16-byte chunks */
+    const size_t ds_bytes = (size_t)(h4 + 2 * m4) * stride * sizeof(int16_t) + 256;
+    HIPCHK(c, hipMalloc(&d, ds_bytes));
+    HIPCHK(c, hipMemsetAsync(d, 0, ds_bytes, c->stream));
     int16_t *origin = (int16_t*)d + (size_t)m4 * stride + m4;
+    c->plane_base[origin] = d;
     dim3 blk(64, 4), grd((w4 + 63) / 64, (h4 + 3) / 4), grd2((w4 + 2 * m4 + 63) / 64, (h4 + 2 * m4 + 3) / 4);
     if (c->depth <= 8)
         hipLaunchKernelGGL(rk_downsample_kernel<uint8_t>, grd, blk, 0, c->stream, (const uint8_t*)orig->origin, (long)orig->stride,
@@ -2013,11 +2060,10 @@ int x265amd_rk_ctu_batch_dev(x265amd_ctx *c, const x265amd_plane *fenc, const x2
     const size_t lds = (512 + 112 * 95 + 16) * sizeof(int16_t);
     if (c->depth <= 8)
     {
-        static bool lds_raised = false;
-        if (!lds_raised)
+        if (!c->rime_lds_raised)
         {
             HIPCHK(c, hipFuncSetAttribute((const void*)rk_rime_kernel<uint8_t>, hipFuncAttributeMaxDynamicSharedMemorySize, RL_TOTAL));
-            lds_raised = true;
+            c->rime_lds_raised = true;
         }
         hipLaunchKernelGGL(rk_cime_kernel<uint8_t>, dim3(nctus), dim3(CIME_THREADS), lds, c->stream, a);
         hipLaunchKernelGGL(rk_rime_kernel<uint8_t>, dim3(nctus), dim3(RIME_THREADS), RL_TOTAL, c->stream, a);

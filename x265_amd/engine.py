@@ -225,7 +225,8 @@ class Engine:
         self._chk(self.L.x265amd_search_batch_dev(self.ctx, C.byref(fenc), refs, int(is_lowres), qp, method, subme,
                                                   C.c_void_p(d_jobs), njobs, C.c_void_p(d_results), max_pu_dim))
 
-    def fields_upload(self, fields):
+    def fields_upload(self, fields, wcu, hcu, method=HEX, merange=16):
+        """Checks the planes against the CU grid / method / merange and puts the descriptors on the device."""
         n = len(fields)
         arr = (Field * n)()
         for i, (fe, refs) in enumerate(fields):
@@ -233,7 +234,7 @@ class Engine:
             for k in range(4):
                 arr[i].ref[k] = refs[k]
         d = C.c_void_p()
-        self._chk(self.L.x265amd_fields_upload(self.ctx, arr, n, C.byref(d)))
+        self._chk(self.L.x265amd_fields_upload(self.ctx, arr, n, wcu, hcu, method, merange, C.byref(d)))
         return d
 
     def device_free(self, d):
@@ -299,7 +300,7 @@ class Engine:
                 m = k + 1
                 while m < len(todo) and 2 * todo[m][0] + todo[m][1] == 2 * todo[m - 1][0] + todo[m - 1][1] + 1:
                     m += 1
-                d_f = self.fields_upload([(frames[i]["fenc"][0], frames[i]["ref%d" % l]) for i, l in todo[k:m]])
+                d_f = self.fields_upload([(frames[i]["fenc"][0], frames[i]["ref%d" % l]) for i, l in todo[k:m]], wcu, hcu, method, merange)
                 owned.append(d_f)
                 slot = 2 * todo[k][0] + todo[k][1]
                 self.lookahead_fields_dev(d_f, m - k, wcu, hcu, qp, method, subme, merange,

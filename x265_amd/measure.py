@@ -111,7 +111,7 @@ def lookahead_costs(e, dev, width=1920, height=1080, nframes=16, reps=3, seed=21
     fields = []
     for b in range(1, n + 1):
         fields += [(low[b][0], low[b - 1]), (low[b][0], low[b + 1])]
-    d_fields = e.fields_upload(fields)
+    d_fields = e.fields_upload(fields, wcu, hcu, HEX, 16)
     d_mvs = torch.zeros((n, 2, ncu, 2), dtype=torch.int16, device=dev)
     d_mvc = torch.zeros((n, 2, ncu), dtype=torch.int32, device=dev)
     out = {"intra_cost": torch.zeros((n, ncu), dtype=torch.int32, device=dev),
