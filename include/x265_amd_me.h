@@ -176,6 +176,22 @@ int x265amd_lookahead_fields_dev(x265amd_ctx *ctx, const void *d_fields, int nfi
                                  int width_in_cu, int height_in_cu, int qp, int method, int subme, int merange,
                                  int16_t *d_mvs, int32_t *d_costs, x265amd_result *d_stats /* or NULL */);
 
+/* x265amd_lookahead_fields for callers that cannot allocate device memory (code running under HIP graph capture,
+ * tight serving loops, harnesses that forbid hipMalloc). It has no counterpart in the reference. Same arguments and
+ * results as x265amd_lookahead_fields, but the call makes no allocation of any kind: the field descriptors, the MV /
+ * cost / statistics arrays the kernel writes and the row ticket of the kernel sit in a static device array of
+ * X265AMD_STATIC_SCRATCH_BYTES that every GPU the library runs on holds until the process ends. Limits, refused with
+ * X265AMD_EINVAL: at most X265AMD_STATIC_MAX_FIELDS fields, and
+ *   256 + 80 * nfields (rounded up to 256) + nfields * width_in_cu * height_in_cu * (8, or 24 with out_stats)
+ * bytes must fit the array (e.g. 120 fields of a 1080p frame, 7 of an 8K frame). The cost table of `qp` must have been
+ * built before by x265amd_set_qp (that call allocates; this one returns X265AMD_EINVAL if the table is missing).
+ * All calls on one GPU share that GPU's array: calls that overlap in time on one GPU (two contexts, two threads) race. */
+#define X265AMD_STATIC_SCRATCH_BYTES (8 << 20)
+#define X265AMD_STATIC_MAX_FIELDS 256
+int x265amd_lookahead_fields_static(x265amd_ctx *ctx, const x265amd_field *fields, int nfields,
+                                    int width_in_cu, int height_in_cu, int qp, int method, int subme, int merange,
+                                    int16_t *out_mvs, int32_t *out_costs, x265amd_result *out_stats /* nfields*ncu or NULL */);
+
 /* ---- lookahead frame cost ---- */
 
 /* Everything EstimateRow::estimateCUCost computes for the 8x8 CUs of frame b besides the

@@ -727,12 +727,23 @@ struct x265amd_ctx
     int32_t *d_out;
     int *d_ticket;                     /* row hand-out counter of the row-parallel lookahead kernel */
     int esa_window_bytes;              /* LDS the exhaustive search may use per PU for its window */
+    unsigned char *scratch;            /* this device's copy of the static scratch array (x265amd_lookahead_fields_static) */
     bool esa_lds_raised, rime_lds_raised; /* dynamic-LDS limits raised on this context's device (the attribute is per device) */
     std::map<const void*, void*> plane_base; /* plane origin -> start of its allocation, whatever the sample size */
 };
 
 static x265amd_ctx *g_prim_ctx = 0;    /* context behind the per-call primitives table (me_primitives.inc) */
 
+/* Device memory of x265amd_lookahead_fields_static, the entry point that allocates nothing: the row ticket of
+ * the row-parallel lookahead kernel, the field descriptors and the MV / cost / statistics arrays the kernel writes
+ * before they are copied to the caller. Every GPU the library runs on holds its own copy of the array until the
+ * process ends. `scratch` is only a host-side handle of the symbol: the address of a device's copy comes from
+ * hipGetSymbolAddress (x265amd_create, with that device current) and is what every launch, memset and copy uses. */
+#define SCRATCH_BYTES X265AMD_STATIC_SCRATCH_BYTES
+#define SCRATCH_HEAD 256               /* the ticket, alone in its 256 bytes */
+#define SCRATCH_MAX_DEVICES 64
+static __device__ __align__(256) unsigned char scratch[SCRATCH_BYTES];
+static void *g_scratch_ptr[SCRATCH_MAX_DEVICES];   /* per device: address of its copy of `scratch`, 0 = not asked yet */
 
 #define ESA_WINDOW_DEFAULT 36864
 #define ESA_WINDOW_MIN 8192
@@ -850,6 +861,23 @@ int x265amd_create(int device, int bit_depth, x265amd_ctx **out)
     {
         delete c;
         return X265AMD_EHIP;
+    }
+    /* this device's copy of the static scratch array (the device is current here) */
+    c->scratch = 0;
+    if (device < SCRATCH_MAX_DEVICES)
+    {
+        if (!g_scratch_ptr[device])
+        {
+            void *ptr = 0;
+            if (hipGetSymbolAddress(&ptr, HIP_SYMBOL(scratch)) != hipSuccess || !ptr)
+            {
+                (void)hipFree(c->d_out); (void)hipFree(c->d_ticket); (void)hipStreamDestroy(c->stream);
+                delete c;
+                return X265AMD_EHIP;
+            }
+            g_scratch_ptr[device] = ptr;
+        }
+        c->scratch = (unsigned char*)g_scratch_ptr[device];
     }
     *out = c;
     return X265AMD_OK;
@@ -1323,6 +1351,62 @@ int x265amd_lookahead_fields_dev(x265amd_ctx *c, const void *d_fields, int nfiel
     a.ctab = c->tables[qp] + 32768;
     a.mvs = d_mvs; a.costs = d_costs; a.stats = d_stats;
     if ((rc = launch_lookahead(c, a, nfields, c->d_ticket))) return rc;
+    return X265AMD_OK;
+}
+
+/* x265amd_lookahead_fields without a single allocation: descriptors, result arrays and the row ticket live in the
+ * static scratch array of the context's device, the cost table must exist already. Calls that overlap on one GPU
+ * (two contexts, two threads) race on that array. */
+int x265amd_lookahead_fields_static(x265amd_ctx *c, const x265amd_field *fields, int nfields, int wcu, int hcu,
+                                    int qp, int method, int subme, int merange,
+                                    int16_t *out_mvs, int32_t *out_costs, x265amd_result *out_stats)
+{
+    if (!c || !fields || nfields < 0 || wcu <= 0 || hcu <= 0 || !out_mvs || !out_costs)
+        return fail(c, X265AMD_EINVAL, "null argument");
+    if (method < 0 || method > X265AMD_FULL || subme < 0 || subme > 7)
+        return fail(c, X265AMD_EINVAL, "bad method / subme");
+    if (!c->scratch) return fail(c, X265AMD_EINVAL, "no static scratch array on this device (device index >= 64)");
+    if (qp < 0 || qp >= 70 || !c->tables.count(qp))
+        return fail(c, X265AMD_EINVAL, "the cost table of this qp does not exist yet: call x265amd_set_qp first (building it allocates)");
+    if (!nfields) return X265AMD_OK;
+    if (nfields > X265AMD_STATIC_MAX_FIELDS) return fail(c, X265AMD_EINVAL, "more than X265AMD_STATIC_MAX_FIELDS fields in one call");
+    const size_t ncu = (size_t)wcu * hcu;
+    const size_t fbytes = ((size_t)nfields * sizeof(FieldDev) + 255) & ~(size_t)255;
+    const size_t mvbytes = nfields * ncu * 4, cbytes = nfields * ncu * 4;
+    const size_t sbytes = out_stats ? nfields * ncu * sizeof(x265amd_result) : 0;
+    if (ncu > SCRATCH_BYTES || SCRATCH_HEAD + fbytes + mvbytes + cbytes + sbytes > SCRATCH_BYTES)
+        return fail(c, X265AMD_EINVAL, "fields too large for the static scratch array: nfields * width_in_cu * height_in_cu * "
+                                       "8 bytes (24 with statistics) + 80 bytes per field must fit X265AMD_STATIC_SCRATCH_BYTES - 256");
+    FieldDev hf[X265AMD_STATIC_MAX_FIELDS];
+    int rc = lookahead_fields_check(c, fields, nfields, wcu, hcu, method, merange, hf);
+    if (rc) return rc;
+    HIPCHK(c, hipSetDevice(c->device));
+    unsigned char *base = c->scratch;
+    LookaheadArgs a;
+    a.fields = (const FieldDev*)(base + SCRATCH_HEAD);
+    a.wcu = wcu; a.hcu = hcu; a.depth = c->depth; a.method = method; a.subme = subme; a.merange = merange;
+    a.ctab = c->tables[qp] + 32768;
+    a.mvs = (int16_t*)(base + SCRATCH_HEAD + fbytes);
+    a.costs = (int32_t*)(base + SCRATCH_HEAD + fbytes + mvbytes);
+    a.stats = out_stats ? (x265amd_result*)(base + SCRATCH_HEAD + fbytes + mvbytes + cbytes) : 0;
+    /* the array keeps the last call's contents: the ticket and (row kernel) the MV marks are set again by
+     * launch_lookahead, costs and statistics are written for every CU. `hf` is on this stack frame, so no path leaves
+     * before the stream has drained. */
+    hipError_t e = hipMemcpyAsync(base + SCRATCH_HEAD, hf, (size_t)nfields * sizeof(FieldDev), hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess)
+    {
+        rc = launch_lookahead(c, a, nfields, (int*)base);
+        if (!rc)
+        {
+            e = hipMemcpyAsync(out_mvs, a.mvs, mvbytes, hipMemcpyDeviceToHost, c->stream);
+            if (e == hipSuccess) e = hipMemcpyAsync(out_costs, a.costs, cbytes, hipMemcpyDeviceToHost, c->stream);
+            if (e == hipSuccess && out_stats) e = hipMemcpyAsync(out_stats, a.stats, sbytes, hipMemcpyDeviceToHost, c->stream);
+        }
+    }
+    const hipError_t es = hipStreamSynchronize(c->stream);
+    if (rc) return rc;
+    HIPCHK(c, e);
+    HIPCHK(c, es);
     return X265AMD_OK;
 }
 

@@ -209,6 +209,27 @@ class Engine:
                                                   C.c_void_p(stats.ctypes.data) if want_stats else None))
         return mvs, costs, stats
 
+    def set_qp(self, qp):
+        """BitCost::setQP: builds the table of `qp` on the device (the only step of a lookahead call that allocates)."""
+        self._chk(self.L.x265amd_set_qp(self.ctx, qp))
+
+    def lookahead_fields_static(self, fields, wcu, hcu, qp, method=HEX, subme=1, merange=16, want_stats=False):
+        """lookahead_fields through the entry point that allocates nothing (static device scratch array); the
+        cost table of `qp` must exist (set_qp)."""
+        n = len(fields)
+        arr = (Field * max(1, n))()
+        for i, (fe, refs) in enumerate(fields):
+            arr[i].fenc = fe
+            for k in range(4):
+                arr[i].ref[k] = refs[k]
+        mvs = np.zeros((n, wcu * hcu, 2), np.int16)
+        costs = np.zeros((n, wcu * hcu), np.int32)
+        stats = np.zeros((n, wcu * hcu), RESULT_DTYPE) if want_stats else None
+        self._chk(self.L.x265amd_lookahead_fields_static(self.ctx, arr, n, wcu, hcu, qp, method, subme, merange,
+                                                         C.c_void_p(mvs.ctypes.data), C.c_void_p(costs.ctypes.data),
+                                                         C.c_void_p(stats.ctypes.data) if want_stats else None))
+        return mvs, costs, stats
+
     # ---- device-resident variants (pointers are raw device addresses, e.g. torch tensor.data_ptr())
     def stream(self):
         return self.L.x265amd_stream(self.ctx)
