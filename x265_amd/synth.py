@@ -39,6 +39,29 @@ def make_clip(width, height, nframes, seed=1234, depth=8, kind="texture"):
     return frames
 
 
+def baseline_clip(width, height, nframes, seed=1234):
+    """Luma frames of the 8-bit 4:2:0 clips the reference encoder's bitstream MD5s were recorded on (chroma is constant
+    128): the same recipe as make_clip(kind="texture"), but with the box filter taken as a float32 window mean, which
+    rounds differently, so the two generators are not interchangeable."""
+    from numpy.lib.stride_tricks import sliding_window_view
+    rng = np.random.default_rng(seed)
+    base = rng.integers(0, 256, size=(height + 64, width + 64), dtype=np.uint8)
+    b = sliding_window_view(np.pad(base.astype(np.float32), 2, mode="edge"), (5, 5)).mean(axis=(2, 3))
+    frames = []
+    for i in range(nframes):
+        dx, dy = (i * 3) % 32, (i * 2) % 32
+        frames.append(np.clip(b[dy:dy + height, dx:dx + width] + rng.normal(0, 2, (height, width)), 0, 255).astype(np.uint8))
+    return frames
+
+
+def write_yuv420(path, frames):
+    """Planar 8-bit 4:2:0 file of luma frames with constant-128 chroma."""
+    with open(path, "wb") as f:
+        for y in frames:
+            f.write(np.ascontiguousarray(y).tobytes())
+            f.write(np.full((y.shape[0] // 2) * (y.shape[1] // 2) * 2, 128, np.uint8).tobytes())
+
+
 def make_chroma(width, height, nframes, seed=1234, depth=8):
     """Cb / Cr planes of a 4:2:0 clip ((height/2, width/2) each): the luma recipe at half size with other seeds."""
     cb = make_clip(width // 2, height // 2, nframes, seed + 7001, depth)

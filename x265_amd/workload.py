@@ -96,6 +96,15 @@ def rk_search_range(pic_w, pic_h, cu_x, cu_y, merange_x, merange_y, search_range
     return (mnx, mny), (mxx, mxy)
 
 
+def rk_cu_offsets():
+    """(x offset, y offset, size) of the 85 CUs of a CTU in offsIdx order (OffsFromCtu64, hardwareC/inter.cpp:23-38):
+    0-63 the 8x8 CUs in raster order, 64-79 16x16, 80-83 32x32, 84 the 64x64 CU."""
+    out = []
+    for size, n in ((8, 8), (16, 4), (32, 2), (64, 1)):
+        out += [((i % n) * size, (i // n) * size, size) for i in range(n * n)]
+    return out
+
+
 def rk_ctu_jobs(pic_w, pic_h, pmvs, mvps, have_mvd=True, me_range=(384, 320), dtype=None):
     """One job per 64x64 CTU in raster order. pmvs: (nctu, 2, 2) even full-pel neighbour PMVs
     (RIME window centres 1 and 2); mvps: (nctu, 3, 2) cost predictors (TEncSearch.cpp:3788-3805)."""
