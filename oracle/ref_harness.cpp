@@ -28,6 +28,9 @@
 #include "TLibCommon/TComSlice.h"
 #include "TLibCommon/TComPicYuv.h"
 #include "slicetype.h"
+#include "TLibCommon/TComYuv.h"
+#include "TShortYUV.h"
+#include "TLibCommon/TComWeightPrediction.h"
 
 #include <string.h>
 #include <stdlib.h>
@@ -634,9 +637,25 @@ void ref_bipred_cost(pixel *fencPU, intptr_t fencStride, pixel *ref0PU, pixel *r
 
 /* ---- merge-candidate estimate (compress.cpp:248-271): the primitive calls that
  * TComPrediction::motionCompensation makes for the luma of one candidate (xPredInterUni ->
- * xPredInterLumaBlk, TComPrediction.cpp:405-476; two lists: the TShortYUV flavour and
- * TComYuv::addAvg, TComYuv.cpp:573-612, whose loop is repeated here because TComYuv needs a whole
- * CU buffer set), then primitives.sa8d[log2 size - 3] as compress.cpp:265 calls it. ---- */
+ * xPredInterLumaBlk, TComPrediction.cpp:405-476; two lists: the TShortYUV flavour and the reference's own
+ * TComYuv::addAvg, TComYuv.cpp:573-612, on CU buffers made with its create()), then
+ * primitives.sa8d[log2 size - 3] as compress.cpp:265 calls it. ---- */
+
+/* The 64x64 CU buffers motionCompensation works in (TComPrediction::m_predShortYuv[2], the caller's predYuv): the
+ * two 14-bit predictions and the prediction samples, created by the reference's own create() so that strides and
+ * chroma geometry are the reference's. */
+struct CuBuffers
+{
+    TShortYUV s0, s1;
+    TComYuv pred;
+    CuBuffers()
+    {
+        s0.create(MAX_CU_SIZE, MAX_CU_SIZE, X265_CSP_I420);
+        s1.create(MAX_CU_SIZE, MAX_CU_SIZE, X265_CSP_I420);
+        pred.create(MAX_CU_SIZE, MAX_CU_SIZE, X265_CSP_I420);
+    }
+    ~CuBuffers() { s0.destroy(); s1.destroy(); pred.destroy(); }
+};
 static void harness_pred_luma_short(pixel *refPU, intptr_t stride, int qx, int qy, int part, int width, int height, int16_t *dst,
                                     int16_t *immed)
 {
@@ -662,19 +681,11 @@ int ref_merge_sa8d(pixel *fencPU, intptr_t fencStride, pixel *ref0PU, intptr_t r
     else if (dir == 2) harness_pred_luma(ref1PU, ref1Stride, mv1[0], mv1[1], part, size, pred, 64, immed);
     else
     {
-        int16_t *s0 = (int16_t*)malloc(sizeof(int16_t) * 64 * 64 * 2), *s1 = s0 + 64 * 64;
-        harness_pred_luma_short(ref0PU, ref0Stride, mv0[0], mv0[1], part, size, size, s0, immed);
-        harness_pred_luma_short(ref1PU, ref1Stride, mv1[0], mv1[1], part, size, size, s1, immed);
-        const int shiftNum = IF_INTERNAL_PREC + 1 - X265_DEPTH;
-        const int offset = (1 << (shiftNum - 1)) + 2 * IF_INTERNAL_OFFS;
-        const int maxv = (1 << X265_DEPTH) - 1;
-        for (int y = 0; y < size; y++)
-            for (int x = 0; x < size; x++)
-            {
-                int v = (s0[y * 64 + x] + s1[y * 64 + x] + offset) >> shiftNum;
-                pred[y * 64 + x] = (pixel)(v < 0 ? 0 : (v > maxv ? maxv : v));
-            }
-        free(s0);
+        CuBuffers cu;
+        harness_pred_luma_short(ref0PU, ref0Stride, mv0[0], mv0[1], part, size, size, cu.s0.getLumaAddr(), immed);
+        harness_pred_luma_short(ref1PU, ref1Stride, mv1[0], mv1[1], part, size, size, cu.s1.getLumaAddr(), immed);
+        cu.pred.addAvg(&cu.s0, &cu.s1, 0, size, size, true, false);         /* TComYuv.cpp:573 */
+        for (int y = 0; y < size; y++) memcpy(pred + y * 64, cu.pred.getLumaAddr() + y * cu.pred.getStride(), size * sizeof(pixel));
     }
     const int cost = primitives.sa8d[g_convertToBit[size]](fencPU, fencStride, pred, 64);
     free(immed);
@@ -717,52 +728,39 @@ static void harness_pred_chroma_short(pixel *refBlk, intptr_t stride, int ex, in
     }
 }
 
-static void harness_add_avg(const int16_t *s0, const int16_t *s1, int pitch, int w, int h, pixel *dst, intptr_t dstStride)
-{
-    const int shiftNum = IF_INTERNAL_PREC + 1 - X265_DEPTH;
-    const int offset = (1 << (shiftNum - 1)) + 2 * IF_INTERNAL_OFFS;
-    const int maxv = (1 << X265_DEPTH) - 1;
-    for (int y = 0; y < h; y++)
-        for (int x = 0; x < w; x++)
-        {
-            int v = (s0[y * pitch + x] + s1[y * pitch + x] + offset) >> shiftNum;
-            dst[y * dstStride + x] = (pixel)(v < 0 ? 0 : (v > maxv ? maxv : v));
-        }
-}
-
-/* addWeightBi on two 14-bit blocks (TComWeightPrediction.cpp:203-313; weightBidirY / weightBidirC :46-54 are
- * file-static there, so the expression is repeated) with getWpScaling's bi-directional parameters (:534-549) */
-static void harness_add_weight_bi(const int16_t *s0, const int16_t *s1, int pitch, int w, int h, int w0, int w1, int offset, int shift,
-                                  pixel *dst, intptr_t dstStride)
-{
-    const int round = shift ? (1 << (shift - 1)) : 0;
-    const int maxv = (1 << X265_DEPTH) - 1;
-    for (int y = 0; y < h; y++)
-        for (int x = 0; x < w; x++)
-        {
-            int v = (w0 * (s0[y * pitch + x] + IF_INTERNAL_OFFS) + w1 * (s1[y * pitch + x] + IF_INTERNAL_OFFS) + round + (offset << (shift - 1))) >> shift;
-            dst[y * dstStride + x] = (pixel)(v < 0 ? 0 : (v > maxv ? maxv : v));
-        }
-}
-
 struct HarnessWeight { int16_t w[3], offset[3]; uint8_t log2denom[3], reserved; };
 
-/* one component of xWeightedPredictionUni / xWeightedPredictionBi on 14-bit blocks: the uni-directional case through
- * the reference's weight_sp primitive as addWeightUni calls it (:433-485) */
-static void harness_weight(int16_t *s0, int16_t *s1, int pitch, int w, int h, int dir, const HarnessWeight *wp0, const HarnessWeight *wp1,
-                           int comp, pixel *dst, intptr_t dstStride)
+/* the derived fields of wpScalingParam as TComWeightPrediction::getWpScaling fills them (TComWeightPrediction.cpp:
+ * 534-560; that function itself reads the tables of a slice through a TComDataCU) */
+static void harness_wp_scaling(const HarnessWeight *h0, const HarnessWeight *h1, bool bidir, wpScalingParam wp0[3], wpScalingParam wp1[3])
 {
-    const int shiftNum = IF_INTERNAL_PREC - X265_DEPTH;
-    if (dir == 3)
-        harness_add_weight_bi(s0, s1, pitch, w, h, wp0->w[comp], wp1->w[comp],
-                              wp0->offset[comp] * (1 << (X265_DEPTH - 8)) + wp1->offset[comp] * (1 << (X265_DEPTH - 8)),
-                              wp0->log2denom[comp] + 1 + shiftNum, dst, dstStride);
-    else
+    for (int c = 0; c < 3; c++)
     {
-        const HarnessWeight *wp = dir == 1 ? wp0 : wp1;
-        const int shift = wp->log2denom[comp] + shiftNum, round = shift ? (1 << (shift - 1)) : 0;
-        primitives.weight_sp(dir == 1 ? s0 : s1, dst, pitch, dstStride, w, h, wp->w[comp], round, shift,
-                             wp->offset[comp] * (1 << (X265_DEPTH - 8)));
+        const HarnessWeight *hs[2] = { h0, h1 };
+        wpScalingParam *ws[2] = { &wp0[c], &wp1[c] };
+        for (int l = 0; l < 2; l++)
+        {
+            if (!hs[l]) continue;
+            ws[l]->bPresentFlag = true;
+            ws[l]->log2WeightDenom = hs[l]->log2denom[c]; ws[l]->inputWeight = hs[l]->w[c]; ws[l]->inputOffset = hs[l]->offset[c];
+            ws[l]->w = ws[l]->inputWeight;
+            ws[l]->o = ws[l]->inputOffset * (1 << (X265_DEPTH - 8));
+        }
+        if (bidir)
+        {
+            wp0[c].offset = wp0[c].o + wp1[c].o;
+            wp0[c].shift = wp0[c].log2WeightDenom + 1;
+            wp0[c].round = 1 << wp0[c].log2WeightDenom;
+            wp1[c].offset = wp0[c].offset; wp1[c].shift = wp0[c].shift; wp1[c].round = wp0[c].round;
+        }
+        else
+            for (int l = 0; l < 2; l++)
+                if (hs[l])
+                {
+                    ws[l]->offset = ws[l]->o;
+                    ws[l]->shift = ws[l]->log2WeightDenom;
+                    ws[l]->round = ws[l]->log2WeightDenom >= 1 ? 1 << (ws[l]->log2WeightDenom - 1) : 0;
+                }
     }
 }
 
@@ -771,35 +769,58 @@ void ref_mc_pu(pixel **ref0, const intptr_t *ref0Strides, pixel **ref1, const in
                const HarnessWeight *wp0, const HarnessWeight *wp1)
 {
     const int part = partitionFromSizes(w, h), cw = w >> 1, ch = h >> 1;
-    const bool weighted = (flags & 4) != 0;
+    const bool weighted = (flags & 4) != 0, bLuma = (flags & 1) != 0, bChroma = (flags & 2) != 0;
     int16_t *immed = (int16_t*)malloc(sizeof(int16_t) * 64 * (64 + 8));
-    int16_t *s0 = (int16_t*)malloc(sizeof(int16_t) * 64 * 64 * 2), *s1 = s0 + 64 * 64;
-    if (flags & 1)
+    if (dir == 3 || weighted)
     {
-        if (dir == 3 || weighted)
+        /* both lists (or any weighted PU): 14-bit predictions into the CU buffers, then the reference's own
+         * TComYuv::addAvg (TComYuv.cpp:573-650), TComWeightPrediction::addWeightBi (TComWeightPrediction.cpp:203-313) or
+         * addWeightUni (:433-485), as xPredInterBi / xWeightedPredictionBi / xWeightedPredictionUni call them */
+        CuBuffers cu;
+        int16_t *sh0[3] = { cu.s0.getLumaAddr(), cu.s0.getCbAddr(), cu.s0.getCrAddr() };
+        int16_t *sh1[3] = { cu.s1.getLumaAddr(), cu.s1.getCbAddr(), cu.s1.getCrAddr() };
+        if (bLuma)
         {
-            if (dir & 1) harness_pred_luma_short(ref0[0], ref0Strides[0], mv0[0], mv0[1], part, w, h, s0, immed);
-            if (dir & 2) harness_pred_luma_short(ref1[0], ref1Strides[0], mv1[0], mv1[1], part, w, h, s1, immed);
-            if (weighted) harness_weight(s0, s1, MAX_CU_SIZE, w, h, dir, wp0, wp1, 0, pred[0], predStrides[0]);
-            else harness_add_avg(s0, s1, MAX_CU_SIZE, w, h, pred[0], predStrides[0]);
+            if (dir & 1) harness_pred_luma_short(ref0[0], ref0Strides[0], mv0[0], mv0[1], part, w, h, sh0[0], immed);
+            if (dir & 2) harness_pred_luma_short(ref1[0], ref1Strides[0], mv1[0], mv1[1], part, w, h, sh1[0], immed);
         }
-        else if (dir == 1) harness_pred_luma(ref0[0], ref0Strides[0], mv0[0], mv0[1], part, w, pred[0], predStrides[0], immed);
-        else harness_pred_luma(ref1[0], ref1Strides[0], mv1[0], mv1[1], part, w, pred[0], predStrides[0], immed);
-    }
-    if (flags & 2)
-        for (int c = 1; c < 3; c++)
-        {
-            if (dir == 3 || weighted)
+        if (bChroma)
+            for (int c = 1; c < 3; c++)
             {
-                if (dir & 1) harness_pred_chroma_short(ref0[c], ref0Strides[1], mv0[0], mv0[1], part, cw, ch, s0, immed);
-                if (dir & 2) harness_pred_chroma_short(ref1[c], ref1Strides[1], mv1[0], mv1[1], part, cw, ch, s1, immed);
-                if (weighted) harness_weight(s0, s1, MAX_CU_SIZE / 2, cw, ch, dir, wp0, wp1, c, pred[c], predStrides[1]);
-                else harness_add_avg(s0, s1, MAX_CU_SIZE / 2, cw, ch, pred[c], predStrides[1]);
+                if (dir & 1) harness_pred_chroma_short(ref0[c], ref0Strides[1], mv0[0], mv0[1], part, cw, ch, sh0[c], immed);
+                if (dir & 2) harness_pred_chroma_short(ref1[c], ref1Strides[1], mv1[0], mv1[1], part, cw, ch, sh1[c], immed);
             }
-            else if (dir == 1) harness_pred_chroma(ref0[c], ref0Strides[1], mv0[0], mv0[1], part, cw, ch, pred[c], predStrides[1], immed);
-            else harness_pred_chroma(ref1[c], ref1Strides[1], mv1[0], mv1[1], part, cw, ch, pred[c], predStrides[1], immed);
+        if (!weighted)
+            cu.pred.addAvg(&cu.s0, &cu.s1, 0, w, h, bLuma, bChroma);
+        else
+        {
+            wpScalingParam p0[3], p1[3];
+            memset(p0, 0, sizeof(p0)); memset(p1, 0, sizeof(p1));
+            harness_wp_scaling((dir & 1) ? wp0 : NULL, (dir & 2) ? wp1 : NULL, dir == 3, p0, p1);
+            TComWeightPrediction wpred;
+            if (dir == 3) wpred.addWeightBi(&cu.s0, &cu.s1, 0, w, h, p0, p1, &cu.pred, true, bLuma, bChroma);
+            else if (dir == 1) wpred.addWeightUni(&cu.s0, 0, w, h, p0, &cu.pred, bLuma, bChroma);
+            else wpred.addWeightUni(&cu.s1, 0, w, h, p1, &cu.pred, bLuma, bChroma);
         }
-    free(s0);
+        if (bLuma)
+            for (int y = 0; y < h; y++) memcpy(pred[0] + y * predStrides[0], cu.pred.getLumaAddr() + y * cu.pred.getStride(), w * sizeof(pixel));
+        if (bChroma)
+            for (int y = 0; y < ch; y++)
+            {
+                memcpy(pred[1] + y * predStrides[1], cu.pred.getCbAddr() + y * cu.pred.getCStride(), cw * sizeof(pixel));
+                memcpy(pred[2] + y * predStrides[1], cu.pred.getCrAddr() + y * cu.pred.getCStride(), cw * sizeof(pixel));
+            }
+    }
+    else
+    {
+        pixel **ref = dir == 1 ? ref0 : ref1;
+        const intptr_t *strides = dir == 1 ? ref0Strides : ref1Strides;
+        const int16_t *mv = dir == 1 ? mv0 : mv1;
+        if (bLuma) harness_pred_luma(ref[0], strides[0], mv[0], mv[1], part, w, pred[0], predStrides[0], immed);
+        if (bChroma)
+            for (int c = 1; c < 3; c++)
+                harness_pred_chroma(ref[c], strides[1], mv[0], mv[1], part, cw, ch, pred[c], predStrides[1], immed);
+    }
     free(immed);
 }
 
