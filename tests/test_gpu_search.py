@@ -76,6 +76,41 @@ def test_every_partition_every_method(engine8, oracle):
             assert np.array_equal(r["mv"], mv) and np.array_equal(r["cost"], cost), (mname, part)
 
 
+@pytest.mark.parametrize("mname", ["star", "hex", "dia", "umh"])
+def test_small_pu_batches_vs_oracle(engine8, oracle, mname):
+    """Batches whose largest PU is 8x8 take the two-kernel route on 8-bit planes (search up to the full-pel / predictor
+    choice one PU per wave, then the sub-pel rounds of the 8x8 PUs four PUs per wave): every subme level, batch sizes
+    that are not multiples of four, 8x4 / 4x8 PUs mixed in (finished by the first kernel), and PUs whose full-pel cost
+    is 0 (no refinement, motion.cpp:1073-1076)."""
+    method = METHODS[mname]
+    W, H = 320, 192
+    m = margin_for(method)
+    for kind in ("texture", "noise"):
+        fenc, ref, org, stride = clip_planes(W, H, 8, kind, margin=m)
+        pf = engine8.upload_plane(fenc, W, H, m, m, stride)
+        pr = engine8.upload_plane(ref, W, H, m, m, stride)
+        for subme in range(8):
+            rng = np.random.default_rng(900 + method * 10 + subme)
+            n = 61 + subme
+            jobs = random_jobs(rng, n, W, H, method, parts=[(8, 8)] * 6 + [(8, 4), (4, 8)])
+            qp = int(rng.integers(10, 45))
+            r = engine8.search_batch(pf, pr, jobs, qp, method, subme)
+            mv, cost, sc, qc = oracle_search(oracle, 8, fenc, [ref], org, stride, jobs, qp, method, subme)
+            assert np.array_equal(r["mv"], mv), (kind, subme)
+            assert np.array_equal(r["cost"], cost), (kind, subme)
+            assert np.array_equal(r["sad_calls"], sc) and np.array_equal(r["subpel_calls"], qc), (kind, subme)
+        if kind == "texture":
+            # a picture against itself: zero-predictor PUs end at cost 0 and are left as they are
+            jobs = random_jobs(np.random.default_rng(5), 37, W, H, method, parts=[(8, 8)])
+            r = engine8.search_batch(pf, pf, jobs, 30, method, 5)
+            mv, cost, sc, qc = oracle_search(oracle, 8, fenc, [fenc], org, stride, jobs, 30, method, 5)
+            assert np.array_equal(r["mv"], mv) and np.array_equal(r["cost"], cost)
+            assert np.array_equal(r["sad_calls"], sc) and np.array_equal(r["subpel_calls"], qc)
+            assert (cost == 0).any()
+        engine8.free_plane(pf)
+        engine8.free_plane(pr)
+
+
 def test_edge_cases(engine8, oracle):
     """Degenerate ranges, zero-cost blocks (sub-pel skipped, motion.cpp:1073), picture corners."""
     W, H = 128, 96

@@ -38,6 +38,7 @@ struct SearchArgs
     x265amd_result *results;
     int njobs;
     int max_dim;   /* largest PU width / height the launch reserved LDS for */
+    int staged;    /* 8x8 PUs stop before the sub-pel refinement; refine8_kernel finishes them four to a wave */
 };
 
 template<typename P, bool LOWRES>
@@ -59,10 +60,12 @@ __global__ __launch_bounds__(64) void search_kernel(SearchArgs a)
         return;
     }
     S.bind(0, a.fenc, a.ref, a.nref, a.ctab, a.depth, job->pu_x, job->pu_y, w, h, a.max_dim, plane_budget(a.max_dim, (int)sizeof(P)));
-    S.search(job, a.method, a.subme, a.results + j);
+    if (a.staged && w == 8 && h == 8) S.search_staged(job, a.method, a.results + j);
+    else S.search(job, a.method, a.subme, a.results + j);
 }
 
 #include "me_esa.h"   /* esa_scan_kernel, esa_finish_kernel: use SearchArgs and xcd_remap */
+#include "me_refine8.h"   /* refine8_kernel: sub-pel refinement of 8x8 PUs, four per wave */
 #include "me_lookahead_cost.h"
 
 /* Lookahead: one workgroup per lowres field, LA_WAVES waves walking the reverse-raster
@@ -794,7 +797,13 @@ static int launch_search(x265amd_ctx *c, const SearchArgs &a, int is_lowres)
     else
     {
         static const int pad = getenv("X265AMD_LDS_PAD") ? atoi(getenv("X265AMD_LDS_PAD")) : 0;   /* occupancy experiments */
-        hipLaunchKernelGGL((search_kernel<P, false>), dim3(a.njobs), dim3(64), wave_lds_bytes<P>(a.max_dim, true) + pad, c->stream, a);
+        /* launches of 8-bit PUs up to 8x8: the 8x8 ones are refined by a second kernel, four PUs per wave */
+        static const bool no_staged = getenv("X265AMD_NO_STAGED") != 0;                            /* measurements only */
+        SearchArgs b = a;
+        b.staged = sizeof(P) == 1 && a.max_dim == 8 && !no_staged;
+        hipLaunchKernelGGL((search_kernel<P, false>), dim3(a.njobs), dim3(64), wave_lds_bytes<P>(a.max_dim, true) + pad, c->stream, b);
+        if (b.staged)
+            hipLaunchKernelGGL(refine8_kernel, dim3((a.njobs + 3) / 4), dim3(64), R8_LDS, c->stream, b);
     }
     HIPCHK(c, hipGetLastError());
     return X265AMD_OK;
@@ -1102,6 +1111,7 @@ static void fill_args(x265amd_ctx *c, SearchArgs &a, const x265amd_plane *fenc, 
         a.ref[i].origin = r->origin; a.ref[i].stride = r->stride;
     }
     a.lowres = is_lowres; a.depth = c->depth; a.method = method; a.subme = subme; a.max_dim = is_lowres ? 8 : 64;
+    a.staged = 0;
     a.ctab = c->tables[qp] + 32768;
 }
 

@@ -1284,6 +1284,34 @@ struct Searcher
 #endif
     }
 
+    /* The stages before the sub-pel refinement, for launches that refine in a kernel of their own (several small
+     * PUs per wave, me_refine8.h): the result record receives the choice between the full-pel winner and the best
+     * quarter-pel predictor (motion.cpp:1063-1069) and the counters so far. */
+    __device__ __forceinline__ void search_staged(const x265amd_job *job, int method, x265amd_result *res)
+    {
+        JobRegs J;
+        J.load(job);
+        SearchState st;
+        startup(J, st);
+        integer(J, method, st);
+        int qx, qy, bcost;
+        choose(st, qx, qy, bcost);
+        if (lane == 0)
+        {
+            res->mv[0] = (int16_t)qx; res->mv[1] = (int16_t)qy;
+            res->cost = bcost;
+            res->sad_calls = nsad; res->subpel_calls = nsub;
+        }
+    }
+
+    /* motion.cpp:1063-1069 */
+    __device__ __forceinline__ void choose(const SearchState &st, int &qx, int &qy, int &bcost) const
+    {
+        bcost = st.bcost;
+        if (st.bprecost < bcost) { qx = st.bpx; qy = st.bpy; bcost = st.bprecost; }
+        else { qx = as_i16(st.bmx << 2); qy = as_i16(st.bmy << 2); }
+    }
+
     /* motion.cpp:562-621: predictor, MV(0,0) and the qpel candidates */
     __device__ __forceinline__ void startup(const JobRegs &J, SearchState &st)
     {
@@ -1517,10 +1545,8 @@ struct Searcher
      * refinement; motion.cpp:1063-1145 */
     __device__ __forceinline__ void finish(int subme, const SearchState &st, x265amd_result *res)
     {
-        int bcost = st.bcost;
-        int qx, qy;
-        if (st.bprecost < bcost) { qx = st.bpx; qy = st.bpy; bcost = st.bprecost; }
-        else { qx = as_i16(st.bmx << 2); qy = as_i16(st.bmy << 2); }
+        int bcost, qx, qy;
+        choose(st, qx, qy, bcost);
 
         const int hpel_iters = kWorkload[subme][0], hpel_dirs = kWorkload[subme][1];
         const int qpel_iters = kWorkload[subme][2], qpel_dirs = kWorkload[subme][3], hpel_satd = kWorkload[subme][4];
