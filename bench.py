@@ -46,9 +46,16 @@ def main():
                     help="frame pairs re-run through the reference build (oracle/_ref) when it is present: the CPU baseline")
     ap.add_argument("--method", default="star")
     ap.add_argument("--subme", type=int, default=SUBME_DEFAULT, help="sub-pel refinement level (experiments only)")
-    ap.add_argument("--launch", choices=("split", "split3", "single", "per-size"), default="split3",
-                    help="search launches per frame: split = 16/8 PUs and 64/32 PUs on two streams (LDS per PU sized "
-                         "per class); single = one launch; per-size = four launches on one stream")
+    ap.add_argument("--launch", choices=("pairs3", "split", "split3", "single", "per-size"), default="pairs3",
+                    help="search launches: pairs3 = per step ONE launch per PU class (8x8 | 16x16 | 64 + 32) over all frame "
+                         "pairs (x265amd_search_batch_pairs_dev), three streams; the others launch per frame pair: split3 = the "
+                         "same three classes, split = 16/8 and 64/32 on two streams (LDS per PU sized per class), single = one "
+                         "launch, per-size = four launches on one stream")
+    ap.add_argument("--flat-priority", action="store_true", help="do not raise the priority of the 64/32 class's stream (experiment)")
+    ap.add_argument("--big-streams", type=int, default=1,
+                    help="streams the launches of the 64/32 PU class rotate over (split / split3): a 64x64 PU is one long wave, "
+                         "so a launch of one frame's 480 + 1980 large PUs is bounded by that wave's latency, and launches of "
+                         "different frame pairs overlap when they sit on different streams")
     ap.add_argument("--rehearse-one-gpu", action="store_true",
                     help="rehearsal of the N > 1 control flow on a box with one GPU: every rank uses cuda:0 and the "
                          "collectives go over gloo through host memory (RCCL wants one GPU per rank); not a measurement")
@@ -81,9 +88,11 @@ def main():
     # ---------------- setup (untimed): planes, lookahead fields, job lists, all on the device
     es = Engine(local_rank, 8)      # search stream (all launches, or the 16/8 class)
     el = Engine(local_rank, 8)      # lookahead stream
-    split = args.launch in ("split", "split3")
-    eb = Engine(local_rank, 8) if split else es   # stream of the 64/32 class
-    em = Engine(local_rank, 8) if args.launch == "split3" else es   # split3: stream of the 16x16 class
+    multi = args.launch == "pairs3"
+    split = args.launch in ("split", "split3", "pairs3")
+    eb = Engine(local_rank, 8, high_priority=not args.flat_priority) if split else es   # stream of the 64/32 class
+    ebs = [eb] + [Engine(local_rank, 8) for _ in range(args.big_streams - 1)] if split else [es]
+    em = Engine(local_rank, 8) if args.launch in ("split3", "pairs3") else es   # stream of the 16x16 class
     B = args.pairs
     clip = make_clip(W, H, B + 1, seed=1234 + rank)
     planes, lowres = [], []
@@ -109,7 +118,7 @@ def main():
                 return (int(idx[0]), len(idx), dim, eng)
             if args.launch == "split":
                 segs = [seg(jobs["w"] <= 16, 16, es), seg(jobs["w"] >= 32, 64, eb)]
-            elif args.launch == "split3":
+            elif args.launch in ("split3", "pairs3"):
                 segs = [seg(jobs["w"] == 8, 8, es), seg(jobs["w"] == 16, 16, em), seg(jobs["w"] >= 32, 64, eb)]
             elif args.launch == "single":
                 segs = [seg(jobs["w"] > 0, 64, es)]
@@ -118,6 +127,25 @@ def main():
         d_jobs.append(torch.from_numpy(jobs.view(np.uint8).reshape(len(jobs), -1).copy()).to(dev))
         d_res.append(torch.zeros((len(jobs), RESULT_DTYPE.itemsize), dtype=torch.uint8, device=dev))
     njobs = len(host_jobs[0])
+    if multi:
+        # one job list per class over all frame pairs: job.reserved names the pair; the 64x64 PUs of all pairs come
+        # before the 32x32 ones (longest waves first), the other classes are pair-major (neighbouring PUs share L2)
+        d_pairs = es.pairs_upload([(planes[i + 1], planes[i]) for i in range(B)])
+        cls_jobs, cls_res, cls_index = [], [], []
+        for (first, cnt, dim, eng) in segs:
+            parts, index = [], []
+            for i in range(B):
+                j = host_jobs[i][first:first + cnt].copy()
+                j["reserved"] = i
+                parts.append(j)
+                index.append(np.stack([np.full(cnt, i), np.arange(first, first + cnt)], axis=1))
+            cj, ci = np.concatenate(parts), np.concatenate(index)
+            if dim == 64:
+                order = np.argsort(-cj["w"].astype(np.int64), kind="stable")
+                cj, ci = cj[order], ci[order]
+            cls_jobs.append(torch.from_numpy(cj.view(np.uint8).reshape(len(cj), -1).copy()).to(dev))
+            cls_res.append(torch.zeros((len(cj), RESULT_DTYPE.itemsize), dtype=torch.uint8, device=dev))
+            cls_index.append(ci)
     d_fields = el.fields_upload(fields, wcu, hcu, HEX, LA_MERANGE)
     d_la_mvs = torch.zeros((B, ncu, 2), dtype=torch.int16, device=dev)
     d_la_costs = torch.zeros((B, ncu), dtype=torch.int32, device=dev)
@@ -130,13 +158,33 @@ def main():
     ev0 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
     ev1 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
 
-    def step(k=None):
+    def step_multi(k=None):
+        el.lookahead_fields_dev(d_fields, B, wcu, hcu, LA_QP, HEX, 1, LA_MERANGE,
+                                d_la_mvs.data_ptr(), d_la_costs.data_ptr())
+        for c in (2, 1, 0):       # the class with the longest waves first; the timed 8x8 class last
+            (first, cnt, dim, eng) = segs[c]
+            if c == 0 and k is not None:
+                ev0[k].record(s_search)
+            eng.search_batch_pairs_dev(d_pairs, B, cls_jobs[c].data_ptr(), cls_jobs[c].shape[0], cls_res[c].data_ptr(),
+                                       QP, method, SUBME, max_pu_dim=dim)
+            if c == 0 and k is not None:
+                ev1[k].record(s_search)
+        es.sync()
+        eb.sync()
+        em.sync()
+        el.sync()
+        if world > 1:
+            sharding.gather_records(torch.cat(cls_res)[:, :8].contiguous().view(-1).to(cdev), dist, dst=0)
+            sharding.gather_records(d_la_mvs.view(torch.uint8).view(-1).to(cdev), dist, dst=0)
+
+    def step_pairwise(k=None):
         el.lookahead_fields_dev(d_fields, B, wcu, hcu, LA_QP, HEX, 1, LA_MERANGE,
                                 d_la_mvs.data_ptr(), d_la_costs.data_ptr())
         for (first, cnt, dim, eng) in segs[1:] if split else ():
             for i in range(B):
-                eng.search_batch_dev(planes[i + 1], planes[i], d_jobs[i].data_ptr() + first * 40, cnt,
-                                     d_res[i].data_ptr() + first * 16, QP, method, SUBME, max_pu_dim=dim)
+                (ebs[i % len(ebs)] if eng is eb else eng).search_batch_dev(
+                    planes[i + 1], planes[i], d_jobs[i].data_ptr() + first * 40, cnt,
+                    d_res[i].data_ptr() + first * 16, QP, method, SUBME, max_pu_dim=dim)
         if k is not None:
             ev0[k].record(s_search)
         for i in range(B):
@@ -146,7 +194,8 @@ def main():
         if k is not None:
             ev1[k].record(s_search)
         es.sync()
-        eb.sync()
+        for e_ in ebs:
+            e_.sync()
         em.sync()
         el.sync()
         if world > 1:
@@ -155,6 +204,7 @@ def main():
             sharding.gather_records(torch.cat(d_res)[:, :8].contiguous().view(-1).to(cdev), dist, dst=0)
             sharding.gather_records(d_la_mvs.view(torch.uint8).view(-1).to(cdev), dist, dst=0)
 
+    step = step_multi if multi else step_pairwise
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
@@ -175,7 +225,15 @@ def main():
         elapsed = float(t.item())
 
     # ---------------- accounting
-    res = [r.cpu().numpy().view(RESULT_DTYPE).reshape(-1) for r in d_res]
+    if multi:
+        res = [np.zeros(njobs, RESULT_DTYPE) for _ in range(B)]
+        for c in range(len(segs)):
+            got = cls_res[c].cpu().numpy().view(RESULT_DTYPE).reshape(-1)
+            for i in range(B):
+                sel = cls_index[c][:, 0] == i
+                res[i][cls_index[c][sel, 1]] = got[sel]
+    else:
+        res = [r.cpu().numpy().view(RESULT_DTYPE).reshape(-1) for r in d_res]
     px_search = sum(workload.pixel_sads(host_jobs[i], res[i]) for i in range(B))
     px_step = px_search + la_pixel_sads
     total_px = torch.tensor([float(px_step) * args.steps], dtype=torch.float64, device=cdev)
@@ -184,9 +242,10 @@ def main():
     value = float(total_px.item()) / elapsed / 1e9
 
     nlaunch = 1 if args.launch != "per-size" else len(segs)
-    launch_ms = sum(ev0[k].elapsed_time(ev1[k]) for k in range(args.steps)) / (args.steps * B * nlaunch)
+    per_step = 1 if multi else B * nlaunch            # timed launches per step
+    launch_ms = sum(ev0[k].elapsed_time(ev1[k]) for k in range(args.steps)) / (args.steps * per_step)
     tsel = slice(timed_first, timed_first + timed_cnt) if args.launch != "per-size" else slice(0, njobs)
-    alg_bytes = sum(workload.algorithmic_bytes(j[tsel]) for j in host_jobs) / (B * nlaunch)
+    alg_bytes = sum(workload.algorithmic_bytes(j[tsel]) for j in host_jobs) / per_step
     achieved = alg_bytes / (launch_ms * 1e-3) / 1e9
     traffic = None
     tpath = os.path.join(ROOT, "profiles", "traffic.json")
@@ -244,7 +303,10 @@ def main():
                                  "reference builds, one thread, %.1f s); MVs and costs compared with the GPU's. The oracle "
                                  "port ran %d pairs in %.1f s (also compared)" % (njobs * nref, nref, B, ref_s, ncpu, cpu_s),
                        "port_value": cpu_px / cpu_s / 1e9}
-        kernel = {"split": "search_kernel<uint8_t,false>, the launch over a frame's %d 16x16 + 8x8 PUs (its 64/32 PUs run "
+        kernel = {"pairs3": "the launch over the %d 8x8 PUs of all %d frame pairs of a step: search_kernel<uint8_t,false> (start-up + "
+                            "integer stage, one PU per wave) followed by refine8_kernel (sub-pel rounds, four PUs per wave); the 16x16 "
+                            "and the 64/32 launches run concurrently on two more streams" % (timed_cnt * B, B),
+                  "split": "search_kernel<uint8_t,false>, the launch over a frame's %d 16x16 + 8x8 PUs (its 64/32 PUs run "
                            "concurrently on a second stream)" % timed_cnt,
                   "split3": "search_kernel<uint8_t,false>, the launch over a frame's %d 8x8 PUs (its 16x16 and its 64/32 PUs "
                             "run concurrently on two more streams)" % timed_cnt,

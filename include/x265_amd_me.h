@@ -51,7 +51,7 @@ typedef struct
     int16_t pu_x, pu_y;        /* PU position in the picture: blockOffset = pu_y * stride + pu_x */
     uint8_t w, h;              /* an HEVC luma partition (common/primitives.h:65-73), not 4x4 */
     uint8_t numc;              /* numCandidates, 0..4 */
-    uint8_t reserved;
+    uint8_t reserved;          /* 0; in the x265amd_search_batch_pairs calls: index of the job's (source, reference) pair */
     int16_t mvmin[2], mvmax[2];
     int16_t qmvp[2];
     int16_t mvc[4][2];
@@ -71,6 +71,10 @@ typedef struct
 /* Creates an engine bound to HIP device `device` for `bit_depth` 8, 10 or 12
  * (the reference fixes this at build time through HIGH_BIT_DEPTH / g_bitDepth). */
 int x265amd_create(int device, int bit_depth, x265amd_ctx **out);
+/* The same, with the engine's stream at the device's highest priority when high_priority != 0 (normal priority
+ * otherwise, as x265amd_create): for the context that carries a step's longest waves (64x64 PUs), so that they are
+ * dispatched ahead of the short ones launched next to them and the step does not end waiting for them. */
+int x265amd_create_priority(int device, int bit_depth, int high_priority, x265amd_ctx **out);
 void x265amd_destroy(x265amd_ctx *ctx);
 const char *x265amd_last_error(const x265amd_ctx *ctx);
 /* HIP stream (hipStream_t) the engine launches on; for event timing by callers */
@@ -125,6 +129,21 @@ int x265amd_search_batch_dev(x265amd_ctx *ctx, const x265amd_plane *fenc, const 
                              int qp, int method, int subme,
                              const x265amd_job *d_jobs, int njobs, x265amd_result *d_results, int max_pu_dim);
 int x265amd_sync(x265amd_ctx *ctx);
+
+/* The same searches over several (source, reference) pairs in ONE launch: job.reserved (0 .. npairs - 1) names the pair
+ * a job searches. This is the shape of the caller's loops -- TEncSearch::predInterSearch runs motionEstimate for every
+ * reference of both lists of a PU (Lib/TLibEncoder/TEncSearch.cpp:4281-4303), and the frame encoders of several frames
+ * run at once (encoder/frameencoder.cpp:1087-1163) -- and what fills the GPU: a 64x64 PU is one long wave, so a launch
+ * over one picture's 480 of them is bounded by that wave's latency, a launch over all pictures in flight by throughput.
+ * Full-resolution planes only. x265amd_pairs_upload puts the table on the device (release with x265amd_device_free).
+ * The host-array form checks every job against its own pair like x265amd_search_batch; the device-resident form does
+ * not validate jobs (a pair index beyond the table is read as 0). */
+typedef struct { x265amd_plane fenc, ref; } x265amd_pair;
+int x265amd_pairs_upload(x265amd_ctx *ctx, const x265amd_pair *pairs, int npairs /* <= 256 */, void **d_pairs);
+int x265amd_search_batch_pairs(x265amd_ctx *ctx, const x265amd_pair *pairs, int npairs, int qp, int method, int subme,
+                               const x265amd_job *jobs, int njobs, x265amd_result *results);
+int x265amd_search_batch_pairs_dev(x265amd_ctx *ctx, const void *d_pairs, int npairs, int qp, int method, int subme,
+                                   const x265amd_job *d_jobs, int njobs, x265amd_result *d_results, int max_pu_dim);
 
 /* X265_FULL_SEARCH (encoder/motion.cpp:1021-1056) on 8-bit planes scans each PU's search range
  * from a copy of the reference window in LDS; ranges too large for the window are scanned in

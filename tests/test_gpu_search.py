@@ -111,6 +111,44 @@ def test_small_pu_batches_vs_oracle(engine8, oracle, mname):
         engine8.free_plane(pr)
 
 
+@pytest.mark.parametrize("depth", [8, 10])
+def test_pairs_in_one_launch_vs_oracle(request, oracle, depth):
+    """x265amd_search_batch_pairs: jobs of three (source, reference) pairs of different sizes and strides in one launch,
+    interleaved job by job (so the four 8x8 PUs one refinement wave takes belong to different pictures), every method,
+    mixed-size and 8x8-only batches."""
+    e = _engine(request, depth)
+    geo = ((320, 192, "texture", 7), (256, 160, "noise", 8), (192, 128, "texture", 9))
+    for mname, method in sorted(GPU_METHODS.items()):
+        m = margin_for(method)
+        host, pairs = [], []
+        for (W, H, kind, seed) in geo:
+            fenc, ref, org, stride = clip_planes(W, H, depth, kind, seed=seed, margin=m)
+            host.append((fenc, ref, org, stride, W, H))
+            pairs.append((e.upload_plane(fenc, W, H, m, m, stride), e.upload_plane(ref, W, H, m, m, stride)))
+        for parts, n in ((None, 90), ([(8, 8)] * 5 + [(4, 8)], 75)):
+            rng = np.random.default_rng(300 + method)
+            per = [random_jobs(rng, n // 3 if method != 4 else 8, W, H, method, parts=parts) for (W, H, _, _) in geo]
+            jobs = make_jobs(sum(len(j) for j in per))
+            order = np.argsort(np.concatenate([np.arange(len(j)) * 3 + k for k, j in enumerate(per)]), kind="stable")
+            allj = np.concatenate(per)
+            which = np.concatenate([np.full(len(j), k) for k, j in enumerate(per)])
+            jobs[:] = allj[order]
+            jobs["reserved"] = which[order]
+            r = e.search_batch_pairs(pairs, jobs, 28 + 6 * (depth - 8), method, 5)
+            for k, (fenc, ref, org, stride, W, H) in enumerate(host):
+                sel = jobs["reserved"] == k
+                mv, cost, sc, qc = oracle_search(oracle, depth, fenc, [ref], org, stride, jobs[sel], 28 + 6 * (depth - 8), method, 5)
+                assert np.array_equal(r["mv"][sel], mv) and np.array_equal(r["cost"][sel], cost), (mname, k)
+                assert np.array_equal(r["sad_calls"][sel], sc) and np.array_equal(r["subpel_calls"][sel], qc), (mname, k)
+        bad = jobs.copy()
+        bad["reserved"][0] = 3
+        with pytest.raises(EngineError):
+            e.search_batch_pairs(pairs, bad, 28, method, 5)        # pair index beyond the table
+        for pf, pr in pairs:
+            e.free_plane(pf)
+            e.free_plane(pr)
+
+
 def test_edge_cases(engine8, oracle):
     """Degenerate ranges, zero-cost blocks (sub-pel skipped, motion.cpp:1073), picture corners."""
     W, H = 128, 96

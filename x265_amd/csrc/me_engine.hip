@@ -28,10 +28,18 @@ __device__ __forceinline__ int xcd_remap(int bid, int n)
     return ((i / C) * 8 + x) * C + (i % C);
 }
 
+/* one (source picture, reference picture) pair of a launch that searches several pairs at once */
+struct PairDev
+{
+    PlaneDev fenc, ref;
+};
+
 struct SearchArgs
 {
     PlaneDev fenc;
     PlaneDev ref[4];
+    const PairDev *pairs;   /* null, or the pair table of the launch: job.reserved picks the entry (full-resolution searches) */
+    int npairs;
     int nref, lowres, depth, method, subme;
     const uint16_t *ctab;
     const x265amd_job *jobs;
@@ -40,6 +48,26 @@ struct SearchArgs
     int max_dim;   /* largest PU width / height the launch reserved LDS for */
     int staged;    /* 8x8 PUs stop before the sub-pel refinement; refine8_kernel finishes them four to a wave */
 };
+
+/* the planes job `job` searches: the launch's own, or its entry of the launch's pair table. Device-resident jobs
+ * are not validated, so an index beyond the table falls back to entry 0 instead of reading past it. */
+__device__ __forceinline__ void job_planes(const SearchArgs &a, const x265amd_job *job, PlaneDev &fenc, PlaneDev ref[4])
+{
+    if (a.pairs)
+    {
+        int pi = uni((int)job->reserved);
+        if (pi >= a.npairs) pi = 0;
+        const PairDev *p = a.pairs + pi;
+        fenc.origin = (const void*)uni64((unsigned long long)p->fenc.origin); fenc.stride = uni(p->fenc.stride);
+        ref[0].origin = (const void*)uni64((unsigned long long)p->ref.origin); ref[0].stride = uni(p->ref.stride);
+        ref[1] = ref[2] = ref[3] = ref[0];
+    }
+    else
+    {
+        fenc = a.fenc;
+        for (int i = 0; i < 4; i++) ref[i] = a.ref[i];
+    }
+}
 
 template<typename P, bool LOWRES>
 __global__ __launch_bounds__(64) void search_kernel(SearchArgs a)
@@ -59,7 +87,9 @@ __global__ __launch_bounds__(64) void search_kernel(SearchArgs a)
         }
         return;
     }
-    S.bind(0, a.fenc, a.ref, a.nref, a.ctab, a.depth, job->pu_x, job->pu_y, w, h, a.max_dim, plane_budget(a.max_dim, (int)sizeof(P)));
+    PlaneDev fenc, ref[4];
+    job_planes(a, job, fenc, ref);
+    S.bind(0, fenc, ref, a.nref, a.ctab, a.depth, job->pu_x, job->pu_y, w, h, a.max_dim, plane_budget(a.max_dim, (int)sizeof(P)));
     if (a.staged && w == 8 && h == 8) S.search_staged(job, a.method, a.results + j);
     else S.search(job, a.method, a.subme, a.results + j);
 }
@@ -855,7 +885,15 @@ int x265amd_partition_from_sizes(int w, int h)
     return -1;
 }
 
-int x265amd_create(int device, int bit_depth, x265amd_ctx **out)
+static int create_ctx(int device, int bit_depth, int high_priority, x265amd_ctx **out);
+
+int x265amd_create(int device, int bit_depth, x265amd_ctx **out) { return create_ctx(device, bit_depth, 0, out); }
+int x265amd_create_priority(int device, int bit_depth, int high_priority, x265amd_ctx **out)
+{
+    return create_ctx(device, bit_depth, high_priority, out);
+}
+
+static int create_ctx(int device, int bit_depth, int high_priority, x265amd_ctx **out)
 {
     if (!out || !(bit_depth == 8 || bit_depth == 10 || bit_depth == 12)) return X265AMD_EINVAL;
     int n = 0;
@@ -865,7 +903,9 @@ int x265amd_create(int device, int bit_depth, x265amd_ctx **out)
     c->d_jobs = c->d_results = c->d_stage = 0; c->d_ticket = 0; c->jobs_cap = c->results_cap = c->stage_cap = 0; c->d_out = 0;
     c->esa_window_bytes = ESA_WINDOW_DEFAULT;
     c->esa_lds_raised = c->rime_lds_raised = false;
-    if (hipSetDevice(device) != hipSuccess || hipStreamCreate(&c->stream) != hipSuccess ||
+    int prio_least = 0, prio_greatest = 0;
+    if (hipSetDevice(device) != hipSuccess || hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest) != hipSuccess ||
+        hipStreamCreateWithPriority(&c->stream, hipStreamDefault, high_priority ? prio_greatest : prio_least + (prio_greatest - prio_least) / 2) != hipSuccess ||
         hipMalloc((void**)&c->d_out, 64) != hipSuccess || hipMalloc((void**)&c->d_ticket, 256) != hipSuccess)
     {
         delete c;
@@ -1111,7 +1151,7 @@ static void fill_args(x265amd_ctx *c, SearchArgs &a, const x265amd_plane *fenc, 
         a.ref[i].origin = r->origin; a.ref[i].stride = r->stride;
     }
     a.lowres = is_lowres; a.depth = c->depth; a.method = method; a.subme = subme; a.max_dim = is_lowres ? 8 : 64;
-    a.staged = 0;
+    a.staged = 0; a.pairs = 0; a.npairs = 0;
     a.ctab = c->tables[qp] + 32768;
 }
 
@@ -1124,9 +1164,9 @@ int x265amd_set_esa_window_bytes(x265amd_ctx *c, int bytes)
 
 static int search_dev(x265amd_ctx *c, const x265amd_plane *fenc, const x265amd_plane *ref, int is_lowres,
                       int qp, int method, int subme, const x265amd_job *d_jobs, int njobs, x265amd_result *d_results,
-                      int max_pu_dim, int esa_window)
+                      int max_pu_dim, int esa_window, const PairDev *d_pairs = 0, int npairs = 0)
 {
-    if (!c || !fenc || !ref || !d_jobs || !d_results || njobs < 0) return fail(c, X265AMD_EINVAL, "null argument");
+    if (!c || !d_jobs || !d_results || njobs < 0 || (!d_pairs && (!fenc || !ref))) return fail(c, X265AMD_EINVAL, "null argument");
     if (method < 0 || method > X265AMD_FULL || subme < 0 || subme > 7)
         return fail(c, X265AMD_EINVAL, "bad method / subme");
     if (max_pu_dim == 0) max_pu_dim = 64;
@@ -1137,7 +1177,10 @@ static int search_dev(x265amd_ctx *c, const x265amd_plane *fenc, const x265amd_p
     if (!njobs) return X265AMD_OK;
     HIPCHK(c, hipSetDevice(c->device));
     SearchArgs a;
-    fill_args(c, a, fenc, ref, is_lowres, qp, method, subme);
+    x265amd_plane none;
+    memset(&none, 0, sizeof(none));
+    fill_args(c, a, d_pairs ? &none : fenc, d_pairs ? &none : ref, is_lowres, qp, method, subme);
+    a.pairs = d_pairs; a.npairs = npairs;
     a.jobs = d_jobs; a.results = d_results; a.njobs = njobs;
     if (!is_lowres) a.max_dim = max_pu_dim;
     if (method == X265AMD_FULL && !is_lowres && c->depth <= 8) return launch_esa(c, a, esa_window, c->table_nowrap[qp]);
@@ -1150,6 +1193,74 @@ int x265amd_search_batch_dev(x265amd_ctx *c, const x265amd_plane *fenc, const x2
 {
     return search_dev(c, fenc, ref, is_lowres, qp, method, subme, d_jobs, njobs, d_results, max_pu_dim,
                       c ? c->esa_window_bytes : 0);
+}
+
+/* ---- searches over several (source, reference) pairs in one launch ---- */
+
+static int pairs_check(x265amd_ctx *c, const x265amd_pair *pairs, int npairs, std::vector<PairDev> &hp)
+{
+    if (!c || !pairs || npairs <= 0 || npairs > 256) return fail(c, X265AMD_EINVAL, "1 .. 256 pairs");
+    hp.resize(npairs);
+    for (int i = 0; i < npairs; i++)
+    {
+        if (!pairs[i].fenc.origin || !pairs[i].ref.origin) return fail(c, X265AMD_EINVAL, "pair: null plane");
+        hp[i].fenc.origin = pairs[i].fenc.origin; hp[i].fenc.stride = pairs[i].fenc.stride;
+        hp[i].ref.origin = pairs[i].ref.origin; hp[i].ref.stride = pairs[i].ref.stride;
+    }
+    return X265AMD_OK;
+}
+
+int x265amd_pairs_upload(x265amd_ctx *c, const x265amd_pair *pairs, int npairs, void **d_pairs)
+{
+    if (!d_pairs) return fail(c, X265AMD_EINVAL, "null argument");
+    std::vector<PairDev> hp;
+    int rc = pairs_check(c, pairs, npairs, hp);
+    if (rc) return rc;
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipMalloc(d_pairs, npairs * sizeof(PairDev)));
+    HIPCHK(c, hipMemcpy(*d_pairs, hp.data(), npairs * sizeof(PairDev), hipMemcpyHostToDevice));
+    return X265AMD_OK;
+}
+
+int x265amd_search_batch_pairs_dev(x265amd_ctx *c, const void *d_pairs, int npairs, int qp, int method, int subme,
+                                   const x265amd_job *d_jobs, int njobs, x265amd_result *d_results, int max_pu_dim)
+{
+    if (!c || !d_pairs || npairs <= 0 || npairs > 256) return fail(c, X265AMD_EINVAL, "1 .. 256 pairs");
+    return search_dev(c, 0, 0, 0, qp, method, subme, d_jobs, njobs, d_results, max_pu_dim, c->esa_window_bytes,
+                      (const PairDev*)d_pairs, npairs);
+}
+
+int x265amd_search_batch_pairs(x265amd_ctx *c, const x265amd_pair *pairs, int npairs, int qp, int method, int subme,
+                               const x265amd_job *jobs, int njobs, x265amd_result *results)
+{
+    if (!c || !jobs || !results || njobs < 0) return fail(c, X265AMD_EINVAL, "null argument");
+    std::vector<PairDev> hp;
+    int rc = pairs_check(c, pairs, npairs, hp);
+    if (rc) return rc;
+    for (int i = 0; i < njobs; i++)
+    {
+        if (jobs[i].reserved >= npairs) return fail(c, X265AMD_EINVAL, "job: pair index (reserved) beyond the pair table");
+        if ((rc = validate_jobs(c, &pairs[jobs[i].reserved].fenc, &pairs[jobs[i].reserved].ref, 0, method, subme, jobs + i, 1))) return rc;
+    }
+    if (!njobs) return X265AMD_OK;
+    HIPCHK(c, hipSetDevice(c->device));
+    const size_t jb = ((size_t)njobs * sizeof(x265amd_job) + 255) & ~(size_t)255;
+    if ((rc = ensure(c, &c->d_jobs, &c->jobs_cap, jb + npairs * sizeof(PairDev)))) return rc;
+    if ((rc = ensure(c, &c->d_results, &c->results_cap, (size_t)njobs * sizeof(x265amd_result)))) return rc;
+    HIPCHK(c, hipMemcpyAsync(c->d_jobs, jobs, (size_t)njobs * sizeof(x265amd_job), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync((char*)c->d_jobs + jb, hp.data(), npairs * sizeof(PairDev), hipMemcpyHostToDevice, c->stream));
+    int dim = 8;
+    for (int i = 0; i < njobs; i++)
+    {
+        const int d = jobs[i].w > jobs[i].h ? jobs[i].w : jobs[i].h;
+        while (dim < d) dim <<= 1;
+    }
+    rc = search_dev(c, 0, 0, 0, qp, method, subme, (const x265amd_job*)c->d_jobs, njobs, (x265amd_result*)c->d_results, dim,
+                    c->esa_window_bytes, (const PairDev*)((char*)c->d_jobs + jb), npairs);
+    if (rc) return rc;
+    HIPCHK(c, hipMemcpyAsync(results, c->d_results, (size_t)njobs * sizeof(x265amd_result), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return X265AMD_OK;
 }
 
 int x265amd_sync(x265amd_ctx *c)

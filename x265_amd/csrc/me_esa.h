@@ -212,6 +212,8 @@ __global__ __launch_bounds__(ESA_THREADS) __attribute__((amdgpu_waves_per_eu(4))
         if (tid == 0) { a.results[j].cost = -1; a.results[j].sad_calls = 0; }
         return;
     }
+    PlaneDev pfenc, pref[4];
+    job_planes(a, job, pfenc, pref);
     const int nx = g.nx, ny = g.ny;
     g.off_cx = esa_fixed_lds(a.max_dim);
     g.off_cy = g.off_cx + 16 * g.xgs;
@@ -219,18 +221,18 @@ __global__ __launch_bounds__(ESA_THREADS) __attribute__((amdgpu_waves_per_eu(4))
 
     {
         /* source block into LDS, pitch 64 (setSourcePU, motion.cpp:116-142) */
-        const char AS1 *src = (const char AS1*)a.fenc.origin + (long)J.puy * a.fenc.stride + J.pux;
+        const char AS1 *src = (const char AS1*)pfenc.origin + (long)J.puy * pfenc.stride + J.pux;
         const int wd = w >> 2;
         for (int i = tid; i < wd * h; i += ESA_THREADS)
         {
             const int y = i / wd, x = i - y * wd;
             typedef uint32_t __attribute__((aligned(1))) u32u;
-            *(uint32_t*)(x265amd_smem + ESA_L_FENC + y * 64 + 4 * x) = *(const u32u AS1*)(src + (long)y * a.fenc.stride + 4 * x);
+            *(uint32_t*)(x265amd_smem + ESA_L_FENC + y * 64 + 4 * x) = *(const u32u AS1*)(src + (long)y * pfenc.stride + 4 * x);
         }
     }
     const uint16_t AS1 *ctab = (const uint16_t AS1*)a.ctab;
-    const P AS1 *ref = (const P AS1*)a.ref[0].origin + (long)J.puy * a.ref[0].stride + J.pux;
-    const int rstride = a.ref[0].stride;
+    const P AS1 *ref = (const P AS1*)pref[0].origin + (long)J.puy * pref[0].stride + J.pux;
+    const int rstride = pref[0].stride;
     const int pd = g.pitch >> 2;
     uint32_t bc = 0xffffffffu, bi = 0xffffffffu;   /* this lane's best (cost, raster index) */
     bool first = true;
@@ -404,7 +406,9 @@ __global__ __launch_bounds__(64) void esa_finish_kernel(SearchArgs a, int win_bu
     const uint32_t bc = (uint32_t)uni(a.results[j].cost), bi = (uint32_t)uni((int)a.results[j].sad_calls);
     Searcher<P, 64> S;
     SearchState st;
-    S.bind(0, a.fenc, a.ref, a.nref, a.ctab, a.depth, J.pux, J.puy, w, h, a.max_dim, plane_budget(a.max_dim, (int)sizeof(P)));
+    PlaneDev pfenc, pref[4];
+    job_planes(a, job, pfenc, pref);
+    S.bind(0, pfenc, pref, a.nref, a.ctab, a.depth, J.pux, J.puy, w, h, a.max_dim, plane_budget(a.max_dim, (int)sizeof(P)));
     S.startup(J, st);
     if (bc < (uint32_t)st.bcost)
     {

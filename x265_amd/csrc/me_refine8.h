@@ -29,8 +29,8 @@ namespace x265amd {
 enum
 {
     R8_TAPS = 0,                            /* 48 dwords of packed filter taps (TapWords) */
-    R8_PARAMS = 192,                        /* per PU: 3 source offsets, 3 phases, 2 unused dwords */
-    R8_PLANES = 192 + 4 * 32
+    R8_PARAMS = 192,                        /* per PU, 48 bytes: 3 source offsets, row pitch, 3 phases, -, plane origin (64 bit) */
+    R8_PLANES = 192 + 4 * 48
 };
 #define R8_LDS (R8_PLANES + 4 * R8_PU_BYTES + 32)
 
@@ -43,11 +43,11 @@ struct Refine8
     int qx, qy, bcost, mvpx, mvpy, roff;
     unsigned nsub;
     bool active;
+    const uint8_t AS1 *ref0;    /* origin of the PU's reference plane (PUs of one wave may search different pictures) */
+    int rstride;
     /* per lane */
     int lane, row, l, f[4];
-    const uint8_t AS1 *ref0;
     const uint16_t AS1 *ctab;
-    int rstride;
 
     /* One refinement round for all four PUs: `dirs` neighbours of (qx, qy) at distance `step`, plus the
      * centre itself first when `centre` (the SATD re-measure of motion.cpp:1086, :1117, whose cost replaces
@@ -71,9 +71,14 @@ struct Refine8
         if (l < 3)
         {
             const int xp = as_i16(qx + (l - 1) * step);
-            int *prm = (int*)(x265amd_smem + R8_PARAMS + row * 32);
+            int *prm = (int*)(x265amd_smem + R8_PARAMS + row * 48);
             prm[l] = roff + __mul24(ymin - 3, rstride) + (xp >> 2) - 3;
             prm[4 + l] = xp & 3;
+            if (l == 0)
+            {
+                prm[3] = rstride;
+                *(unsigned long long*)(prm + 8) = (unsigned long long)ref0;
+            }
         }
         wave_sync();
         /* horizontal pass: 96 items per PU (3 planes x 16 rows x 2 quads of samples), 384 per wave */
@@ -83,9 +88,9 @@ struct Refine8
             const int item = pass * 64 + lane;
             const int pu = (item * 683) >> 16, rem = item - pu * 96;
             const int p = rem >> 5, r = (rem >> 1) & 15, q = rem & 1;
-            const int *prm = (const int*)(x265amd_smem + R8_PARAMS + pu * 32);
+            const int *prm = (const int*)(x265amd_smem + R8_PARAMS + pu * 48);
             const int *tp = (const int*)(x265amd_smem + R8_TAPS) + prm[4 + p] * 12;
-            const uint8_t AS1 *s = ref0 + prm[p] + __mul24(r, rstride) + 4 * q;
+            const uint8_t AS1 *s = (const uint8_t AS1*)*(const unsigned long long*)(prm + 8) + prm[p] + __mul24(r, prm[3]) + 4 * q;
             /* samples biased to signed bytes for v_dot4_i32_i8; the taps of every phase add up to 64, so the sum
              * comes out 8192 low, which is exactly luma_hps's offset (ipfilter.cpp:246-247 with 8-bit samples) */
             const uint32_t d0 = Px<uint8_t>::load_g(s) ^ 0x80808080u, d1 = Px<uint8_t>::load_g(s + 4) ^ 0x80808080u,
@@ -158,17 +163,28 @@ __global__ __launch_bounds__(64) void refine8_kernel(SearchArgs a)
     /* a PU whose full-pel cost is 0 is not refined (motion.cpp:1073-1076); PUs of other sizes are final already */
     R.active = valid && (d1 & 0xffff) == 0x0808 && R.bcost != 0;
     if (__ballot(R.active) == 0) return;
-    R.rstride = a.ref[0].stride;
-    R.roff = puy * R.rstride + pux;
+    /* the planes of the row's PU: the launch's own, or its entry of the pair table (as job_planes) */
+    const uint8_t AS1 *fenc0 = (const uint8_t AS1*)a.fenc.origin;
+    int fstride = a.fenc.stride;
     R.ref0 = (const uint8_t AS1*)a.ref[0].origin;
+    R.rstride = a.ref[0].stride;
+    if (a.pairs)
+    {
+        int pi = (d1 >> 24) & 0xff;
+        if (pi >= a.npairs) pi = 0;
+        const PairDev *p = a.pairs + pi;
+        fenc0 = (const uint8_t AS1*)p->fenc.origin; fstride = p->fenc.stride;
+        R.ref0 = (const uint8_t AS1*)p->ref.origin; R.rstride = p->ref.stride;
+    }
+    R.roff = puy * R.rstride + pux;
     R.ctab = (const uint16_t AS1*)a.ctab;
     if (R.lane < 48) ((int*)(x265amd_smem + R8_TAPS))[R.lane] = kTapWords.w[R.lane];
     {
         /* the lane's column of its tile of the source block */
         const int t = R.l >> 2;
-        const uint8_t AS1 *src = (const uint8_t AS1*)a.fenc.origin + (long)(puy + (t >> 1) * 4) * a.fenc.stride + pux + (t & 1) * 4 + (R.l & 3);
+        const uint8_t AS1 *src = fenc0 + (long)(puy + (t >> 1) * 4) * fstride + pux + (t & 1) * 4 + (R.l & 3);
 #pragma unroll
-        for (int y = 0; y < 4; y++) R.f[y] = (int)src[(long)y * a.fenc.stride];
+        for (int y = 0; y < 4; y++) R.f[y] = (int)src[(long)y * fstride];
     }
     /* SubpelWorkload, motion.cpp:53-63, and the round sequence of :1100-1141 */
     const int hpel_iters = kWorkload[a.subme][0], hpel_dirs = kWorkload[a.subme][1];

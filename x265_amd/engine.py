@@ -63,6 +63,11 @@ class Picture(C.Structure):
     _fields_ = [("y", Plane), ("cb", Plane), ("cr", Plane)]
 
 
+class Pair(C.Structure):
+    """x265amd_pair: one (source, reference) pair of a multi-pair search launch."""
+    _fields_ = [("fenc", Plane), ("ref", Plane)]
+
+
 class Field(C.Structure):
     _fields_ = [("fenc", Plane), ("ref", Plane * 4)]
 
@@ -120,14 +125,14 @@ def partition_from_sizes(w, h):
 
 
 class Engine:
-    def __init__(self, device=0, bit_depth=8):
+    def __init__(self, device=0, bit_depth=8, high_priority=False):
         self.L = L = load_library()
         L.x265amd_last_error.restype = C.c_char_p
         L.x265amd_stream.restype = C.c_void_p
         self.depth = bit_depth
         self.dtype = np.uint8 if bit_depth <= 8 else np.uint16
         self.ctx = C.c_void_p()
-        rc = L.x265amd_create(device, bit_depth, C.byref(self.ctx))
+        rc = L.x265amd_create_priority(device, bit_depth, int(high_priority), C.byref(self.ctx))
         if rc:
             raise EngineError("x265amd_create(device=%d) failed with %d (no MI355X visible?)" % (device, rc))
 
@@ -245,6 +250,30 @@ class Engine:
         refs = (Plane * 4)(*ref) if is_lowres else (Plane * 1)(ref if isinstance(ref, Plane) else ref[0])
         self._chk(self.L.x265amd_search_batch_dev(self.ctx, C.byref(fenc), refs, int(is_lowres), qp, method, subme,
                                                   C.c_void_p(d_jobs), njobs, C.c_void_p(d_results), max_pu_dim))
+
+    def pairs_upload(self, pairs):
+        """pairs: list of (source Plane, reference Plane) -> device table for search_batch_pairs_dev."""
+        arr = (Pair * len(pairs))()
+        for i, (f, r) in enumerate(pairs):
+            arr[i].fenc, arr[i].ref = f, r
+        d = C.c_void_p()
+        self._chk(self.L.x265amd_pairs_upload(self.ctx, arr, len(pairs), C.byref(d)))
+        return d
+
+    def search_batch_pairs(self, pairs, jobs, qp, method, subme):
+        """Searches over several (source, reference) pairs in one launch; jobs["reserved"] names each job's pair."""
+        jobs = np.ascontiguousarray(jobs, JOB_DTYPE)
+        res = np.zeros(len(jobs), RESULT_DTYPE)
+        arr = (Pair * max(1, len(pairs)))()
+        for i, (f, r) in enumerate(pairs):
+            arr[i].fenc, arr[i].ref = f, r
+        self._chk(self.L.x265amd_search_batch_pairs(self.ctx, arr, len(pairs), qp, method, subme,
+                                                    C.c_void_p(jobs.ctypes.data), len(jobs), C.c_void_p(res.ctypes.data)))
+        return res
+
+    def search_batch_pairs_dev(self, d_pairs, npairs, d_jobs, njobs, d_results, qp, method, subme, max_pu_dim=0):
+        self._chk(self.L.x265amd_search_batch_pairs_dev(self.ctx, d_pairs, npairs, qp, method, subme,
+                                                        C.c_void_p(d_jobs), njobs, C.c_void_p(d_results), max_pu_dim))
 
     def fields_upload(self, fields, wcu, hcu, method=HEX, merange=16):
         """Checks the planes against the CU grid / method / merange and puts the descriptors on the device."""
