@@ -757,6 +757,7 @@ struct x265amd_ctx
     void *d_jobs; size_t jobs_cap;
     void *d_results; size_t results_cap;
     void *d_stage; size_t stage_cap;   /* staging for the per-call primitives */
+    void *d_queue; size_t queue_cap;   /* work queue between star8_kernel and search_queue_kernel */
     int32_t *d_out;
     int *d_ticket;                     /* row hand-out counter of the row-parallel lookahead kernel */
     int esa_window_bytes;              /* LDS the exhaustive search may use per PU for its window */
@@ -829,9 +830,22 @@ static int launch_search(x265amd_ctx *c, const SearchArgs &a, int is_lowres)
         static const int pad = getenv("X265AMD_LDS_PAD") ? atoi(getenv("X265AMD_LDS_PAD")) : 0;   /* occupancy experiments */
         /* launches of 8-bit PUs up to 8x8: the 8x8 ones are refined by a second kernel, four PUs per wave */
         static const bool no_staged = getenv("X265AMD_NO_STAGED") != 0;                            /* measurements only */
+        static const bool no_star8 = getenv("X265AMD_NO_STAR8") != 0;
         SearchArgs b = a;
         b.staged = sizeof(P) == 1 && a.max_dim == 8 && !no_staged;
-        hipLaunchKernelGGL((search_kernel<P, false>), dim3(a.njobs), dim3(64), wave_lds_bytes<P>(a.max_dim, true) + pad, c->stream, b);
+        if (b.staged && a.method == X265AMD_STAR && !no_star8)
+        {
+            /* STAR: the common case (start point stands after three star rounds) four PUs per wave; the rest through a
+             * queue to the one-wave search */
+            int rc = ensure(c, &c->d_queue, &c->queue_cap, ((size_t)a.njobs + 2) * sizeof(int));
+            if (rc) return rc;
+            HIPCHK(c, hipMemsetAsync(c->d_queue, 0, 2 * sizeof(int), c->stream));
+            hipLaunchKernelGGL(star8_kernel, dim3((a.njobs + 3) / 4), dim3(64), S8_LDS, c->stream, b, (int*)c->d_queue);
+            hipLaunchKernelGGL(search_queue_kernel<uint8_t>, dim3(a.njobs < 8192 ? a.njobs : 8192), dim3(64),
+                               wave_lds_bytes<uint8_t>(8, true) + pad, c->stream, b, (int*)c->d_queue);
+        }
+        else
+            hipLaunchKernelGGL((search_kernel<P, false>), dim3(a.njobs), dim3(64), wave_lds_bytes<P>(a.max_dim, true) + pad, c->stream, b);
         if (b.staged)
             hipLaunchKernelGGL(refine8_kernel, dim3((a.njobs + 3) / 4), dim3(64), R8_LDS, c->stream, b);
     }
@@ -901,6 +915,7 @@ static int create_ctx(int device, int bit_depth, int high_priority, x265amd_ctx 
     x265amd_ctx *c = new x265amd_ctx();
     c->device = device; c->depth = bit_depth;
     c->d_jobs = c->d_results = c->d_stage = 0; c->d_ticket = 0; c->jobs_cap = c->results_cap = c->stage_cap = 0; c->d_out = 0;
+    c->d_queue = 0; c->queue_cap = 0;
     c->esa_window_bytes = ESA_WINDOW_DEFAULT;
     c->esa_lds_raised = c->rime_lds_raised = false;
     int prio_least = 0, prio_greatest = 0;
@@ -942,6 +957,7 @@ void x265amd_destroy(x265amd_ctx *c)
     if (c->d_jobs) (void)hipFree(c->d_jobs);
     if (c->d_results) (void)hipFree(c->d_results);
     if (c->d_stage) (void)hipFree(c->d_stage);
+    if (c->d_queue) (void)hipFree(c->d_queue);
     if (c->d_out) (void)hipFree(c->d_out);
     if (c->d_ticket) (void)hipFree(c->d_ticket);
     (void)hipStreamDestroy(c->stream);
