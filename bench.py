@@ -51,7 +51,9 @@ def main():
                          "pairs (x265amd_search_batch_pairs_dev), three streams; the others launch per frame pair: split3 = the "
                          "same three classes, split = 16/8 and 64/32 on two streams (LDS per PU sized per class), single = one "
                          "launch, per-size = four launches on one stream")
-    ap.add_argument("--flat-priority", action="store_true", help="do not raise the priority of the 64/32 class's stream (experiment)")
+    ap.add_argument("--prio", choices=("small", "big", "flat"), default="small",
+                    help="which search stream gets the device's highest priority: small = the 8x8 class, whose launch is a chain of "
+                         "three dependent kernels that should not end the step alone; big = the 64/32 class; flat = none")
     ap.add_argument("--big-streams", type=int, default=1,
                     help="streams the launches of the 64/32 PU class rotate over (split / split3): a 64x64 PU is one long wave, "
                          "so a launch of one frame's 480 + 1980 large PUs is bounded by that wave's latency, and launches of "
@@ -86,11 +88,11 @@ def main():
     SUBME = args.subme
 
     # ---------------- setup (untimed): planes, lookahead fields, job lists, all on the device
-    es = Engine(local_rank, 8)      # search stream (all launches, or the 16/8 class)
+    es = Engine(local_rank, 8, high_priority=args.prio == "small")      # search stream (all launches, or the 16/8 class)
     el = Engine(local_rank, 8)      # lookahead stream
     multi = args.launch == "pairs3"
     split = args.launch in ("split", "split3", "pairs3")
-    eb = Engine(local_rank, 8, high_priority=not args.flat_priority) if split else es   # stream of the 64/32 class
+    eb = Engine(local_rank, 8, high_priority=args.prio == "big") if split else es   # stream of the 64/32 class
     ebs = [eb] + [Engine(local_rank, 8) for _ in range(args.big_streams - 1)] if split else [es]
     em = Engine(local_rank, 8) if args.launch in ("split3", "pairs3") else es   # stream of the 16x16 class
     B = args.pairs

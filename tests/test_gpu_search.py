@@ -76,13 +76,16 @@ def test_every_partition_every_method(engine8, oracle):
             assert np.array_equal(r["mv"], mv) and np.array_equal(r["cost"], cost), (mname, part)
 
 
+@pytest.mark.parametrize("size", [8, 16])
 @pytest.mark.parametrize("mname", ["star", "hex", "dia", "umh"])
-def test_small_pu_batches_vs_oracle(engine8, oracle, mname):
-    """Batches whose largest PU is 8x8 take the two-kernel route on 8-bit planes (search up to the full-pel / predictor
-    choice one PU per wave, then the sub-pel rounds of the 8x8 PUs four PUs per wave): every subme level, batch sizes
-    that are not multiples of four, 8x4 / 4x8 PUs mixed in (finished by the first kernel), and PUs whose full-pel cost
-    is 0 (no refinement, motion.cpp:1073-1076)."""
+def test_small_pu_batches_vs_oracle(engine8, oracle, mname, size):
+    """Batches whose largest PU is 8x8 or 16x16 take the staged route on 8-bit planes (the search up to the full-pel /
+    predictor choice -- for STAR the fixed-shape kernel with a queue for the PUs that leave the common case -- then the
+    sub-pel rounds of the square PUs of that size in their own kernel, four 8x8 PUs or one 16x16 PU per wave): every
+    subme level, batch sizes that are not multiples of four, other partitions mixed in (finished by the one-wave
+    search), and PUs whose full-pel cost is 0 (no refinement, motion.cpp:1073-1076)."""
     method = METHODS[mname]
+    others = [(8, 4), (4, 8)] if size == 8 else [(16, 8), (8, 16), (8, 8), (12, 16), (16, 4)]
     W, H = 320, 192
     m = margin_for(method)
     for kind in ("texture", "noise"):
@@ -92,7 +95,7 @@ def test_small_pu_batches_vs_oracle(engine8, oracle, mname):
         for subme in range(8):
             rng = np.random.default_rng(900 + method * 10 + subme)
             n = 61 + subme
-            jobs = random_jobs(rng, n, W, H, method, parts=[(8, 8)] * 6 + [(8, 4), (4, 8)])
+            jobs = random_jobs(rng, n, W, H, method, parts=[(size, size)] * 6 + others)
             qp = int(rng.integers(10, 45))
             r = engine8.search_batch(pf, pr, jobs, qp, method, subme)
             mv, cost, sc, qc = oracle_search(oracle, 8, fenc, [ref], org, stride, jobs, qp, method, subme)
@@ -101,7 +104,7 @@ def test_small_pu_batches_vs_oracle(engine8, oracle, mname):
             assert np.array_equal(r["sad_calls"], sc) and np.array_equal(r["subpel_calls"], qc), (kind, subme)
         if kind == "texture":
             # a picture against itself: zero-predictor PUs end at cost 0 and are left as they are
-            jobs = random_jobs(np.random.default_rng(5), 37, W, H, method, parts=[(8, 8)])
+            jobs = random_jobs(np.random.default_rng(5), 37, W, H, method, parts=[(size, size)])
             r = engine8.search_batch(pf, pf, jobs, 30, method, 5)
             mv, cost, sc, qc = oracle_search(oracle, 8, fenc, [fenc], org, stride, jobs, 30, method, 5)
             assert np.array_equal(r["mv"], mv) and np.array_equal(r["cost"], cost)

@@ -28,6 +28,8 @@ __device__ __forceinline__ int xcd_remap(int bid, int n)
     return ((i / C) * 8 + x) * C + (i % C);
 }
 
+#define SMALL_REDO 0xFFFFFFFFu   /* sad_calls of a result record: star_small_kernel left this PU to the one-wave search */
+
 /* one (source picture, reference picture) pair of a launch that searches several pairs at once */
 struct PairDev
 {
@@ -46,7 +48,8 @@ struct SearchArgs
     x265amd_result *results;
     int njobs;
     int max_dim;   /* largest PU width / height the launch reserved LDS for */
-    int staged;    /* 8x8 PUs stop before the sub-pel refinement; refine8_kernel finishes them four to a wave */
+    int only_redo; /* search only the PUs whose result record carries SMALL_REDO (left over by star_small_kernel) */
+    int staged;    /* 8 or 16: square PUs of this size stop before the sub-pel refinement, which refine_small_kernel does; 0: none */
 };
 
 /* the planes job `job` searches: the launch's own, or its entry of the launch's pair table. Device-resident jobs
@@ -74,6 +77,7 @@ __global__ __launch_bounds__(64) void search_kernel(SearchArgs a)
 {
     const int j = xcd_remap(blockIdx.x, a.njobs);
     if (j >= a.njobs) return;
+    if (a.only_redo && (unsigned)uni((int)a.results[j].sad_calls) != SMALL_REDO) return;
     const x265amd_job *job = a.jobs + j;
     Searcher<P, LOWRES ? 8 : 64, LOWRES> S;
     const int w = job->w, h = job->h;
@@ -90,12 +94,12 @@ __global__ __launch_bounds__(64) void search_kernel(SearchArgs a)
     PlaneDev fenc, ref[4];
     job_planes(a, job, fenc, ref);
     S.bind(0, fenc, ref, a.nref, a.ctab, a.depth, job->pu_x, job->pu_y, w, h, a.max_dim, plane_budget(a.max_dim, (int)sizeof(P)));
-    if (a.staged && w == 8 && h == 8) S.search_staged(job, a.method, a.results + j);
+    if (a.staged && w == a.staged && h == a.staged) S.search_staged(job, a.method, a.results + j);
     else S.search(job, a.method, a.subme, a.results + j);
 }
 
 #include "me_esa.h"   /* esa_scan_kernel, esa_finish_kernel: use SearchArgs and xcd_remap */
-#include "me_refine8.h"   /* refine8_kernel: sub-pel refinement of 8x8 PUs, four per wave */
+#include "me_small.h"   /* star_small_kernel, refine_small_kernel: 8x8 / 16x16 PUs in fixed-shape kernels, four / one per wave */
 #include "me_lookahead_cost.h"
 
 /* Lookahead: one workgroup per lowres field, LA_WAVES waves walking the reverse-raster
@@ -757,7 +761,6 @@ struct x265amd_ctx
     void *d_jobs; size_t jobs_cap;
     void *d_results; size_t results_cap;
     void *d_stage; size_t stage_cap;   /* staging for the per-call primitives */
-    void *d_queue; size_t queue_cap;   /* work queue between star8_kernel and search_queue_kernel */
     int32_t *d_out;
     int *d_ticket;                     /* row hand-out counter of the row-parallel lookahead kernel */
     int esa_window_bytes;              /* LDS the exhaustive search may use per PU for its window */
@@ -830,24 +833,29 @@ static int launch_search(x265amd_ctx *c, const SearchArgs &a, int is_lowres)
         static const int pad = getenv("X265AMD_LDS_PAD") ? atoi(getenv("X265AMD_LDS_PAD")) : 0;   /* occupancy experiments */
         /* launches of 8-bit PUs up to 8x8: the 8x8 ones are refined by a second kernel, four PUs per wave */
         static const bool no_staged = getenv("X265AMD_NO_STAGED") != 0;                            /* measurements only */
-        static const bool no_star8 = getenv("X265AMD_NO_STAR8") != 0;
+        static const bool no_star = getenv("X265AMD_NO_STAR8") != 0;
         SearchArgs b = a;
-        b.staged = sizeof(P) == 1 && a.max_dim == 8 && !no_staged;
-        if (b.staged && a.method == X265AMD_STAR && !no_star8)
+        /* launches of 8-bit PUs up to 8x8 or up to 16x16: the square PUs of that size are refined by a second kernel
+         * (four 8x8 PUs or one 16x16 PU per wave) */
+        b.staged = sizeof(P) == 1 && (a.max_dim == 8 || a.max_dim == 16) && !no_staged ? a.max_dim : 0;
+        const int npu = b.staged == 8 ? 4 : 1, groups = (a.njobs + npu - 1) / npu;
+        if (b.staged && a.method == X265AMD_STAR && !no_star)
         {
-            /* STAR: the common case (start point stands after three star rounds) four PUs per wave; the rest through a
-             * queue to the one-wave search */
-            int rc = ensure(c, &c->d_queue, &c->queue_cap, ((size_t)a.njobs + 2) * sizeof(int));
-            if (rc) return rc;
-            HIPCHK(c, hipMemsetAsync(c->d_queue, 0, 2 * sizeof(int), c->stream));
-            hipLaunchKernelGGL(star8_kernel, dim3((a.njobs + 3) / 4), dim3(64), S8_LDS, c->stream, b, (int*)c->d_queue);
-            hipLaunchKernelGGL(search_queue_kernel<uint8_t>, dim3(a.njobs < 8192 ? a.njobs : 8192), dim3(64),
-                               wave_lds_bytes<uint8_t>(8, true) + pad, c->stream, b, (int*)c->d_queue);
+            /* STAR: the common case (start point stands after three star rounds) in a fixed-shape kernel, which marks the
+             * records of the PUs it leaves to the one-wave search */
+            if (b.staged == 8)
+                hipLaunchKernelGGL(star_small_kernel<8>, dim3(groups), dim3(64), StarLds<8>::TOTAL, c->stream, b);
+            else
+                hipLaunchKernelGGL(star_small_kernel<16>, dim3(groups), dim3(64), StarLds<16>::TOTAL, c->stream, b);
+            b.only_redo = 1;
+            hipLaunchKernelGGL((search_kernel<P, false>), dim3(a.njobs), dim3(64), wave_lds_bytes<P>(a.max_dim, true) + pad, c->stream, b);
         }
         else
             hipLaunchKernelGGL((search_kernel<P, false>), dim3(a.njobs), dim3(64), wave_lds_bytes<P>(a.max_dim, true) + pad, c->stream, b);
-        if (b.staged)
-            hipLaunchKernelGGL(refine8_kernel, dim3((a.njobs + 3) / 4), dim3(64), R8_LDS, c->stream, b);
+        if (b.staged == 8)
+            hipLaunchKernelGGL(refine_small_kernel<8>, dim3(groups), dim3(64), RefineLds<8>::TOTAL, c->stream, b);
+        else if (b.staged == 16)
+            hipLaunchKernelGGL(refine_small_kernel<16>, dim3(groups), dim3(64), RefineLds<16>::TOTAL, c->stream, b);
     }
     HIPCHK(c, hipGetLastError());
     return X265AMD_OK;
@@ -915,7 +923,6 @@ static int create_ctx(int device, int bit_depth, int high_priority, x265amd_ctx 
     x265amd_ctx *c = new x265amd_ctx();
     c->device = device; c->depth = bit_depth;
     c->d_jobs = c->d_results = c->d_stage = 0; c->d_ticket = 0; c->jobs_cap = c->results_cap = c->stage_cap = 0; c->d_out = 0;
-    c->d_queue = 0; c->queue_cap = 0;
     c->esa_window_bytes = ESA_WINDOW_DEFAULT;
     c->esa_lds_raised = c->rime_lds_raised = false;
     int prio_least = 0, prio_greatest = 0;
@@ -957,7 +964,6 @@ void x265amd_destroy(x265amd_ctx *c)
     if (c->d_jobs) (void)hipFree(c->d_jobs);
     if (c->d_results) (void)hipFree(c->d_results);
     if (c->d_stage) (void)hipFree(c->d_stage);
-    if (c->d_queue) (void)hipFree(c->d_queue);
     if (c->d_out) (void)hipFree(c->d_out);
     if (c->d_ticket) (void)hipFree(c->d_ticket);
     (void)hipStreamDestroy(c->stream);
@@ -1167,7 +1173,7 @@ static void fill_args(x265amd_ctx *c, SearchArgs &a, const x265amd_plane *fenc, 
         a.ref[i].origin = r->origin; a.ref[i].stride = r->stride;
     }
     a.lowres = is_lowres; a.depth = c->depth; a.method = method; a.subme = subme; a.max_dim = is_lowres ? 8 : 64;
-    a.staged = 0; a.pairs = 0; a.npairs = 0;
+    a.staged = 0; a.only_redo = 0; a.pairs = 0; a.npairs = 0;
     a.ctab = c->tables[qp] + 32768;
 }
 

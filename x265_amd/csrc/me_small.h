@@ -1,0 +1,488 @@
+/* 8x8 and 16x16 PUs in fixed-shape kernels (8-bit samples, full-resolution planes): the sub-pel refinement
+ * (refine_small_kernel) and the common case of the STAR integer stage (star_small_kernel), a PU per group of
+ * S * S / 4 lanes -- four 8x8 PUs or one 16x16 PU per wave.
+ *
+ * The refinement rounds of MotionEstimate::motionEstimate (motion.cpp:1071-1141) have a fixed shape: the
+ * neighbours of one centre at one distance, in the order of the square table, each an 8-tap interpolation
+ * plus SAD or SATD (subpelCompare, motion.cpp:1651-1689). The one-wave search (me_search.h) runs them through its
+ * general candidate machinery, and an 8x8 PU, four 4x4 tiles, fills a quarter of its passes. Here what is uniform
+ * per PU (centre, best cost, predictor) is a value every lane of the PU's group holds, decisions are group-wide
+ * minima (DPP), the passes are straight-line code and, for 8x8 PUs, filled by four PUs.
+ *
+ * Per round and PU the three columns of candidates (x - step, x, x + step) share their horizontal pass: one
+ * plane of luma_hps intermediates (ipfilter.cpp:235-278) per column, S + 8 rows x S samples, int16, column-major
+ * in LDS. With 8-bit samples that intermediate keeps every bit, luma_vsp (:359-400) with the phase-0 taps on it
+ * gives exactly luma_hpp's (sum + 32) >> 6, and the phase-0 intermediate of a sample is 64 * sample - 8192, on
+ * which luma_vsp equals luma_vpp: one plane kind serves every fraction, as in eval_planes. The vertical pass
+ * and the cost run one lane per (tile, column) in plane_column_cost, one candidate of every PU per pass.
+ *
+ * The stage before leaves (mv, cost, counters) of the full-pel / predictor choice (motion.cpp:1063-1069) in
+ * the PU's result record; refine_small_kernel refines that record in place. PUs of other sizes were finished by
+ * the one-wave search and are skipped.
+ */
+#ifndef X265AMD_ME_SMALL_H
+#define X265AMD_ME_SMALL_H
+
+namespace x265amd {
+
+template<int S> struct SmallGeo
+{
+    static_assert(S == 8 || S == 16, "8x8 or 16x16 PUs");
+    static constexpr int LG = S == 8 ? 4 : 6;       /* log2 of the lanes of a PU's group: a lane per (tile, column) */
+    static constexpr int LPP = 1 << LG;
+    static constexpr int NPU = 64 / LPP;            /* PUs per wave */
+    static constexpr int TW = S / 4;                /* tiles in a PU row */
+    static constexpr int LTW = S == 8 ? 1 : 2;
+    static constexpr int LT = 2 * LTW;              /* log2 of the tiles of a PU */
+    static constexpr int ROWS = S + 8;              /* rows of a plane: the PU, the 7 rows the taps reach and one for a second first row */
+    static constexpr int PROW = ROWS + 2;           /* int16 rows of a plane column, with slack for an odd first row */
+    static constexpr int PLANE = S * PROW * 2;      /* bytes of one plane */
+    static constexpr int IPP = ROWS * TW;           /* horizontal-pass items (4 samples of a row) per plane */
+    static constexpr int SIZE_CODE = S | (S << 8);  /* the (w, h) bytes of a job record */
+};
+#define SM_TAPS 0                                   /* 48 dwords of packed filter taps (TapWords) */
+
+template<int LG> __device__ __forceinline__ int grp_lane(int v, int k) { return __shfl(v, (int)(threadIdx.x & 63 & ~((1 << LG) - 1)) + k); }
+template<int LG> __device__ __forceinline__ int grp_min(int v) { return LG == 4 ? row_min16(v) : wave_min(v); }
+/* flags of the first 16 lanes of the group */
+template<int LG> __device__ __forceinline__ unsigned grp_bits16(bool p)
+{
+    const unsigned long long b = __ballot(p);
+    return (unsigned)((b >> (threadIdx.x & 63 & ~((1 << LG) - 1))) & 0xffff);
+}
+template<int LG> __device__ __forceinline__ int grp_count(bool p)
+{
+    const unsigned long long b = __ballot(p);
+    return LG == 6 ? (int)__builtin_popcountll(b) : (int)__builtin_popcount((unsigned)((b >> (threadIdx.x & 48)) & 0xffff));
+}
+template<int LG> __device__ __forceinline__ bool grp_any(bool p)
+{
+    const unsigned long long b = __ballot(p);
+    return LG == 6 ? b != 0 : ((b >> (threadIdx.x & 48)) & 0xffff) != 0;
+}
+
+/* four samples of one plane row: luma_hps of 8-bit samples on v_dot4_i32_i8. The samples are biased to signed bytes;
+ * the taps of every phase add up to 64, so the sum comes out 8192 low, which is exactly luma_hps's offset
+ * (ipfilter.cpp:246-247 with 8-bit samples). `tp`: the packed taps of the phase (TapWords). */
+__device__ __forceinline__ void hps_quad(const uint8_t AS1 *s, const int *tp, int16_t *dst, int pitch)
+{
+    const uint32_t d0 = Px<uint8_t>::load_g(s) ^ 0x80808080u, d1 = Px<uint8_t>::load_g(s + 4) ^ 0x80808080u,
+                   d2 = Px<uint8_t>::load_g(s + 8) ^ 0x80808080u;
+    const int tlo = tp[9], thi = tp[10];
+    dst[0] = (int16_t)__builtin_amdgcn_sdot4(d0, tlo, __builtin_amdgcn_sdot4(d1, thi, 0, false), false);
+#pragma unroll
+    for (int x = 1; x < 4; x++)
+        dst[x * pitch] = (int16_t)__builtin_amdgcn_sdot4(__builtin_amdgcn_alignbyte(d1, d0, x), tlo,
+                                                         __builtin_amdgcn_sdot4(__builtin_amdgcn_alignbyte(d2, d1, x), thi, 0, false), false);
+}
+
+/* vertical pass + cost of the lane's (tile, column) against plane `poff`, first tap row `r0`, vertical phase yf */
+template<int S>
+__device__ __forceinline__ int small_column_cost(int poff, int r0, int yf, bool satd, const ColTile<uint8_t> &ct, int x)
+{
+    ColCand cc;
+    cc.poff = poff; cc.prow = SmallGeo<S>::PROW; cc.R0 = r0;
+    cc.shiftV = 12;                                  /* 6 + the headroom of 8-bit samples */
+    cc.offV = (1 << 11) + (8192 << 6);
+    cc.satd = satd ? 1 : 0;
+    const int *tp = (const int*)(x265amd_smem + SM_TAPS) + yf * 12;
+#pragma unroll
+    for (int k = 0; k < 4; k++) cc.ev[k] = (uint32_t)tp[k];
+#pragma unroll
+    for (int k = 0; k < 5; k++) cc.od[k] = (uint32_t)tp[4 + k];
+    return plane_column_cost<uint8_t>(0, cc, ct, x, 8);
+}
+
+/* the lane's tile column of the source block */
+template<int S>
+__device__ __forceinline__ void small_source_column(const uint8_t AS1 *fenc0, int fstride, int pux, int puy, int l, ColTile<uint8_t> &ct)
+{
+    typedef SmallGeo<S> G;
+    const int t = l >> 2, tx = t & (G::TW - 1), ty = t >> G::LTW;
+    ct.ty = ty; ct.col = tx * 4 + (l & 3);
+    const uint8_t AS1 *src = fenc0 + (long)(puy + ty * 4) * fstride + pux + ct.col;
+#pragma unroll
+    for (int y = 0; y < 4; y++) ct.f[y] = (int)src[(long)y * fstride];
+}
+
+/* the planes of a job: the launch's own, or its entry of the pair table (as job_planes, per lane) */
+__device__ __forceinline__ void small_planes(const SearchArgs &a, int d1, const uint8_t AS1 *&fenc0, int &fstride,
+                                             const uint8_t AS1 *&ref0, int &rstride)
+{
+    fenc0 = (const uint8_t AS1*)a.fenc.origin; fstride = a.fenc.stride;
+    ref0 = (const uint8_t AS1*)a.ref[0].origin; rstride = a.ref[0].stride;
+    if (a.pairs)
+    {
+        int pi = (d1 >> 24) & 0xff;
+        if (pi >= a.npairs) pi = 0;
+        const PairDev *p = a.pairs + pi;
+        fenc0 = (const uint8_t AS1*)p->fenc.origin; fstride = p->fenc.stride;
+        ref0 = (const uint8_t AS1*)p->ref.origin; rstride = p->ref.stride;
+    }
+}
+
+/* ---------------------------------------------------------------- sub-pel refinement */
+
+template<int S> struct RefineLds
+{
+    typedef SmallGeo<S> G;
+    static constexpr int PARAMS = 192;                              /* per PU, 48 bytes: 3 source offsets, row pitch, 3 phases, -, plane origin (64 bit) */
+    static constexpr int PLANES = PARAMS + G::NPU * 48;
+    static constexpr int PU_BYTES = 3 * G::PLANE + 4;               /* the odd dword staggers the PUs over the LDS banks */
+    static constexpr int TOTAL = PLANES + G::NPU * PU_BYTES + 32;
+};
+
+template<int S> struct RefineSmall
+{
+    typedef SmallGeo<S> G;
+    typedef RefineLds<S> L;
+    /* per PU, the same in every lane of its group */
+    int qx, qy, bcost, mvpx, mvpy, roff;
+    unsigned nsub;
+    bool active;
+    const uint8_t AS1 *ref0;    /* origin of the PU's reference plane (PUs of one wave may search different pictures) */
+    int rstride;
+    /* per lane */
+    int lane, grp, l;
+    ColTile<uint8_t> ct;
+    const uint16_t AS1 *ctab;
+
+    /* One refinement round for every PU of the wave: `dirs` neighbours of (qx, qy) at distance `step`, plus the
+     * centre itself first when `centre` (the SATD re-measure of motion.cpp:1086, :1117, whose cost replaces
+     * bcost). dirs = 0 with centre measures the centre alone (the closing SATD of subme 0). */
+    __device__ __forceinline__ void round(int step, int dirs, bool satd, bool centre)
+    {
+        constexpr unsigned long long SQX = nibs({ 0, 0, 0, -1, 1, -1, -1, 1, 1 }), SQY = nibs({ 0, -1, 1, 0, 0, -1, 1, -1, 1 });
+        const int k0 = centre ? 1 : 0, K = k0 + dirs;
+        /* lambda * bits of the candidate this lane folds (bitcost.h:46: the sum wraps at 16 bits) */
+        int mvc = 0;
+        {
+            const int i = l < K ? l + 1 - k0 : 0;
+            const int tx = as_i16(qx + nib(SQX, i) * step), ty = as_i16(qy + nib(SQY, i) * step);
+            if (l < K && active) mvc = ((int)ctab[tx - mvpx] + (int)ctab[ty - mvpy]) & 0xffff;
+        }
+        /* rows of the planes: the candidates' first rows are ymin or ymin + 1 */
+        const int ya = as_i16(qy - step) >> 2, yb = qy >> 2, yc = as_i16(qy + step) >> 2;
+        int ymin = ya < yb ? ya : yb;
+        ymin = yc < ymin ? yc : ymin;
+        wave_sync();
+        if (l < 3)
+        {
+            const int xp = as_i16(qx + (l - 1) * step);
+            int *prm = (int*)(x265amd_smem + L::PARAMS + grp * 48);
+            prm[l] = roff + __mul24(ymin - 3, rstride) + (xp >> 2) - 3;
+            prm[4 + l] = xp & 3;
+            if (l == 0)
+            {
+                prm[3] = rstride;
+                *(unsigned long long*)(prm + 8) = (unsigned long long)ref0;
+            }
+        }
+        wave_sync();
+        /* horizontal pass: 3 planes per PU */
+        constexpr int TOTAL = G::NPU * 3 * G::IPP;
+#pragma unroll 2
+        for (int i0 = 0; i0 < TOTAL; i0 += 64)
+        {
+            const int item = i0 + lane < TOTAL ? i0 + lane : TOTAL - 1;     /* a short last pass repeats the last item */
+            const int pu = item / (3 * G::IPP), rem = item - pu * (3 * G::IPP);
+            const int p = rem / G::IPP, rr = rem - p * G::IPP, r = rr >> G::LTW, q = rr & (G::TW - 1);
+            const int *prm = (const int*)(x265amd_smem + L::PARAMS + pu * 48);
+            hps_quad((const uint8_t AS1*)*(const unsigned long long*)(prm + 8) + prm[p] + __mul24(r, prm[3]) + 4 * q,
+                     (const int*)(x265amd_smem + SM_TAPS) + prm[4 + p] * 12,
+                     (int16_t*)(x265amd_smem + L::PLANES + pu * L::PU_BYTES + p * G::PLANE) + (4 * q) * G::PROW + r, G::PROW);
+        }
+        wave_sync();
+        /* vertical pass + cost: candidate c of every PU per pass, a lane per (tile, column) */
+        int mycost = 0;
+        for (int c = 0; c < K; c++)
+        {
+            const int i = c + 1 - k0;
+            const int ty = as_i16(qy + nib(SQY, i) * step);
+            int v = small_column_cost<S>(L::PLANES + grp * L::PU_BYTES + (nib(SQX, i) + 1) * G::PLANE, (ty >> 2) - ymin, ty & 3, satd, ct, l & 3);
+            v = seg_sum(v, G::LG);
+            if (l == c) mycost = (satd ? v >> 1 : v) + mvc;   /* every 4x4 abs-sum is even: halving the total = halving per tile */
+        }
+        /* the reference's strict '<' over the candidates in table order */
+        if (centre && active) bcost = grp_lane<G::LG>(mycost, 0);
+        int key = 0x7fffffff;
+        if (l >= k0 && l < K) key = (mycost << 6) | l;
+        key = grp_min<G::LG>(key);
+        int bdir = 0;
+        if (active && (key >> 6) < bcost) { bcost = key >> 6; bdir = (key & 63) - k0 + 1; }
+        qx = as_i16(qx + nib(SQX, bdir) * step); qy = as_i16(qy + nib(SQY, bdir) * step);
+        if (active) nsub += (unsigned)K;
+    }
+};
+
+template<int S>
+__global__ __launch_bounds__(64) void refine_small_kernel(SearchArgs a)
+{
+    typedef SmallGeo<S> G;
+    const int ngroups = (a.njobs + G::NPU - 1) / G::NPU;
+    const int g = xcd_remap((int)blockIdx.x, ngroups);
+    if (g >= ngroups) return;
+    RefineSmall<S> R;
+    R.lane = (int)threadIdx.x; R.grp = R.lane >> G::LG; R.l = R.lane & (G::LPP - 1);
+    int j = g * G::NPU + R.grp;
+    const bool valid = j < a.njobs;
+    if (!valid) j = a.njobs - 1;
+    const int *job = (const int*)(a.jobs + j);
+    const int d0 = job[0], d1 = job[1], d4 = job[4];
+    const int pux = as_i16(d0), puy = d0 >> 16;
+    int *res = (int*)(a.results + j);
+    const int r0 = res[0];
+    R.qx = as_i16(r0); R.qy = r0 >> 16; R.bcost = res[1]; R.nsub = (unsigned)res[3];
+    R.mvpx = as_i16(d4); R.mvpy = d4 >> 16;
+    /* a PU whose full-pel cost is 0 is not refined (motion.cpp:1073-1076); PUs of other sizes are final already */
+    R.active = valid && (d1 & 0xffff) == G::SIZE_CODE && R.bcost != 0;
+    if (__ballot(R.active) == 0) return;
+    const uint8_t AS1 *fenc0;
+    int fstride;
+    small_planes(a, d1, fenc0, fstride, R.ref0, R.rstride);
+    R.roff = puy * R.rstride + pux;
+    R.ctab = (const uint16_t AS1*)a.ctab;
+    if (R.lane < 48) ((int*)(x265amd_smem + SM_TAPS))[R.lane] = kTapWords.w[R.lane];
+    small_source_column<S>(fenc0, fstride, pux, puy, R.l, R.ct);
+    /* SubpelWorkload, motion.cpp:53-63, and the round sequence of :1100-1141 */
+    const int hpel_iters = kWorkload[a.subme][0], hpel_dirs = kWorkload[a.subme][1];
+    const int qpel_iters = kWorkload[a.subme][2], qpel_dirs = kWorkload[a.subme][3], hpel_satd = kWorkload[a.subme][4];
+    bool centre = hpel_satd != 0;
+    for (int it = 0; it < hpel_iters; it++)
+    {
+        R.round(2, hpel_dirs, hpel_satd != 0, centre);
+        centre = false;
+    }
+    centre = !hpel_satd;
+    if (centre && !qpel_iters) R.round(1, 0, true, true);
+    for (int it = 0; it < qpel_iters; it++)
+    {
+        R.round(1, qpel_dirs, true, centre);
+        centre = false;
+    }
+    if (R.l == 0 && R.active)
+    {
+        res[0] = (R.qx & 0xffff) | (R.qy << 16);
+        res[1] = R.bcost;
+        res[3] = (int)R.nsub;
+    }
+}
+
+/* ---------------------------------------------------------------- the common case of a STAR search
+ *
+ * Most PUs of a picture end their integer search where it began: the start-up candidates (motion.cpp:562-621)
+ * pick a full-pel start, none of the 20 points of the first three star rounds (distance 1, 2, 4; StarPatternSearch,
+ * :307-547) beats it, three rounds without improvement end the pattern (earlyExitIters = 3, :914) and with
+ * bDistance == 0 nothing else runs (:916-1017). For such a PU the order of the points does not matter -- only that
+ * none is cheaper -- so the whole stage has a fixed shape: the start-up candidates as one plane + one vertical pass
+ * each (all SAD; full-pel ones are the phase-0 case), the decisions of :575-621 on group-uniform values, then the 20
+ * points as plain SADs, four points per pass. A PU one of whose points improves is left to the one-wave search from
+ * the start, as are the PUs of other sizes: their result records get SMALL_REDO in sad_calls, and the search kernel
+ * launched next over all jobs works on exactly those (its other waves leave at once; no counter or queue that a
+ * picture full of such PUs could choke). The others get their record of the full-pel / predictor choice (:1063-1069)
+ * written here, ready for refine_small_kernel. */
+#define SM_SLOTS 7                                  /* clipped predictor, its full-pel rounding, MV 0, four candidates */
+template<int S> struct StarLds
+{
+    typedef SmallGeo<S> G;
+    static constexpr int PU = 192;                                  /* per PU, 16 bytes: plane origin (64 bit), row pitch, candidates in use */
+    static constexpr int CAND = PU + G::NPU * 16;                   /* per PU and candidate, 8 bytes: source offset of the plane, x phase */
+    static constexpr int PLANES = CAND + G::NPU * SM_SLOTS * 8;
+    static constexpr int PU_BYTES = SM_SLOTS * G::PLANE + 4;
+    static constexpr int TOTAL = PLANES + G::NPU * PU_BYTES + 32;
+};
+
+template<int S>
+__global__ __launch_bounds__(64) void star_small_kernel(SearchArgs a)
+{
+    typedef SmallGeo<S> G;
+    typedef StarLds<S> L;
+    const int ngroups = (a.njobs + G::NPU - 1) / G::NPU;
+    const int g = xcd_remap((int)blockIdx.x, ngroups);
+    if (g >= ngroups) return;
+    const int lane = (int)threadIdx.x, grp = lane >> G::LG, l = lane & (G::LPP - 1);
+    int j = g * G::NPU + grp;
+    const bool valid = j < a.njobs;
+    if (!valid) j = a.njobs - 1;
+    const int *job = (const int*)(a.jobs + j);
+    int d[10];
+#pragma unroll
+    for (int i = 0; i < 10; i++) d[i] = job[i];
+    const bool sized = (d[1] & 0xffff) == G::SIZE_CODE;
+    if (valid && !sized && l == 0) a.results[j].sad_calls = SMALL_REDO;
+    const bool act = valid && sized;
+    if (__ballot(act) == 0) return;
+
+    const int pux = as_i16(d[0]), puy = d[0] >> 16, numc = (d[1] >> 16) & 0xff;
+    const int mnx = as_i16(d[2]), mny = d[2] >> 16, mxx = as_i16(d[3]), mxy = d[3] >> 16;
+    const int mvpx = as_i16(d[4]), mvpy = d[4] >> 16;
+    const uint8_t AS1 *fenc0, *ref0;
+    int fstride, rstride;
+    small_planes(a, d[1], fenc0, fstride, ref0, rstride);
+    const int roff = puy * rstride + pux;
+    const uint16_t AS1 *ctab = (const uint16_t AS1*)a.ctab;
+    if (lane < 48) ((int*)(x265amd_smem + SM_TAPS))[lane] = kTapWords.w[lane];
+
+    /* ---- start-up candidates, motion.cpp:575-621 (values every lane of the group holds) ---- */
+    const int qmnx = as_i16(mnx << 2), qmny = as_i16(mny << 2), qmxx = as_i16(mxx << 2), qmxy = as_i16(mxy << 2);
+#define SM_CLIPX(v) ((v) > qmxx ? qmxx : ((v) < qmnx ? qmnx : (v)))
+#define SM_CLIPY(v) ((v) > qmxy ? qmxy : ((v) < qmny ? qmny : (v)))
+    const int pmx = SM_CLIPX(mvpx), pmy = SM_CLIPY(mvpy);
+    int bmx = as_i16((pmx + 2) >> 2), bmy = as_i16((pmy + 2) >> 2);
+    const bool fpOn = ((pmx | pmy) & 3) != 0, zeroOn = (pmx | pmy) != 0;
+    int ccx[4], ccy[4];
+    bool cOn[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+    {
+        ccx[i] = SM_CLIPX(as_i16(d[5 + i])); ccy[i] = SM_CLIPY(d[5 + i] >> 16);
+        cOn[i] = i < numc && (ccx[i] | ccy[i]) != 0 && !(ccx[i] == pmx && ccy[i] == pmy);
+    }
+#undef SM_CLIPX
+#undef SM_CLIPY
+    /* lane l < 7 of a group looks after candidate slot l: where it is measured (quarter-pel) and whether it is in use.
+     * A group without a PU of this size measures slot 0 only, so that every address below stays defined. */
+    int sx = pmx, sy = pmy;
+    bool on = l == 0;
+    if (l == 1) { sx = as_i16(bmx << 2); sy = as_i16(bmy << 2); on = fpOn; }
+    if (l == 2) { sx = 0; sy = 0; on = zeroOn; }
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+        if (l == 3 + i) { sx = ccx[i]; sy = ccy[i]; on = cOn[i]; }
+    on = l < SM_SLOTS && (act ? on : l == 0);
+    const int slotbits = (int)(grp_bits16<G::LG>(on) & 0x7f);
+    const int cidx = __builtin_popcount(slotbits & ((1 << l) - 1)), nact = __builtin_popcount(slotbits);
+    int kmax = __builtin_amdgcn_readlane(nact, 0);
+    if (G::NPU > 1)
+    {
+        const int n1 = __builtin_amdgcn_readlane(nact, 16), n2 = __builtin_amdgcn_readlane(nact, 32), n3 = __builtin_amdgcn_readlane(nact, 48);
+        kmax = n1 > kmax ? n1 : kmax; kmax = n2 > kmax ? n2 : kmax; kmax = n3 > kmax ? n3 : kmax;
+    }
+    /* lambda * bits of the slot (bitcost.h:46); the clipped predictor itself carries none (motion.cpp:579-582) */
+    int mvc = 0;
+    if (on && act && l != 0) mvc = ((int)ctab[sx - mvpx] + (int)ctab[sy - mvpy]) & 0xffff;
+    if (on)
+    {
+        int *cd = (int*)(x265amd_smem + L::CAND + (grp * SM_SLOTS + cidx) * 8);
+        cd[0] = roff + __mul24((sy >> 2) - 3, rstride) + (sx >> 2) - 3;
+        cd[1] = sx & 3;
+    }
+    if (l == 0)
+    {
+        int *pu = (int*)(x265amd_smem + L::PU + grp * 16);
+        *(unsigned long long*)pu = (unsigned long long)ref0;
+        pu[2] = rstride; pu[3] = nact;
+    }
+    wave_sync();
+    /* horizontal pass: the planes of the candidates in use, kmax per PU (a PU with fewer repeats its last) */
+    {
+        const int total = kmax * (G::NPU * G::IPP);
+        for (int i0 = 0; i0 < total; i0 += 64)
+        {
+            const int item = i0 + lane < total ? i0 + lane : total - 1;
+            const int k = item / (G::NPU * G::IPP), rem = item - k * (G::NPU * G::IPP);
+            const int pu = rem / G::IPP, rr = rem - pu * G::IPP, r = rr >> G::LTW, q = rr & (G::TW - 1);
+            const int *pp = (const int*)(x265amd_smem + L::PU + pu * 16);
+            const int kk = k < pp[3] ? k : pp[3] - 1;
+            const int *cd = (const int*)(x265amd_smem + L::CAND + (pu * SM_SLOTS + kk) * 8);
+            hps_quad((const uint8_t AS1*)*(const unsigned long long*)pp + cd[0] + __mul24(r, pp[2]) + 4 * q,
+                     (const int*)(x265amd_smem + SM_TAPS) + cd[1] * 12,
+                     (int16_t*)(x265amd_smem + L::PLANES + pu * L::PU_BYTES + kk * G::PLANE) + (4 * q) * G::PROW + r, G::PROW);
+        }
+    }
+    wave_sync();
+    /* vertical pass + SAD: the k-th candidate in use of every PU per pass */
+    ColTile<uint8_t> ct;
+    small_source_column<S>(fenc0, fstride, pux, puy, l, ct);
+    int mycost = 0;
+    {
+        int rem = slotbits;
+        for (int k = 0; k < kmax; k++)
+        {
+            const int sk = rem ? __builtin_ctz(rem) : 15;
+            rem &= rem - 1;
+            const int ysk = grp_lane<G::LG>(sy, sk < SM_SLOTS ? sk : 0);
+            int v = small_column_cost<S>(L::PLANES + grp * L::PU_BYTES + (k < nact ? k : nact - 1) * G::PLANE, 0, ysk & 3, false, ct, l & 3);
+            v = seg_sum(v, G::LG);
+            if (l == sk) mycost = v + mvc;
+        }
+    }
+    /* the reference's sequence of tests on the measured costs (motion.cpp:579-621) */
+    int bprecost = grp_lane<G::LG>(mycost, 0), bcost = bprecost;
+    unsigned nsad = 0, nsub = 1;
+    {
+        const int cFp = grp_lane<G::LG>(mycost, 1), cZero = grp_lane<G::LG>(mycost, 2);
+        if (fpOn) { bcost = cFp; nsad++; }
+        if (zeroOn)
+        {
+            nsad++;
+            if (cZero < bcost) { bcost = cZero; bmx = 0; bmy = 0; }
+        }
+    }
+    int bpx = pmx, bpy = pmy;
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+    {
+        const int c = grp_lane<G::LG>(mycost, 3 + i);
+        if (cOn[i] && !(ccx[i] == bpx && ccy[i] == bpy))
+        {
+            nsub++;
+            if (c < bprecost) { bprecost = c; bpx = ccx[i]; bpy = ccy[i]; }
+        }
+    }
+    /* ---- the first three star rounds around (bmx, bmy): 4 + 8 + 8 points (motion.cpp:330-452), does any beat bcost?
+     * A lane per (point, tile), four points per pass ---- */
+    constexpr unsigned long long X4 = nibs({ 0, -1, 1, 0 }), Y4 = nibs({ -1, 0, 0, 1 });
+    constexpr unsigned long long X8 = nibs({ 0, -1, 1, -2, 2, -1, 1, 0 }), Y8 = nibs({ -2, -1, -1, 0, 0, 1, 1, 2 });
+    const int tile = l & ((1 << G::LT) - 1), tlx = (tile & (G::TW - 1)) * 4, tly = (tile >> G::LTW) * 4;
+    uint32_t fq[4];
+    {
+        const uint8_t AS1 *src = fenc0 + (long)(puy + tly) * fstride + pux + tlx;
+#pragma unroll
+        for (int y = 0; y < 4; y++) fq[y] = Px<uint8_t>::load_g(src + (long)y * fstride);
+    }
+    bool improve = false;
+    unsigned npts = 0;
+#pragma unroll 1
+    for (int pass = 0; pass < 5; pass++)
+    {
+        const int p = pass * 4 + (l >> G::LT);
+        const int r = p < 4 ? 0 : (p < 12 ? 1 : 2), i = p < 4 ? p : (p - 4) & 7;
+        const int unit = r == 2 ? 2 : 1;
+        const int dx = nib(r == 0 ? X4 : X8, i) * unit, dy = nib(r == 0 ? Y4 : Y8, i) * unit;
+        const int x = as_i16(bmx + dx), y = as_i16(bmy + dy);
+        /* the reference tests only the bounds a point can cross */
+        const bool ok = act && (dy >= 0 || y >= mny) && (dy <= 0 || y <= mxy) && (dx >= 0 || x >= mnx) && (dx <= 0 || x <= mxx);
+        int v = 0, cost = 0;
+        if (ok)
+        {
+            const uint8_t AS1 *rp = ref0 + roff + (long)__mul24(y + tly, rstride) + x + tlx;
+#pragma unroll
+            for (int yy = 0; yy < 4; yy++) v = Px<uint8_t>::sad(fq[yy], Px<uint8_t>::load_g(rp + (long)yy * rstride), v);
+            cost = ((int)ctab[as_i16(x << 2) - mvpx] + (int)ctab[as_i16(y << 2) - mvpy]) & 0xffff;
+        }
+        v = seg_sum(v, G::LT);      /* the tiles of a point are adjacent lanes */
+        improve = improve || (ok && v + cost < bcost);
+        npts += (unsigned)grp_count<G::LG>(ok && tile == 0);
+    }
+    const bool anyImprove = grp_any<G::LG>(improve);
+    if (!act || l != 0) return;
+    if (anyImprove)
+    {
+        a.results[j].sad_calls = SMALL_REDO;
+        return;
+    }
+    /* three rounds without improvement end the pattern with the start point standing; motion.cpp:1063-1069 */
+    nsad += npts;
+    int qx, qy;
+    if (bprecost < bcost) { qx = bpx; qy = bpy; bcost = bprecost; }
+    else { qx = as_i16(bmx << 2); qy = as_i16(bmy << 2); }
+    int *res = (int*)(a.results + j);
+    res[0] = (qx & 0xffff) | (qy << 16);
+    res[1] = bcost;
+    res[2] = (int)nsad;
+    res[3] = (int)nsub;
+}
+
+} // namespace x265amd
+#endif
