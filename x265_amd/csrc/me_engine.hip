@@ -301,6 +301,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void lo
     }
 }
 
+#include "me_lookahead_hex.h"   /* lookahead_band_kernel: hexagon search, four CU rows per wave */
+
 /* frame_init_lowres_core (pixel.cpp:595-618): one thread per lowres pixel, four outputs */
 template<typename P>
 __global__ void lowres_core_kernel(const P *src, P *d0, P *dh, P *dv, P *dc, long ss, long ds, int w, int h)
@@ -868,11 +870,14 @@ static int launch_search(x265amd_ctx *c, const SearchArgs &a, int is_lowres)
 #define LA_ROWS_MAX_FIELDS 512
 static int launch_lookahead(x265amd_ctx *c, LookaheadArgs &a, int nfields, int *d_ticket)
 {
-    const char *force = getenv("X265AMD_LOOKAHEAD_KERNEL");   /* "field" or "rows": measurements only */
-    bool rows = force ? !strcmp(force, "rows") : nfields <= LA_ROWS_MAX_FIELDS;
-    /* the row-parallel kernel marks unfinished CUs with MV x = 0x7FFF: a grid wide enough for a real quarter-pel MV
+    const char *force = getenv("X265AMD_LOOKAHEAD_KERNEL");   /* "field", "rows" or "band": measurements only */
+    /* the hexagon search -- the only method the reference's lookahead uses -- has a kernel of its own (four CU rows per
+     * wave, any number of fields) */
+    bool band = a.method == X265AMD_HEX && (force ? !strcmp(force, "band") : true);
+    bool rows = band || (force ? strcmp(force, "field") != 0 : nfields <= LA_ROWS_MAX_FIELDS);
+    /* the row-parallel kernels mark unfinished CUs with MV x = 0x7FFF: a grid wide enough for a real quarter-pel MV
      * of that value (range end (wcu * 8 + 8) * 4 + 3) goes to the kernel that needs no mark */
-    if ((a.wcu * 8 + 8) * 4 + 3 >= 0x7FFF) rows = false;
+    if ((a.wcu * 8 + 8) * 4 + 3 >= 0x7FFF) rows = band = false;
     a.nfields = nfields;
     a.ticket = d_ticket;
     if (!rows)
@@ -887,6 +892,18 @@ static int launch_lookahead(x265amd_ctx *c, LookaheadArgs &a, int nfields, int *
         const size_t words = (size_t)nfields * a.wcu * a.hcu;
         HIPCHK(c, hipMemsetD32Async((hipDeviceptr_t)a.mvs, LA_MV_UNSET, words, c->stream));
         HIPCHK(c, hipMemsetAsync(d_ticket, 0, sizeof(int), c->stream));
+        if (band)
+        {
+            long nb = (long)nfields * ((a.hcu + LB_ROWS - 1) / LB_ROWS);
+            if (nb > 8192) nb = 8192;
+            const size_t lds = (size_t)LB_ROWS * a.wcu * sizeof(int) + 64;
+            if (c->depth <= 8)
+                hipLaunchKernelGGL(lookahead_band_kernel<uint8_t>, dim3((unsigned)nb), dim3(64), lds, c->stream, a);
+            else
+                hipLaunchKernelGGL(lookahead_band_kernel<uint16_t>, dim3((unsigned)nb), dim3(64), lds, c->stream, a);
+            HIPCHK(c, hipGetLastError());
+            return X265AMD_OK;
+        }
         long waves = (long)nfields * a.hcu;
         if (waves > 8192) waves = 8192;     /* more than the chip holds at once; the rest of the rows go to waves that finish */
         if (c->depth <= 8)

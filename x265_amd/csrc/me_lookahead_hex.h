@@ -1,0 +1,323 @@
+/* Lookahead MV fields, hexagon search, four CU rows per wave.
+ *
+ * The lookahead's search (EstimateRow::estimateCUCost, slicetype.cpp:1401-1470) is always X265_HEX_SEARCH on 8x8
+ * CUs of the half-resolution planes (slicetype.h:65-72), a CU taking its predictors from its right neighbour and the
+ * three CUs below (:1442-1466). The general one-wave search spends ~2000 instructions on such a CU, nearly all of it
+ * bookkeeping: a CU has four 4x4 tiles and a hexagon step three to eight candidates. Here a wave owns a band of four
+ * CU rows of one field, a row per group of 16 lanes = 4 candidates x 4 tiles per pass. The rows run right to left in
+ * lockstep, each two CUs behind the row below it (the lag of the reference's own wavefront, :1362-1379), so inside a
+ * band the three CUs below are always done -- their MVs wait in LDS -- and only the bottom row of a band polls the
+ * top row of the band below (device-scope loads of the MV array, preset to x = 0x7FFF, the reference's "not searched"
+ * mark, :1150). Bands are handed out bottom-up by a ticket, a band only waits on a smaller ticket, so every wait ends.
+ *
+ * Per CU, as MotionEstimate::motionEstimate does for a lowres reference (motion.cpp:549-1146): the start-up
+ * candidates (:575-621), the hexagon (:651-723: ring, half-hexagon walk, closing square, none range-checked), the
+ * choice of :1063-1069, then one half-pel round on SAD and one quarter-pel round on SATD with the centre re-measured
+ * (:1077-1099); every fractional position through lowresQPelCost (lowres.h:78-97: the half-pel plane of the
+ * position, averaged with the next one for odd quarter-pels). Decisions are the reference's strict '<' in its visit
+ * order; all of it is per-lane code that the lanes of a group take together.
+ */
+#ifndef X265AMD_ME_LOOKAHEAD_HEX_H
+#define X265AMD_ME_LOOKAHEAD_HEX_H
+
+namespace x265amd {
+
+#define LB_ROWS 4                       /* CU rows of a band = groups of a wave */
+
+template<typename P> struct BandCu
+{
+    /* group-uniform */
+    const P AS1 *ref[4];                /* the four half-pel planes, at this CU's position */
+    const uint16_t AS1 *ctab;
+    int rstride, mvpx, mvpy, depth;
+    unsigned nsad, nsub;
+    /* per lane */
+    int l, tile;
+    typename Px<P>::quad f[4];          /* the lane's tile of the source CU */
+
+    __device__ __forceinline__ const P AS1 *pick(int i) const
+    {
+        const P AS1 *lo = (i & 1) ? ref[1] : ref[0], *hi = (i & 1) ? ref[3] : ref[2];
+        return (i & 2) ? hi : lo;
+    }
+    /* lowresQPelCost of the lane's tile at quarter-pel (cx, cy); lowres.h:78-97 */
+    __device__ __forceinline__ int tile_cost(int cx, int cy, bool satd) const
+    {
+        const int toff = __mul24((tile >> 1) * 4, rstride) + (tile & 1) * 4;
+        typename Px<P>::quad q[4];
+        const P AS1 *ra = pick((cy & 2) | ((cx & 2) >> 1)) + __mul24(cy >> 2, rstride) + (cx >> 2) + toff;
+#pragma unroll
+        for (int y = 0; y < 4; y++) q[y] = Px<P>::load_g(ra + y * rstride);
+        if ((cx | cy) & 1)
+        {
+            const int bx = as_i16(cx + (cx & 1) * 2), by = as_i16(cy + (cy & 1) * 2);
+            const P AS1 *rb = pick((by & 2) | ((bx & 2) >> 1)) + __mul24(by >> 2, rstride) + (bx >> 2) + toff;
+#pragma unroll
+            for (int y = 0; y < 4; y++) q[y] = Px<P>::avg(q[y], Px<P>::load_g(rb + y * rstride));
+        }
+        return tile_cost_quads<P>(f, q, satd);
+    }
+    /* bitcost.h:46 for a quarter-pel MV (full-pel candidates come in as mv << 2) */
+    __device__ __forceinline__ int mvcost(int qx, int qy) const
+    {
+        return ((int)ctab[qx - mvpx] + (int)ctab[qy - mvpy]) & 0xffff;
+    }
+    /* Costs of K candidates, four per pass: pos(k, x, y) names candidate k's quarter-pel position. Lane k < K of the
+     * group gets candidate k's distortion (+ lambda * bits when addmv(k)); the other lanes INT_MAX. */
+    template<class POS, class ADD>
+    __device__ __forceinline__ int eval(int K, bool satd, POS pos, ADD addmv) const
+    {
+        int mine = 0x7fffffff;
+        int mx = 0, my = 0;
+        if (l < K) pos(l, mx, my);
+        const int mvc = l < K && addmv(l) ? mvcost(mx, my) : 0;
+        for (int k0 = 0; k0 < K; k0 += 4)
+        {
+            const int k = k0 + (l >> 2);
+            int cx = 0, cy = 0;
+            pos(k < K ? k : K - 1, cx, cy);
+            int v = tile_cost(cx, cy, satd);
+            v += dpp_all<0xB1>(v);
+            v += dpp_all<0x4E>(v);
+            /* candidate k0 + i sits in quad i; lane k0 + i of the group takes it */
+            const int c = grp_lane<4>(v, ((l - k0) & 3) * 4);
+            if (l >= k0 && l < k0 + 4 && l < K) mine = c + mvc;
+        }
+        return mine;
+    }
+    /* first minimum of the lanes [k0, k1) in lane order if it beats bcost: its lane, or -1 */
+    __device__ __forceinline__ int fold(int mine, int k0, int k1, int &bcost) const
+    {
+        int key = 0x7fffffff;
+        if (l >= k0 && l < k1) key = (mine << 6) | l;
+        key = row_min16(key);
+        if ((key >> 6) < bcost) { bcost = key >> 6; return key & 63; }
+        return -1;
+    }
+};
+
+__device__ __forceinline__ int mv_word(int x, int y) { return (x & 0xffff) | (y << 16); }
+
+template<typename P>
+__global__ __launch_bounds__(64) void lookahead_band_kernel(LookaheadArgs a)
+{
+    int *rowmv = (int*)x265amd_smem;                /* LB_ROWS rows of W MV words: the rows of this band */
+    const int lane = (int)threadIdx.x, g = lane >> 4, l = lane & 15;
+    const int W = a.wcu, H = a.hcu, ncu = W * H;
+    const int bands = (H + LB_ROWS - 1) / LB_ROWS, nbands = a.nfields * bands;
+    constexpr unsigned long long SQX = nibs({ 0, 0, 0, -1, 1, -1, -1, 1, 1 }), SQY = nibs({ 0, -1, 1, 0, 0, -1, 1, -1, 1 });
+    constexpr unsigned long long HRX = nibs({ -2, -1, 1, 2, 1, -1 }), HRY = nibs({ 0, 2, 2, 0, -2, -2 });
+    constexpr unsigned long long H2X = nibs({ -1, -2, -1, 1, 2, 1, -1, -2 }), H2Y = nibs({ -2, 0, 2, 2, 0, -2, -2, 0 });
+    constexpr unsigned long long MOD6M1 = nibs({ 5, 0, 1, 2, 3, 4, 5, 0 });
+    const int hpel_dirs = kWorkload[a.subme][1], qpel_dirs = kWorkload[a.subme][3];
+    for (;;)
+    {
+        int t = 0;
+        if (lane == 0) t = atomicAdd(a.ticket, 1);
+        t = uni(t);
+        if (t >= nbands) break;
+        const int fi = t % a.nfields, band = t / a.nfields;
+        const FieldDev &fd = a.fields[fi];
+        const int cuy = H - 1 - band * LB_ROWS - g;             /* this group's CU row; rows above the field idle */
+        int *mvw = (int*)(a.mvs + (size_t)fi * ncu * 2);
+        int32_t *costs = a.costs + (size_t)fi * ncu;
+        BandCu<P> C;
+        C.l = l; C.tile = l & 3;
+        C.ctab = (const uint16_t AS1*)a.ctab;
+        C.rstride = fd.ref[0].stride;
+        C.depth = a.depth;
+        int right = 0;
+        wave_sync();
+        for (int s = 0; s < W + 2 * (LB_ROWS - 1); s++)
+        {
+            const int cux = W - 1 - (s - 2 * g);
+            if (cuy >= 0 && cux >= 0 && cux < W)
+            {
+                const int cuXY = cux + cuy * W;
+                /* ---- predictors: right neighbour and the three CUs below (slicetype.cpp:1442-1466) ---- */
+                int below = 0, bleft = 0, bright = 0;
+                if (cuy < H - 1)
+                {
+                    if (g == 0)
+                    {
+                        int nb = 0;
+                        const int dx = l == 0 ? 0 : (l == 1 ? -1 : 1);
+                        if (l < 3 && cux + dx >= 0 && cux + dx < W)
+                        {
+                            const int *src = mvw + cuXY + W + dx;
+                            nb = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            while ((nb & 0xffff) == 0x7FFF)
+                            {
+                                __builtin_amdgcn_s_sleep(4);
+                                nb = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            }
+                        }
+                        below = grp_lane<4>(nb, 0); bleft = grp_lane<4>(nb, 1); bright = grp_lane<4>(nb, 2);
+                    }
+                    else
+                    {
+                        const int *rb = rowmv + (g - 1) * W + cux;
+                        below = rb[0];
+                        if (cux > 0) bleft = rb[-1];
+                        if (cux < W - 1) bright = rb[1];
+                    }
+                }
+                int cx[4] = { 0, 0, 0, 0 }, cy[4] = { 0, 0, 0, 0 }, numc = 0;
+#define LB_PUSH(word) do { const int w_ = (word); if (numc == 0) { cx[0] = as_i16(w_); cy[0] = w_ >> 16; } else if (numc == 1) { cx[1] = as_i16(w_); cy[1] = w_ >> 16; } \
+                           else if (numc == 2) { cx[2] = as_i16(w_); cy[2] = w_ >> 16; } else { cx[3] = as_i16(w_); cy[3] = w_ >> 16; } numc++; } while (0)
+                if (cux < W - 1) LB_PUSH(right);
+                if (cuy < H - 1)
+                {
+                    LB_PUSH(below);
+                    if (cux > 0) LB_PUSH(bleft);
+                    if (cux < W - 1) LB_PUSH(bright);
+                }
+#undef LB_PUSH
+                int mvpx = cx[0], mvpy = cy[0];
+                if (numc > 1) { mvpx = median3(cx[0], cx[1], cx[2]); mvpy = median3(cy[0], cy[1], cy[2]); }
+                C.mvpx = mvpx; C.mvpy = mvpy;
+                /* bounds through the reference's uint16 casts (slicetype.cpp:1427-1430) */
+                const int mnx = as_i16(-cux * 8 - 8), mny = as_i16(-cuy * 8 - 8);
+                const int mxx = as_i16((W - cux - 1) * 8 + 8), mxy = as_i16((H - cuy - 1) * 8 + 8);
+                {
+                    const long off = (long)(cuy * 8) * C.rstride + cux * 8;
+#pragma unroll
+                    for (int i = 0; i < 4; i++) C.ref[i] = (const P AS1*)fd.ref[i].origin + off;
+                    const P AS1 *src = (const P AS1*)fd.fenc.origin + (long)(cuy * 8 + (C.tile >> 1) * 4) * fd.fenc.stride + cux * 8 + (C.tile & 1) * 4;
+#pragma unroll
+                    for (int y = 0; y < 4; y++) C.f[y] = Px<P>::load_g(src + (long)y * fd.fenc.stride);
+                }
+                C.nsad = 0; C.nsub = 0;
+
+                /* ---- start-up candidates, motion.cpp:575-621 ---- */
+                const int qmnx = as_i16(mnx << 2), qmny = as_i16(mny << 2), qmxx = as_i16(mxx << 2), qmxy = as_i16(mxy << 2);
+#define LB_CLIPX(v) ((v) > qmxx ? qmxx : ((v) < qmnx ? qmnx : (v)))
+#define LB_CLIPY(v) ((v) > qmxy ? qmxy : ((v) < qmny ? qmny : (v)))
+                const int pmx = LB_CLIPX(mvpx), pmy = LB_CLIPY(mvpy);
+                int bmx = as_i16((pmx + 2) >> 2), bmy = as_i16((pmy + 2) >> 2);
+                const bool fpOn = ((pmx | pmy) & 3) != 0, zeroOn = (pmx | pmy) != 0;
+                bool cOn[4];
+#pragma unroll
+                for (int i = 0; i < 4; i++)
+                {
+                    cx[i] = LB_CLIPX(cx[i]); cy[i] = LB_CLIPY(cy[i]);
+                    cOn[i] = i < numc && (cx[i] | cy[i]) != 0 && !(cx[i] == pmx && cy[i] == pmy);
+                }
+#undef LB_CLIPX
+#undef LB_CLIPY
+                int bcost, bprecost, bpx = pmx, bpy = pmy;
+                {
+                    const int fx = as_i16(bmx << 2), fy = as_i16(bmy << 2);
+                    /* slots: 0 clipped predictor (no lambda * bits of its own, :579-582), 1 its full-pel rounding, 2 MV 0, 3.. candidates */
+                    auto pos = [&](int k, int &x, int &y)
+                    {
+                        x = pmx; y = pmy;
+                        if (k == 1) { x = fx; y = fy; }
+                        if (k == 2) { x = 0; y = 0; }
+                        if (k == 3) { x = cx[0]; y = cy[0]; }
+                        if (k == 4) { x = cx[1]; y = cy[1]; }
+                        if (k == 5) { x = cx[2]; y = cy[2]; }
+                        if (k == 6) { x = cx[3]; y = cy[3]; }
+                    };
+                    const int mine = C.eval(3 + numc, false, pos, [](int k) { return k != 0; });
+                    bprecost = grp_lane<4>(mine, 0);
+                    C.nsub++;
+                    bcost = bprecost;
+                    if (fpOn) { bcost = grp_lane<4>(mine, 1); C.nsad++; }
+                    if (zeroOn)
+                    {
+                        const int c = grp_lane<4>(mine, 2);
+                        C.nsad++;
+                        if (c < bcost) { bcost = c; bmx = 0; bmy = 0; }
+                    }
+#pragma unroll
+                    for (int i = 0; i < 4; i++)
+                    {
+                        const int c = grp_lane<4>(mine, 3 + i);
+                        if (cOn[i] && !(cx[i] == bpx && cy[i] == bpy))
+                        {
+                            C.nsub++;
+                            if (c < bprecost) { bprecost = c; bpx = cx[i]; bpy = cy[i]; }
+                        }
+                    }
+                }
+
+                /* ---- hexagon search, motion.cpp:651-723 ---- */
+                {
+                    const int ox = bmx, oy = bmy;
+                    const int mine = C.eval(6, false, [&](int k, int &x, int &y) { x = as_i16(as_i16(ox + nib(HRX, k)) << 2); y = as_i16(as_i16(oy + nib(HRY, k)) << 2); },
+                                            [](int) { return true; });
+                    C.nsad += 6;
+                    int dir = C.fold(mine, 0, 6, bcost);
+                    if (dir >= 0)
+                    {
+                        bmx = as_i16(bmx + nib(H2X, dir + 1)); bmy = as_i16(bmy + nib(H2Y, dir + 1));
+                        for (int i = (a.merange >> 1) - 1; i > 0 && bmx >= mnx && bmx <= mxx && bmy >= mny && bmy <= mxy; i--)
+                        {
+                            const int hx = bmx, hy = bmy, hd = dir;
+                            const int m3 = C.eval(3, false, [&](int k, int &x, int &y) { x = as_i16(as_i16(hx + nib(H2X, hd + k)) << 2); y = as_i16(as_i16(hy + nib(H2Y, hd + k)) << 2); },
+                                                  [](int) { return true; });
+                            C.nsad += 3;
+                            const int step = C.fold(m3, 0, 3, bcost) + 1;
+                            if (!step) break;
+                            dir += step - 2;
+                            dir = nib(MOD6M1, dir + 1);
+                            bmx = as_i16(bmx + nib(H2X, dir + 1)); bmy = as_i16(bmy + nib(H2Y, dir + 1));
+                        }
+                    }
+                    const int sx = bmx, sy = bmy;
+                    const int m8 = C.eval(8, false, [&](int k, int &x, int &y) { x = as_i16(as_i16(sx + nib(SQX, k + 1)) << 2); y = as_i16(as_i16(sy + nib(SQY, k + 1)) << 2); },
+                                          [](int) { return true; });
+                    C.nsad += 8;
+                    const int sq = C.fold(m8, 0, 8, bcost) + 1;
+                    bmx = as_i16(bmx + nib(SQX, sq)); bmy = as_i16(bmy + nib(SQY, sq));
+                }
+
+                /* ---- motion.cpp:1063-1069, then the lowres sub-pel rounds, :1077-1099 ---- */
+                int qx, qy;
+                if (bprecost < bcost) { qx = bpx; qy = bpy; bcost = bprecost; }
+                else { qx = as_i16(bmx << 2); qy = as_i16(bmy << 2); }
+                if (bcost)
+                {
+                    {
+                        const int ox = qx, oy = qy;
+                        const int mine = C.eval(hpel_dirs, false, [&](int k, int &x, int &y) { x = as_i16(ox + nib(SQX, k + 1) * 2); y = as_i16(oy + nib(SQY, k + 1) * 2); },
+                                                [](int) { return true; });
+                        C.nsub += (unsigned)hpel_dirs;
+                        const int k = C.fold(mine, 0, hpel_dirs, bcost);
+                        const int bdir = k < 0 ? 0 : k + 1;
+                        qx = as_i16(qx + nib(SQX, bdir) * 2); qy = as_i16(qy + nib(SQY, bdir) * 2);
+                    }
+                    {
+                        const int ox = qx, oy = qy;
+                        const int mine = C.eval(1 + qpel_dirs, true, [&](int k, int &x, int &y) { x = as_i16(ox + nib(SQX, k)); y = as_i16(oy + nib(SQY, k)); },
+                                                [](int) { return true; });
+                        C.nsub += (unsigned)(1 + qpel_dirs);
+                        bcost = grp_lane<4>(mine, 0);
+                        const int k = C.fold(mine, 1, 1 + qpel_dirs, bcost);
+                        const int bdir = k < 0 ? 0 : k;
+                        qx = as_i16(qx + nib(SQX, bdir)); qy = as_i16(qy + nib(SQY, bdir));
+                    }
+                }
+
+                right = mv_word(qx, qy);
+                rowmv[g * W + cux] = right;
+                if (l == 0)
+                {
+                    costs[cuXY] = bcost;
+                    if (a.stats)
+                    {
+                        x265amd_result r;
+                        r.mv[0] = (int16_t)qx; r.mv[1] = (int16_t)qy; r.cost = bcost; r.sad_calls = C.nsad; r.subpel_calls = C.nsub;
+                        a.stats[(size_t)fi * ncu + cuXY] = r;
+                    }
+                    __hip_atomic_store(mvw + cuXY, right, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
+            wave_sync();
+        }
+    }
+}
+
+} // namespace x265amd
+#endif
