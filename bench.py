@@ -34,6 +34,157 @@ LA_QP, LA_MERANGE = 12, 16
 HBM_PEAK_GBS = 8000.0
 
 
+def host_threads(args):
+    """Threads of the many-core CPU leg: the box's CPU share, not the machine's core count."""
+    if args.cpu_threads > 0:
+        return args.cpu_threads
+    n = len(os.sched_getaffinity(0))
+    env = os.environ.get("OMP_NUM_THREADS", "")
+    return max(1, min(n, int(env))) if env.isdigit() else n
+
+
+def valu_bound(profile, kernels, pus, launch_s):
+    """VALU-issue accounting of one launch class from the SQ counters kept in profiles/valu.json (per frame pair):
+    wave instructions issued per PU and the fraction of the launch during which the chip's 1024 SIMDs would be busy
+    issuing them back to back (a wave64 VALU instruction occupies its SIMD for 4 cycles)."""
+    if not profile:
+        return None
+    k = [profile["kernels_per_pair"][n] for n in kernels if n in profile["kernels_per_pair"]]
+    if not k:
+        return None
+    valu, salu, lds = (sum(x[c] for x in k) for c in ("valu", "salu", "lds"))
+    per_pair_pus = profile["pus_per_pair"]
+    npairs = pus / per_pair_pus
+    return {"issued_wave_instr_per_pu": {"valu": valu / per_pair_pus, "salu": salu / per_pair_pus, "lds": lds / per_pair_pus},
+            "busy_frac": valu * npairs * 4 / (profile["simds"] * profile["clock_hz"] * launch_s),
+            "essential_wave_instr_per_pu": profile["essential_wave_instr_per_pu"],
+            "source": profile["source"]}
+
+
+def run_split_workload(args, torch, dist, dev, cdev, rank, local_rank, world):
+    """--workload esa4k / la8k: one picture's (reference, CTU-row band) units, or one lookahead window's fields, split
+    over the ranks; every step ends with the gather of the MV records to rank 0. Strong scaling: the total work is
+    fixed, `value` = the pixel-SADs of the whole picture / window per second."""
+    from x265_amd.engine import Engine
+    from x265_amd import sharded, sharding, workload
+    from x265_amd.measure import SAD_ISSUE_PEAK
+    e = Engine(local_rank, 8)
+    if args.workload == "esa4k":
+        wl = sharded.EsaPicture(e, rank, world)
+        wl.validate()
+        name = ("3840x2160 8-bit, --me full --merange 92 --subme 5, every square 64/32/16/8 PU of one picture against 3 references; "
+                "%d (reference, CTU row) units split contiguously over %d GPU(s), each rank holds only its bands' rows + halo"
+                % (wl.nrefs * wl.nrows, world))
+    else:
+        wl = sharded.LookaheadWindow(e, rank, world)
+        name = ("7680x4320 8-bit lookahead window of 10 frames (bframes 8): the %d lowres MV fields (HEX, subme 1, merange 16, "
+                "%d CUs each) of every (frame, reference) at most 9 apart, dealt out in turn over %d GPU(s)"
+                % (len(wl.all_fields), wl.ncu, world))
+
+    # the rank's records in a tensor of its own, so that RCCL gathers straight from where the kernels wrote them
+    rec = torch.zeros(wl.records_bytes, dtype=torch.uint8, device=dev)
+    wl.records_ptr = rec.data_ptr()
+
+    def step():
+        wl.step()
+        if world > 1:
+            sharding.gather_records(rec.to(cdev), dist, dst=0)
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    tot = torch.tensor([float(wl.pixel_sads()), float(wl.algorithmic_bytes())], dtype=torch.float64, device=cdev)
+    t = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
+    if world > 1:
+        dist.all_reduce(tot, op=dist.ReduceOp.SUM)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t.item())
+    px, alg = float(tot[0].item()), float(tot[1].item())
+    # parity: the gathered records against the unsharded run of the same units on rank 0's GPU (N > 1), and a sample
+    # against the CPU oracle (rank 0)
+    gathered = sharding.gather_records(rec.to(cdev), dist, dst=0) if world > 1 else [rec]
+    if rank == 0:
+        from oracle.bindings import Oracle   # checker / baseline only
+        from x265_amd.synth import pad_plane
+        orc = Oracle()
+        rng = np.random.default_rng(7)
+        cpu_s, cpu_px = 0.0, 0
+        if args.workload == "esa4k":
+            mv, cost = wl.assemble([g.cpu().numpy() for g in gathered])
+            assert all((c >= 0).all() for c in cost), "a job of the picture was searched by no rank"
+            cur, org, stride = pad_plane(wl.cur, 128)
+            for r in range(wl.nrefs if args.cpu_pairs else 0):
+                ref, _, _ = pad_plane(wl.refs[r], 128)
+                ctx = orc.make_ctx(8, cur, org, stride, [ref], org, stride, False, wl.qp, 4, wl.subme)
+                jobs = wl.jobs[r]
+                pick = np.concatenate([rng.choice(np.flatnonzero(jobs["w"] == s), n, replace=False)
+                                       for s, n in ((64, 64), (32, 192), (16, 768), (8, 3072))])
+                c0 = time.perf_counter()
+                exp = orc.me_search_batch(ctx, jobs[pick])
+                cpu_s += time.perf_counter() - c0
+                if not (np.array_equal(exp["mv"], mv[r][pick]) and np.array_equal(exp["cost"], cost[r][pick])):
+                    print("PARITY FAILURE: gathered records of reference %d differ from the oracle" % r, file=sys.stderr)
+                    sys.exit(2)
+                cpu_px += workload.pixel_sads(jobs[pick], exp)
+            sample = ("12288 PUs of the picture (64 64x64, 192 32x32, 768 16x16, 3072 8x8 per reference, seeded) through "
+                      "oracle/me_oracle.c -O3, one thread")
+        else:
+            fields = wl.assemble([g.cpu().numpy() for g in gathered])
+            from oracle.bindings import MEStats
+            from x265_amd.synth import lowres_dims
+
+            def host_lowres_planes(img):
+                """Four padded lowres planes made with the oracle's downscaler (lowres.cpp:155-166): (planes, origin, stride)."""
+                lw, lh, _, _ = lowres_dims(img.shape[1], img.shape[0])
+                src, so, ss = pad_plane(img, 24)
+                padded = [pad_plane(o, 64, stride_align=32) for o in orc.lowres_core(8, src, so, ss, lw, lh)]
+                return [p[0] for p in padded], padded[0][1], padded[0][2]
+            low = {}
+            for u in (range(len(wl.all_fields)) if args.cpu_pairs else ()):
+                b, r = wl.all_fields[int(u)]
+                for f in (b, r):
+                    if f not in low:
+                        low[f] = host_lowres_planes(wl.clip[f])
+                pa, pb = low[b], low[r]
+                ctx = orc.make_ctx(8, pa[0][0], pa[1], pa[2], pb[0], pa[1], pa[2], True, wl.qp, 1, 1)
+                st = MEStats()
+                c0 = time.perf_counter()
+                emv, _ = orc.lookahead_field(ctx, wl.wcu, wl.hcu, 16, stats=st)
+                cpu_s += time.perf_counter() - c0
+                if not np.array_equal(emv, fields[int(u)]):
+                    print("PARITY FAILURE: gathered field %d differs from the oracle" % int(u), file=sys.stderr)
+                    sys.exit(2)
+                cpu_px += (st.sad_calls + st.subpel_calls) * 64
+            sample = "all fields of the window through oracle/me_oracle.c -O3, one thread (lowres planes made beforehand)"
+        value = px * args.steps / elapsed / 1e9
+        out = {"metric": "ME Gpixel-SAD/s", "value": value, "unit": "Gpixel-SAD/s", "n_gpus": world, "steps": args.steps,
+               "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "strong",
+               "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+               "config": {"workload": name, "parallelism": "units split over %d GPU(s), gather of MV records to rank 0" % world},
+               "roofline": {"bound": "hbm", "achieved": alg * args.steps / elapsed / 1e9, "peak": HBM_PEAK_GBS * world, "unit": "GB/s",
+                            "frac": alg * args.steps / elapsed / 1e9 / (HBM_PEAK_GBS * world), "traffic": None,
+                            "algorithmic_bytes_per_step": alg,
+                            "note": "whole step (all launches + gather), not one kernel; compulsory bytes with no reuse between units"},
+               "cpu_baseline": {"value": cpu_px / cpu_s / 1e9, "unit": "Gpixel-SAD/s", "cores": 1, "kind": "port",
+                                "sample": sample + ", %.1f s; compared with the gathered GPU records" % cpu_s} if cpu_s else None}
+        if args.workload == "esa4k":
+            out["roofline"]["valu"] = {"bound": "v_sad_u8 / v_qsad_pk_u16_u8 issue", "peak_pixel_sads_per_s": SAD_ISSUE_PEAK * world,
+                                       "frac": value * 1e9 / (SAD_ISSUE_PEAK * world)}
+        print(json.dumps(out))
+    wl.close()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -44,6 +195,14 @@ def main():
                     help="frame pairs whose PU searches are re-run on one host core (parity gate + CPU baseline; 0 = skip)")
     ap.add_argument("--ref-pairs", type=int, default=8,
                     help="frame pairs re-run through the reference build (oracle/_ref) when it is present: the CPU baseline")
+    ap.add_argument("--workload", choices=("me1080p", "esa4k", "la8k"), default="me1080p",
+                    help="me1080p = the headline (BASELINE configs[1]; weak scaling: 32 frame pairs per GPU); esa4k = one 4K picture "
+                         "searched exhaustively against 3 references, (reference, CTU-row band) units split over the GPUs "
+                         "(configs[2], strong scaling); la8k = the lowres MV fields of one 8K lookahead window dealt out over the "
+                         "GPUs (configs[4], strong scaling)")
+    ap.add_argument("--cpu-threads", type=int, default=0,
+                    help="threads of the many-core CPU baseline leg (0 = the box's CPU share: OMP_NUM_THREADS, else the "
+                         "affinity mask)")
     ap.add_argument("--method", default="star")
     ap.add_argument("--subme", type=int, default=SUBME_DEFAULT, help="sub-pel refinement level (experiments only)")
     ap.add_argument("--launch", choices=("pairs3", "split", "split3", "single", "per-size"), default="pairs3",
@@ -86,6 +245,12 @@ def main():
             dist.init_process_group("nccl", device_id=dev)
     method = METHODS[args.method]
     SUBME = args.subme
+    if args.workload != "me1080p":
+        run_split_workload(args, torch, dist, dev, cdev, rank, local_rank, world)
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
 
     # ---------------- setup (untimed): planes, lookahead fields, job lists, all on the device
     es = Engine(local_rank, 8, high_priority=args.prio == "small")      # search stream (all launches, or the 16/8 class)
@@ -109,7 +274,12 @@ def main():
     la_mvs, la_costs, la_stats = el.lookahead_fields(fields, wcu, hcu, LA_QP, HEX, 1, LA_MERANGE, want_stats=True)
     la_pixel_sads = int((la_stats["sad_calls"].astype(np.int64) + la_stats["subpel_calls"]).sum()) * 64
 
+    njobs = len(workload.square_pu_jobs(W, H, la_mvs[0], wcu, hcu, MERANGE))
     host_jobs, d_jobs, d_res = [], [], []
+    # one result buffer for all launches of a step (each writes its own slice), and the 8 of a record's 16 bytes the host
+    # encoder reads back (MV, cost) as the persistent buffer a rank contributes to the gather
+    all_res = torch.zeros((njobs * B, RESULT_DTYPE.itemsize), dtype=torch.uint8, device=dev)
+    d_mvcost = torch.zeros((njobs * B, 8), dtype=torch.uint8, device=dev)
     segs = None     # per launch of a frame: (first job, count, largest PU size, engine); timed launch first
     for i in range(B):
         jobs = workload.square_pu_jobs(W, H, la_mvs[i], wcu, hcu, MERANGE)   # sorted 64, 32, 16, 8
@@ -127,13 +297,13 @@ def main():
             else:
                 segs = [seg(jobs["w"] == s_, s_, es) for s_ in (8, 16, 32, 64)]
         d_jobs.append(torch.from_numpy(jobs.view(np.uint8).reshape(len(jobs), -1).copy()).to(dev))
-        d_res.append(torch.zeros((len(jobs), RESULT_DTYPE.itemsize), dtype=torch.uint8, device=dev))
-    njobs = len(host_jobs[0])
+        d_res.append(all_res[i * njobs:(i + 1) * njobs])
     if multi:
         # one job list per class over all frame pairs: job.reserved names the pair; the 64x64 PUs of all pairs come
         # before the 32x32 ones (longest waves first), the other classes are pair-major (neighbouring PUs share L2)
         d_pairs = es.pairs_upload([(planes[i + 1], planes[i]) for i in range(B)])
         cls_jobs, cls_res, cls_index = [], [], []
+        res_first = 0
         for (first, cnt, dim, eng) in segs:
             parts, index = [], []
             for i in range(B):
@@ -146,7 +316,8 @@ def main():
                 order = np.argsort(-cj["w"].astype(np.int64), kind="stable")
                 cj, ci = cj[order], ci[order]
             cls_jobs.append(torch.from_numpy(cj.view(np.uint8).reshape(len(cj), -1).copy()).to(dev))
-            cls_res.append(torch.zeros((len(cj), RESULT_DTYPE.itemsize), dtype=torch.uint8, device=dev))
+            cls_res.append(all_res[res_first:res_first + len(cj)])
+            res_first += len(cj)
             cls_index.append(ci)
     d_fields = el.fields_upload(fields, wcu, hcu, HEX, LA_MERANGE)
     d_la_mvs = torch.zeros((B, ncu, 2), dtype=torch.int16, device=dev)
@@ -176,7 +347,9 @@ def main():
         em.sync()
         el.sync()
         if world > 1:
-            sharding.gather_records(torch.cat(cls_res)[:, :8].contiguous().view(-1).to(cdev), dist, dst=0)
+            # hand the MV / cost records to the rank that feeds the host encoder
+            d_mvcost.copy_(all_res[:, :8])
+            sharding.gather_records(d_mvcost.view(-1).to(cdev), dist, dst=0)
             sharding.gather_records(d_la_mvs.view(torch.uint8).view(-1).to(cdev), dist, dst=0)
 
     def step_pairwise(k=None):
@@ -201,9 +374,8 @@ def main():
         em.sync()
         el.sync()
         if world > 1:
-            # hand the MV / cost records to the rank that feeds the host encoder
-            # what the host encoder reads back: outQMv and the cost (8 of a record's 16 bytes; the rest are counters)
-            sharding.gather_records(torch.cat(d_res)[:, :8].contiguous().view(-1).to(cdev), dist, dst=0)
+            d_mvcost.copy_(all_res[:, :8])
+            sharding.gather_records(d_mvcost.view(-1).to(cdev), dist, dst=0)
             sharding.gather_records(d_la_mvs.view(torch.uint8).view(-1).to(cdev), dist, dst=0)
 
     step = step_multi if multi else step_pairwise
@@ -253,6 +425,10 @@ def main():
     tpath = os.path.join(ROOT, "profiles", "traffic.json")
     if os.path.exists(tpath):
         traffic = json.load(open(tpath)).get("search_kernel_hbm_bytes_per_launch", {}).get(args.launch)
+        if traffic is not None and multi:
+            traffic *= B      # kept per frame pair (the counters were collected on a 2-pair step)
+    vpath = os.path.join(ROOT, "profiles", "valu.json")
+    vprof = json.load(open(vpath)) if os.path.exists(vpath) and multi and method == METHODS["star"] and SUBME == 5 else None
 
     if rank == 0:
         # parity gate + CPU baseline: the oracle re-runs every PU search of the first frame pairs
@@ -305,9 +481,45 @@ def main():
                                  "reference builds, one thread, %.1f s); MVs and costs compared with the GPU's. The oracle "
                                  "port ran %d pairs in %.1f s (also compared)" % (njobs * nref, nref, B, ref_s, ncpu, cpu_s),
                        "port_value": cpu_px / cpu_s / 1e9}
-        kernel = {"pairs3": "the launch over the %d 8x8 PUs of all %d frame pairs of a step: search_kernel<uint8_t,false> (start-up + "
-                            "integer stage, one PU per wave) followed by refine8_kernel (sub-pel rounds, four PUs per wave); the 16x16 "
-                            "and the 64/32 launches run concurrently on two more streams" % (timed_cnt * B, B),
+        if cpu is not None:
+            # the same searches on all of the box's host cores: one MotionEstimate per thread (as the reference keeps
+            # one per worker, TEncSearch.h:91), frame pairs dealt out over the threads, results compared as well
+            from concurrent.futures import ThreadPoolExecutor
+            nthr = host_threads(args)
+            use_ref = cpu["kind"] == "reference"
+            padded = [pad_plane(f, MARGIN) for f in clip]
+
+            def work(t):
+                px, ok = 0, True
+                rf_t = Ref(8) if use_ref else None
+                for i in range(t, B, nthr):
+                    (cur, org, stride), (ref, _, _) = padded[i + 1], padded[i]
+                    if use_ref:
+                        rf_t.me_config(cur, org, stride, QP, method, SUBME)
+                        exp = rf_t.me_search_batch(ref, org, stride, host_jobs[i])
+                    else:
+                        exp = orc.me_search_batch(orc.make_ctx(8, cur, org, stride, [ref], org, stride, False, QP, method, SUBME),
+                                                  host_jobs[i])
+                    ok &= bool(np.array_equal(res[i]["mv"], exp["mv"]) and np.array_equal(res[i]["cost"], exp["cost"]))
+                    px += workload.pixel_sads(host_jobs[i], res[i])
+                return px, ok
+            c0 = time.perf_counter()
+            with ThreadPoolExecutor(nthr) as ex:
+                outs = list(ex.map(work, range(nthr)))
+            mt_s = time.perf_counter() - c0
+            if not all(o[1] for o in outs):
+                print("PARITY FAILURE: GPU results differ from the CPU baseline's (threaded leg)", file=sys.stderr)
+                sys.exit(2)
+            one = {k: cpu[k] for k in ("value", "cores", "sample")}
+            cpu.update({"value": sum(o[0] for o in outs) / mt_s / 1e9, "cores": nthr, "one_core": one,
+                        "sample": "all %d PU searches of all %d frame pairs of one step on %d threads (one MotionEstimate per "
+                                  "thread, frame pairs dealt out in turn), %.1f s, %s; MVs and costs compared with the GPU's"
+                                  % (njobs * B, B, nthr, mt_s, "the reference's own code (oracle/_ref)" if use_ref
+                                     else "oracle/me_oracle.c -O3")})
+        kernel = {"pairs3": "the launch over the %d 8x8 PUs of all %d frame pairs of a step: star_small_kernel<8> (start-up and the "
+                            "common case of the integer stage, four PUs per wave), search_kernel<uint8_t,false> (the PUs the first "
+                            "kernel marked: one PU per wave) and refine_small_kernel<8> (sub-pel rounds, four PUs per wave); the "
+                            "16x16 and the 64/32 launches run concurrently on two more streams" % (timed_cnt * B, B),
                   "split": "search_kernel<uint8_t,false>, the launch over a frame's %d 16x16 + 8x8 PUs (its 64/32 PUs run "
                            "concurrently on a second stream)" % timed_cnt,
                   "split3": "search_kernel<uint8_t,false>, the launch over a frame's %d 8x8 PUs (its 16x16 and its 64/32 PUs "
@@ -326,9 +538,19 @@ def main():
                        "parallelism": "frame pairs sharded over %d GPU(s), gather of MV records" % world},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": kernel, "launch_ms": launch_ms, "algorithmic_bytes_per_launch": alg_bytes},
+                         "kernel": kernel, "launch_ms": launch_ms, "algorithmic_bytes_per_launch": alg_bytes,
+                         "valu": valu_bound(vprof, vprof["timed_kernels"], timed_cnt * B, launch_ms * 1e-3) if vprof else None,
+                         "note": "the HBM figure prices the compulsory bytes with no reuse between PUs; the launch is bound "
+                                 "by VALU issue (see valu), and its measured HBM traffic is far below the algorithmic bytes "
+                                 "because neighbouring PUs share their windows through L2"},
             "cpu_baseline": cpu,
             "fps_equiv": B * args.steps * world / elapsed,
+            "encode_fps_equiv": {
+                "value": 1.0 / (25.1 * (1 - 0.67) + elapsed / (B * args.steps * world)), "unit": "fps", "derived": True,
+                "how": "NOT a measured encode. Amdahl estimate for a 1080p encode of the reference (survey container, "
+                       "--preset medium --threads 1: 0.04 fps = 25.1 s per frame, ME-related functions 67 % of CPU time) "
+                       "if its motion estimation were served at this step's rate (one frame pair's ME + lookahead field per "
+                       "frame) and the host share stayed as it is"},
         }
         if not args.no_other_paths:
             # the two other search paths of the reference, measured the same way (HIP events, inputs resident);

@@ -265,6 +265,12 @@ int x265amd_lookahead_frame_costs_dev(x265amd_ctx *ctx, const void *d_frames, in
 int x265amd_device_alloc(x265amd_ctx *ctx, size_t bytes, void **d_ptr);
 int x265amd_upload(x265amd_ctx *ctx, void *d_dst, const void *src, size_t bytes);
 
+/* out[i] = the first 8 bytes of results[i] (x265amd_mv mv; int32 cost): what motionEstimate hands back to its caller
+ * (outQMv and the return value, encoder/motion.cpp:549, 1144-1145) without the two visit counters, packed for the
+ * copy to the host or the gather to the rank that feeds the encoder. Device pointers; asynchronous on the engine's
+ * stream, after the searches launched before it. */
+int x265amd_pack_mv_cost(x265amd_ctx *ctx, const void *d_results, int n, void *d_out);
+
 /* ---- explicit weighted prediction ---- */
 
 /* primitives.weight_pp (common/pixel.cpp:512-529) over a whole padded buffer, the way the

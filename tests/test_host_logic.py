@@ -72,6 +72,50 @@ def test_shard_range_partitions_everything():
     assert (lo, hi) == (5, 10) and y0 == 5 * 64 - 100 and y1 == 10 * 64 + 100
 
 
+def _random_field_jobs(width, height, merange, seed, nrefs=3):
+    lw, lh, wcu, hcu = lowres_dims(width, height)
+    rng = np.random.default_rng(seed)
+    return [workload.square_pu_jobs(width, height, rng.integers(-40, 41, (wcu * hcu, 2)).astype(np.int16), wcu, hcu, merange)
+            for _ in range(nrefs)]
+
+
+def test_band_units_cover_the_picture_and_windows_fit():
+    """(reference, CTU row) units: every job of every reference belongs to exactly one rank; a band's cropped planes
+    hold every row its jobs' search windows (plus the sub-pel apron) can read, at the rows the shifted jobs name."""
+    W, H, M, merange = 1920, 1080, 256, 57
+    jobs = _random_field_jobs(W, H, merange, 11)
+    nrows = (H + 63) // 64
+    img = np.random.default_rng(2).integers(0, 256, (H, W)).astype(np.uint8)
+    buf, org, stride = pad_plane(img, M)
+    rows = buf.reshape(-1, stride)
+    for world in (1, 2, 3, 8):
+        seen = [np.zeros(len(j), int) for j in jobs]
+        for rank in range(world):
+            pieces = sharding.row_units(len(jobs), nrows, rank, world)
+            index = sharding.band_record_index(jobs, nrows, rank, world)
+            for r in range(len(jobs)):
+                np.add.at(seen[r], index[index[:, 0] == r, 1], 1)
+            sizes = np.array([jobs[r]["w"][i] for r, i in index])
+            assert (np.diff(sizes.astype(int)) <= 0).all()          # one launch per size, largest first
+            for (r, lo, hi) in pieces:
+                idx, top, bottom = sharding.band_jobs(jobs[r], lo, hi)
+                crop, hb, halo, y0 = sharding.crop_band(buf, stride, M, H, lo, hi, top, bottom)
+                assert y0 == lo * 64 and hb == min(hi * 64, H) - y0 and crop.size == (hb + 2 * halo) * stride
+                j = jobs[r][idx]
+                y = j["pu_y"].astype(int) - y0
+                assert (y + j["mvmin"][:, 1] - 8 >= -halo).all() and (y + j["h"] + j["mvmax"][:, 1] + 8 <= hb + halo).all()
+                assert np.array_equal(crop.reshape(-1, stride), rows[M + y0 - halo:M + y0 + hb + halo])
+        assert all((s_ == 1).all() for s_ in seen), world
+    # a band whose windows leave the padded plane is refused, not cropped short
+    try:
+        sharding.crop_band(buf, stride, M, H, 0, 2, -M - 1, 200)
+        assert False
+    except ValueError:
+        pass
+    assert sharding.round_robin(10, 1, 4) == [1, 5, 9] and sharding.padded_count(10, 4) == 3
+    assert sorted(sum((sharding.round_robin(90, r, 8) for r in range(8)), [])) == list(range(90))
+
+
 _WORKER = r'''
 import os, sys
 sys.path.insert(0, sys.argv[1])
@@ -151,3 +195,50 @@ def test_tile_plan_properties():
     bad = np.array([4, 0, 4], np.int32)
     assert L.x265amd_tile_plan(C.c_void_p(bad.ctypes.data), 3, 0, C.c_void_p(first.ctypes.data), C.c_void_p(chunk.ctypes.data), C.byref(nch)) == -1
 
+
+
+_BAND_WORKER = r'''
+import os, sys
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, os.path.join(sys.argv[1], "tests"))
+import numpy as np, torch, torch.distributed as dist
+from x265_amd import sharding
+from test_host_logic import _random_field_jobs
+dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%s" % sys.argv[2], rank=int(sys.argv[3]), world_size=2)
+rank = dist.get_rank()
+W, H = 640, 360
+jobs = _random_field_jobs(W, H, 24, 5)          # every rank derives the same unsharded lists
+nrows = (H + 63) // 64
+index = sharding.band_record_index(jobs, nrows, rank, 2)
+n_pad = max(len(sharding.band_record_index(jobs, nrows, q, 2)) for q in range(2))
+rec = np.zeros((n_pad, 8), np.uint8)
+mine = np.zeros(len(index), np.dtype([("mv", "<i2", (2,)), ("cost", "<i4")]))
+mine["mv"][:, 0], mine["mv"][:, 1], mine["cost"] = index[:, 0], index[:, 1] % 1000, index[:, 0] * 100000 + index[:, 1]
+rec[:len(index)] = mine.view(np.uint8).reshape(-1, 8)
+got = sharding.gather_records(torch.from_numpy(rec.reshape(-1).copy()), dist, dst=0)
+if rank == 0:
+    mv, cost = sharding.assemble_band_records(jobs, nrows, 2, [g.numpy() for g in got])
+    for r in range(len(jobs)):
+        n = len(jobs[r])
+        assert np.array_equal(cost[r], r * 100000 + np.arange(n)) and (mv[r][:, 0] == r).all()
+        assert np.array_equal(mv[r][:, 1], np.arange(n) % 1000)
+    print("BANDS_OK")
+dist.barrier()
+dist.destroy_process_group()
+'''
+
+
+def test_two_rank_band_records_over_gloo(tmp_path):
+    """World size 2: each rank reports the records of its (reference, CTU-row band) units, rank 0 puts the gathered
+    records back into the order of the unsharded job lists."""
+    script = tmp_path / "band_worker.py"
+    script.write_text(_BAND_WORKER)
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = str(s.getsockname()[1])
+    s.close()
+    procs = [subprocess.Popen([sys.executable, str(script), ROOT, port, str(r)], stdout=subprocess.PIPE,
+                              stderr=subprocess.STDOUT, text=True) for r in range(2)]
+    outs = [p.communicate(timeout=240)[0] for p in procs]
+    assert all(p.returncode == 0 for p in procs), outs
+    assert "BANDS_OK" in outs[0]

@@ -1653,6 +1653,23 @@ int x265amd_upload(x265amd_ctx *c, void *d_dst, const void *src, size_t bytes)
     return X265AMD_OK;
 }
 
+/* the 8 bytes of each 16-byte result record that go back to the host encoder */
+__global__ __launch_bounds__(256) void pack_mv_cost_kernel(const uint2 *records, uint2 *out, int n)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) out[i] = records[2 * i];
+}
+
+int x265amd_pack_mv_cost(x265amd_ctx *c, const void *d_results, int n, void *d_out)
+{
+    if (!c || n < 0 || (n && (!d_results || !d_out))) return fail(c, X265AMD_EINVAL, "null argument");
+    if (!n) return X265AMD_OK;
+    HIPCHK(c, hipSetDevice(c->device));
+    hipLaunchKernelGGL(pack_mv_cost_kernel, dim3((n + 255) / 256), dim3(256), 0, c->stream, (const uint2*)d_results, (uint2*)d_out, n);
+    HIPCHK(c, hipGetLastError());
+    return X265AMD_OK;
+}
+
 /* ---- explicit weighted prediction ---- */
 
 static int weight_args_ok(int w0, int shift)

@@ -287,6 +287,10 @@ class Engine:
         self._chk(self.L.x265amd_fields_upload(self.ctx, arr, n, wcu, hcu, method, merange, C.byref(d)))
         return d
 
+    def pack_mv_cost(self, d_results, n, d_out):
+        """The MV + cost halves of n result records, packed (device pointers, asynchronous on the engine's stream)."""
+        self._chk(self.L.x265amd_pack_mv_cost(self.ctx, C.c_void_p(d_results), n, C.c_void_p(d_out)))
+
     def device_free(self, d):
         self._chk(self.L.x265amd_device_free(self.ctx, C.c_void_p(d) if isinstance(d, int) else d))
 
