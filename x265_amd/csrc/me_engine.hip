@@ -48,7 +48,9 @@ struct SearchArgs
     x265amd_result *results;
     int njobs;
     int max_dim;   /* largest PU width / height the launch reserved LDS for */
-    int only_redo; /* search only the PUs whose result record carries SMALL_REDO (left over by star_small_kernel) */
+    int *redo;         /* null, or the list redo_list_kernel made of the PUs whose result record carries SMALL_REDO (left over
+                          by star_small_kernel): redo[0] = their number, redo[REDO_LIST..] = their job indices. The launch
+                          then searches only these, each wave taking every gridDim.x-th entry */
     int staged;    /* 8 or 16: square PUs of this size stop before the sub-pel refinement, which refine_small_kernel does; 0: none */
 };
 
@@ -72,30 +74,70 @@ __device__ __forceinline__ void job_planes(const SearchArgs &a, const x265amd_jo
     }
 }
 
+/* The list of the PUs star_small_kernel left to the one-wave search, made by one small kernel so that the search
+ * launch behind it costs what the marked PUs cost and not a wave per PU of the launch. `redo` (ints): [0] the number
+ * of marked PUs (star_small_kernel zeroes it), [REDO_LIST ..) their job indices, a block's entries together and in job
+ * order, the blocks in the order their reservations arrive (the searches do not depend on each other). */
+#define REDO_CHUNK 2048                /* jobs per block: one atomic reservation per block */
+#define REDO_LIST 64                   /* ints in front of the list */
+#define REDO_GRID 8192                 /* waves of the search launch that walks the list */
+
+__global__ __launch_bounds__(256) void redo_list_kernel(const x265amd_result *results, int njobs, int *redo)
+{
+    __shared__ int part[REDO_CHUNK / 64];
+    __shared__ int first;
+    const int base = blockIdx.x * REDO_CHUNK, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    bool m[REDO_CHUNK / 256];
+    unsigned long long bal[REDO_CHUNK / 256];
+#pragma unroll
+    for (int k = 0; k < REDO_CHUNK / 256; k++)
+    {
+        const int j = base + k * 256 + (int)threadIdx.x;
+        m[k] = j < njobs && results[j].sad_calls == SMALL_REDO;
+        bal[k] = __ballot(m[k]);
+        if (lane == 0) part[k * 4 + wave] = __popcll(bal[k]);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0)
+    {
+        int n = 0;
+        for (int i = 0; i < REDO_CHUNK / 64; i++) { const int c = part[i]; part[i] = n; n += c; }
+        first = n ? atomicAdd(redo, n) : 0;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < REDO_CHUNK / 256; k++)
+        if (m[k]) redo[REDO_LIST + first + part[k * 4 + wave] + __popcll(bal[k] & ((1ull << lane) - 1))] = base + k * 256 + (int)threadIdx.x;
+}
+
 template<typename P, bool LOWRES>
 __global__ __launch_bounds__(64) void search_kernel(SearchArgs a)
 {
-    const int j = xcd_remap(blockIdx.x, a.njobs);
-    if (j >= a.njobs) return;
-    if (a.only_redo && (unsigned)uni((int)a.results[j].sad_calls) != SMALL_REDO) return;
-    const x265amd_job *job = a.jobs + j;
-    Searcher<P, LOWRES ? 8 : 64, LOWRES> S;
-    const int w = job->w, h = job->h;
-    if (w > a.max_dim || h > a.max_dim)
+    /* one PU per wave: the PU of this workgroup, or every gridDim.x-th entry of the redo list */
+    const int total = a.redo ? uni(a.redo[0]) : a.njobs;
+    for (int k = blockIdx.x; k < total; k += a.redo ? (int)gridDim.x : total)
     {
-        /* the launch did not reserve LDS for a PU this large */
-        if (threadIdx.x == 0)
+        const int j = a.redo ? uni(a.redo[REDO_LIST + k]) : xcd_remap(k, a.njobs);
+        if (j >= a.njobs) return;
+        const x265amd_job *job = a.jobs + j;
+        Searcher<P, LOWRES ? 8 : 64, LOWRES> S;
+        const int w = job->w, h = job->h;
+        if (w > a.max_dim || h > a.max_dim)
         {
-            x265amd_result r = { { 0, 0 }, -1, 0, 0 };
-            a.results[j] = r;
+            /* the launch did not reserve LDS for a PU this large */
+            if (threadIdx.x == 0)
+            {
+                x265amd_result r = { { 0, 0 }, -1, 0, 0 };
+                a.results[j] = r;
+            }
+            continue;
         }
-        return;
+        PlaneDev fenc, ref[4];
+        job_planes(a, job, fenc, ref);
+        S.bind(0, fenc, ref, a.nref, a.ctab, a.depth, job->pu_x, job->pu_y, w, h, a.max_dim, plane_budget(a.max_dim, (int)sizeof(P)));
+        if (a.staged && w == a.staged && h == a.staged) S.search_staged(job, a.method, a.results + j);
+        else S.search(job, a.method, a.subme, a.results + j);
     }
-    PlaneDev fenc, ref[4];
-    job_planes(a, job, fenc, ref);
-    S.bind(0, fenc, ref, a.nref, a.ctab, a.depth, job->pu_x, job->pu_y, w, h, a.max_dim, plane_budget(a.max_dim, (int)sizeof(P)));
-    if (a.staged && w == a.staged && h == a.staged) S.search_staged(job, a.method, a.results + j);
-    else S.search(job, a.method, a.subme, a.results + j);
 }
 
 #include "me_esa.h"   /* esa_scan_kernel, esa_finish_kernel: use SearchArgs and xcd_remap */
@@ -763,6 +805,7 @@ struct x265amd_ctx
     void *d_jobs; size_t jobs_cap;
     void *d_results; size_t results_cap;
     void *d_stage; size_t stage_cap;   /* staging for the per-call primitives */
+    void *d_redo; size_t redo_cap;     /* list of the PUs a fixed-shape kernel left to the one-wave search (redo_list_kernel) */
     int32_t *d_out;
     int *d_ticket;                     /* row hand-out counter of the row-parallel lookahead kernel */
     int esa_window_bytes;              /* LDS the exhaustive search may use per PU for its window */
@@ -843,14 +886,19 @@ static int launch_search(x265amd_ctx *c, const SearchArgs &a, int is_lowres)
         const int npu = b.staged == 8 ? 4 : 1, groups = (a.njobs + npu - 1) / npu;
         if (b.staged && a.method == X265AMD_STAR && !no_star)
         {
+            if (ensure(c, &c->d_redo, &c->redo_cap, sizeof(int) * ((size_t)REDO_LIST + a.njobs))) return X265AMD_EHIP;
+            const int blocks = (a.njobs + REDO_CHUNK - 1) / REDO_CHUNK;
             /* STAR: the common case (start point stands after three star rounds) in a fixed-shape kernel, which marks the
              * records of the PUs it leaves to the one-wave search */
+            b.redo = (int*)c->d_redo;
             if (b.staged == 8)
                 hipLaunchKernelGGL(star_small_kernel<8>, dim3(groups), dim3(64), StarLds<8>::TOTAL, c->stream, b);
             else
                 hipLaunchKernelGGL(star_small_kernel<16>, dim3(groups), dim3(64), StarLds<16>::TOTAL, c->stream, b);
-            b.only_redo = 1;
-            hipLaunchKernelGGL((search_kernel<P, false>), dim3(a.njobs), dim3(64), wave_lds_bytes<P>(a.max_dim, true) + pad, c->stream, b);
+            hipLaunchKernelGGL(redo_list_kernel, dim3(blocks), dim3(256), 0, c->stream, a.results, a.njobs, (int*)c->d_redo);
+            hipLaunchKernelGGL((search_kernel<P, false>), dim3(a.njobs < REDO_GRID ? a.njobs : REDO_GRID), dim3(64),
+                               wave_lds_bytes<P>(a.max_dim, true) + pad, c->stream, b);
+            b.redo = 0;
         }
         else
             hipLaunchKernelGGL((search_kernel<P, false>), dim3(a.njobs), dim3(64), wave_lds_bytes<P>(a.max_dim, true) + pad, c->stream, b);
@@ -939,7 +987,8 @@ static int create_ctx(int device, int bit_depth, int high_priority, x265amd_ctx 
     if (hipGetDeviceCount(&n) != hipSuccess || device < 0 || device >= n) return X265AMD_EHIP;
     x265amd_ctx *c = new x265amd_ctx();
     c->device = device; c->depth = bit_depth;
-    c->d_jobs = c->d_results = c->d_stage = 0; c->d_ticket = 0; c->jobs_cap = c->results_cap = c->stage_cap = 0; c->d_out = 0;
+    c->d_jobs = c->d_results = c->d_stage = c->d_redo = 0; c->d_ticket = 0;
+    c->jobs_cap = c->results_cap = c->stage_cap = c->redo_cap = 0; c->d_out = 0;
     c->esa_window_bytes = ESA_WINDOW_DEFAULT;
     c->esa_lds_raised = c->rime_lds_raised = false;
     int prio_least = 0, prio_greatest = 0;
@@ -981,6 +1030,7 @@ void x265amd_destroy(x265amd_ctx *c)
     if (c->d_jobs) (void)hipFree(c->d_jobs);
     if (c->d_results) (void)hipFree(c->d_results);
     if (c->d_stage) (void)hipFree(c->d_stage);
+    if (c->d_redo) (void)hipFree(c->d_redo);
     if (c->d_out) (void)hipFree(c->d_out);
     if (c->d_ticket) (void)hipFree(c->d_ticket);
     (void)hipStreamDestroy(c->stream);
@@ -1190,7 +1240,7 @@ static void fill_args(x265amd_ctx *c, SearchArgs &a, const x265amd_plane *fenc, 
         a.ref[i].origin = r->origin; a.ref[i].stride = r->stride;
     }
     a.lowres = is_lowres; a.depth = c->depth; a.method = method; a.subme = subme; a.max_dim = is_lowres ? 8 : 64;
-    a.staged = 0; a.only_redo = 0; a.pairs = 0; a.npairs = 0;
+    a.staged = 0; a.redo = 0; a.pairs = 0; a.npairs = 0;
     a.ctab = c->tables[qp] + 32768;
 }
 

@@ -298,6 +298,7 @@ __global__ __launch_bounds__(64) void star_small_kernel(SearchArgs a)
     typedef SmallGeo<S> G;
     typedef StarLds<S> L;
     const int ngroups = (a.njobs + G::NPU - 1) / G::NPU;
+    if (blockIdx.x == 0 && threadIdx.x == 0 && a.redo) a.redo[0] = 0;     /* the list of marked PUs starts empty (redo_list_kernel) */
     const int g = xcd_remap((int)blockIdx.x, ngroups);
     if (g >= ngroups) return;
     const int lane = (int)threadIdx.x, grp = lane >> G::LG, l = lane & (G::LPP - 1);
