@@ -856,14 +856,31 @@ static int launch_esa(x265amd_ctx *c, const SearchArgs &a, int window_bytes, int
 {
     if (!c->esa_lds_raised)
     {
-        HIPCHK(c, hipFuncSetAttribute((const void*)esa_scan_kernel<uint8_t>, hipFuncAttributeMaxDynamicSharedMemorySize,
+        HIPCHK(c, hipFuncSetAttribute((const void*)esa_scan_kernel<uint8_t, 0>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      esa_fixed_lds(64) + ESA_WINDOW_MAX));
+        HIPCHK(c, hipFuncSetAttribute((const void*)esa_scan_kernel<uint8_t, 8>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      esa_fixed_lds(64) + ESA_WINDOW_MAX));
+        HIPCHK(c, hipFuncSetAttribute((const void*)esa_scan_kernel<uint8_t, 16>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                       esa_fixed_lds(64) + ESA_WINDOW_MAX));
         c->esa_lds_raised = true;
     }
-    hipLaunchKernelGGL(esa_scan_kernel<uint8_t>, dim3(a.njobs), dim3(ESA_THREADS), esa_fixed_lds(a.max_dim) + window_bytes,
-                       c->stream, a, window_bytes, nowrap);
+    /* launches of PUs up to 8x8 or up to 16x16: the square PUs of that size are refined by refine_small_kernel */
+    static const bool no_staged = getenv("X265AMD_NO_STAGED") != 0;      /* measurements only */
+    SearchArgs b = a;
+    b.staged = (a.max_dim == 8 || a.max_dim == 16) && !no_staged ? a.max_dim : 0;
+    const size_t scan_lds = esa_fixed_lds(a.max_dim) + window_bytes;
+    if (a.max_dim == 8)
+        hipLaunchKernelGGL((esa_scan_kernel<uint8_t, 8>), dim3(a.njobs), dim3(ESA_THREADS), scan_lds, c->stream, b, window_bytes, nowrap);
+    else if (a.max_dim == 16)
+        hipLaunchKernelGGL((esa_scan_kernel<uint8_t, 16>), dim3(a.njobs), dim3(ESA_THREADS), scan_lds, c->stream, b, window_bytes, nowrap);
+    else
+        hipLaunchKernelGGL((esa_scan_kernel<uint8_t, 0>), dim3(a.njobs), dim3(ESA_THREADS), scan_lds, c->stream, b, window_bytes, nowrap);
     hipLaunchKernelGGL(esa_finish_kernel<uint8_t>, dim3(a.njobs), dim3(64), wave_lds_bytes<uint8_t>(a.max_dim, true),
-                       c->stream, a, window_bytes);
+                       c->stream, b, window_bytes);
+    if (b.staged == 8)
+        hipLaunchKernelGGL(refine_small_kernel<8>, dim3((a.njobs + 3) / 4), dim3(64), RefineLds<8>::TOTAL, c->stream, b);
+    else if (b.staged == 16)
+        hipLaunchKernelGGL(refine_small_kernel<16>, dim3(a.njobs), dim3(64), RefineLds<16>::TOTAL, c->stream, b);
     HIPCHK(c, hipGetLastError());
     return X265AMD_OK;
 }

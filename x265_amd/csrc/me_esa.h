@@ -83,18 +83,22 @@ __device__ __forceinline__ uint64_t lds_pair(int off)
  * size at compile time: the loops unroll, the accumulators start from the instruction's zero
  * operand and the single widening needs no running totals (8x8 PUs spend more instructions on
  * that bookkeeping than on SADs otherwise). */
+/* PU sizes whose packed 16-bit sums hold a whole candidate (at most 64 accumulations of 4 pixels): esa_patch then
+ * leaves the sums packed in a16 and does not fill tot. */
+template<int W, int H> struct EsaPacked { static constexpr bool value = W && H && (W >> 2) * H <= 64; };
+
 template<int W, int H>
-__device__ __forceinline__ void esa_patch(int org, int pitch, int fenc, int w_, int h_, uint32_t tot[ESA_R][4])
+__device__ __forceinline__ void esa_patch(int org, int pitch, int fenc, int w_, int h_, uint32_t tot[ESA_R][4], uint64_t a16[ESA_R])
 {
     const int w = W ? W : w_, h = H ? H : h_;
     static_assert(ESA_R == 8, "the row bookkeeping below is written for 8 candidate rows");
-    uint64_t a16[ESA_R];
 #pragma unroll
     for (int c = 0; c < ESA_R; c++)
     {
         a16[c] = 0;
+        if (!EsaPacked<W, H>::value)
 #pragma unroll
-        for (int i = 0; i < 4; i++) tot[c][i] = 0;
+            for (int i = 0; i < 4; i++) tot[c][i] = 0;
     }
     int cnt = 0;
     const int ncol = w >> 2;
@@ -152,7 +156,7 @@ __device__ __forceinline__ void esa_patch(int org, int pitch, int fenc, int w_, 
                     a16[c] = __builtin_amdgcn_qsad_pk_u16_u8(yy + c < 7 ? old[yy + c < 7 ? yy + c : 0] : nw[yy + c < 7 ? 0 : yy + c - 7], f[yy], a16[c]);
         }
         cnt += h;
-        if (cnt + h > 64 || j == ncol - 1)
+        if (!EsaPacked<W, H>::value && (cnt + h > 64 || j == ncol - 1))
         {
 #pragma unroll
             for (int c = 0; c < ESA_R; c++)
@@ -185,56 +189,17 @@ __device__ __forceinline__ bool esa_job_ok(const JobRegs &J, int w, int h, int m
 /* The raster scan of motion.cpp:1025-1053 for one PU per workgroup: writes the smallest
  * (SAD + lambda * bits, raster index) of the range into results[j].cost / .sad_calls, where
  * esa_finish_kernel picks it up. */
-template<typename P>
-__global__ __launch_bounds__(ESA_THREADS) __attribute__((amdgpu_waves_per_eu(4))) void esa_scan_kernel(SearchArgs a, int win_budget, int nowrap)
+/* The scan of one PU by its workgroup: every strip of the range staged and measured; leaves this lane's best (cost,
+ * raster index) in bc / bi. W, H != 0: the PU size, fixed at compile time. */
+template<typename P, int W, int H>
+__device__ __forceinline__ void esa_scan_pu(const SearchArgs &a, const JobRegs &J, const EsaGeo &g, const PlaneDev *pref, int w, int h,
+                                            int nowrap, int tid, int wave, int lane, uint32_t &bc, uint32_t &bi)
 {
-    static_assert(sizeof(P) == 1, "the packed quad-SAD path is for 8-bit samples");
-    const int j = xcd_remap(blockIdx.x, a.njobs);
-    if (j >= a.njobs) return;
-    const x265amd_job *job = a.jobs + j;
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-#ifdef X265AMD_TRACE
-    /* debug builds only: per-wave start / end time (100 MHz counter) and placement, in a side
-     * buffer behind the result records */
-    unsigned long long *trace = (unsigned long long*)(a.results + a.njobs) + ((size_t)blockIdx.x * (ESA_THREADS / 64) + wave) * 4;
-    if (lane == 0)
-    {
-        trace[0] = wall_clock64();
-        trace[2] = ((unsigned long long)__builtin_amdgcn_s_getreg(63508) << 32) | (unsigned)__builtin_amdgcn_s_getreg(63492);
-    }
-#endif
-    JobRegs J;
-    J.load(job);
-    const int w = uni(job->w), h = uni(job->h);
-    EsaGeo g;
-    if (!esa_job_ok(J, w, h, a.max_dim, win_budget, g))
-    {
-        if (tid == 0) { a.results[j].cost = -1; a.results[j].sad_calls = 0; }
-        return;
-    }
-    PlaneDev pfenc, pref[4];
-    job_planes(a, job, pfenc, pref);
     const int nx = g.nx, ny = g.ny;
-    g.off_cx = esa_fixed_lds(a.max_dim);
-    g.off_cy = g.off_cx + 16 * g.xgs;
-    g.off_win = g.off_cy + 4 * ESA_R * g.ygs;
-
-    {
-        /* source block into LDS, pitch 64 (setSourcePU, motion.cpp:116-142) */
-        const char AS1 *src = (const char AS1*)pfenc.origin + (long)J.puy * pfenc.stride + J.pux;
-        const int wd = w >> 2;
-        for (int i = tid; i < wd * h; i += ESA_THREADS)
-        {
-            const int y = i / wd, x = i - y * wd;
-            typedef uint32_t __attribute__((aligned(1))) u32u;
-            *(uint32_t*)(x265amd_smem + ESA_L_FENC + y * 64 + 4 * x) = *(const u32u AS1*)(src + (long)y * pfenc.stride + 4 * x);
-        }
-    }
     const uint16_t AS1 *ctab = (const uint16_t AS1*)a.ctab;
     const P AS1 *ref = (const P AS1*)pref[0].origin + (long)J.puy * pref[0].stride + J.pux;
     const int rstride = pref[0].stride;
     const int pd = g.pitch >> 2;
-    uint32_t bc = 0xffffffffu, bi = 0xffffffffu;   /* this lane's best (cost, raster index) */
     bool first = true;
     for (int ys0 = 0; ys0 < g.nyg; ys0 += g.ygs)
         for (int xs0 = 0; xs0 < g.nxg; xs0 += g.xgs)
@@ -309,14 +274,47 @@ __global__ __launch_bounds__(ESA_THREADS) __attribute__((amdgpu_waves_per_eu(4))
                 const int it = live ? i0 + lane : ni - 1;
                 const int yg = (it * inv) >> 16, xg = it - yg * xgc;
                 uint32_t tot[ESA_R][4];
+                uint64_t a16[ESA_R];
                 const int porg = g.off_win + yg * ESA_R * g.pitch + xg * 4;
-                if (w == 8 && h == 8) esa_patch<8, 8>(porg, g.pitch, ESA_L_FENC, w, h, tot);
-                else if (w == 16 && h == 16) esa_patch<16, 16>(porg, g.pitch, ESA_L_FENC, w, h, tot);
-                else esa_patch<0, 0>(porg, g.pitch, ESA_L_FENC, w, h, tot);
+                constexpr bool packed = EsaPacked<W, H>::value;
+                esa_patch<W, H>(porg, g.pitch, ESA_L_FENC, w, h, tot, a16);
                 int cx[4];
 #pragma unroll
                 for (int i = 0; i < 4; i++) cx[i] = lds_i(0, g.off_cx)[xg * 4 + i];
                 uint32_t best = 0xffffffffu;
+                if (packed && nowrap)
+                {
+                    /* as below, straight from the packed sums: key = sum16 * 32 + (cx << 5 | column) in one
+                     * multiply-add that picks its 16-bit half */
+                    uint32_t kx[4];
+#pragma unroll
+                    for (int i = 0; i < 4; i++) kx[i] = ((uint32_t)cx[i] << 5) | (uint32_t)i;
+#pragma unroll
+                    for (int c = 0; c < ESA_R; c++)
+                    {
+                        const uint32_t ky = ((uint32_t)lds_i(0, g.off_cy)[yg * ESA_R + c] << 5) | (uint32_t)(c * 4);
+                        const uint32_t lo = (uint32_t)a16[c], hi = (uint32_t)(a16[c] >> 32);
+                        uint32_t k0, k1, k2, k3;
+                        asm("v_mad_u32_u16 %0, %1, 32, %2" : "=v"(k0) : "v"(lo), "v"(kx[0]));
+                        asm("v_mad_u32_u16 %0, %1, 32, %2 op_sel:[1,0,0,0]" : "=v"(k1) : "v"(lo), "v"(kx[1]));
+                        asm("v_mad_u32_u16 %0, %1, 32, %2" : "=v"(k2) : "v"(hi), "v"(kx[2]));
+                        asm("v_mad_u32_u16 %0, %1, 32, %2 op_sel:[1,0,0,0]" : "=v"(k3) : "v"(hi), "v"(kx[3]));
+                        uint32_t m = k0 < k1 ? k0 : k1;
+                        m = k2 < m ? k2 : m;
+                        m = k3 < m ? k3 : m;
+                        m += ky;
+                        best = m < best ? m : best;
+                    }
+                }
+                else
+                {
+                if (packed)
+#pragma unroll
+                    for (int c = 0; c < ESA_R; c++)
+                    {
+                        const uint32_t lo = (uint32_t)a16[c], hi = (uint32_t)(a16[c] >> 32);
+                        tot[c][0] = lo & 0xffff; tot[c][1] = lo >> 16; tot[c][2] = hi & 0xffff; tot[c][3] = hi >> 16;
+                    }
                 if (nowrap)
                 {
                     /* No two entries of this QP's table add up to 2^16 (the host checked), so the
@@ -354,11 +352,63 @@ __global__ __launch_bounds__(ESA_THREADS) __attribute__((amdgpu_waves_per_eu(4))
                         best = key < best ? key : best;
                     }
                 }
+                }
                 const uint32_t cost = best >> 5, ci = best & 31;
                 const uint32_t idx = (uint32_t)((ys0 + yg) * ESA_R + (ci >> 2)) * (uint32_t)nx + (uint32_t)((xs0 + xg) * 4 + (ci & 3));
                 if (live && cost < ESA_SENTINEL && (cost < bc || (cost == bc && idx < bi))) { bc = cost; bi = idx; }
             }
         }
+}
+
+/* SZ: 8 or 16 when the launch is one of 8x8 or 16x16 PUs (PUs of other sizes still go through, by the general
+ * code); each size gets a kernel of its own so that its registers are allocated for its own unrolled patch. */
+template<typename P, int SZ>
+__global__ __launch_bounds__(ESA_THREADS) __attribute__((amdgpu_waves_per_eu(4))) void esa_scan_kernel(SearchArgs a, int win_budget, int nowrap)
+{
+    static_assert(sizeof(P) == 1, "the packed quad-SAD path is for 8-bit samples");
+    const int j = xcd_remap(blockIdx.x, a.njobs);
+    if (j >= a.njobs) return;
+    const x265amd_job *job = a.jobs + j;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+#ifdef X265AMD_TRACE
+    /* debug builds only: per-wave start / end time (100 MHz counter) and placement, in a side
+     * buffer behind the result records */
+    unsigned long long *trace = (unsigned long long*)(a.results + a.njobs) + ((size_t)blockIdx.x * (ESA_THREADS / 64) + wave) * 4;
+    if (lane == 0)
+    {
+        trace[0] = wall_clock64();
+        trace[2] = ((unsigned long long)__builtin_amdgcn_s_getreg(63508) << 32) | (unsigned)__builtin_amdgcn_s_getreg(63492);
+    }
+#endif
+    JobRegs J;
+    J.load(job);
+    const int w = uni(job->w), h = uni(job->h);
+    EsaGeo g;
+    if (!esa_job_ok(J, w, h, a.max_dim, win_budget, g))
+    {
+        if (tid == 0) { a.results[j].cost = -1; a.results[j].sad_calls = 0; }
+        return;
+    }
+    PlaneDev pfenc, pref[4];
+    job_planes(a, job, pfenc, pref);
+    g.off_cx = esa_fixed_lds(a.max_dim);
+    g.off_cy = g.off_cx + 16 * g.xgs;
+    g.off_win = g.off_cy + 4 * ESA_R * g.ygs;
+
+    {
+        /* source block into LDS, pitch 64 (setSourcePU, motion.cpp:116-142) */
+        const char AS1 *src = (const char AS1*)pfenc.origin + (long)J.puy * pfenc.stride + J.pux;
+        const int wd = w >> 2;
+        for (int i = tid; i < wd * h; i += ESA_THREADS)
+        {
+            const int y = i / wd, x = i - y * wd;
+            typedef uint32_t __attribute__((aligned(1))) u32u;
+            *(uint32_t*)(x265amd_smem + ESA_L_FENC + y * 64 + 4 * x) = *(const u32u AS1*)(src + (long)y * pfenc.stride + 4 * x);
+        }
+    }
+    uint32_t bc = 0xffffffffu, bi = 0xffffffffu;   /* this lane's best (cost, raster index) */
+    if (SZ && w == SZ && h == SZ) esa_scan_pu<P, SZ, SZ>(a, J, g, pref, w, h, nowrap, tid, wave, lane, bc, bi);
+    else esa_scan_pu<P, 0, 0>(a, J, g, pref, w, h, nowrap, tid, wave, lane, bc, bi);
     for (int o = 1; o < 64; o <<= 1)
     {
         const uint32_t oc = __shfl_xor(bc, o), oi = __shfl_xor(bi, o);
@@ -383,7 +433,7 @@ __global__ __launch_bounds__(ESA_THREADS) __attribute__((amdgpu_waves_per_eu(4))
 
 /* The stages around the scan, one wave per PU: the start-up candidates (motion.cpp:562-621, which
  * do not depend on the scan), the scan's winner folded in with the reference's strict '<', then
- * the sub-pel refinement. */
+ * the sub-pel refinement (or, in launches of 8x8 / 16x16 PUs, the hand-over to refine_small_kernel). */
 template<typename P>
 __global__ __launch_bounds__(64) void esa_finish_kernel(SearchArgs a, int win_budget)
 {
@@ -416,7 +466,18 @@ __global__ __launch_bounds__(64) void esa_finish_kernel(SearchArgs a, int win_bu
         st.bcost = (int)bc; st.bmy = J.mny + by; st.bmx = J.mnx + (int)(bi - (uint32_t)by * (uint32_t)g.nx);
     }
     S.nsad += (unsigned)(g.nx * g.ny);
-    S.finish(a.subme, st, a.results + j);
+    if (a.staged && w == a.staged && h == a.staged)
+    {
+        /* the sub-pel refinement of these PUs runs in refine_small_kernel: leave it the choice of motion.cpp:1063-1069 */
+        int qx, qy, bcost;
+        S.choose(st, qx, qy, bcost);
+        if (threadIdx.x == 0)
+        {
+            x265amd_result r = { { (int16_t)qx, (int16_t)qy }, bcost, S.nsad, S.nsub };
+            a.results[j] = r;
+        }
+    }
+    else S.finish(a.subme, st, a.results + j);
 }
 
 } // namespace x265amd

@@ -235,7 +235,7 @@ __global__ __launch_bounds__(64) void refine_small_kernel(SearchArgs a)
     R.qx = as_i16(r0); R.qy = r0 >> 16; R.bcost = res[1]; R.nsub = (unsigned)res[3];
     R.mvpx = as_i16(d4); R.mvpy = d4 >> 16;
     /* a PU whose full-pel cost is 0 is not refined (motion.cpp:1073-1076); PUs of other sizes are final already */
-    R.active = valid && (d1 & 0xffff) == G::SIZE_CODE && R.bcost != 0;
+    R.active = valid && (d1 & 0xffff) == G::SIZE_CODE && R.bcost > 0;      /* a negative cost marks a job that was refused */
     if (__ballot(R.active) == 0) return;
     const uint8_t AS1 *fenc0;
     int fstride;
