@@ -573,6 +573,10 @@ def main():
                 bp = measure.bipred_picture(es, dev)
                 e10 = Engine(local_rank, 10)
                 m10 = measure.pattern_search_picture(e10, dev)
+                rows10, _ = measure.esa_per_size(e10, dev)
+                ms10 = sum(r["ms"] for r in rows10)
+                px10 = sum(r["pixel_sads"] for r in rows10)
+                rk10 = measure.rk_picture(e10, dev, qp=42)
                 e10.close()
                 out["other_paths"] = {
                     "main10_4k": {"workload": "3840x2160 10-bit, --me star --merange 57 --subme 5, all 64/32/16/8 square PUs of one "
@@ -588,6 +592,12 @@ def main():
                                "bound": "valu", "peak": measure.SAD_ISSUE_PEAK / 1e9,
                                "frac": px / (ms * 1e-3) / measure.SAD_ISSUE_PEAK,
                                "per_pu_size_ms": {str(r["size"]): r["ms"] for r in rows}},
+                    "esa_4k_main10": {"workload": "the same exhaustive search on 10-bit samples (v_sad_u16: two samples per lane "
+                                                  "and instruction, half the byte-SAD peak)",
+                                      "ms_per_picture_reference": ms10, "value": px10 / ms10 / 1e6, "unit": "Gpixel-SAD/s",
+                                      "bound": "valu", "peak": measure.SAD_ISSUE_PEAK / 2e9,
+                                      "frac": px10 / (ms10 * 1e-3) / (measure.SAD_ISSUE_PEAK / 2),
+                                      "per_pu_size_ms": {str(r["size"]): r["ms"] for r in rows10}},
                     "mc_4k": {"workload": "3840x2160 8-bit TComPrediction::motionCompensation of every PU of a picture (mixed quadtree "
                                           "partitioning, luma + 4:2:0 chroma, random quarter-pel MVs), device-resident job list",
                               "bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -602,7 +612,10 @@ def main():
                     "rk_1080p": {"workload": "1920x1080 8-bit, Rockchip rd>=5 path: CIME + RIME + FME of all 510 CTUs (85 CUs each) "
                                              "against one reference, default RK range",
                                  "ms_per_picture_reference": rk["ms"], "ctus_per_s": rk["ctus"] / (rk["ms"] * 1e-3),
-                                 "value": rk["pixel_sads"] / rk["ms"] / 1e6, "unit": "Gpixel-SAD/s"}}
+                                 "value": rk["pixel_sads"] / rk["ms"] / 1e6, "unit": "Gpixel-SAD/s"},
+                    "rk_1080p_main10": {"workload": "the same on 10-bit samples", "ms_per_picture_reference": rk10["ms"],
+                                        "ctus_per_s": rk10["ctus"] / (rk10["ms"] * 1e-3),
+                                        "value": rk10["pixel_sads"] / rk10["ms"] / 1e6, "unit": "Gpixel-SAD/s"}}
             except Exception as ex:   # the headline line must survive a failure here
                 out["other_paths"] = {"error": repr(ex)}
         print(json.dumps(out))

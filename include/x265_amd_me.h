@@ -145,9 +145,10 @@ int x265amd_search_batch_pairs(x265amd_ctx *ctx, const x265amd_pair *pairs, int 
 int x265amd_search_batch_pairs_dev(x265amd_ctx *ctx, const void *d_pairs, int npairs, int qp, int method, int subme,
                                    const x265amd_job *d_jobs, int njobs, x265amd_result *d_results, int max_pu_dim);
 
-/* X265_FULL_SEARCH (encoder/motion.cpp:1021-1056) on 8-bit planes scans each PU's search range
- * from a copy of the reference window in LDS; ranges too large for the window are scanned in
- * strips. `bytes` (8192 .. 131072, default 65536) is the LDS one PU may use for that copy when
+/* X265_FULL_SEARCH (encoder/motion.cpp:1021-1056) scans each PU's search range from a copy of
+ * the reference window in LDS; ranges too large for the window are scanned in strips. `bytes`
+ * (8192 .. 131072 with 8-bit samples, 16384 .. 131072 with deeper ones; unset, the library takes 36864, or 49152 / 65536
+ * for launches of 16-bit PUs up to 32x32 / 64x64) is the LDS one PU may use for that copy when
  * the jobs are device-resident (x265amd_search_batch sizes it from the jobs it is given, up to
  * this limit): smaller windows keep more PUs resident per compute unit. Tuning only; results do
  * not depend on it. */
@@ -493,7 +494,9 @@ typedef struct
 int x265amd_rk_ds_plane(x265amd_ctx *ctx, const x265amd_plane *orig, x265amd_plane *out);
 
 /* fenc: source picture; recon: reconstructed reference (fpelPlane); ds: x265amd_rk_ds_plane
- * of the reference's original picture (fpelPlaneOrigDS). ctus / results are HOST arrays. */
+ * of the reference's original picture (fpelPlaneOrigDS). ctus / results are HOST arrays.
+ * Contexts of more than 10 bits per sample are refused (X265AMD_EINVAL): the 4x4 sums and the
+ * 8x8 block SADs of this path are 16-bit quantities, as the reference's `short` buffers are. */
 int x265amd_rk_ctu_batch(x265amd_ctx *ctx, const x265amd_plane *fenc, const x265amd_plane *recon,
                          const x265amd_plane *ds, int qp, const x265amd_rk_ctu *ctus, int nctus,
                          x265amd_rk_result *results);

@@ -94,18 +94,40 @@ def test_rk_golden(engine8):
         assert np.array_equal(got[k]["mv"], g[k + "_mv"]) and np.array_equal(got[k]["cost"], g[k + "_cost"])
 
 
-def test_rk_10bit_vs_oracle(engine10, oracle):
-    """The RK overload compiles for 16-bit pixels (HIGH_BIT_DEPTH ME-only build); same arithmetic."""
-    W, H = 192, 128
-    cur, rorig, recon, org, stride, jobs = rk_case(10, W, H, 9)
-    pc = engine10.upload_plane(cur, W, H, M, M, stride)
-    po = engine10.upload_plane(rorig, W, H, M, M, stride)
-    pr = engine10.upload_plane(recon, W, H, M, M, stride)
-    pds = engine10.rk_ds_plane(po)
-    ds, dorg, dstride = oracle.rk_downsample(10, rorig, org, W, H, stride, M // 4)
-    ctx = oracle.make_ctx(10, cur, org, stride, [recon], org, stride, False, 36, 0, 0)
+@pytest.mark.parametrize("case", [(10, 192, 128, "clip"), (10, 204, 140, "clip"), (10, 416, 240, "clip"), (10, 128, 128, "extreme")])
+def test_rk_10bit_vs_oracle(engine10, oracle, case):
+    """The RK overload compiles for 16-bit pixels (HIGH_BIT_DEPTH ME-only build); same arithmetic. RIME runs for the
+    whole CTU from 16-bit block surfaces (partial CTUs included); "extreme" is a black picture against a white
+    reference, where every 8x8 SAD is 64 * 1023, the largest value such a surface entry can take, and every position
+    ties. Deeper samples are refused."""
+    from x265_amd.engine import Engine, EngineError
+    depth, W, H, kind = case
+    e = engine10
+    cur, rorig, recon, org, stride, jobs = rk_case(depth, W, H, 9)
+    if kind == "extreme":
+        cur = np.zeros_like(cur)
+        recon = np.full_like(recon, 1023)
+    pc = e.upload_plane(cur, W, H, M, M, stride)
+    po = e.upload_plane(rorig, W, H, M, M, stride)
+    pr = e.upload_plane(recon, W, H, M, M, stride)
+    pds = e.rk_ds_plane(po)
+    qp = 36 + 6 * (depth - 10)
+    ds, dorg, dstride = oracle.rk_downsample(depth, rorig, org, W, H, stride, M // 4)
+    ctx = oracle.make_ctx(depth, cur, org, stride, [recon], org, stride, False, qp, 0, 0)
     exp = oracle.rk_ctu_batch(ctx, ds, dorg, dstride, W, H, jobs)
-    assert same(engine10.rk_ctu_batch(pc, pr, pds, 36, jobs), exp)
+    got = e.rk_ctu_batch(pc, pr, pds, qp, jobs)
+    assert same(got, exp)
+    if kind == "extreme":
+        assert (got["rime"]["cost"][:, :64] >= 64 * 1023).all()
+    for p in (pc, po, pr, pds):
+        e.free_plane(p)
+    if kind == "extreme":
+        e12 = Engine(0, 12)
+        planes = [e12.upload_plane(b, W, H, M, M, stride) for b in (cur, recon)]
+        pds12 = e12.rk_ds_plane(planes[1])
+        with pytest.raises(EngineError):
+            e12.rk_ctu_batch(planes[0], planes[1], pds12, 40, jobs)
+        e12.close()
 
 
 def test_rk_argument_errors(engine8):

@@ -263,13 +263,19 @@ def test_full_size_properties(engine8):
     assert (r["sad_calls"] == 81).all()   # the 9x9 raster; the zero predictor itself is measured through subpelCompare
 
 
-def test_exhaustive_search_windows(engine8, oracle):
-    """X265_FULL_SEARCH through the LDS-window kernel: ranges that are not multiples of the lane patch
-    (4 columns x 8 rows), asymmetric and clipped ranges, every partition height class, and the same
-    jobs again with the smallest window budget so that the range is scanned in several x / y strips."""
+@pytest.mark.parametrize("depth,kind", [(8, "texture"), (8, "static"), (10, "texture"), (10, "static"), (12, "noise")])
+def test_exhaustive_search_windows(engine8, engine10, oracle, depth, kind):
+    """X265_FULL_SEARCH through the LDS-window kernels (8-bit: packed quad-SAD, 4 columns x 8 rows per lane; deeper
+    samples: v_sad_u16, 2 columns x 8 rows): ranges that are not multiples of the lane patch, asymmetric and clipped
+    ranges, every partition height class, and the same jobs again with the smallest window budget so that the range is
+    scanned in several x / y strips. A static clip makes every position of a range cost the same SAD, so the winner is
+    decided by the table costs and the raster order alone; 12-bit noise gives the largest sums."""
+    from x265_amd.engine import Engine
     W, H = 256, 160
     m = 110
-    fenc, ref, org, stride = clip_planes(W, H, 8, "texture", seed=21, margin=m)
+    fenc, ref, org, stride = clip_planes(W, H, depth, kind, seed=21, margin=m)
+    own = Engine(0, depth) if depth == 12 else None
+    engine8 = {8: engine8, 10: engine10, 12: own}[depth]      # the engine of this depth
     pf = engine8.upload_plane(fenc, W, H, m, m, stride)
     pr = engine8.upload_plane(ref, W, H, m, m, stride)
     rng = np.random.default_rng(77)
@@ -288,14 +294,16 @@ def test_exhaustive_search_windows(engine8, oracle):
         j["mvc"][0] = (int(rng.integers(-60, 61)), int(rng.integers(-60, 61)))
         j["mvc"][1] = (0, 4)
         j["merange"] = 45
-    mv, cost, sc, qc = oracle_search(oracle, 8, fenc, [ref], org, stride, jobs, 27, METHODS["full"], 5)
-    for budget in (65536, 8192):
+    mv, cost, sc, qc = oracle_search(oracle, depth, fenc, [ref], org, stride, jobs, 27, METHODS["full"], 5)
+    for budget in (65536, 8192 if depth == 8 else 16384):
         engine8.set_esa_window_bytes(budget)
         r = engine8.search_batch(pf, pr, jobs, 27, METHODS["full"], 5)
         assert np.array_equal(r["mv"], mv) and np.array_equal(r["cost"], cost), budget
         assert np.array_equal(r["sad_calls"], sc) and np.array_equal(r["subpel_calls"], qc), budget
-    engine8.set_esa_window_bytes(65536)
+    engine8.set_esa_window_bytes(36864)      # what the library takes for most launches when none is set
     with pytest.raises(EngineError):
         engine8.set_esa_window_bytes(100)
     engine8.free_plane(pf)
     engine8.free_plane(pr)
+    if own:
+        own.close()

@@ -23,6 +23,7 @@ def main():
     ap.add_argument("--merange", type=int, default=92)
     ap.add_argument("--sizes", default="64,32,16,8")
     ap.add_argument("--subme", type=int, default=5)
+    ap.add_argument("--depth", type=int, default=8, help="bits per sample; above 8 the peak is v_sad_u16's, half the byte-SAD one")
     ap.add_argument("--reps", type=int, default=3)
     ap.add_argument("--window", type=int, default=0, help="LDS window bytes (0 = library default)")
     ap.add_argument("--check", type=int, default=0, help="PUs per size to compare with the CPU oracle")
@@ -37,7 +38,8 @@ def main():
     from x265_amd import measure
 
     dev = torch.device("cuda", 0)
-    e = Engine(0, 8)
+    e = Engine(0, args.depth)
+    peak = measure.SAD_ISSUE_PEAK if args.depth <= 8 else measure.SAD_ISSUE_PEAK / 2
     if args.window:
         e.set_esa_window_bytes(args.window)
     rows, (cur, ref, org, stride) = measure.esa_per_size(e, dev, args.width, args.height, args.merange,
@@ -48,20 +50,20 @@ def main():
         total_ms += r["ms"]
         line = "%2dx%-2d  %6d PUs  %8.3f ms  %7.2f T pixel-SAD/s  %5.1f %% of SAD issue peak" % (
             r["size"], r["size"], r["pus"], r["ms"], r["pixel_sads"] / r["ms"] / 1e9,
-            100.0 * r["pixel_sads"] / (r["ms"] * 1e-3) / measure.SAD_ISSUE_PEAK)
+            100.0 * r["pixel_sads"] / (r["ms"] * 1e-3) / peak)
         if args.check:
             from oracle.bindings import Oracle   # checker only
             sys.path.insert(0, os.path.join(ROOT, "tests"))
             from util import oracle_search
             pick = np.linspace(0, r["pus"] - 1, args.check).astype(int)
-            mv, cost, sc, qc = oracle_search(Oracle(), 8, cur, [ref], org, stride, r["jobs"][pick], 32, METHODS["full"], args.subme)
+            mv, cost, sc, qc = oracle_search(Oracle(), args.depth, cur, [ref], org, stride, r["jobs"][pick], 32, METHODS["full"], args.subme)
             res = r["results"]
             ok = (np.array_equal(res["mv"][pick], mv) and np.array_equal(res["cost"][pick], cost)
                   and np.array_equal(res["sad_calls"][pick], sc))
             line += "  oracle %s" % ("OK" if ok else "MISMATCH")
         print(line, flush=True)
     print("all     %8.3f ms  %7.2f T pixel-SAD/s  %5.1f %% of SAD issue peak" % (
-        total_ms, total_px / total_ms / 1e9, 100.0 * total_px / (total_ms * 1e-3) / measure.SAD_ISSUE_PEAK))
+        total_ms, total_px / total_ms / 1e9, 100.0 * total_px / (total_ms * 1e-3) / peak))
 
 
 if __name__ == "__main__":

@@ -23,14 +23,15 @@ def main():
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--reps", type=int, default=5)
     ap.add_argument("--check", type=int, default=0, help="CTUs to compare with the CPU oracle")
+    ap.add_argument("--depth", type=int, default=8, help="bits per sample (8 or 10)")
     args = ap.parse_args()
 
     import torch
     from x265_amd.engine import Engine
     from x265_amd import measure
 
-    e = Engine(0, 8)
-    m = measure.rk_picture(e, torch.device("cuda", 0), args.width, args.height, args.reps)
+    e = Engine(0, args.depth)
+    m = measure.rk_picture(e, torch.device("cuda", 0), args.width, args.height, args.reps, qp=30 + 6 * (args.depth - 8))
     line = "%dx%d  %d CTUs  %.3f ms per picture-reference  %.1f kCTU/s  %.2f T pixel-SAD/s (CIME %.2f G, RIME+FME %.2f G per picture)" % (
         args.width, args.height, m["ctus"], m["ms"], m["ctus"] / m["ms"], m["pixel_sads"] / m["ms"] / 1e9,
         m["cime_pixel_sads"] / 1e9, m["cu_pixel_sads"] / 1e9)
@@ -38,8 +39,8 @@ def main():
         from oracle.bindings import Oracle   # checker only
         orc = Oracle()
         cur, rorig, recon, org, stride = m["planes"]
-        ds, dorg, dstride = orc.rk_downsample(8, rorig, org, args.width, args.height, stride, m["margin"] // 4)
-        ctx = orc.make_ctx(8, cur, org, stride, [recon], org, stride, False, m["qp"], 0, 0)
+        ds, dorg, dstride = orc.rk_downsample(args.depth, rorig, org, args.width, args.height, stride, m["margin"] // 4)
+        ctx = orc.make_ctx(args.depth, cur, org, stride, [recon], org, stride, False, m["qp"], 0, 0)
         pick = np.linspace(0, m["ctus"] - 1, args.check).astype(int)
         t0 = time.perf_counter()
         exp = orc.rk_ctu_batch(ctx, ds, dorg, dstride, args.width, args.height, m["jobs"][pick])

@@ -808,7 +808,7 @@ struct x265amd_ctx
     void *d_redo; size_t redo_cap;     /* list of the PUs a fixed-shape kernel left to the one-wave search (redo_list_kernel) */
     int32_t *d_out;
     int *d_ticket;                     /* row hand-out counter of the row-parallel lookahead kernel */
-    int esa_window_bytes;              /* LDS the exhaustive search may use per PU for its window */
+    int esa_window_bytes;              /* LDS the exhaustive search may use per PU for its window; 0 = the library's choice */
     unsigned char *scratch;            /* this device's copy of the static scratch array (x265amd_lookahead_fields_static) */
     bool esa_lds_raised, rime_lds_raised; /* dynamic-LDS limits raised on this context's device (the attribute is per device) */
     std::map<const void*, void*> plane_base; /* plane origin -> start of its allocation, whatever the sample size */
@@ -850,32 +850,34 @@ static int ensure(x265amd_ctx *c, void **p, size_t *cap, size_t need)
     return 0;
 }
 
-/* X265_FULL_SEARCH on 8-bit planes: workgroup-per-PU scan through an LDS window, then the
- * one-wave stages around it */
+/* X265_FULL_SEARCH: workgroup-per-PU scan through an LDS window, then the one-wave stages around it */
+template<typename P>
 static int launch_esa(x265amd_ctx *c, const SearchArgs &a, int window_bytes, int nowrap)
 {
+    constexpr int BPS = (int)sizeof(P);
     if (!c->esa_lds_raised)
     {
-        HIPCHK(c, hipFuncSetAttribute((const void*)esa_scan_kernel<uint8_t, 0>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                      esa_fixed_lds(64) + ESA_WINDOW_MAX));
-        HIPCHK(c, hipFuncSetAttribute((const void*)esa_scan_kernel<uint8_t, 8>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                      esa_fixed_lds(64) + ESA_WINDOW_MAX));
-        HIPCHK(c, hipFuncSetAttribute((const void*)esa_scan_kernel<uint8_t, 16>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                      esa_fixed_lds(64) + ESA_WINDOW_MAX));
+        const int most = esa_fixed_lds(64, 2) + ESA_WINDOW_MAX;
+        HIPCHK(c, hipFuncSetAttribute((const void*)esa_scan_kernel<uint8_t, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, most));
+        HIPCHK(c, hipFuncSetAttribute((const void*)esa_scan_kernel<uint8_t, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, most));
+        HIPCHK(c, hipFuncSetAttribute((const void*)esa_scan_kernel<uint8_t, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, most));
+        HIPCHK(c, hipFuncSetAttribute((const void*)esa_scan_kernel<uint16_t, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, most));
+        HIPCHK(c, hipFuncSetAttribute((const void*)esa_scan_kernel<uint16_t, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, most));
+        HIPCHK(c, hipFuncSetAttribute((const void*)esa_scan_kernel<uint16_t, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, most));
         c->esa_lds_raised = true;
     }
-    /* launches of PUs up to 8x8 or up to 16x16: the square PUs of that size are refined by refine_small_kernel */
+    /* launches of 8-bit PUs up to 8x8 or up to 16x16: the square PUs of that size are refined by refine_small_kernel */
     static const bool no_staged = getenv("X265AMD_NO_STAGED") != 0;      /* measurements only */
     SearchArgs b = a;
-    b.staged = (a.max_dim == 8 || a.max_dim == 16) && !no_staged ? a.max_dim : 0;
-    const size_t scan_lds = esa_fixed_lds(a.max_dim) + window_bytes;
+    b.staged = BPS == 1 && (a.max_dim == 8 || a.max_dim == 16) && !no_staged ? a.max_dim : 0;
+    const size_t scan_lds = esa_fixed_lds(a.max_dim, BPS) + window_bytes;
     if (a.max_dim == 8)
-        hipLaunchKernelGGL((esa_scan_kernel<uint8_t, 8>), dim3(a.njobs), dim3(ESA_THREADS), scan_lds, c->stream, b, window_bytes, nowrap);
+        hipLaunchKernelGGL((esa_scan_kernel<P, 8>), dim3(a.njobs), dim3(ESA_THREADS), scan_lds, c->stream, b, window_bytes, nowrap);
     else if (a.max_dim == 16)
-        hipLaunchKernelGGL((esa_scan_kernel<uint8_t, 16>), dim3(a.njobs), dim3(ESA_THREADS), scan_lds, c->stream, b, window_bytes, nowrap);
+        hipLaunchKernelGGL((esa_scan_kernel<P, 16>), dim3(a.njobs), dim3(ESA_THREADS), scan_lds, c->stream, b, window_bytes, nowrap);
     else
-        hipLaunchKernelGGL((esa_scan_kernel<uint8_t, 0>), dim3(a.njobs), dim3(ESA_THREADS), scan_lds, c->stream, b, window_bytes, nowrap);
-    hipLaunchKernelGGL(esa_finish_kernel<uint8_t>, dim3(a.njobs), dim3(64), wave_lds_bytes<uint8_t>(a.max_dim, true),
+        hipLaunchKernelGGL((esa_scan_kernel<P, 0>), dim3(a.njobs), dim3(ESA_THREADS), scan_lds, c->stream, b, window_bytes, nowrap);
+    hipLaunchKernelGGL(esa_finish_kernel<P>, dim3(a.njobs), dim3(64), wave_lds_bytes<P>(a.max_dim, true),
                        c->stream, b, window_bytes);
     if (b.staged == 8)
         hipLaunchKernelGGL(refine_small_kernel<8>, dim3((a.njobs + 3) / 4), dim3(64), RefineLds<8>::TOTAL, c->stream, b);
@@ -1006,7 +1008,7 @@ static int create_ctx(int device, int bit_depth, int high_priority, x265amd_ctx 
     c->device = device; c->depth = bit_depth;
     c->d_jobs = c->d_results = c->d_stage = c->d_redo = 0; c->d_ticket = 0;
     c->jobs_cap = c->results_cap = c->stage_cap = c->redo_cap = 0; c->d_out = 0;
-    c->esa_window_bytes = ESA_WINDOW_DEFAULT;
+    c->esa_window_bytes = 0;
     c->esa_lds_raised = c->rime_lds_raised = false;
     int prio_least = 0, prio_greatest = 0;
     if (hipSetDevice(device) != hipSuccess || hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest) != hipSuccess ||
@@ -1261,9 +1263,21 @@ static void fill_args(x265amd_ctx *c, SearchArgs &a, const x265amd_plane *fenc, 
     a.ctab = c->tables[qp] + 32768;
 }
 
+/* The window a launch gets when the caller set none: 36 KB keeps four workgroups on a compute unit, which is what
+ * the 8-bit scans and the small 16-bit PUs want; the rows of a large 16-bit PU are so long that fewer, larger strips
+ * win (measured on 4K, merange 92). */
+static int esa_window_for(const x265amd_ctx *c, int max_dim)
+{
+    if (c->esa_window_bytes) return c->esa_window_bytes;
+    if (c->depth <= 8) return ESA_WINDOW_DEFAULT;
+    return max_dim > 32 ? 65536 : max_dim > 16 ? 49152 : ESA_WINDOW_DEFAULT;
+}
+
 int x265amd_set_esa_window_bytes(x265amd_ctx *c, int bytes)
 {
-    if (!c || bytes < ESA_WINDOW_MIN || bytes > ESA_WINDOW_MAX) return fail(c, X265AMD_EINVAL, "window bytes out of range");
+    /* the smallest window still holds one lane patch of a 64x64 PU: 71 rows of 72 bytes (8-bit), of 136 bytes (16-bit) */
+    if (!c || bytes < (c->depth <= 8 ? ESA_WINDOW_MIN : 2 * ESA_WINDOW_MIN) || bytes > ESA_WINDOW_MAX)
+        return fail(c, X265AMD_EINVAL, "window bytes out of range");
     c->esa_window_bytes = bytes & ~15;
     return X265AMD_OK;
 }
@@ -1289,7 +1303,9 @@ static int search_dev(x265amd_ctx *c, const x265amd_plane *fenc, const x265amd_p
     a.pairs = d_pairs; a.npairs = npairs;
     a.jobs = d_jobs; a.results = d_results; a.njobs = njobs;
     if (!is_lowres) a.max_dim = max_pu_dim;
-    if (method == X265AMD_FULL && !is_lowres && c->depth <= 8) return launch_esa(c, a, esa_window, c->table_nowrap[qp]);
+    if (method == X265AMD_FULL && !is_lowres)
+        return c->depth <= 8 ? launch_esa<uint8_t>(c, a, esa_window, c->table_nowrap[qp])
+                             : launch_esa<uint16_t>(c, a, esa_window, c->table_nowrap[qp]);
     return c->depth <= 8 ? launch_search<uint8_t>(c, a, is_lowres) : launch_search<uint16_t>(c, a, is_lowres);
 }
 
@@ -1298,7 +1314,7 @@ int x265amd_search_batch_dev(x265amd_ctx *c, const x265amd_plane *fenc, const x2
                              int max_pu_dim)
 {
     return search_dev(c, fenc, ref, is_lowres, qp, method, subme, d_jobs, njobs, d_results, max_pu_dim,
-                      c ? c->esa_window_bytes : 0);
+                      c ? esa_window_for(c, max_pu_dim > 0 ? max_pu_dim : 64) : 0);
 }
 
 /* ---- searches over several (source, reference) pairs in one launch ---- */
@@ -1332,7 +1348,7 @@ int x265amd_search_batch_pairs_dev(x265amd_ctx *c, const void *d_pairs, int npai
                                    const x265amd_job *d_jobs, int njobs, x265amd_result *d_results, int max_pu_dim)
 {
     if (!c || !d_pairs || npairs <= 0 || npairs > 256) return fail(c, X265AMD_EINVAL, "1 .. 256 pairs");
-    return search_dev(c, 0, 0, 0, qp, method, subme, d_jobs, njobs, d_results, max_pu_dim, c->esa_window_bytes,
+    return search_dev(c, 0, 0, 0, qp, method, subme, d_jobs, njobs, d_results, max_pu_dim, esa_window_for(c, max_pu_dim > 0 ? max_pu_dim : 64),
                       (const PairDev*)d_pairs, npairs);
 }
 
@@ -1362,7 +1378,7 @@ int x265amd_search_batch_pairs(x265amd_ctx *c, const x265amd_pair *pairs, int np
         while (dim < d) dim <<= 1;
     }
     rc = search_dev(c, 0, 0, 0, qp, method, subme, (const x265amd_job*)c->d_jobs, njobs, (x265amd_result*)c->d_results, dim,
-                    c->esa_window_bytes, (const PairDev*)((char*)c->d_jobs + jb), npairs);
+                    esa_window_for(c, dim), (const PairDev*)((char*)c->d_jobs + jb), npairs);
     if (rc) return rc;
     HIPCHK(c, hipMemcpyAsync(results, c->d_results, (size_t)njobs * sizeof(x265amd_result), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -1396,14 +1412,15 @@ int x265amd_search_batch(x265amd_ctx *c, const x265amd_plane *fenc, const x265am
         while (dim < d) dim <<= 1;
     }
     /* exhaustive search: no more window LDS than the largest range of the batch needs */
-    int window = ESA_WINDOW_MIN;
+    int window = c->depth <= 8 ? ESA_WINDOW_MIN : 2 * ESA_WINDOW_MIN;
     if (method == X265AMD_FULL)
         for (int i = 0; i < njobs; i++)
         {
-            const int nxg = (jobs[i].mvmax[0] - jobs[i].mvmin[0] + 4) >> 2;
+            const int cx = c->depth <= 8 ? 4 : 2, bps = c->depth <= 8 ? 1 : 2;
+            const int nxg = (jobs[i].mvmax[0] - jobs[i].mvmin[0] + cx) / cx;
             const int nyg = (jobs[i].mvmax[1] - jobs[i].mvmin[1] + ESA_R) / ESA_R;
-            const long need = (long)16 * nxg + (long)esa_pitch(nxg, jobs[i].w) * (nyg * ESA_R + jobs[i].h - 1) + 4 * ESA_R * nyg;
-            if (need > window) window = need > c->esa_window_bytes ? c->esa_window_bytes : (int)((need + 15) & ~15);
+            const long need = esa_strip_bytes(nxg, nyg, jobs[i].w, jobs[i].h, cx, bps);
+            if (need > window) window = need > esa_window_for(c, dim) ? esa_window_for(c, dim) : (int)((need + 15) & ~15);
         }
     rc = search_dev(c, fenc, ref, is_lowres, qp, method, subme, (const x265amd_job*)c->d_jobs, njobs,
                     (x265amd_result*)c->d_results, dim, window);
@@ -2373,6 +2390,9 @@ int x265amd_rk_ctu_batch_dev(x265amd_ctx *c, const x265amd_plane *fenc, const x2
                              int qp, const x265amd_rk_ctu *d_ctus, int nctus, x265amd_rk_result *d_results)
 {
     if (!c || !fenc || !recon || !ds || !d_ctus || !d_results || nctus < 0) return fail(c, X265AMD_EINVAL, "null argument");
+    /* the 4x4 sums of the coarse stage are int16 and the block surfaces of the refinement 16 bits wide, as the
+     * reference's `short` buffers are: 16 * 1023 and 64 * 1023 fit, the sums of deeper samples do not */
+    if (c->depth > 10) return fail(c, X265AMD_EINVAL, "the Rockchip path takes samples of up to 10 bits");
     int rc = x265amd_set_qp(c, qp);
     if (rc) return rc;
     if (!nctus) return X265AMD_OK;
@@ -2399,8 +2419,15 @@ int x265amd_rk_ctu_batch_dev(x265amd_ctx *c, const x265amd_plane *fenc, const x2
     }
     else
     {
+        /* RIME of the whole CTU from 8x8 block surfaces, as with 8-bit samples */
+        if (!c->rime_lds_raised)
+        {
+            HIPCHK(c, hipFuncSetAttribute((const void*)rk_rime16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, R16_TOTAL));
+            c->rime_lds_raised = true;
+        }
         hipLaunchKernelGGL(rk_cime_kernel<uint16_t>, dim3(nctus), dim3(CIME_THREADS), lds, c->stream, a);
-        hipLaunchKernelGGL((rk_cu_kernel<uint16_t, false>), dim3(nctus * 85), dim3(64), wave_lds_bytes<uint16_t>(64) + rk_region_bytes<uint16_t>(64), c->stream, a);
+        hipLaunchKernelGGL(rk_rime16_kernel, dim3(nctus), dim3(RIME_THREADS), R16_TOTAL, c->stream, a);
+        hipLaunchKernelGGL((rk_cu_kernel<uint16_t, true>), dim3(nctus * 85), dim3(64), L_FENC + rk_region_bytes<uint16_t>(64), c->stream, a);
     }
     HIPCHK(c, hipGetLastError());
     return X265AMD_OK;

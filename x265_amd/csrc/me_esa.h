@@ -1,5 +1,5 @@
 /* Exhaustive integer search (X265_FULL_SEARCH, source/encoder/motion.cpp:1021-1056) as a
- * workgroup-per-PU kernel for 8-bit planes.
+ * workgroup-per-PU kernel (8-bit planes: packed quad-SAD; 16-bit planes: v_sad_u16).
  *
  * The reference scans [mvmin, mvmax] in raster order and keeps the first position whose
  * SAD + lambda * bits beats everything before it. Here the reference window of the PU is staged
@@ -28,42 +28,49 @@ namespace x265amd {
 #define ESA_THREADS 256
 #endif
 #define ESA_R 8                  /* candidate rows per lane */
-#define ESA_SENTINEL 0x1000000   /* added to the cost of positions outside the range */
+/* candidate columns a lane measures at once and bytes per sample: four with the packed quad-SAD of 8-bit samples,
+ * two (an even and an odd one) with v_sad_u16. SENT is added to the cost of positions outside the range: one bit
+ * above every real cost (a 64x64 SAD of 12-bit samples plus two table entries stays below 2^25). */
+template<typename P> struct EsaLane
+{
+    static constexpr int CX = sizeof(P) == 1 ? 4 : 2, BPS = (int)sizeof(P);
+    static constexpr uint32_t SENT = sizeof(P) == 1 ? 0x1000000u : 0x2000000u;
+};
 
 /* how one PU's scan is laid out; the same values in every thread of the workgroup */
 struct EsaGeo
 {
     int nx, ny;       /* positions per row / rows of the search range */
-    int nxg, nyg;     /* groups of 4 columns / ESA_R rows */
+    int nxg, nyg;     /* groups of cx columns / ESA_R rows */
     int xgs, ygs;     /* groups per LDS strip */
     int pitch;        /* window row pitch in bytes, a whole number of dwords */
     int off_cx, off_cy, off_win;   /* LDS byte offsets */
 };
 
-__host__ __device__ inline int esa_pitch(int xgs, int w)
+__host__ __device__ inline int esa_pitch(int xgs, int w, int cx = 4, int bps = 1)
 {
-    return (xgs + (w >> 2) + 1) * 4;   /* the last lane reads one dword past its columns */
+    return (((xgs * cx + w) * bps + 3) & ~3) + 4;   /* the last lane reads one dword past its columns */
 }
 
 /* LDS bytes a strip of xgs x ygs groups needs after the fixed part */
-__host__ __device__ inline int esa_strip_bytes(int xgs, int ygs, int w, int h)
+__host__ __device__ inline int esa_strip_bytes(int xgs, int ygs, int w, int h, int cx = 4, int bps = 1)
 {
-    return 16 * xgs + 4 * ESA_R * ygs + esa_pitch(xgs, w) * (ygs * ESA_R + h - 1);
+    return 4 * cx * xgs + 4 * ESA_R * ygs + esa_pitch(xgs, w, cx, bps) * (ygs * ESA_R + h - 1);
 }
 
 /* Largest strips that fit `budget` bytes, evened out over the range; false if not even one
  * group fits. */
-__host__ __device__ inline bool esa_plan(int nx, int ny, int w, int h, int budget, EsaGeo &g)
+__host__ __device__ inline bool esa_plan(int nx, int ny, int w, int h, int budget, EsaGeo &g, int cx = 4, int bps = 1)
 {
     g.nx = nx; g.ny = ny;
-    g.nxg = (nx + 3) >> 2; g.nyg = (ny + ESA_R - 1) / ESA_R;
+    g.nxg = (nx + cx - 1) / cx; g.nyg = (ny + ESA_R - 1) / ESA_R;
     int xgs = g.nxg;
-    while (xgs > 1 && esa_strip_bytes(xgs, 1, w, h) > budget) xgs = (xgs + 1) >> 1;
-    if (esa_strip_bytes(xgs, 1, w, h) > budget) return false;
+    while (xgs > 1 && esa_strip_bytes(xgs, 1, w, h, cx, bps) > budget) xgs = (xgs + 1) >> 1;
+    if (esa_strip_bytes(xgs, 1, w, h, cx, bps) > budget) return false;
     const int nxs = (g.nxg + xgs - 1) / xgs;
     xgs = (g.nxg + nxs - 1) / nxs;
-    const int p = esa_pitch(xgs, w);
-    int ygs = (budget - 16 * xgs - p * (h - 1)) / (ESA_R * (p + 4));
+    const int p = esa_pitch(xgs, w, cx, bps);
+    int ygs = (budget - 4 * cx * xgs - p * (h - 1)) / (ESA_R * (p + 4));
     if (ygs > g.nyg) ygs = g.nyg;
     const int nys = (g.nyg + ygs - 1) / ygs;
     ygs = (g.nyg + nys - 1) / nys;
@@ -171,19 +178,86 @@ __device__ __forceinline__ void esa_patch(int org, int pitch, int fenc, int w_, 
     }
 }
 
+/* The same for 16-bit samples: the 2 x ESA_R candidates whose first one has its top-left reference sample at LDS byte
+ * `org` (a dword boundary), source pitch 128 bytes. v_sad_u16 measures two samples; the even candidate's operand is
+ * the reference dword itself, the odd one's the pair of dwords shifted by one sample. Sums are 32 bits wide. */
+template<int W, int H>
+__device__ __forceinline__ void esa_patch16(int org, int pitch, int fenc, int w_, int h_, uint32_t tot[ESA_R][2])
+{
+    const int w = W ? W : w_, h = H ? H : h_;
+#pragma unroll
+    for (int c = 0; c < ESA_R; c++) tot[c][0] = tot[c][1] = 0;
+    const int ncol = w >> 1;
+#pragma unroll
+    for (int j = 0; j < ncol; j++)
+    {
+        const int col = org + 4 * j, fcol = fenc + 4 * j;
+        uint32_t oe[7], oo[7];
+#pragma unroll
+        for (int k = 0; k < 7; k++)
+        {
+            const uint64_t pr = lds_pair(col + k * pitch);
+            oe[k] = (uint32_t)pr; oo[k] = __builtin_amdgcn_alignbyte((uint32_t)(pr >> 32), (uint32_t)pr, 2);
+        }
+        int y0 = 0;
+#pragma unroll
+        for (; y0 + 8 <= h; y0 += 8)
+        {
+            uint32_t ne[8], no[8], f[8];
+#pragma unroll
+            for (int k = 0; k < 8; k++)
+            {
+                const uint64_t pr = lds_pair(col + (y0 + 7 + k) * pitch);
+                ne[k] = (uint32_t)pr; no[k] = __builtin_amdgcn_alignbyte((uint32_t)(pr >> 32), (uint32_t)pr, 2);
+                f[k] = *(const uint32_t*)(x265amd_smem + fcol + (y0 + k) * 128);
+            }
+#pragma unroll
+            for (int yy = 0; yy < 8; yy++)
+#pragma unroll
+                for (int c = 0; c < ESA_R; c++)
+                {
+                    tot[c][0] = __builtin_amdgcn_sad_u16(yy + c < 7 ? oe[yy + c < 7 ? yy + c : 0] : ne[yy + c < 7 ? 0 : yy + c - 7], f[yy], tot[c][0]);
+                    tot[c][1] = __builtin_amdgcn_sad_u16(yy + c < 7 ? oo[yy + c < 7 ? yy + c : 0] : no[yy + c < 7 ? 0 : yy + c - 7], f[yy], tot[c][1]);
+                }
+#pragma unroll
+            for (int k = 0; k < 7; k++) { oe[k] = ne[k + 1]; oo[k] = no[k + 1]; }
+        }
+        if (h & 4)
+        {
+            /* heights 4 and 12: a last block of four source rows */
+            uint32_t ne[4], no[4], f[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++)
+            {
+                const uint64_t pr = lds_pair(col + (y0 + 7 + k) * pitch);
+                ne[k] = (uint32_t)pr; no[k] = __builtin_amdgcn_alignbyte((uint32_t)(pr >> 32), (uint32_t)pr, 2);
+                f[k] = *(const uint32_t*)(x265amd_smem + fcol + (y0 + k) * 128);
+            }
+#pragma unroll
+            for (int yy = 0; yy < 4; yy++)
+#pragma unroll
+                for (int c = 0; c < ESA_R; c++)
+                {
+                    tot[c][0] = __builtin_amdgcn_sad_u16(yy + c < 7 ? oe[yy + c < 7 ? yy + c : 0] : ne[yy + c < 7 ? 0 : yy + c - 7], f[yy], tot[c][0]);
+                    tot[c][1] = __builtin_amdgcn_sad_u16(yy + c < 7 ? oo[yy + c < 7 ? yy + c : 0] : no[yy + c < 7 ? 0 : yy + c - 7], f[yy], tot[c][1]);
+                }
+        }
+    }
+}
+
 /* LDS layout of the scan kernel: [counter, per-wave winners][source block, pitch 64][cost of
  * each column's MV x][cost of each row's MV y][reference window strip] */
 #define ESA_L_CNT 0
 #define ESA_L_RED 16
 #define ESA_L_FENC 64
-__host__ __device__ inline int esa_fixed_lds(int max_dim) { return ESA_L_FENC + max_dim * 64; }
+__host__ __device__ inline int esa_fixed_lds(int max_dim, int bps = 1) { return ESA_L_FENC + max_dim * 64 * bps; }
 
 /* A job the scan cannot take (PU larger than the launch allows, empty range, window budget too
  * small for a single group) gets cost -1 from both kernels. */
-__device__ __forceinline__ bool esa_job_ok(const JobRegs &J, int w, int h, int max_dim, int win_budget, EsaGeo &g)
+__device__ __forceinline__ bool esa_job_ok(const JobRegs &J, int w, int h, int max_dim, int win_budget, EsaGeo &g, int cx, int bps)
 {
     const int nx = J.mxx - J.mnx + 1, ny = J.mxy - J.mny + 1;
-    return w <= max_dim && h <= max_dim && nx > 0 && ny > 0 && esa_plan(nx, ny, w, h, win_budget, g);
+    return w <= max_dim && h <= max_dim && nx > 0 && ny > 0 && esa_plan(nx, ny, w, h, win_budget, g, cx, bps);
 }
 
 /* The raster scan of motion.cpp:1025-1053 for one PU per workgroup: writes the smallest
@@ -195,10 +269,11 @@ template<typename P, int W, int H>
 __device__ __forceinline__ void esa_scan_pu(const SearchArgs &a, const JobRegs &J, const EsaGeo &g, const PlaneDev *pref, int w, int h,
                                             int nowrap, int tid, int wave, int lane, uint32_t &bc, uint32_t &bi)
 {
+    constexpr int CX = EsaLane<P>::CX, BPS = EsaLane<P>::BPS;
     const int nx = g.nx, ny = g.ny;
     const uint16_t AS1 *ctab = (const uint16_t AS1*)a.ctab;
     const P AS1 *ref = (const P AS1*)pref[0].origin + (long)J.puy * pref[0].stride + J.pux;
-    const int rstride = pref[0].stride;
+    const long rstride = (long)pref[0].stride * BPS;          /* bytes */
     const int pd = g.pitch >> 2;
     bool first = true;
     for (int ys0 = 0; ys0 < g.nyg; ys0 += g.ygs)
@@ -210,15 +285,15 @@ __device__ __forceinline__ void esa_scan_pu(const SearchArgs &a, const JobRegs &
             first = false;
             /* lambda * bits of each column / row of the strip, as the reference's two table
              * operands (bitcost.h:46); positions outside the range carry the sentinel */
-            for (int i = tid; i < 4 * xgc; i += ESA_THREADS)
+            for (int i = tid; i < CX * xgc; i += ESA_THREADS)
             {
-                const int dxi = xs0 * 4 + i;
-                lds_i(0, g.off_cx)[i] = dxi < nx ? (int)ctab[as_i16((J.mnx + dxi) << 2) - J.qmx] : ESA_SENTINEL;
+                const int dxi = xs0 * CX + i;
+                lds_i(0, g.off_cx)[i] = dxi < nx ? (int)ctab[as_i16((J.mnx + dxi) << 2) - J.qmx] : (int)EsaLane<P>::SENT;
             }
             for (int i = tid; i < ESA_R * ygc; i += ESA_THREADS)
             {
                 const int dyi = ys0 * ESA_R + i;
-                lds_i(0, g.off_cy)[i] = dyi < ny ? (int)ctab[as_i16((J.mny + dyi) << 2) - J.qmy] : ESA_SENTINEL;
+                lds_i(0, g.off_cy)[i] = dyi < ny ? (int)ctab[as_i16((J.mny + dyi) << 2) - J.qmy] : (int)EsaLane<P>::SENT;
             }
             {
                 /* window strip: rows below the last row any valid candidate needs repeat that
@@ -226,8 +301,8 @@ __device__ __forceinline__ void esa_scan_pu(const SearchArgs &a, const JobRegs &
                  * rows (lane = dword), eight rows in flight before the first is stored. */
                 const int rows = ygc * ESA_R + h - 1;
                 const int rlast = (ny - 1 - ys0 * ESA_R) + h - 1;
-                const int dlast = (nx - 1 - xs0 * 4 + w - 1 + 4) >> 2;
-                const char AS1 *src0 = (const char AS1*)(ref + (long)(J.mny + ys0 * ESA_R) * rstride + J.mnx + xs0 * 4);
+                const int dlast = (((nx - 1 - xs0 * CX + w - 1) * BPS) >> 2) + 1;
+                const char AS1 *src0 = (const char AS1*)(ref + J.mnx + xs0 * CX) + (long)(J.mny + ys0 * ESA_R) * rstride;
 #ifdef X265AMD_ESA_SKIP
                 /* timing builds only: 1 = no window staging, 2 = no scan; results are then meaningless */
                 if (X265AMD_ESA_SKIP != 1)
@@ -245,7 +320,7 @@ __device__ __forceinline__ void esa_scan_pu(const SearchArgs &a, const JobRegs &
                             int r = r0 + u * (ESA_THREADS / 64);
                             r = r < rlast ? r : rlast;
                             typedef uint32_t __attribute__((aligned(1))) u32u;
-                            v[u] = *(const u32u AS1*)(src0 + (long)r * rstride + voff);
+                            v[u] = *(const u32u AS1*)(src0 + r * rstride + voff);
                         }
 #pragma unroll
                         for (int u = 0; u < 8; u++)
@@ -273,16 +348,33 @@ __device__ __forceinline__ void esa_scan_pu(const SearchArgs &a, const JobRegs &
                 const bool live = i0 + lane < ni;
                 const int it = live ? i0 + lane : ni - 1;
                 const int yg = (it * inv) >> 16, xg = it - yg * xgc;
-                uint32_t tot[ESA_R][4];
+                uint32_t tot[ESA_R][CX];
                 uint64_t a16[ESA_R];
-                const int porg = g.off_win + yg * ESA_R * g.pitch + xg * 4;
-                constexpr bool packed = EsaPacked<W, H>::value;
-                esa_patch<W, H>(porg, g.pitch, ESA_L_FENC, w, h, tot, a16);
-                int cx[4];
+                const int porg = g.off_win + yg * ESA_R * g.pitch + xg * 4;     /* CX * BPS = 4 bytes per group */
+                constexpr bool packed = BPS == 1 && EsaPacked<W, H>::value;
+                if constexpr (BPS == 1) esa_patch<W, H>(porg, g.pitch, ESA_L_FENC, w, h, tot, a16);
+                else esa_patch16<W, H>(porg, g.pitch, ESA_L_FENC, w, h, tot);
+                int cx[CX];
 #pragma unroll
-                for (int i = 0; i < 4; i++) cx[i] = lds_i(0, g.off_cx)[xg * 4 + i];
+                for (int i = 0; i < CX; i++) cx[i] = lds_i(0, g.off_cx)[xg * CX + i];
                 uint32_t best = 0xffffffffu;
-                if (packed && nowrap)
+                if constexpr (BPS == 2)
+                {
+                    /* 16-bit samples: (cost << 4 | patch index); cost < 2^27 with the sentinel */
+#pragma unroll
+                    for (int c = 0; c < ESA_R; c++)
+                    {
+                        const int cy = lds_i(0, g.off_cy)[yg * ESA_R + c];
+#pragma unroll
+                        for (int i = 0; i < CX; i++)
+                        {
+                            const uint32_t cost = tot[c][i] + ((uint32_t)(cx[i] + cy) & (0xffffu | (3u * EsaLane<P>::SENT)));
+                            const uint32_t key = (cost << 4) | (uint32_t)(c * CX + i);
+                            best = key < best ? key : best;
+                        }
+                    }
+                }
+                else if (packed && nowrap)
                 {
                     /* as below, straight from the packed sums: key = sum16 * 32 + (cx << 5 | column) in one
                      * multiply-add that picks its 16-bit half */
@@ -347,15 +439,17 @@ __device__ __forceinline__ void esa_scan_pu(const SearchArgs &a, const JobRegs &
                     for (int i = 0; i < 4; i++)
                     {
                         /* uint16 wrap of the sum of the two table entries; the sentinel bits survive */
-                        const uint32_t cost = tot[c][i] + ((uint32_t)(cx[i] + cy) & 0x0300ffffu);
+                        const uint32_t cost = tot[c][i] + ((uint32_t)(cx[i] + cy) & (0xffffu | (3u * EsaLane<P>::SENT)));
                         const uint32_t key = (cost << 5) | (uint32_t)(c * 4 + i);
                         best = key < best ? key : best;
                     }
                 }
                 }
-                const uint32_t cost = best >> 5, ci = best & 31;
-                const uint32_t idx = (uint32_t)((ys0 + yg) * ESA_R + (ci >> 2)) * (uint32_t)nx + (uint32_t)((xs0 + xg) * 4 + (ci & 3));
-                if (live && cost < ESA_SENTINEL && (cost < bc || (cost == bc && idx < bi))) { bc = cost; bi = idx; }
+                /* cost and patch index (row * 4 + column) of the lane's best position */
+                const uint32_t cost = BPS == 2 ? best >> 4 : best >> 5;
+                const uint32_t ci = BPS == 2 ? (((best & 15) >> 1) << 2) | (best & 1) : best & 31;
+                const uint32_t idx = (uint32_t)((ys0 + yg) * ESA_R + (ci >> 2)) * (uint32_t)nx + (uint32_t)((xs0 + xg) * CX + (ci & 3));
+                if (live && cost < EsaLane<P>::SENT && (cost < bc || (cost == bc && idx < bi))) { bc = cost; bi = idx; }
             }
         }
 }
@@ -365,7 +459,7 @@ __device__ __forceinline__ void esa_scan_pu(const SearchArgs &a, const JobRegs &
 template<typename P, int SZ>
 __global__ __launch_bounds__(ESA_THREADS) __attribute__((amdgpu_waves_per_eu(4))) void esa_scan_kernel(SearchArgs a, int win_budget, int nowrap)
 {
-    static_assert(sizeof(P) == 1, "the packed quad-SAD path is for 8-bit samples");
+    constexpr int CX = EsaLane<P>::CX, BPS = EsaLane<P>::BPS;
     const int j = xcd_remap(blockIdx.x, a.njobs);
     if (j >= a.njobs) return;
     const x265amd_job *job = a.jobs + j;
@@ -384,26 +478,26 @@ __global__ __launch_bounds__(ESA_THREADS) __attribute__((amdgpu_waves_per_eu(4))
     J.load(job);
     const int w = uni(job->w), h = uni(job->h);
     EsaGeo g;
-    if (!esa_job_ok(J, w, h, a.max_dim, win_budget, g))
+    if (!esa_job_ok(J, w, h, a.max_dim, win_budget, g, CX, BPS))
     {
         if (tid == 0) { a.results[j].cost = -1; a.results[j].sad_calls = 0; }
         return;
     }
     PlaneDev pfenc, pref[4];
     job_planes(a, job, pfenc, pref);
-    g.off_cx = esa_fixed_lds(a.max_dim);
-    g.off_cy = g.off_cx + 16 * g.xgs;
+    g.off_cx = esa_fixed_lds(a.max_dim, BPS);
+    g.off_cy = g.off_cx + 4 * CX * g.xgs;
     g.off_win = g.off_cy + 4 * ESA_R * g.ygs;
 
     {
-        /* source block into LDS, pitch 64 (setSourcePU, motion.cpp:116-142) */
-        const char AS1 *src = (const char AS1*)pfenc.origin + (long)J.puy * pfenc.stride + J.pux;
-        const int wd = w >> 2;
+        /* source block into LDS, pitch 64 samples (setSourcePU, motion.cpp:116-142) */
+        const char AS1 *src = (const char AS1*)((const P AS1*)pfenc.origin + (long)J.puy * pfenc.stride + J.pux);
+        const int wd = (w * BPS) >> 2;
         for (int i = tid; i < wd * h; i += ESA_THREADS)
         {
             const int y = i / wd, x = i - y * wd;
             typedef uint32_t __attribute__((aligned(1))) u32u;
-            *(uint32_t*)(x265amd_smem + ESA_L_FENC + y * 64 + 4 * x) = *(const u32u AS1*)(src + (long)y * pfenc.stride + 4 * x);
+            *(uint32_t*)(x265amd_smem + ESA_L_FENC + y * 64 * BPS + 4 * x) = *(const u32u AS1*)(src + (long)y * pfenc.stride * BPS + 4 * x);
         }
     }
     uint32_t bc = 0xffffffffu, bi = 0xffffffffu;   /* this lane's best (cost, raster index) */
@@ -444,7 +538,7 @@ __global__ __launch_bounds__(64) void esa_finish_kernel(SearchArgs a, int win_bu
     J.load(job);
     const int w = uni(job->w), h = uni(job->h);
     EsaGeo g;
-    if (!esa_job_ok(J, w, h, a.max_dim, win_budget, g))
+    if (!esa_job_ok(J, w, h, a.max_dim, win_budget, g, EsaLane<P>::CX, EsaLane<P>::BPS))
     {
         if (threadIdx.x == 0)
         {

@@ -205,6 +205,204 @@ __global__ __launch_bounds__(RIME_THREADS) void rk_rime_kernel(RkArgs a)
 }
 
 
+/* ---- RIME of a whole CTU for 16-bit planes of up to 10 bits per sample ----
+ *
+ * The same four steps as rk_rime_kernel. v_sad_u16 measures two samples per lane, so a lane's four horizontally
+ * adjacent positions are two that start on a dword of the window row and two that start one sample later, measured
+ * against the pairs of dwords shifted by one sample (v_alignbyte); the three vertically adjacent positions share every
+ * row and its shifted copies. An 8x8 SAD of 10-bit samples still fits 16 bits (64 * 1023), the 16x16 sums do not, and
+ * SAD + lambda * bits of a 64x64 CU needs more than the 22 bits a 32-bit (cost, visit index) key has room for: the
+ * upper surfaces are 32 bits wide (they reuse the LDS of the source CTU and the windows, which nothing reads after
+ * step 2) and the minimum runs on 64-bit keys. */
+#define RIME16_WPITCH 164         /* bytes per window row: 64 + 15 samples, a last dword pair read past them, odd number of dwords */
+enum
+{
+    R16_FENC = 0,                                                   /* 64 x 64 source, pitch 128 bytes */
+    R16_WIN = 8192,                                                 /* 3 windows */
+    R16_S16 = 0,                                                    /* after step 2: uint32[16][576] ... */
+    R16_S64 = R16_S16 + 4 * 16 * RIME_NCAND,                        /* ... and uint32[576] over the same bytes */
+    R16_MVC = (R16_WIN + 3 * RIME_WROWS * RIME16_WPITCH + 15) & ~15, /* int[576] */
+    R16_BEST = R16_MVC + 4 * RIME_NCAND,                            /* uint64[85]: running minimum key per CU */
+    R16_S8 = R16_BEST + 8 * 86,                                     /* uint16[64][576] */
+    R16_S32 = R16_S8 + 2 * 64 * RIME_NCAND,                         /* uint32[4][576] */
+    R16_TOTAL = R16_S32 + 4 * 4 * RIME_NCAND
+};
+static_assert(R16_S64 + 4 * RIME_NCAND <= R16_MVC, "the upper surfaces fit the bytes of the source CTU and the windows");
+
+__global__ __launch_bounds__(RIME_THREADS) void rk_rime16_kernel(RkArgs a)
+{
+    const x265amd_rk_ctu &j = a.ctus[blockIdx.x];
+    x265amd_rk_result &res = a.results[blockIdx.x];
+    const int tid = threadIdx.x;
+    const int pmv[3][2] = { { res.cime.mv[0], res.cime.mv[1] }, { j.pmv[0][0], j.pmv[0][1] }, { j.pmv[1][0], j.pmv[1][1] } };
+    unsigned long long *best = (unsigned long long*)(x265amd_smem + R16_BEST);
+
+    /* ---- 1. source CTU, windows, lambda * bits ---- */
+    {
+        typedef uint32_t __attribute__((aligned(2))) u32u;
+        const char AS1 *src = (const char AS1*)((const uint16_t AS1*)a.fenc.origin + (long)j.ctu_y * a.fenc.stride + j.ctu_x);
+        for (int i = tid; i < 64 * 32; i += RIME_THREADS)
+        {
+            const int y = i >> 5, x = i & 31;         /* 64 rows x 32 dwords */
+            *(uint32_t*)(x265amd_smem + R16_FENC + y * 128 + 4 * x) = *(const u32u AS1*)(src + (long)y * a.fenc.stride * 2 + 4 * x);
+        }
+        const uint16_t AS1 *rec = (const uint16_t AS1*)a.recon.origin + (long)j.ctu_y * a.recon.stride + j.ctu_x;
+        const int wd = RIME16_WPITCH / 4;
+        for (int i = tid; i < 3 * RIME_WROWS * wd; i += RIME_THREADS)
+        {
+            const int p = i / (RIME_WROWS * wd), r = (i - p * RIME_WROWS * wd) / wd, d = i - (p * RIME_WROWS + r) * wd;
+            const int px = as_i16(pmv[p][0] - 8), py = as_i16(pmv[p][1] - 6);   /* first position of the window */
+            *(uint32_t*)(x265amd_smem + R16_WIN + (p * RIME_WROWS + r) * RIME16_WPITCH + 4 * d) =
+                *(const u32u AS1*)((const char AS1*)(rec + (long)(py + r) * a.recon.stride + px) + 4 * d);
+        }
+        if (tid < RIME_NCAND)
+        {
+            const int p = tid / 192, i = (tid - p * 192) >> 4, jx = tid & 15;
+            const int tx = as_i16(pmv[p][0] + jx - 8), ty = as_i16(pmv[p][1] + i - 6);
+            int mvc = 0;
+            if (j.have_mvd)
+            {
+                const uint16_t AS1 *ctab = (const uint16_t AS1*)a.ctab;
+                mvc = 0x7fffffff;
+#pragma unroll
+                for (int k = 0; k < 3; k++)
+                {
+                    const int v = ((int)ctab[tx - j.mvp[k][0]] + (int)ctab[ty - j.mvp[k][1]]) & 0xffff;
+                    mvc = v < mvc ? v : mvc;
+                }
+            }
+            lds_i(0, R16_MVC)[tid] = mvc;
+        }
+        if (tid < 85) best[tid] = ~0ull;
+    }
+    __syncthreads();
+
+    /* ---- 2. 8x8 block surfaces: item = (block, window, row group of 3, column group of 4) ---- */
+    const int nbx = j.valid_w >> 3, nby = j.valid_h >> 3;     /* blocks inside the picture */
+    for (int it = tid; it < 64 * 3 * 4 * 4; it += RIME_THREADS)
+    {
+        const int xg = it & 3, yg = (it >> 2) & 3, pb = it >> 4;
+        const int p = pb % 3, blk = pb / 3;
+        const int bx = blk & 7, by = blk >> 3;
+        if (bx >= nbx || by >= nby) continue;
+        const int org = R16_WIN + (p * RIME_WROWS + by * 8 + yg * RIME_RR) * RIME16_WPITCH + (bx * 8 + xg * 4) * 2;
+        const int fo = R16_FENC + by * 8 * 128 + bx * 16;
+        uint32_t f[8][4];
+#pragma unroll
+        for (int y = 0; y < 8; y++)
+        {
+            const uint64_t lo = *(const uint64_t*)(x265amd_smem + fo + y * 128), hi = *(const uint64_t*)(x265amd_smem + fo + y * 128 + 8);
+            f[y][0] = (uint32_t)lo; f[y][1] = (uint32_t)(lo >> 32); f[y][2] = (uint32_t)hi; f[y][3] = (uint32_t)(hi >> 32);
+        }
+        uint32_t acc[RIME_RR][4];
+#pragma unroll
+        for (int c = 0; c < RIME_RR; c++)
+#pragma unroll
+            for (int i = 0; i < 4; i++) acc[c][i] = 0;
+#pragma unroll
+        for (int r = 0; r < 8 + RIME_RR - 1; r++)
+        {
+            uint32_t d[6], s[5];
+#pragma unroll
+            for (int k = 0; k < 3; k++)
+            {
+                const uint64_t pr = rime_pair(org + r * RIME16_WPITCH + 8 * k);
+                d[2 * k] = (uint32_t)pr; d[2 * k + 1] = (uint32_t)(pr >> 32);
+            }
+#pragma unroll
+            for (int k = 0; k < 5; k++) s[k] = __builtin_amdgcn_alignbyte(d[k + 1], d[k], 2);
+#pragma unroll
+            for (int c = 0; c < RIME_RR; c++)
+            {
+                const int y = r - c;              /* the source row this reference row meets for position row c */
+                if (y < 0 || y > 7) continue;
+#pragma unroll
+                for (int k = 0; k < 4; k++)
+                {
+                    acc[c][0] = __builtin_amdgcn_sad_u16(d[k], f[y][k], acc[c][0]);
+                    acc[c][1] = __builtin_amdgcn_sad_u16(s[k], f[y][k], acc[c][1]);
+                    acc[c][2] = __builtin_amdgcn_sad_u16(d[k + 1], f[y][k], acc[c][2]);
+                    acc[c][3] = __builtin_amdgcn_sad_u16(s[k + 1], f[y][k], acc[c][3]);
+                }
+            }
+        }
+        /* an 8x8 SAD of 10-bit samples is at most 65472: the surface entries are 16 bits */
+#pragma unroll
+        for (int c = 0; c < RIME_RR; c++)
+            *(uint64_t*)(x265amd_smem + R16_S8 + 2 * (blk * RIME_NCAND + p * 192 + (yg * RIME_RR + c) * 16 + xg * 4)) =
+                (uint64_t)(acc[c][0] | (acc[c][1] << 16)) | ((uint64_t)(acc[c][2] | (acc[c][3] << 16)) << 32);
+    }
+    __syncthreads();
+
+    /* ---- 3. up the quadtree (the source CTU and the windows are dead: their bytes hold the upper surfaces) ---- */
+    const uint16_t *s8 = (const uint16_t*)(x265amd_smem + R16_S8);
+    uint32_t *s16 = (uint32_t*)(x265amd_smem + R16_S16);
+    uint32_t *s32 = (uint32_t*)(x265amd_smem + R16_S32), *s64 = (uint32_t*)(x265amd_smem + R16_S64);
+    for (int i = tid; i < 16 * RIME_NCAND; i += RIME_THREADS)
+    {
+        const int cu = i / RIME_NCAND, cand = i - cu * RIME_NCAND;
+        const int b0 = (cu >> 2) * 16 + (cu & 3) * 2;      /* top-left 8x8 block of the 16x16 CU */
+        s16[i] = (uint32_t)s8[b0 * RIME_NCAND + cand] + s8[(b0 + 1) * RIME_NCAND + cand] +
+                 s8[(b0 + 8) * RIME_NCAND + cand] + s8[(b0 + 9) * RIME_NCAND + cand];
+    }
+    __syncthreads();
+    for (int i = tid; i < 4 * RIME_NCAND; i += RIME_THREADS)
+    {
+        const int cu = i / RIME_NCAND, cand = i - cu * RIME_NCAND;
+        const int c0 = (cu >> 1) * 8 + (cu & 1) * 2;       /* top-left 16x16 CU of the 32x32 CU */
+        s32[i] = s16[c0 * RIME_NCAND + cand] + s16[(c0 + 1) * RIME_NCAND + cand] +
+                 s16[(c0 + 4) * RIME_NCAND + cand] + s16[(c0 + 5) * RIME_NCAND + cand];
+    }
+    __syncthreads();
+    if (tid < RIME_NCAND) s64[tid] = s32[tid] + s32[RIME_NCAND + tid] + s32[2 * RIME_NCAND + tid] + s32[3 * RIME_NCAND + tid];
+    __syncthreads();
+
+    /* ---- 4. per CU: first minimum in visit order; 12 threads share a CU ---- */
+    if (tid < 85 * 12)
+    {
+        const int idx = tid / 12, part = tid - idx * 12;
+        int size, ox, oy;
+        if (idx < 64) { size = 8; ox = (idx & 7) * 8; oy = (idx >> 3) * 8; }
+        else if (idx < 80) { size = 16; ox = ((idx - 64) & 3) * 16; oy = ((idx - 64) >> 2) * 16; }
+        else if (idx < 84) { size = 32; ox = ((idx - 80) & 1) * 32; oy = ((idx - 80) >> 1) * 32; }
+        else { size = 64; ox = 0; oy = 0; }
+        if (j.ctu_x + ox + size <= a.pic_w && j.ctu_y + oy + size <= a.pic_h)
+        {
+            const int *mvc = lds_i(0, R16_MVC);
+            unsigned long long key = ~0ull;
+            for (int k = 0; k < 48; k++)
+            {
+                const int cand = part * 48 + k;
+                uint32_t sad;
+                if (idx < 64) sad = s8[idx * RIME_NCAND + cand];
+                else if (idx < 80) sad = s16[(idx - 64) * RIME_NCAND + cand];
+                else if (idx < 84) sad = s32[(idx - 80) * RIME_NCAND + cand];
+                else sad = s64[cand];
+                const unsigned long long kk = ((unsigned long long)(sad + (uint32_t)mvc[cand]) << 10) | (unsigned)cand;
+                key = kk < key ? kk : key;
+            }
+            atomicMin(&best[idx], key);
+        }
+    }
+    __syncthreads();
+    if (tid < 85)
+    {
+        const unsigned long long key = best[tid];
+        if (key == ~0ull)
+        {
+            /* CU outside the picture (TEncCu.cpp:475-493) */
+            res.rime[tid].mv[0] = res.rime[tid].mv[1] = 0; res.rime[tid].cost = -1;
+        }
+        else
+        {
+            const int cand = (int)(key & 1023), p = cand / 192, i = (cand - p * 192) >> 4, jx = cand & 15;
+            res.rime[tid].mv[0] = (int16_t)(pmv[p][0] + jx - 8);
+            res.rime[tid].mv[1] = (int16_t)(pmv[p][1] + i - 6);
+            res.rime[tid].cost = (int)(key >> 10);
+        }
+    }
+}
+
 /* ---- FME: the 7 x 7 quarter-pel grid around the RIME vector (motion.cpp:1364-1403; filters
  * InterpHoriz / InterpVert / FilterHorizontal + FilterVertical with N = 4, :1495-1648) ----
  *

@@ -7,7 +7,8 @@ from . import workload
 from .engine import METHODS, RESULT_DTYPE, RK_RESULT_DTYPE
 from .synth import make_clip, pad_plane
 
-SAD_ISSUE_PEAK = 150e12   # pixel-SADs/s of v_sad_u8 / v_qsad_pk_u16_u8 on all 1024 SIMDs (tools/sad_rate.hip, measured)
+SAD_ISSUE_PEAK = 150e12   # pixel-SADs/s of v_sad_u8 / v_qsad_pk_u16_u8 on all 1024 SIMDs (tools/sad_rate.hip, measured);
+                          # v_sad_u16 measures two samples where those measure four: half of it for 16-bit samples
 
 
 def _timed(torch, e, dev, launch, reps):
@@ -28,7 +29,7 @@ def esa_per_size(e, dev, width=3840, height=2160, merange=92, sizes=(64, 32, 16,
     Returns (rows, host planes); rows = [{size, pus, ms, pixel_sads, jobs, results}]."""
     import torch
     M = 128
-    clip = make_clip(width, height, 2, seed=seed)
+    clip = make_clip(width, height, 2, seed=seed, depth=e.depth)
     cur, org, stride = pad_plane(clip[1], M)
     ref, _, _ = pad_plane(clip[0], M)
     pc = e.upload_plane(cur, width, height, M, M, stride)
@@ -57,11 +58,11 @@ def rk_picture(e, dev, width=1920, height=1080, reps=5, seed=5, qp=30):
     Returns a dict with ms, ctus, pixel_sads and the inputs / results for checking."""
     import torch
     M = 304
-    clip = make_clip(width, height, 3, seed=seed)
+    clip = make_clip(width, height, 3, seed=seed, depth=e.depth)
     cur, org, stride = pad_plane(clip[2], M)
     rorig, _, _ = pad_plane(clip[0], M)
     noise = np.random.default_rng(seed).integers(-2, 3, clip[0].shape)
-    recon, _, _ = pad_plane(np.clip(clip[0].astype(int) + noise, 0, 255).astype(np.uint8), M)
+    recon, _, _ = pad_plane(np.clip(clip[0].astype(int) + noise, 0, (1 << e.depth) - 1).astype(clip[0].dtype), M)
     pc = e.upload_plane(cur, width, height, M, M, stride)
     po = e.upload_plane(rorig, width, height, M, M, stride)
     pr = e.upload_plane(recon, width, height, M, M, stride)
