@@ -276,7 +276,7 @@ __global__ __launch_bounds__(64) void refine_small_kernel(SearchArgs a)
  * bDistance == 0 nothing else runs (:916-1017). For such a PU the order of the points does not matter -- only that
  * none is cheaper -- so the whole stage has a fixed shape: the start-up candidates as one plane + one vertical pass
  * each (all SAD; full-pel ones are the phase-0 case), the decisions of :575-621 on group-uniform values, then the 20
- * points as plain SADs, four points per pass. A PU one of whose points improves is left to the one-wave search from
+ * points as plain SADs from a window of the reference staged in LDS, four points per pass. A PU one of whose points improves is left to the one-wave search from
  * the start, as are the PUs of other sizes: their result records get SMALL_REDO in sad_calls, and the search kernel
  * launched next over all jobs works on exactly those (its other waves leave at once; no counter or queue that a
  * picture full of such PUs could choke). The others get their record of the full-pel / predictor choice (:1063-1069)
@@ -444,6 +444,23 @@ __global__ __launch_bounds__(64) void star_small_kernel(SearchArgs a)
     }
     bool improve = false;
     unsigned npts = 0;
+#ifndef X265AMD_STAR_GLOBAL_LOADS
+    /* the (S + 8)^2 samples the 20 points can touch, staged once per PU into the LDS of the start-up planes (dead by
+     * now); the points are measured from there. (X265AMD_STAR_GLOBAL_LOADS, tools builds only: the points read global
+     * memory instead, the variant this one was measured against.) */
+    constexpr int WP = S + 12;                      /* window row pitch: S + 8 samples and the dword a lane reads past them */
+    const int woff = L::PLANES + grp * L::PU_BYTES;
+    wave_sync();
+    {
+        const uint8_t AS1 *w0 = ref0 + roff + (long)__mul24(bmy - 4, rstride) + bmx - 4;
+        for (int i = l; i < (S + 8) * (WP / 4); i += G::LPP)
+        {
+            const int r = i / (WP / 4), q = i - r * (WP / 4);
+            *(uint32_t*)(x265amd_smem + woff + r * WP + 4 * q) = Px<uint8_t>::load_g(w0 + (long)r * rstride + 4 * q);
+        }
+    }
+    wave_sync();
+#endif
 #pragma unroll 1
     for (int pass = 0; pass < 5; pass++)
     {
@@ -457,9 +474,19 @@ __global__ __launch_bounds__(64) void star_small_kernel(SearchArgs a)
         int v = 0, cost = 0;
         if (ok)
         {
+#ifndef X265AMD_STAR_GLOBAL_LOADS
+            const int bo = woff + (4 + dy + tly) * WP + 4 + dx + tlx, al = bo & ~3, sh = bo & 3;
+#pragma unroll
+            for (int yy = 0; yy < 4; yy++)
+            {
+                const uint32_t *q = (const uint32_t*)(x265amd_smem + al + yy * WP);
+                v = Px<uint8_t>::sad(fq[yy], __builtin_amdgcn_alignbyte(q[1], q[0], sh), v);
+            }
+#else
             const uint8_t AS1 *rp = ref0 + roff + (long)__mul24(y + tly, rstride) + x + tlx;
 #pragma unroll
             for (int yy = 0; yy < 4; yy++) v = Px<uint8_t>::sad(fq[yy], Px<uint8_t>::load_g(rp + (long)yy * rstride), v);
+#endif
             cost = ((int)ctab[as_i16(x << 2) - mvpx] + (int)ctab[as_i16(y << 2) - mvpy]) & 0xffff;
         }
         v = seg_sum(v, G::LT);      /* the tiles of a point are adjacent lanes */

@@ -15,7 +15,8 @@ import os
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libx265_amd_me.so")
+# X265AMD_LIB names another build of the same library (timing / experiment builds under tools/); never a fallback
+LIB_PATH = os.environ.get("X265AMD_LIB") or os.path.join(HERE, "libx265_amd_me.so")
 
 DIA, HEX, UMH, STAR, FULL = 0, 1, 2, 3, 4
 METHODS = {"dia": DIA, "hex": HEX, "umh": UMH, "star": STAR, "full": FULL}
