@@ -205,14 +205,18 @@ def main():
                          "affinity mask)")
     ap.add_argument("--method", default="star")
     ap.add_argument("--subme", type=int, default=SUBME_DEFAULT, help="sub-pel refinement level (experiments only)")
-    ap.add_argument("--launch", choices=("pairs3", "split", "split3", "single", "per-size"), default="pairs3",
-                    help="search launches: pairs3 = per step ONE launch per PU class (8x8 | 16x16 | 64 + 32) over all frame "
-                         "pairs (x265amd_search_batch_pairs_dev), three streams; the others launch per frame pair: split3 = the "
+    ap.add_argument("--launch", choices=("pairs4", "pairs3", "split", "split3", "single", "per-size"), default="pairs4",
+                    help="search launches: pairs4 = per step ONE launch per PU size (8x8 | 16x16 | 32x32, 64x64) over all frame "
+                         "pairs (x265amd_search_batch_pairs_dev), three streams, the two large sizes sharing one; pairs3 = "
+                         "the 64x64 and 32x32 PUs in one launch; the others launch per frame pair: split3 = the "
                          "same three classes, split = 16/8 and 64/32 on two streams (LDS per PU sized per class), single = one "
                          "launch, per-size = four launches on one stream")
     ap.add_argument("--prio", choices=("small", "big", "flat"), default="small",
                     help="which search stream gets the device's highest priority: small = the 8x8 class, whose launch is a chain of "
                          "three dependent kernels that should not end the step alone; big = the 64/32 class; flat = none")
+    ap.add_argument("--s32", choices=("big", "mid", "la", "own"), default="big",
+                    help="pairs4: the stream of the 32x32 launch: behind the 64x64 launch, behind the 16x16 launch, behind the "
+                         "lookahead field, or one of its own")
     ap.add_argument("--big-streams", type=int, default=1,
                     help="streams the launches of the 64/32 PU class rotate over (split / split3): a 64x64 PU is one long wave, "
                          "so a launch of one frame's 480 + 1980 large PUs is bounded by that wave's latency, and launches of "
@@ -255,11 +259,12 @@ def main():
     # ---------------- setup (untimed): planes, lookahead fields, job lists, all on the device
     es = Engine(local_rank, 8, high_priority=args.prio == "small")      # search stream (all launches, or the 16/8 class)
     el = Engine(local_rank, 8)      # lookahead stream
-    multi = args.launch == "pairs3"
-    split = args.launch in ("split", "split3", "pairs3")
+    multi = args.launch in ("pairs3", "pairs4")
+    split = args.launch in ("split", "split3", "pairs3", "pairs4")
     eb = Engine(local_rank, 8, high_priority=args.prio == "big") if split else es   # stream of the 64/32 class
     ebs = [eb] + [Engine(local_rank, 8) for _ in range(args.big_streams - 1)] if split else [es]
-    em = Engine(local_rank, 8) if args.launch in ("split3", "pairs3") else es   # stream of the 16x16 class
+    em = Engine(local_rank, 8) if args.launch in ("split3", "pairs3", "pairs4") else es   # stream of the 16x16 class
+    e32 = {"big": eb, "mid": em, "la": el, "own": None}[args.s32] or Engine(local_rank, 8)     # stream of the 32x32 class (pairs4)
     B = args.pairs
     clip = make_clip(W, H, B + 1, seed=1234 + rank)
     planes, lowres = [], []
@@ -292,6 +297,9 @@ def main():
                 segs = [seg(jobs["w"] <= 16, 16, es), seg(jobs["w"] >= 32, 64, eb)]
             elif args.launch in ("split3", "pairs3"):
                 segs = [seg(jobs["w"] == 8, 8, es), seg(jobs["w"] == 16, 16, em), seg(jobs["w"] >= 32, 64, eb)]
+            elif args.launch == "pairs4":
+                segs = [seg(jobs["w"] == 8, 8, es), seg(jobs["w"] == 16, 16, em), seg(jobs["w"] == 32, 32, e32),
+                        seg(jobs["w"] == 64, 64, eb)]
             elif args.launch == "single":
                 segs = [seg(jobs["w"] > 0, 64, es)]
             else:
@@ -334,7 +342,7 @@ def main():
     def step_multi(k=None):
         el.lookahead_fields_dev(d_fields, B, wcu, hcu, LA_QP, HEX, 1, LA_MERANGE,
                                 d_la_mvs.data_ptr(), d_la_costs.data_ptr())
-        for c in (2, 1, 0):       # the class with the longest waves first; the timed 8x8 class last
+        for c in reversed(range(len(segs))):       # the class with the longest waves first; the timed 8x8 class last
             (first, cnt, dim, eng) = segs[c]
             if c == 0 and k is not None:
                 ev0[k].record(s_search)
@@ -346,6 +354,7 @@ def main():
         eb.sync()
         em.sync()
         el.sync()
+        e32.sync()
         if world > 1:
             # hand the MV / cost records to the rank that feeds the host encoder
             d_mvcost.copy_(all_res[:, :8])
@@ -424,7 +433,8 @@ def main():
     traffic = None
     tpath = os.path.join(ROOT, "profiles", "traffic.json")
     if os.path.exists(tpath):
-        traffic = json.load(open(tpath)).get("search_kernel_hbm_bytes_per_launch", {}).get(args.launch)
+        traffic = json.load(open(tpath)).get("search_kernel_hbm_bytes_per_launch", {}).get(
+            "pairs3" if args.launch == "pairs4" else args.launch)     # the 8x8 launch is the same in both
         if traffic is not None and multi:
             traffic *= B      # kept per frame pair (the counters were collected on a 2-pair step)
     vpath = os.path.join(ROOT, "profiles", "valu.json")
@@ -516,7 +526,11 @@ def main():
                                   "thread, frame pairs dealt out in turn), %.1f s, %s; MVs and costs compared with the GPU's"
                                   % (njobs * B, B, nthr, mt_s, "the reference's own code (oracle/_ref)" if use_ref
                                      else "oracle/me_oracle.c -O3")})
-        kernel = {"pairs3": "the launch over the %d 8x8 PUs of all %d frame pairs of a step: star_small_kernel<8> (start-up and the "
+        kernel = {"pairs4": "the launch over the %d 8x8 PUs of all %d frame pairs of a step: star_small_kernel<8> (start-up and the "
+                            "common case of the integer stage, four PUs per wave), search_kernel<uint8_t,false> (the PUs the first "
+                            "kernel marked: one PU per wave) and refine_small_kernel<8> (sub-pel rounds, four PUs per wave); the "
+                            "16x16 launch and the 64x64 + 32x32 launches run concurrently on two more streams" % (timed_cnt * B, B),
+                  "pairs3": "the launch over the %d 8x8 PUs of all %d frame pairs of a step: star_small_kernel<8> (start-up and the "
                             "common case of the integer stage, four PUs per wave), search_kernel<uint8_t,false> (the PUs the first "
                             "kernel marked: one PU per wave) and refine_small_kernel<8> (sub-pel rounds, four PUs per wave); the "
                             "16x16 and the 64/32 launches run concurrently on two more streams" % (timed_cnt * B, B),

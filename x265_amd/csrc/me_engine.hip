@@ -51,7 +51,8 @@ struct SearchArgs
     int *redo;         /* null, or the list redo_list_kernel made of the PUs whose result record carries SMALL_REDO (left over
                           by star_small_kernel): redo[0] = their number, redo[REDO_LIST..] = their job indices. The launch
                           then searches only these, each wave taking every gridDim.x-th entry */
-    int staged;    /* 8 or 16: square PUs of this size stop before the sub-pel refinement, which refine_small_kernel does; 0: none */
+    int staged;    /* 8, 16, 32 or 64: square PUs of this size stop before the sub-pel refinement, which refine_small_kernel
+                      (8, 16) or refine_big_kernel (32, 64) does; 0: none */
 };
 
 /* the planes job `job` searches: the launch's own, or its entry of the launch's pair table. Device-resident jobs
@@ -899,11 +900,13 @@ static int launch_search(x265amd_ctx *c, const SearchArgs &a, int is_lowres)
         static const bool no_staged = getenv("X265AMD_NO_STAGED") != 0;                            /* measurements only */
         static const bool no_star = getenv("X265AMD_NO_STAR8") != 0;
         SearchArgs b = a;
-        /* launches of 8-bit PUs up to 8x8 or up to 16x16: the square PUs of that size are refined by a second kernel
-         * (four 8x8 PUs or one 16x16 PU per wave) */
-        b.staged = sizeof(P) == 1 && (a.max_dim == 8 || a.max_dim == 16) && !no_staged ? a.max_dim : 0;
+        /* launches of 8-bit PUs up to 8x8, 16x16, 32x32 or 64x64: the square PUs of that size are refined by a second
+         * kernel (four 8x8 PUs or one 16x16 PU per wave; four waves per 32x32 PU, sixteen per 64x64 PU) */
+        static const bool no_big = getenv("X265AMD_NO_STAGED_BIG") != 0;                             /* measurements only */
+        b.staged = sizeof(P) == 1 && !no_staged && (a.max_dim == 8 || a.max_dim == 16 || ((a.max_dim == 32 || a.max_dim == 64) && !no_big))
+                 ? a.max_dim : 0;
         const int npu = b.staged == 8 ? 4 : 1, groups = (a.njobs + npu - 1) / npu;
-        if (b.staged && a.method == X265AMD_STAR && !no_star)
+        if (b.staged && b.staged <= 16 && a.method == X265AMD_STAR && !no_star)
         {
             if (ensure(c, &c->d_redo, &c->redo_cap, sizeof(int) * ((size_t)REDO_LIST + a.njobs))) return X265AMD_EHIP;
             const int blocks = (a.njobs + REDO_CHUNK - 1) / REDO_CHUNK;
@@ -925,6 +928,10 @@ static int launch_search(x265amd_ctx *c, const SearchArgs &a, int is_lowres)
             hipLaunchKernelGGL(refine_small_kernel<8>, dim3(groups), dim3(64), RefineLds<8>::TOTAL, c->stream, b);
         else if (b.staged == 16)
             hipLaunchKernelGGL(refine_small_kernel<16>, dim3(groups), dim3(64), RefineLds<16>::TOTAL, c->stream, b);
+        else if (b.staged == 32)
+            hipLaunchKernelGGL(refine_big_kernel<32>, dim3(a.njobs), dim3(SmallGeo<32>::WAVES * 64), BigLds<32>::TOTAL, c->stream, b);
+        else if (b.staged == 64)
+            hipLaunchKernelGGL(refine_big_kernel<64>, dim3(a.njobs), dim3(SmallGeo<64>::WAVES * 64), BigLds<64>::TOTAL, c->stream, b);
     }
     HIPCHK(c, hipGetLastError());
     return X265AMD_OK;

@@ -27,20 +27,67 @@ namespace x265amd {
 
 template<int S> struct SmallGeo
 {
-    static_assert(S == 8 || S == 16, "8x8 or 16x16 PUs");
-    static constexpr int LG = S == 8 ? 4 : 6;       /* log2 of the lanes of a PU's group: a lane per (tile, column) */
-    static constexpr int LPP = 1 << LG;
-    static constexpr int NPU = 64 / LPP;            /* PUs per wave */
+    static_assert(S == 8 || S == 16 || S == 32 || S == 64, "square PUs of 8 to 64 samples");
+    static constexpr int LTW = S == 8 ? 1 : S == 16 ? 2 : S == 32 ? 3 : 4;
     static constexpr int TW = S / 4;                /* tiles in a PU row */
-    static constexpr int LTW = S == 8 ? 1 : 2;
     static constexpr int LT = 2 * LTW;              /* log2 of the tiles of a PU */
+    static constexpr int LG = LT + 2;               /* log2 of the lanes of a PU's group: a lane per (tile, column) */
+    static constexpr int LPP = 1 << LG;
+    static constexpr int NPU = LPP < 64 ? 64 / LPP : 1;     /* PUs per wave */
+    static constexpr int WAVES = LPP > 64 ? LPP / 64 : 1;   /* waves per PU (32x32 and 64x64: a workgroup per PU) */
     static constexpr int ROWS = S + 8;              /* rows of a plane: the PU, the 7 rows the taps reach and one for a second first row */
     static constexpr int PROW = ROWS + 2;           /* int16 rows of a plane column, with slack for an odd first row */
     static constexpr int PLANE = S * PROW * 2;      /* bytes of one plane */
     static constexpr int IPP = ROWS * TW;           /* horizontal-pass items (4 samples of a row) per plane */
     static constexpr int SIZE_CODE = S | (S << 8);  /* the (w, h) bytes of a job record */
 };
-#define SM_TAPS 0                                   /* 48 dwords of packed filter taps (TapWords) */
+#define SM_TAPS 0                                   /* 48 dwords of packed filter taps (TapWords): the horizontal pass reads words 9, 10 of a phase */
+#define SM_VTAPS 192                                /* 80 dwords: the vertical pass's taps (VTapWords) */
+#define SM_FIXED 512                                /* first byte behind the tap tables */
+
+/* The taps of the vertical pass as the lanes of small_column_cost read them: per (phase, parity of the first row in
+ * the column's dword pairs) two sets of five int16 pairs, P for output rows 0 and 2 and Q for rows 1 and 3, each
+ * applied to five consecutive dwords (ten plane rows). Even first row: P = the taps on rows 0..7 of the ten, Q = on
+ * rows 1..8; odd: P = on rows 1..8, Q = on rows 2..9 -- so a lane needs no realignment of what it loads. The taps are
+ * scaled by 16: the sum then carries luma_vsp's (sum + offset) >> 12 (ipfilter.cpp:372-389 with 8-bit samples) in its
+ * high half, where the int16 the reference casts to (:389) is taken with one byte permute. */
+struct VTapWords
+{
+    int w[80];
+    constexpr VTapWords() : w()
+    {
+        const int taps[4][8] = { { 0, 0, 0, 64, 0, 0, 0, 0 }, { -1, 4, -10, 58, 17, -5, 1, 0 },
+                                 { -1, 4, -11, 40, 40, -11, 4, -1 }, { 0, 1, -5, 17, 58, -10, 4, -1 } };
+        for (int ph = 0; ph < 4; ph++)
+            for (int par = 0; par < 2; par++)
+                for (int set = 0; set < 2; set++)
+                {
+                    const int first = par + set;        /* row of the ten the first tap falls on */
+                    for (int j = 0; j < 5; j++)
+                    {
+                        const int a = 2 * j - first, b = 2 * j + 1 - first;
+                        const int lo = a >= 0 && a < 8 ? taps[ph][a] * 16 : 0, hi = b >= 0 && b < 8 ? taps[ph][b] * 16 : 0;
+                        w[(ph * 2 + par) * 10 + set * 5 + j] = (int)((unsigned)(lo & 0xffff) | ((unsigned)(hi & 0xffff) << 16));
+                    }
+                }
+    }
+};
+__constant__ static const VTapWords kVTapWords = VTapWords();
+
+/* both tap tables into LDS, by the first 64 threads of the workgroup */
+__device__ __forceinline__ void small_load_taps(int tid)
+{
+    if (tid < 48) ((int*)(x265amd_smem + SM_TAPS))[tid] = kTapWords.w[tid];
+    if (tid < 64) ((int*)(x265amd_smem + SM_VTAPS))[tid] = kVTapWords.w[tid];
+    if (tid < 16) ((int*)(x265amd_smem + SM_VTAPS))[64 + tid] = kVTapWords.w[64 + tid];
+}
+
+/* the lane's column of a 4x4 source tile, rows (0, 1) and (2, 3) as int16 pairs */
+struct ColSrc
+{
+    int ty, col;
+    uint32_t f01, f23;
+};
 
 template<int LG> __device__ __forceinline__ int grp_lane(int v, int k) { return __shfl(v, (int)(threadIdx.x & 63 & ~((1 << LG) - 1)) + k); }
 template<int LG> __device__ __forceinline__ int grp_min(int v) { return LG == 4 ? row_min16(v) : wave_min(v); }
@@ -76,33 +123,66 @@ __device__ __forceinline__ void hps_quad(const uint8_t AS1 *s, const int *tp, in
                                                          __builtin_amdgcn_sdot4(__builtin_amdgcn_alignbyte(d2, d1, x), thi, 0, false), false);
 }
 
-/* vertical pass + cost of the lane's (tile, column) against plane `poff`, first tap row `r0`, vertical phase yf */
+/* Vertical pass + cost of the lane's (tile, column) against plane `poff` (8-bit samples): first tap row `r0` of tile
+ * row 0, vertical phase yf. The four lanes of a quad hold the four columns of a tile. SAD: the sum over the lane's
+ * column. SATD: the vertical Hadamard inside the lane, the horizontal one across the quad (DPP); the lane returns the
+ * abs-sum of its four coefficients and the caller halves the total (every tile's abs-sum is even, pixel.cpp:226). */
 template<int S>
-__device__ __forceinline__ int small_column_cost(int poff, int r0, int yf, bool satd, const ColTile<uint8_t> &ct, int x)
+__device__ __forceinline__ int small_column_cost(int poff, int r0, int yf, bool satd, const ColSrc &ct, int x)
 {
-    ColCand cc;
-    cc.poff = poff; cc.prow = SmallGeo<S>::PROW; cc.R0 = r0;
-    cc.shiftV = 12;                                  /* 6 + the headroom of 8-bit samples */
-    cc.offV = (1 << 11) + (8192 << 6);
-    cc.satd = satd ? 1 : 0;
-    const int *tp = (const int*)(x265amd_smem + SM_TAPS) + yf * 12;
+    const int R = r0 + 4 * ct.ty;
+    const uint32_t *col = (const uint32_t*)(x265amd_smem + poff + (__mul24(ct.col, SmallGeo<S>::PROW) + (R & ~1)) * 2);
+    const uint32_t *tp = (const uint32_t*)(x265amd_smem + SM_VTAPS) + ((yf << 1) | (r0 & 1)) * 10;
+    uint32_t E[6], P[5], Q[5];
 #pragma unroll
-    for (int k = 0; k < 4; k++) cc.ev[k] = (uint32_t)tp[k];
+    for (int i = 0; i < 6; i++) E[i] = col[i];
 #pragma unroll
-    for (int k = 0; k < 5; k++) cc.od[k] = (uint32_t)tp[4 + k];
-    return plane_column_cost<uint8_t>(0, cc, ct, x, 8);
+    for (int i = 0; i < 5; i++) { P[i] = tp[i]; Q[i] = tp[5 + i]; }
+    constexpr int OFF = ((1 << 11) + (8192 << 6)) << 4;     /* luma_vsp's rounding and the intermediates' bias, scaled like the taps */
+    int o[4];
+    o[0] = dot2(E[0], P[0], dot2(E[1], P[1], dot2(E[2], P[2], dot2(E[3], P[3], dot2(E[4], P[4], OFF)))));
+    o[1] = dot2(E[0], Q[0], dot2(E[1], Q[1], dot2(E[2], Q[2], dot2(E[3], Q[3], dot2(E[4], Q[4], OFF)))));
+    o[2] = dot2(E[1], P[0], dot2(E[2], P[1], dot2(E[3], P[2], dot2(E[4], P[3], dot2(E[5], P[4], OFF)))));
+    o[3] = dot2(E[1], Q[0], dot2(E[2], Q[1], dot2(E[3], Q[2], dot2(E[4], Q[3], dot2(E[5], Q[4], OFF)))));
+    /* the high halves are (int16_t)(sum >> 12); clipped to 0 .. 255 as pairs */
+    const s16x2 lo = { 0, 0 }, hi = { 255, 255 }, one = { 1, 1 };
+    s16x2 p01 = __builtin_bit_cast(s16x2, __builtin_amdgcn_perm((uint32_t)o[1], (uint32_t)o[0], 0x07060302u));
+    s16x2 p23 = __builtin_bit_cast(s16x2, __builtin_amdgcn_perm((uint32_t)o[3], (uint32_t)o[2], 0x07060302u));
+    p01 = __builtin_elementwise_min(__builtin_elementwise_max(p01, lo), hi);
+    p23 = __builtin_elementwise_min(__builtin_elementwise_max(p23, lo), hi);
+    const s16x2 d01 = __builtin_bit_cast(s16x2, ct.f01) - p01, d23 = __builtin_bit_cast(s16x2, ct.f23) - p23;
+    if (!satd)
+    {
+        const s16x2 a = __builtin_elementwise_max(d01, -d01), b = __builtin_elementwise_max(d23, -d23);
+        return __builtin_amdgcn_sdot2(a, one, __builtin_amdgcn_sdot2(b, one, 0, false), false);
+    }
+    /* differences and every Hadamard stage fit int16 (16 * 255) */
+    const s16x2 Sm = d01 + d23, Df = d01 - d23;                     /* (r0+r2, r1+r3), (r0-r2, r1-r3) */
+    const s16x2 A = __builtin_shufflevector(Sm, Df, 0, 2), B = __builtin_shufflevector(Sm, Df, 1, 3);
+    s16x2 U = A + B, W = A - B;                                     /* vertical coefficients (c0, c2), (c1, c3) */
+    const short m1 = (short)(1 - 2 * (x & 1)), m2 = (short)(1 - (x & 2));
+    const s16x2 s1 = { m1, m1 }, s2 = { m2, m2 };
+    U = U * s1 + __builtin_bit_cast(s16x2, dpp_all<0xB1>(__builtin_bit_cast(int, U)));
+    W = W * s1 + __builtin_bit_cast(s16x2, dpp_all<0xB1>(__builtin_bit_cast(int, W)));
+    U = U * s2 + __builtin_bit_cast(s16x2, dpp_all<0x4E>(__builtin_bit_cast(int, U)));
+    W = W * s2 + __builtin_bit_cast(s16x2, dpp_all<0x4E>(__builtin_bit_cast(int, W)));
+    U = __builtin_elementwise_max(U, -U);
+    W = __builtin_elementwise_max(W, -W);
+    return __builtin_amdgcn_sdot2(U, one, __builtin_amdgcn_sdot2(W, one, 0, false), false);
 }
 
 /* the lane's tile column of the source block */
 template<int S>
-__device__ __forceinline__ void small_source_column(const uint8_t AS1 *fenc0, int fstride, int pux, int puy, int l, ColTile<uint8_t> &ct)
+__device__ __forceinline__ void small_source_column(const uint8_t AS1 *fenc0, int fstride, int pux, int puy, int l, ColSrc &ct)
 {
     typedef SmallGeo<S> G;
     const int t = l >> 2, tx = t & (G::TW - 1), ty = t >> G::LTW;
     ct.ty = ty; ct.col = tx * 4 + (l & 3);
     const uint8_t AS1 *src = fenc0 + (long)(puy + ty * 4) * fstride + pux + ct.col;
+    uint32_t f[4];
 #pragma unroll
-    for (int y = 0; y < 4; y++) ct.f[y] = (int)src[(long)y * fstride];
+    for (int y = 0; y < 4; y++) f[y] = (uint32_t)src[(long)y * fstride];
+    ct.f01 = f[0] | (f[1] << 16); ct.f23 = f[2] | (f[3] << 16);
 }
 
 /* the planes of a job: the launch's own, or its entry of the pair table (as job_planes, per lane) */
@@ -126,8 +206,7 @@ __device__ __forceinline__ void small_planes(const SearchArgs &a, int d1, const 
 template<int S> struct RefineLds
 {
     typedef SmallGeo<S> G;
-    static constexpr int PARAMS = 192;                              /* per PU, 48 bytes: 3 source offsets, row pitch, 3 phases, -, plane origin (64 bit) */
-    static constexpr int PLANES = PARAMS + G::NPU * 48;
+    static constexpr int PLANES = SM_FIXED;
     static constexpr int PU_BYTES = 3 * G::PLANE + 4;               /* the odd dword staggers the PUs over the LDS banks */
     static constexpr int TOTAL = PLANES + G::NPU * PU_BYTES + 32;
 };
@@ -144,16 +223,18 @@ template<int S> struct RefineSmall
     int rstride;
     /* per lane */
     int lane, grp, l;
-    ColTile<uint8_t> ct;
+    ColSrc ct;
     const uint16_t AS1 *ctab;
 
-    /* One refinement round for every PU of the wave: `dirs` neighbours of (qx, qy) at distance `step`, plus the
-     * centre itself first when `centre` (the SATD re-measure of motion.cpp:1086, :1117, whose cost replaces
-     * bcost). dirs = 0 with centre measures the centre alone (the closing SATD of subme 0). */
-    __device__ __forceinline__ void round(int step, int dirs, bool satd, bool centre)
+    /* One refinement round for every PU of the wave: DIRS neighbours of (qx, qy) at distance `step`, plus the
+     * centre itself first when CENTRE (the SATD re-measure of motion.cpp:1086, :1117, whose cost replaces
+     * bcost). DIRS = 0 with CENTRE measures the centre alone (the closing SATD of subme 0). The candidate loop is
+     * unrolled, so which plane and which of the three first rows / phases a candidate reads is fixed at compile time. */
+    template<int DIRS, bool CENTRE>
+    __device__ __forceinline__ void round_t(int step, bool satd)
     {
         constexpr unsigned long long SQX = nibs({ 0, 0, 0, -1, 1, -1, -1, 1, 1 }), SQY = nibs({ 0, -1, 1, 0, 0, -1, 1, -1, 1 });
-        const int k0 = centre ? 1 : 0, K = k0 + dirs;
+        constexpr int k0 = CENTRE ? 1 : 0, K = k0 + DIRS;
         /* lambda * bits of the candidate this lane folds (bitcost.h:46: the sum wraps at 16 bits) */
         int mvc = 0;
         {
@@ -162,56 +243,87 @@ template<int S> struct RefineSmall
             if (l < K && active) mvc = ((int)ctab[tx - mvpx] + (int)ctab[ty - mvpy]) & 0xffff;
         }
         /* rows of the planes: the candidates' first rows are ymin or ymin + 1 */
-        const int ya = as_i16(qy - step) >> 2, yb = qy >> 2, yc = as_i16(qy + step) >> 2;
-        int ymin = ya < yb ? ya : yb;
-        ymin = yc < ymin ? yc : ymin;
-        wave_sync();
-        if (l < 3)
+        int r0y[3], phy[3];
+#pragma unroll
+        for (int d = 0; d < 3; d++)
         {
-            const int xp = as_i16(qx + (l - 1) * step);
-            int *prm = (int*)(x265amd_smem + L::PARAMS + grp * 48);
-            prm[l] = roff + __mul24(ymin - 3, rstride) + (xp >> 2) - 3;
-            prm[4 + l] = xp & 3;
-            if (l == 0)
+            const int ty = as_i16(qy + (d - 1) * step);
+            r0y[d] = ty >> 2; phy[d] = ty & 3;
+        }
+        int ymin = r0y[0] < r0y[1] ? r0y[0] : r0y[1];
+        ymin = r0y[2] < ymin ? r0y[2] : ymin;
+#pragma unroll
+        for (int d = 0; d < 3; d++) r0y[d] -= ymin;
+        /* the three planes of the PU: where their first sample lies in the reference, and the phase */
+        const uint8_t AS1 *src[3];
+        const int *htap[3];
+        const int first = roff + __mul24(ymin - 3, rstride) - 3;
+#pragma unroll
+        for (int p = 0; p < 3; p++)
+        {
+            const int xp = as_i16(qx + (p - 1) * step);
+            src[p] = ref0 + (first + (xp >> 2));
+            htap[p] = (const int*)(x265amd_smem + SM_TAPS) + (xp & 3) * 12;
+        }
+        const int pbase = L::PLANES + grp * L::PU_BYTES;
+        wave_sync();
+        /* horizontal pass: the lanes of a PU fill its own three planes, so everything they need is in their registers */
+        if constexpr (S == 8)
+        {
+#pragma unroll
+            for (int it = 0; it < 6; it++)
             {
-                prm[3] = rstride;
-                *(unsigned long long*)(prm + 8) = (unsigned long long)ref0;
+                const int p = it >> 1, item = (it & 1) * 16 + l, r = item >> 1, q = item & 1;
+                hps_quad(src[p] + (__mul24(r, rstride) + 4 * q), htap[p],
+                         (int16_t*)(x265amd_smem + pbase + p * G::PLANE) + (4 * q) * G::PROW + r, G::PROW);
             }
         }
-        wave_sync();
-        /* horizontal pass: 3 planes per PU */
-        constexpr int TOTAL = G::NPU * 3 * G::IPP;
-#pragma unroll 2
-        for (int i0 = 0; i0 < TOTAL; i0 += 64)
+        else
         {
-            const int item = i0 + lane < TOTAL ? i0 + lane : TOTAL - 1;     /* a short last pass repeats the last item */
-            const int pu = item / (3 * G::IPP), rem = item - pu * (3 * G::IPP);
-            const int p = rem / G::IPP, rr = rem - p * G::IPP, r = rr >> G::LTW, q = rr & (G::TW - 1);
-            const int *prm = (const int*)(x265amd_smem + L::PARAMS + pu * 48);
-            hps_quad((const uint8_t AS1*)*(const unsigned long long*)(prm + 8) + prm[p] + __mul24(r, prm[3]) + 4 * q,
-                     (const int*)(x265amd_smem + SM_TAPS) + prm[4 + p] * 12,
-                     (int16_t*)(x265amd_smem + L::PLANES + pu * L::PU_BYTES + p * G::PLANE) + (4 * q) * G::PROW + r, G::PROW);
+            constexpr int TOTAL = 3 * G::IPP;
+#pragma unroll
+            for (int i0 = 0; i0 < TOTAL; i0 += 64)
+            {
+                const int item = i0 + l < TOTAL ? i0 + l : TOTAL - 1;     /* a short last pass repeats the last item */
+                const int p = (item >= G::IPP ? 1 : 0) + (item >= 2 * G::IPP ? 1 : 0), rr = item - p * G::IPP;
+                const int r = rr >> G::LTW, q = rr & (G::TW - 1);
+                const uint8_t AS1 *sp = p == 0 ? src[0] : (p == 1 ? src[1] : src[2]);
+                const int *tp = p == 0 ? htap[0] : (p == 1 ? htap[1] : htap[2]);
+                hps_quad(sp + (__mul24(r, rstride) + 4 * q), tp,
+                         (int16_t*)(x265amd_smem + pbase + p * G::PLANE) + (4 * q) * G::PROW + r, G::PROW);
+            }
         }
         wave_sync();
         /* vertical pass + cost: candidate c of every PU per pass, a lane per (tile, column) */
         int mycost = 0;
+#pragma unroll
         for (int c = 0; c < K; c++)
         {
-            const int i = c + 1 - k0;
-            const int ty = as_i16(qy + nib(SQY, i) * step);
-            int v = small_column_cost<S>(L::PLANES + grp * L::PU_BYTES + (nib(SQX, i) + 1) * G::PLANE, (ty >> 2) - ymin, ty & 3, satd, ct, l & 3);
+            const int i = c + 1 - k0, dx = nib(SQX, i), dy = nib(SQY, i);
+            int v = small_column_cost<S>(pbase + (dx + 1) * G::PLANE, r0y[dy + 1], phy[dy + 1], satd, ct, l & 3);
             v = seg_sum(v, G::LG);
             if (l == c) mycost = (satd ? v >> 1 : v) + mvc;   /* every 4x4 abs-sum is even: halving the total = halving per tile */
         }
         /* the reference's strict '<' over the candidates in table order */
-        if (centre && active) bcost = grp_lane<G::LG>(mycost, 0);
-        int key = 0x7fffffff;
-        if (l >= k0 && l < K) key = (mycost << 6) | l;
-        key = grp_min<G::LG>(key);
+        if (CENTRE && active) bcost = grp_lane<G::LG>(mycost, 0);
         int bdir = 0;
-        if (active && (key >> 6) < bcost) { bcost = key >> 6; bdir = (key & 63) - k0 + 1; }
+        if (DIRS)
+        {
+            int key = 0x7fffffff;
+            if (l >= k0 && l < K) key = (mycost << 6) | l;
+            key = grp_min<G::LG>(key);
+            if (active && (key >> 6) < bcost) { bcost = key >> 6; bdir = (key & 63) - k0 + 1; }
+        }
         qx = as_i16(qx + nib(SQX, bdir) * step); qy = as_i16(qy + nib(SQY, bdir) * step);
         if (active) nsub += (unsigned)K;
+    }
+
+    /* the rounds the workload table can ask for (motion.cpp:53-63: four or eight directions) */
+    __device__ __forceinline__ void round(int step, int dirs, bool satd, bool centre)
+    {
+        if (dirs == 8) { if (centre) round_t<8, true>(step, satd); else round_t<8, false>(step, satd); }
+        else if (dirs == 4) { if (centre) round_t<4, true>(step, satd); else round_t<4, false>(step, satd); }
+        else if (centre) round_t<0, true>(step, satd);
     }
 };
 
@@ -242,7 +354,7 @@ __global__ __launch_bounds__(64) void refine_small_kernel(SearchArgs a)
     small_planes(a, d1, fenc0, fstride, R.ref0, R.rstride);
     R.roff = puy * R.rstride + pux;
     R.ctab = (const uint16_t AS1*)a.ctab;
-    if (R.lane < 48) ((int*)(x265amd_smem + SM_TAPS))[R.lane] = kTapWords.w[R.lane];
+    small_load_taps(R.lane);
     small_source_column<S>(fenc0, fstride, pux, puy, R.l, R.ct);
     /* SubpelWorkload, motion.cpp:53-63, and the round sequence of :1100-1141 */
     const int hpel_iters = kWorkload[a.subme][0], hpel_dirs = kWorkload[a.subme][1];
@@ -268,6 +380,147 @@ __global__ __launch_bounds__(64) void refine_small_kernel(SearchArgs a)
     }
 }
 
+/* ---------------------------------------------------------------- sub-pel refinement of 32x32 and 64x64 PUs
+ *
+ * The same rounds with a workgroup per PU: a lane per (tile, column) makes 4 waves for a 32x32 PU and 16 for a
+ * 64x64 one, where the one-wave search walks the PU's 64 or 256 tiles in passes and holds its SIMD with one long
+ * dependent chain. The three planes of a round are filled by all waves together; every wave measures its 16 tiles of
+ * every candidate and adds the wave's sum to the candidate's cell in LDS (one cell array per round, zeroed at the
+ * start, so no round has to wait for cells to be cleared); after the barrier every wave reads the same totals and
+ * takes the same decisions on its own copy of the PU's values. */
+template<int S> struct BigLds
+{
+    typedef SmallGeo<S> G;
+    static constexpr int PARAMS = SM_FIXED;                         /* as RefineLds: 48 bytes */
+    static constexpr int CELLS = PARAMS + 48;                       /* per round 16 candidate sums */
+    static constexpr int ROUNDS = 5;                                /* motion.cpp:53-63: at most 2 + 2 rounds, or the closing re-measure */
+    static constexpr int PLANES = CELLS + ROUNDS * 64;
+    static constexpr int TOTAL = PLANES + 3 * G::PLANE + 32;
+};
+
+template<int S>
+__global__ __launch_bounds__(SmallGeo<S>::WAVES * 64) void refine_big_kernel(SearchArgs a)
+{
+    typedef SmallGeo<S> G;
+    typedef BigLds<S> L;
+    constexpr int THREADS = G::WAVES * 64;
+    static_assert(G::NPU == 1 && G::WAVES > 1, "a workgroup per PU");
+    const int j = xcd_remap((int)blockIdx.x, a.njobs);
+    if (j >= a.njobs) return;
+    const int tid = (int)threadIdx.x, lane = tid & 63;
+    const int *job = (const int*)(a.jobs + j);
+    const int d0 = uni(job[0]), d1 = uni(job[1]), d4 = uni(job[4]);
+    const int pux = as_i16(d0), puy = d0 >> 16;
+    int *res = (int*)(a.results + j);
+    const int r0 = uni(res[0]);
+    int qx = as_i16(r0), qy = r0 >> 16, bcost = uni(res[1]);
+    unsigned nsub = (unsigned)uni(res[3]);
+    const int mvpx = as_i16(d4), mvpy = d4 >> 16;
+    /* a PU whose full-pel cost is 0 is not refined (motion.cpp:1073-1076), a negative cost marks a job that was
+     * refused; PUs of other sizes are final already */
+    if ((d1 & 0xffff) != G::SIZE_CODE || bcost <= 0) return;
+    const uint8_t AS1 *fenc0, *ref0;
+    int fstride, rstride;
+    small_planes(a, d1, fenc0, fstride, ref0, rstride);
+    const int roff = puy * rstride + pux;
+    const uint16_t AS1 *ctab = (const uint16_t AS1*)a.ctab;
+    small_load_taps(tid);
+    if (tid < L::ROUNDS * 16) ((int*)(x265amd_smem + L::CELLS))[tid] = 0;
+    ColSrc ct;
+    small_source_column<S>(fenc0, fstride, pux, puy, tid, ct);
+    int rnd = 0;
+    __syncthreads();
+
+    /* one refinement round, as RefineSmall::round */
+    auto round = [&](int step, int dirs, bool satd, bool centre)
+    {
+        constexpr unsigned long long SQX = nibs({ 0, 0, 0, -1, 1, -1, -1, 1, 1 }), SQY = nibs({ 0, -1, 1, 0, 0, -1, 1, -1, 1 });
+        const int k0 = centre ? 1 : 0, K = k0 + dirs;
+        int mvc = 0;
+        {
+            const int i = lane < K ? lane + 1 - k0 : 0;
+            const int tx = as_i16(qx + nib(SQX, i) * step), ty = as_i16(qy + nib(SQY, i) * step);
+            if (lane < K) mvc = ((int)ctab[tx - mvpx] + (int)ctab[ty - mvpy]) & 0xffff;
+        }
+        const int ya = as_i16(qy - step) >> 2, yb = qy >> 2, yc = as_i16(qy + step) >> 2;
+        int ymin = ya < yb ? ya : yb;
+        ymin = yc < ymin ? yc : ymin;
+        /* source offset and phase of the three planes (wave-uniform) */
+        int poffs[3], pph[3];
+#pragma unroll
+        for (int p = 0; p < 3; p++)
+        {
+            const int xp = as_i16(qx + (p - 1) * step);
+            poffs[p] = roff + __mul24(ymin - 3, rstride) + (xp >> 2) - 3;
+            pph[p] = xp & 3;
+        }
+        /* horizontal pass: all waves, plane by plane (every wave is past the vertical pass of the round before: it
+         * has read that round's totals behind a barrier) */
+#pragma unroll
+        for (int p = 0; p < 3; p++)
+        {
+            const int *tp = (const int*)(x265amd_smem + SM_TAPS) + pph[p] * 12;
+            int16_t *plane = (int16_t*)(x265amd_smem + L::PLANES + p * G::PLANE);
+            for (int item = tid; item < G::IPP; item += THREADS)
+            {
+                const int r = item >> G::LTW, q = item & (G::TW - 1);
+                hps_quad(ref0 + poffs[p] + __mul24(r, rstride) + 4 * q, tp, plane + (4 * q) * G::PROW + r, G::PROW);
+            }
+        }
+        __syncthreads();
+        /* vertical pass + cost: a candidate per pass, the wave's 16 tiles of it */
+        int part = 0;
+        for (int c = 0; c < K; c++)
+        {
+            const int i = c + 1 - k0;
+            const int ty = as_i16(qy + nib(SQY, i) * step);
+            int v = small_column_cost<S>(L::PLANES + (nib(SQX, i) + 1) * G::PLANE, (ty >> 2) - ymin, ty & 3, satd, ct, tid & 3);
+            v = seg_sum(v, 6);
+            if (lane == c) part = v;
+        }
+        int *cells = (int*)(x265amd_smem + L::CELLS) + rnd * 16;
+        if (lane < K) atomicAdd(cells + lane, part);
+        __syncthreads();
+        int mycost = 0;
+        if (lane < K)
+        {
+            const int v = cells[lane];
+            mycost = (satd ? v >> 1 : v) + mvc;     /* every 4x4 abs-sum is even: halving the total = halving per tile */
+        }
+        if (centre) bcost = __shfl(mycost, 0);
+        int key = 0x7fffffff;
+        if (lane >= k0 && lane < K) key = (mycost << 6) | lane;
+        key = wave_min(key);
+        int bdir = 0;
+        if ((key >> 6) < bcost) { bcost = key >> 6; bdir = (key & 63) - k0 + 1; }
+        qx = as_i16(qx + nib(SQX, bdir) * step); qy = as_i16(qy + nib(SQY, bdir) * step);
+        nsub += (unsigned)K;
+        rnd++;
+    };
+
+    const int hpel_iters = kWorkload[a.subme][0], hpel_dirs = kWorkload[a.subme][1];
+    const int qpel_iters = kWorkload[a.subme][2], qpel_dirs = kWorkload[a.subme][3], hpel_satd = kWorkload[a.subme][4];
+    bool centre = hpel_satd != 0;
+    for (int it = 0; it < hpel_iters; it++)
+    {
+        round(2, hpel_dirs, hpel_satd != 0, centre);
+        centre = false;
+    }
+    centre = !hpel_satd;
+    if (centre && !qpel_iters) round(1, 0, true, true);
+    for (int it = 0; it < qpel_iters; it++)
+    {
+        round(1, qpel_dirs, true, centre);
+        centre = false;
+    }
+    if (tid == 0)
+    {
+        res[0] = (qx & 0xffff) | (qy << 16);
+        res[1] = bcost;
+        res[3] = (int)nsub;
+    }
+}
+
 /* ---------------------------------------------------------------- the common case of a STAR search
  *
  * Most PUs of a picture end their integer search where it began: the start-up candidates (motion.cpp:562-621)
@@ -285,7 +538,7 @@ __global__ __launch_bounds__(64) void refine_small_kernel(SearchArgs a)
 template<int S> struct StarLds
 {
     typedef SmallGeo<S> G;
-    static constexpr int PU = 192;                                  /* per PU, 16 bytes: plane origin (64 bit), row pitch, candidates in use */
+    static constexpr int PU = SM_FIXED;                             /* per PU, 16 bytes: plane origin (64 bit), row pitch, candidates in use */
     static constexpr int CAND = PU + G::NPU * 16;                   /* per PU and candidate, 8 bytes: source offset of the plane, x phase */
     static constexpr int PLANES = CAND + G::NPU * SM_SLOTS * 8;
     static constexpr int PU_BYTES = SM_SLOTS * G::PLANE + 4;
@@ -322,7 +575,7 @@ __global__ __launch_bounds__(64) void star_small_kernel(SearchArgs a)
     small_planes(a, d[1], fenc0, fstride, ref0, rstride);
     const int roff = puy * rstride + pux;
     const uint16_t AS1 *ctab = (const uint16_t AS1*)a.ctab;
-    if (lane < 48) ((int*)(x265amd_smem + SM_TAPS))[lane] = kTapWords.w[lane];
+    small_load_taps(lane);
 
     /* ---- start-up candidates, motion.cpp:575-621 (values every lane of the group holds) ---- */
     const int qmnx = as_i16(mnx << 2), qmny = as_i16(mny << 2), qmxx = as_i16(mxx << 2), qmxy = as_i16(mxy << 2);
@@ -393,7 +646,7 @@ __global__ __launch_bounds__(64) void star_small_kernel(SearchArgs a)
     }
     wave_sync();
     /* vertical pass + SAD: the k-th candidate in use of every PU per pass */
-    ColTile<uint8_t> ct;
+    ColSrc ct;
     small_source_column<S>(fenc0, fstride, pux, puy, l, ct);
     int mycost = 0;
     {
