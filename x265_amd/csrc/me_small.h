@@ -34,7 +34,6 @@ template<int S> struct SmallGeo
     static constexpr int LG = LT + 2;               /* log2 of the lanes of a PU's group: a lane per (tile, column) */
     static constexpr int LPP = 1 << LG;
     static constexpr int NPU = LPP < 64 ? 64 / LPP : 1;     /* PUs per wave */
-    static constexpr int WAVES = LPP > 64 ? LPP / 64 : 1;   /* waves per PU (32x32 and 64x64: a workgroup per PU) */
     static constexpr int ROWS = S + 8;              /* rows of a plane: the PU, the 7 rows the taps reach and one for a second first row */
     static constexpr int PROW = ROWS + 2;           /* int16 rows of a plane column, with slack for an odd first row */
     static constexpr int PLANE = S * PROW * 2;      /* bytes of one plane */
@@ -382,29 +381,36 @@ __global__ __launch_bounds__(64) void refine_small_kernel(SearchArgs a)
 
 /* ---------------------------------------------------------------- sub-pel refinement of 32x32 and 64x64 PUs
  *
- * The same rounds with a workgroup per PU: a lane per (tile, column) makes 4 waves for a 32x32 PU and 16 for a
- * 64x64 one, where the one-wave search walks the PU's 64 or 256 tiles in passes and holds its SIMD with one long
- * dependent chain. The three planes of a round are filled by all waves together; every wave measures its 16 tiles of
- * every candidate and adds the wave's sum to the candidate's cell in LDS (one cell array per round, zeroed at the
- * start, so no round has to wait for cells to be cleared); after the barrier every wave reads the same totals and
- * takes the same decisions on its own copy of the PU's values. */
+ * The same rounds for the large PUs: one wave per 32x32 PU and a workgroup of four waves per 64x64 PU, every lane
+ * looking after four (tile, column) pairs, one tile row band apart, where the one-wave search walks the PU's 64 or 256 tiles through
+ * its general candidate machinery. The three planes of a round are filled by all waves together; every wave measures
+ * its tiles of every candidate and adds the wave's sum to the candidate's cell in LDS (one cell array per round,
+ * zeroed at the start, so no round has to wait for cells to be cleared); after the barrier every wave reads the same
+ * totals and takes the same decisions on its own copy of the PU's values. Workgroups stay small on purpose: a
+ * sixteen-wave workgroup per 64x64 PU waits for a compute unit with that much room while launches of small PUs share
+ * the chip, and ended every step alone. */
+template<int S> struct BigGeo
+{
+    static_assert(S == 32 || S == 64, "32x32 or 64x64 PUs");
+    static constexpr int WAVES = S == 32 ? 1 : 4;
+    static constexpr int THREADS = WAVES * 64;
+    static constexpr int ITEMS = SmallGeo<S>::LPP / THREADS;        /* (tile, column) pairs per lane */
+};
 template<int S> struct BigLds
 {
     typedef SmallGeo<S> G;
-    static constexpr int PARAMS = SM_FIXED;                         /* as RefineLds: 48 bytes */
-    static constexpr int CELLS = PARAMS + 48;                       /* per round 16 candidate sums */
+    static constexpr int CELLS = SM_FIXED;                          /* per round 16 candidate sums */
     static constexpr int ROUNDS = 5;                                /* motion.cpp:53-63: at most 2 + 2 rounds, or the closing re-measure */
     static constexpr int PLANES = CELLS + ROUNDS * 64;
     static constexpr int TOTAL = PLANES + 3 * G::PLANE + 32;
 };
 
 template<int S>
-__global__ __launch_bounds__(SmallGeo<S>::WAVES * 64) void refine_big_kernel(SearchArgs a)
+__global__ __launch_bounds__(BigGeo<S>::THREADS) void refine_big_kernel(SearchArgs a)
 {
     typedef SmallGeo<S> G;
     typedef BigLds<S> L;
-    constexpr int THREADS = G::WAVES * 64;
-    static_assert(G::NPU == 1 && G::WAVES > 1, "a workgroup per PU");
+    constexpr int THREADS = BigGeo<S>::THREADS, ITEMS = BigGeo<S>::ITEMS;
     const int j = xcd_remap((int)blockIdx.x, a.njobs);
     if (j >= a.njobs) return;
     const int tid = (int)threadIdx.x, lane = tid & 63;
@@ -425,13 +431,14 @@ __global__ __launch_bounds__(SmallGeo<S>::WAVES * 64) void refine_big_kernel(Sea
     const int roff = puy * rstride + pux;
     const uint16_t AS1 *ctab = (const uint16_t AS1*)a.ctab;
     small_load_taps(tid);
-    if (tid < L::ROUNDS * 16) ((int*)(x265amd_smem + L::CELLS))[tid] = 0;
-    ColSrc ct;
-    small_source_column<S>(fenc0, fstride, pux, puy, tid, ct);
+    for (int i = tid; i < L::ROUNDS * 16; i += THREADS) ((int*)(x265amd_smem + L::CELLS))[i] = 0;
+    ColSrc ct[ITEMS];
+#pragma unroll
+    for (int u = 0; u < ITEMS; u++) small_source_column<S>(fenc0, fstride, pux, puy, tid + u * THREADS, ct[u]);
     int rnd = 0;
     __syncthreads();
 
-    /* one refinement round, as RefineSmall::round */
+    /* one refinement round, as RefineSmall::round_t */
     auto round = [&](int step, int dirs, bool satd, bool centre)
     {
         constexpr unsigned long long SQX = nibs({ 0, 0, 0, -1, 1, -1, -1, 1, 1 }), SQY = nibs({ 0, -1, 1, 0, 0, -1, 1, -1, 1 });
@@ -445,36 +452,32 @@ __global__ __launch_bounds__(SmallGeo<S>::WAVES * 64) void refine_big_kernel(Sea
         const int ya = as_i16(qy - step) >> 2, yb = qy >> 2, yc = as_i16(qy + step) >> 2;
         int ymin = ya < yb ? ya : yb;
         ymin = yc < ymin ? yc : ymin;
-        /* source offset and phase of the three planes (wave-uniform) */
-        int poffs[3], pph[3];
-#pragma unroll
-        for (int p = 0; p < 3; p++)
-        {
-            const int xp = as_i16(qx + (p - 1) * step);
-            poffs[p] = roff + __mul24(ymin - 3, rstride) + (xp >> 2) - 3;
-            pph[p] = xp & 3;
-        }
         /* horizontal pass: all waves, plane by plane (every wave is past the vertical pass of the round before: it
          * has read that round's totals behind a barrier) */
 #pragma unroll
         for (int p = 0; p < 3; p++)
         {
-            const int *tp = (const int*)(x265amd_smem + SM_TAPS) + pph[p] * 12;
+            const int xp = as_i16(qx + (p - 1) * step);
+            const uint8_t AS1 *src = ref0 + (roff + __mul24(ymin - 3, rstride) + (xp >> 2) - 3);
+            const int *tp = (const int*)(x265amd_smem + SM_TAPS) + (xp & 3) * 12;
             int16_t *plane = (int16_t*)(x265amd_smem + L::PLANES + p * G::PLANE);
             for (int item = tid; item < G::IPP; item += THREADS)
             {
                 const int r = item >> G::LTW, q = item & (G::TW - 1);
-                hps_quad(ref0 + poffs[p] + __mul24(r, rstride) + 4 * q, tp, plane + (4 * q) * G::PROW + r, G::PROW);
+                hps_quad(src + (__mul24(r, rstride) + 4 * q), tp, plane + (4 * q) * G::PROW + r, G::PROW);
             }
         }
         __syncthreads();
-        /* vertical pass + cost: a candidate per pass, the wave's 16 tiles of it */
+        /* vertical pass + cost: a candidate per pass, the wave's tiles of it */
         int part = 0;
         for (int c = 0; c < K; c++)
         {
             const int i = c + 1 - k0;
             const int ty = as_i16(qy + nib(SQY, i) * step);
-            int v = small_column_cost<S>(L::PLANES + (nib(SQX, i) + 1) * G::PLANE, (ty >> 2) - ymin, ty & 3, satd, ct, tid & 3);
+            const int poff = L::PLANES + (nib(SQX, i) + 1) * G::PLANE, rr = (ty >> 2) - ymin;
+            int v = 0;
+#pragma unroll
+            for (int u = 0; u < ITEMS; u++) v += small_column_cost<S>(poff, rr, ty & 3, satd, ct[u], tid & 3);
             v = seg_sum(v, 6);
             if (lane == c) part = v;
         }
@@ -527,21 +530,21 @@ __global__ __launch_bounds__(SmallGeo<S>::WAVES * 64) void refine_big_kernel(Sea
  * pick a full-pel start, none of the 20 points of the first three star rounds (distance 1, 2, 4; StarPatternSearch,
  * :307-547) beats it, three rounds without improvement end the pattern (earlyExitIters = 3, :914) and with
  * bDistance == 0 nothing else runs (:916-1017). For such a PU the order of the points does not matter -- only that
- * none is cheaper -- so the whole stage has a fixed shape: the start-up candidates as one plane + one vertical pass
- * each (all SAD; full-pel ones are the phase-0 case), the decisions of :575-621 on group-uniform values, then the 20
+ * none is cheaper -- so the whole stage has a fixed shape: the start-up candidates (the quarter-pel ones as one plane +
+ * one vertical pass each, all SAD; the rounded predictor and MV 0 as plain SADs), the decisions of :575-621 on group-uniform values, then the 20
  * points as plain SADs from a window of the reference staged in LDS, four points per pass. A PU one of whose points improves is left to the one-wave search from
  * the start, as are the PUs of other sizes: their result records get SMALL_REDO in sad_calls, and the search kernel
  * launched next over all jobs works on exactly those (its other waves leave at once; no counter or queue that a
  * picture full of such PUs could choke). The others get their record of the full-pel / predictor choice (:1063-1069)
  * written here, ready for refine_small_kernel. */
 #define SM_SLOTS 7                                  /* clipped predictor, its full-pel rounding, MV 0, four candidates */
+#define SM_PLANES 5                                 /* the slots that can lie between samples: all but the rounding and MV 0 */
 template<int S> struct StarLds
 {
     typedef SmallGeo<S> G;
-    static constexpr int PU = SM_FIXED;                             /* per PU, 16 bytes: plane origin (64 bit), row pitch, candidates in use */
-    static constexpr int CAND = PU + G::NPU * 16;                   /* per PU and candidate, 8 bytes: source offset of the plane, x phase */
-    static constexpr int PLANES = CAND + G::NPU * SM_SLOTS * 8;
-    static constexpr int PU_BYTES = SM_SLOTS * G::PLANE + 4;
+    static constexpr int PLANES = SM_FIXED;
+    static constexpr int PU_BYTES = SM_PLANES * G::PLANE + 4;       /* the planes, later the window of the star points */
+    static_assert((S + 8) * (S + 12) <= SM_PLANES * G::PLANE, "the window of the star points fits the planes");
     static constexpr int TOTAL = PLANES + G::NPU * PU_BYTES + 32;
 };
 
@@ -604,59 +607,101 @@ __global__ __launch_bounds__(64) void star_small_kernel(SearchArgs a)
     for (int i = 0; i < 4; i++)
         if (l == 3 + i) { sx = ccx[i]; sy = ccy[i]; on = cOn[i]; }
     on = l < SM_SLOTS && (act ? on : l == 0);
-    const int slotbits = (int)(grp_bits16<G::LG>(on) & 0x7f);
-    const int cidx = __builtin_popcount(slotbits & ((1 << l) - 1)), nact = __builtin_popcount(slotbits);
-    int kmax = __builtin_amdgcn_readlane(nact, 0);
+    /* slots 1 and 2 are whole-sample positions and measured as plain SADs; the others get a plane each */
+    const int planebits = (int)(grp_bits16<G::LG>(on) & 0x79);
+    const int nplanes = __builtin_popcount(planebits);
+    int kmax = __builtin_amdgcn_readlane(nplanes, 0);
     if (G::NPU > 1)
     {
-        const int n1 = __builtin_amdgcn_readlane(nact, 16), n2 = __builtin_amdgcn_readlane(nact, 32), n3 = __builtin_amdgcn_readlane(nact, 48);
+        const int n1 = __builtin_amdgcn_readlane(nplanes, 16), n2 = __builtin_amdgcn_readlane(nplanes, 32), n3 = __builtin_amdgcn_readlane(nplanes, 48);
         kmax = n1 > kmax ? n1 : kmax; kmax = n2 > kmax ? n2 : kmax; kmax = n3 > kmax ? n3 : kmax;
     }
     /* lambda * bits of the slot (bitcost.h:46); the clipped predictor itself carries none (motion.cpp:579-582) */
     int mvc = 0;
     if (on && act && l != 0) mvc = ((int)ctab[sx - mvpx] + (int)ctab[sy - mvpy]) & 0xffff;
-    if (on)
+    /* where the slot's plane begins in the reference, and its horizontal phase */
+    const int slot_off = roff + __mul24((sy >> 2) - 3, rstride) + (sx >> 2) - 3, slot_ph = sx & 3;
+
+    /* the lane's tile of the source block, for the plain SADs: a lane per (point, tile) */
+    const int tile = l & ((1 << G::LT) - 1), tlx = (tile & (G::TW - 1)) * 4, tly = (tile >> G::LTW) * 4;
+    uint32_t fq[4];
     {
-        int *cd = (int*)(x265amd_smem + L::CAND + (grp * SM_SLOTS + cidx) * 8);
-        cd[0] = roff + __mul24((sy >> 2) - 3, rstride) + (sx >> 2) - 3;
-        cd[1] = sx & 3;
+        const uint8_t AS1 *src = fenc0 + (long)(puy + tly) * fstride + pux + tlx;
+#pragma unroll
+        for (int y = 0; y < 4; y++) fq[y] = Px<uint8_t>::load_g(src + (long)y * fstride);
     }
-    if (l == 0)
+    /* slots 1 and 2: point 0 = the rounded predictor, point 1 = MV 0 */
+    int vdir = 0;
     {
-        int *pu = (int*)(x265amd_smem + L::PU + grp * 16);
-        *(unsigned long long*)pu = (unsigned long long)ref0;
-        pu[2] = rstride; pu[3] = nact;
-    }
-    wave_sync();
-    /* horizontal pass: the planes of the candidates in use, kmax per PU (a PU with fewer repeats its last) */
-    {
-        const int total = kmax * (G::NPU * G::IPP);
-        for (int i0 = 0; i0 < total; i0 += 64)
+        const int pnt = l >> G::LT;
+        if (pnt < 2)
         {
-            const int item = i0 + lane < total ? i0 + lane : total - 1;
-            const int k = item / (G::NPU * G::IPP), rem = item - k * (G::NPU * G::IPP);
-            const int pu = rem / G::IPP, rr = rem - pu * G::IPP, r = rr >> G::LTW, q = rr & (G::TW - 1);
-            const int *pp = (const int*)(x265amd_smem + L::PU + pu * 16);
-            const int kk = k < pp[3] ? k : pp[3] - 1;
-            const int *cd = (const int*)(x265amd_smem + L::CAND + (pu * SM_SLOTS + kk) * 8);
-            hps_quad((const uint8_t AS1*)*(const unsigned long long*)pp + cd[0] + __mul24(r, pp[2]) + 4 * q,
-                     (const int*)(x265amd_smem + SM_TAPS) + cd[1] * 12,
-                     (int16_t*)(x265amd_smem + L::PLANES + pu * L::PU_BYTES + kk * G::PLANE) + (4 * q) * G::PROW + r, G::PROW);
+            const uint8_t AS1 *rp = ref0 + roff + (long)__mul24((pnt ? 0 : bmy) + tly, rstride) + (pnt ? 0 : bmx) + tlx;
+#pragma unroll
+            for (int yy = 0; yy < 4; yy++) vdir = Px<uint8_t>::sad(fq[yy], Px<uint8_t>::load_g(rp + (long)yy * rstride), vdir);
+        }
+        vdir = seg_sum(vdir, G::LT);
+    }
+    /* horizontal pass: the lanes of a PU fill the planes of its own slots, kmax per PU (a PU with fewer repeats its
+     * last); slot values come from the lane that looks after the slot */
+    const int pbase = L::PLANES + grp * L::PU_BYTES;
+    wave_sync();
+    {
+        int rem = planebits, sk = 0;
+        if constexpr (S == 8)
+        {
+            for (int k = 0; k < kmax; k++)
+            {
+                if (rem) { sk = __builtin_ctz(rem); rem &= rem - 1; }
+                const int so = grp_lane<G::LG>(slot_off, sk), ph = grp_lane<G::LG>(slot_ph, sk);
+                const int kk = k < nplanes ? k : nplanes - 1;
+                const int *tp = (const int*)(x265amd_smem + SM_TAPS) + ph * 12;
+#pragma unroll
+                for (int it = 0; it < 2; it++)
+                {
+                    const int item = it * 16 + l, r = item >> 1, q = item & 1;
+                    hps_quad(ref0 + (so + __mul24(r, rstride) + 4 * q), tp,
+                             (int16_t*)(x265amd_smem + pbase + kk * G::PLANE) + (4 * q) * G::PROW + r, G::PROW);
+                }
+            }
+        }
+        else
+        {
+            /* 96 items per plane and 64 lanes: two planes in three passes */
+            for (int k = 0; k < kmax; k += 2)
+            {
+                int so[2], ph[2];
+#pragma unroll
+                for (int u = 0; u < 2; u++)
+                {
+                    if (rem) { sk = __builtin_ctz(rem); rem &= rem - 1; }
+                    so[u] = grp_lane<G::LG>(slot_off, sk); ph[u] = grp_lane<G::LG>(slot_ph, sk);
+                }
+#pragma unroll
+                for (int it = 0; it < 3; it++)
+                {
+                    const int item = it * 64 + l, pl = item >= G::IPP ? 1 : 0, rr = item - pl * G::IPP;
+                    const int r = rr >> G::LTW, q = rr & (G::TW - 1);
+                    const int kk = k + pl < nplanes ? k + pl : nplanes - 1;
+                    hps_quad(ref0 + ((pl ? so[1] : so[0]) + __mul24(r, rstride) + 4 * q),
+                             (const int*)(x265amd_smem + SM_TAPS) + (pl ? ph[1] : ph[0]) * 12,
+                             (int16_t*)(x265amd_smem + pbase + kk * G::PLANE) + (4 * q) * G::PROW + r, G::PROW);
+                }
+            }
         }
     }
     wave_sync();
-    /* vertical pass + SAD: the k-th candidate in use of every PU per pass */
+    /* vertical pass + SAD: the k-th plane of every PU per pass */
     ColSrc ct;
     small_source_column<S>(fenc0, fstride, pux, puy, l, ct);
     int mycost = 0;
     {
-        int rem = slotbits;
+        int rem = planebits, sk = 0;
         for (int k = 0; k < kmax; k++)
         {
-            const int sk = rem ? __builtin_ctz(rem) : 15;
-            rem &= rem - 1;
-            const int ysk = grp_lane<G::LG>(sy, sk < SM_SLOTS ? sk : 0);
-            int v = small_column_cost<S>(L::PLANES + grp * L::PU_BYTES + (k < nact ? k : nact - 1) * G::PLANE, 0, ysk & 3, false, ct, l & 3);
+            if (rem) { sk = __builtin_ctz(rem); rem &= rem - 1; }
+            const int ysk = grp_lane<G::LG>(sy, sk);
+            int v = small_column_cost<S>(pbase + (k < nplanes ? k : nplanes - 1) * G::PLANE, 0, ysk & 3, false, ct, l & 3);
             v = seg_sum(v, G::LG);
             if (l == sk) mycost = v + mvc;
         }
@@ -665,7 +710,8 @@ __global__ __launch_bounds__(64) void star_small_kernel(SearchArgs a)
     int bprecost = grp_lane<G::LG>(mycost, 0), bcost = bprecost;
     unsigned nsad = 0, nsub = 1;
     {
-        const int cFp = grp_lane<G::LG>(mycost, 1), cZero = grp_lane<G::LG>(mycost, 2);
+        const int cFp = grp_lane<G::LG>(vdir, 0) + grp_lane<G::LG>(mvc, 1);
+        const int cZero = grp_lane<G::LG>(vdir, 1 << G::LT) + grp_lane<G::LG>(mvc, 2);
         if (fpOn) { bcost = cFp; nsad++; }
         if (zeroOn)
         {
@@ -688,13 +734,6 @@ __global__ __launch_bounds__(64) void star_small_kernel(SearchArgs a)
      * A lane per (point, tile), four points per pass ---- */
     constexpr unsigned long long X4 = nibs({ 0, -1, 1, 0 }), Y4 = nibs({ -1, 0, 0, 1 });
     constexpr unsigned long long X8 = nibs({ 0, -1, 1, -2, 2, -1, 1, 0 }), Y8 = nibs({ -2, -1, -1, 0, 0, 1, 1, 2 });
-    const int tile = l & ((1 << G::LT) - 1), tlx = (tile & (G::TW - 1)) * 4, tly = (tile >> G::LTW) * 4;
-    uint32_t fq[4];
-    {
-        const uint8_t AS1 *src = fenc0 + (long)(puy + tly) * fstride + pux + tlx;
-#pragma unroll
-        for (int y = 0; y < 4; y++) fq[y] = Px<uint8_t>::load_g(src + (long)y * fstride);
-    }
     bool improve = false;
     unsigned npts = 0;
 #ifndef X265AMD_STAR_GLOBAL_LOADS
