@@ -43,10 +43,12 @@ def host_threads(args):
     return max(1, min(n, int(env))) if env.isdigit() else n
 
 
-def valu_bound(profile, kernels, pus, launch_s):
+def valu_bound(profile, kernels, pus, launch_s, step_pairs=0, step_s=0.0):
     """VALU-issue accounting of one launch class from the SQ counters kept in profiles/valu.json (per frame pair):
     wave instructions issued per PU and the fraction of the launch during which the chip's 1024 SIMDs would be busy
-    issuing them back to back (a wave64 VALU instruction occupies its SIMD for 4 cycles)."""
+    issuing them back to back (a wave64 VALU instruction occupies its SIMD for 4 cycles). The launch shares the chip
+    with the other classes' launches, so the figure that says how close the step is to the VALU issue bound is
+    step_busy_frac: the same for all kernels of a step over the step's duration."""
     if not profile:
         return None
     k = [profile["kernels_per_pair"][n] for n in kernels if n in profile["kernels_per_pair"]]
@@ -55,8 +57,11 @@ def valu_bound(profile, kernels, pus, launch_s):
     valu, salu, lds = (sum(x[c] for x in k) for c in ("valu", "salu", "lds"))
     per_pair_pus = profile["pus_per_pair"]
     npairs = pus / per_pair_pus
+    all_valu = profile.get("valu_wave_instr_per_pair_all_kernels")
     return {"issued_wave_instr_per_pu": {"valu": valu / per_pair_pus, "salu": salu / per_pair_pus, "lds": lds / per_pair_pus},
             "busy_frac": valu * npairs * 4 / (profile["simds"] * profile["clock_hz"] * launch_s),
+            "step_busy_frac": all_valu * step_pairs * 4 / (profile["simds"] * profile["clock_hz"] * step_s) if all_valu and step_s else None,
+            "step_valu_wave_instr_per_frame_pair": all_valu,
             "essential_wave_instr_per_pu": profile["essential_wave_instr_per_pu"],
             "source": profile["source"]}
 
@@ -214,7 +219,7 @@ def main():
     ap.add_argument("--prio", choices=("small", "big", "flat"), default="small",
                     help="which search stream gets the device's highest priority: small = the 8x8 class, whose launch is a chain of "
                          "three dependent kernels that should not end the step alone; big = the 64/32 class; flat = none")
-    ap.add_argument("--s32", choices=("big", "mid", "la", "own"), default="big",
+    ap.add_argument("--s32", choices=("big", "mid", "la", "own"), default="la",
                     help="pairs4: the stream of the 32x32 launch: behind the 64x64 launch, behind the 16x16 launch, behind the "
                          "lookahead field, or one of its own")
     ap.add_argument("--big-streams", type=int, default=1,
@@ -553,7 +558,7 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel": kernel, "launch_ms": launch_ms, "algorithmic_bytes_per_launch": alg_bytes,
-                         "valu": valu_bound(vprof, vprof["timed_kernels"], timed_cnt * B, launch_ms * 1e-3) if vprof else None,
+                         "valu": valu_bound(vprof, vprof["timed_kernels"], timed_cnt * B, launch_ms * 1e-3, B, elapsed / args.steps) if vprof else None,
                          "note": "the HBM figure prices the compulsory bytes with no reuse between PUs; the launch is bound "
                                  "by VALU issue (see valu), and its measured HBM traffic is far below the algorithmic bytes "
                                  "because neighbouring PUs share their windows through L2"},
