@@ -883,7 +883,7 @@ static int launch_esa(x265amd_ctx *c, const SearchArgs &a, int window_bytes, int
     if (b.staged == 8)
         hipLaunchKernelGGL(refine_small_kernel<8>, dim3((a.njobs + 3) / 4), dim3(64), RefineLds<8>::TOTAL, c->stream, b);
     else if (b.staged == 16)
-        hipLaunchKernelGGL(refine_small_kernel<16>, dim3(a.njobs), dim3(64), RefineLds<16>::TOTAL, c->stream, b);
+        hipLaunchKernelGGL(refine_small_kernel<16>, dim3((a.njobs + 3) / 4), dim3(64), RefineLds<16>::TOTAL, c->stream, b);
     HIPCHK(c, hipGetLastError());
     return X265AMD_OK;
 }
@@ -905,7 +905,8 @@ static int launch_search(x265amd_ctx *c, const SearchArgs &a, int is_lowres)
         static const bool no_big = getenv("X265AMD_NO_STAGED_BIG") != 0;                             /* measurements only */
         b.staged = sizeof(P) == 1 && !no_staged && (a.max_dim == 8 || a.max_dim == 16 || ((a.max_dim == 32 || a.max_dim == 64) && !no_big))
                  ? a.max_dim : 0;
-        const int npu = b.staged == 8 ? 4 : 1, groups = (a.njobs + npu - 1) / npu;
+        const int npu = b.staged == 8 ? 4 : 1, groups = (a.njobs + npu - 1) / npu;      /* star_small_kernel's PUs per wave */
+        const int rgroups = (a.njobs + 3) / 4;                                              /* refine_small_kernel's */
         if (b.staged && b.staged <= 16 && a.method == X265AMD_STAR && !no_star)
         {
             if (ensure(c, &c->d_redo, &c->redo_cap, sizeof(int) * ((size_t)REDO_LIST + a.njobs))) return X265AMD_EHIP;
@@ -925,9 +926,9 @@ static int launch_search(x265amd_ctx *c, const SearchArgs &a, int is_lowres)
         else
             hipLaunchKernelGGL((search_kernel<P, false>), dim3(a.njobs), dim3(64), wave_lds_bytes<P>(a.max_dim, true) + pad, c->stream, b);
         if (b.staged == 8)
-            hipLaunchKernelGGL(refine_small_kernel<8>, dim3(groups), dim3(64), RefineLds<8>::TOTAL, c->stream, b);
+            hipLaunchKernelGGL(refine_small_kernel<8>, dim3(rgroups), dim3(64), RefineLds<8>::TOTAL, c->stream, b);
         else if (b.staged == 16)
-            hipLaunchKernelGGL(refine_small_kernel<16>, dim3(groups), dim3(64), RefineLds<16>::TOTAL, c->stream, b);
+            hipLaunchKernelGGL(refine_small_kernel<16>, dim3(rgroups), dim3(64), RefineLds<16>::TOTAL, c->stream, b);
         else if (b.staged == 32)
             hipLaunchKernelGGL(refine_big_kernel<32>, dim3(a.njobs), dim3(BigGeo<32>::THREADS), BigLds<32>::TOTAL, c->stream, b);
         else if (b.staged == 64)

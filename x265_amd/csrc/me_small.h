@@ -202,17 +202,28 @@ __device__ __forceinline__ void small_planes(const SearchArgs &a, int d1, const 
 
 /* ---------------------------------------------------------------- sub-pel refinement */
 
+/* Sixteen lanes per PU and four PUs per wave for both sizes: a lane of an 8x8 PU looks after one (tile, column) pair,
+ * a lane of a 16x16 PU after four, one tile row apart -- its cross-lane sums and the bookkeeping of a candidate are
+ * then paid once per four pairs. */
+template<int S> struct RefineGeo
+{
+    static_assert(S == 8 || S == 16, "8x8 or 16x16 PUs");
+    static constexpr int LG = 4, LPP = 16, NPU = 4;
+    static constexpr int ITEMS = SmallGeo<S>::LPP / LPP;
+};
+
 template<int S> struct RefineLds
 {
     typedef SmallGeo<S> G;
     static constexpr int PLANES = SM_FIXED;
     static constexpr int PU_BYTES = 3 * G::PLANE + 4;               /* the odd dword staggers the PUs over the LDS banks */
-    static constexpr int TOTAL = PLANES + G::NPU * PU_BYTES + 32;
+    static constexpr int TOTAL = PLANES + RefineGeo<S>::NPU * PU_BYTES + 32;
 };
 
 template<int S> struct RefineSmall
 {
     typedef SmallGeo<S> G;
+    typedef RefineGeo<S> RG;
     typedef RefineLds<S> L;
     /* per PU, the same in every lane of its group */
     int qx, qy, bcost, mvpx, mvpy, roff;
@@ -222,7 +233,7 @@ template<int S> struct RefineSmall
     int rstride;
     /* per lane */
     int lane, grp, l;
-    ColSrc ct;
+    ColSrc ct[RG::ITEMS];
     const uint16_t AS1 *ctab;
 
     /* One refinement round for every PU of the wave: DIRS neighbours of (qx, qy) at distance `step`, plus the
@@ -253,64 +264,46 @@ template<int S> struct RefineSmall
         ymin = r0y[2] < ymin ? r0y[2] : ymin;
 #pragma unroll
         for (int d = 0; d < 3; d++) r0y[d] -= ymin;
-        /* the three planes of the PU: where their first sample lies in the reference, and the phase */
-        const uint8_t AS1 *src[3];
-        const int *htap[3];
+        const int pbase = L::PLANES + grp * L::PU_BYTES;
         const int first = roff + __mul24(ymin - 3, rstride) - 3;
+        wave_sync();
+        /* horizontal pass: the lanes of a PU fill its own three planes, so everything they need is in their registers */
 #pragma unroll
         for (int p = 0; p < 3; p++)
         {
             const int xp = as_i16(qx + (p - 1) * step);
-            src[p] = ref0 + (first + (xp >> 2));
-            htap[p] = (const int*)(x265amd_smem + SM_TAPS) + (xp & 3) * 12;
-        }
-        const int pbase = L::PLANES + grp * L::PU_BYTES;
-        wave_sync();
-        /* horizontal pass: the lanes of a PU fill its own three planes, so everything they need is in their registers */
-        if constexpr (S == 8)
-        {
+            const uint8_t AS1 *src = ref0 + (first + (xp >> 2));
+            const int *htap = (const int*)(x265amd_smem + SM_TAPS) + (xp & 3) * 12;
 #pragma unroll
-            for (int it = 0; it < 6; it++)
+            for (int it = 0; it < G::IPP / RG::LPP; it++)
             {
-                const int p = it >> 1, item = (it & 1) * 16 + l, r = item >> 1, q = item & 1;
-                hps_quad(src[p] + (__mul24(r, rstride) + 4 * q), htap[p],
-                         (int16_t*)(x265amd_smem + pbase + p * G::PLANE) + (4 * q) * G::PROW + r, G::PROW);
-            }
-        }
-        else
-        {
-            constexpr int TOTAL = 3 * G::IPP;
-#pragma unroll
-            for (int i0 = 0; i0 < TOTAL; i0 += 64)
-            {
-                const int item = i0 + l < TOTAL ? i0 + l : TOTAL - 1;     /* a short last pass repeats the last item */
-                const int p = (item >= G::IPP ? 1 : 0) + (item >= 2 * G::IPP ? 1 : 0), rr = item - p * G::IPP;
-                const int r = rr >> G::LTW, q = rr & (G::TW - 1);
-                const uint8_t AS1 *sp = p == 0 ? src[0] : (p == 1 ? src[1] : src[2]);
-                const int *tp = p == 0 ? htap[0] : (p == 1 ? htap[1] : htap[2]);
-                hps_quad(sp + (__mul24(r, rstride) + 4 * q), tp,
+                const int item = it * RG::LPP + l, r = item >> G::LTW, q = item & (G::TW - 1);
+                hps_quad(src + (__mul24(r, rstride) + 4 * q), htap,
                          (int16_t*)(x265amd_smem + pbase + p * G::PLANE) + (4 * q) * G::PROW + r, G::PROW);
             }
         }
         wave_sync();
-        /* vertical pass + cost: candidate c of every PU per pass, a lane per (tile, column) */
+        /* vertical pass + cost: candidate c of every PU per pass, a lane per (tile, column) or four of them */
         int mycost = 0;
 #pragma unroll
         for (int c = 0; c < K; c++)
         {
             const int i = c + 1 - k0, dx = nib(SQX, i), dy = nib(SQY, i);
-            int v = small_column_cost<S>(pbase + (dx + 1) * G::PLANE, r0y[dy + 1], phy[dy + 1], satd, ct, l & 3);
-            v = seg_sum(v, G::LG);
+            int v = 0;
+#pragma unroll
+            for (int u = 0; u < RG::ITEMS; u++)
+                v += small_column_cost<S>(pbase + (dx + 1) * G::PLANE, r0y[dy + 1], phy[dy + 1], satd, ct[u], l & 3);
+            v = seg_sum(v, RG::LG);
             if (l == c) mycost = (satd ? v >> 1 : v) + mvc;   /* every 4x4 abs-sum is even: halving the total = halving per tile */
         }
         /* the reference's strict '<' over the candidates in table order */
-        if (CENTRE && active) bcost = grp_lane<G::LG>(mycost, 0);
+        if (CENTRE && active) bcost = grp_lane<RG::LG>(mycost, 0);
         int bdir = 0;
         if (DIRS)
         {
             int key = 0x7fffffff;
             if (l >= k0 && l < K) key = (mycost << 6) | l;
-            key = grp_min<G::LG>(key);
+            key = grp_min<RG::LG>(key);
             if (active && (key >> 6) < bcost) { bcost = key >> 6; bdir = (key & 63) - k0 + 1; }
         }
         qx = as_i16(qx + nib(SQX, bdir) * step); qy = as_i16(qy + nib(SQY, bdir) * step);
@@ -330,12 +323,13 @@ template<int S>
 __global__ __launch_bounds__(64) void refine_small_kernel(SearchArgs a)
 {
     typedef SmallGeo<S> G;
-    const int ngroups = (a.njobs + G::NPU - 1) / G::NPU;
+    typedef RefineGeo<S> RG;
+    const int ngroups = (a.njobs + RG::NPU - 1) / RG::NPU;
     const int g = xcd_remap((int)blockIdx.x, ngroups);
     if (g >= ngroups) return;
     RefineSmall<S> R;
-    R.lane = (int)threadIdx.x; R.grp = R.lane >> G::LG; R.l = R.lane & (G::LPP - 1);
-    int j = g * G::NPU + R.grp;
+    R.lane = (int)threadIdx.x; R.grp = R.lane >> RG::LG; R.l = R.lane & (RG::LPP - 1);
+    int j = g * RG::NPU + R.grp;
     const bool valid = j < a.njobs;
     if (!valid) j = a.njobs - 1;
     const int *job = (const int*)(a.jobs + j);
@@ -354,7 +348,8 @@ __global__ __launch_bounds__(64) void refine_small_kernel(SearchArgs a)
     R.roff = puy * R.rstride + pux;
     R.ctab = (const uint16_t AS1*)a.ctab;
     small_load_taps(R.lane);
-    small_source_column<S>(fenc0, fstride, pux, puy, R.l, R.ct);
+#pragma unroll
+    for (int u = 0; u < RG::ITEMS; u++) small_source_column<S>(fenc0, fstride, pux, puy, R.l + u * RG::LPP, R.ct[u]);
     /* SubpelWorkload, motion.cpp:53-63, and the round sequence of :1100-1141 */
     const int hpel_iters = kWorkload[a.subme][0], hpel_dirs = kWorkload[a.subme][1];
     const int qpel_iters = kWorkload[a.subme][2], qpel_dirs = kWorkload[a.subme][3], hpel_satd = kWorkload[a.subme][4];
