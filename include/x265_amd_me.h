@@ -123,7 +123,9 @@ int x265amd_search_batch(x265amd_ctx *ctx, const x265amd_plane *fenc, const x265
  * engine's stream (x265amd_sync waits). The jobs are not validated. `max_pu_dim` (8, 16, 32,
  * 64; 0 = 64) is the largest PU width / height in the batch: LDS per PU is reserved for that
  * size, so batches of small PUs keep more PUs resident per CU; a larger job in the batch gets
- * cost -1 and is not searched. Planes must be readable 32 bytes past their last sample
+ * cost -1 and is not searched. With 8-bit samples the square PUs of exactly that size take the
+ * fixed-shape kernels (several PUs per wave, or several waves per PU), so a caller after
+ * throughput launches one batch per PU size; results do not depend on it. Planes must be readable 32 bytes past their last sample
  * (planes made by this library are). */
 int x265amd_search_batch_dev(x265amd_ctx *ctx, const x265amd_plane *fenc, const x265amd_plane *ref, int is_lowres,
                              int qp, int method, int subme,
@@ -144,6 +146,18 @@ int x265amd_search_batch_pairs(x265amd_ctx *ctx, const x265amd_pair *pairs, int 
                                const x265amd_job *jobs, int njobs, x265amd_result *results);
 int x265amd_search_batch_pairs_dev(x265amd_ctx *ctx, const void *d_pairs, int npairs, int qp, int method, int subme,
                                    const x265amd_job *d_jobs, int njobs, x265amd_result *d_results, int max_pu_dim);
+
+/* The checks x265amd_search_batch makes on host job arrays (partition of motion.cpp:119, numc, range, PU inside the
+ * source plane, search window + 8-tap apron inside the padded reference: what xSetSearchRange, TEncSearch.cpp:4188-4215,
+ * and the caller's margins guarantee in the reference), for a DEVICE-resident job list, which the *_dev entry points run
+ * as it is: a caller that builds or edits jobs on the device checks the list once and launches it as often as it likes.
+ * X265AMD_OK when every job may run; otherwise X265AMD_EINVAL, the message names the first offending job and why,
+ * *n_bad (optional) is how many there are and *first_bad (optional) the first one's index. Synchronous; no counterpart
+ * in the reference, which asserts. The pairs form takes the HOST pair array x265amd_pairs_upload was given. */
+int x265amd_check_jobs_dev(x265amd_ctx *ctx, const x265amd_plane *fenc, const x265amd_plane *ref, int is_lowres, int method,
+                           const x265amd_job *d_jobs, int njobs, int *n_bad, int *first_bad);
+int x265amd_check_jobs_pairs_dev(x265amd_ctx *ctx, const x265amd_pair *pairs, int npairs, int method,
+                                 const x265amd_job *d_jobs, int njobs, int *n_bad, int *first_bad);
 
 /* X265_FULL_SEARCH (encoder/motion.cpp:1021-1056) scans each PU's search range from a copy of
  * the reference window in LDS; ranges too large for the window are scanned in strips. `bytes`

@@ -76,16 +76,18 @@ def test_every_partition_every_method(engine8, oracle):
             assert np.array_equal(r["mv"], mv) and np.array_equal(r["cost"], cost), (mname, part)
 
 
-@pytest.mark.parametrize("size", [8, 16])
+@pytest.mark.parametrize("size", [8, 16, 32, 64])
 @pytest.mark.parametrize("mname", ["star", "hex", "dia", "umh"])
 def test_small_pu_batches_vs_oracle(engine8, oracle, mname, size):
-    """Batches whose largest PU is 8x8 or 16x16 take the staged route on 8-bit planes (the search up to the full-pel /
-    predictor choice -- for STAR the fixed-shape kernel with a queue for the PUs that leave the common case -- then the
-    sub-pel rounds of the square PUs of that size in their own kernel, four 8x8 PUs or one 16x16 PU per wave): every
-    subme level, batch sizes that are not multiples of four, other partitions mixed in (finished by the one-wave
-    search), and PUs whose full-pel cost is 0 (no refinement, motion.cpp:1073-1076)."""
+    """Batches whose largest PU is a square of 8, 16, 32 or 64 samples take the staged route on 8-bit planes (the search
+    up to the full-pel / predictor choice -- for STAR on 8x8 / 16x16 the fixed-shape kernel with a list of the PUs that
+    leave the common case -- then the sub-pel rounds of the square PUs of that size in their own kernel: four 8x8 or
+    16x16 PUs per wave, a wave per 32x32 PU, four waves per 64x64 PU): every subme level, batch sizes that are not
+    multiples of four, other partitions mixed in (finished by the one-wave search), and PUs whose full-pel cost is 0
+    (no refinement, motion.cpp:1073-1076)."""
     method = METHODS[mname]
-    others = [(8, 4), (4, 8)] if size == 8 else [(16, 8), (8, 16), (8, 8), (12, 16), (16, 4)]
+    others = {8: [(8, 4), (4, 8)], 16: [(16, 8), (8, 16), (8, 8), (12, 16), (16, 4)],
+              32: [(32, 16), (16, 32), (16, 16), (32, 24), (8, 32)], 64: [(64, 32), (32, 64), (64, 48), (16, 64), (32, 32)]}[size]
     W, H = 320, 192
     m = margin_for(method)
     for kind in ("texture", "noise"):
@@ -179,6 +181,33 @@ def test_edge_cases(engine8, oracle):
         assert np.array_equal(r["mv"], mv) and np.array_equal(r["cost"], cost)
         assert np.array_equal(r["sad_calls"], sc) and np.array_equal(r["subpel_calls"], qc)
     assert len(engine8.search_batch(pf, pf, make_jobs(0), 30, 1, 5)) == 0   # empty batch
+
+
+def test_device_resident_jobs_are_checkable(engine8):
+    """x265amd_check_jobs_dev / _pairs_dev: the host entry points' checks for job lists the *_dev entry points run as
+    they are -- a good list passes, a list with two jobs that must not run is refused with the first one named."""
+    W, H, m = 128, 128, margin_for(3)
+    fenc, _, org, stride = clip_planes(W, H, 8, "static", margin=m)
+    pf = engine8.upload_plane(fenc, W, H, m, m, stride)
+    jobs = random_jobs(np.random.default_rng(3), 200, W, H, 3)
+    d = engine8.device_alloc(jobs.nbytes)
+    engine8.upload(d, jobs.view(np.uint8))
+    engine8.check_jobs_dev(pf, pf, d, len(jobs), 3)
+    assert engine8.check_jobs_pairs_dev([(pf, pf)], d, len(jobs), 3) == (0, -1)
+    bad = jobs.copy()
+    bad["mvmax"][57] = (300, 4)         # window leaves the padded plane
+    bad["w"][150] = 20                  # not a partition
+    engine8.upload(d, bad.view(np.uint8))
+    with pytest.raises(EngineError, match="first is job 57: search window"):
+        engine8.check_jobs_dev(pf, pf, d, len(jobs), 3)
+    assert engine8.check_jobs_pairs_dev([(pf, pf)], d, len(jobs), 3) == (2, 57)
+    bad = jobs.copy()
+    bad["reserved"][9] = 1              # names a pair the table does not have
+    engine8.upload(d, bad.view(np.uint8))
+    assert engine8.check_jobs_pairs_dev([(pf, pf)], d, len(jobs), 3) == (1, 9)
+    engine8.check_jobs_dev(pf, pf, d, len(jobs), 3)      # one pair of planes for all jobs: the field is not read
+    engine8.device_free(d)
+    engine8.free_plane(pf)
 
 
 def test_argument_errors(engine8):

@@ -1223,37 +1223,90 @@ int x265amd_lowres_init(x265amd_ctx *c, const x265amd_plane *src, x265amd_plane 
 /* Every address a job can touch must lie inside the padded planes: candidates in
  * [mvmin-3, mvmax+3] (hexagon / square steps are unchecked), the 8-tap footprint of
  * the sub-pel refinement around them, and MV (0,0). */
+/* what a search needs to know of a plane to check a job against it */
+struct PlaneGeo
+{
+    int width, height, margin_x, margin_y;
+};
+static PlaneGeo geo_of(const x265amd_plane *p)
+{
+    PlaneGeo g = { p->width, p->height, p->margin_x, p->margin_y };
+    return g;
+}
+
+/* the luma partitions motionEstimate searches (primitives.h:65-73 without 4x4, motion.cpp:119): an edge of 8 .. 64
+ * and the other edge the same, a half, or -- from 16 up -- a quarter or three quarters of it */
+__host__ __device__ static inline bool searchable_partition(int w, int h)
+{
+    const int m = w > h ? w : h, n = w > h ? h : w;
+    if (!(m == 8 || m == 16 || m == 32 || m == 64)) return false;
+    if (n == m || n * 2 == m) return true;
+    return m > 8 && (n * 4 == m * 3 || n * 4 == m);
+}
+
+/* One job against its planes: 0, or why a search must not run it. The same function checks host job arrays before a
+ * launch and device-resident ones in check_jobs_kernel. */
+enum { JOB_OK = 0, JOB_PARTITION, JOB_LOWRES_SIZE, JOB_NUMC, JOB_RANGE, JOB_SOURCE, JOB_WINDOW, JOB_PAIR };
+__host__ __device__ static inline int job_fault(const x265amd_job &j, const PlaneGeo &f, const PlaneGeo &r, int is_lowres, int method)
+{
+    if (!searchable_partition(j.w, j.h)) return JOB_PARTITION;
+    if (is_lowres && !(j.w == 8 && j.h == 8)) return JOB_LOWRES_SIZE;
+    if (j.numc > 4) return JOB_NUMC;
+    if (j.mvmin[0] > j.mvmax[0] || j.mvmin[1] > j.mvmax[1]) return JOB_RANGE;
+    if (j.pu_x < 0 || j.pu_y < 0 || j.pu_x + j.w > f.width + f.margin_x || j.pu_y + j.h > f.height + f.margin_y) return JOB_SOURCE;
+    const int apron = 8;
+    const int lox = j.mvmin[0] < 0 ? j.mvmin[0] : 0, hix = j.mvmax[0] > 0 ? j.mvmax[0] : 0;
+    const int loy = j.mvmin[1] < 0 ? j.mvmin[1] : 0, hiy = j.mvmax[1] > 0 ? j.mvmax[1] : 0;
+    int x0 = j.pu_x + lox - apron, x1 = j.pu_x + j.w + hix + apron;
+    int y0 = j.pu_y + loy - apron, y1 = j.pu_y + j.h + hiy + apron;
+    if (method == X265AMD_UMH)
+    {
+        /* UMH measures its cross / diamond groups relative to the block it started from and
+         * its vertical cross at x = omv.x + omv.y (motion.cpp:732, :301-303), up to the
+         * rescaled range (x 6/4) away */
+        const int b = ((j.merange * 6) >> 2) + 6;
+        x0 = j.pu_x + lox + loy - b - apron; x1 = j.pu_x + j.w + hix + hiy + b + apron;
+        y0 = j.pu_y + loy - b - apron; y1 = j.pu_y + j.h + hiy + b + apron;
+    }
+    if (x0 < -r.margin_x || y0 < -r.margin_y || x1 > r.width + r.margin_x || y1 > r.height + r.margin_y) return JOB_WINDOW;
+    return JOB_OK;
+}
+static const char *job_fault_text(int code)
+{
+    static const char *const text[] = { "ok", "not a searchable luma partition", "lowres searches are 8x8 only", "numc > 4",
+                                        "empty search range", "PU outside the source plane",
+                                        "search window leaves the padded reference plane", "pair index beyond the table" };
+    return text[code];
+}
+
 static int validate_jobs(x265amd_ctx *c, const x265amd_plane *fenc, const x265amd_plane *ref, int is_lowres,
                          int method, int subme, const x265amd_job *jobs, int njobs)
 {
     if (method < 0 || method > X265AMD_FULL || subme < 0 || subme > 7) return fail(c, X265AMD_EINVAL, "bad method / subme");
+    const PlaneGeo f = geo_of(fenc), r = geo_of(ref);
     for (int i = 0; i < njobs; i++)
     {
-        const x265amd_job &j = jobs[i];
-        if (x265amd_partition_from_sizes(j.w, j.h) <= 0) return fail(c, X265AMD_EINVAL, "job: not a searchable luma partition");
-        if (is_lowres && !(j.w == 8 && j.h == 8)) return fail(c, X265AMD_EINVAL, "lowres searches are 8x8 only");
-        if (j.numc > 4) return fail(c, X265AMD_EINVAL, "job: numc > 4");
-        if (j.mvmin[0] > j.mvmax[0] || j.mvmin[1] > j.mvmax[1]) return fail(c, X265AMD_EINVAL, "job: empty search range");
-        if (j.pu_x < 0 || j.pu_y < 0 || j.pu_x + j.w > fenc->width + fenc->margin_x || j.pu_y + j.h > fenc->height + fenc->margin_y)
-            return fail(c, X265AMD_EINVAL, "job: PU outside the source plane");
-        const int apron = 8;
-        const int lox = j.mvmin[0] < 0 ? j.mvmin[0] : 0, hix = j.mvmax[0] > 0 ? j.mvmax[0] : 0;
-        const int loy = j.mvmin[1] < 0 ? j.mvmin[1] : 0, hiy = j.mvmax[1] > 0 ? j.mvmax[1] : 0;
-        int x0 = j.pu_x + lox - apron, x1 = j.pu_x + j.w + hix + apron;
-        int y0 = j.pu_y + loy - apron, y1 = j.pu_y + j.h + hiy + apron;
-        if (method == X265AMD_UMH)
-        {
-            /* UMH measures its cross / diamond groups relative to the block it started from and
-             * its vertical cross at x = omv.x + omv.y (motion.cpp:732, :301-303), up to the
-             * rescaled range (x 6/4) away */
-            const int b = ((j.merange * 6) >> 2) + 6;
-            x0 = j.pu_x + lox + loy - b - apron; x1 = j.pu_x + j.w + hix + hiy + b + apron;
-            y0 = j.pu_y + loy - b - apron; y1 = j.pu_y + j.h + hiy + b + apron;
-        }
-        if (x0 < -ref->margin_x || y0 < -ref->margin_y || x1 > ref->width + ref->margin_x || y1 > ref->height + ref->margin_y)
-            return fail(c, X265AMD_EINVAL, "job: search window leaves the padded reference plane");
+        const int code = job_fault(jobs[i], f, r, is_lowres, method);
+        if (code) return fail(c, X265AMD_EINVAL, std::string("job: ") + job_fault_text(code));
     }
     return 0;
+}
+
+/* device-resident jobs: out[0] = number of jobs that must not run, out[1] = the first of them (preset to njobs).
+ * `geo`: per pair the source and the reference plane (job.reserved picks the pair), or one pair for all jobs. */
+__global__ __launch_bounds__(256) void check_jobs_kernel(const x265amd_job *jobs, int njobs, const PlaneGeo *geo, int npairs,
+                                                          int by_pair, int is_lowres, int method, int *out)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= njobs) return;
+    const x265amd_job j = jobs[i];
+    const int pi = by_pair ? (int)j.reserved : 0;
+    const int code = pi >= npairs ? JOB_PAIR : job_fault(j, geo[2 * pi], geo[2 * pi + 1], is_lowres, method);
+    if (code)
+    {
+        atomicAdd(out, 1);
+        atomicMin(out + 1, i);
+    }
 }
 
 static void fill_args(x265amd_ctx *c, SearchArgs &a, const x265amd_plane *fenc, const x265amd_plane *ref, int is_lowres,
@@ -1358,6 +1411,60 @@ int x265amd_search_batch_pairs_dev(x265amd_ctx *c, const void *d_pairs, int npai
     if (!c || !d_pairs || npairs <= 0 || npairs > 256) return fail(c, X265AMD_EINVAL, "1 .. 256 pairs");
     return search_dev(c, 0, 0, 0, qp, method, subme, d_jobs, njobs, d_results, max_pu_dim, esa_window_for(c, max_pu_dim > 0 ? max_pu_dim : 64),
                       (const PairDev*)d_pairs, npairs);
+}
+
+/* the jobs of a device-resident list against their planes, before a *_dev entry point runs them unchecked */
+static int check_jobs_dev(x265amd_ctx *c, const std::vector<PlaneGeo> &geo, int by_pair, int is_lowres, int method,
+                          const x265amd_job *d_jobs, int njobs, int *n_bad, int *first_bad)
+{
+    if (!c || !d_jobs || njobs < 0) return fail(c, X265AMD_EINVAL, "null argument");
+    if (method < 0 || method > X265AMD_FULL) return fail(c, X265AMD_EINVAL, "bad method");
+    if (n_bad) *n_bad = 0;
+    if (first_bad) *first_bad = -1;
+    if (!njobs) return X265AMD_OK;
+    HIPCHK(c, hipSetDevice(c->device));
+    const size_t gbytes = geo.size() * sizeof(PlaneGeo);
+    if (ensure(c, &c->d_stage, &c->stage_cap, 16 + gbytes)) return X265AMD_EHIP;
+    int out[2] = { 0, njobs };
+    HIPCHK(c, hipMemcpyAsync(c->d_stage, out, sizeof(out), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync((char*)c->d_stage + 16, geo.data(), gbytes, hipMemcpyHostToDevice, c->stream));
+    hipLaunchKernelGGL(check_jobs_kernel, dim3((njobs + 255) / 256), dim3(256), 0, c->stream, d_jobs, njobs,
+                       (const PlaneGeo*)((char*)c->d_stage + 16), (int)(geo.size() / 2), by_pair, is_lowres, method, (int*)c->d_stage);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipMemcpyAsync(out, c->d_stage, sizeof(out), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (n_bad) *n_bad = out[0];
+    if (!out[0]) return X265AMD_OK;
+    if (first_bad) *first_bad = out[1];
+    x265amd_job j;
+    HIPCHK(c, hipMemcpy(&j, d_jobs + out[1], sizeof(j), hipMemcpyDeviceToHost));
+    const int pi = by_pair ? (int)j.reserved : 0;
+    const int code = pi >= (int)(geo.size() / 2) ? JOB_PAIR : job_fault(j, geo[2 * pi], geo[2 * pi + 1], is_lowres, method);
+    return fail(c, X265AMD_EINVAL, std::to_string(out[0]) + " job(s) must not run; the first is job " + std::to_string(out[1]) + ": " +
+                job_fault_text(code));
+}
+
+int x265amd_check_jobs_dev(x265amd_ctx *c, const x265amd_plane *fenc, const x265amd_plane *ref, int is_lowres, int method,
+                           const x265amd_job *d_jobs, int njobs, int *n_bad, int *first_bad)
+{
+    if (!c || !fenc || !ref) return fail(c, X265AMD_EINVAL, "null argument");
+    std::vector<PlaneGeo> geo;
+    geo.push_back(geo_of(fenc));
+    geo.push_back(geo_of(ref));
+    return check_jobs_dev(c, geo, 0, is_lowres, method, d_jobs, njobs, n_bad, first_bad);
+}
+
+int x265amd_check_jobs_pairs_dev(x265amd_ctx *c, const x265amd_pair *pairs, int npairs, int method,
+                                 const x265amd_job *d_jobs, int njobs, int *n_bad, int *first_bad)
+{
+    if (!c || !pairs || npairs <= 0 || npairs > 256) return fail(c, X265AMD_EINVAL, "1 .. 256 pairs");
+    std::vector<PlaneGeo> geo;
+    for (int i = 0; i < npairs; i++)
+    {
+        geo.push_back(geo_of(&pairs[i].fenc));
+        geo.push_back(geo_of(&pairs[i].ref));
+    }
+    return check_jobs_dev(c, geo, 1, 0, method, d_jobs, njobs, n_bad, first_bad);
 }
 
 int x265amd_search_batch_pairs(x265amd_ctx *c, const x265amd_pair *pairs, int npairs, int qp, int method, int subme,

@@ -252,6 +252,26 @@ class Engine:
         self._chk(self.L.x265amd_search_batch_dev(self.ctx, C.byref(fenc), refs, int(is_lowres), qp, method, subme,
                                                   C.c_void_p(d_jobs), njobs, C.c_void_p(d_results), max_pu_dim))
 
+    def check_jobs_dev(self, fenc, ref, d_jobs, njobs, method, is_lowres=False):
+        """The host entry points' checks for a device-resident job list (which search_batch_dev runs as it is):
+        raises EngineError naming the first job that must not run; returns nothing when all may."""
+        refs = (Plane * 4)(*ref) if is_lowres else (Plane * 1)(ref if isinstance(ref, Plane) else ref[0])
+        self._chk(self.L.x265amd_check_jobs_dev(self.ctx, C.byref(fenc), refs, int(is_lowres), method,
+                                                C.c_void_p(d_jobs), njobs, None, None))
+
+    def check_jobs_pairs_dev(self, pairs, d_jobs, njobs, method):
+        """check_jobs_dev for a list that search_batch_pairs_dev runs: `pairs` is the list pairs_upload was given.
+        Returns (number of jobs that must not run, index of the first or -1) instead of raising."""
+        arr = (Pair * len(pairs))()
+        for i, (f, r) in enumerate(pairs):
+            arr[i].fenc, arr[i].ref = f, r
+        n_bad, first = C.c_int(0), C.c_int(-1)
+        rc = self.L.x265amd_check_jobs_pairs_dev(self.ctx, arr, len(pairs), method, C.c_void_p(d_jobs), njobs,
+                                                 C.byref(n_bad), C.byref(first))
+        if rc and not n_bad.value:
+            self._chk(rc)
+        return n_bad.value, first.value
+
     def pairs_upload(self, pairs):
         """pairs: list of (source Plane, reference Plane) -> device table for search_batch_pairs_dev."""
         arr = (Pair * len(pairs))()
