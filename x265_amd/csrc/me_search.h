@@ -1284,9 +1284,9 @@ struct Searcher
 #endif
     }
 
-    /* The stages before the sub-pel refinement, for launches that refine in a kernel of their own (several small
-     * PUs per wave, me_refine8.h): the result record receives the choice between the full-pel winner and the best
-     * quarter-pel predictor (motion.cpp:1063-1069) and the counters so far. */
+    /* The stages before the sub-pel refinement, for launches that refine in a kernel of their own (me_small.h):
+     * the result record receives the choice between the full-pel winner and the best quarter-pel predictor
+     * (motion.cpp:1063-1069) and the counters so far. */
     __device__ __forceinline__ void search_staged(const x265amd_job *job, int method, x265amd_result *res)
     {
         JobRegs J;

@@ -1,23 +1,24 @@
-/* 8x8 and 16x16 PUs in fixed-shape kernels (8-bit samples, full-resolution planes): the sub-pel refinement
- * (refine_small_kernel) and the common case of the STAR integer stage (star_small_kernel), a PU per group of
- * S * S / 4 lanes -- four 8x8 PUs or one 16x16 PU per wave.
+/* Square PUs of 8-bit samples in fixed-shape kernels (full-resolution planes): the sub-pel refinement
+ * (refine_small_kernel for 8x8 and 16x16 PUs, refine_big_kernel for 32x32 and 64x64) and the common case of the STAR
+ * integer stage of 8x8 and 16x16 PUs (star_small_kernel).
  *
  * The refinement rounds of MotionEstimate::motionEstimate (motion.cpp:1071-1141) have a fixed shape: the
  * neighbours of one centre at one distance, in the order of the square table, each an 8-tap interpolation
  * plus SAD or SATD (subpelCompare, motion.cpp:1651-1689). The one-wave search (me_search.h) runs them through its
  * general candidate machinery, and an 8x8 PU, four 4x4 tiles, fills a quarter of its passes. Here what is uniform
  * per PU (centre, best cost, predictor) is a value every lane of the PU's group holds, decisions are group-wide
- * minima (DPP), the passes are straight-line code and, for 8x8 PUs, filled by four PUs.
+ * minima (DPP), the passes are straight-line code and, for the small sizes, filled by four PUs.
  *
  * Per round and PU the three columns of candidates (x - step, x, x + step) share their horizontal pass: one
  * plane of luma_hps intermediates (ipfilter.cpp:235-278) per column, S + 8 rows x S samples, int16, column-major
  * in LDS. With 8-bit samples that intermediate keeps every bit, luma_vsp (:359-400) with the phase-0 taps on it
  * gives exactly luma_hpp's (sum + 32) >> 6, and the phase-0 intermediate of a sample is 64 * sample - 8192, on
  * which luma_vsp equals luma_vpp: one plane kind serves every fraction, as in eval_planes. The vertical pass
- * and the cost run one lane per (tile, column) in plane_column_cost, one candidate of every PU per pass.
+ * and the cost run one lane per (tile, column) in small_column_cost, one candidate of every PU per pass; a lane of a
+ * PU above 8x8 looks after four such pairs.
  *
  * The stage before leaves (mv, cost, counters) of the full-pel / predictor choice (motion.cpp:1063-1069) in
- * the PU's result record; refine_small_kernel refines that record in place. PUs of other sizes were finished by
+ * the PU's result record; the refinement kernels refine that record in place. PUs of other sizes were finished by
  * the one-wave search and are skipped.
  */
 #ifndef X265AMD_ME_SMALL_H
