@@ -76,31 +76,33 @@ def test_every_partition_every_method(engine8, oracle):
             assert np.array_equal(r["mv"], mv) and np.array_equal(r["cost"], cost), (mname, part)
 
 
+@pytest.mark.parametrize("depth", [8, 10])
 @pytest.mark.parametrize("size", [8, 16, 32, 64])
 @pytest.mark.parametrize("mname", ["star", "hex", "dia", "umh"])
-def test_small_pu_batches_vs_oracle(engine8, oracle, mname, size):
+def test_small_pu_batches_vs_oracle(request, oracle, mname, size, depth):
     """Batches whose largest PU is a square of 8, 16, 32 or 64 samples take the staged route on 8-bit planes (the search
-    up to the full-pel / predictor choice -- for STAR on 8x8 / 16x16 the fixed-shape kernel with a list of the PUs that
-    leave the common case -- then the sub-pel rounds of the square PUs of that size in their own kernel: four 8x8 or
+    up to the full-pel / predictor choice -- for STAR on 8-bit 8x8 / 16x16 PUs the fixed-shape kernel with a list of the
+    PUs that leave the common case -- then the sub-pel rounds of the square PUs of that size in their own kernel: four 8x8 or
     16x16 PUs per wave, a wave per 32x32 PU, four waves per 64x64 PU): every subme level, batch sizes that are not
     multiples of four, other partitions mixed in (finished by the one-wave search), and PUs whose full-pel cost is 0
-    (no refinement, motion.cpp:1073-1076)."""
+    (no refinement, motion.cpp:1073-1076). 10-bit samples take the same refinement kernels on 16-bit planes."""
+    engine8 = _engine(request, depth)
     method = METHODS[mname]
     others = {8: [(8, 4), (4, 8)], 16: [(16, 8), (8, 16), (8, 8), (12, 16), (16, 4)],
               32: [(32, 16), (16, 32), (16, 16), (32, 24), (8, 32)], 64: [(64, 32), (32, 64), (64, 48), (16, 64), (32, 32)]}[size]
     W, H = 320, 192
     m = margin_for(method)
     for kind in ("texture", "noise"):
-        fenc, ref, org, stride = clip_planes(W, H, 8, kind, margin=m)
+        fenc, ref, org, stride = clip_planes(W, H, depth, kind, margin=m)
         pf = engine8.upload_plane(fenc, W, H, m, m, stride)
         pr = engine8.upload_plane(ref, W, H, m, m, stride)
         for subme in range(8):
             rng = np.random.default_rng(900 + method * 10 + subme)
             n = 61 + subme
             jobs = random_jobs(rng, n, W, H, method, parts=[(size, size)] * 6 + others)
-            qp = int(rng.integers(10, 45))
+            qp = int(rng.integers(10, 45)) + 6 * (depth - 8)
             r = engine8.search_batch(pf, pr, jobs, qp, method, subme)
-            mv, cost, sc, qc = oracle_search(oracle, 8, fenc, [ref], org, stride, jobs, qp, method, subme)
+            mv, cost, sc, qc = oracle_search(oracle, depth, fenc, [ref], org, stride, jobs, qp, method, subme)
             assert np.array_equal(r["mv"], mv), (kind, subme)
             assert np.array_equal(r["cost"], cost), (kind, subme)
             assert np.array_equal(r["sad_calls"], sc) and np.array_equal(r["subpel_calls"], qc), (kind, subme)
@@ -108,7 +110,7 @@ def test_small_pu_batches_vs_oracle(engine8, oracle, mname, size):
             # a picture against itself: zero-predictor PUs end at cost 0 and are left as they are
             jobs = random_jobs(np.random.default_rng(5), 37, W, H, method, parts=[(size, size)])
             r = engine8.search_batch(pf, pf, jobs, 30, method, 5)
-            mv, cost, sc, qc = oracle_search(oracle, 8, fenc, [fenc], org, stride, jobs, 30, method, 5)
+            mv, cost, sc, qc = oracle_search(oracle, depth, fenc, [fenc], org, stride, jobs, 30, method, 5)
             assert np.array_equal(r["mv"], mv) and np.array_equal(r["cost"], cost)
             assert np.array_equal(r["sad_calls"], sc) and np.array_equal(r["subpel_calls"], qc)
             assert (cost == 0).any()

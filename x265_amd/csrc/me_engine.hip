@@ -870,7 +870,7 @@ static int launch_esa(x265amd_ctx *c, const SearchArgs &a, int window_bytes, int
     /* launches of 8-bit PUs up to 8x8 or up to 16x16: the square PUs of that size are refined by refine_small_kernel */
     static const bool no_staged = getenv("X265AMD_NO_STAGED") != 0;      /* measurements only */
     SearchArgs b = a;
-    b.staged = BPS == 1 && (a.max_dim == 8 || a.max_dim == 16) && !no_staged ? a.max_dim : 0;
+    b.staged = (BPS == 1 || c->depth <= 10) && (a.max_dim == 8 || a.max_dim == 16) && !no_staged ? a.max_dim : 0;
     const size_t scan_lds = esa_fixed_lds(a.max_dim, BPS) + window_bytes;
     if (a.max_dim == 8)
         hipLaunchKernelGGL((esa_scan_kernel<P, 8>), dim3(a.njobs), dim3(ESA_THREADS), scan_lds, c->stream, b, window_bytes, nowrap);
@@ -881,9 +881,9 @@ static int launch_esa(x265amd_ctx *c, const SearchArgs &a, int window_bytes, int
     hipLaunchKernelGGL(esa_finish_kernel<P>, dim3(a.njobs), dim3(64), wave_lds_bytes<P>(a.max_dim, true),
                        c->stream, b, window_bytes);
     if (b.staged == 8)
-        hipLaunchKernelGGL(refine_small_kernel<8>, dim3((a.njobs + 3) / 4), dim3(64), RefineLds<8>::TOTAL, c->stream, b);
+        hipLaunchKernelGGL((refine_small_kernel<8, P>), dim3((a.njobs + 3) / 4), dim3(64), RefineLds<8>::TOTAL, c->stream, b);
     else if (b.staged == 16)
-        hipLaunchKernelGGL(refine_small_kernel<16>, dim3((a.njobs + 3) / 4), dim3(64), RefineLds<16>::TOTAL, c->stream, b);
+        hipLaunchKernelGGL((refine_small_kernel<16, P>), dim3((a.njobs + 3) / 4), dim3(64), RefineLds<16>::TOTAL, c->stream, b);
     HIPCHK(c, hipGetLastError());
     return X265AMD_OK;
 }
@@ -903,11 +903,11 @@ static int launch_search(x265amd_ctx *c, const SearchArgs &a, int is_lowres)
         /* launches of 8-bit PUs up to 8x8, 16x16, 32x32 or 64x64: the square PUs of that size are refined by a second
          * kernel (four 8x8 PUs, one 16x16 PU or one 32x32 PU per wave; four waves per 64x64 PU) */
         static const bool no_big = getenv("X265AMD_NO_STAGED_BIG") != 0;                             /* measurements only */
-        b.staged = sizeof(P) == 1 && !no_staged && (a.max_dim == 8 || a.max_dim == 16 || ((a.max_dim == 32 || a.max_dim == 64) && !no_big))
-                 ? a.max_dim : 0;
+        b.staged = (sizeof(P) == 1 || c->depth <= 10) && !no_staged &&
+                   (a.max_dim == 8 || a.max_dim == 16 || ((a.max_dim == 32 || a.max_dim == 64) && !no_big)) ? a.max_dim : 0;
         const int npu = b.staged == 8 ? 4 : 1, groups = (a.njobs + npu - 1) / npu;      /* star_small_kernel's PUs per wave */
         const int rgroups = (a.njobs + 3) / 4;                                              /* refine_small_kernel's */
-        if (b.staged && b.staged <= 16 && a.method == X265AMD_STAR && !no_star)
+        if (sizeof(P) == 1 && b.staged && b.staged <= 16 && a.method == X265AMD_STAR && !no_star)
         {
             if (ensure(c, &c->d_redo, &c->redo_cap, sizeof(int) * ((size_t)REDO_LIST + a.njobs))) return X265AMD_EHIP;
             const int blocks = (a.njobs + REDO_CHUNK - 1) / REDO_CHUNK;
@@ -926,13 +926,13 @@ static int launch_search(x265amd_ctx *c, const SearchArgs &a, int is_lowres)
         else
             hipLaunchKernelGGL((search_kernel<P, false>), dim3(a.njobs), dim3(64), wave_lds_bytes<P>(a.max_dim, true) + pad, c->stream, b);
         if (b.staged == 8)
-            hipLaunchKernelGGL(refine_small_kernel<8>, dim3(rgroups), dim3(64), RefineLds<8>::TOTAL, c->stream, b);
+            hipLaunchKernelGGL((refine_small_kernel<8, P>), dim3(rgroups), dim3(64), RefineLds<8>::TOTAL, c->stream, b);
         else if (b.staged == 16)
-            hipLaunchKernelGGL(refine_small_kernel<16>, dim3(rgroups), dim3(64), RefineLds<16>::TOTAL, c->stream, b);
+            hipLaunchKernelGGL((refine_small_kernel<16, P>), dim3(rgroups), dim3(64), RefineLds<16>::TOTAL, c->stream, b);
         else if (b.staged == 32)
-            hipLaunchKernelGGL(refine_big_kernel<32>, dim3(a.njobs), dim3(BigGeo<32>::THREADS), BigLds<32>::TOTAL, c->stream, b);
+            hipLaunchKernelGGL((refine_big_kernel<32, P>), dim3(a.njobs), dim3(BigGeo<32>::THREADS), BigLds<32>::TOTAL, c->stream, b);
         else if (b.staged == 64)
-            hipLaunchKernelGGL(refine_big_kernel<64>, dim3(a.njobs), dim3(BigGeo<64>::THREADS), BigLds<64>::TOTAL, c->stream, b);
+            hipLaunchKernelGGL((refine_big_kernel<64, P>), dim3(a.njobs), dim3(BigGeo<64>::THREADS), BigLds<64>::TOTAL, c->stream, b);
     }
     HIPCHK(c, hipGetLastError());
     return X265AMD_OK;

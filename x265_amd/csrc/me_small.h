@@ -74,12 +74,26 @@ struct VTapWords
 };
 __constant__ static const VTapWords kVTapWords = VTapWords();
 
-/* both tap tables into LDS, by the first 64 threads of the workgroup */
-__device__ __forceinline__ void small_load_taps(int tid)
+/* both tap tables into LDS, by the first 64 threads of the workgroup. 8-bit samples: the table above. Deeper samples:
+ * the same layout with the taps scaled by 2^(depth - 4), so that luma_vsp's shift of 20 - depth (ipfilter.cpp:372-375)
+ * again ends at bit 16; the scaled taps (at most 58 << 6 with 10 bits) still fit int16. */
+template<typename P>
+__device__ __forceinline__ void small_load_taps(int tid, int depth)
 {
     if (tid < 48) ((int*)(x265amd_smem + SM_TAPS))[tid] = kTapWords.w[tid];
-    if (tid < 64) ((int*)(x265amd_smem + SM_VTAPS))[tid] = kVTapWords.w[tid];
-    if (tid < 16) ((int*)(x265amd_smem + SM_VTAPS))[64 + tid] = kVTapWords.w[64 + tid];
+    if constexpr (sizeof(P) == 1)
+    {
+        if (tid < 64) ((int*)(x265amd_smem + SM_VTAPS))[tid] = kVTapWords.w[tid];
+        if (tid < 16) ((int*)(x265amd_smem + SM_VTAPS))[64 + tid] = kVTapWords.w[64 + tid];
+    }
+    else
+        for (int i = tid; i < 80; i += 64)
+        {
+            const int ph = i / 20, rem = i - ph * 20, par = rem / 10, k = rem - par * 10, set = k / 5, j = k - set * 5;
+            const int first = par + set, a = 2 * j - first, b = 2 * j + 1 - first;
+            const int lo = a >= 0 && a < 8 ? (int)kLumaTaps[ph][a] << (depth - 4) : 0, hi = b >= 0 && b < 8 ? (int)kLumaTaps[ph][b] << (depth - 4) : 0;
+            ((int*)(x265amd_smem + SM_VTAPS))[i] = (int)((unsigned)(lo & 0xffff) | ((unsigned)(hi & 0xffff) << 16));
+        }
 }
 
 /* the lane's column of a 4x4 source tile, rows (0, 1) and (2, 3) as int16 pairs */
@@ -123,12 +137,26 @@ __device__ __forceinline__ void hps_quad(const uint8_t AS1 *s, const int *tp, in
                                                          __builtin_amdgcn_sdot4(__builtin_amdgcn_alignbyte(d2, d1, x), thi, 0, false), false);
 }
 
-/* Vertical pass + cost of the lane's (tile, column) against plane `poff` (8-bit samples): first tap row `r0` of tile
+/* The same for 16-bit samples of `depth` bits: luma_hps's (sum - (8192 << shift)) >> shift with shift = depth - 8
+ * (ipfilter.cpp:244-247). The intermediate drops `shift` bits of the sum, and still it serves every fraction:
+ * luma_hpp's (sum + 32) >> 6 equals ((sum >> shift) + (32 >> shift)) >> (6 - shift), which is what luma_vsp's formula
+ * gives for the phase-0 taps, and a phase-0 intermediate is the sample itself, scaled. */
+__device__ __forceinline__ void hps_quad(const uint16_t AS1 *s, const int *tp, int16_t *dst, int pitch, int depth)
+{
+    int sum[4];
+    HFilter<uint16_t>::run(s, tp, sum);
+    const int shift = depth - 8, off = -(8192 << shift);
+#pragma unroll
+    for (int x = 0; x < 4; x++) dst[x * pitch] = (int16_t)((sum[x] + off) >> shift);
+}
+__device__ __forceinline__ void hps_quad(const uint8_t AS1 *s, const int *tp, int16_t *dst, int pitch, int) { hps_quad(s, tp, dst, pitch); }
+
+/* Vertical pass + cost of the lane's (tile, column) against plane `poff` (samples of `depth` bits, at most 10): first tap row `r0` of tile
  * row 0, vertical phase yf. The four lanes of a quad hold the four columns of a tile. SAD: the sum over the lane's
  * column. SATD: the vertical Hadamard inside the lane, the horizontal one across the quad (DPP); the lane returns the
  * abs-sum of its four coefficients and the caller halves the total (every tile's abs-sum is even, pixel.cpp:226). */
 template<int S>
-__device__ __forceinline__ int small_column_cost(int poff, int r0, int yf, bool satd, const ColSrc &ct, int x)
+__device__ __forceinline__ int small_column_cost(int poff, int r0, int yf, bool satd, const ColSrc &ct, int x, int depth = 8)
 {
     const int R = r0 + 4 * ct.ty;
     const uint32_t *col = (const uint32_t*)(x265amd_smem + poff + (__mul24(ct.col, SmallGeo<S>::PROW) + (R & ~1)) * 2);
@@ -138,14 +166,17 @@ __device__ __forceinline__ int small_column_cost(int poff, int r0, int yf, bool 
     for (int i = 0; i < 6; i++) E[i] = col[i];
 #pragma unroll
     for (int i = 0; i < 5; i++) { P[i] = tp[i]; Q[i] = tp[5 + i]; }
-    constexpr int OFF = ((1 << 11) + (8192 << 6)) << 4;     /* luma_vsp's rounding and the intermediates' bias, scaled like the taps */
+    /* luma_vsp's rounding and the intermediates' bias (ipfilter.cpp:372-375: shift 20 - depth), scaled like the taps */
+    const int OFF = ((1 << (19 - depth)) + (8192 << 6)) << (depth - 4);
     int o[4];
     o[0] = dot2(E[0], P[0], dot2(E[1], P[1], dot2(E[2], P[2], dot2(E[3], P[3], dot2(E[4], P[4], OFF)))));
     o[1] = dot2(E[0], Q[0], dot2(E[1], Q[1], dot2(E[2], Q[2], dot2(E[3], Q[3], dot2(E[4], Q[4], OFF)))));
     o[2] = dot2(E[1], P[0], dot2(E[2], P[1], dot2(E[3], P[2], dot2(E[4], P[3], dot2(E[5], P[4], OFF)))));
     o[3] = dot2(E[1], Q[0], dot2(E[2], Q[1], dot2(E[3], Q[2], dot2(E[4], Q[3], dot2(E[5], Q[4], OFF)))));
-    /* the high halves are (int16_t)(sum >> 12); clipped to 0 .. 255 as pairs */
-    const s16x2 lo = { 0, 0 }, hi = { 255, 255 }, one = { 1, 1 };
+    /* the high halves are (int16_t)(sum >> (20 - depth)); clipped to the sample range as pairs. Differences and every
+     * Hadamard stage fit int16 up to 10 bits (16 * 1023) */
+    const short maxv = (short)((1 << depth) - 1);
+    const s16x2 lo = { 0, 0 }, hi = { maxv, maxv }, one = { 1, 1 };
     s16x2 p01 = __builtin_bit_cast(s16x2, __builtin_amdgcn_perm((uint32_t)o[1], (uint32_t)o[0], 0x07060302u));
     s16x2 p23 = __builtin_bit_cast(s16x2, __builtin_amdgcn_perm((uint32_t)o[3], (uint32_t)o[2], 0x07060302u));
     p01 = __builtin_elementwise_min(__builtin_elementwise_max(p01, lo), hi);
@@ -156,7 +187,6 @@ __device__ __forceinline__ int small_column_cost(int poff, int r0, int yf, bool 
         const s16x2 a = __builtin_elementwise_max(d01, -d01), b = __builtin_elementwise_max(d23, -d23);
         return __builtin_amdgcn_sdot2(a, one, __builtin_amdgcn_sdot2(b, one, 0, false), false);
     }
-    /* differences and every Hadamard stage fit int16 (16 * 255) */
     const s16x2 Sm = d01 + d23, Df = d01 - d23;                     /* (r0+r2, r1+r3), (r0-r2, r1-r3) */
     const s16x2 A = __builtin_shufflevector(Sm, Df, 0, 2), B = __builtin_shufflevector(Sm, Df, 1, 3);
     s16x2 U = A + B, W = A - B;                                     /* vertical coefficients (c0, c2), (c1, c3) */
@@ -172,13 +202,13 @@ __device__ __forceinline__ int small_column_cost(int poff, int r0, int yf, bool 
 }
 
 /* the lane's tile column of the source block */
-template<int S>
-__device__ __forceinline__ void small_source_column(const uint8_t AS1 *fenc0, int fstride, int pux, int puy, int l, ColSrc &ct)
+template<int S, typename P>
+__device__ __forceinline__ void small_source_column(const P AS1 *fenc0, int fstride, int pux, int puy, int l, ColSrc &ct)
 {
     typedef SmallGeo<S> G;
     const int t = l >> 2, tx = t & (G::TW - 1), ty = t >> G::LTW;
     ct.ty = ty; ct.col = tx * 4 + (l & 3);
-    const uint8_t AS1 *src = fenc0 + (long)(puy + ty * 4) * fstride + pux + ct.col;
+    const P AS1 *src = fenc0 + (long)(puy + ty * 4) * fstride + pux + ct.col;
     uint32_t f[4];
 #pragma unroll
     for (int y = 0; y < 4; y++) f[y] = (uint32_t)src[(long)y * fstride];
@@ -186,18 +216,19 @@ __device__ __forceinline__ void small_source_column(const uint8_t AS1 *fenc0, in
 }
 
 /* the planes of a job: the launch's own, or its entry of the pair table (as job_planes, per lane) */
-__device__ __forceinline__ void small_planes(const SearchArgs &a, int d1, const uint8_t AS1 *&fenc0, int &fstride,
-                                             const uint8_t AS1 *&ref0, int &rstride)
+template<typename P>
+__device__ __forceinline__ void small_planes(const SearchArgs &a, int d1, const P AS1 *&fenc0, int &fstride,
+                                             const P AS1 *&ref0, int &rstride)
 {
-    fenc0 = (const uint8_t AS1*)a.fenc.origin; fstride = a.fenc.stride;
-    ref0 = (const uint8_t AS1*)a.ref[0].origin; rstride = a.ref[0].stride;
+    fenc0 = (const P AS1*)a.fenc.origin; fstride = a.fenc.stride;
+    ref0 = (const P AS1*)a.ref[0].origin; rstride = a.ref[0].stride;
     if (a.pairs)
     {
         int pi = (d1 >> 24) & 0xff;
         if (pi >= a.npairs) pi = 0;
         const PairDev *p = a.pairs + pi;
-        fenc0 = (const uint8_t AS1*)p->fenc.origin; fstride = p->fenc.stride;
-        ref0 = (const uint8_t AS1*)p->ref.origin; rstride = p->ref.stride;
+        fenc0 = (const P AS1*)p->fenc.origin; fstride = p->fenc.stride;
+        ref0 = (const P AS1*)p->ref.origin; rstride = p->ref.stride;
     }
 }
 
@@ -221,16 +252,17 @@ template<int S> struct RefineLds
     static constexpr int TOTAL = PLANES + RefineGeo<S>::NPU * PU_BYTES + 32;
 };
 
-template<int S> struct RefineSmall
+template<int S, typename P> struct RefineSmall
 {
     typedef SmallGeo<S> G;
     typedef RefineGeo<S> RG;
     typedef RefineLds<S> L;
+    int depth;                  /* bits per sample: 8 for uint8_t planes, at most 10 otherwise */
     /* per PU, the same in every lane of its group */
     int qx, qy, bcost, mvpx, mvpy, roff;
     unsigned nsub;
     bool active;
-    const uint8_t AS1 *ref0;    /* origin of the PU's reference plane (PUs of one wave may search different pictures) */
+    const P AS1 *ref0;          /* origin of the PU's reference plane (PUs of one wave may search different pictures) */
     int rstride;
     /* per lane */
     int lane, grp, l;
@@ -273,14 +305,14 @@ template<int S> struct RefineSmall
         for (int p = 0; p < 3; p++)
         {
             const int xp = as_i16(qx + (p - 1) * step);
-            const uint8_t AS1 *src = ref0 + (first + (xp >> 2));
+            const P AS1 *src = ref0 + (first + (xp >> 2));
             const int *htap = (const int*)(x265amd_smem + SM_TAPS) + (xp & 3) * 12;
 #pragma unroll
             for (int it = 0; it < G::IPP / RG::LPP; it++)
             {
                 const int item = it * RG::LPP + l, r = item >> G::LTW, q = item & (G::TW - 1);
                 hps_quad(src + (__mul24(r, rstride) + 4 * q), htap,
-                         (int16_t*)(x265amd_smem + pbase + p * G::PLANE) + (4 * q) * G::PROW + r, G::PROW);
+                         (int16_t*)(x265amd_smem + pbase + p * G::PLANE) + (4 * q) * G::PROW + r, G::PROW, depth);
             }
         }
         wave_sync();
@@ -293,7 +325,7 @@ template<int S> struct RefineSmall
             int v = 0;
 #pragma unroll
             for (int u = 0; u < RG::ITEMS; u++)
-                v += small_column_cost<S>(pbase + (dx + 1) * G::PLANE, r0y[dy + 1], phy[dy + 1], satd, ct[u], l & 3);
+                v += small_column_cost<S>(pbase + (dx + 1) * G::PLANE, r0y[dy + 1], phy[dy + 1], satd, ct[u], l & 3, depth);
             v = seg_sum(v, RG::LG);
             if (l == c) mycost = (satd ? v >> 1 : v) + mvc;   /* every 4x4 abs-sum is even: halving the total = halving per tile */
         }
@@ -320,7 +352,7 @@ template<int S> struct RefineSmall
     }
 };
 
-template<int S>
+template<int S, typename P>
 __global__ __launch_bounds__(64) void refine_small_kernel(SearchArgs a)
 {
     typedef SmallGeo<S> G;
@@ -328,7 +360,8 @@ __global__ __launch_bounds__(64) void refine_small_kernel(SearchArgs a)
     const int ngroups = (a.njobs + RG::NPU - 1) / RG::NPU;
     const int g = xcd_remap((int)blockIdx.x, ngroups);
     if (g >= ngroups) return;
-    RefineSmall<S> R;
+    RefineSmall<S, P> R;
+    R.depth = sizeof(P) == 1 ? 8 : a.depth;
     R.lane = (int)threadIdx.x; R.grp = R.lane >> RG::LG; R.l = R.lane & (RG::LPP - 1);
     int j = g * RG::NPU + R.grp;
     const bool valid = j < a.njobs;
@@ -343,12 +376,12 @@ __global__ __launch_bounds__(64) void refine_small_kernel(SearchArgs a)
     /* a PU whose full-pel cost is 0 is not refined (motion.cpp:1073-1076); PUs of other sizes are final already */
     R.active = valid && (d1 & 0xffff) == G::SIZE_CODE && R.bcost > 0;      /* a negative cost marks a job that was refused */
     if (__ballot(R.active) == 0) return;
-    const uint8_t AS1 *fenc0;
+    const P AS1 *fenc0;
     int fstride;
-    small_planes(a, d1, fenc0, fstride, R.ref0, R.rstride);
+    small_planes<P>(a, d1, fenc0, fstride, R.ref0, R.rstride);
     R.roff = puy * R.rstride + pux;
     R.ctab = (const uint16_t AS1*)a.ctab;
-    small_load_taps(R.lane);
+    small_load_taps<P>(R.lane, R.depth);
 #pragma unroll
     for (int u = 0; u < RG::ITEMS; u++) small_source_column<S>(fenc0, fstride, pux, puy, R.l + u * RG::LPP, R.ct[u]);
     /* SubpelWorkload, motion.cpp:53-63, and the round sequence of :1100-1141 */
@@ -401,9 +434,10 @@ template<int S> struct BigLds
     static constexpr int TOTAL = PLANES + 3 * G::PLANE + 32;
 };
 
-template<int S>
+template<int S, typename P>
 __global__ __launch_bounds__(BigGeo<S>::THREADS) void refine_big_kernel(SearchArgs a)
 {
+    const int depth = sizeof(P) == 1 ? 8 : a.depth;
     typedef SmallGeo<S> G;
     typedef BigLds<S> L;
     constexpr int THREADS = BigGeo<S>::THREADS, ITEMS = BigGeo<S>::ITEMS;
@@ -421,12 +455,12 @@ __global__ __launch_bounds__(BigGeo<S>::THREADS) void refine_big_kernel(SearchAr
     /* a PU whose full-pel cost is 0 is not refined (motion.cpp:1073-1076), a negative cost marks a job that was
      * refused; PUs of other sizes are final already */
     if ((d1 & 0xffff) != G::SIZE_CODE || bcost <= 0) return;
-    const uint8_t AS1 *fenc0, *ref0;
+    const P AS1 *fenc0, *ref0;
     int fstride, rstride;
-    small_planes(a, d1, fenc0, fstride, ref0, rstride);
+    small_planes<P>(a, d1, fenc0, fstride, ref0, rstride);
     const int roff = puy * rstride + pux;
     const uint16_t AS1 *ctab = (const uint16_t AS1*)a.ctab;
-    small_load_taps(tid);
+    small_load_taps<P>(tid, depth);
     for (int i = tid; i < L::ROUNDS * 16; i += THREADS) ((int*)(x265amd_smem + L::CELLS))[i] = 0;
     ColSrc ct[ITEMS];
 #pragma unroll
@@ -454,13 +488,13 @@ __global__ __launch_bounds__(BigGeo<S>::THREADS) void refine_big_kernel(SearchAr
         for (int p = 0; p < 3; p++)
         {
             const int xp = as_i16(qx + (p - 1) * step);
-            const uint8_t AS1 *src = ref0 + (roff + __mul24(ymin - 3, rstride) + (xp >> 2) - 3);
+            const P AS1 *src = ref0 + (roff + __mul24(ymin - 3, rstride) + (xp >> 2) - 3);
             const int *tp = (const int*)(x265amd_smem + SM_TAPS) + (xp & 3) * 12;
             int16_t *plane = (int16_t*)(x265amd_smem + L::PLANES + p * G::PLANE);
             for (int item = tid; item < G::IPP; item += THREADS)
             {
                 const int r = item >> G::LTW, q = item & (G::TW - 1);
-                hps_quad(src + (__mul24(r, rstride) + 4 * q), tp, plane + (4 * q) * G::PROW + r, G::PROW);
+                hps_quad(src + (__mul24(r, rstride) + 4 * q), tp, plane + (4 * q) * G::PROW + r, G::PROW, depth);
             }
         }
         __syncthreads();
@@ -473,7 +507,7 @@ __global__ __launch_bounds__(BigGeo<S>::THREADS) void refine_big_kernel(SearchAr
             const int poff = L::PLANES + (nib(SQX, i) + 1) * G::PLANE, rr = (ty >> 2) - ymin;
             int v = 0;
 #pragma unroll
-            for (int u = 0; u < ITEMS; u++) v += small_column_cost<S>(poff, rr, ty & 3, satd, ct[u], tid & 3);
+            for (int u = 0; u < ITEMS; u++) v += small_column_cost<S>(poff, rr, ty & 3, satd, ct[u], tid & 3, depth);
             v = seg_sum(v, 6);
             if (lane == c) part = v;
         }
@@ -571,10 +605,10 @@ __global__ __launch_bounds__(64) void star_small_kernel(SearchArgs a)
     const int mvpx = as_i16(d[4]), mvpy = d[4] >> 16;
     const uint8_t AS1 *fenc0, *ref0;
     int fstride, rstride;
-    small_planes(a, d[1], fenc0, fstride, ref0, rstride);
+    small_planes<uint8_t>(a, d[1], fenc0, fstride, ref0, rstride);
     const int roff = puy * rstride + pux;
     const uint16_t AS1 *ctab = (const uint16_t AS1*)a.ctab;
-    small_load_taps(lane);
+    small_load_taps<uint8_t>(lane, 8);
 
     /* ---- start-up candidates, motion.cpp:575-621 (values every lane of the group holds) ---- */
     const int qmnx = as_i16(mnx << 2), qmny = as_i16(mny << 2), qmxx = as_i16(mxx << 2), qmxy = as_i16(mxy << 2);

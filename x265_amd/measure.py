@@ -156,7 +156,7 @@ def lookahead_costs(e, dev, width=1920, height=1080, nframes=16, reps=3, seed=21
 
 def pattern_search_picture(e, dev, width=3840, height=2160, depth=10, method="star", subme=5, merange=57, reps=5, seed=31, qp=38):
     """Pattern search + sub-pel refinement of every square 64/32/16/8 PU of one picture against one reference in
-    two launches (16/8 and 64/32 classes, as the headline does), for an engine of `depth` bits. Predictors come from
+    one launch per PU size (as the headline does), for an engine of `depth` bits. Predictors come from
     the lookahead field of the same pair. Returns ms per picture-reference, the pixel-SAD count and jobs / results."""
     import torch
     from .engine import HEX
@@ -172,15 +172,18 @@ def pattern_search_picture(e, dev, width=3840, height=2160, depth=10, method="st
     la_mvs, _, _ = e.lookahead_fields([(low[1][0], low[0])], wcu, hcu, 12 + 6 * (depth - 8), HEX, 1, 16)
     jobs = workload.square_pu_jobs(width, height, la_mvs[0], wcu, hcu, merange)      # sorted 64, 32, 16, 8
     n = len(jobs)
-    nbig = int((jobs["w"] >= 32).sum())
+    classes = []
+    for s_ in (64, 32, 16, 8):
+        idx = np.flatnonzero(jobs["w"] == s_)
+        classes.append((int(idx[0]), len(idx), s_))
     d_jobs = torch.from_numpy(jobs.view(np.uint8).reshape(n, -1).copy()).to(dev)
     d_res = torch.zeros((n, RESULT_DTYPE.itemsize), dtype=torch.uint8, device=dev)
     torch.cuda.synchronize()
 
     def launch():
-        e.search_batch_dev(planes[1], planes[0], d_jobs.data_ptr(), nbig, d_res.data_ptr(), qp, METHODS[method], subme, max_pu_dim=64)
-        e.search_batch_dev(planes[1], planes[0], d_jobs.data_ptr() + nbig * 40, n - nbig, d_res.data_ptr() + nbig * 16, qp,
-                           METHODS[method], subme, max_pu_dim=16)
+        for (first, cnt, dim) in classes:
+            e.search_batch_dev(planes[1], planes[0], d_jobs.data_ptr() + first * 40, cnt, d_res.data_ptr() + first * 16, qp,
+                               METHODS[method], subme, max_pu_dim=dim)
     ms = _timed(torch, e, dev, launch, reps)
     res = d_res.cpu().numpy().view(RESULT_DTYPE).reshape(-1)
     for l in low:
