@@ -907,7 +907,7 @@ static int launch_search(x265amd_ctx *c, const SearchArgs &a, int is_lowres)
                    (a.max_dim == 8 || a.max_dim == 16 || ((a.max_dim == 32 || a.max_dim == 64) && !no_big)) ? a.max_dim : 0;
         const int npu = b.staged == 8 ? 4 : 1, groups = (a.njobs + npu - 1) / npu;      /* star_small_kernel's PUs per wave */
         const int rgroups = (a.njobs + 3) / 4;                                              /* refine_small_kernel's */
-        if (sizeof(P) == 1 && b.staged && b.staged <= 16 && a.method == X265AMD_STAR && !no_star)
+        if (b.staged && b.staged <= 16 && a.method == X265AMD_STAR && !no_star)
         {
             if (ensure(c, &c->d_redo, &c->redo_cap, sizeof(int) * ((size_t)REDO_LIST + a.njobs))) return X265AMD_EHIP;
             const int blocks = (a.njobs + REDO_CHUNK - 1) / REDO_CHUNK;
@@ -915,9 +915,9 @@ static int launch_search(x265amd_ctx *c, const SearchArgs &a, int is_lowres)
              * records of the PUs it leaves to the one-wave search */
             b.redo = (int*)c->d_redo;
             if (b.staged == 8)
-                hipLaunchKernelGGL(star_small_kernel<8>, dim3(groups), dim3(64), StarLds<8>::TOTAL, c->stream, b);
+                hipLaunchKernelGGL((star_small_kernel<8, P>), dim3(groups), dim3(64), StarLds<8>::TOTAL, c->stream, b);
             else
-                hipLaunchKernelGGL(star_small_kernel<16>, dim3(groups), dim3(64), StarLds<16>::TOTAL, c->stream, b);
+                hipLaunchKernelGGL((star_small_kernel<16, P>), dim3(groups), dim3(64), StarLds<16>::TOTAL, c->stream, b);
             hipLaunchKernelGGL(redo_list_kernel, dim3(blocks), dim3(256), 0, c->stream, a.results, a.njobs, (int*)c->d_redo);
             hipLaunchKernelGGL((search_kernel<P, false>), dim3(a.njobs < REDO_GRID ? a.njobs : REDO_GRID), dim3(64),
                                wave_lds_bytes<P>(a.max_dim, true) + pad, c->stream, b);

@@ -574,13 +574,14 @@ template<int S> struct StarLds
     typedef SmallGeo<S> G;
     static constexpr int PLANES = SM_FIXED;
     static constexpr int PU_BYTES = SM_PLANES * G::PLANE + 4;       /* the planes, later the window of the star points */
-    static_assert((S + 8) * (S + 12) <= SM_PLANES * G::PLANE, "the window of the star points fits the planes");
+    static_assert((S + 8) * (S + 12) * 2 + 8 <= SM_PLANES * G::PLANE, "the window of the star points (16-bit samples) fits the planes");
     static constexpr int TOTAL = PLANES + G::NPU * PU_BYTES + 32;
 };
 
-template<int S>
+template<int S, typename P>
 __global__ __launch_bounds__(64) void star_small_kernel(SearchArgs a)
 {
+    const int depth = sizeof(P) == 1 ? 8 : a.depth;
     typedef SmallGeo<S> G;
     typedef StarLds<S> L;
     const int ngroups = (a.njobs + G::NPU - 1) / G::NPU;
@@ -603,12 +604,12 @@ __global__ __launch_bounds__(64) void star_small_kernel(SearchArgs a)
     const int pux = as_i16(d[0]), puy = d[0] >> 16, numc = (d[1] >> 16) & 0xff;
     const int mnx = as_i16(d[2]), mny = d[2] >> 16, mxx = as_i16(d[3]), mxy = d[3] >> 16;
     const int mvpx = as_i16(d[4]), mvpy = d[4] >> 16;
-    const uint8_t AS1 *fenc0, *ref0;
+    const P AS1 *fenc0, *ref0;
     int fstride, rstride;
-    small_planes<uint8_t>(a, d[1], fenc0, fstride, ref0, rstride);
+    small_planes<P>(a, d[1], fenc0, fstride, ref0, rstride);
     const int roff = puy * rstride + pux;
     const uint16_t AS1 *ctab = (const uint16_t AS1*)a.ctab;
-    small_load_taps<uint8_t>(lane, 8);
+    small_load_taps<P>(lane, depth);
 
     /* ---- start-up candidates, motion.cpp:575-621 (values every lane of the group holds) ---- */
     const int qmnx = as_i16(mnx << 2), qmny = as_i16(mny << 2), qmxx = as_i16(mxx << 2), qmxy = as_i16(mxy << 2);
@@ -654,11 +655,11 @@ __global__ __launch_bounds__(64) void star_small_kernel(SearchArgs a)
 
     /* the lane's tile of the source block, for the plain SADs: a lane per (point, tile) */
     const int tile = l & ((1 << G::LT) - 1), tlx = (tile & (G::TW - 1)) * 4, tly = (tile >> G::LTW) * 4;
-    uint32_t fq[4];
+    typename Px<P>::quad fq[4];
     {
-        const uint8_t AS1 *src = fenc0 + (long)(puy + tly) * fstride + pux + tlx;
+        const P AS1 *src = fenc0 + (long)(puy + tly) * fstride + pux + tlx;
 #pragma unroll
-        for (int y = 0; y < 4; y++) fq[y] = Px<uint8_t>::load_g(src + (long)y * fstride);
+        for (int y = 0; y < 4; y++) fq[y] = Px<P>::load_g(src + (long)y * fstride);
     }
     /* slots 1 and 2: point 0 = the rounded predictor, point 1 = MV 0 */
     int vdir = 0;
@@ -666,9 +667,9 @@ __global__ __launch_bounds__(64) void star_small_kernel(SearchArgs a)
         const int pnt = l >> G::LT;
         if (pnt < 2)
         {
-            const uint8_t AS1 *rp = ref0 + roff + (long)__mul24((pnt ? 0 : bmy) + tly, rstride) + (pnt ? 0 : bmx) + tlx;
+            const P AS1 *rp = ref0 + roff + (long)__mul24((pnt ? 0 : bmy) + tly, rstride) + (pnt ? 0 : bmx) + tlx;
 #pragma unroll
-            for (int yy = 0; yy < 4; yy++) vdir = Px<uint8_t>::sad(fq[yy], Px<uint8_t>::load_g(rp + (long)yy * rstride), vdir);
+            for (int yy = 0; yy < 4; yy++) vdir = Px<P>::sad(fq[yy], Px<P>::load_g(rp + (long)yy * rstride), vdir);
         }
         vdir = seg_sum(vdir, G::LT);
     }
@@ -691,7 +692,7 @@ __global__ __launch_bounds__(64) void star_small_kernel(SearchArgs a)
                 {
                     const int item = it * 16 + l, r = item >> 1, q = item & 1;
                     hps_quad(ref0 + (so + __mul24(r, rstride) + 4 * q), tp,
-                             (int16_t*)(x265amd_smem + pbase + kk * G::PLANE) + (4 * q) * G::PROW + r, G::PROW);
+                             (int16_t*)(x265amd_smem + pbase + kk * G::PLANE) + (4 * q) * G::PROW + r, G::PROW, depth);
                 }
             }
         }
@@ -715,7 +716,7 @@ __global__ __launch_bounds__(64) void star_small_kernel(SearchArgs a)
                     const int kk = k + pl < nplanes ? k + pl : nplanes - 1;
                     hps_quad(ref0 + ((pl ? so[1] : so[0]) + __mul24(r, rstride) + 4 * q),
                              (const int*)(x265amd_smem + SM_TAPS) + (pl ? ph[1] : ph[0]) * 12,
-                             (int16_t*)(x265amd_smem + pbase + kk * G::PLANE) + (4 * q) * G::PROW + r, G::PROW);
+                             (int16_t*)(x265amd_smem + pbase + kk * G::PLANE) + (4 * q) * G::PROW + r, G::PROW, depth);
                 }
             }
         }
@@ -731,7 +732,7 @@ __global__ __launch_bounds__(64) void star_small_kernel(SearchArgs a)
         {
             if (rem) { sk = __builtin_ctz(rem); rem &= rem - 1; }
             const int ysk = grp_lane<G::LG>(sy, sk);
-            int v = small_column_cost<S>(pbase + (k < nplanes ? k : nplanes - 1) * G::PLANE, 0, ysk & 3, false, ct, l & 3);
+            int v = small_column_cost<S>(pbase + (k < nplanes ? k : nplanes - 1) * G::PLANE, 0, ysk & 3, false, ct, l & 3, depth);
             v = seg_sum(v, G::LG);
             if (l == sk) mycost = v + mvc;
         }
@@ -770,15 +771,17 @@ __global__ __launch_bounds__(64) void star_small_kernel(SearchArgs a)
     /* the (S + 8)^2 samples the 20 points can touch, staged once per PU into the LDS of the start-up planes (dead by
      * now); the points are measured from there. (X265AMD_STAR_GLOBAL_LOADS, tools builds only: the points read global
      * memory instead, the variant this one was measured against.) */
-    constexpr int WP = S + 12;                      /* window row pitch: S + 8 samples and the dword a lane reads past them */
+    constexpr int BPS = (int)sizeof(P);
+    constexpr int WP = (S + 12) * BPS;              /* window row pitch in bytes: S + 8 samples and what a lane reads past them */
     const int woff = L::PLANES + grp * L::PU_BYTES;
     wave_sync();
     {
-        const uint8_t AS1 *w0 = ref0 + roff + (long)__mul24(bmy - 4, rstride) + bmx - 4;
+        typedef uint32_t __attribute__((aligned(1))) u32u;      /* the window starts at any sample */
+        const char AS1 *w0 = (const char AS1*)(ref0 + roff + (long)__mul24(bmy - 4, rstride) + bmx - 4);
         for (int i = l; i < (S + 8) * (WP / 4); i += G::LPP)
         {
             const int r = i / (WP / 4), q = i - r * (WP / 4);
-            *(uint32_t*)(x265amd_smem + woff + r * WP + 4 * q) = Px<uint8_t>::load_g(w0 + (long)r * rstride + 4 * q);
+            *(uint32_t*)(x265amd_smem + woff + r * WP + 4 * q) = *(const u32u AS1*)(w0 + (long)r * rstride * BPS + 4 * q);
         }
     }
     wave_sync();
@@ -797,17 +800,13 @@ __global__ __launch_bounds__(64) void star_small_kernel(SearchArgs a)
         if (ok)
         {
 #ifndef X265AMD_STAR_GLOBAL_LOADS
-            const int bo = woff + (4 + dy + tly) * WP + 4 + dx + tlx, al = bo & ~3, sh = bo & 3;
+            const int bo = woff + (4 + dy + tly) * WP + (4 + dx + tlx) * BPS;
 #pragma unroll
-            for (int yy = 0; yy < 4; yy++)
-            {
-                const uint32_t *q = (const uint32_t*)(x265amd_smem + al + yy * WP);
-                v = Px<uint8_t>::sad(fq[yy], __builtin_amdgcn_alignbyte(q[1], q[0], sh), v);
-            }
+            for (int yy = 0; yy < 4; yy++) v = Px<P>::sad(fq[yy], Px<P>::load_lds(bo + yy * WP), v);
 #else
-            const uint8_t AS1 *rp = ref0 + roff + (long)__mul24(y + tly, rstride) + x + tlx;
+            const P AS1 *rp = ref0 + roff + (long)__mul24(y + tly, rstride) + x + tlx;
 #pragma unroll
-            for (int yy = 0; yy < 4; yy++) v = Px<uint8_t>::sad(fq[yy], Px<uint8_t>::load_g(rp + (long)yy * rstride), v);
+            for (int yy = 0; yy < 4; yy++) v = Px<P>::sad(fq[yy], Px<P>::load_g(rp + (long)yy * rstride), v);
 #endif
             cost = ((int)ctab[as_i16(x << 2) - mvpx] + (int)ctab[as_i16(y << 2) - mvpy]) & 0xffff;
         }
