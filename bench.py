@@ -43,7 +43,7 @@ def host_threads(args):
     return max(1, min(n, int(env))) if env.isdigit() else n
 
 
-def valu_bound(profile, kernels, pus, launch_s, step_pairs=0, step_s=0.0):
+def valu_bound(profile, kernels, pus, launch_s, step_pairs=0, step_s=0.0, clock_mhz=None):
     """VALU-issue accounting of one launch class from the SQ counters kept in profiles/valu.json (per frame pair):
     wave instructions issued per PU and the fraction of the launch during which the chip's 1024 SIMDs would be busy
     issuing them back to back (a wave64 VALU instruction occupies its SIMD for 4 cycles). The launch shares the chip
@@ -58,9 +58,13 @@ def valu_bound(profile, kernels, pus, launch_s, step_pairs=0, step_s=0.0):
     per_pair_pus = profile["pus_per_pair"]
     npairs = pus / per_pair_pus
     all_valu = profile.get("valu_wave_instr_per_pair_all_kernels")
+    hz = clock_mhz * 1e6 if clock_mhz else profile["clock_hz"]
     return {"issued_wave_instr_per_pu": {"valu": valu / per_pair_pus, "salu": salu / per_pair_pus, "lds": lds / per_pair_pus},
-            "busy_frac": valu * npairs * 4 / (profile["simds"] * profile["clock_hz"] * launch_s),
-            "step_busy_frac": all_valu * step_pairs * 4 / (profile["simds"] * profile["clock_hz"] * step_s) if all_valu and step_s else None,
+            "shader_clock_mhz": hz / 1e6,
+            "shader_clock_how": "measured during three extra steps by a probe wave (x265amd_clock_probe_*)" if clock_mhz
+                                else "nominal (no probe)",
+            "busy_frac": valu * npairs * 4 / (profile["simds"] * hz * launch_s),
+            "step_busy_frac": all_valu * step_pairs * 4 / (profile["simds"] * hz * step_s) if all_valu and step_s else None,
             "step_valu_wave_instr_per_frame_pair": all_valu,
             "essential_wave_instr_per_pu": profile["essential_wave_instr_per_pu"],
             "source": profile["source"]}
@@ -412,6 +416,21 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    # the shader clock under this load: three more steps (untimed) with the probe wave beside them on a stream of its own
+    clock_mhz = None
+    if rank == 0 and multi:
+        try:
+            ep = Engine(local_rank, 8)
+            step()
+            ep.clock_probe_start(2.5 * elapsed / args.steps * 1e3)
+            for _ in range(3):
+                step()
+            clock_mhz = ep.clock_probe_read()
+            ep.close()
+        except Exception as ex:     # the bench line must survive a failure here
+            clock_mhz = None
+            print("clock probe failed: %r" % (ex,), file=sys.stderr)
+
     # ---------------- accounting
     if multi:
         res = [np.zeros(njobs, RESULT_DTYPE) for _ in range(B)]
@@ -566,7 +585,7 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel": kernel, "launch_ms": launch_ms, "algorithmic_bytes_per_launch": alg_bytes,
-                         "valu": valu_bound(vprof, vprof["timed_kernels"], timed_cnt * B, launch_ms * 1e-3, B, elapsed / args.steps) if vprof else None,
+                         "valu": valu_bound(vprof, vprof["timed_kernels"], timed_cnt * B, launch_ms * 1e-3, B, elapsed / args.steps, clock_mhz) if vprof else None,
                          "compulsory": compulsory,
                          "note": "achieved prices every PU's source block and search window as if no two PUs shared a byte (the "
                                  "per-job formula); neighbouring PUs share their windows through L2, so it is not HBM traffic and "

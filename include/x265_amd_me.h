@@ -286,6 +286,14 @@ int x265amd_upload(x265amd_ctx *ctx, void *d_dst, const void *src, size_t bytes)
  * stream, after the searches launched before it. */
 int x265amd_pack_mv_cost(x265amd_ctx *ctx, const void *d_results, int n, void *d_out);
 
+/* Measurement aid, no counterpart in the reference: the shader clock while the chip is busy. _start queues one wave on
+ * the engine's stream that sleeps for `ms` milliseconds of the device's constant-rate clock and counts shader cycles
+ * meanwhile (launch it on a stream of its own next to the work of interest); _read waits for it and gives the average
+ * shader clock over that time in MHz. The issue-rate bounds reported next to the kernels (VALU instructions x 4 cycles per
+ * SIMD) are priced at this clock, which a loaded MI355X holds well below its nominal 2.4 GHz. */
+int x265amd_clock_probe_start(x265amd_ctx *ctx, double ms);
+int x265amd_clock_probe_read(x265amd_ctx *ctx, double *shader_mhz);
+
 /* ---- explicit weighted prediction ---- */
 
 /* primitives.weight_pp (common/pixel.cpp:512-529) over a whole padded buffer, the way the

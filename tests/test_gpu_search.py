@@ -212,6 +212,15 @@ def test_device_resident_jobs_are_checkable(engine8):
     engine8.free_plane(pf)
 
 
+def test_clock_probe(engine8):
+    """The measurement aid behind the issue-rate bounds: a plausible shader clock, and the argument checks."""
+    engine8.clock_probe_start(2.0)
+    mhz = engine8.clock_probe_read()
+    assert 300.0 < mhz < 4000.0, mhz
+    with pytest.raises(EngineError):
+        engine8.clock_probe_start(0.0)
+
+
 def test_argument_errors(engine8):
     W, H = 64, 64
     fenc, _, org, stride = clip_planes(W, H, 8, "static", margin=32)

@@ -806,6 +806,7 @@ struct x265amd_ctx
     void *d_jobs; size_t jobs_cap;
     void *d_results; size_t results_cap;
     void *d_stage; size_t stage_cap;   /* staging for the per-call primitives */
+    int probe_khz;                     /* constant-rate clock of the last x265amd_clock_probe_start, kHz */
     void *d_redo; size_t redo_cap;     /* list of the PUs a fixed-shape kernel left to the one-wave search (redo_list_kernel) */
     int32_t *d_out;
     int *d_ticket;                     /* row hand-out counter of the row-parallel lookahead kernel */
@@ -1017,6 +1018,7 @@ static int create_ctx(int device, int bit_depth, int high_priority, x265amd_ctx 
     c->d_jobs = c->d_results = c->d_stage = c->d_redo = 0; c->d_ticket = 0;
     c->jobs_cap = c->results_cap = c->stage_cap = c->redo_cap = 0; c->d_out = 0;
     c->esa_window_bytes = 0;
+    c->probe_khz = 0;
     c->esa_lds_raised = c->rime_lds_raised = false;
     int prio_least = 0, prio_greatest = 0;
     if (hipSetDevice(device) != hipSuccess || hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest) != hipSuccess ||
@@ -1849,6 +1851,46 @@ int x265amd_upload(x265amd_ctx *c, void *d_dst, const void *src, size_t bytes)
     HIPCHK(c, hipSetDevice(c->device));
     HIPCHK(c, hipMemcpyAsync(d_dst, src, bytes, hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    return X265AMD_OK;
+}
+
+/* One wave that sleeps for `ticks` of the constant-rate clock and counts the shader clock meanwhile: what the chip
+ * clocks at while other streams keep it busy (the shader clock follows power, so a loaded chip runs below its
+ * nominal rate and an issue-rate bound has to be priced at the measured one). */
+__global__ __launch_bounds__(64) void clock_probe_kernel(long long *out, long long ticks)
+{
+    const long long w0 = wall_clock64(), c0 = clock64();
+    while (wall_clock64() - w0 < ticks) __builtin_amdgcn_s_sleep(32);
+    if (threadIdx.x == 0)
+    {
+        out[0] = clock64() - c0;
+        out[1] = wall_clock64() - w0;
+    }
+}
+
+int x265amd_clock_probe_start(x265amd_ctx *c, double ms)
+{
+    if (!c || !(ms > 0 && ms < 1000)) return fail(c, X265AMD_EINVAL, "probe time out of range");
+    HIPCHK(c, hipSetDevice(c->device));
+    int khz = 0;
+    HIPCHK(c, hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, c->device));
+    if (khz <= 0) return fail(c, X265AMD_EHIP, "no constant-rate clock on this device");
+    if (ensure(c, &c->d_stage, &c->stage_cap, 16)) return X265AMD_EHIP;
+    c->probe_khz = khz;
+    hipLaunchKernelGGL(clock_probe_kernel, dim3(1), dim3(64), 0, c->stream, (long long*)c->d_stage, (long long)(ms * khz));
+    HIPCHK(c, hipGetLastError());
+    return X265AMD_OK;
+}
+
+int x265amd_clock_probe_read(x265amd_ctx *c, double *shader_mhz)
+{
+    if (!c || !shader_mhz || !c->probe_khz) return fail(c, X265AMD_EINVAL, "no probe started");
+    HIPCHK(c, hipSetDevice(c->device));
+    long long out[2] = { 0, 0 };
+    HIPCHK(c, hipMemcpyAsync(out, c->d_stage, sizeof(out), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (out[1] <= 0) return fail(c, X265AMD_EHIP, "probe did not run");
+    *shader_mhz = (double)out[0] / (double)out[1] * c->probe_khz / 1000.0;
     return X265AMD_OK;
 }
 

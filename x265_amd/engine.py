@@ -243,6 +243,16 @@ class Engine:
     def sync(self):
         self._chk(self.L.x265amd_sync(self.ctx))
 
+    def clock_probe_start(self, ms):
+        """Queues the shader-clock probe on this engine's stream (give it an engine of its own next to the work)."""
+        self._chk(self.L.x265amd_clock_probe_start(self.ctx, C.c_double(ms)))
+
+    def clock_probe_read(self):
+        """Average shader clock in MHz over the probe's time."""
+        mhz = C.c_double(0)
+        self._chk(self.L.x265amd_clock_probe_read(self.ctx, C.byref(mhz)))
+        return mhz.value
+
     def set_esa_window_bytes(self, nbytes):
         """LDS one PU of an exhaustive (FULL) search may use for its reference window; tuning only."""
         self._chk(self.L.x265amd_set_esa_window_bytes(self.ctx, int(nbytes)))
