@@ -226,6 +226,10 @@ def main():
     ap.add_argument("--s32", choices=("big", "mid", "la", "own"), default="la",
                     help="pairs4: the stream of the 32x32 launch: behind the 64x64 launch, behind the 16x16 launch, behind the "
                          "lookahead field, or one of its own")
+    ap.add_argument("--sync-steps", choices=("yes", "no"), default="yes",
+                    help="wait for every stream at the end of each step (yes), or let the launches of consecutive steps queue "
+                         "behind each other and wait once at the end of the timed region (no: one GPU, pairs3 / pairs4 only; "
+                         "measured 3 % slower: the next step's first kernels take room from this step's last ones)")
     ap.add_argument("--big-streams", type=int, default=1,
                     help="streams the launches of the 64/32 PU class rotate over (split / split3): a 64x64 PU is one long wave, "
                          "so a launch of one frame's 480 + 1980 large PUs is bounded by that wave's latency, and launches of "
@@ -359,6 +363,8 @@ def main():
                                        QP, method, SUBME, max_pu_dim=dim)
             if c == 0 and k is not None:
                 ev1[k].record(s_search)
+        if not sync_steps:
+            return      # the next step's launches queue behind this one's on every stream; the timed region ends with a sync
         es.sync()
         eb.sync()
         em.sync()
@@ -396,6 +402,7 @@ def main():
             sharding.gather_records(d_mvcost.view(-1).to(cdev), dist, dst=0)
             sharding.gather_records(d_la_mvs.view(torch.uint8).view(-1).to(cdev), dist, dst=0)
 
+    sync_steps = args.sync_steps == "yes" or world > 1 or not multi
     step = step_multi if multi else step_pairwise
     for _ in range(args.warmup):
         step()
@@ -430,6 +437,7 @@ def main():
         except Exception as ex:     # the bench line must survive a failure here
             clock_mhz = None
             print("clock probe failed: %r" % (ex,), file=sys.stderr)
+    torch.cuda.synchronize()
 
     # ---------------- accounting
     if multi:
@@ -581,6 +589,7 @@ def main():
                                    % (args.method, MERANGE, SUBME, B),
                        "pu_searches_per_step_per_gpu": njobs * B, "lookahead_cus_per_step_per_gpu": ncu * B,
                        "qp": QP, "launch": args.launch,
+                       "steps_synchronised": bool(sync_steps),
                        "parallelism": "frame pairs sharded over %d GPU(s), gather of MV records" % world},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
