@@ -868,10 +868,10 @@ static int launch_esa(x265amd_ctx *c, const SearchArgs &a, int window_bytes, int
         HIPCHK(c, hipFuncSetAttribute((const void*)esa_scan_kernel<uint16_t, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, most));
         c->esa_lds_raised = true;
     }
-    /* launches of 8-bit PUs up to 8x8 or up to 16x16: the square PUs of that size are refined by refine_small_kernel */
+    /* the square PUs of the launch's largest size (8- and 10-bit samples) are refined by the fixed-shape kernels */
     static const bool no_staged = getenv("X265AMD_NO_STAGED") != 0;      /* measurements only */
     SearchArgs b = a;
-    b.staged = (BPS == 1 || c->depth <= 10) && (a.max_dim == 8 || a.max_dim == 16) && !no_staged ? a.max_dim : 0;
+    b.staged = (BPS == 1 || c->depth <= 10) && !no_staged ? a.max_dim : 0;     /* 8, 16, 32 or 64 */
     const size_t scan_lds = esa_fixed_lds(a.max_dim, BPS) + window_bytes;
     if (a.max_dim == 8)
         hipLaunchKernelGGL((esa_scan_kernel<P, 8>), dim3(a.njobs), dim3(ESA_THREADS), scan_lds, c->stream, b, window_bytes, nowrap);
@@ -885,6 +885,10 @@ static int launch_esa(x265amd_ctx *c, const SearchArgs &a, int window_bytes, int
         hipLaunchKernelGGL((refine_small_kernel<8, P>), dim3((a.njobs + 3) / 4), dim3(64), RefineLds<8>::TOTAL, c->stream, b);
     else if (b.staged == 16)
         hipLaunchKernelGGL((refine_small_kernel<16, P>), dim3((a.njobs + 3) / 4), dim3(64), RefineLds<16>::TOTAL, c->stream, b);
+    else if (b.staged == 32)
+        hipLaunchKernelGGL((refine_big_kernel<32, P>), dim3(a.njobs), dim3(BigGeo<32>::THREADS), BigLds<32>::TOTAL, c->stream, b);
+    else if (b.staged == 64)
+        hipLaunchKernelGGL((refine_big_kernel<64, P>), dim3(a.njobs), dim3(BigGeo<64>::THREADS), BigLds<64>::TOTAL, c->stream, b);
     HIPCHK(c, hipGetLastError());
     return X265AMD_OK;
 }
