@@ -237,6 +237,9 @@ def main():
     ap.add_argument("--rehearse-one-gpu", action="store_true",
                     help="rehearsal of the N > 1 control flow on a box with one GPU: every rank uses cuda:0 and the "
                          "collectives go over gloo through host memory (RCCL wants one GPU per rank); not a measurement")
+    ap.add_argument("--no-clock-probe", action="store_true",
+                    help="skip the three extra (untimed) steps during which the shader clock is measured: profiler passes, "
+                         "whose per-kernel sums should hold the timed steps only")
     ap.add_argument("--no-other-paths", action="store_true",
                     help="skip the exhaustive-search (4K) and Rockchip-path (1080p) measurements reported beside the headline")
     args = ap.parse_args()
@@ -425,7 +428,7 @@ def main():
 
     # the shader clock under this load: three more steps (untimed) with the probe wave beside them on a stream of its own
     clock_mhz = None
-    if rank == 0 and multi:
+    if rank == 0 and multi and not args.no_clock_probe:
         try:
             ep = Engine(local_rank, 8)
             step()

@@ -2,7 +2,7 @@ set -e
 OUT=$GRAFT_REPO_ROOT/gpurun_out
 cd /tmp && export TMPDIR=/tmp
 rm -rf $OUT/exp_sq
-timeout -s KILL 120 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY --output-format csv -d $OUT/exp_sq -- python3 $GRAFT_REPO_ROOT/bench.py --steps 1 --warmup 0 --pairs 2 --cpu-pairs 0 --no-other-paths $EXP_OPTS > $OUT/exp_sq.log 2>&1
+timeout -s KILL 120 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY --output-format csv -d $OUT/exp_sq -- python3 $GRAFT_REPO_ROOT/bench.py --steps 1 --warmup 0 --pairs 2 --cpu-pairs 0 --no-other-paths --no-clock-probe $EXP_OPTS > $OUT/exp_sq.log 2>&1
 python3 - $(find $OUT/exp_sq -name '*counter_collection.csv' | head -1) <<'PY'
 import csv, sys, collections, re
 cnt = collections.defaultdict(lambda: collections.defaultdict(float))

@@ -44,10 +44,10 @@ def class_of(kernels):
     if "lookahead_band_kernel" in names:
         parts.append("lookahead")
     for s in ("8", "16"):
-        if "star_small_kernel<%s>" % s in names:
+        if re.search(r"star_small_kernel<%s[,>]" % s, names):
             parts.append("%sx%s" % (s, s))
     for s in ("32", "64"):
-        if "refine_big_kernel<%s>" % s in names:
+        if re.search(r"refine_big_kernel<%s[,>]" % s, names):
             parts.append("%sx%s" % (s, s))
     return " + ".join(parts) or "other"
 
@@ -61,7 +61,7 @@ for r in rows:
     agg[(k, g)].append((s, e))
     ev.append((s, e, k, g, r["Queue_Id"]))
 ev.sort()
-lines = ["rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 5 --warmup 2 --cpu-pairs 0 --no-other-paths",
+lines = ["rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 5 --warmup 2 --cpu-pairs 0 --no-other-paths --no-clock-probe",
          "(set-up launches included in the call counts; durations in microseconds)", "",
          "%-44s %9s %6s %9s %9s %9s %9s" % ("kernel", "grid", "calls", "avg", "median", "min", "max")]
 for (k, g), v in sorted(agg.items(), key=lambda kv: -sum(e - s for s, e in kv[1])):
@@ -100,7 +100,7 @@ for r in rows:
     key = (short(r["Kernel_Name"]), int(r["Grid_Size"]), r["Queue_Id"])
     cnt[key][r["Counter_Name"]] += float(r["Counter_Value"])
 lines = ["rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_WAVE_CYCLES "
-         "SQ_WAIT_INST_ANY -- python3 bench.py --steps 1 --warmup 0 --pairs 2 --cpu-pairs 0 --no-other-paths",
+         "SQ_WAIT_INST_ANY -- python3 bench.py --steps 1 --warmup 0 --pairs 2 --cpu-pairs 0 --no-other-paths --no-clock-probe",
          "(totals over the run: one step of 2 frame pairs; kernels of the set-up included under their own grids)", ""]
 for (k, g, q), v in sorted(cnt.items(), key=lambda kv: -kv[1].get("SQ_INSTS_VALU", 0)):
     w = v.get("SQ_WAVES", 0)
@@ -120,10 +120,10 @@ def per_pair(v):
 q_of = {}
 for (k, g, q) in cnt:
     for s in ("8", "16"):
-        if k == "star_small_kernel<%s>" % s:
+        if re.match(r"star_small_kernel<%s[,>]" % s, k):
             q_of[q] = q_of.get(q, []) + [s]
     for s in ("32", "64"):
-        if k == "refine_big_kernel<%s>" % s:
+        if re.match(r"refine_big_kernel<%s[,>]" % s, k):
             q_of[q] = q_of.get(q, []) + [s]
 kern, timed = {}, []
 for (k, g, q), v in cnt.items():
@@ -174,7 +174,7 @@ for (k, g), v in tr.items():
     b = (2 * v.get("FETCH_SIZE", 0) + v.get("WRITE_SIZE", 0)) * 1024 / PAIRS_PMC
     detail["%s grid %d" % (k, g)] = {"FETCH_SIZE_KB": v.get("FETCH_SIZE", 0) / PAIRS_PMC, "WRITE_SIZE_KB": v.get("WRITE_SIZE", 0) / PAIRS_PMC,
                                       "hbm_bytes_per_pair": b}
-    if k in ("star_small_kernel<8>", "refine_small_kernel<8>") or k == "redo_list_kernel" and g == (PUS_8 * PAIRS_PMC + 2047) // 2048 * 256:
+    if re.match(r"(star_small_kernel|refine_small_kernel)<8[,>]", k) or k == "redo_list_kernel" and g == (PUS_8 * PAIRS_PMC + 2047) // 2048 * 256:
         total += b
 # the one-wave search over the marked 8x8 PUs shares its grid with the 16x16 class's: half of the pair is charged
 red = tr.get(("search_kernel<unsigned char, false>", 8192 * 64))

@@ -1,16 +1,16 @@
+# Everything measured for a round's profiles/ in one go (run on the GPU box from the repo root):
+#   bash tools/round_measure.sh r02
+# then, back in the container: python tools/profile_summary.py gpurun_out r02, and copy the text outputs to profiles/.
 set -e
+TAG=${1:-r02}
 cd $GRAFT_REPO_ROOT
-timeout -k 10 600 python -u -m pytest tests -m gpu -x -q --timeout 120 --timeout-method thread > gpurun_out/pytest_final.log 2>&1
-timeout -k 10 400 python bench.py > gpurun_out/bench_final.json 2> gpurun_out/bench_final.err
-cd /tmp && export TMPDIR=/tmp
-timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/prof_final -- python3 $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 > $GRAFT_REPO_ROOT/gpurun_out/prof_final.log 2>&1
-timeout -s KILL 120 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/pmc_fetch2 -- python3 $GRAFT_REPO_ROOT/bench.py --steps 1 --warmup 0 --pairs 2 --cpu-pairs 0 --no-other-paths > $GRAFT_REPO_ROOT/gpurun_out/pmc_fetch2.log 2>&1
-timeout -s KILL 120 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/pmc_write2 -- python3 $GRAFT_REPO_ROOT/bench.py --steps 1 --warmup 0 --pairs 2 --cpu-pairs 0 --no-other-paths > $GRAFT_REPO_ROOT/gpurun_out/pmc_write2.log 2>&1
-timeout -s KILL 120 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/pmc_sq2 -- python3 $GRAFT_REPO_ROOT/bench.py --steps 1 --warmup 0 --pairs 2 --cpu-pairs 0 --no-other-paths > $GRAFT_REPO_ROOT/gpurun_out/pmc_sq2.log 2>&1
-cd $GRAFT_REPO_ROOT
-timeout -k 10 200 python -u tools/mc_bench.py > gpurun_out/mc_bench_final.txt 2>&1
-timeout -k 10 200 python -u tools/mc_bench.py --width 3840 --height 2160 --no-check >> gpurun_out/mc_bench_final.txt 2>&1
-timeout -k 10 200 python -u tools/mc_bench.py --width 3840 --height 2160 --depth 10 --no-check >> gpurun_out/mc_bench_final.txt 2>&1
-cd /tmp
-timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/prof_mc -- python3 $GRAFT_REPO_ROOT/tools/mc_bench.py --width 3840 --height 2160 --no-check > $GRAFT_REPO_ROOT/gpurun_out/prof_mc.log 2>&1
-timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/prof_bipred_final -- python3 $GRAFT_REPO_ROOT/tools/bipred_bench.py > $GRAFT_REPO_ROOT/gpurun_out/bipred_bench_final.txt 2>&1
+export PYTHONPATH=$GRAFT_REPO_ROOT
+timeout -k 10 900 python -u -m pytest tests -m gpu -x -q --timeout 120 --timeout-method thread > gpurun_out/${TAG}_pytest.log 2>&1
+timeout -k 10 300 python -c "import __graft_entry__ as g; g.smoke()" > gpurun_out/${TAG}_smoke.log 2>&1
+timeout -k 10 400 python bench.py > gpurun_out/${TAG}_bench.json 2> gpurun_out/${TAG}_bench.err
+timeout -k 10 300 python -u tools/esa_bench.py --check 64 > gpurun_out/${TAG}_esa_bench.txt 2>&1
+timeout -k 10 300 python -u tools/esa_bench.py --depth 10 --check 32 > gpurun_out/${TAG}_esa_main10_bench.txt 2>&1
+timeout -k 10 300 python -u tools/rk_bench.py > gpurun_out/${TAG}_rk_bench.txt 2>&1
+timeout -k 10 300 python -u tools/la_bench.py > gpurun_out/${TAG}_la_bench.txt 2>&1
+timeout -k 10 300 python -u tools/pattern_bench.py > gpurun_out/${TAG}_pattern_4k.txt 2>&1
+bash tools/profile_round.sh $TAG
