@@ -884,7 +884,7 @@ static int launch_esa(x265amd_ctx *c, const SearchArgs &a, int window_bytes, int
     if (b.staged == 8)
         hipLaunchKernelGGL((refine_small_kernel<8, P>), dim3((a.njobs + 3) / 4), dim3(64), RefineLds<8>::TOTAL, c->stream, b);
     else if (b.staged == 16)
-        hipLaunchKernelGGL((refine_small_kernel<16, P>), dim3((a.njobs + 3) / 4), dim3(64), RefineLds<16>::TOTAL, c->stream, b);
+        hipLaunchKernelGGL((refine_small_kernel<16, P>), dim3((a.njobs + RefineGeo<16>::NPU - 1) / RefineGeo<16>::NPU), dim3(64), RefineLds<16>::TOTAL, c->stream, b);
     else if (b.staged == 32)
         hipLaunchKernelGGL((refine_big_kernel<32, P>), dim3(a.njobs), dim3(BigGeo<32>::THREADS), BigLds<32>::TOTAL, c->stream, b);
     else if (b.staged == 64)
@@ -906,7 +906,7 @@ static int launch_search(x265amd_ctx *c, const SearchArgs &a, int is_lowres)
         static const bool no_star = getenv("X265AMD_NO_STAR8") != 0;
         SearchArgs b = a;
         /* launches of 8-bit PUs up to 8x8, 16x16, 32x32 or 64x64: the square PUs of that size are refined by a second
-         * kernel (four 8x8 PUs, one 16x16 PU or one 32x32 PU per wave; four waves per 64x64 PU) */
+         * kernel (four 8x8 PUs or two 16x16 PUs per wave; two waves per 32x32 PU, four per 64x64 PU) */
         static const bool no_big = getenv("X265AMD_NO_STAGED_BIG") != 0;                             /* measurements only */
         b.staged = (sizeof(P) == 1 || c->depth <= 10) && !no_staged &&
                    (a.max_dim == 8 || a.max_dim == 16 || ((a.max_dim == 32 || a.max_dim == 64) && !no_big)) ? a.max_dim : 0;
@@ -933,7 +933,7 @@ static int launch_search(x265amd_ctx *c, const SearchArgs &a, int is_lowres)
         if (b.staged == 8)
             hipLaunchKernelGGL((refine_small_kernel<8, P>), dim3(rgroups), dim3(64), RefineLds<8>::TOTAL, c->stream, b);
         else if (b.staged == 16)
-            hipLaunchKernelGGL((refine_small_kernel<16, P>), dim3(rgroups), dim3(64), RefineLds<16>::TOTAL, c->stream, b);
+            hipLaunchKernelGGL((refine_small_kernel<16, P>), dim3((a.njobs + RefineGeo<16>::NPU - 1) / RefineGeo<16>::NPU), dim3(64), RefineLds<16>::TOTAL, c->stream, b);
         else if (b.staged == 32)
             hipLaunchKernelGGL((refine_big_kernel<32, P>), dim3(a.njobs), dim3(BigGeo<32>::THREADS), BigLds<32>::TOTAL, c->stream, b);
         else if (b.staged == 64)

@@ -104,7 +104,16 @@ struct ColSrc
 };
 
 template<int LG> __device__ __forceinline__ int grp_lane(int v, int k) { return __shfl(v, (int)(threadIdx.x & 63 & ~((1 << LG) - 1)) + k); }
-template<int LG> __device__ __forceinline__ int grp_min(int v) { return LG == 4 ? row_min16(v) : wave_min(v); }
+template<int LG> __device__ __forceinline__ int grp_min(int v)
+{
+    if (LG == 4) return row_min16(v);
+    if (LG == 5)
+    {
+        const int m = row_min16(v), o = __shfl_xor(m, 16);
+        return o < m ? o : m;
+    }
+    return wave_min(v);
+}
 /* flags of the first 16 lanes of the group */
 template<int LG> __device__ __forceinline__ unsigned grp_bits16(bool p)
 {
@@ -234,13 +243,14 @@ __device__ __forceinline__ void small_planes(const SearchArgs &a, int d1, const 
 
 /* ---------------------------------------------------------------- sub-pel refinement */
 
-/* Sixteen lanes per PU and four PUs per wave for both sizes: a lane of an 8x8 PU looks after one (tile, column) pair,
- * a lane of a 16x16 PU after four, one tile row apart -- its cross-lane sums and the bookkeeping of a candidate are
- * then paid once per four pairs. */
+/* Sixteen lanes per 8x8 PU, four PUs per wave, a (tile, column) pair per lane. Thirty-two lanes per 16x16 PU, two PUs
+ * per wave, two pairs per lane, one tile row band apart: the cross-lane sums and the bookkeeping of a candidate are paid
+ * once per two pairs. (Sixteen lanes with four pairs issue 9 % fewer instructions, but need 157 registers and 10 KB of
+ * LDS per wave -- three waves per SIMD -- and were 1.4 % slower on the headline step; a pair per lane, 6 % slower.) */
 template<int S> struct RefineGeo
 {
     static_assert(S == 8 || S == 16, "8x8 or 16x16 PUs");
-    static constexpr int LG = 4, LPP = 16, NPU = 4;
+    static constexpr int LG = S == 16 ? 5 : 4, LPP = 1 << LG, NPU = 64 / LPP;
     static constexpr int ITEMS = SmallGeo<S>::LPP / LPP;
 };
 
@@ -410,8 +420,8 @@ __global__ __launch_bounds__(64) void refine_small_kernel(SearchArgs a)
 
 /* ---------------------------------------------------------------- sub-pel refinement of 32x32 and 64x64 PUs
  *
- * The same rounds for the large PUs: one wave per 32x32 PU and a workgroup of four waves per 64x64 PU, every lane
- * looking after four (tile, column) pairs, one tile row band apart, where the one-wave search walks the PU's 64 or 256 tiles through
+ * The same rounds for the large PUs: a workgroup of two waves per 32x32 PU and of four waves per 64x64 PU, every lane
+ * looking after two or four (tile, column) pairs, one tile row band apart, where the one-wave search walks the PU's 64 or 256 tiles through
  * its general candidate machinery. The three planes of a round are filled by all waves together; every wave measures
  * its tiles of every candidate and adds the wave's sum to the candidate's cell in LDS (one cell array per round,
  * zeroed at the start, so no round has to wait for cells to be cleared); after the barrier every wave reads the same
@@ -421,7 +431,9 @@ __global__ __launch_bounds__(64) void refine_small_kernel(SearchArgs a)
 template<int S> struct BigGeo
 {
     static_assert(S == 32 || S == 64, "32x32 or 64x64 PUs");
-    static constexpr int WAVES = S == 32 ? 1 : 4;
+    /* measured on the headline step: one wave per 32x32 PU (four pairs per lane) issues 9 % fewer instructions and is
+     * 0.4 % slower than two (its LDS leaves 4.5 waves per SIMD); eight waves per 64x64 PU are 1.4 % slower than four */
+    static constexpr int WAVES = S == 32 ? 2 : 4;
     static constexpr int THREADS = WAVES * 64;
     static constexpr int ITEMS = SmallGeo<S>::LPP / THREADS;        /* (tile, column) pairs per lane */
 };
