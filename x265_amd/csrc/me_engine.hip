@@ -51,6 +51,7 @@ struct SearchArgs
     int *redo;         /* null, or the list redo_list_kernel made of the PUs whose result record carries SMALL_REDO (left over
                           by star_small_kernel): redo[0] = their number, redo[REDO_LIST..] = their job indices. The launch
                           then searches only these, each wave taking every gridDim.x-th entry */
+    int plane_lds; /* LDS bytes a wave of search_kernel has for interpolation planes (0: plane_budget of max_dim) */
     int staged;    /* 8, 16, 32 or 64: square PUs of this size stop before the sub-pel refinement, which refine_small_kernel
                       (8, 16) or refine_big_kernel (32, 64) does; 0: none */
 };
@@ -135,7 +136,8 @@ __global__ __launch_bounds__(64) void search_kernel(SearchArgs a)
         }
         PlaneDev fenc, ref[4];
         job_planes(a, job, fenc, ref);
-        S.bind(0, fenc, ref, a.nref, a.ctab, a.depth, job->pu_x, job->pu_y, w, h, a.max_dim, plane_budget(a.max_dim, (int)sizeof(P)));
+        S.bind(0, fenc, ref, a.nref, a.ctab, a.depth, job->pu_x, job->pu_y, w, h, a.max_dim,
+               a.plane_lds ? a.plane_lds : plane_budget(a.max_dim, (int)sizeof(P)));
         if (a.staged && w == a.staged && h == a.staged) S.search_staged(job, a.method, a.results + j);
         else S.search(job, a.method, a.subme, a.results + j);
     }
@@ -929,7 +931,18 @@ static int launch_search(x265amd_ctx *c, const SearchArgs &a, int is_lowres)
             b.redo = 0;
         }
         else
-            hipLaunchKernelGGL((search_kernel<P, false>), dim3(a.njobs), dim3(64), wave_lds_bytes<P>(a.max_dim, true) + pad, c->stream, b);
+        {
+            /* a launch of large PUs that refines elsewhere interpolates only its quarter-pel start-up candidates: room
+             * for one plane instead of two lets a compute unit hold a third more of its waves */
+            static const bool lean = getenv("X265AMD_NO_LEAN") == 0;
+            int lds = wave_lds_bytes<P>(a.max_dim, true);
+            if (b.staged >= 32 && lean)
+            {
+                b.plane_lds = plane_budget(a.max_dim, (int)sizeof(P)) / 2;
+                lds -= b.plane_lds;
+            }
+            hipLaunchKernelGGL((search_kernel<P, false>), dim3(a.njobs), dim3(64), lds + pad, c->stream, b);
+        }
         if (b.staged == 8)
             hipLaunchKernelGGL((refine_small_kernel<8, P>), dim3(rgroups), dim3(64), RefineLds<8>::TOTAL, c->stream, b);
         else if (b.staged == 16)
@@ -1326,7 +1339,7 @@ static void fill_args(x265amd_ctx *c, SearchArgs &a, const x265amd_plane *fenc, 
         a.ref[i].origin = r->origin; a.ref[i].stride = r->stride;
     }
     a.lowres = is_lowres; a.depth = c->depth; a.method = method; a.subme = subme; a.max_dim = is_lowres ? 8 : 64;
-    a.staged = 0; a.redo = 0; a.pairs = 0; a.npairs = 0;
+    a.staged = 0; a.redo = 0; a.pairs = 0; a.npairs = 0; a.plane_lds = 0;
     a.ctab = c->tables[qp] + 32768;
 }
 
