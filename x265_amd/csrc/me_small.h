@@ -164,30 +164,38 @@ __device__ __forceinline__ void hps_quad(const uint8_t AS1 *s, const int *tp, in
  * row 0, vertical phase yf. The four lanes of a quad hold the four columns of a tile. SAD: the sum over the lane's
  * column. SATD: the vertical Hadamard inside the lane, the horizontal one across the quad (DPP); the lane returns the
  * abs-sum of its four coefficients and the caller halves the total (every tile's abs-sum is even, pixel.cpp:226). */
-template<int S>
-__device__ __forceinline__ int small_column_cost(int poff, int r0, int yf, bool satd, const ColSrc &ct, int x, int depth = 8)
+/* N (4 or 5) consecutive output rows of the vertical pass for the lane's column: sums whose high halves are
+ * (int16_t)(sum >> (20 - depth)), luma_vsp's result before the clip (ipfilter.cpp:372-389) */
+template<int S, int N>
+__device__ __forceinline__ void small_column_rows(int poff, int r0, int yf, const ColSrc &ct, int depth, int o[N])
 {
     const int R = r0 + 4 * ct.ty;
     const uint32_t *col = (const uint32_t*)(x265amd_smem + poff + (__mul24(ct.col, SmallGeo<S>::PROW) + (R & ~1)) * 2);
     const uint32_t *tp = (const uint32_t*)(x265amd_smem + SM_VTAPS) + ((yf << 1) | (r0 & 1)) * 10;
-    uint32_t E[6], P[5], Q[5];
+    uint32_t E[N + 2], P[5], Q[5];
 #pragma unroll
-    for (int i = 0; i < 6; i++) E[i] = col[i];
+    for (int i = 0; i < N + 2; i++) E[i] = col[i];
 #pragma unroll
     for (int i = 0; i < 5; i++) { P[i] = tp[i]; Q[i] = tp[5 + i]; }
-    /* luma_vsp's rounding and the intermediates' bias (ipfilter.cpp:372-375: shift 20 - depth), scaled like the taps */
+    /* luma_vsp's rounding and the intermediates' bias (shift 20 - depth), scaled like the taps */
     const int OFF = ((1 << (19 - depth)) + (8192 << 6)) << (depth - 4);
-    int o[4];
-    o[0] = dot2(E[0], P[0], dot2(E[1], P[1], dot2(E[2], P[2], dot2(E[3], P[3], dot2(E[4], P[4], OFF)))));
-    o[1] = dot2(E[0], Q[0], dot2(E[1], Q[1], dot2(E[2], Q[2], dot2(E[3], Q[3], dot2(E[4], Q[4], OFF)))));
-    o[2] = dot2(E[1], P[0], dot2(E[2], P[1], dot2(E[3], P[2], dot2(E[4], P[3], dot2(E[5], P[4], OFF)))));
-    o[3] = dot2(E[1], Q[0], dot2(E[2], Q[1], dot2(E[3], Q[2], dot2(E[4], Q[3], dot2(E[5], Q[4], OFF)))));
-    /* the high halves are (int16_t)(sum >> (20 - depth)); clipped to the sample range as pairs. Differences and every
-     * Hadamard stage fit int16 up to 10 bits (16 * 1023) */
+#pragma unroll
+    for (int k = 0; k < N; k++)
+    {
+        const uint32_t *T = (k & 1) ? Q : P;
+        const int e = k >> 1;
+        o[k] = dot2(E[e], T[0], dot2(E[e + 1], T[1], dot2(E[e + 2], T[2], dot2(E[e + 3], T[3], dot2(E[e + 4], T[4], OFF)))));
+    }
+}
+
+/* cost of the lane's column given its four output rows: clipped to the sample range as pairs, then SAD or the lane's
+ * share of the 4x4 Hadamard. Differences and every Hadamard stage fit int16 up to 10 bits (16 * 1023) */
+__device__ __forceinline__ int small_rows_cost(int o0, int o1, int o2, int o3, bool satd, const ColSrc &ct, int x, int depth)
+{
     const short maxv = (short)((1 << depth) - 1);
     const s16x2 lo = { 0, 0 }, hi = { maxv, maxv }, one = { 1, 1 };
-    s16x2 p01 = __builtin_bit_cast(s16x2, __builtin_amdgcn_perm((uint32_t)o[1], (uint32_t)o[0], 0x07060302u));
-    s16x2 p23 = __builtin_bit_cast(s16x2, __builtin_amdgcn_perm((uint32_t)o[3], (uint32_t)o[2], 0x07060302u));
+    s16x2 p01 = __builtin_bit_cast(s16x2, __builtin_amdgcn_perm((uint32_t)o1, (uint32_t)o0, 0x07060302u));
+    s16x2 p23 = __builtin_bit_cast(s16x2, __builtin_amdgcn_perm((uint32_t)o3, (uint32_t)o2, 0x07060302u));
     p01 = __builtin_elementwise_min(__builtin_elementwise_max(p01, lo), hi);
     p23 = __builtin_elementwise_min(__builtin_elementwise_max(p23, lo), hi);
     const s16x2 d01 = __builtin_bit_cast(s16x2, ct.f01) - p01, d23 = __builtin_bit_cast(s16x2, ct.f23) - p23;
@@ -208,6 +216,26 @@ __device__ __forceinline__ int small_column_cost(int poff, int r0, int yf, bool 
     U = __builtin_elementwise_max(U, -U);
     W = __builtin_elementwise_max(W, -W);
     return __builtin_amdgcn_sdot2(U, one, __builtin_amdgcn_sdot2(W, one, 0, false), false);
+}
+
+template<int S>
+__device__ __forceinline__ int small_column_cost(int poff, int r0, int yf, bool satd, const ColSrc &ct, int x, int depth = 8)
+{
+    int o[4];
+    small_column_rows<S, 4>(poff, r0, yf, ct, depth, o);
+    return small_rows_cost(o[0], o[1], o[2], o[3], satd, ct, x, depth);
+}
+
+/* Two candidates of one plane and phase whose first rows are r0 and r0 + 1 -- the half-pel neighbours above and below
+ * a centre: (y - 2) and (y + 2) quarter-pels are one row apart -- share three of their four output rows: five vertical
+ * sums instead of eight. */
+template<int S>
+__device__ __forceinline__ void small_column_cost_pair(int poff, int r0, int yf, bool satd, const ColSrc &ct, int x, int depth, int &va, int &vb)
+{
+    int o[5];
+    small_column_rows<S, 5>(poff, r0, yf, ct, depth, o);
+    va += small_rows_cost(o[0], o[1], o[2], o[3], satd, ct, x, depth);
+    vb += small_rows_cost(o[1], o[2], o[3], o[4], satd, ct, x, depth);
 }
 
 /* the lane's tile column of the source block */
@@ -283,9 +311,10 @@ template<int S, typename P> struct RefineSmall
      * centre itself first when CENTRE (the SATD re-measure of motion.cpp:1086, :1117, whose cost replaces
      * bcost). DIRS = 0 with CENTRE measures the centre alone (the closing SATD of subme 0). The candidate loop is
      * unrolled, so which plane and which of the three first rows / phases a candidate reads is fixed at compile time. */
-    template<int DIRS, bool CENTRE>
-    __device__ __forceinline__ void round_t(int step, bool satd)
+    template<int DIRS, bool CENTRE, bool HPEL>
+    __device__ __forceinline__ void round_t(bool satd)
     {
+        constexpr int step = HPEL ? 2 : 1;
         constexpr unsigned long long SQX = nibs({ 0, 0, 0, -1, 1, -1, -1, 1, 1 }), SQY = nibs({ 0, -1, 1, 0, 0, -1, 1, -1, 1 });
         constexpr int k0 = CENTRE ? 1 : 0, K = k0 + DIRS;
         /* lambda * bits of the candidate this lane folds (bitcost.h:46: the sum wraps at 16 bits) */
@@ -332,6 +361,19 @@ template<int S, typename P> struct RefineSmall
         for (int c = 0; c < K; c++)
         {
             const int i = c + 1 - k0, dx = nib(SQX, i), dy = nib(SQY, i);
+            /* half-pel rounds: the table lists (dx, -1) right before (dx, +1), one row apart in the same plane and phase */
+            if (HPEL && i >= 2 && dy == 1 && nib(SQY, i - 1) == -1 && nib(SQX, i - 1) == dx) continue;   /* measured with its partner */
+            if (HPEL && i >= 1 && dy == -1 && c + 1 < K && nib(SQY, i + 1) == 1 && nib(SQX, i + 1) == dx)
+            {
+                int va = 0, vb = 0;
+#pragma unroll
+                for (int u = 0; u < RG::ITEMS; u++)
+                    small_column_cost_pair<S>(pbase + (dx + 1) * G::PLANE, r0y[0], phy[0], satd, ct[u], l & 3, depth, va, vb);
+                va = seg_sum(va, RG::LG); vb = seg_sum(vb, RG::LG);
+                if (l == c) mycost = (satd ? va >> 1 : va) + mvc;
+                if (l == c + 1) mycost = (satd ? vb >> 1 : vb) + mvc;
+                continue;
+            }
             int v = 0;
 #pragma unroll
             for (int u = 0; u < RG::ITEMS; u++)
@@ -356,9 +398,14 @@ template<int S, typename P> struct RefineSmall
     /* the rounds the workload table can ask for (motion.cpp:53-63: four or eight directions) */
     __device__ __forceinline__ void round(int step, int dirs, bool satd, bool centre)
     {
-        if (dirs == 8) { if (centre) round_t<8, true>(step, satd); else round_t<8, false>(step, satd); }
-        else if (dirs == 4) { if (centre) round_t<4, true>(step, satd); else round_t<4, false>(step, satd); }
-        else if (centre) round_t<0, true>(step, satd);
+        if (step == 2)
+        {
+            if (dirs == 8) { if (centre) round_t<8, true, true>(satd); else round_t<8, false, true>(satd); }
+            else if (dirs == 4) { if (centre) round_t<4, true, true>(satd); else round_t<4, false, true>(satd); }
+        }
+        else if (dirs == 8) { if (centre) round_t<8, true, false>(satd); else round_t<8, false, false>(satd); }
+        else if (dirs == 4) { if (centre) round_t<4, true, false>(satd); else round_t<4, false, false>(satd); }
+        else if (centre) round_t<0, true, false>(satd);
     }
 };
 
@@ -517,6 +564,19 @@ __global__ __launch_bounds__(BigGeo<S>::THREADS) void refine_big_kernel(SearchAr
             const int i = c + 1 - k0;
             const int ty = as_i16(qy + nib(SQY, i) * step);
             const int poff = L::PLANES + (nib(SQX, i) + 1) * G::PLANE, rr = (ty >> 2) - ymin;
+            /* half-pel rounds: (dx, -1) and (dx, +1) follow each other in the table and are one row apart in the same
+             * plane and phase -- measured together */
+            if (step == 2 && i >= 1 && nib(SQY, i) == -1 && c + 1 < K && nib(SQY, i + 1) == 1 && nib(SQX, i + 1) == nib(SQX, i))
+            {
+                int va = 0, vb = 0;
+#pragma unroll
+                for (int u = 0; u < ITEMS; u++) small_column_cost_pair<S>(poff, rr, ty & 3, satd, ct[u], tid & 3, depth, va, vb);
+                va = seg_sum(va, 6); vb = seg_sum(vb, 6);
+                if (lane == c) part = va;
+                if (lane == c + 1) part = vb;
+                c++;
+                continue;
+            }
             int v = 0;
 #pragma unroll
             for (int u = 0; u < ITEMS; u++) v += small_column_cost<S>(poff, rr, ty & 3, satd, ct[u], tid & 3, depth);
