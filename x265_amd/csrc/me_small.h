@@ -193,17 +193,16 @@ __device__ __forceinline__ void small_column_rows(int poff, int r0, int yf, cons
 __device__ __forceinline__ int small_rows_cost(int o0, int o1, int o2, int o3, bool satd, const ColSrc &ct, int x, int depth)
 {
     const short maxv = (short)((1 << depth) - 1);
-    const s16x2 lo = { 0, 0 }, hi = { maxv, maxv }, one = { 1, 1 };
+    const s16x2 lo = { 0, 0 }, hi = { maxv, maxv };
     s16x2 p01 = __builtin_bit_cast(s16x2, __builtin_amdgcn_perm((uint32_t)o1, (uint32_t)o0, 0x07060302u));
     s16x2 p23 = __builtin_bit_cast(s16x2, __builtin_amdgcn_perm((uint32_t)o3, (uint32_t)o2, 0x07060302u));
     p01 = __builtin_elementwise_min(__builtin_elementwise_max(p01, lo), hi);
     p23 = __builtin_elementwise_min(__builtin_elementwise_max(p23, lo), hi);
-    const s16x2 d01 = __builtin_bit_cast(s16x2, ct.f01) - p01, d23 = __builtin_bit_cast(s16x2, ct.f23) - p23;
+    /* SAD: source and prediction are unsigned 16-bit pairs, which is what v_sad_u16 takes */
     if (!satd)
-    {
-        const s16x2 a = __builtin_elementwise_max(d01, -d01), b = __builtin_elementwise_max(d23, -d23);
-        return __builtin_amdgcn_sdot2(a, one, __builtin_amdgcn_sdot2(b, one, 0, false), false);
-    }
+        return (int)__builtin_amdgcn_sad_u16(ct.f01, __builtin_bit_cast(uint32_t, p01),
+                                             __builtin_amdgcn_sad_u16(ct.f23, __builtin_bit_cast(uint32_t, p23), 0u));
+    const s16x2 d01 = __builtin_bit_cast(s16x2, ct.f01) - p01, d23 = __builtin_bit_cast(s16x2, ct.f23) - p23;
     const s16x2 Sm = d01 + d23, Df = d01 - d23;                     /* (r0+r2, r1+r3), (r0-r2, r1-r3) */
     const s16x2 A = __builtin_shufflevector(Sm, Df, 0, 2), B = __builtin_shufflevector(Sm, Df, 1, 3);
     s16x2 U = A + B, W = A - B;                                     /* vertical coefficients (c0, c2), (c1, c3) */
@@ -213,9 +212,10 @@ __device__ __forceinline__ int small_rows_cost(int o0, int o1, int o2, int o3, b
     W = W * s1 + __builtin_bit_cast(s16x2, dpp_all<0xB1>(__builtin_bit_cast(int, W)));
     U = U * s2 + __builtin_bit_cast(s16x2, dpp_all<0x4E>(__builtin_bit_cast(int, U)));
     W = W * s2 + __builtin_bit_cast(s16x2, dpp_all<0x4E>(__builtin_bit_cast(int, W)));
-    U = __builtin_elementwise_max(U, -U);
-    W = __builtin_elementwise_max(W, -W);
-    return __builtin_amdgcn_sdot2(U, one, __builtin_amdgcn_sdot2(W, one, 0, false), false);
+    /* sum of the four magnitudes: a coefficient c as the unsigned c + 0x8000 is |c| away from 0x8000 */
+    const uint32_t bias = 0x80008000u;
+    return (int)__builtin_amdgcn_sad_u16(__builtin_bit_cast(uint32_t, U) ^ bias, bias,
+                                         __builtin_amdgcn_sad_u16(__builtin_bit_cast(uint32_t, W) ^ bias, bias, 0u));
 }
 
 template<int S>
