@@ -559,14 +559,13 @@ __device__ __forceinline__ int plane_column_cost(int base, const ColCand &cc, co
     {
         /* 8-bit samples: differences and every Hadamard stage fit int16 (16 * 255), so rows
          * (0, 1) and (2, 3) travel as packed pairs through v_pk_* instructions */
-        const s16x2 one = { 1, 1 };
         const s16x2 d01 = __builtin_bit_cast(s16x2, (uint32_t)(ct.f[0] | (ct.f[1] << 16))) - __builtin_bit_cast(s16x2, (uint32_t)(pr[0] | (pr[1] << 16)));
         const s16x2 d23 = __builtin_bit_cast(s16x2, (uint32_t)(ct.f[2] | (ct.f[3] << 16))) - __builtin_bit_cast(s16x2, (uint32_t)(pr[2] | (pr[3] << 16)));
+        /* sums of magnitudes on v_sad_u16: a signed 16-bit value c as the unsigned c + 0x8000 is |c| away from 0x8000 */
+        const uint32_t bias = 0x80008000u;
         if (!cc.satd)
-        {
-            const s16x2 a = __builtin_elementwise_max(d01, -d01), b = __builtin_elementwise_max(d23, -d23);
-            return __builtin_amdgcn_sdot2(a, one, __builtin_amdgcn_sdot2(b, one, 0, false), false);
-        }
+            return (int)__builtin_amdgcn_sad_u16(__builtin_bit_cast(uint32_t, d01) ^ bias, bias,
+                                                 __builtin_amdgcn_sad_u16(__builtin_bit_cast(uint32_t, d23) ^ bias, bias, 0u));
         const s16x2 S = d01 + d23, D = d01 - d23;                       /* (r0+r2, r1+r3), (r0-r2, r1-r3) */
         const s16x2 A = __builtin_shufflevector(S, D, 0, 2), B = __builtin_shufflevector(S, D, 1, 3);
         s16x2 U = A + B, W = A - B;                                     /* vertical coefficients (c0, c2), (c1, c3) */
@@ -576,9 +575,8 @@ __device__ __forceinline__ int plane_column_cost(int base, const ColCand &cc, co
         W = W * s1 + __builtin_bit_cast(s16x2, dpp_all<0xB1>(__builtin_bit_cast(int, W)));
         U = U * s2 + __builtin_bit_cast(s16x2, dpp_all<0x4E>(__builtin_bit_cast(int, U)));
         W = W * s2 + __builtin_bit_cast(s16x2, dpp_all<0x4E>(__builtin_bit_cast(int, W)));
-        U = __builtin_elementwise_max(U, -U);
-        W = __builtin_elementwise_max(W, -W);
-        return __builtin_amdgcn_sdot2(U, one, __builtin_amdgcn_sdot2(W, one, 0, false), false);
+        return (int)__builtin_amdgcn_sad_u16(__builtin_bit_cast(uint32_t, U) ^ bias, bias,
+                                             __builtin_amdgcn_sad_u16(__builtin_bit_cast(uint32_t, W) ^ bias, bias, 0u));
     }
     int dv[4];
 #pragma unroll
