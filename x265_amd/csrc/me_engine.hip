@@ -809,6 +809,7 @@ struct x265amd_ctx
     void *d_results; size_t results_cap;
     void *d_stage; size_t stage_cap;   /* staging for the per-call primitives */
     int probe_khz;                     /* constant-rate clock of the last x265amd_clock_probe_start, kHz */
+    long long *d_probe;                /* the probe wave's two counters (a buffer of its own: other calls may run meanwhile) */
     void *d_redo; size_t redo_cap;     /* list of the PUs a fixed-shape kernel left to the one-wave search (redo_list_kernel) */
     int32_t *d_out;
     int *d_ticket;                     /* row hand-out counter of the row-parallel lookahead kernel */
@@ -1032,7 +1033,7 @@ static int create_ctx(int device, int bit_depth, int high_priority, x265amd_ctx 
     if (hipGetDeviceCount(&n) != hipSuccess || device < 0 || device >= n) return X265AMD_EHIP;
     x265amd_ctx *c = new x265amd_ctx();
     c->device = device; c->depth = bit_depth;
-    c->d_jobs = c->d_results = c->d_stage = c->d_redo = 0; c->d_ticket = 0;
+    c->d_jobs = c->d_results = c->d_stage = c->d_redo = 0; c->d_ticket = 0; c->d_probe = 0;
     c->jobs_cap = c->results_cap = c->stage_cap = c->redo_cap = 0; c->d_out = 0;
     c->esa_window_bytes = 0;
     c->probe_khz = 0;
@@ -1077,6 +1078,7 @@ void x265amd_destroy(x265amd_ctx *c)
     if (c->d_results) (void)hipFree(c->d_results);
     if (c->d_stage) (void)hipFree(c->d_stage);
     if (c->d_redo) (void)hipFree(c->d_redo);
+    if (c->d_probe) (void)hipFree(c->d_probe);
     if (c->d_out) (void)hipFree(c->d_out);
     if (c->d_ticket) (void)hipFree(c->d_ticket);
     (void)hipStreamDestroy(c->stream);
@@ -1892,9 +1894,10 @@ int x265amd_clock_probe_start(x265amd_ctx *c, double ms)
     int khz = 0;
     HIPCHK(c, hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, c->device));
     if (khz <= 0) return fail(c, X265AMD_EHIP, "no constant-rate clock on this device");
-    if (ensure(c, &c->d_stage, &c->stage_cap, 16)) return X265AMD_EHIP;
+    if (!c->d_probe) HIPCHK(c, hipMalloc((void**)&c->d_probe, 16));
+    HIPCHK(c, hipMemsetAsync(c->d_probe, 0, 16, c->stream));
     c->probe_khz = khz;
-    hipLaunchKernelGGL(clock_probe_kernel, dim3(1), dim3(64), 0, c->stream, (long long*)c->d_stage, (long long)(ms * khz));
+    hipLaunchKernelGGL(clock_probe_kernel, dim3(1), dim3(64), 0, c->stream, c->d_probe, (long long)(ms * khz));
     HIPCHK(c, hipGetLastError());
     return X265AMD_OK;
 }
@@ -1904,7 +1907,7 @@ int x265amd_clock_probe_read(x265amd_ctx *c, double *shader_mhz)
     if (!c || !shader_mhz || !c->probe_khz) return fail(c, X265AMD_EINVAL, "no probe started");
     HIPCHK(c, hipSetDevice(c->device));
     long long out[2] = { 0, 0 };
-    HIPCHK(c, hipMemcpyAsync(out, c->d_stage, sizeof(out), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(out, c->d_probe, sizeof(out), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     if (out[1] <= 0) return fail(c, X265AMD_EHIP, "probe did not run");
     *shader_mhz = (double)out[0] / (double)out[1] * c->probe_khz / 1000.0;
