@@ -427,9 +427,14 @@ __device__ __forceinline__ void rk_fme_grid(int base, int region, int pitch, int
     const int shiftV = 6 + headRoom, offV = (1 << (shiftV - 1)) + (8192 << 6);
     if (lane < 49) lds_i(base, L_COSTS)[lane] = 0;
     wave_sync();
+    /* An 8x8 CU has 28 (x offset, tile) pairs. Both halves of the wave take them and share out the seven y offsets:
+     * lanes 0-31 take offsets 0 .. 3, lanes 32-63 offsets 4 .. 6 one region row lower, where they use the same rows
+     * of their registers and the same phases as offsets 0 .. 2 -- four vertical passes instead of seven. */
+    const bool split = T == 4;
+    const int hs = split && lane >= 32 ? 1 : 0;
     for (int task0 = 0; task0 < 7 * T; task0 += 64)
     {
-        const int task = task0 + lane;
+        const int task = split ? (lane & 31) : task0 + lane;
         const bool live = task < 7 * T;
         const int i = live ? task >> lT : 0, t = task & (T - 1);
         const int ty = t >> (lT >> 1), tx = t & (wt - 1);
@@ -458,7 +463,8 @@ __device__ __forceinline__ void rk_fme_grid(int base, int region, int pitch, int
 #pragma unroll
             for (int r = 0; r < 8; r++)
             {
-                const uint32_t *q = (const uint32_t*)(x265amd_smem + ((off0 + r * pitch) & ~3));
+                const int rr = r + hs < 8 ? r + hs : 7;   /* the shifted half never uses its last row */
+                const uint32_t *q = (const uint32_t*)(x265amd_smem + ((off0 + rr * pitch) & ~3));
                 const uint32_t q0 = q[0], q1 = q[1], q2 = q[2];
                 const uint32_t d0 = __builtin_amdgcn_alignbyte(q1, q0, sh) ^ 0x80808080u, d1 = __builtin_amdgcn_alignbyte(q2, q1, sh) ^ 0x80808080u;
                 D[r][0] = __builtin_amdgcn_sdot4(d0, tH, 0, false);
@@ -471,9 +477,14 @@ __device__ __forceinline__ void rk_fme_grid(int base, int region, int pitch, int
 #pragma unroll
                 for (int x = 0; x < 4; x++) pk[r][x] = __builtin_amdgcn_perm((uint32_t)D[r + 1][x], (uint32_t)D[r][x], 0x05040100u);
 #pragma unroll
-            for (int jj = 0; jj < 7; jj++)
+            for (int k = 0; k < 7; k++)
             {
-                const int yf = (jj + 1) & 3, o = jj < 3 ? 0 : 1;
+                if (split && k >= 4) break;
+                /* y offset of this pass: k, or with the wave split k for the first half and k + 4 for the second, whose
+                 * rows sit one lower in its registers: offsets 4 .. 6 then read like 0 .. 2 */
+                const int jj = k + 4 * hs;
+                const bool mine = live && jj < 7;
+                const int yf = (k + 1) & 3, o = k < 3 || split ? 0 : 1;
                 int pr[4][4];
 #pragma unroll
                 for (int y = 0; y < 4; y++)
@@ -484,11 +495,12 @@ __device__ __forceinline__ void rk_fme_grid(int base, int region, int pitch, int
                                            : (D[y + 2][x] + 8192 + 32) >> 6;
                         pr[y][x] = clip_pixel(sum, maxv);
                     }
-                int v = live ? tile_cost_px<P>(fq, pr, true) : 0;
+                int v = mine ? tile_cost_px<P>(fq, pr, true) : 0;
                 v = seg_sum(v, lG);
-                if (live && (lane & ((1 << lG) - 1)) == 0) lds_i(base, L_COSTS)[i * 7 + jj] += v;
+                if (mine && (lane & ((1 << lG) - 1)) == 0) lds_i(base, L_COSTS)[i * 7 + jj] += v;
                 if (T > 64) wave_sync();   /* several passes add to the same entry */
             }
+            if (split) break;
             continue;
         }
         int ch[4];
@@ -499,7 +511,8 @@ __device__ __forceinline__ void rk_fme_grid(int base, int region, int pitch, int
 #pragma unroll
         for (int r = 0; r < 8; r++)
         {
-            const int off = base + region + ((ty * 4 + r) * pitch + col0) * (int)sizeof(P);
+            const int rr = r + hs < 8 ? r + hs : 7;
+            const int off = base + region + ((ty * 4 + rr) * pitch + col0) * (int)sizeof(P);
             int px[8];
             Px<P>::unpack(Px<P>::load_lds(off), px);
             Px<P>::unpack(Px<P>::load_lds(off + 4 * (int)sizeof(P)), px + 4);
@@ -514,9 +527,11 @@ __device__ __forceinline__ void rk_fme_grid(int base, int region, int pitch, int
 #pragma unroll
             for (int x = 0; x < 4; x++) hv[r][x] = xf ? as_i16((hr[r][x] + offH) >> shiftH) : hr[r][x];
         const int sv = xf ? shiftV : 6, ov = xf ? offV : 32;
-        for (int jj = 0; jj < 7; jj++)
+        for (int k = 0; k < (split ? 4 : 7); k++)
         {
-            const int yf = (jj + 1) & 3;
+            const int jj = k + 4 * hs;
+            const bool mine = live && jj < 7;
+            const int yf = (k + 1) & 3;
             int pr[4][4];   /* the predicted tile */
             if (yf == 0)
             {
@@ -532,7 +547,7 @@ __device__ __forceinline__ void rk_fme_grid(int base, int region, int pitch, int
                 int cv[4];
 #pragma unroll
                 for (int k = 0; k < 4; k++) cv[k] = kRkTaps[yf][k];
-                if (jj < 3)
+                if (k < 3 || split)
                 {
 #pragma unroll
                     for (int y = 0; y < 4; y++)
@@ -555,11 +570,12 @@ __device__ __forceinline__ void rk_fme_grid(int base, int region, int pitch, int
                         }
                 }
             }
-            int v = live ? tile_cost_px<P>(fq, pr, true) : 0;
+            int v = mine ? tile_cost_px<P>(fq, pr, true) : 0;
             v = seg_sum(v, lG);
-            if (live && (lane & ((1 << lG) - 1)) == 0) lds_i(base, L_COSTS)[i * 7 + jj] += v;
+            if (mine && (lane & ((1 << lG) - 1)) == 0) lds_i(base, L_COSTS)[i * 7 + jj] += v;
             if (T > 64) wave_sync();   /* several passes add to the same entry */
         }
+        if (split) break;
     }
     wave_sync();
 }
