@@ -220,9 +220,9 @@ def main():
                          "the 64x64 and 32x32 PUs in one launch; the others launch per frame pair: split3 = the "
                          "same three classes, split = 16/8 and 64/32 on two streams (LDS per PU sized per class), single = one "
                          "launch, per-size = four launches on one stream")
-    ap.add_argument("--prio", choices=("small", "big", "flat"), default="small",
+    ap.add_argument("--prio", choices=("small", "big", "la", "flat"), default="small",
                     help="which search stream gets the device's highest priority: small = the 8x8 class, whose launch is a chain of "
-                         "three dependent kernels that should not end the step alone; big = the 64/32 class; flat = none")
+                         "dependent kernels (measured: 3 % over flat); big = the 64x64 class; la = the lookahead's stream; flat = none")
     ap.add_argument("--s32", choices=("big", "mid", "la", "own"), default="la",
                     help="pairs4: the stream of the 32x32 launch: behind the 64x64 launch, behind the 16x16 launch, behind the "
                          "lookahead field, or one of its own")
@@ -274,7 +274,7 @@ def main():
 
     # ---------------- setup (untimed): planes, lookahead fields, job lists, all on the device
     es = Engine(local_rank, 8, high_priority=args.prio == "small")      # search stream (all launches, or the 16/8 class)
-    el = Engine(local_rank, 8)      # lookahead stream
+    el = Engine(local_rank, 8, high_priority=args.prio == "la")      # lookahead stream
     multi = args.launch in ("pairs3", "pairs4")
     split = args.launch in ("split", "split3", "pairs3", "pairs4")
     eb = Engine(local_rank, 8, high_priority=args.prio == "big") if split else es   # stream of the 64/32 class
