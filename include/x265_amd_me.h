@@ -71,9 +71,9 @@ typedef struct
 /* Creates an engine bound to HIP device `device` for `bit_depth` 8, 10 or 12
  * (the reference fixes this at build time through HIGH_BIT_DEPTH / g_bitDepth). */
 int x265amd_create(int device, int bit_depth, x265amd_ctx **out);
-/* The same, with the engine's stream at the device's highest priority when high_priority != 0 (normal priority
- * otherwise, as x265amd_create): for the context that carries a step's longest waves (64x64 PUs), so that they are
- * dispatched ahead of the short ones launched next to them and the step does not end waiting for them. */
+/* The same, with the engine's stream at the device's highest priority when high_priority > 0, at its lowest when
+ * high_priority < 0 (normal priority otherwise, as x265amd_create): for a caller that runs several engines side by side
+ * and wants one launch chain dispatched ahead of the others (or behind them). */
 int x265amd_create_priority(int device, int bit_depth, int high_priority, x265amd_ctx **out);
 void x265amd_destroy(x265amd_ctx *ctx);
 const char *x265amd_last_error(const x265amd_ctx *ctx);

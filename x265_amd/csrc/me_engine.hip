@@ -1040,7 +1040,8 @@ static int create_ctx(int device, int bit_depth, int high_priority, x265amd_ctx 
     c->esa_lds_raised = c->rime_lds_raised = false;
     int prio_least = 0, prio_greatest = 0;
     if (hipSetDevice(device) != hipSuccess || hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest) != hipSuccess ||
-        hipStreamCreateWithPriority(&c->stream, hipStreamDefault, high_priority ? prio_greatest : prio_least + (prio_greatest - prio_least) / 2) != hipSuccess ||
+        hipStreamCreateWithPriority(&c->stream, hipStreamDefault, high_priority > 0 ? prio_greatest : high_priority < 0 ? prio_least
+                                    : prio_least + (prio_greatest - prio_least) / 2) != hipSuccess ||
         hipMalloc((void**)&c->d_out, 64) != hipSuccess || hipMalloc((void**)&c->d_ticket, 256) != hipSuccess)
     {
         delete c;
