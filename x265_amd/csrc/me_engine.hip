@@ -990,11 +990,10 @@ static int launch_lookahead(x265amd_ctx *c, LookaheadArgs &a, int nfields, int *
         {
             long nb = (long)nfields * ((a.hcu + LB_ROWS - 1) / LB_ROWS);
             if (nb > 8192) nb = 8192;
-            const size_t lds = (size_t)LB_ROWS * a.wcu * sizeof(int) + 64;
             if (c->depth <= 8)
-                hipLaunchKernelGGL(lookahead_band_kernel<uint8_t>, dim3((unsigned)nb), dim3(64), lds, c->stream, a);
+                hipLaunchKernelGGL(lookahead_band_kernel<uint8_t>, dim3((unsigned)nb), dim3(64), band_lds_bytes<uint8_t>(), c->stream, a);
             else
-                hipLaunchKernelGGL(lookahead_band_kernel<uint16_t>, dim3((unsigned)nb), dim3(64), lds, c->stream, a);
+                hipLaunchKernelGGL(lookahead_band_kernel<uint16_t>, dim3((unsigned)nb), dim3(64), band_lds_bytes<uint16_t>(), c->stream, a);
             HIPCHK(c, hipGetLastError());
             return X265AMD_OK;
         }

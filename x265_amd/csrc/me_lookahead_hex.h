@@ -23,6 +23,13 @@
 namespace x265amd {
 
 #define LB_ROWS 4                       /* CU rows of a band = groups of a wave */
+#define LB_WIN_W 12                     /* the sub-pel window of a CU: samples per row, rows */
+#define LB_WIN_H 11
+/* LDS of a wave: per CU row a ring of four MV words (a row reads the row below at its own column +-1 while that row
+ * is two columns further on), then the four groups' sub-pel windows of four planes each */
+#define LB_RING_BYTES (LB_ROWS * 4 * 4)
+template<typename P> constexpr int band_window_bytes() { return 4 * LB_WIN_H * LB_WIN_W * (int)sizeof(P) + 16; }
+template<typename P> constexpr int band_lds_bytes() { return LB_RING_BYTES + LB_ROWS * band_window_bytes<P>(); }
 
 template<typename P> struct BandCu
 {
@@ -31,6 +38,7 @@ template<typename P> struct BandCu
     const uint16_t AS1 *ctab;
     int rstride, mvpx, mvpy, depth;
     unsigned nsad, nsub;
+    int wbase, wx0, wy0;                /* the staged sub-pel window: LDS byte offset, origin relative to the CU */
     /* per lane */
     int l, tile;
     typename Px<P>::quad f[4];          /* the lane's tile of the source CU */
@@ -39,6 +47,72 @@ template<typename P> struct BandCu
     {
         const P AS1 *lo = (i & 1) ? ref[1] : ref[0], *hi = (i & 1) ? ref[3] : ref[2];
         return (i & 2) ? hi : lo;
+    }
+    /* The sub-pel rounds stay within 3 quarter-pels of where the integer search ended, so all they read lies in a
+     * window of LB_WIN_W x LB_WIN_H samples of each half-pel plane; the group stages it in LDS once (one row segment
+     * per lane and pass) instead of fetching every candidate's tile from memory. The origin is pulled back where the
+     * window would leave the 12 margin samples the planes are sure to have: what is cut off no candidate reads. */
+    __device__ __forceinline__ void stage_window(int qx, int qy, int xlim, int ylim)
+    {
+        wx0 = min((qx >> 2) - 1, xlim); wy0 = min((qy >> 2) - 1, ylim);
+        constexpr int NSEG = 4 * LB_WIN_H, NW = LB_WIN_W * (int)sizeof(P) / 4;
+        uint32_t v[(NSEG + 15) / 16][NW];
+        /* every load of the lane before the first store, so that they are in flight together */
+#pragma unroll
+        for (int i = 0; i < (NSEG + 15) / 16; i++)
+        {
+            const int sg = l + 16 * i;
+            const int p = (sg >= LB_WIN_H) + (sg >= 2 * LB_WIN_H) + (sg >= 3 * LB_WIN_H), r = sg - p * LB_WIN_H;
+            const P AS1 *src = pick(p & 3) + __mul24(wy0 + r, rstride) + wx0;
+            if (sg < NSEG)
+            {
+                if constexpr (sizeof(P) == 1)
+                {
+                    typedef uint32_t __attribute__((ext_vector_type(2), aligned(1))) u32x2u;
+                    typedef uint32_t __attribute__((aligned(1))) u32u;
+                    const u32x2u a = *(const u32x2u AS1*)src;
+                    v[i][0] = a.x; v[i][1] = a.y; v[i][2] = *(const u32u AS1*)(src + 8);
+                }
+                else
+                {
+                    typedef uint32_t __attribute__((ext_vector_type(4), aligned(2))) u32x4u;
+                    typedef uint32_t __attribute__((ext_vector_type(2), aligned(2))) u32x2u;
+                    const u32x4u a = *(const u32x4u AS1*)src;
+                    const u32x2u b = *(const u32x2u AS1*)(src + 8);
+                    v[i][0] = a.x; v[i][1] = a.y; v[i][2] = a.z; v[i][3] = a.w; v[i][4] = b.x; v[i][5] = b.y;
+                }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < (NSEG + 15) / 16; i++)
+        {
+            const int sg = l + 16 * i;
+            uint32_t *dst = (uint32_t*)(x265amd_smem + wbase + sg * LB_WIN_W * (int)sizeof(P));
+            if (sg < NSEG)
+            {
+#pragma unroll
+                for (int k = 0; k < NW; k++) dst[k] = v[i][k];
+            }
+        }
+    }
+    /* lowresQPelCost of the lane's tile at quarter-pel (cx, cy), from the staged window */
+    __device__ __forceinline__ int tile_cost_window(int cx, int cy, bool satd) const
+    {
+        const int toff = ((tile >> 1) * 4 - wy0) * LB_WIN_W + (tile & 1) * 4 - wx0;
+        typename Px<P>::quad q[4];
+        const int pa = (cy & 2) | ((cx & 2) >> 1);
+        const int oa = wbase + ((pa * LB_WIN_H + (cy >> 2)) * LB_WIN_W + (cx >> 2) + toff) * (int)sizeof(P);
+#pragma unroll
+        for (int y = 0; y < 4; y++) q[y] = Px<P>::load_lds(oa + y * LB_WIN_W * (int)sizeof(P));
+        if ((cx | cy) & 1)
+        {
+            const int bx = as_i16(cx + (cx & 1) * 2), by = as_i16(cy + (cy & 1) * 2);
+            const int pb = (by & 2) | ((bx & 2) >> 1);
+            const int ob = wbase + ((pb * LB_WIN_H + (by >> 2)) * LB_WIN_W + (bx >> 2) + toff) * (int)sizeof(P);
+#pragma unroll
+            for (int y = 0; y < 4; y++) q[y] = Px<P>::avg(q[y], Px<P>::load_lds(ob + y * LB_WIN_W * (int)sizeof(P)));
+        }
+        return tile_cost_quads<P>(f, q, satd);
     }
     /* lowresQPelCost of the lane's tile at quarter-pel (cx, cy); lowres.h:78-97 */
     __device__ __forceinline__ int tile_cost(int cx, int cy, bool satd) const
@@ -64,7 +138,7 @@ template<typename P> struct BandCu
     }
     /* Costs of K candidates, four per pass: pos(k, x, y) names candidate k's quarter-pel position. Lane k < K of the
      * group gets candidate k's distortion (+ lambda * bits when addmv(k)); the other lanes INT_MAX. */
-    template<class POS, class ADD>
+    template<bool WINDOW = false, class POS, class ADD>
     __device__ __forceinline__ int eval(int K, bool satd, POS pos, ADD addmv) const
     {
         int mine = 0x7fffffff;
@@ -76,13 +150,68 @@ template<typename P> struct BandCu
             const int k = k0 + (l >> 2);
             int cx = 0, cy = 0;
             pos(k < K ? k : K - 1, cx, cy);
-            int v = tile_cost(cx, cy, satd);
+            int v = WINDOW ? tile_cost_window(cx, cy, satd) : tile_cost(cx, cy, satd);
             v += dpp_all<0xB1>(v);
             v += dpp_all<0x4E>(v);
             /* candidate k0 + i sits in quad i; lane k0 + i of the group takes it */
             const int c = grp_lane<4>(v, ((l - k0) & 3) * 4);
             if (l >= k0 && l < k0 + 4 && l < K) mine = c + mvc;
         }
+        return mine;
+    }
+    /* eval for the integer stage (SAD, at most 4 * NP candidates, FULLPEL: all of them full-pel positions): the loads
+     * of every pass are issued before the first cost is formed, so the passes cost one trip to memory, not NP */
+    template<int NP, bool FULLPEL, class POS, class ADD>
+    __device__ __forceinline__ int eval_sad(int K, POS pos, ADD addmv) const
+    {
+        int mine = 0x7fffffff;
+        int mx = 0, my = 0;
+        if (l < K) pos(l, mx, my);
+        const int mvc = l < K && addmv(l) ? mvcost(mx, my) : 0;
+        const int toff = __mul24((tile >> 1) * 4, rstride) + (tile & 1) * 4;
+        typename Px<P>::quad qa[NP][4], qb[NP][4];
+        bool odd[NP];
+#pragma unroll
+        for (int p = 0; p < NP; p++)
+        {
+            odd[p] = false;
+            if (p == 0 || p * 4 < K)
+            {
+                const int k = p * 4 + (l >> 2);
+                int cx = 0, cy = 0;
+                pos(k < K ? k : K - 1, cx, cy);
+                const P AS1 *ra = pick((cy & 2) | ((cx & 2) >> 1)) + __mul24(cy >> 2, rstride) + (cx >> 2) + toff;
+#pragma unroll
+                for (int y = 0; y < 4; y++) qa[p][y] = Px<P>::load_g(ra + y * rstride);
+                if constexpr (!FULLPEL)
+                {
+                    odd[p] = ((cx | cy) & 1) != 0;
+                    if (odd[p])
+                    {
+                        const int bx = as_i16(cx + (cx & 1) * 2), by = as_i16(cy + (cy & 1) * 2);
+                        const P AS1 *rb = pick((by & 2) | ((bx & 2) >> 1)) + __mul24(by >> 2, rstride) + (bx >> 2) + toff;
+#pragma unroll
+                        for (int y = 0; y < 4; y++) qb[p][y] = Px<P>::load_g(rb + y * rstride);
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int p = 0; p < NP; p++)
+            if (p == 0 || p * 4 < K)
+            {
+                if constexpr (!FULLPEL)
+                    if (odd[p])
+                    {
+#pragma unroll
+                        for (int y = 0; y < 4; y++) qa[p][y] = Px<P>::avg(qa[p][y], qb[p][y]);
+                    }
+                int v = tile_cost_quads<P>(f, qa[p], false);
+                v += dpp_all<0xB1>(v);
+                v += dpp_all<0x4E>(v);
+                const int c = grp_lane<4>(v, ((l - p * 4) & 3) * 4);
+                if (l >= p * 4 && l < p * 4 + 4 && l < K) mine = c + mvc;
+            }
         return mine;
     }
     /* first minimum of the lanes [k0, k1) in lane order if it beats bcost: its lane, or -1 */
@@ -101,7 +230,7 @@ __device__ __forceinline__ int mv_word(int x, int y) { return (x & 0xffff) | (y 
 template<typename P>
 __global__ __launch_bounds__(64) void lookahead_band_kernel(LookaheadArgs a)
 {
-    int *rowmv = (int*)x265amd_smem;                /* LB_ROWS rows of W MV words: the rows of this band */
+    int *rowmv = (int*)x265amd_smem;                /* per CU row of this band the MV words of its last four CUs */
     const int lane = (int)threadIdx.x, g = lane >> 4, l = lane & 15;
     const int W = a.wcu, H = a.hcu, ncu = W * H;
     const int bands = (H + LB_ROWS - 1) / LB_ROWS, nbands = a.nfields * bands;
@@ -123,6 +252,7 @@ __global__ __launch_bounds__(64) void lookahead_band_kernel(LookaheadArgs a)
         int32_t *costs = a.costs + (size_t)fi * ncu;
         BandCu<P> C;
         C.l = l; C.tile = l & 3;
+        C.wbase = LB_RING_BYTES + g * band_window_bytes<P>();
         C.ctab = (const uint16_t AS1*)a.ctab;
         C.rstride = fd.ref[0].stride;
         C.depth = a.depth;
@@ -156,10 +286,10 @@ __global__ __launch_bounds__(64) void lookahead_band_kernel(LookaheadArgs a)
                     }
                     else
                     {
-                        const int *rb = rowmv + (g - 1) * W + cux;
-                        below = rb[0];
-                        if (cux > 0) bleft = rb[-1];
-                        if (cux < W - 1) bright = rb[1];
+                        const int *rb = rowmv + (g - 1) * 4;
+                        below = rb[cux & 3];
+                        if (cux > 0) bleft = rb[(cux - 1) & 3];
+                        if (cux < W - 1) bright = rb[(cux + 1) & 3];
                     }
                 }
                 int cx[4] = { 0, 0, 0, 0 }, cy[4] = { 0, 0, 0, 0 }, numc = 0;
@@ -219,7 +349,10 @@ __global__ __launch_bounds__(64) void lookahead_band_kernel(LookaheadArgs a)
                         if (k == 5) { x = cx[2]; y = cy[2]; }
                         if (k == 6) { x = cx[3]; y = cy[3]; }
                     };
-                    const int mine = C.eval(3 + numc, false, pos, [](int k) { return k != 0; });
+                    /* (16-bit samples: both passes' tiles and their averaging partners at once cost a wave of occupancy) */
+                    int mine;
+                    if constexpr (sizeof(P) == 1) mine = C.template eval_sad<2, false>(3 + numc, pos, [](int k) { return k != 0; });
+                    else mine = C.eval(3 + numc, false, pos, [](int k) { return k != 0; });
                     bprecost = grp_lane<4>(mine, 0);
                     C.nsub++;
                     bcost = bprecost;
@@ -245,7 +378,7 @@ __global__ __launch_bounds__(64) void lookahead_band_kernel(LookaheadArgs a)
                 /* ---- hexagon search, motion.cpp:651-723 ---- */
                 {
                     const int ox = bmx, oy = bmy;
-                    const int mine = C.eval(6, false, [&](int k, int &x, int &y) { x = as_i16(as_i16(ox + nib(HRX, k)) << 2); y = as_i16(as_i16(oy + nib(HRY, k)) << 2); },
+                    const int mine = C.template eval_sad<2, true>(6, [&](int k, int &x, int &y) { x = as_i16(as_i16(ox + nib(HRX, k)) << 2); y = as_i16(as_i16(oy + nib(HRY, k)) << 2); },
                                             [](int) { return true; });
                     C.nsad += 6;
                     int dir = C.fold(mine, 0, 6, bcost);
@@ -255,7 +388,7 @@ __global__ __launch_bounds__(64) void lookahead_band_kernel(LookaheadArgs a)
                         for (int i = (a.merange >> 1) - 1; i > 0 && bmx >= mnx && bmx <= mxx && bmy >= mny && bmy <= mxy; i--)
                         {
                             const int hx = bmx, hy = bmy, hd = dir;
-                            const int m3 = C.eval(3, false, [&](int k, int &x, int &y) { x = as_i16(as_i16(hx + nib(H2X, hd + k)) << 2); y = as_i16(as_i16(hy + nib(H2Y, hd + k)) << 2); },
+                            const int m3 = C.template eval_sad<1, true>(3, [&](int k, int &x, int &y) { x = as_i16(as_i16(hx + nib(H2X, hd + k)) << 2); y = as_i16(as_i16(hy + nib(H2Y, hd + k)) << 2); },
                                                   [](int) { return true; });
                             C.nsad += 3;
                             const int step = C.fold(m3, 0, 3, bcost) + 1;
@@ -266,7 +399,7 @@ __global__ __launch_bounds__(64) void lookahead_band_kernel(LookaheadArgs a)
                         }
                     }
                     const int sx = bmx, sy = bmy;
-                    const int m8 = C.eval(8, false, [&](int k, int &x, int &y) { x = as_i16(as_i16(sx + nib(SQX, k + 1)) << 2); y = as_i16(as_i16(sy + nib(SQY, k + 1)) << 2); },
+                    const int m8 = C.template eval_sad<2, true>(8, [&](int k, int &x, int &y) { x = as_i16(as_i16(sx + nib(SQX, k + 1)) << 2); y = as_i16(as_i16(sy + nib(SQY, k + 1)) << 2); },
                                           [](int) { return true; });
                     C.nsad += 8;
                     const int sq = C.fold(m8, 0, 8, bcost) + 1;
@@ -279,9 +412,11 @@ __global__ __launch_bounds__(64) void lookahead_band_kernel(LookaheadArgs a)
                 else { qx = as_i16(bmx << 2); qy = as_i16(bmy << 2); }
                 if (bcost)
                 {
+                    C.stage_window(qx, qy, (W - cux) * 8, (H - cuy) * 8 + 12 - LB_WIN_H);
+                    wave_sync();
                     {
                         const int ox = qx, oy = qy;
-                        const int mine = C.eval(hpel_dirs, false, [&](int k, int &x, int &y) { x = as_i16(ox + nib(SQX, k + 1) * 2); y = as_i16(oy + nib(SQY, k + 1) * 2); },
+                        const int mine = C.template eval<true>(hpel_dirs, false, [&](int k, int &x, int &y) { x = as_i16(ox + nib(SQX, k + 1) * 2); y = as_i16(oy + nib(SQY, k + 1) * 2); },
                                                 [](int) { return true; });
                         C.nsub += (unsigned)hpel_dirs;
                         const int k = C.fold(mine, 0, hpel_dirs, bcost);
@@ -290,7 +425,7 @@ __global__ __launch_bounds__(64) void lookahead_band_kernel(LookaheadArgs a)
                     }
                     {
                         const int ox = qx, oy = qy;
-                        const int mine = C.eval(1 + qpel_dirs, true, [&](int k, int &x, int &y) { x = as_i16(ox + nib(SQX, k)); y = as_i16(oy + nib(SQY, k)); },
+                        const int mine = C.template eval<true>(1 + qpel_dirs, true, [&](int k, int &x, int &y) { x = as_i16(ox + nib(SQX, k)); y = as_i16(oy + nib(SQY, k)); },
                                                 [](int) { return true; });
                         C.nsub += (unsigned)(1 + qpel_dirs);
                         bcost = grp_lane<4>(mine, 0);
@@ -301,7 +436,7 @@ __global__ __launch_bounds__(64) void lookahead_band_kernel(LookaheadArgs a)
                 }
 
                 right = mv_word(qx, qy);
-                rowmv[g * W + cux] = right;
+                rowmv[g * 4 + (cux & 3)] = right;
                 if (l == 0)
                 {
                     costs[cuXY] = bcost;
