@@ -34,6 +34,15 @@ LA_QP, LA_MERANGE = 12, 16
 HBM_PEAK_GBS = 8000.0
 
 
+_T0 = time.perf_counter()
+
+
+def progress(msg, rank=0):
+    """One line on stderr per phase (stdout carries the JSON line only): a long run stays visibly alive."""
+    if rank == 0:
+        print("[bench %6.1f s] %s" % (time.perf_counter() - _T0, msg), file=sys.stderr, flush=True)
+
+
 def host_threads(args):
     """Threads of the many-core CPU leg: the box's CPU share, not the machine's core count."""
     if args.cpu_threads > 0:
@@ -99,12 +108,14 @@ def run_split_workload(args, torch, dist, dev, cdev, rank, local_rank, world):
         if world > 1:
             sharding.gather_records(rec.to(cdev), dist, dst=0)
 
+    progress("set-up done: %s; warm-up" % args.workload, rank)
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
+    progress("timed steps", rank)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
@@ -122,6 +133,7 @@ def run_split_workload(args, torch, dist, dev, cdev, rank, local_rank, world):
     px, alg = float(tot[0].item()), float(tot[1].item())
     # parity: the gathered records against the unsharded run of the same units on rank 0's GPU (N > 1), and a sample
     # against the CPU oracle (rank 0)
+    progress("%d timed steps: %.3f ms per step; parity against the oracle" % (args.steps, elapsed / args.steps * 1e3), rank)
     gathered = sharding.gather_records(rec.to(cdev), dist, dst=0) if world > 1 else [rec]
     if rank == 0:
         from oracle.bindings import Oracle   # checker / baseline only
@@ -355,7 +367,7 @@ def main():
     ev0 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
     ev1 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
 
-    def step_multi(k=None):
+    def step_multi(k=None, gather=True):
         el.lookahead_fields_dev(d_fields, B, wcu, hcu, LA_QP, HEX, 1, LA_MERANGE,
                                 d_la_mvs.data_ptr(), d_la_costs.data_ptr())
         for c in reversed(range(len(segs))):       # the class with the longest waves first; the timed 8x8 class last
@@ -373,13 +385,13 @@ def main():
         em.sync()
         el.sync()
         e32.sync()
-        if world > 1:
+        if world > 1 and gather:
             # hand the MV / cost records to the rank that feeds the host encoder
             d_mvcost.copy_(all_res[:, :8])
             sharding.gather_records(d_mvcost.view(-1).to(cdev), dist, dst=0)
             sharding.gather_records(d_la_mvs.view(torch.uint8).view(-1).to(cdev), dist, dst=0)
 
-    def step_pairwise(k=None):
+    def step_pairwise(k=None, gather=True):
         el.lookahead_fields_dev(d_fields, B, wcu, hcu, LA_QP, HEX, 1, LA_MERANGE,
                                 d_la_mvs.data_ptr(), d_la_costs.data_ptr())
         for (first, cnt, dim, eng) in segs[1:] if split else ():
@@ -400,13 +412,14 @@ def main():
             e_.sync()
         em.sync()
         el.sync()
-        if world > 1:
+        if world > 1 and gather:
             d_mvcost.copy_(all_res[:, :8])
             sharding.gather_records(d_mvcost.view(-1).to(cdev), dist, dst=0)
             sharding.gather_records(d_la_mvs.view(torch.uint8).view(-1).to(cdev), dist, dst=0)
 
     sync_steps = args.sync_steps == "yes" or world > 1 or not multi
     step = step_multi if multi else step_pairwise
+    progress("set-up done (%d frame pairs, %d PU searches each); warm-up" % (B, njobs), rank)
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
@@ -425,16 +438,18 @@ def main():
         t = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+    progress("%d timed steps: %.3f ms per step" % (args.steps, elapsed / args.steps * 1e3), rank)
 
     # the shader clock under this load: three more steps (untimed) with the probe wave beside them on a stream of its own
     clock_mhz = None
     if rank == 0 and multi and not args.no_clock_probe:
         try:
+            # (rank 0 alone runs these steps: without the gather, which every rank would have to join)
             ep = Engine(local_rank, 8)
-            step()
+            step(gather=False)
             ep.clock_probe_start(2.5 * elapsed / args.steps * 1e3)
             for _ in range(3):
-                step()
+                step(gather=False)
             clock_mhz = ep.clock_probe_read()
             ep.close()
         except Exception as ex:     # the bench line must survive a failure here
@@ -492,6 +507,7 @@ def main():
         if ncpu > 0:
             cpu_s, cpu_px = 0.0, 0
             for i in range(ncpu):
+                progress("parity + CPU baseline: frame pair %d of %d through the oracle" % (i + 1, ncpu))
                 cur, org, stride = pad_plane(clip[i + 1], MARGIN)
                 ref, _, _ = pad_plane(clip[i], MARGIN)
                 ctx = orc.make_ctx(8, cur, org, stride, [ref], org, stride, False, QP, method, SUBME)
@@ -518,6 +534,7 @@ def main():
                 rf = Ref(8)
                 ref_s, ref_px = 0.0, 0
                 for i in range(nref):
+                    progress("parity + CPU baseline: frame pair %d of %d through the reference build" % (i + 1, nref))
                     cur, org, stride = pad_plane(clip[i + 1], MARGIN)
                     ref, _, _ = pad_plane(clip[i], MARGIN)
                     rf.me_config(cur, org, stride, QP, method, SUBME)
@@ -556,6 +573,7 @@ def main():
                     ok &= bool(np.array_equal(res[i]["mv"], exp["mv"]) and np.array_equal(res[i]["cost"], exp["cost"]))
                     px += workload.pixel_sads(host_jobs[i], res[i])
                 return px, ok
+            progress("CPU baseline on %d threads: all %d frame pairs" % (nthr, B))
             c0 = time.perf_counter()
             with ThreadPoolExecutor(nthr) as ex:
                 outs = list(ex.map(work, range(nthr)))
@@ -617,9 +635,11 @@ def main():
             # reported beside the headline, never part of `value`
             try:
                 from x265_amd import measure
+                progress("other paths: exhaustive search 4K")
                 rows, _ = measure.esa_per_size(es, dev)
                 ms = sum(r["ms"] for r in rows)
                 px = sum(r["pixel_sads"] for r in rows)
+                progress("other paths: Rockchip path, lookahead frame costs")
                 rk = measure.rk_picture(es, dev)
                 la = {}
                 for (lw_, lh_, n_) in ((1920, 1080, 16), (7680, 4320, 4)):
@@ -629,8 +649,10 @@ def main():
                         "ms_intra_bidir_choice": m["ms_costs"],
                         "frame_costs_per_s": m["frames"] / (m["ms_search"] + m["ms_costs"]) * 1e3,
                         "searched_cus_per_s": m["fields"] * m["cus"] / (m["ms_search"] * 1e-3)}
+                progress("other paths: motion compensation, bi-prediction")
                 mc = measure.mc_picture(es, dev)
                 bp = measure.bipred_picture(es, dev)
+                progress("other paths: Main10")
                 e10 = Engine(local_rank, 10)
                 m10 = measure.pattern_search_picture(e10, dev)
                 rows10, _ = measure.esa_per_size(e10, dev)
@@ -678,6 +700,7 @@ def main():
                                         "value": rk10["pixel_sads"] / rk10["ms"] / 1e6, "unit": "Gpixel-SAD/s"}}
             except Exception as ex:   # the headline line must survive a failure here
                 out["other_paths"] = {"error": repr(ex)}
+        progress("done")
         print(json.dumps(out))
     if world > 1:
         dist.barrier()
