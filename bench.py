@@ -367,6 +367,28 @@ def main():
     ev0 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
     ev1 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
 
+    # The MV / cost records go to the rank that feeds the host encoder: copied out of the kernels' result buffers into
+    # send buffers of their own, so the gather of step k runs while step k + 1 computes; the copies wait for the gather
+    # before (it still reads the send buffers) and every gather is over before the timed region ends.
+    d_la_out = torch.zeros_like(d_la_mvs)
+    pending, recv = [], {}
+
+    def gathers_wait():
+        for (work, _keep) in pending:
+            if work is not None:
+                work.wait()
+        pending.clear()
+
+    def hand_over():
+        gathers_wait()
+        d_mvcost.copy_(all_res[:, :8])
+        d_la_out.copy_(d_la_mvs)
+        for name, t in (("mv", d_mvcost.view(-1)), ("la", d_la_out.view(torch.uint8).view(-1))):
+            src = t.to(cdev)
+            bufs, work = sharding.gather_records(src, dist, dst=0, bufs=recv.get(name), async_op=True)
+            recv[name] = bufs
+            pending.append((work, src))
+
     def step_multi(k=None, gather=True):
         el.lookahead_fields_dev(d_fields, B, wcu, hcu, LA_QP, HEX, 1, LA_MERANGE,
                                 d_la_mvs.data_ptr(), d_la_costs.data_ptr())
@@ -386,10 +408,7 @@ def main():
         el.sync()
         e32.sync()
         if world > 1 and gather:
-            # hand the MV / cost records to the rank that feeds the host encoder
-            d_mvcost.copy_(all_res[:, :8])
-            sharding.gather_records(d_mvcost.view(-1).to(cdev), dist, dst=0)
-            sharding.gather_records(d_la_mvs.view(torch.uint8).view(-1).to(cdev), dist, dst=0)
+            hand_over()
 
     def step_pairwise(k=None, gather=True):
         el.lookahead_fields_dev(d_fields, B, wcu, hcu, LA_QP, HEX, 1, LA_MERANGE,
@@ -413,15 +432,14 @@ def main():
         em.sync()
         el.sync()
         if world > 1 and gather:
-            d_mvcost.copy_(all_res[:, :8])
-            sharding.gather_records(d_mvcost.view(-1).to(cdev), dist, dst=0)
-            sharding.gather_records(d_la_mvs.view(torch.uint8).view(-1).to(cdev), dist, dst=0)
+            hand_over()
 
     sync_steps = args.sync_steps == "yes" or world > 1 or not multi
     step = step_multi if multi else step_pairwise
     progress("set-up done (%d frame pairs, %d PU searches each); warm-up" % (B, njobs), rank)
     for _ in range(args.warmup):
         step()
+    gathers_wait()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -429,6 +447,7 @@ def main():
     t0 = time.perf_counter()
     for k in range(args.steps):
         step(k)
+    gathers_wait()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()

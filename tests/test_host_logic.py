@@ -144,6 +144,22 @@ if rank == 0:
     print("GATHER_OK")
 else:
     assert got is None
+# the overlapped form: two gathers in flight into receive buffers that are used again
+bufs = None
+for step in range(3):
+    a = t + step
+    b = t * 0 + rank + step
+    ga, wa = sharding.gather_records(a, dist, dst=0, bufs=bufs, async_op=True)
+    gb, wb = sharding.gather_records(b, dist, dst=0, async_op=True)
+    wa.wait(); wb.wait()
+    if rank == 0:
+        assert bufs is None or all(x is y for x, y in zip(ga, bufs))
+        bufs = ga
+        assert torch.equal(ga[0], a) and int(gb[1][0]) == 1 + step and int(gb[0][0]) == step
+    else:
+        assert ga is None and gb is None
+if rank == 0:
+    print("ASYNC_GATHER_OK")
 dist.barrier()
 dist.destroy_process_group()
 '''
@@ -161,7 +177,7 @@ def test_two_rank_gather_over_gloo(tmp_path):
                               stderr=subprocess.STDOUT, text=True) for r in range(2)]
     outs = [p.communicate(timeout=240)[0] for p in procs]
     assert all(p.returncode == 0 for p in procs), outs
-    assert "GATHER_OK" in outs[0]
+    assert "GATHER_OK" in outs[0] and "ASYNC_GATHER_OK" in outs[0]
 
 
 def test_tile_plan_properties():

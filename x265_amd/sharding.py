@@ -21,19 +21,22 @@ def shard_rows(n_ctu_rows, rank, world, merange, ctu=64, apron=8):
     return lo, hi, lo * ctu - merange - apron, hi * ctu + merange + apron
 
 
-def gather_records(local, dist=None, dst=0):
+def gather_records(local, dist=None, dst=0, bufs=None, async_op=False):
     """Gather equally-shaped record tensors to `dst`. `local` is a torch tensor (uint8 view of the
-    records); returns the list of per-rank tensors on dst, None elsewhere."""
+    records); returns the list of per-rank tensors on dst, None elsewhere. `bufs`: dst's receive tensors to use again
+    (a list of world tensors like `local`). With async_op the call returns (tensors or None, work or None) at once and
+    the caller waits on the work object before it reads the tensors or writes `local` again."""
     if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
-        return [local]
+        return ([local], None) if async_op else [local]
     import torch
     world = dist.get_world_size()
     if dist.get_rank() == dst:
-        bufs = [torch.empty_like(local) for _ in range(world)]
-        dist.gather(local, bufs, dst=dst)
-        return bufs
-    dist.gather(local, None, dst=dst)
-    return None
+        if bufs is None:
+            bufs = [torch.empty_like(local) for _ in range(world)]
+        work = dist.gather(local, bufs, dst=dst, async_op=async_op)
+        return (bufs, work) if async_op else bufs
+    work = dist.gather(local, None, dst=dst, async_op=async_op)
+    return (None, work) if async_op else None
 
 
 # ---------------------------------------------------------------- (reference, CTU-row band) units of one picture
