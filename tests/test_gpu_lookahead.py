@@ -198,3 +198,28 @@ def test_both_lookahead_kernels_agree(engine8, oracle, monkeypatch):
     ctx = oracle.make_ctx(8, pa[0][0], pa[1], pa[2], pb[0], pa[1], pa[2], True, 12, 1, 1)
     mv, cost = oracle.lookahead_field(ctx, 26, 15, 16)
     assert np.array_equal(out["rows"][0][0], mv) and np.array_equal(out["rows"][1][0], cost)
+
+
+@pytest.mark.parametrize("depth", [8, 10])
+def test_fields_at_the_margin_limit(request, oracle, depth):
+    """Reference planes with exactly the 12 margin samples the entry point asks for, and motion that drags the border
+    CUs' searches to the end of their range on every side: the fields equal the oracle's (which reads wide planes)."""
+    from util import lowres_dims
+    e = request.getfixturevalue("engine8" if depth == 8 else "engine10")
+    w, h = 224, 128
+    big = make_clip(w + 96, h + 96, 1, seed=31, depth=depth)[0]
+    ref = np.ascontiguousarray(big[48:48 + h, 48:48 + w])
+    for (dx, dy) in ((22, 18), (-22, -18), (20, -14), (-6, 24)):
+        cur = np.ascontiguousarray(big[48 + dy:48 + dy + h, 48 + dx:48 + dx + w])
+        pa = host_lowres_planes(oracle, depth, cur, 64)
+        pb = host_lowres_planes(oracle, depth, ref, 64)
+        wcu, hcu, lw, lh = pa[3], pa[4], pa[5], pa[6]
+        ctx = oracle.make_ctx(depth, pa[0][0], pa[1], pa[2], pb[0], pa[1], pa[2], True, 12, 1, 1)
+        mv, cost = oracle.lookahead_field(ctx, wcu, hcu, 16)
+        assert np.abs(mv.astype(np.int32)).max() >= 4 * 8        # some search did reach the end of its range
+        na = host_lowres_planes(oracle, depth, cur, 16)
+        nb = host_lowres_planes(oracle, depth, ref, 12)
+        fenc = e.upload_plane(na[0][0], lw, lh, 16, 16, na[2])
+        refs = [e.upload_plane(nb[0][k], lw, lh, 12, 12, nb[2]) for k in range(4)]
+        mvs, costs, _ = e.lookahead_fields([(fenc, refs)], wcu, hcu, 12, 1, 1, 16)
+        assert np.array_equal(mvs[0], mv) and np.array_equal(costs[0], cost), (dx, dy)
