@@ -121,19 +121,23 @@ __global__ __launch_bounds__(LA_INTRA_WAVES * 64) void la_intra_kernel(const Fra
     const int cuy = blockIdx.x;
     const long stride = f.fenc.stride;
     int sum_cost = 0, sum_scored = 0, sum_aq = 0;              /* lane 0 of each wave accumulates */
+    /* what a lane reads of a CU: a sample of the raw edges (lanes 0-16 above, 32-48 left) and one of the block. The
+     * next CU's are fetched while this one is worked on. */
+    const int ei = lane & 31, es = lane >> 5, ej = ei < 8 ? ei : 8;
+    const long eoff = -1 - stride + (es ? ej * stride : ej), poff = (lane >> 3) * stride + (lane & 7);
+    const uint8_t AS1 *row = (const uint8_t AS1*)f.fenc.origin + (long)(8 * cuy) * stride;
+    uint8_t nedge = 0, npx = 0;
+    if (wave < W) { nedge = row[8 * wave + eoff]; npx = row[8 * wave + poff]; }
     for (int cux = wave; cux < W; cux += LA_INTRA_WAVES)
     {
     const int cu = cuy * W + cux;
-    const uint8_t AS1 *cur = (const uint8_t AS1*)f.fenc.origin + (long)(8 * cuy) * stride + 8 * cux;
     uint8_t *e = lds[wave], *src = e + LA_OFF_SRC, *srct = e + LA_OFF_SRCT, *ext = e + LA_OFF_EXT;
-    /* raw edges: lanes 0-16 above, 32-48 left */
     {
-        const int i = lane & 31, s = lane >> 5, j = i < 8 ? i : 8;
-        if (i <= 16)
-            e[s * LA_EDGE_BYTES + i] = s ? cur[-1 - stride + j * stride] : cur[-1 - stride + j];
-        const uint8_t px = cur[(lane >> 3) * stride + (lane & 7)];
-        src[lane] = px;
-        srct[(lane & 7) * 8 + (lane >> 3)] = px;
+        if (ei <= 16) e[es * LA_EDGE_BYTES + ei] = nedge;
+        src[lane] = npx;
+        srct[(lane & 7) * 8 + (lane >> 3)] = npx;
+        const int nx = cux + LA_INTRA_WAVES;
+        if (nx < W) { nedge = row[8 * nx + eoff]; npx = row[8 * nx + poff]; }
     }
     wave_sync();
     {
@@ -145,28 +149,32 @@ __global__ __launch_bounds__(LA_INTRA_WAVES * 64) void la_intra_kernel(const Fra
         }
     }
     wave_sync();
-    /* extended main edges of modes 11..25: entry j < 8 is main index j - 8 = side[(128 + (8 - j) * invAngle) >> 8];
-     * entries the mode never reads may project past the side edge and are clamped */
-    for (int t = lane; t < 15 * 25; t += 64)
+    /* extended main edges of modes 11..25: entry j < 8 is main index j - 8 = side[(128 + (8 - j) * invAngle) >> 8]
+     * (entries the mode never reads may project past the side edge and are clamped), entries 8..24 the main edge
+     * itself, copied as five dwords (the edges and the extended edges start on dwords) */
+    for (int t = lane; t < 15 * 8; t += 64)
     {
-        const int m = t / 25, j = t - m * 25, mode = m + 11;
+        const int m = t >> 3, j = t & 7, mode = m + 11;
         const int fl = mode == 18, ver = mode >= 18;
         const uint8_t *main_ = e + (fl * 2 + (ver ? 0 : 1)) * LA_EDGE_BYTES, *side = e + (fl * 2 + (ver ? 1 : 0)) * LA_EDGE_BYTES;
         const int idx = ver ? 26 - mode : mode - 10;
-        int v;
-        if (j >= 8) v = main_[j - 8];
-        else
-        {
-            int si = (128 + (8 - j) * kInvAngle[idx]) >> 8;
-            v = side[si > 16 ? 16 : si];
-        }
-        ext[m * LA_EXT_BYTES + j] = (uint8_t)v;
+        const int si = (128 + (8 - j) * kInvAngle[idx]) >> 8;
+        ext[m * LA_EXT_BYTES + j] = side[si > 16 ? 16 : si];
+        if (j < 5) *(uint32_t*)(ext + m * LA_EXT_BYTES + 8 + 4 * j) = *(const uint32_t*)(main_ + 4 * j);
     }
     wave_sync();
-    int dc = 8;
-#pragma unroll
-    for (int i = 1; i <= 8; i++) dc += e[i] + e[LA_EDGE_BYTES + i];
-    dc >>= 4;
+    /* DC: the eight samples above and the eight to the left (indices 1..8 of the raw edges), summed as bytes of dwords */
+    int dc;
+    {
+        const uint32_t *ea = (const uint32_t*)e, *el = (const uint32_t*)(e + LA_EDGE_BYTES);
+        uint32_t t = __builtin_amdgcn_sad_u8(ea[0] & 0xffffff00u, 0u, 8u);
+        t = __builtin_amdgcn_sad_u8(ea[1], 0u, t);
+        t = __builtin_amdgcn_sad_u8(ea[2] & 0xffu, 0u, t);
+        t = __builtin_amdgcn_sad_u8(el[0] & 0xffffff00u, 0u, t);
+        t = __builtin_amdgcn_sad_u8(el[1], 0u, t);
+        t = __builtin_amdgcn_sad_u8(el[2] & 0xffu, 0u, t);
+        dc = (int)(t >> 4);
+    }
     int icost = LA_COST_MAX;
     for (int pass = 0; pass < 3; pass++)
     {
@@ -174,13 +182,21 @@ __global__ __launch_bounds__(LA_INTRA_WAVES * 64) void la_intra_kernel(const Fra
         int v = 0;
         if (mode < 35)
         {
-            int p[4][4];
+            /* the tile's prediction as packed pairs: columns (0, 2) and (1, 3) of every row, the layout the packed
+             * Hadamard takes */
+            typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+            pk16 P02[4], P13[4];
             if (mode < 2)
             {
 #pragma unroll
                 for (int k = 0; k < 4; k++)
+                {
+                    int p[4];
 #pragma unroll
-                    for (int l = 0; l < 4; l++) p[k][l] = la_pred_dc_planar(e, mode, 4 * ty + k, 4 * tx + l, dc);
+                    for (int l = 0; l < 4; l++) p[l] = la_pred_dc_planar(e, mode, 4 * ty + k, 4 * tx + l, dc);
+                    P02[k] = __builtin_bit_cast(pk16, (uint32_t)(p[0] | (p[2] << 16)));
+                    P13[k] = __builtin_bit_cast(pk16, (uint32_t)(p[1] | (p[3] << 16)));
+                }
             }
             else
             {
@@ -195,14 +211,21 @@ __global__ __launch_bounds__(LA_INTRA_WAVES * 64) void la_intra_kernel(const Fra
 #pragma unroll
                 for (int k = 0; k < 4; k++)
                 {
-                    const int dp = (4 * ty + k + 1) * ang, fr = dp & 31;
+                    const int dp = (4 * ty + k + 1) * ang;
+                    const unsigned short fr = (unsigned short)(dp & 31), fc = (unsigned short)(32 - (dp & 31));
+                    /* five edge samples r0..r4 from two aligned dwords (the wave's LDS block is dword aligned) */
                     const uint8_t *r = refMain + 4 * tx + (dp >> 5) + 1;
-                    const int r0 = r[0], r1 = r[1], r2 = r[2], r3 = r[3], r4 = r[4];
+                    const unsigned sh = (unsigned)(uintptr_t)r & 3u;
+                    const uint32_t *w = (const uint32_t*)(r - sh);
+                    const uint32_t q0 = w[0], q1 = w[1];
+                    const uint32_t lo = __builtin_amdgcn_alignbyte(q1, q0, sh), r4 = (q1 >> (8 * sh)) & 0xffu;
+                    const u16x2 A = __builtin_bit_cast(u16x2, __builtin_amdgcn_perm(lo, lo, 0x0c020c00u));   /* r0, r2 */
+                    const u16x2 B = __builtin_bit_cast(u16x2, __builtin_amdgcn_perm(lo, lo, 0x0c030c01u));   /* r1, r3 */
+                    const u16x2 C = __builtin_bit_cast(u16x2, __builtin_amdgcn_perm(r4, lo, 0x0c040c02u));   /* r2, r4 */
+                    const u16x2 wf = { fr, fr }, wc = { fc, fc }, rnd = { 16, 16 };
                     /* with fr = 0 this is the plain copy of :233-240 */
-                    p[k][0] = ((32 - fr) * r0 + fr * r1 + 16) >> 5;
-                    p[k][1] = ((32 - fr) * r1 + fr * r2 + 16) >> 5;
-                    p[k][2] = ((32 - fr) * r2 + fr * r3 + 16) >> 5;
-                    p[k][3] = ((32 - fr) * r3 + fr * r4 + 16) >> 5;
+                    P02[k] = __builtin_bit_cast(pk16, (u16x2)((A * wc + B * wf + rnd) >> 5));
+                    P13[k] = __builtin_bit_cast(pk16, (u16x2)((B * wc + C * wf + rnd) >> 5));
                 }
                 if (absAng == 0 && tx == 0)
                 {
@@ -211,16 +234,21 @@ __global__ __launch_bounds__(LA_INTRA_WAVES * 64) void la_intra_kernel(const Fra
 #pragma unroll
                     for (int k = 0; k < 4; k++)
                     {
-                        const int t = p[k][0] + (((int)refSide[4 * ty + k + 1] - (int)refSide[0]) >> 1);
-                        p[k][0] = t < 0 ? 0 : (t > 255 ? 255 : t);
+                        const int t = (int)(unsigned short)P02[k].x + (((int)refSide[4 * ty + k + 1] - (int)refSide[0]) >> 1);
+                        P02[k].x = (short)(t < 0 ? 0 : (t > 255 ? 255 : t));
                     }
                 }
             }
             const uint8_t *sp = ((mode >= 2 && mode < 18) ? srct : src) + (4 * ty) * 8 + 4 * tx;
-            uint32_t q[4];
+            pk16 E[4], O[4];
 #pragma unroll
-            for (int k = 0; k < 4; k++) q[k] = *(const uint32_t*)(sp + 8 * k);
-            v = tile_cost_px<uint8_t>(q, p, true);
+            for (int k = 0; k < 4; k++)
+            {
+                const uint32_t q = *(const uint32_t*)(sp + 8 * k);
+                E[k] = even_bytes(q) - P02[k];
+                O[k] = odd_bytes(q) - P13[k];
+            }
+            v = had4x4_half_pk(E, O);
         }
         v = seg_sum(v, 2);
         v = mode < 35 ? v : LA_COST_MAX;
