@@ -67,9 +67,12 @@ def test_field_geometry_is_checked(engine8):
         engine8.lookahead_fields([(Plane(), lb)], 26, 15, 12, 1, 1, 16)           # null source plane
 
 
-def test_field_shapes_vs_oracle(engine8, oracle):
-    """Ragged and tiny CU grids: 1xN, Nx1, 2x2, odd sizes."""
+@pytest.mark.parametrize("rows", [2, 4])
+def test_field_shapes_vs_oracle(engine8, oracle, monkeypatch, rows):
+    """Ragged and tiny CU grids: 1xN, Nx1, 2x2, odd sizes; through both forms of the band kernel (the library picks by
+    launch size; X265AMD_LOOKAHEAD_ROWS forces the CU rows per wave)."""
     from oracle.bindings import MEStats
+    monkeypatch.setenv("X265AMD_LOOKAHEAD_ROWS", str(rows))
     for (w, h) in ((16, 16), (16, 144), (144, 16), (32, 32), (88, 56), (300, 200)):
         clip = make_clip(w, h, 3, seed=w + h, depth=8)
         pa = host_lowres_planes(oracle, 8, clip[2], 64)

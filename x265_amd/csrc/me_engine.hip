@@ -962,6 +962,7 @@ static int launch_search(x265amd_ctx *c, const SearchArgs &a, int is_lowres)
  * kernel spreads a field over up to min(H, W / 2) waves and wins whenever the fields alone cannot
  * fill the chip. LA_ROWS_MAX_FIELDS is where a launch switches over. */
 #define LA_ROWS_MAX_FIELDS 512
+#define LB_LATENCY_WAVES 1024      /* band waves up to which a lookahead launch trades lane work for latency */
 static int launch_lookahead(x265amd_ctx *c, LookaheadArgs &a, int nfields, int *d_ticket)
 {
     const char *force = getenv("X265AMD_LOOKAHEAD_KERNEL");   /* "field", "rows" or "band": measurements only */
@@ -988,12 +989,27 @@ static int launch_lookahead(x265amd_ctx *c, LookaheadArgs &a, int nfields, int *
         HIPCHK(c, hipMemsetAsync(d_ticket, 0, sizeof(int), c->stream));
         if (band)
         {
-            long nb = (long)nfields * ((a.hcu + LB_ROWS - 1) / LB_ROWS);
+            /* CU rows per wave: a CU on 32 lanes measures eight candidates per pass instead of four and is through
+             * ~10 % sooner, for a third more lane work (on all 64 lanes it is no faster still). A field's latency is its
+             * dependency chain of W + 2 (H - 1) CU searches whatever the rows per wave, so a launch that leaves most of the
+             * chip idle takes the wide form and one that can fill it the narrow one. */
+            const char *fr = getenv("X265AMD_LOOKAHEAD_ROWS");                     /* "2" or "4": tests and measurements */
+            const int force_rows = fr ? atoi(fr) : 0;
+            int rows = (long)nfields * ((a.hcu + 1) / 2) <= LB_LATENCY_WAVES ? 2 : LB_ROWS;
+            if (force_rows == 2 || force_rows == 4) rows = force_rows;
+            long nb = (long)nfields * ((a.hcu + rows - 1) / rows);
             if (nb > 8192) nb = 8192;
-            if (c->depth <= 8)
-                hipLaunchKernelGGL(lookahead_band_kernel<uint8_t>, dim3((unsigned)nb), dim3(64), band_lds_bytes<uint8_t>(), c->stream, a);
+            const bool p8 = c->depth <= 8;
+            if (rows == 4)
+            {
+                if (p8) hipLaunchKernelGGL((lookahead_band_kernel<uint8_t, 4>), dim3((unsigned)nb), dim3(64), (band_lds_bytes<uint8_t, 4>()), c->stream, a);
+                else hipLaunchKernelGGL((lookahead_band_kernel<uint16_t, 4>), dim3((unsigned)nb), dim3(64), (band_lds_bytes<uint16_t, 4>()), c->stream, a);
+            }
             else
-                hipLaunchKernelGGL(lookahead_band_kernel<uint16_t>, dim3((unsigned)nb), dim3(64), band_lds_bytes<uint16_t>(), c->stream, a);
+            {
+                if (p8) hipLaunchKernelGGL((lookahead_band_kernel<uint8_t, 5>), dim3((unsigned)nb), dim3(64), (band_lds_bytes<uint8_t, 5>()), c->stream, a);
+                else hipLaunchKernelGGL((lookahead_band_kernel<uint16_t, 5>), dim3((unsigned)nb), dim3(64), (band_lds_bytes<uint16_t, 5>()), c->stream, a);
+            }
             HIPCHK(c, hipGetLastError());
             return X265AMD_OK;
         }

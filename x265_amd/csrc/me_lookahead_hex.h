@@ -1,10 +1,11 @@
-/* Lookahead MV fields, hexagon search, four CU rows per wave.
+/* Lookahead MV fields, hexagon search, four (or two) CU rows per wave.
  *
  * The lookahead's search (EstimateRow::estimateCUCost, slicetype.cpp:1401-1470) is always X265_HEX_SEARCH on 8x8
  * CUs of the half-resolution planes (slicetype.h:65-72), a CU taking its predictors from its right neighbour and the
  * three CUs below (:1442-1466). The general one-wave search spends ~2000 instructions on such a CU, nearly all of it
  * bookkeeping: a CU has four 4x4 tiles and a hexagon step three to eight candidates. Here a wave owns a band of four
- * CU rows of one field, a row per group of 16 lanes = 4 candidates x 4 tiles per pass. The rows run right to left in
+ * CU rows of one field, a row per group of 16 lanes = 4 candidates x 4 tiles per pass (launches too small to fill
+ * the chip: two rows, 32 lanes and 8 candidates per pass -- shorter steps for more lane work). The rows run right to left in
  * lockstep, each two CUs behind the row below it (the lag of the reference's own wavefront, :1362-1379), so inside a
  * band the three CUs below are always done -- their MVs wait in LDS -- and only the bottom row of a band polls the
  * top row of the band below (device-scope loads of the MV array, preset to x = 0x7FFF, the reference's "not searched"
@@ -22,17 +23,19 @@
 
 namespace x265amd {
 
-#define LB_ROWS 4                       /* CU rows of a band = groups of a wave */
+#define LB_ROWS 4                       /* most CU rows of a band = groups of a wave */
 #define LB_WIN_W 12                     /* the sub-pel window of a CU: samples per row, rows */
 #define LB_WIN_H 11
 /* LDS of a wave: per CU row a ring of four MV words (a row reads the row below at its own column +-1 while that row
  * is two columns further on), then the four groups' sub-pel windows of four planes each */
 #define LB_RING_BYTES (LB_ROWS * 4 * 4)
 template<typename P> constexpr int band_window_bytes() { return 4 * LB_WIN_H * LB_WIN_W * (int)sizeof(P) + 16; }
-template<typename P> constexpr int band_lds_bytes() { return LB_RING_BYTES + LB_ROWS * band_window_bytes<P>(); }
+/* LG: log2 of the lanes of a group (4 or 5: four or two CU rows per wave) */
+template<typename P, int LG> constexpr int band_lds_bytes() { return LB_RING_BYTES + (64 >> LG) * band_window_bytes<P>(); }
 
-template<typename P> struct BandCu
+template<typename P, int LG> struct BandCu
 {
+    static constexpr int LPP = 1 << LG, CPP = LPP / 4;      /* lanes of the group; candidates per pass (a lane per 4x4 tile) */
     /* group-uniform */
     const P AS1 *ref[4];                /* the four half-pel planes, at this CU's position */
     const uint16_t AS1 *ctab;
@@ -56,12 +59,12 @@ template<typename P> struct BandCu
     {
         wx0 = min((qx >> 2) - 1, xlim); wy0 = min((qy >> 2) - 1, ylim);
         constexpr int NSEG = 4 * LB_WIN_H, NW = LB_WIN_W * (int)sizeof(P) / 4;
-        uint32_t v[(NSEG + 15) / 16][NW];
+        uint32_t v[(NSEG + LPP - 1) / LPP][NW];
         /* every load of the lane before the first store, so that they are in flight together */
 #pragma unroll
-        for (int i = 0; i < (NSEG + 15) / 16; i++)
+        for (int i = 0; i < (NSEG + LPP - 1) / LPP; i++)
         {
-            const int sg = l + 16 * i;
+            const int sg = l + LPP * i;
             const int p = (sg >= LB_WIN_H) + (sg >= 2 * LB_WIN_H) + (sg >= 3 * LB_WIN_H), r = sg - p * LB_WIN_H;
             const P AS1 *src = pick(p & 3) + __mul24(wy0 + r, rstride) + wx0;
             if (sg < NSEG)
@@ -84,9 +87,9 @@ template<typename P> struct BandCu
             }
         }
 #pragma unroll
-        for (int i = 0; i < (NSEG + 15) / 16; i++)
+        for (int i = 0; i < (NSEG + LPP - 1) / LPP; i++)
         {
-            const int sg = l + 16 * i;
+            const int sg = l + LPP * i;
             uint32_t *dst = (uint32_t*)(x265amd_smem + wbase + sg * LB_WIN_W * (int)sizeof(P));
             if (sg < NSEG)
             {
@@ -136,7 +139,7 @@ template<typename P> struct BandCu
     {
         return ((int)ctab[qx - mvpx] + (int)ctab[qy - mvpy]) & 0xffff;
     }
-    /* Costs of K candidates, four per pass: pos(k, x, y) names candidate k's quarter-pel position. Lane k < K of the
+    /* Costs of K candidates, CPP per pass: pos(k, x, y) names candidate k's quarter-pel position. Lane k < K of the
      * group gets candidate k's distortion (+ lambda * bits when addmv(k)); the other lanes INT_MAX. */
     template<bool WINDOW = false, class POS, class ADD>
     __device__ __forceinline__ int eval(int K, bool satd, POS pos, ADD addmv) const
@@ -145,7 +148,7 @@ template<typename P> struct BandCu
         int mx = 0, my = 0;
         if (l < K) pos(l, mx, my);
         const int mvc = l < K && addmv(l) ? mvcost(mx, my) : 0;
-        for (int k0 = 0; k0 < K; k0 += 4)
+        for (int k0 = 0; k0 < K; k0 += CPP)
         {
             const int k = k0 + (l >> 2);
             int cx = 0, cy = 0;
@@ -153,13 +156,13 @@ template<typename P> struct BandCu
             int v = WINDOW ? tile_cost_window(cx, cy, satd) : tile_cost(cx, cy, satd);
             v += dpp_all<0xB1>(v);
             v += dpp_all<0x4E>(v);
-            /* candidate k0 + i sits in quad i; lane k0 + i of the group takes it */
-            const int c = grp_lane<4>(v, ((l - k0) & 3) * 4);
-            if (l >= k0 && l < k0 + 4 && l < K) mine = c + mvc;
+            /* candidate k0 + i sits in quad i of the group; lane k0 + i of the group takes it */
+            const int c = grp_lane<LG>(v, ((l - k0) & (CPP - 1)) * 4);
+            if (l >= k0 && l < k0 + CPP && l < K) mine = c + mvc;
         }
         return mine;
     }
-    /* eval for the integer stage (SAD, at most 4 * NP candidates, FULLPEL: all of them full-pel positions): the loads
+    /* eval for the integer stage (SAD, at most CPP * NP candidates, FULLPEL: all of them full-pel positions): the loads
      * of every pass are issued before the first cost is formed, so the passes cost one trip to memory, not NP */
     template<int NP, bool FULLPEL, class POS, class ADD>
     __device__ __forceinline__ int eval_sad(int K, POS pos, ADD addmv) const
@@ -175,9 +178,9 @@ template<typename P> struct BandCu
         for (int p = 0; p < NP; p++)
         {
             odd[p] = false;
-            if (p == 0 || p * 4 < K)
+            if (p == 0 || p * CPP < K)
             {
-                const int k = p * 4 + (l >> 2);
+                const int k = p * CPP + (l >> 2);
                 int cx = 0, cy = 0;
                 pos(k < K ? k : K - 1, cx, cy);
                 const P AS1 *ra = pick((cy & 2) | ((cx & 2) >> 1)) + __mul24(cy >> 2, rstride) + (cx >> 2) + toff;
@@ -198,7 +201,7 @@ template<typename P> struct BandCu
         }
 #pragma unroll
         for (int p = 0; p < NP; p++)
-            if (p == 0 || p * 4 < K)
+            if (p == 0 || p * CPP < K)
             {
                 if constexpr (!FULLPEL)
                     if (odd[p])
@@ -209,8 +212,8 @@ template<typename P> struct BandCu
                 int v = tile_cost_quads<P>(f, qa[p], false);
                 v += dpp_all<0xB1>(v);
                 v += dpp_all<0x4E>(v);
-                const int c = grp_lane<4>(v, ((l - p * 4) & 3) * 4);
-                if (l >= p * 4 && l < p * 4 + 4 && l < K) mine = c + mvc;
+                const int c = grp_lane<LG>(v, ((l - p * CPP) & (CPP - 1)) * 4);
+                if (l >= p * CPP && l < p * CPP + CPP && l < K) mine = c + mvc;
             }
         return mine;
     }
@@ -219,7 +222,7 @@ template<typename P> struct BandCu
     {
         int key = 0x7fffffff;
         if (l >= k0 && l < k1) key = (mine << 6) | l;
-        key = row_min16(key);
+        key = grp_min<LG>(key);
         if ((key >> 6) < bcost) { bcost = key >> 6; return key & 63; }
         return -1;
     }
@@ -227,13 +230,16 @@ template<typename P> struct BandCu
 
 __device__ __forceinline__ int mv_word(int x, int y) { return (x & 0xffff) | (y << 16); }
 
-template<typename P>
+template<typename P, int LG>
 __global__ __launch_bounds__(64) void lookahead_band_kernel(LookaheadArgs a)
 {
+    constexpr int ROWS = 64 >> LG;                  /* CU rows of a band */
+    /* passes of the integer stage's evaluations: start-up (at most 7 candidates), hexagon (6), closing square (8) */
+    constexpr int CPP = BandCu<P, LG>::CPP, NP7 = (7 + CPP - 1) / CPP, NP6 = (6 + CPP - 1) / CPP, NP8 = (8 + CPP - 1) / CPP;
     int *rowmv = (int*)x265amd_smem;                /* per CU row of this band the MV words of its last four CUs */
-    const int lane = (int)threadIdx.x, g = lane >> 4, l = lane & 15;
+    const int lane = (int)threadIdx.x, g = lane >> LG, l = lane & ((1 << LG) - 1);
     const int W = a.wcu, H = a.hcu, ncu = W * H;
-    const int bands = (H + LB_ROWS - 1) / LB_ROWS, nbands = a.nfields * bands;
+    const int bands = (H + ROWS - 1) / ROWS, nbands = a.nfields * bands;
     constexpr unsigned long long SQX = nibs({ 0, 0, 0, -1, 1, -1, -1, 1, 1 }), SQY = nibs({ 0, -1, 1, 0, 0, -1, 1, -1, 1 });
     constexpr unsigned long long HRX = nibs({ -2, -1, 1, 2, 1, -1 }), HRY = nibs({ 0, 2, 2, 0, -2, -2 });
     constexpr unsigned long long H2X = nibs({ -1, -2, -1, 1, 2, 1, -1, -2 }), H2Y = nibs({ -2, 0, 2, 2, 0, -2, -2, 0 });
@@ -247,10 +253,10 @@ __global__ __launch_bounds__(64) void lookahead_band_kernel(LookaheadArgs a)
         if (t >= nbands) break;
         const int fi = t % a.nfields, band = t / a.nfields;
         const FieldDev &fd = a.fields[fi];
-        const int cuy = H - 1 - band * LB_ROWS - g;             /* this group's CU row; rows above the field idle */
+        const int cuy = H - 1 - band * ROWS - g;             /* this group's CU row; rows above the field idle */
         int *mvw = (int*)(a.mvs + (size_t)fi * ncu * 2);
         int32_t *costs = a.costs + (size_t)fi * ncu;
-        BandCu<P> C;
+        BandCu<P, LG> C;
         C.l = l; C.tile = l & 3;
         C.wbase = LB_RING_BYTES + g * band_window_bytes<P>();
         C.ctab = (const uint16_t AS1*)a.ctab;
@@ -258,7 +264,7 @@ __global__ __launch_bounds__(64) void lookahead_band_kernel(LookaheadArgs a)
         C.depth = a.depth;
         int right = 0;
         wave_sync();
-        for (int s = 0; s < W + 2 * (LB_ROWS - 1); s++)
+        for (int s = 0; s < W + 2 * (ROWS - 1); s++)
         {
             const int cux = W - 1 - (s - 2 * g);
             if (cuy >= 0 && cux >= 0 && cux < W)
@@ -282,7 +288,7 @@ __global__ __launch_bounds__(64) void lookahead_band_kernel(LookaheadArgs a)
                                 nb = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                             }
                         }
-                        below = grp_lane<4>(nb, 0); bleft = grp_lane<4>(nb, 1); bright = grp_lane<4>(nb, 2);
+                        below = grp_lane<LG>(nb, 0); bleft = grp_lane<LG>(nb, 1); bright = grp_lane<LG>(nb, 2);
                     }
                     else
                     {
@@ -351,22 +357,22 @@ __global__ __launch_bounds__(64) void lookahead_band_kernel(LookaheadArgs a)
                     };
                     /* (16-bit samples: both passes' tiles and their averaging partners at once cost a wave of occupancy) */
                     int mine;
-                    if constexpr (sizeof(P) == 1) mine = C.template eval_sad<2, false>(3 + numc, pos, [](int k) { return k != 0; });
+                    if constexpr (sizeof(P) == 1 || NP7 == 1) mine = C.template eval_sad<NP7, false>(3 + numc, pos, [](int k) { return k != 0; });
                     else mine = C.eval(3 + numc, false, pos, [](int k) { return k != 0; });
-                    bprecost = grp_lane<4>(mine, 0);
+                    bprecost = grp_lane<LG>(mine, 0);
                     C.nsub++;
                     bcost = bprecost;
-                    if (fpOn) { bcost = grp_lane<4>(mine, 1); C.nsad++; }
+                    if (fpOn) { bcost = grp_lane<LG>(mine, 1); C.nsad++; }
                     if (zeroOn)
                     {
-                        const int c = grp_lane<4>(mine, 2);
+                        const int c = grp_lane<LG>(mine, 2);
                         C.nsad++;
                         if (c < bcost) { bcost = c; bmx = 0; bmy = 0; }
                     }
 #pragma unroll
                     for (int i = 0; i < 4; i++)
                     {
-                        const int c = grp_lane<4>(mine, 3 + i);
+                        const int c = grp_lane<LG>(mine, 3 + i);
                         if (cOn[i] && !(cx[i] == bpx && cy[i] == bpy))
                         {
                             C.nsub++;
@@ -374,11 +380,10 @@ __global__ __launch_bounds__(64) void lookahead_band_kernel(LookaheadArgs a)
                         }
                     }
                 }
-
                 /* ---- hexagon search, motion.cpp:651-723 ---- */
                 {
                     const int ox = bmx, oy = bmy;
-                    const int mine = C.template eval_sad<2, true>(6, [&](int k, int &x, int &y) { x = as_i16(as_i16(ox + nib(HRX, k)) << 2); y = as_i16(as_i16(oy + nib(HRY, k)) << 2); },
+                    const int mine = C.template eval_sad<NP6, true>(6, [&](int k, int &x, int &y) { x = as_i16(as_i16(ox + nib(HRX, k)) << 2); y = as_i16(as_i16(oy + nib(HRY, k)) << 2); },
                                             [](int) { return true; });
                     C.nsad += 6;
                     int dir = C.fold(mine, 0, 6, bcost);
@@ -399,13 +404,12 @@ __global__ __launch_bounds__(64) void lookahead_band_kernel(LookaheadArgs a)
                         }
                     }
                     const int sx = bmx, sy = bmy;
-                    const int m8 = C.template eval_sad<2, true>(8, [&](int k, int &x, int &y) { x = as_i16(as_i16(sx + nib(SQX, k + 1)) << 2); y = as_i16(as_i16(sy + nib(SQY, k + 1)) << 2); },
+                    const int m8 = C.template eval_sad<NP8, true>(8, [&](int k, int &x, int &y) { x = as_i16(as_i16(sx + nib(SQX, k + 1)) << 2); y = as_i16(as_i16(sy + nib(SQY, k + 1)) << 2); },
                                           [](int) { return true; });
                     C.nsad += 8;
                     const int sq = C.fold(m8, 0, 8, bcost) + 1;
                     bmx = as_i16(bmx + nib(SQX, sq)); bmy = as_i16(bmy + nib(SQY, sq));
                 }
-
                 /* ---- motion.cpp:1063-1069, then the lowres sub-pel rounds, :1077-1099 ---- */
                 int qx, qy;
                 if (bprecost < bcost) { qx = bpx; qy = bpy; bcost = bprecost; }
@@ -428,13 +432,12 @@ __global__ __launch_bounds__(64) void lookahead_band_kernel(LookaheadArgs a)
                         const int mine = C.template eval<true>(1 + qpel_dirs, true, [&](int k, int &x, int &y) { x = as_i16(ox + nib(SQX, k)); y = as_i16(oy + nib(SQY, k)); },
                                                 [](int) { return true; });
                         C.nsub += (unsigned)(1 + qpel_dirs);
-                        bcost = grp_lane<4>(mine, 0);
+                        bcost = grp_lane<LG>(mine, 0);
                         const int k = C.fold(mine, 1, 1 + qpel_dirs, bcost);
                         const int bdir = k < 0 ? 0 : k;
                         qx = as_i16(qx + nib(SQX, bdir)); qy = as_i16(qy + nib(SQY, bdir));
                     }
                 }
-
                 right = mv_word(qx, qy);
                 rowmv[g * 4 + (cux & 3)] = right;
                 if (l == 0)
