@@ -192,7 +192,10 @@ typedef struct
  * (slicetype.cpp:1427-1430), hexagon / square steps 3 more without a range check, the quarter-pel average one more.
  * X265AMD_UMH reads much further (motion.cpp:732, :301-303: its cross is measured from the start block, the vertical one
  * at x = omv.x + omv.y) and needs margin_x >= 32 + 8 * (height_in_cu - 1) + 6 * merange / 4 + 6 and
- * margin_y >= 30 + 6 * merange / 4; the reference's own lookahead only ever uses X265_HEX_SEARCH (slicetype.h:65-72). */
+ * margin_y >= 30 + 6 * merange / 4; the reference's own lookahead only ever uses X265_HEX_SEARCH (slicetype.h:65-72).
+ * Performance: a field's latency is its dependency chain of width_in_cu + 2 * (height_in_cu - 1) CU searches however many
+ * fields a launch holds (about 1 ms for a 1080p field), so batch fields: launches of up to ~1000 waves (nfields *
+ * height_in_cu / 2) run a form of the kernel with shorter steps, larger ones the form with the higher throughput. */
 int x265amd_lookahead_fields(x265amd_ctx *ctx, const x265amd_field *fields, int nfields,
                              int width_in_cu, int height_in_cu, int qp, int method, int subme, int merange,
                              int16_t *out_mvs, int32_t *out_costs, x265amd_result *out_stats /* nfields*ncu or NULL */);
