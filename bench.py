@@ -226,8 +226,10 @@ def main():
                          "affinity mask)")
     ap.add_argument("--method", default="star")
     ap.add_argument("--subme", type=int, default=SUBME_DEFAULT, help="sub-pel refinement level (experiments only)")
-    ap.add_argument("--launch", choices=("pairs4", "pairs3", "split", "split3", "single", "per-size"), default="pairs4",
-                    help="search launches: pairs4 = per step ONE launch per PU size (8x8 | 16x16 | 32x32, 64x64) over all frame "
+    ap.add_argument("--launch", choices=("families", "pairs4", "pairs3", "split", "split3", "single", "per-size"), default="families",
+                    help="families = pairs3 with the list of the 64x64 + 32x32 launch in quadtree order: every 64x64 PU followed "
+                         "by its four 32x32 children, which the library then refines together with it where they start from "
+                         "the same MV (32x32 PUs without a parent at the end of a pair's part); search launches: pairs4 = per step ONE launch per PU size (8x8 | 16x16 | 32x32, 64x64) over all frame "
                          "pairs (x265amd_search_batch_pairs_dev), three streams, the two large sizes sharing one; pairs3 = "
                          "the 64x64 and 32x32 PUs in one launch; the others launch per frame pair: split3 = the "
                          "same three classes, split = 16/8 and 64/32 on two streams (LDS per PU sized per class), single = one "
@@ -287,11 +289,11 @@ def main():
     # ---------------- setup (untimed): planes, lookahead fields, job lists, all on the device
     es = Engine(local_rank, 8, high_priority=args.prio == "small")      # search stream (all launches, or the 16/8 class)
     el = Engine(local_rank, 8, high_priority=args.prio == "la")      # lookahead stream
-    multi = args.launch in ("pairs3", "pairs4")
-    split = args.launch in ("split", "split3", "pairs3", "pairs4")
+    multi = args.launch in ("pairs3", "pairs4", "families")
+    split = args.launch in ("split", "split3", "pairs3", "pairs4", "families")
     eb = Engine(local_rank, 8, high_priority=args.prio == "big") if split else es   # stream of the 64/32 class
     ebs = [eb] + [Engine(local_rank, 8) for _ in range(args.big_streams - 1)] if split else [es]
-    em = Engine(local_rank, 8) if args.launch in ("split3", "pairs3", "pairs4") else es   # stream of the 16x16 class
+    em = Engine(local_rank, 8) if args.launch in ("split3", "pairs3", "pairs4", "families") else es   # stream of the 16x16 class
     e32 = {"big": eb, "mid": em, "la": el, "own": None}[args.s32] or Engine(local_rank, 8)     # stream of the 32x32 class (pairs4)
     B = args.pairs
     clip = make_clip(W, H, B + 1, seed=1234 + rank)
@@ -323,7 +325,7 @@ def main():
                 return (int(idx[0]), len(idx), dim, eng)
             if args.launch == "split":
                 segs = [seg(jobs["w"] <= 16, 16, es), seg(jobs["w"] >= 32, 64, eb)]
-            elif args.launch in ("split3", "pairs3"):
+            elif args.launch in ("split3", "pairs3", "families"):
                 segs = [seg(jobs["w"] == 8, 8, es), seg(jobs["w"] == 16, 16, em), seg(jobs["w"] >= 32, 64, eb)]
             elif args.launch == "pairs4":
                 segs = [seg(jobs["w"] == 8, 8, es), seg(jobs["w"] == 16, 16, em), seg(jobs["w"] == 32, 32, e32),
@@ -347,8 +349,26 @@ def main():
                 j["reserved"] = i
                 parts.append(j)
                 index.append(np.stack([np.full(cnt, i), np.arange(first, first + cnt)], axis=1))
+            if dim == 64 and args.launch == "families":
+                # quadtree order inside every pair's part: a 64x64 PU, then its four 32x32 children in raster order;
+                # the 32x32 PUs without a parent (the picture's height is no multiple of 64) at the end
+                j0 = host_jobs[0][first:first + cnt]
+                pos = {(int(j["pu_x"]), int(j["pu_y"]), int(j["w"])): k for k, j in enumerate(j0)}
+                fam, used = [], set()
+                for k, j in enumerate(j0):
+                    if j["w"] != 64:
+                        continue
+                    kids = [pos.get((int(j["pu_x"]) + 32 * (q & 1), int(j["pu_y"]) + 32 * (q >> 1), 32)) for q in range(4)]
+                    fam.append(k)
+                    if all(c is not None for c in kids):
+                        fam += kids
+                        used.update(kids)
+                fam += [k for k, j in enumerate(j0) if j["w"] == 32 and k not in used]
+                fam = np.array(fam)
+                assert len(fam) == cnt and len(set(fam.tolist())) == cnt
+                parts, index = [p_[fam] for p_ in parts], [x_[fam] for x_ in index]
             cj, ci = np.concatenate(parts), np.concatenate(index)
-            if dim == 64:
+            if dim == 64 and args.launch != "families":
                 order = np.argsort(-cj["w"].astype(np.int64), kind="stable")
                 cj, ci = cj[order], ci[order]
             cls_jobs.append(torch.from_numpy(cj.view(np.uint8).reshape(len(cj), -1).copy()).to(dev))
@@ -503,7 +523,7 @@ def main():
     tpath = os.path.join(ROOT, "profiles", "traffic.json")
     if os.path.exists(tpath):
         traffic = json.load(open(tpath)).get("search_kernel_hbm_bytes_per_launch", {}).get(
-            "pairs3" if args.launch == "pairs4" else args.launch)     # the 8x8 launch is the same in both
+            "pairs3" if args.launch in ("pairs4", "families") else args.launch)     # the 8x8 launch is the same in all three
         if traffic is not None and multi:
             traffic *= B      # kept per frame pair (the counters were collected on a 2-pair step)
     # the floor of a step's HBM bytes: every plane of the frame pairs read once (padded as uploaded), job records in,
@@ -606,7 +626,12 @@ def main():
                                   "thread, frame pairs dealt out in turn), %.1f s, %s; MVs and costs compared with the GPU's"
                                   % (njobs * B, B, nthr, mt_s, "the reference's own code (oracle/_ref)" if use_ref
                                      else "oracle/me_oracle.c -O3")})
-        kernel = {"pairs4": "the launch over the %d 8x8 PUs of all %d frame pairs of a step: star_small_kernel<8> (start-up and the "
+        kernel = {"families": "the launch over the %d 8x8 PUs of all %d frame pairs of a step: star_small_kernel<8> (start-up and the "
+                              "common case of the integer stage, four PUs per wave), search_kernel<uint8_t,false> (the PUs the first "
+                              "kernel marked: one PU per wave) and refine_small_kernel<8> (sub-pel rounds, four PUs per wave); the "
+                              "16x16 launch and the launch of the 64x64 PUs with their 32x32 children run concurrently on two more "
+                              "streams" % (timed_cnt * B, B),
+                  "pairs4": "the launch over the %d 8x8 PUs of all %d frame pairs of a step: star_small_kernel<8> (start-up and the "
                             "common case of the integer stage, four PUs per wave), search_kernel<uint8_t,false> (the PUs the first "
                             "kernel marked: one PU per wave) and refine_small_kernel<8> (sub-pel rounds, four PUs per wave); the "
                             "16x16 launch and the 64x64 + 32x32 launches run concurrently on two more streams" % (timed_cnt * B, B),

@@ -347,3 +347,57 @@ def test_exhaustive_search_windows(engine8, engine10, oracle, depth, kind):
     engine8.free_plane(pr)
     if own:
         own.close()
+
+
+@pytest.mark.parametrize("depth", [8, 10])
+@pytest.mark.parametrize("mname", ["star", "hex"])
+def test_children_refined_with_their_parent(request, oracle, mname, depth):
+    """A launch for 64x64 PUs whose list has every 64x64 PU followed by its four 32x32 children: where the five start
+    their refinement from one MV the children's candidates are measured with the parent's (the sums of the quadrants),
+    as long as every decision keeps them together; otherwise, and for children in any other place of the list, each is
+    refined on its own. Coherent motion (the children mostly follow), predictors of their own per child (they mostly
+    do not), orphans and strays, every subme level."""
+    e = _engine(request, depth)
+    method = METHODS[mname]
+    W, H = 320, 192
+    m = margin_for(method)
+    fenc, ref, org, stride = clip_planes(W, H, depth, "texture", margin=m)
+    pf = e.upload_plane(fenc, W, H, m, m, stride)
+    pr = e.upload_plane(ref, W, H, m, m, stride)
+    shared = 0
+    for subme in range(8):
+        rng = np.random.default_rng(4000 + subme)
+        jl = []
+        for cy in range(H // 64):
+            for cx in range(W // 64):
+                coherent = (cx + cy + subme) % 3 != 0
+                fam = random_jobs(rng, 5, W, H, method, parts=[(64, 64)], meranges=(16, 24))
+                fam["pu_x"], fam["pu_y"] = cx * 64, cy * 64
+                for q in range(1, 5):
+                    fam[q]["w"] = fam[q]["h"] = 32
+                    fam[q]["pu_x"] += 32 * ((q - 1) & 1)
+                    fam[q]["pu_y"] += 32 * ((q - 1) >> 1)
+                    if coherent:
+                        for k in ("qmvp", "numc", "mvc", "merange"):
+                            fam[q][k] = fam[0][k]
+                for j in fam:           # the range of each PU around its own predictor
+                    fx, fy = int(j["qmvp"][0]) >> 2, int(j["qmvp"][1]) >> 2
+                    mr = int(j["merange"])
+                    j["mvmin"] = (max(fx - mr, -int(j["pu_x"]) - 60), max(fy - mr, -int(j["pu_y"]) - 60))
+                    j["mvmax"] = (min(fx + mr, W - int(j["pu_x"]) - int(j["w"]) + 60), min(fy + mr, H - int(j["pu_y"]) - int(j["h"]) + 60))
+                if (cx + cy) % 4 == 3:
+                    fam = fam[[0, 2, 1, 3, 4]]      # children out of order: nobody is taken along
+                jl.append(fam)
+        jl.append(random_jobs(rng, 9, W, H, method, parts=[(32, 32), (64, 64), (16, 16), (64, 32)]))    # strays
+        jobs = np.concatenate(jl)
+        qp = int(rng.integers(10, 45)) + 6 * (depth - 8)
+        r = e.search_batch(pf, pr, jobs, qp, method, subme)
+        mv, cost, sc, qc = oracle_search(oracle, depth, fenc, [ref], org, stride, jobs, qp, method, subme)
+        assert np.array_equal(r["mv"], mv), subme
+        assert np.array_equal(r["cost"], cost), subme
+        assert np.array_equal(r["sad_calls"], sc) and np.array_equal(r["subpel_calls"], qc), subme
+        par = np.flatnonzero(jobs["w"][:-9] == 64)
+        shared += sum(int((mv[p + 1:p + 5] == mv[p]).all()) for p in par if p + 4 < len(jobs))
+    assert shared > 0       # families that ended on one MV did occur
+    e.free_plane(pf)
+    e.free_plane(pr)

@@ -54,6 +54,9 @@ struct SearchArgs
     int plane_lds; /* LDS bytes a wave of search_kernel has for interpolation planes (0: plane_budget of max_dim) */
     int staged;    /* 8, 16, 32 or 64: square PUs of this size stop before the sub-pel refinement, which refine_small_kernel
                       (8, 16) or refine_big_kernel (32, 64) does; 0: none */
+    int staged2;   /* 32 in a launch staged for 64: its 32x32 PUs stop there too and are refined with their parents where
+                      the list has them behind one (refine_big_kernel<64>), by refine_big_kernel<32> otherwise; else 0 */
+    unsigned char *done;   /* null, or per job: refined already (set by refine_big_kernel<64> for the children it took along) */
 };
 
 /* the planes job `job` searches: the launch's own, or its entry of the launch's pair table. Device-resident jobs
@@ -138,7 +141,7 @@ __global__ __launch_bounds__(64) void search_kernel(SearchArgs a)
         job_planes(a, job, fenc, ref);
         S.bind(0, fenc, ref, a.nref, a.ctab, a.depth, job->pu_x, job->pu_y, w, h, a.max_dim,
                a.plane_lds ? a.plane_lds : plane_budget(a.max_dim, (int)sizeof(P)));
-        if (a.staged && w == a.staged && h == a.staged) S.search_staged(job, a.method, a.results + j);
+        if (a.staged && w == h && (w == a.staged || w == a.staged2)) S.search_staged(job, a.method, a.results + j);
         else S.search(job, a.method, a.subme, a.results + j);
     }
 }
@@ -810,6 +813,7 @@ struct x265amd_ctx
     void *d_stage; size_t stage_cap;   /* staging for the per-call primitives */
     int probe_khz;                     /* constant-rate clock of the last x265amd_clock_probe_start, kHz */
     long long *d_probe;                /* the probe wave's two counters (a buffer of its own: other calls may run meanwhile) */
+    void *d_done; size_t done_cap;     /* per job of a launch: refined with its parent (refine_big_kernel<64>) */
     void *d_redo; size_t redo_cap;     /* list of the PUs a fixed-shape kernel left to the one-wave search (redo_list_kernel) */
     int32_t *d_out;
     int *d_ticket;                     /* row hand-out counter of the row-parallel lookahead kernel */
@@ -913,6 +917,15 @@ static int launch_search(x265amd_ctx *c, const SearchArgs &a, int is_lowres)
         static const bool no_big = getenv("X265AMD_NO_STAGED_BIG") != 0;                             /* measurements only */
         b.staged = (sizeof(P) == 1 || c->depth <= 10) && !no_staged &&
                    (a.max_dim == 8 || a.max_dim == 16 || ((a.max_dim == 32 || a.max_dim == 64) && !no_big)) ? a.max_dim : 0;
+        if (b.staged == 64 && !getenv("X265AMD_NO_QUAD"))
+        {
+            /* a launch for 64x64 PUs refines the 32x32 PUs of its list in the fixed-shape kernels as well: together
+             * with their parent where the list has the four children right behind it, on their own otherwise */
+            if (ensure(c, &c->d_done, &c->done_cap, (size_t)a.njobs)) return X265AMD_EHIP;
+            HIPCHK(c, hipMemsetAsync(c->d_done, 0, (size_t)a.njobs, c->stream));
+            b.staged2 = 32;
+            b.done = (unsigned char*)c->d_done;
+        }
         const int npu = b.staged == 8 ? 4 : 1, groups = (a.njobs + npu - 1) / npu;      /* star_small_kernel's PUs per wave */
         const int rgroups = (a.njobs + 3) / 4;                                              /* refine_small_kernel's */
         if (b.staged && b.staged <= 16 && a.method == X265AMD_STAR && !no_star)
@@ -951,7 +964,11 @@ static int launch_search(x265amd_ctx *c, const SearchArgs &a, int is_lowres)
         else if (b.staged == 32)
             hipLaunchKernelGGL((refine_big_kernel<32, P>), dim3(a.njobs), dim3(BigGeo<32>::THREADS), BigLds<32>::TOTAL, c->stream, b);
         else if (b.staged == 64)
+        {
             hipLaunchKernelGGL((refine_big_kernel<64, P>), dim3(a.njobs), dim3(BigGeo<64>::THREADS), BigLds<64>::TOTAL, c->stream, b);
+            if (b.staged2)      /* the 32x32 PUs their parents did not take along */
+                hipLaunchKernelGGL((refine_big_kernel<32, P>), dim3(a.njobs), dim3(BigGeo<32>::THREADS), BigLds<32>::TOTAL, c->stream, b);
+        }
     }
     HIPCHK(c, hipGetLastError());
     return X265AMD_OK;
@@ -1048,6 +1065,7 @@ static int create_ctx(int device, int bit_depth, int high_priority, x265amd_ctx 
     if (hipGetDeviceCount(&n) != hipSuccess || device < 0 || device >= n) return X265AMD_EHIP;
     x265amd_ctx *c = new x265amd_ctx();
     c->device = device; c->depth = bit_depth;
+    c->d_done = 0; c->done_cap = 0;
     c->d_jobs = c->d_results = c->d_stage = c->d_redo = 0; c->d_ticket = 0; c->d_probe = 0;
     c->jobs_cap = c->results_cap = c->stage_cap = c->redo_cap = 0; c->d_out = 0;
     c->esa_window_bytes = 0;
@@ -1094,6 +1112,7 @@ void x265amd_destroy(x265amd_ctx *c)
     if (c->d_results) (void)hipFree(c->d_results);
     if (c->d_stage) (void)hipFree(c->d_stage);
     if (c->d_redo) (void)hipFree(c->d_redo);
+    if (c->d_done) (void)hipFree(c->d_done);
     if (c->d_probe) (void)hipFree(c->d_probe);
     if (c->d_out) (void)hipFree(c->d_out);
     if (c->d_ticket) (void)hipFree(c->d_ticket);
@@ -1357,7 +1376,7 @@ static void fill_args(x265amd_ctx *c, SearchArgs &a, const x265amd_plane *fenc, 
         a.ref[i].origin = r->origin; a.ref[i].stride = r->stride;
     }
     a.lowres = is_lowres; a.depth = c->depth; a.method = method; a.subme = subme; a.max_dim = is_lowres ? 8 : 64;
-    a.staged = 0; a.redo = 0; a.pairs = 0; a.npairs = 0; a.plane_lds = 0;
+    a.staged = 0; a.staged2 = 0; a.done = 0; a.redo = 0; a.pairs = 0; a.npairs = 0; a.plane_lds = 0;
     a.ctab = c->tables[qp] + 32768;
 }
 

@@ -487,9 +487,10 @@ template<int S> struct BigGeo
 template<int S> struct BigLds
 {
     typedef SmallGeo<S> G;
-    static constexpr int CELLS = SM_FIXED;                          /* per round 16 candidate sums */
+    static constexpr int CELLS = SM_FIXED;                          /* per round 16 candidates' sums, one per quadrant of the PU */
     static constexpr int ROUNDS = 5;                                /* motion.cpp:53-63: at most 2 + 2 rounds, or the closing re-measure */
-    static constexpr int PLANES = CELLS + ROUNDS * 64;
+    static constexpr int VOTES = CELLS + ROUNDS * 256;              /* per round the four children's decisions */
+    static constexpr int PLANES = VOTES + ROUNDS * 16;
     static constexpr int TOTAL = PLANES + 3 * G::PLANE + 32;
 };
 
@@ -514,13 +515,40 @@ __global__ __launch_bounds__(BigGeo<S>::THREADS) void refine_big_kernel(SearchAr
     /* a PU whose full-pel cost is 0 is not refined (motion.cpp:1073-1076), a negative cost marks a job that was
      * refused; PUs of other sizes are final already */
     if ((d1 & 0xffff) != G::SIZE_CODE || bcost <= 0) return;
+    if (a.done && a.done[j]) return;                /* refined together with its parent already */
     const P AS1 *fenc0, *ref0;
     int fstride, rstride;
     small_planes<P>(a, d1, fenc0, fstride, ref0, rstride);
     const int roff = puy * rstride + pux;
     const uint16_t AS1 *ctab = (const uint16_t AS1*)a.ctab;
     small_load_taps<P>(tid, depth);
-    for (int i = tid; i < L::ROUNDS * 16; i += THREADS) ((int*)(x265amd_smem + L::CELLS))[i] = 0;
+    for (int i = tid; i < L::ROUNDS * 68; i += THREADS) ((int*)(x265amd_smem + L::CELLS))[i] = 0;
+    /* A 64x64 PU directly followed in the list by its four 32x32 children (raster order, same pictures), all five
+     * starting from the same MV: SAD and SATD are sums over 4x4 tiles, so a candidate's distortion for a child is the
+     * sum over the child's quadrant -- wave w keeps the sums of quadrant-aligned halves apart and takes child w's
+     * decisions beside the parent's. The children stay with the parent as long as every decision moves all five to
+     * the same MV; if one differs, the parent goes on alone and the children are left for their own refinement. */
+    const int wave = tid >> 6;
+    bool quad = false;
+    int cbcost = 0, cmvpx = 0, cmvpy = 0;
+    unsigned cnsub = 0;
+    if constexpr (S == 64)
+    {
+        if (a.done && j + 4 < a.njobs)
+        {
+            quad = true;
+#pragma unroll
+            for (int q = 0; q < 4; q++)
+            {
+                const int *cj = (const int*)(a.jobs + j + 1 + q);
+                const int *cr = (const int*)(a.results + j + 1 + q);
+                const int c0 = uni(cj[0]), c1 = uni(cj[1]), c4 = uni(cj[4]), m = uni(cr[0]), bc = uni(cr[1]);
+                quad = quad && (c1 & 0xffff) == SmallGeo<32>::SIZE_CODE && (c1 >> 24) == (d1 >> 24) &&
+                       as_i16(c0) == pux + 32 * (q & 1) && (c0 >> 16) == puy + 32 * (q >> 1) && m == r0 && bc > 0;
+                if (q == wave) { cbcost = bc; cmvpx = as_i16(c4); cmvpy = c4 >> 16; cnsub = (unsigned)uni(cr[3]); }
+            }
+        }
+    }
     ColSrc ct[ITEMS];
 #pragma unroll
     for (int u = 0; u < ITEMS; u++) small_source_column<S>(fenc0, fstride, pux, puy, tid + u * THREADS, ct[u]);
@@ -532,11 +560,12 @@ __global__ __launch_bounds__(BigGeo<S>::THREADS) void refine_big_kernel(SearchAr
     {
         constexpr unsigned long long SQX = nibs({ 0, 0, 0, -1, 1, -1, -1, 1, 1 }), SQY = nibs({ 0, -1, 1, 0, 0, -1, 1, -1, 1 });
         const int k0 = centre ? 1 : 0, K = k0 + dirs;
-        int mvc = 0;
+        int mvc = 0, cmvc = 0;
         {
             const int i = lane < K ? lane + 1 - k0 : 0;
             const int tx = as_i16(qx + nib(SQX, i) * step), ty = as_i16(qy + nib(SQY, i) * step);
             if (lane < K) mvc = ((int)ctab[tx - mvpx] + (int)ctab[ty - mvpy]) & 0xffff;
+            if (lane < K && quad) cmvc = ((int)ctab[tx - cmvpx] + (int)ctab[ty - cmvpy]) & 0xffff;
         }
         const int ya = as_i16(qy - step) >> 2, yb = qy >> 2, yc = as_i16(qy + step) >> 2;
         int ymin = ya < yb ? ya : yb;
@@ -557,8 +586,10 @@ __global__ __launch_bounds__(BigGeo<S>::THREADS) void refine_big_kernel(SearchAr
             }
         }
         __syncthreads();
-        /* vertical pass + cost: a candidate per pass, the wave's tiles of it */
-        int part = 0;
+        /* vertical pass + cost: a candidate per pass, the wave's tiles of it. A lane's first half of its pairs lies in
+         * the upper half of the PU and the second in the lower (tile rows wave + 4 u), lanes 0-31 in the left half and
+         * 32-63 in the right: the sums of the four quadrants stay apart (lane c: left, lane c + 32: right) */
+        int partT = 0, partB = 0;
         for (int c = 0; c < K; c++)
         {
             const int i = c + 1 - k0;
@@ -568,29 +599,44 @@ __global__ __launch_bounds__(BigGeo<S>::THREADS) void refine_big_kernel(SearchAr
              * plane and phase -- measured together */
             if (step == 2 && i >= 1 && nib(SQY, i) == -1 && c + 1 < K && nib(SQY, i + 1) == 1 && nib(SQX, i + 1) == nib(SQX, i))
             {
-                int va = 0, vb = 0;
+                int vaT = 0, vbT = 0, vaB = 0, vbB = 0;
 #pragma unroll
-                for (int u = 0; u < ITEMS; u++) small_column_cost_pair<S>(poff, rr, ty & 3, satd, ct[u], tid & 3, depth, va, vb);
-                va = seg_sum(va, 6); vb = seg_sum(vb, 6);
-                if (lane == c) part = va;
-                if (lane == c + 1) part = vb;
+                for (int u = 0; u < ITEMS; u++)
+                {
+                    if (u < ITEMS / 2) small_column_cost_pair<S>(poff, rr, ty & 3, satd, ct[u], tid & 3, depth, vaT, vbT);
+                    else small_column_cost_pair<S>(poff, rr, ty & 3, satd, ct[u], tid & 3, depth, vaB, vbB);
+                }
+                vaT = seg_sum(vaT, 5); vbT = seg_sum(vbT, 5); vaB = seg_sum(vaB, 5); vbB = seg_sum(vbB, 5);
+                if ((lane & 31) == c) { partT = vaT; partB = vaB; }
+                if ((lane & 31) == c + 1) { partT = vbT; partB = vbB; }
                 c++;
                 continue;
             }
-            int v = 0;
+            int vT = 0, vB = 0;
 #pragma unroll
-            for (int u = 0; u < ITEMS; u++) v += small_column_cost<S>(poff, rr, ty & 3, satd, ct[u], tid & 3, depth);
-            v = seg_sum(v, 6);
-            if (lane == c) part = v;
+            for (int u = 0; u < ITEMS; u++)
+            {
+                const int v = small_column_cost<S>(poff, rr, ty & 3, satd, ct[u], tid & 3, depth);
+                if (u < ITEMS / 2) vT += v; else vB += v;
+            }
+            vT = seg_sum(vT, 5); vB = seg_sum(vB, 5);
+            if ((lane & 31) == c) { partT = vT; partB = vB; }
         }
-        int *cells = (int*)(x265amd_smem + L::CELLS) + rnd * 16;
-        if (lane < K) atomicAdd(cells + lane, part);
+        int *cells = (int*)(x265amd_smem + L::CELLS) + rnd * 64;           /* [candidate][TL, TR, BL, BR] */
+        if ((lane & 31) < K)
+        {
+            atomicAdd(cells + (lane & 31) * 4 + (lane >> 5), partT);
+            atomicAdd(cells + (lane & 31) * 4 + 2 + (lane >> 5), partB);
+        }
         __syncthreads();
-        int mycost = 0;
+        int mycost = 0, ccost = 0;
         if (lane < K)
         {
-            const int v = cells[lane];
+            const int4 q4 = *(const int4*)(cells + lane * 4);
+            const int v = q4.x + q4.y + q4.z + q4.w;
             mycost = (satd ? v >> 1 : v) + mvc;     /* every 4x4 abs-sum is even: halving the total = halving per tile */
+            const int vq = wave == 0 ? q4.x : (wave == 1 ? q4.y : (wave == 2 ? q4.z : q4.w));
+            ccost = (satd ? vq >> 1 : vq) + cmvc;
         }
         if (centre) bcost = __shfl(mycost, 0);
         int key = 0x7fffffff;
@@ -598,6 +644,21 @@ __global__ __launch_bounds__(BigGeo<S>::THREADS) void refine_big_kernel(SearchAr
         key = wave_min(key);
         int bdir = 0;
         if ((key >> 6) < bcost) { bcost = key >> 6; bdir = (key & 63) - k0 + 1; }
+        if (quad)
+        {
+            /* child `wave`: the same sequence on its quadrant's sums and its own lambda * bits */
+            if (centre) cbcost = __shfl(ccost, 0);
+            int ckey = 0x7fffffff;
+            if (lane >= k0 && lane < K) ckey = (ccost << 6) | lane;
+            ckey = wave_min(ckey);
+            int cdir = 0;
+            if ((ckey >> 6) < cbcost) { cbcost = ckey >> 6; cdir = (ckey & 63) - k0 + 1; }
+            cnsub += (unsigned)K;
+            int *votes = (int*)(x265amd_smem + L::VOTES) + rnd * 4;
+            if (lane == 0) votes[wave] = cdir;
+            __syncthreads();
+            quad = votes[0] == bdir && votes[1] == bdir && votes[2] == bdir && votes[3] == bdir;
+        }
         qx = as_i16(qx + nib(SQX, bdir) * step); qy = as_i16(qy + nib(SQY, bdir) * step);
         nsub += (unsigned)K;
         rnd++;
@@ -623,6 +684,14 @@ __global__ __launch_bounds__(BigGeo<S>::THREADS) void refine_big_kernel(SearchAr
         res[0] = (qx & 0xffff) | (qy << 16);
         res[1] = bcost;
         res[3] = (int)nsub;
+    }
+    if (quad && lane == 0)
+    {
+        int *cr = (int*)(a.results + j + 1 + wave);
+        cr[0] = (qx & 0xffff) | (qy << 16);
+        cr[1] = cbcost;
+        cr[3] = (int)cnsub;
+        a.done[j + 1 + wave] = 1;
     }
 }
 
