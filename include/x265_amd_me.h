@@ -125,8 +125,11 @@ int x265amd_search_batch(x265amd_ctx *ctx, const x265amd_plane *fenc, const x265
  * size, so batches of small PUs keep more PUs resident per CU; a larger job in the batch gets
  * cost -1 and is not searched. With 8-bit samples the square PUs of exactly that size take the
  * fixed-shape kernels (several PUs per wave, or several waves per PU), so a caller after
- * throughput launches one batch per PU size; results do not depend on it. Planes must be readable 32 bytes past their last sample
- * (planes made by this library are). */
+ * throughput launches one batch per PU size; results do not depend on it. A batch for 64x64 PUs (samples of at most
+ * 10 bits) takes its 32x32 PUs through the fixed-shape kernels as well, and a 64x64 PU that is directly followed in the list by
+ * its four 32x32 children (raster order, same pictures) refines them together with itself where all five start the sub-pel
+ * rounds from one MV -- a quarter of the children's work; the list order changes no result.
+ * Planes must be readable 32 bytes past their last sample (planes made by this library are). */
 int x265amd_search_batch_dev(x265amd_ctx *ctx, const x265amd_plane *fenc, const x265amd_plane *ref, int is_lowres,
                              int qp, int method, int subme,
                              const x265amd_job *d_jobs, int njobs, x265amd_result *d_results, int max_pu_dim);

@@ -351,12 +351,13 @@ def test_exhaustive_search_windows(engine8, engine10, oracle, depth, kind):
 
 @pytest.mark.parametrize("depth", [8, 10])
 @pytest.mark.parametrize("mname", ["star", "hex"])
-def test_children_refined_with_their_parent(request, oracle, mname, depth):
-    """A launch for 64x64 PUs whose list has every 64x64 PU followed by its four 32x32 children: where the five start
-    their refinement from one MV the children's candidates are measured with the parent's (the sums of the quadrants),
-    as long as every decision keeps them together; otherwise, and for children in any other place of the list, each is
-    refined on its own. Coherent motion (the children mostly follow), predictors of their own per child (they mostly
-    do not), orphans and strays, every subme level."""
+@pytest.mark.parametrize("psize", [64, 16])
+def test_children_refined_with_their_parent(request, oracle, mname, depth, psize):
+    """A launch for 64x64 (16x16) PUs whose list has every such PU followed by its four 32x32 (8x8) children: where the
+    five start their refinement from one MV the children's candidates are measured with the parent's (the sums of the
+    quadrants), as long as every decision keeps them together; otherwise, and for children in any other place of the
+    list, each is refined on its own. Coherent motion (the children mostly follow), predictors of their own per child
+    (they mostly do not), orphans and strays, every subme level."""
     e = _engine(request, depth)
     method = METHODS[mname]
     W, H = 320, 192
@@ -368,15 +369,16 @@ def test_children_refined_with_their_parent(request, oracle, mname, depth):
     for subme in range(8):
         rng = np.random.default_rng(4000 + subme)
         jl = []
-        for cy in range(H // 64):
-            for cx in range(W // 64):
+        half = psize // 2
+        for cy in range(H // psize if psize == 64 else 5):
+            for cx in range(W // psize if psize == 64 else 9):
                 coherent = (cx + cy + subme) % 3 != 0
-                fam = random_jobs(rng, 5, W, H, method, parts=[(64, 64)], meranges=(16, 24))
-                fam["pu_x"], fam["pu_y"] = cx * 64, cy * 64
+                fam = random_jobs(rng, 5, W, H, method, parts=[(psize, psize)], meranges=(16, 24))
+                fam["pu_x"], fam["pu_y"] = cx * psize + 32 * (psize == 16), cy * psize + 48 * (psize == 16)
                 for q in range(1, 5):
-                    fam[q]["w"] = fam[q]["h"] = 32
-                    fam[q]["pu_x"] += 32 * ((q - 1) & 1)
-                    fam[q]["pu_y"] += 32 * ((q - 1) >> 1)
+                    fam[q]["w"] = fam[q]["h"] = half
+                    fam[q]["pu_x"] += half * ((q - 1) & 1)
+                    fam[q]["pu_y"] += half * ((q - 1) >> 1)
                     if coherent:
                         for k in ("qmvp", "numc", "mvc", "merange"):
                             fam[q][k] = fam[0][k]
@@ -388,7 +390,8 @@ def test_children_refined_with_their_parent(request, oracle, mname, depth):
                 if (cx + cy) % 4 == 3:
                     fam = fam[[0, 2, 1, 3, 4]]      # children out of order: nobody is taken along
                 jl.append(fam)
-        jl.append(random_jobs(rng, 9, W, H, method, parts=[(32, 32), (64, 64), (16, 16), (64, 32)]))    # strays
+        strays = [(32, 32), (64, 64), (16, 16), (64, 32)] if psize == 64 else [(8, 8), (16, 16), (16, 8), (8, 4)]
+        jl.append(random_jobs(rng, 9, W, H, method, parts=strays))
         jobs = np.concatenate(jl)
         qp = int(rng.integers(10, 45)) + 6 * (depth - 8)
         r = e.search_batch(pf, pr, jobs, qp, method, subme)
@@ -396,7 +399,7 @@ def test_children_refined_with_their_parent(request, oracle, mname, depth):
         assert np.array_equal(r["mv"], mv), subme
         assert np.array_equal(r["cost"], cost), subme
         assert np.array_equal(r["sad_calls"], sc) and np.array_equal(r["subpel_calls"], qc), subme
-        par = np.flatnonzero(jobs["w"][:-9] == 64)
+        par = np.flatnonzero((jobs["w"][:-9] == psize) & (jobs["h"][:-9] == psize))
         shared += sum(int((mv[p + 1:p + 5] == mv[p]).all()) for p in par if p + 4 < len(jobs))
     assert shared > 0       # families that ended on one MV did occur
     e.free_plane(pf)

@@ -134,7 +134,9 @@ for (k, g, q), v in cnt.items():
         sizes = q_of.get(q, ["?"])
         # the integer stage of the 32x32 / 64x64 PUs has a wave per PU; the launches over marked PUs have at most 8192 waves
         big = [s for s in sizes if s in ("32", "64") and abs(waves - {"32": 1980, "64": 480}[s] * PAIRS_PMC) < 1]
-        name = "search_kernel (%s)" % ("integer stage of the %sx%s PUs" % (big[0], big[0]) if big else
+        both = "32" in sizes and "64" in sizes and abs(waves - (1980 + 480) * PAIRS_PMC) < 1    # one launch for parents and children
+        name = "search_kernel (%s)" % ("integer stage of the 64x64 and 32x32 PUs" if both else
+                                       "integer stage of the %sx%s PUs" % (big[0], big[0]) if big else
                                        "PUs star_small_kernel marked, %s" % "/".join(s for s in sizes if s in ("8", "16")))
     else:
         continue
