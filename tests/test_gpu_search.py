@@ -353,11 +353,12 @@ def test_exhaustive_search_windows(engine8, engine10, oracle, depth, kind):
 @pytest.mark.parametrize("mname", ["star", "hex"])
 @pytest.mark.parametrize("psize", [64, 16])
 def test_children_refined_with_their_parent(request, oracle, mname, depth, psize):
-    """A launch for 64x64 (16x16) PUs whose list has every such PU followed by its four 32x32 (8x8) children: where the
-    five start their refinement from one MV the children's candidates are measured with the parent's (the sums of the
-    quadrants), as long as every decision keeps them together; otherwise, and for children in any other place of the
-    list, each is refined on its own. Coherent motion (the children mostly follow), predictors of their own per child
-    (they mostly do not), orphans and strays, every subme level."""
+    """A launch for 64x64 PUs whose list has every 64x64 PU followed by its four 32x32 children: where the five start
+    their refinement from one MV the children's candidates are measured with the parent's (the sums of the quadrants),
+    as long as every decision keeps them together; otherwise, and for children in any other place of the list, each is
+    refined on its own. Coherent motion (the children mostly follow), predictors of their own per child (they mostly
+    do not), orphans and strays, every subme level. The same lists of 16x16 PUs and 8x8 children (each PU on its own
+    there) must give the oracle's results as well."""
     e = _engine(request, depth)
     method = METHODS[mname]
     W, H = 320, 192
