@@ -32,6 +32,7 @@ W, H, MARGIN = 1920, 1080, 128
 QP, MERANGE, SUBME_DEFAULT = 32, 57, 5
 LA_QP, LA_MERANGE = 12, 16
 HBM_PEAK_GBS = 8000.0
+SIMDS = 1024            # 256 CUs x 4 SIMDs
 
 
 _T0 = time.perf_counter()
@@ -50,6 +51,96 @@ def host_threads(args):
     n = len(os.sched_getaffinity(0))
     env = os.environ.get("OMP_NUM_THREADS", "")
     return max(1, min(n, int(env))) if env.isdigit() else n
+
+
+def measured_encode(frames=30):
+    """BASELINE configs[0] encoded for real: the reference's own encoder + CLI (oracle/_ref/x265_served, compiled in the
+    build container from where the reference's sources lie) run twice on this box -- once with its motion estimation
+    answered by the engine through the C ABI (oracle/enc_serve.cpp: one x265amd_rk_ctu_batch per CTU, one
+    x265amd_lookahead_fields per lowres field, reference planes and lowres planes made on the device), once on the CPU
+    alone -- bitstream MD5 and the fps of the encoder's own summary line (x265.cpp:761) for both."""
+    import hashlib
+    import re
+    import subprocess
+    import tempfile
+    exe = os.path.join(ROOT, "oracle", "_ref", "x265_served")
+    if not os.path.exists(exe):
+        return {"value": None, "measured": False, "why": "oracle/_ref/x265_served was not built (needs the reference's sources)"}
+    from x265_amd.synth import baseline_clip, write_yuv420
+    recorded = "f2fe9f37c8c7e18d4f4610df4a25c48f"
+    out = {"unit": "fps", "measured": True,
+           "config": "416x240 synthetic 8-bit 4:2:0, %d frames, --preset medium --me hex --threads 1 (rd 6: the Rockchip "
+                     "CIME + RIME + FME overload per CU, lookahead HEX field per P-frame)" % frames,
+           "recorded_md5": recorded}
+    with tempfile.TemporaryDirectory() as tmp:
+        yuv = os.path.join(tmp, "c0.yuv")
+        write_yuv420(yuv, baseline_clip(416, 240, frames, 1234))
+        for mode in ("gpu", "cpu"):
+            progress("measured encode: %d frames, motion estimation on the %s" % (frames, "engine" if mode == "gpu" else "host"))
+            hevc, stats = os.path.join(tmp, mode + ".hevc"), os.path.join(tmp, mode + ".json")
+            env = dict(os.environ, X265AMD_SERVE_STATS=stats)
+            env.pop("X265AMD_SERVE", None)
+            if mode == "gpu":
+                env["X265AMD_SERVE"] = "gpu"
+            t0 = time.perf_counter()
+            p = subprocess.run([exe, "--input", yuv, "--input-res", "416x240", "--fps", "30", "-f", str(frames), "--preset", "medium",
+                                "--me", "hex", "--threads", "1", "--no-progress", "-o", hevc],
+                               env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
+            wall = time.perf_counter() - t0
+            m = re.search(r"encoded (\d+) frames in ([0-9.]+)s \(([0-9.]+) fps\)", p.stdout.decode(errors="replace"))
+            if p.returncode != 0 or not m:
+                return {"value": None, "measured": False, "why": "%s run failed (rc %d)" % (mode, p.returncode)}
+            st = json.load(open(stats))
+            md5 = hashlib.md5(open(hevc, "rb").read()).hexdigest()
+            out[mode] = {"fps": float(m.group(3)), "encoder_seconds": float(m.group(2)), "process_wall_seconds": wall,
+                         "bitstream_md5": md5, "md5_is_the_recorded_one": md5 == recorded,
+                         "seconds_inside_motionEstimate": st["rk_seconds"] + st["lookahead_seconds"],
+                         "seconds_uploading_planes": st["upload_seconds"],
+                         "motionEstimate_calls": st["rk_calls"] + st["lookahead_calls"], "calls_not_served": st["fallback_calls"],
+                         "engine_launches": {"rk_ctu": st["rk_ctu_launches"], "lookahead_field": st["lookahead_field_launches"]}}
+    out["value"] = out["gpu"]["fps"]
+    out["cpu_only_fps"] = out["cpu"]["fps"]
+    out["note"] = ("the encoder's mode decision needs a CTU's MVs before it derives the next CTU's predictors, so the engine is "
+                   "called once per CTU (85 CUs x 3 stages per launch) and synchronously: this measures dispatch latency, not "
+                   "throughput. What stays on the host is everything else of the encoder, including the hardware C-model's own "
+                   "re-computation of CIME / RIME / FME for its self-check (hardwareC.cpp:67-155), which dominates both runs")
+    return out
+
+
+
+def headline_roofline(vb, pus, launch_ms, alg_gbs, alg_bytes, traffic, compulsory, kernel):
+    """The roofline entry of the timed launch class. The bound that holds is VALU issue: `achieved` counts the ESSENTIAL
+    wave64 VALU instructions of the class's searches (profiles/valu.json says how they are counted) per second of the
+    launch, `peak` is what the chip's 1024 SIMDs issue at the measured shader clock (one wave64 VALU instruction per 4
+    cycles), so frac <= busy_frac <= 1 by construction; busy_frac is the same with the instructions the kernels really
+    issued (SQ counters). HBM is far from binding: `hbm` is the measured traffic of the launch (FETCH_SIZE doubled +
+    WRITE_SIZE, separate --pmc passes) over its duration; `hbm_per_job` keeps the per-job algorithmic byte formula, which
+    prices every PU's window as if no two PUs shared a byte and is therefore not traffic."""
+    launch_s = launch_ms * 1e-3
+    hbm = {"achieved": traffic / launch_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+           "frac": traffic / launch_s / 1e9 / HBM_PEAK_GBS, "bytes_per_launch": traffic} if traffic else None
+    per_job = {"algorithmic_gbs": alg_gbs, "algorithmic_bytes_per_launch": alg_bytes,
+               "formula": "per PU: source block + search window incl. 8-tap apron + result record, no reuse between PUs assumed; "
+                          "neighbouring PUs share their windows through L2, so this is not HBM traffic and may exceed the HBM peak"}
+    if vb is None:
+        # no instruction profile for this method / level: only the measured traffic can be priced
+        return {"bound": "hbm", "achieved": hbm["achieved"] if hbm else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": hbm["frac"] if hbm else None, "traffic": traffic, "kernel": kernel, "launch_ms": launch_ms,
+                "hbm_per_job": per_job, "compulsory": compulsory,
+                "note": "no VALU instruction profile for this method: HBM traffic of the star / subme-5 launch is reported as is"}
+    hz = vb["shader_clock_mhz"] * 1e6
+    peak = SIMDS * hz / 4
+    ess = vb["essential_wave_instr_per_pu"]["value"] * pus / launch_s
+    return {"bound": "valu", "achieved": ess / 1e9, "peak": peak / 1e9,
+            "unit": "G wave-instr/s (wave64 VALU instructions; a SIMD issues one per 4 cycles, %d SIMDs at the measured shader clock)" % SIMDS,
+            "frac": ess / peak, "busy_frac": vb["busy_frac"], "step_busy_frac": vb["step_busy_frac"],
+            "traffic": traffic, "kernel": kernel, "launch_ms": launch_ms,
+            "valu": vb, "hbm": hbm, "hbm_per_job": per_job, "compulsory": compulsory,
+            "note": "achieved = essential VALU wave instructions per PU x PUs of the launch / launch duration (HIP events on the "
+                    "launch's stream while the other classes run beside it); busy_frac = the instructions actually issued, same "
+                    "denominator; step_busy_frac = all kernels of a step over the step. The launch reads %s of HBM peak"
+                    % ("%.1f %%" % (100 * hbm["frac"]) if hbm else "an unmeasured share")}
+
 
 
 def valu_bound(profile, kernels, pus, launch_s, step_pairs=0, step_s=0.0, clock_mhz=None):
@@ -77,6 +168,25 @@ def valu_bound(profile, kernels, pus, launch_s, step_pairs=0, step_s=0.0, clock_
             "step_valu_wave_instr_per_frame_pair": all_valu,
             "essential_wave_instr_per_pu": profile["essential_wave_instr_per_pu"],
             "source": profile["source"]}
+
+
+def split_roofline(workload_name, value_gpx, alg_gbs, alg_bytes, world):
+    """Roofline entry of the split workloads (whole step: all launches + the gather, not one kernel). The exhaustive
+    search is bound by the issue rate of the byte-SAD instructions; the lookahead window by the dependency chain of its
+    wavefront (its HBM and VALU shares are both small), for which the HBM entry prices the compulsory bytes only."""
+    from x265_amd.measure import SAD_ISSUE_PEAK
+    per_job = {"algorithmic_gbs": alg_gbs, "algorithmic_bytes_per_step": alg_bytes,
+               "formula": "compulsory bytes with no reuse between units; not measured traffic"}
+    if workload_name == "esa4k":
+        peak = SAD_ISSUE_PEAK * world / 1e9
+        return {"bound": "valu", "achieved": value_gpx, "peak": peak, "unit": "Gpixel-SAD/s (v_sad_u8 / v_qsad_pk_u16_u8 issue rate)",
+                "frac": value_gpx / peak, "traffic": None, "hbm_per_job": per_job,
+                "note": "whole step (all launches + gather); 10^3 - 10^4 pixel-SADs per byte of window: HBM does not bind"}
+    return {"bound": "hbm", "achieved": alg_gbs, "peak": HBM_PEAK_GBS * world, "unit": "GB/s", "frac": alg_gbs / (HBM_PEAK_GBS * world),
+            "traffic": None, "hbm_per_job": per_job,
+            "note": "whole step; the launch is bound by the dependency chain of the lookahead wavefront (width + 2 x height CU "
+                    "searches per field), neither by HBM nor by VALU issue: achieved prices every plane of a field once"}
+
 
 
 def run_split_workload(args, torch, dist, dev, cdev, rank, local_rank, world):
@@ -193,15 +303,9 @@ def run_split_workload(args, torch, dist, dev, cdev, rank, local_rank, world):
                "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "strong",
                "vs_baseline": None, "dtype": "u8", "data": "synthetic",
                "config": {"workload": name, "parallelism": "units split over %d GPU(s), gather of MV records to rank 0" % world},
-               "roofline": {"bound": "hbm", "achieved": alg * args.steps / elapsed / 1e9, "peak": HBM_PEAK_GBS * world, "unit": "GB/s",
-                            "frac": alg * args.steps / elapsed / 1e9 / (HBM_PEAK_GBS * world), "traffic": None,
-                            "algorithmic_bytes_per_step": alg,
-                            "note": "whole step (all launches + gather), not one kernel; compulsory bytes with no reuse between units"},
+               "roofline": split_roofline(args.workload, value, alg * args.steps / elapsed / 1e9, alg, world),
                "cpu_baseline": {"value": cpu_px / cpu_s / 1e9, "unit": "Gpixel-SAD/s", "cores": 1, "kind": "port",
                                 "sample": sample + ", %.1f s; compared with the gathered GPU records" % cpu_s} if cpu_s else None}
-        if args.workload == "esa4k":
-            out["roofline"]["valu"] = {"bound": "v_sad_u8 / v_qsad_pk_u16_u8 issue", "peak_pixel_sads_per_s": SAD_ISSUE_PEAK * world,
-                                       "frac": value * 1e9 / (SAD_ISSUE_PEAK * world)}
         print(json.dumps(out))
     wl.close()
 
@@ -645,6 +749,7 @@ def main():
                             "run concurrently on two more streams)" % timed_cnt,
                   "single": "search_kernel<uint8_t,false>, one launch per frame (%d PUs)" % timed_cnt,
                   "per-size": "search_kernel<uint8_t,false>, average of the 4 per-size launches of a frame"}[args.launch]
+        vb = valu_bound(vprof, vprof["timed_kernels"], timed_cnt * B, launch_ms * 1e-3, B, elapsed / args.steps, clock_mhz) if vprof else None
         out = {
             "metric": "ME Gpixel-SAD/s", "value": value, "unit": "Gpixel-SAD/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
@@ -656,23 +761,10 @@ def main():
                        "qp": QP, "launch": args.launch,
                        "steps_synchronised": bool(sync_steps),
                        "parallelism": "frame pairs sharded over %d GPU(s), gather of MV records" % world},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": kernel, "launch_ms": launch_ms, "algorithmic_bytes_per_launch": alg_bytes,
-                         "valu": valu_bound(vprof, vprof["timed_kernels"], timed_cnt * B, launch_ms * 1e-3, B, elapsed / args.steps, clock_mhz) if vprof else None,
-                         "compulsory": compulsory,
-                         "note": "achieved prices every PU's source block and search window as if no two PUs shared a byte (the "
-                                 "per-job formula); neighbouring PUs share their windows through L2, so it is not HBM traffic and "
-                                 "can exceed the HBM peak -- `traffic` is what HBM served, `compulsory` prices each plane once, and "
-                                 "the launch is bound by VALU issue (see valu)"},
+            "roofline": headline_roofline(vb, timed_cnt * B, launch_ms, achieved, alg_bytes, traffic, compulsory, kernel),
             "cpu_baseline": cpu,
             "fps_equiv": B * args.steps * world / elapsed,
-            "encode_fps_equiv": {
-                "value": 1.0 / (25.1 * (1 - 0.67) + elapsed / (B * args.steps * world)), "unit": "fps", "derived": True,
-                "how": "NOT a measured encode. Amdahl estimate for a 1080p encode of the reference (survey container, "
-                       "--preset medium --threads 1: 0.04 fps = 25.1 s per frame, ME-related functions 67 % of CPU time) "
-                       "if its motion estimation were served at this step's rate (one frame pair's ME + lookahead field per "
-                       "frame) and the host share stayed as it is"},
+            "encode_fps": measured_encode() if not args.no_other_paths else None,
         }
         if not args.no_other_paths:
             # the two other search paths of the reference, measured the same way (HIP events, inputs resident);
