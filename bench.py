@@ -355,6 +355,9 @@ def main():
     ap.add_argument("--rehearse-one-gpu", action="store_true",
                     help="rehearsal of the N > 1 control flow on a box with one GPU: every rank uses cuda:0 and the "
                          "collectives go over gloo through host memory (RCCL wants one GPU per rank); not a measurement")
+    ap.add_argument("--only", default="",
+                    help="experiments only (the result is then no measurement of the workload): comma-separated launch classes "
+                         "of the multi-pair step to run, of 8, 16, 64 (32 with pairs4) and la; the others are left out")
     ap.add_argument("--no-clock-probe", action="store_true",
                     help="skip the three extra (untimed) steps during which the shader clock is measured: profiler passes, "
                          "whose per-kernel sums should hold the timed steps only")
@@ -513,13 +516,20 @@ def main():
             recv[name] = bufs
             pending.append((work, src))
 
+    only = set(args.only.split(",")) if args.only else None
+
     def step_multi(k=None, gather=True):
-        el.lookahead_fields_dev(d_fields, B, wcu, hcu, LA_QP, HEX, 1, LA_MERANGE,
-                                d_la_mvs.data_ptr(), d_la_costs.data_ptr())
+        if only is None or "la" in only:
+            el.lookahead_fields_dev(d_fields, B, wcu, hcu, LA_QP, HEX, 1, LA_MERANGE,
+                                    d_la_mvs.data_ptr(), d_la_costs.data_ptr())
         for c in reversed(range(len(segs))):       # the class with the longest waves first; the timed 8x8 class last
             (first, cnt, dim, eng) = segs[c]
             if c == 0 and k is not None:
                 ev0[k].record(s_search)
+            if only is not None and str(dim) not in only:
+                if c == 0 and k is not None:
+                    ev1[k].record(s_search)
+                continue
             eng.search_batch_pairs_dev(d_pairs, B, cls_jobs[c].data_ptr(), cls_jobs[c].shape[0], cls_res[c].data_ptr(),
                                        QP, method, SUBME, max_pu_dim=dim)
             if c == 0 and k is not None:
