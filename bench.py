@@ -27,6 +27,10 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+# The step runs four launch chains side by side, and every search context forks a second stream for the few PUs whose
+# searches run long: give the HIP runtime a hardware queue per stream (its default of 4 makes streams share queues, and
+# chains that share a queue run one after the other). Read when the runtime starts, so set before torch is imported.
+os.environ["GPU_MAX_HW_QUEUES"] = os.environ.get("X265AMD_BENCH_HW_QUEUES", "8")
 
 W, H, MARGIN = 1920, 1080, 128
 QP, MERANGE, SUBME_DEFAULT = 32, 57, 5
@@ -367,7 +371,7 @@ def main():
 
     import torch
     import torch.distributed as dist
-    from x265_amd.engine import Engine, METHODS, RESULT_DTYPE, HEX
+    from x265_amd.engine import Engine, METHODS, RESULT_DTYPE, HEX, SQUARE_ONLY
     from x265_amd.synth import make_clip, pad_plane, lowres_dims
     from x265_amd import workload, sharding
 
@@ -531,7 +535,7 @@ def main():
                     ev1[k].record(s_search)
                 continue
             eng.search_batch_pairs_dev(d_pairs, B, cls_jobs[c].data_ptr(), cls_jobs[c].shape[0], cls_res[c].data_ptr(),
-                                       QP, method, SUBME, max_pu_dim=dim)
+                                       QP, method, SUBME, max_pu_dim=dim | SQUARE_ONLY)      # every list holds squares only
             if c == 0 and k is not None:
                 ev1[k].record(s_search)
         if not sync_steps:

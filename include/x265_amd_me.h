@@ -129,11 +129,21 @@ int x265amd_search_batch(x265amd_ctx *ctx, const x265amd_plane *fenc, const x265
  * 10 bits) takes its 32x32 PUs through the fixed-shape kernels as well, and a 64x64 PU that is directly followed in the list by
  * its four 32x32 children (raster order, same pictures) refines them together with itself where all five start the sub-pel
  * rounds from one MV -- a quarter of the children's work; the list order changes no result.
- * Planes must be readable 32 bytes past their last sample (planes made by this library are). */
+ * Planes must be readable 32 bytes past their last sample (planes made by this library are).
+ * max_pu_dim | X265AMD_SQUARE_ONLY: the caller states that every PU of the list is a square of max_pu_dim samples (with
+ * 64: of 64 or 32 samples), which is what a list made per PU size for throughput holds. An X265_STAR_SEARCH launch then
+ * leaves out the pass that looks for PUs of other shapes in the list; such PUs, if the statement is false, are not
+ * searched and their result records are meaningless. x265amd_search_batch sees its host job array and sets this itself. */
+#define X265AMD_SQUARE_ONLY 0x100
 int x265amd_search_batch_dev(x265amd_ctx *ctx, const x265amd_plane *fenc, const x265amd_plane *ref, int is_lowres,
                              int qp, int method, int subme,
                              const x265amd_job *d_jobs, int njobs, x265amd_result *d_results, int max_pu_dim);
 int x265amd_sync(x265amd_ctx *ctx);
+/* Measurement aid, no counterpart in the reference: how many PUs of this context's last X265_STAR_SEARCH launch through the
+ * fixed-shape kernels did not end with their first three pattern rounds (StarPatternSearch, encoder/motion.cpp:307-547:
+ * a point improved, so larger distances, the two-point or raster refinement and re-centred patterns followed) or were of
+ * a shape those kernels do not take; 0 for any other launch. Waits for the engine's stream. */
+int x265amd_marked_count(x265amd_ctx *ctx, int *marked);
 
 /* The same searches over several (source, reference) pairs in ONE launch: job.reserved (0 .. npairs - 1) names the pair
  * a job searches. This is the shape of the caller's loops -- TEncSearch::predInterSearch runs motionEstimate for every

@@ -1,9 +1,9 @@
-# bench.py option variants on the headline step, alternating, three runs each: EXP_VARIANTS="opts1|opts2|..."
-set -e
-cd $GRAFT_REPO_ROOT
-IFS='|' read -ra V <<< "$EXP_VARIANTS"
-for i in 1 2 3; do
-  for o in "${V[@]}"; do
-    timeout -k 10 200 python bench.py --cpu-pairs 2 --ref-pairs 0 --no-other-paths --no-clock-probe $o | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('[$o]', round(d['value'],1), round(d['ms_per_step'],4))"
+# bench.py under several option sets (EXP_SETS: one set of options per '|'-separated field), two runs each
+cd "${GRAFT_REPO_ROOT:-/root/repo}"
+IFS='|' read -ra SETS <<< "$EXP_SETS"
+for rep in 1 2; do
+  for o in "${SETS[@]}"; do
+    r=$(timeout -k 10 200 python bench.py --cpu-pairs 0 --no-other-paths --no-clock-probe $o 2>/dev/null | python3 -c "import json,sys; d=json.loads(sys.stdin.read()); print('%.1f Gpx/s %.3f ms' % (d['value'], d['ms_per_step']))")
+    echo "[$o] $r"
   done
 done

@@ -10,7 +10,7 @@ for r in csv.DictReader(open(sys.argv[1])):
     k = re.sub(r"^void |x265amd::", "", r["Kernel_Name"])[:40]
     cnt[(k, int(r["Grid_Size"]))][r["Counter_Name"]] += float(r["Counter_Value"])
 tot = 0
-for (k, g), v in sorted(cnt.items(), key=lambda kv: -kv[1].get("SQ_INSTS_VALU", 0))[:14]:
+for (k, g), v in sorted(cnt.items(), key=lambda kv: -kv[1].get("SQ_INSTS_VALU", 0))[:22]:
     w = v["SQ_WAVES"]
     tot += v["SQ_INSTS_VALU"]
     print("%-42s grid %9d waves %7d  VALU %10.0f (%7.1f/wave) SALU %9.0f LDS %9.0f wavecyc/wave %8.0f wait/wave %8.0f" % (

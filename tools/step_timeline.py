@@ -13,6 +13,8 @@ if len(las) < 2:
 if len(las) < 2:
     las = [e for e in ev if "star_small_kernel<16" in e[2]]
 if len(las) < 2:
+    las = [e for e in ev if "star_big_kernel<64" in e[2]]
+if len(las) < 2:
     las = [e for e in ev if "search_kernel" in e[2] and e[3] > 1000000]
 t0, prev = las[-1][0], las[-2][0]
 print("step period %.3f ms" % ((t0 - prev) / 1e6))

@@ -28,7 +28,12 @@ __device__ __forceinline__ int xcd_remap(int bid, int n)
     return ((i / C) * 8 + x) * C + (i % C);
 }
 
-#define SMALL_REDO 0xFFFFFFFFu   /* sad_calls of a result record: star_small_kernel left this PU to the one-wave search */
+/* sad_calls of a result record while a launch is under way: the fixed-shape STAR kernels (star_small_kernel,
+ * star_big_kernel) left this PU to the one-wave search from the start (SMALL_REDO: not a size of theirs), or measured
+ * its start-up candidates and first three pattern rounds, found an improving point and left the rest of the integer
+ * search to star_resume_kernel (SMALL_RESUME: the state record of the PU says where it stands) */
+#define SMALL_REDO 0xFFFFFFFFu
+#define SMALL_RESUME 0xFFFFFFFEu
 
 /* one (source picture, reference picture) pair of a launch that searches several pairs at once */
 struct PairDev
@@ -57,6 +62,9 @@ struct SearchArgs
     int staged2;   /* 32 in a launch staged for 64: its 32x32 PUs stop there too and are refined with their parents where
                       the list has them behind one (refine_big_kernel<64>), by refine_big_kernel<32> otherwise; else 0 */
     unsigned char *done;   /* null, or per job: refined already (set by refine_big_kernel<64> for the children it took along) */
+    int *state;            /* per job 8 ints: where a STAR search stands that a fixed-shape kernel began (StarFold::store) */
+    unsigned char *mark;   /* null, or per job: 1 = a STAR kernel handed this PU on (it is in the redo list), 0 = it did not */
+    int list;              /* refinement kernels: 1 = refine the PUs of the redo list instead of those of the job list */
 };
 
 /* the planes job `job` searches: the launch's own, or its entry of the launch's pair table. Device-resident jobs
@@ -98,7 +106,7 @@ __global__ __launch_bounds__(256) void redo_list_kernel(const x265amd_result *re
     for (int k = 0; k < REDO_CHUNK / 256; k++)
     {
         const int j = base + k * 256 + (int)threadIdx.x;
-        m[k] = j < njobs && results[j].sad_calls == SMALL_REDO;
+        m[k] = j < njobs && results[j].sad_calls >= SMALL_RESUME;
         bal[k] = __ballot(m[k]);
         if (lane == 0) part[k * 4 + wave] = __popcll(bal[k]);
     }
@@ -118,12 +126,16 @@ __global__ __launch_bounds__(256) void redo_list_kernel(const x265amd_result *re
 template<typename P, bool LOWRES>
 __global__ __launch_bounds__(64) void search_kernel(SearchArgs a)
 {
-    /* one PU per wave: the PU of this workgroup, or every gridDim.x-th entry of the redo list */
+    /* one PU per wave at a time: every gridDim.x-th job of the launch, or of the redo list (there only the PUs left
+     * to this kernel from the start; star_resume_kernel takes the others). The waves of this kernel call functions
+     * and so carry a stack, which makes them slow to launch (tens of nanoseconds each): a grid of a few thousand
+     * waves that walk the jobs costs less than a wave per job. */
     const int total = a.redo ? uni(a.redo[0]) : a.njobs;
-    for (int k = blockIdx.x; k < total; k += a.redo ? (int)gridDim.x : total)
+    for (int k = blockIdx.x; k < total; k += (int)gridDim.x)
     {
         const int j = a.redo ? uni(a.redo[REDO_LIST + k]) : xcd_remap(k, a.njobs);
         if (j >= a.njobs) return;
+        if (a.redo && uni((int)a.results[j].sad_calls) != (int)SMALL_REDO) continue;
         const x265amd_job *job = a.jobs + j;
         Searcher<P, LOWRES ? 8 : 64, LOWRES> S;
         const int w = job->w, h = job->h;
@@ -149,6 +161,28 @@ __global__ __launch_bounds__(64) void search_kernel(SearchArgs a)
 #include "me_esa.h"   /* esa_scan_kernel, esa_finish_kernel: use SearchArgs and xcd_remap */
 #include "me_small.h"   /* star_small_kernel, refine_small_kernel: 8x8 / 16x16 PUs in fixed-shape kernels, four / one per wave */
 #include "me_lookahead_cost.h"
+
+/* The rest of the STAR searches a fixed-shape kernel began and could not end (SMALL_RESUME): later pattern rounds,
+ * the two-point and raster refinements, the re-centred patterns (motion.cpp:916-1017) -- full-pel SADs only, one PU
+ * per wave at a time from the redo list. The evaluations are inlined (Searcher LEAN): no calls, no stack, so the
+ * waves of a launch that finds nothing to do cost next to nothing. Leaves the PU's record as search_staged does. */
+template<typename P>
+__global__ __launch_bounds__(64) void star_resume_kernel(SearchArgs a)
+{
+    const int total = uni(a.redo[0]);
+    for (int k = blockIdx.x; k < total; k += (int)gridDim.x)
+    {
+        const int j = uni(a.redo[REDO_LIST + k]);
+        if (j >= a.njobs) return;
+        if (uni((int)a.results[j].sad_calls) != (int)SMALL_RESUME) continue;
+        const x265amd_job *job = a.jobs + j;
+        Searcher<P, 64, false, false, true> S;
+        PlaneDev fenc, ref[4];
+        job_planes(a, job, fenc, ref);
+        S.bind(0, fenc, ref, 1, a.ctab, a.depth, job->pu_x, job->pu_y, job->w, job->h, a.max_dim, 0);
+        S.resume_star(job, a.state + 8 * (long)j, a.results + j);
+    }
+}
 
 /* Lookahead: one workgroup per lowres field, LA_WAVES waves walking the reverse-raster
  * dependency wavefront. CU (x, y) needs the final MVs of (x+1, y) and of
@@ -815,6 +849,11 @@ struct x265amd_ctx
     long long *d_probe;                /* the probe wave's two counters (a buffer of its own: other calls may run meanwhile) */
     void *d_done; size_t done_cap;     /* per job of a launch: refined with its parent (refine_big_kernel<64>) */
     void *d_redo; size_t redo_cap;     /* list of the PUs a fixed-shape kernel left to the one-wave search (redo_list_kernel) */
+    void *d_state; size_t state_cap;   /* per job of a launch: where the STAR search of a marked PU stands (StarFold::store) */
+    void *d_mark; size_t mark_cap;     /* per job of a launch: handed on by the STAR kernels */
+    hipStream_t aux;                   /* second stream of STAR launches: the marked PUs' searches run beside the others' refinement */
+    hipEvent_t ev_fork, ev_join;
+    bool redo_valid;                   /* d_redo[0] holds the marked-PU count of this context's last search launch */
     int32_t *d_out;
     int *d_ticket;                     /* row hand-out counter of the row-parallel lookahead kernel */
     int esa_window_bytes;              /* LDS the exhaustive search may use per PU for its window; 0 = the library's choice */
@@ -900,49 +939,104 @@ static int launch_esa(x265amd_ctx *c, const SearchArgs &a, int window_bytes, int
     return X265AMD_OK;
 }
 
+/* the sub-pel refinement of the launch's fixed-shape sizes: every PU of the job list (list_grid == 0), or the PUs of the
+ * redo list, walked by list_grid workgroups */
 template<typename P>
-static int launch_search(x265amd_ctx *c, const SearchArgs &a, int is_lowres)
+static void launch_refine(const SearchArgs &b, hipStream_t st, int list_grid)
 {
+    const int n = b.njobs;
+    if (b.staged == 8)
+        hipLaunchKernelGGL((refine_small_kernel<8, P>), dim3(list_grid ? list_grid : (n + 3) / 4), dim3(64), RefineLds<8>::TOTAL, st, b);
+    else if (b.staged == 16)
+        hipLaunchKernelGGL((refine_small_kernel<16, P>), dim3(list_grid ? list_grid : (n + RefineGeo<16>::NPU - 1) / RefineGeo<16>::NPU), dim3(64),
+                           RefineLds<16>::TOTAL, st, b);
+    else if (b.staged == 32)
+        hipLaunchKernelGGL((refine_big_kernel<32, P>), dim3(list_grid ? list_grid : n), dim3(BigGeo<32>::THREADS), BigLds<32>::TOTAL, st, b);
+    else if (b.staged == 64)
+    {
+        hipLaunchKernelGGL((refine_big_kernel<64, P>), dim3(list_grid ? list_grid : n), dim3(BigGeo<64>::THREADS), BigLds<64>::TOTAL, st, b);
+        if (b.staged2)      /* the 32x32 PUs their parents did not take along */
+            hipLaunchKernelGGL((refine_big_kernel<32, P>), dim3(list_grid ? list_grid : n), dim3(BigGeo<32>::THREADS), BigLds<32>::TOTAL, st, b);
+    }
+}
+
+/* waves of a launch of search_kernel: a wave per PU up to this many, then every wave walks the list */
+#define SEARCH_GRID 8192
+
+template<typename P>
+static int launch_search(x265amd_ctx *c, const SearchArgs &a, int is_lowres, bool square_only)
+{
+    c->redo_valid = false;
     if (is_lowres)
-        hipLaunchKernelGGL((search_kernel<P, true>), dim3(a.njobs), dim3(64), wave_lds_bytes<P>(8), c->stream, a);
+        hipLaunchKernelGGL((search_kernel<P, true>), dim3(a.njobs < SEARCH_GRID ? a.njobs : SEARCH_GRID), dim3(64), wave_lds_bytes<P>(8), c->stream, a);
     else
     {
         static const int pad = getenv("X265AMD_LDS_PAD") ? atoi(getenv("X265AMD_LDS_PAD")) : 0;   /* occupancy experiments */
-        /* launches of 8-bit PUs up to 8x8: the 8x8 ones are refined by a second kernel, four PUs per wave */
         static const bool no_staged = getenv("X265AMD_NO_STAGED") != 0;                            /* measurements only */
         static const bool no_star = getenv("X265AMD_NO_STAR8") != 0;
+        static const bool no_big = getenv("X265AMD_NO_STAGED_BIG") != 0;
+        static const bool no_star_big = getenv("X265AMD_NO_STAR_BIG") != 0;
         SearchArgs b = a;
-        /* launches of 8-bit PUs up to 8x8, 16x16, 32x32 or 64x64: the square PUs of that size are refined by a second
-         * kernel (four 8x8 PUs or two 16x16 PUs per wave; two waves per 32x32 PU, four per 64x64 PU) */
-        static const bool no_big = getenv("X265AMD_NO_STAGED_BIG") != 0;                             /* measurements only */
+        /* launches of PUs up to 8x8, 16x16, 32x32 or 64x64 (samples of at most 10 bits): the square PUs of that size are
+         * refined by a second kernel (four 8x8 PUs or two 16x16 PUs per wave; two waves per 32x32 PU, four per 64x64 PU) */
         b.staged = (sizeof(P) == 1 || c->depth <= 10) && !no_staged &&
                    (a.max_dim == 8 || a.max_dim == 16 || ((a.max_dim == 32 || a.max_dim == 64) && !no_big)) ? a.max_dim : 0;
         if (b.staged == 64 && !getenv("X265AMD_NO_QUAD"))
         {
-            /* a launch for 64x64 PUs refines the 32x32 PUs of its list in the fixed-shape kernels as well: together
-             * with their parent where the list has the four children right behind it, on their own otherwise */
+            /* a launch for 64x64 PUs takes the 32x32 PUs of its list through the fixed-shape kernels as well; they are
+             * refined together with their parent where the list has the four children right behind it */
             if (ensure(c, &c->d_done, &c->done_cap, (size_t)a.njobs)) return X265AMD_EHIP;
             HIPCHK(c, hipMemsetAsync(c->d_done, 0, (size_t)a.njobs, c->stream));
             b.staged2 = 32;
             b.done = (unsigned char*)c->d_done;
         }
-        const int npu = b.staged == 8 ? 4 : 1, groups = (a.njobs + npu - 1) / npu;      /* star_small_kernel's PUs per wave */
-        const int rgroups = (a.njobs + 3) / 4;                                              /* refine_small_kernel's */
-        if (b.staged && b.staged <= 16 && a.method == X265AMD_STAR && !no_star)
+        const int grid = a.njobs < SEARCH_GRID ? a.njobs : SEARCH_GRID;
+        const bool star = b.staged && a.method == X265AMD_STAR && !no_star && (b.staged <= 16 || !no_star_big);
+        if (star)
         {
+            /* STAR: start-up candidates and the first three pattern rounds of every PU in fixed-shape kernels. Most PUs
+             * end there; the others are listed, star_resume_kernel takes their searches to the end, and the PUs that are
+             * no fixed-shape kernel's (other shapes in the list) go through the one-wave search from the start. */
             if (ensure(c, &c->d_redo, &c->redo_cap, sizeof(int) * ((size_t)REDO_LIST + a.njobs))) return X265AMD_EHIP;
-            const int blocks = (a.njobs + REDO_CHUNK - 1) / REDO_CHUNK;
-            /* STAR: the common case (start point stands after three star rounds) in a fixed-shape kernel, which marks the
-             * records of the PUs it leaves to the one-wave search */
+            if (ensure(c, &c->d_state, &c->state_cap, 32 * (size_t)a.njobs)) return X265AMD_EHIP;
+            if (ensure(c, &c->d_mark, &c->mark_cap, (size_t)a.njobs)) return X265AMD_EHIP;
             b.redo = (int*)c->d_redo;
+            b.state = (int*)c->d_state;
+            b.mark = (unsigned char*)c->d_mark;
             if (b.staged == 8)
-                hipLaunchKernelGGL((star_small_kernel<8, P>), dim3(groups), dim3(64), StarLds<8>::TOTAL, c->stream, b);
+                hipLaunchKernelGGL((star_small_kernel<8, P>), dim3((a.njobs + 3) / 4), dim3(64), StarLds<8>::TOTAL, c->stream, b);
+            else if (b.staged == 16)
+                hipLaunchKernelGGL((star_small_kernel<16, P>), dim3(a.njobs), dim3(64), StarLds<16>::TOTAL, c->stream, b);
             else
-                hipLaunchKernelGGL((star_small_kernel<16, P>), dim3(groups), dim3(64), StarLds<16>::TOTAL, c->stream, b);
-            hipLaunchKernelGGL(redo_list_kernel, dim3(blocks), dim3(256), 0, c->stream, a.results, a.njobs, (int*)c->d_redo);
-            hipLaunchKernelGGL((search_kernel<P, false>), dim3(a.njobs < REDO_GRID ? a.njobs : REDO_GRID), dim3(64),
-                               wave_lds_bytes<P>(a.max_dim, true) + pad, c->stream, b);
-            b.redo = 0;
+            {
+                HIPCHK(c, hipMemsetAsync(c->d_redo, 0, sizeof(int), c->stream));
+                if (b.staged == 64)
+                    hipLaunchKernelGGL((star_big_kernel<64, P>), dim3(a.njobs), dim3(StarBigGeo<64>::THREADS), StarBigLds<64>::TOTAL, c->stream, b);
+                if (b.staged == 32 || b.staged2 == 32)
+                    hipLaunchKernelGGL((star_big_kernel<32, P>), dim3(a.njobs), dim3(StarBigGeo<32>::THREADS), StarBigLds<32>::TOTAL, c->stream, b);
+            }
+            /* The PUs handed on are few as a rule and each a long chain of dependent steps in one wave: their
+             * searches and refinement run on the context's second stream while this one refines all the others. */
+            static const bool no_fork = getenv("X265AMD_NO_FORK") != 0;                              /* measurements only */
+            hipStream_t side = no_fork ? c->stream : c->aux;
+            if (!no_fork)
+            {
+                HIPCHK(c, hipEventRecord(c->ev_fork, c->stream));
+                HIPCHK(c, hipStreamWaitEvent(c->aux, c->ev_fork, 0));
+            }
+            const int blocks = (a.njobs + REDO_CHUNK - 1) / REDO_CHUNK, lgrid = a.njobs < REDO_GRID ? a.njobs : REDO_GRID;
+            hipLaunchKernelGGL(redo_list_kernel, dim3(blocks), dim3(256), 0, side, a.results, a.njobs, (int*)c->d_redo);
+            hipLaunchKernelGGL((star_resume_kernel<P>), dim3(lgrid), dim3(64), wave_lds_bytes<P>(a.max_dim), side, b);
+            /* a caller that states its list holds only the squares these kernels take saves the launch that looks for others */
+            if (!square_only)
+                hipLaunchKernelGGL((search_kernel<P, false>), dim3(lgrid), dim3(64), wave_lds_bytes<P>(a.max_dim, true) + pad, side, b);
+            SearchArgs l = b;
+            l.list = 1;
+            launch_refine<P>(l, side, lgrid);
+            if (!no_fork) HIPCHK(c, hipEventRecord(c->ev_join, c->aux));
+            launch_refine<P>(b, c->stream, 0);
+            if (!no_fork) HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_join, 0));
+            c->redo_valid = true;
         }
         else
         {
@@ -955,19 +1049,8 @@ static int launch_search(x265amd_ctx *c, const SearchArgs &a, int is_lowres)
                 b.plane_lds = plane_budget(a.max_dim, (int)sizeof(P)) / 2;
                 lds -= b.plane_lds;
             }
-            hipLaunchKernelGGL((search_kernel<P, false>), dim3(a.njobs), dim3(64), lds + pad, c->stream, b);
-        }
-        if (b.staged == 8)
-            hipLaunchKernelGGL((refine_small_kernel<8, P>), dim3(rgroups), dim3(64), RefineLds<8>::TOTAL, c->stream, b);
-        else if (b.staged == 16)
-            hipLaunchKernelGGL((refine_small_kernel<16, P>), dim3((a.njobs + RefineGeo<16>::NPU - 1) / RefineGeo<16>::NPU), dim3(64), RefineLds<16>::TOTAL, c->stream, b);
-        else if (b.staged == 32)
-            hipLaunchKernelGGL((refine_big_kernel<32, P>), dim3(a.njobs), dim3(BigGeo<32>::THREADS), BigLds<32>::TOTAL, c->stream, b);
-        else if (b.staged == 64)
-        {
-            hipLaunchKernelGGL((refine_big_kernel<64, P>), dim3(a.njobs), dim3(BigGeo<64>::THREADS), BigLds<64>::TOTAL, c->stream, b);
-            if (b.staged2)      /* the 32x32 PUs their parents did not take along */
-                hipLaunchKernelGGL((refine_big_kernel<32, P>), dim3(a.njobs), dim3(BigGeo<32>::THREADS), BigLds<32>::TOTAL, c->stream, b);
+            hipLaunchKernelGGL((search_kernel<P, false>), dim3(grid), dim3(64), lds + pad, c->stream, b);
+            launch_refine<P>(b, c->stream, 0);
         }
     }
     HIPCHK(c, hipGetLastError());
@@ -1065,16 +1148,23 @@ static int create_ctx(int device, int bit_depth, int high_priority, x265amd_ctx 
     if (hipGetDeviceCount(&n) != hipSuccess || device < 0 || device >= n) return X265AMD_EHIP;
     x265amd_ctx *c = new x265amd_ctx();
     c->device = device; c->depth = bit_depth;
-    c->d_done = 0; c->done_cap = 0;
+    c->d_done = 0; c->done_cap = 0; c->d_state = 0; c->state_cap = 0; c->redo_valid = false; c->d_mark = 0; c->mark_cap = 0;
     c->d_jobs = c->d_results = c->d_stage = c->d_redo = 0; c->d_ticket = 0; c->d_probe = 0;
     c->jobs_cap = c->results_cap = c->stage_cap = c->redo_cap = 0; c->d_out = 0;
     c->esa_window_bytes = 0;
     c->probe_khz = 0;
     c->esa_lds_raised = c->rime_lds_raised = false;
     int prio_least = 0, prio_greatest = 0;
-    if (hipSetDevice(device) != hipSuccess || hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest) != hipSuccess ||
-        hipStreamCreateWithPriority(&c->stream, hipStreamDefault, high_priority > 0 ? prio_greatest : high_priority < 0 ? prio_least
-                                    : prio_least + (prio_greatest - prio_least) / 2) != hipSuccess ||
+    if (hipSetDevice(device) != hipSuccess || hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest) != hipSuccess)
+    {
+        delete c;
+        return X265AMD_EHIP;
+    }
+    const int prio = high_priority > 0 ? prio_greatest : high_priority < 0 ? prio_least : prio_least + (prio_greatest - prio_least) / 2;
+    if (hipStreamCreateWithPriority(&c->stream, hipStreamDefault, prio) != hipSuccess ||
+        hipStreamCreateWithPriority(&c->aux, hipStreamNonBlocking, prio) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) != hipSuccess ||
         hipMalloc((void**)&c->d_out, 64) != hipSuccess || hipMalloc((void**)&c->d_ticket, 256) != hipSuccess)
     {
         delete c;
@@ -1089,7 +1179,8 @@ static int create_ctx(int device, int bit_depth, int high_priority, x265amd_ctx 
             void *ptr = 0;
             if (hipGetSymbolAddress(&ptr, HIP_SYMBOL(scratch)) != hipSuccess || !ptr)
             {
-                (void)hipFree(c->d_out); (void)hipFree(c->d_ticket); (void)hipStreamDestroy(c->stream);
+                (void)hipFree(c->d_out); (void)hipFree(c->d_ticket); (void)hipStreamDestroy(c->stream); (void)hipStreamDestroy(c->aux);
+                (void)hipEventDestroy(c->ev_fork); (void)hipEventDestroy(c->ev_join);
                 delete c;
                 return X265AMD_EHIP;
             }
@@ -1113,6 +1204,12 @@ void x265amd_destroy(x265amd_ctx *c)
     if (c->d_stage) (void)hipFree(c->d_stage);
     if (c->d_redo) (void)hipFree(c->d_redo);
     if (c->d_done) (void)hipFree(c->d_done);
+    if (c->d_state) (void)hipFree(c->d_state);
+    if (c->d_mark) (void)hipFree(c->d_mark);
+    (void)hipStreamSynchronize(c->aux);
+    (void)hipStreamDestroy(c->aux);
+    (void)hipEventDestroy(c->ev_fork);
+    (void)hipEventDestroy(c->ev_join);
     if (c->d_probe) (void)hipFree(c->d_probe);
     if (c->d_out) (void)hipFree(c->d_out);
     if (c->d_ticket) (void)hipFree(c->d_ticket);
@@ -1376,7 +1473,7 @@ static void fill_args(x265amd_ctx *c, SearchArgs &a, const x265amd_plane *fenc, 
         a.ref[i].origin = r->origin; a.ref[i].stride = r->stride;
     }
     a.lowres = is_lowres; a.depth = c->depth; a.method = method; a.subme = subme; a.max_dim = is_lowres ? 8 : 64;
-    a.staged = 0; a.staged2 = 0; a.done = 0; a.redo = 0; a.pairs = 0; a.npairs = 0; a.plane_lds = 0;
+    a.staged = 0; a.staged2 = 0; a.done = 0; a.redo = 0; a.pairs = 0; a.npairs = 0; a.plane_lds = 0; a.state = 0; a.mark = 0; a.list = 0;
     a.ctab = c->tables[qp] + 32768;
 }
 
@@ -1406,9 +1503,11 @@ static int search_dev(x265amd_ctx *c, const x265amd_plane *fenc, const x265amd_p
     if (!c || !d_jobs || !d_results || njobs < 0 || (!d_pairs && (!fenc || !ref))) return fail(c, X265AMD_EINVAL, "null argument");
     if (method < 0 || method > X265AMD_FULL || subme < 0 || subme > 7)
         return fail(c, X265AMD_EINVAL, "bad method / subme");
+    const bool square_only = (max_pu_dim & X265AMD_SQUARE_ONLY) != 0;
+    max_pu_dim &= ~X265AMD_SQUARE_ONLY;
     if (max_pu_dim == 0) max_pu_dim = 64;
     if (!(max_pu_dim == 8 || max_pu_dim == 16 || max_pu_dim == 32 || max_pu_dim == 64))
-        return fail(c, X265AMD_EINVAL, "max_pu_dim must be 0, 8, 16, 32 or 64");
+        return fail(c, X265AMD_EINVAL, "max_pu_dim must be 0, 8, 16, 32 or 64 (+ X265AMD_SQUARE_ONLY)");
     int rc = x265amd_set_qp(c, qp);
     if (rc) return rc;
     if (!njobs) return X265AMD_OK;
@@ -1423,15 +1522,16 @@ static int search_dev(x265amd_ctx *c, const x265amd_plane *fenc, const x265amd_p
     if (method == X265AMD_FULL && !is_lowres)
         return c->depth <= 8 ? launch_esa<uint8_t>(c, a, esa_window, c->table_nowrap[qp])
                              : launch_esa<uint16_t>(c, a, esa_window, c->table_nowrap[qp]);
-    return c->depth <= 8 ? launch_search<uint8_t>(c, a, is_lowres) : launch_search<uint16_t>(c, a, is_lowres);
+    return c->depth <= 8 ? launch_search<uint8_t>(c, a, is_lowres, square_only) : launch_search<uint16_t>(c, a, is_lowres, square_only);
 }
 
 int x265amd_search_batch_dev(x265amd_ctx *c, const x265amd_plane *fenc, const x265amd_plane *ref, int is_lowres,
                              int qp, int method, int subme, const x265amd_job *d_jobs, int njobs, x265amd_result *d_results,
                              int max_pu_dim)
 {
+    const int dim = max_pu_dim & ~X265AMD_SQUARE_ONLY;
     return search_dev(c, fenc, ref, is_lowres, qp, method, subme, d_jobs, njobs, d_results, max_pu_dim,
-                      c ? esa_window_for(c, max_pu_dim > 0 ? max_pu_dim : 64) : 0);
+                      c ? esa_window_for(c, dim > 0 ? dim : 64) : 0);
 }
 
 /* ---- searches over several (source, reference) pairs in one launch ---- */
@@ -1465,7 +1565,8 @@ int x265amd_search_batch_pairs_dev(x265amd_ctx *c, const void *d_pairs, int npai
                                    const x265amd_job *d_jobs, int njobs, x265amd_result *d_results, int max_pu_dim)
 {
     if (!c || !d_pairs || npairs <= 0 || npairs > 256) return fail(c, X265AMD_EINVAL, "1 .. 256 pairs");
-    return search_dev(c, 0, 0, 0, qp, method, subme, d_jobs, njobs, d_results, max_pu_dim, esa_window_for(c, max_pu_dim > 0 ? max_pu_dim : 64),
+    const int dim = max_pu_dim & ~X265AMD_SQUARE_ONLY;
+    return search_dev(c, 0, 0, 0, qp, method, subme, d_jobs, njobs, d_results, max_pu_dim, esa_window_for(c, dim > 0 ? dim : 64),
                       (const PairDev*)d_pairs, npairs);
 }
 
@@ -1564,6 +1665,17 @@ int x265amd_sync(x265amd_ctx *c)
     return X265AMD_OK;
 }
 
+int x265amd_marked_count(x265amd_ctx *c, int *marked)
+{
+    if (!c || !marked) return fail(c, X265AMD_EINVAL, "null argument");
+    *marked = 0;
+    if (!c->redo_valid) return X265AMD_OK;
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipMemcpy(marked, c->d_redo, sizeof(int), hipMemcpyDeviceToHost));
+    return X265AMD_OK;
+}
+
 int x265amd_search_batch(x265amd_ctx *c, const x265amd_plane *fenc, const x265amd_plane *ref, int is_lowres,
                          int qp, int method, int subme, const x265amd_job *jobs, int njobs, x265amd_result *results)
 {
@@ -1582,6 +1694,10 @@ int x265amd_search_batch(x265amd_ctx *c, const x265amd_plane *fenc, const x265am
         const int d = jobs[i].w > jobs[i].h ? jobs[i].w : jobs[i].h;
         while (dim < d) dim <<= 1;
     }
+    /* does the list hold only what the fixed-shape kernels take (squares of the largest size; with 64 also of 32)? */
+    bool squares = true;
+    for (int i = 0; i < njobs && squares; i++)
+        squares = jobs[i].w == jobs[i].h && (jobs[i].w == dim || (dim == 64 && jobs[i].w == 32));
     /* exhaustive search: no more window LDS than the largest range of the batch needs */
     int window = c->depth <= 8 ? ESA_WINDOW_MIN : 2 * ESA_WINDOW_MIN;
     if (method == X265AMD_FULL)
@@ -1594,7 +1710,7 @@ int x265amd_search_batch(x265amd_ctx *c, const x265amd_plane *fenc, const x265am
             if (need > window) window = need > esa_window_for(c, dim) ? esa_window_for(c, dim) : (int)((need + 15) & ~15);
         }
     rc = search_dev(c, fenc, ref, is_lowres, qp, method, subme, (const x265amd_job*)c->d_jobs, njobs,
-                    (x265amd_result*)c->d_results, dim, window);
+                    (x265amd_result*)c->d_results, dim | (squares ? X265AMD_SQUARE_ONLY : 0), window);
     if (rc) return rc;
     HIPCHK(c, hipMemcpyAsync(results, c->d_results, (size_t)njobs * sizeof(x265amd_result), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));

@@ -186,7 +186,9 @@ template<int N> constexpr unsigned long long nibs(const int (&v)[N])
 }
 __device__ __forceinline__ int nib(unsigned long long t, int i) { return (int)((t >> (4 * i)) & 15) - 4; }
 
-/* lambda * bits term of candidate `lane` (0 for lanes that have none) */
+/* lambda * bits term of candidate `lane` (0 for lanes that have none). PLAIN: full-pel candidates of the classic
+ * searches only (no Rockchip predictors, no UMH grid flavour), for kernels that carry nothing else */
+template<bool PLAIN = false>
 __device__ __forceinline__ int gather_mvcost(int base, int K, int mode, int addmv)
 {
     const int lane = threadIdx.x & 63;
@@ -200,7 +202,7 @@ __device__ __forceinline__ int gather_mvcost(int base, int K, int mode, int addm
         const int mvpx = uni(cx->mvpx), mvpy = uni(cx->mvpy);
         const int s = lds_i(base, L_SH)[lane];
         const int mx = lds_i(base, L_MVX)[lane], my = lds_i(base, L_MVY)[lane];
-        if (s & 16)
+        if (!PLAIN && (s & 16))
         {
             /* Rockchip stages: min over three predictors, each sum truncated to uint16
              * (motion.cpp:1284-1292) */
@@ -215,13 +217,13 @@ __device__ __forceinline__ int gather_mvcost(int base, int K, int mode, int addm
                 }
             }
         }
-        else if (s & 8)
+        else if (!PLAIN && (s & 8))
             /* UMH hexagon grid: table entries added as ints, MV * 4 without the int16 wrap
              * (ADD_MVCOST, motion.cpp:856) */
             mvc = (int)ctab[mx * 4 - mvpx] + (int)ctab[my * 4 - mvpy];
         else
             /* bitcost.h:46 -- the sum is truncated to uint16 */
-            mvc = ((int)ctab[as_i16(mx << s) - mvpx] + (int)ctab[as_i16(my << s) - mvpy]) & 0xffff;
+            mvc = ((int)ctab[as_i16(mx << (s & 7)) - mvpx] + (int)ctab[as_i16(my << (s & 7)) - mvpy]) & 0xffff;
     }
     return mvc;
 }
@@ -310,9 +312,11 @@ __device__ __forceinline__ int tile_cost(int base, const Geo &c, int k, int t, i
 /* costs[k] = distortion(k) [+ mvcost(mv[k] << sh[k])] for k < K, every (candidate, tile) pair
  * measured independently by one lane. Serves all full-pel batches, and the sub-pel batches
  * of the lookahead (half-pel planes) and Rockchip (4-tap) flavours. */
-template<typename P, bool LOWRES, bool RK>
-__device__ __noinline__ void eval_batch(int base, int K, int mode, int addmv)
+template<typename P, bool LOWRES, bool RK, bool FULLPEL>
+__device__ __forceinline__ void eval_batch_body(int base, int K, int mode_, int addmv)
 {
+    /* FULLPEL: the caller only ever measures full-pel SADs (mode 0); everything else compiles out */
+    const int mode = FULLPEL ? 0 : mode_;
     wave_sync();
     Geo c;
     c.load<LOWRES>(base);
@@ -320,7 +324,7 @@ __device__ __noinline__ void eval_batch(int base, int K, int mode, int addmv)
     /* the lambda * bits term of candidate `lane` is gathered first so that its table loads
      * overlap the distortion work */
     const bool mixed = mode < 0;
-    const int mvc = gather_mvcost(base, K, mode, addmv);
+    const int mvc = gather_mvcost<FULLPEL>(base, K, mode, addmv);
     if (c.Tp <= 64)
     {
         const int g = lane >> c.lTp, t = lane & (c.Tp - 1);
@@ -360,7 +364,7 @@ __device__ __noinline__ void eval_batch(int base, int K, int mode, int addmv)
                 }
             }
         }
-        else
+        else if constexpr (!FULLPEL)
             for (int k0 = 0; k0 < K; k0 += cpp)
             {
                 const int k = k0 + g;
@@ -414,7 +418,7 @@ __device__ __noinline__ void eval_batch(int base, int K, int mode, int addmv)
             if (lane == 0) lds_i(base, L_COSTS)[k] = v;
         }
     }
-    else
+    else if constexpr (!FULLPEL)
     {
         for (int k = 0; k < K; k++)
         {
@@ -429,6 +433,8 @@ __device__ __noinline__ void eval_batch(int base, int K, int mode, int addmv)
     if (lane < K) lds_i(base, L_COSTS)[lane] += mvc;
     wave_sync();
 }
+template<typename P, bool LOWRES, bool RK>
+__device__ __noinline__ void eval_batch(int base, int K, int mode, int addmv) { eval_batch_body<P, LOWRES, RK, false>(base, K, mode, addmv); }
 
 /* ---- sub-pel batches of the classic path: separable interpolation through LDS planes ----
  *
@@ -913,7 +919,10 @@ struct SearchState
 
 /* LOWRES selects the lookahead flavour at compile time (half-pel planes instead of
  * interpolation), which keeps the 8-tap code out of the lookahead kernel. */
-template<typename P, int ROWS = 64, bool LOWRES = false, bool RK = false>
+/* LEAN: a searcher that only ever measures full-pel SADs (the continuation of a STAR search whose start-up a
+ * fixed-shape kernel has done, and whose refinement another will do): its evaluations are inlined, so the kernel
+ * makes no calls and needs no stack. */
+template<typename P, int ROWS = 64, bool LOWRES = false, bool RK = false, bool LEAN = false>
 struct Searcher
 {
     int base;           /* byte offset of this wave's LDS block */
@@ -923,6 +932,7 @@ struct Searcher
 
     __device__ __forceinline__ void eval(int K, int mode, bool addmv)
     {
+        if constexpr (LEAN) { eval_batch_body<P, false, false, true>(base, K, 0, 1); nsad += K; return; }
         /* sub-pel (and mixed) batches of the classic path interpolate through LDS planes */
         if (!LOWRES && !RK && mode != 0) eval_planes<P>(base, K, mode, addmv ? 1 : 0);
         else eval_batch<P, LOWRES, RK>(base, K, mode, addmv ? 1 : 0);
@@ -1019,8 +1029,11 @@ struct Searcher
      * are certain to run (earlyExitIters minus the current count) form ONE batch: lane i takes
      * point i of the concatenated rounds, points outside the search range drop out, and the
      * per-round bookkeeping is replayed on the costs in visit order. */
+    /* (ox, oy): the centre the rounds are measured around (the reference's omv = bmv on entry); a search that a
+     * fixed-shape kernel began continues at round ra0 with rounds0 rounds without improvement behind it. */
     __device__ __forceinline__ void star_pattern(int mnx, int mny, int mxx, int mxy, int &bmx, int &bmy, int &bcost,
-                                 int &bPointNr, int &bDistance, int earlyExitIters, int merange)
+                                 int &bPointNr, int &bDistance, int earlyExitIters, int merange,
+                                 int ox, int oy, int ra0 = 0, int rounds0 = 0)
     {
         /* point offsets in units of distance (round 0), distance / 2 (rounds 1-3, visit order
          * 2,1,3,4,5,6,8,7), distance / 4 (later rounds); motion.cpp:330-540 */
@@ -1029,11 +1042,10 @@ struct Searcher
                                      P8 = nibs({ 2, 1, 3, 4, 5, 6, 8, 7 });
         constexpr unsigned long long X16 = nibs({ 0, -4, 4, 0, -1, 1, -1, 1, -2, 2, -2, 2, -3, 3, -3, 3 }),
                                      Y16 = nibs({ -4, 0, 0, 4, -3, -3, 3, 3, -2, -2, 2, 2, -1, -1, 1, 1 });
-        const int ox = bmx, oy = bmy;
         int rl = 3;
         for (int d = 16; d <= as_i16(merange) && d > 0; d = as_i16(d << 1)) rl++;
-        int rounds = 0;
-        for (int ra = 0; ra <= rl;)
+        int rounds = rounds0;
+        for (int ra = ra0; ra <= rl;)
         {
             int rb = ra + (earlyExitIters - rounds) - 1;
             if (rb > rl) rb = rl;
@@ -1106,6 +1118,88 @@ struct Searcher
         if (K == MAXC) q_flush(K, bmx, bmy, bcost);
         put(K, sx_, sy_, mx_, my_, sh_, 0);
         K++;
+    }
+
+    /* X265_STAR_SEARCH, motion.cpp:911-1019, from round ra0 of its first pattern on (0: all of it). */
+    __device__ __forceinline__ void star_rest(int mnx, int mny, int mxx, int mxy, int merange, int ox, int oy, int ra0, int rounds0,
+                                              int &bmx, int &bmy, int &bcost, int &bPointNr, int &bDistance)
+    {
+        star_pattern(mnx, mny, mxx, mxy, bmx, bmy, bcost, bPointNr, bDistance, 3, merange, ox, oy, ra0, rounds0);
+        if (bDistance == 1)
+        {
+            if (!bPointNr) return;
+            const int saved = bcost;
+            two_point(bPointNr, mnx, mny, mxx, mxy, bmx, bmy, bcost);
+            if (bcost == saved) return;
+        }
+
+        if (bDistance > 5)
+        {
+            /* raster refinement with step 5 (motion.cpp:952-990): row-major scan; within a row the
+             * points go in groups of four while a whole group fits, and the MV bits of a
+             * group's 4th point use tmv << 3 (:975). One lane per point. */
+            const int nx = (mxx - mnx) / 5 + 1;
+            const int grouped = mxx - mnx >= 15 ? ((mxx - mnx - 15) / 20 + 1) * 4 : 0;
+            int pn, pd;
+            if (nx <= MAXC)
+            {
+                const int rpb = MAXC / nx, inv = (65536 + nx - 1) / nx;
+                const int rs = (lane * inv) >> 16, j = lane - rs * nx;
+                for (int ty = mny; ty <= mxy; ty += 5 * rpb)
+                {
+                    const int y = ty + 5 * rs, x = mnx + 5 * j;
+                    const int K = put_lanes(rs < rpb && y <= mxy, x, y, as_i16(x), y, (j < grouped && (j & 3) == 3) ? 3 : 2, 0);
+                    fold_pt(K, bmx, bmy, bcost, pn, pd);
+                }
+            }
+            else
+                for (int ty = mny; ty <= mxy; ty += 5)
+                    for (int j0 = 0; j0 < nx; j0 += MAXC)
+                    {
+                        const int j = j0 + lane, x = mnx + 5 * j;
+                        const int K = put_lanes(j < nx, x, ty, as_i16(x), ty, (j < grouped && (j & 3) == 3) ? 3 : 2, 0);
+                        fold_pt(K, bmx, bmy, bcost, pn, pd);
+                    }
+        }
+
+        while (bDistance > 0)
+        {
+            bDistance = 0;
+            bPointNr = 0;
+            star_pattern(mnx, mny, mxx, mxy, bmx, bmy, bcost, bPointNr, bDistance, 32, merange, bmx, bmy);
+            if (bDistance == 1)
+            {
+                if (!bPointNr) break;
+                two_point(bPointNr, mnx, mny, mxx, mxy, bmx, bmy, bcost);
+                break;
+            }
+        }
+    }
+
+    /* The rest of a STAR search whose start-up candidates and first three pattern rounds a fixed-shape kernel has
+     * measured and folded (me_small.h): `state` holds what the reference has in hand at that point. Leaves the
+     * choice of motion.cpp:1063-1069 and the counters in the result record, as search_staged does. */
+    __device__ __forceinline__ void resume_star(const x265amd_job *job, const int *state, x265amd_result *res)
+    {
+        JobRegs J;
+        J.load(job);
+        set_mvp(J.qmx, J.qmy);
+        const int s0 = uni(state[0]), s1 = uni(state[1]), s3 = uni(state[3]), s5 = uni(state[5]);
+        SearchState st;
+        int bmx = as_i16(s1), bmy = s1 >> 16, bcost = uni(state[2]);
+        int bPointNr = s3 & 0xff, bDistance = (s3 >> 8) & 0xff;
+        st.bprecost = uni(state[4]); st.bpx = as_i16(s5); st.bpy = s5 >> 16;
+        nsad = (unsigned)uni(state[6]); nsub = (unsigned)uni(state[7]);
+        star_rest(J.mnx, J.mny, J.mxx, J.mxy, J.merange, as_i16(s0), s0 >> 16, 3, (s3 >> 16) & 0xff, bmx, bmy, bcost, bPointNr, bDistance);
+        st.bmx = bmx; st.bmy = bmy; st.bcost = bcost;
+        int qx, qy, c;
+        choose(st, qx, qy, c);
+        if (lane == 0)
+        {
+            res->mv[0] = (int16_t)qx; res->mv[1] = (int16_t)qy;
+            res->cost = c;
+            res->sad_calls = nsad; res->subpel_calls = nsub;
+        }
     }
 
     /* COST_MV_X4 of the UMH case: SAD measured relative to pix_base (pbx, pby), MV
@@ -1415,64 +1509,8 @@ struct Searcher
             break;
         case X265AMD_STAR:
         {
-            /* motion.cpp:911-1019 */
             int bPointNr = 0, bDistance = 0;
-            star_pattern(mnx, mny, mxx, mxy, bmx, bmy, bcost, bPointNr, bDistance, 3, merange);
-            bool done = false;
-            if (bDistance == 1)
-            {
-                if (bPointNr)
-                {
-                    const int saved = bcost;
-                    two_point(bPointNr, mnx, mny, mxx, mxy, bmx, bmy, bcost);
-                    if (bcost == saved) done = true;
-                }
-                else
-                    done = true;
-            }
-            if (done) break;
-
-            if (bDistance > 5)
-            {
-                /* raster refinement with step 5 (motion.cpp:952-990): row-major scan; within a row the
-                 * points go in groups of four while a whole group fits, and the MV bits of a
-                 * group's 4th point use tmv << 3 (:975). One lane per point. */
-                const int nx = (mxx - mnx) / 5 + 1;
-                const int grouped = mxx - mnx >= 15 ? ((mxx - mnx - 15) / 20 + 1) * 4 : 0;
-                int pn, pd;
-                if (nx <= MAXC)
-                {
-                    const int rpb = MAXC / nx, inv = (65536 + nx - 1) / nx;
-                    const int rs = (lane * inv) >> 16, j = lane - rs * nx;
-                    for (int ty = mny; ty <= mxy; ty += 5 * rpb)
-                    {
-                        const int y = ty + 5 * rs, x = mnx + 5 * j;
-                        const int K = put_lanes(rs < rpb && y <= mxy, x, y, as_i16(x), y, (j < grouped && (j & 3) == 3) ? 3 : 2, 0);
-                        fold_pt(K, bmx, bmy, bcost, pn, pd);
-                    }
-                }
-                else
-                    for (int ty = mny; ty <= mxy; ty += 5)
-                        for (int j0 = 0; j0 < nx; j0 += MAXC)
-                        {
-                            const int j = j0 + lane, x = mnx + 5 * j;
-                            const int K = put_lanes(j < nx, x, ty, as_i16(x), ty, (j < grouped && (j & 3) == 3) ? 3 : 2, 0);
-                            fold_pt(K, bmx, bmy, bcost, pn, pd);
-                        }
-            }
-
-            while (bDistance > 0)
-            {
-                bDistance = 0;
-                bPointNr = 0;
-                star_pattern(mnx, mny, mxx, mxy, bmx, bmy, bcost, bPointNr, bDistance, 32, merange);
-                if (bDistance == 1)
-                {
-                    if (!bPointNr) break;
-                    two_point(bPointNr, mnx, mny, mxx, mxy, bmx, bmy, bcost);
-                    break;
-                }
-            }
+            star_rest(mnx, mny, mxx, mxy, merange, bmx, bmy, 0, 0, bmx, bmy, bcost, bPointNr, bDistance);
             break;
         }
         case X265AMD_FULL:

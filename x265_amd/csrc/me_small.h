@@ -409,20 +409,30 @@ template<int S, typename P> struct RefineSmall
     }
 };
 
+/* one wave's group of PUs: group g of the launch's jobs, or of the launch's list of marked PUs (a.list) */
 template<int S, typename P>
-__global__ __launch_bounds__(64) void refine_small_kernel(SearchArgs a)
+__device__ __forceinline__ void refine_small_group(const SearchArgs &a, int g)
 {
     typedef SmallGeo<S> G;
     typedef RefineGeo<S> RG;
-    const int ngroups = (a.njobs + RG::NPU - 1) / RG::NPU;
-    const int g = xcd_remap((int)blockIdx.x, ngroups);
-    if (g >= ngroups) return;
     RefineSmall<S, P> R;
     R.depth = sizeof(P) == 1 ? 8 : a.depth;
     R.lane = (int)threadIdx.x; R.grp = R.lane >> RG::LG; R.l = R.lane & (RG::LPP - 1);
     int j = g * RG::NPU + R.grp;
-    const bool valid = j < a.njobs;
-    if (!valid) j = a.njobs - 1;
+    bool valid;
+    if (a.list)
+    {
+        const int total = uni(a.redo[0]);
+        valid = j < total;
+        j = a.redo[REDO_LIST + (valid ? j : total - 1)];
+    }
+    else
+    {
+        valid = j < a.njobs;
+        if (!valid) j = a.njobs - 1;
+        /* a PU the STAR kernels handed on is refined by the list-driven launch that follows its search */
+        if (a.mark && a.mark[j]) valid = false;
+    }
     const int *job = (const int*)(a.jobs + j);
     const int d0 = job[0], d1 = job[1], d4 = job[4];
     const int pux = as_i16(d0), puy = d0 >> 16;
@@ -438,7 +448,6 @@ __global__ __launch_bounds__(64) void refine_small_kernel(SearchArgs a)
     small_planes<P>(a, d1, fenc0, fstride, R.ref0, R.rstride);
     R.roff = puy * R.rstride + pux;
     R.ctab = (const uint16_t AS1*)a.ctab;
-    small_load_taps<P>(R.lane, R.depth);
 #pragma unroll
     for (int u = 0; u < RG::ITEMS; u++) small_source_column<S>(fenc0, fstride, pux, puy, R.l + u * RG::LPP, R.ct[u]);
     /* SubpelWorkload, motion.cpp:53-63, and the round sequence of :1100-1141 */
@@ -462,6 +471,20 @@ __global__ __launch_bounds__(64) void refine_small_kernel(SearchArgs a)
         res[0] = (R.qx & 0xffff) | (R.qy << 16);
         res[1] = R.bcost;
         res[3] = (int)R.nsub;
+    }
+}
+
+template<int S, typename P>
+__global__ __launch_bounds__(64) void refine_small_kernel(SearchArgs a)
+{
+    typedef RefineGeo<S> RG;
+    small_load_taps<P>((int)threadIdx.x, sizeof(P) == 1 ? 8 : a.depth);
+    /* every PU of the launch, a group per wave; or (a.list) the launch's list of marked PUs, every wave walking it */
+    const int n = a.list ? uni(a.redo[0]) : a.njobs, ngroups = (n + RG::NPU - 1) / RG::NPU;
+    for (int k = (int)blockIdx.x; k < ngroups; k += a.list ? (int)gridDim.x : ngroups)
+    {
+        wave_sync();
+        refine_small_group<S, P>(a, a.list ? k : xcd_remap(k, ngroups));
     }
 }
 
@@ -495,14 +518,12 @@ template<int S> struct BigLds
 };
 
 template<int S, typename P>
-__global__ __launch_bounds__(BigGeo<S>::THREADS) void refine_big_kernel(SearchArgs a)
+__device__ __forceinline__ void refine_big_pu(const SearchArgs &a, int j)
 {
     const int depth = sizeof(P) == 1 ? 8 : a.depth;
     typedef SmallGeo<S> G;
     typedef BigLds<S> L;
     constexpr int THREADS = BigGeo<S>::THREADS, ITEMS = BigGeo<S>::ITEMS;
-    const int j = xcd_remap((int)blockIdx.x, a.njobs);
-    if (j >= a.njobs) return;
     const int tid = (int)threadIdx.x, lane = tid & 63;
     const int *job = (const int*)(a.jobs + j);
     const int d0 = uni(job[0]), d1 = uni(job[1]), d4 = uni(job[4]);
@@ -515,13 +536,14 @@ __global__ __launch_bounds__(BigGeo<S>::THREADS) void refine_big_kernel(SearchAr
     /* a PU whose full-pel cost is 0 is not refined (motion.cpp:1073-1076), a negative cost marks a job that was
      * refused; PUs of other sizes are final already */
     if ((d1 & 0xffff) != G::SIZE_CODE || bcost <= 0) return;
-    if (a.done && a.done[j]) return;                /* refined together with its parent already */
+    if (!a.list && a.done && a.done[j]) return;     /* refined together with its parent already */
+    /* a PU the STAR kernels handed on is refined by the list-driven launch that follows its search */
+    if (!a.list && a.mark && a.mark[j]) return;
     const P AS1 *fenc0, *ref0;
     int fstride, rstride;
     small_planes<P>(a, d1, fenc0, fstride, ref0, rstride);
     const int roff = puy * rstride + pux;
     const uint16_t AS1 *ctab = (const uint16_t AS1*)a.ctab;
-    small_load_taps<P>(tid, depth);
     for (int i = tid; i < L::ROUNDS * 68; i += THREADS) ((int*)(x265amd_smem + L::CELLS))[i] = 0;
     /* A 64x64 PU directly followed in the list by its four 32x32 children (raster order, same pictures), all five
      * starting from the same MV: SAD and SATD are sums over 4x4 tiles, so a candidate's distortion for a child is the
@@ -534,7 +556,8 @@ __global__ __launch_bounds__(BigGeo<S>::THREADS) void refine_big_kernel(SearchAr
     unsigned cnsub = 0;
     if constexpr (S == 64)
     {
-        if (a.done && j + 4 < a.njobs)
+        /* (the list-driven launch refines PU by PU: the children of a marked parent were refined on their own) */
+        if (!a.list && a.done && j + 4 < a.njobs)
         {
             quad = true;
 #pragma unroll
@@ -544,7 +567,8 @@ __global__ __launch_bounds__(BigGeo<S>::THREADS) void refine_big_kernel(SearchAr
                 const int *cr = (const int*)(a.results + j + 1 + q);
                 const int c0 = uni(cj[0]), c1 = uni(cj[1]), c4 = uni(cj[4]), m = uni(cr[0]), bc = uni(cr[1]);
                 quad = quad && (c1 & 0xffff) == SmallGeo<32>::SIZE_CODE && (c1 >> 24) == (d1 >> 24) &&
-                       as_i16(c0) == pux + 32 * (q & 1) && (c0 >> 16) == puy + 32 * (q >> 1) && m == r0 && bc > 0;
+                       as_i16(c0) == pux + 32 * (q & 1) && (c0 >> 16) == puy + 32 * (q >> 1) && m == r0 && bc > 0 &&
+                       !(a.mark && a.mark[j + 1 + q]);    /* a marked child's record is not ready yet */
                 if (q == wave) { cbcost = bc; cmvpx = as_i16(c4); cmvpy = c4 >> 16; cnsub = (unsigned)uni(cr[3]); }
             }
         }
@@ -695,6 +719,20 @@ __global__ __launch_bounds__(BigGeo<S>::THREADS) void refine_big_kernel(SearchAr
     }
 }
 
+template<int S, typename P>
+__global__ __launch_bounds__(BigGeo<S>::THREADS) void refine_big_kernel(SearchArgs a)
+{
+    small_load_taps<P>((int)threadIdx.x, sizeof(P) == 1 ? 8 : a.depth);
+    /* a workgroup per PU of the launch; or (a.list) the launch's list of marked PUs, every workgroup walking it */
+    const int n = a.list ? uni(a.redo[0]) : a.njobs;
+    for (int k = (int)blockIdx.x; k < n; k += a.list ? (int)gridDim.x : n)
+    {
+        __syncthreads();        /* the workgroup's LDS belongs to the PU before until here */
+        const int j = a.list ? uni(a.redo[REDO_LIST + k]) : xcd_remap(k, a.njobs);
+        if (j < a.njobs) refine_big_pu<S, P>(a, j);
+    }
+}
+
 /* ---------------------------------------------------------------- the common case of a STAR search
  *
  * Most PUs of a picture end their integer search where it began: the start-up candidates (motion.cpp:562-621)
@@ -719,6 +757,50 @@ template<int S> struct StarLds
     static constexpr int TOTAL = PLANES + G::NPU * PU_BYTES + 32;
 };
 
+/* point p (0 .. 19) of the first three rounds of the star pattern in visit order: 4 points at distance 1, 8 at
+ * distance 2, 8 at distance 4 (motion.cpp:330-452) */
+__device__ __forceinline__ void star_point(int p, int &dx, int &dy)
+{
+    constexpr unsigned long long X4 = nibs({ 0, -1, 1, 0 }), Y4 = nibs({ -1, 0, 0, 1 });
+    constexpr unsigned long long X8 = nibs({ 0, -1, 1, -2, 2, -1, 1, 0 }), Y8 = nibs({ -2, -1, -1, 0, 0, 1, 1, 2 });
+    const int r = p < 4 ? 0 : (p < 12 ? 1 : 2), i = p < 4 ? p : (p - 4) & 7;
+    const int unit = r == 2 ? 2 : 1;
+    dx = nib(r == 0 ? X4 : X8, i) * unit; dy = nib(r == 0 ? Y4 : Y8, i) * unit;
+}
+
+/* What StarPatternSearch has in hand after its first three rounds, given each round's first minimum
+ * (cost << 6 | point, 0x7fffffff for a round without points): best MV and cost, bPointNr / bDistance of the winner
+ * (COST_MV_PT_DIST, motion.cpp:182-194) and the count of rounds without improvement (:443-446). */
+struct StarFold
+{
+    int ox, oy, bmx, bmy, bcost, pt, dist, rounds;
+    __device__ __forceinline__ void start(int x, int y, int c) { ox = bmx = x; oy = bmy = y; bcost = c; pt = 0; dist = 0; rounds = 0; }
+    __device__ __forceinline__ void round(int key)
+    {
+        if ((key >> 6) < bcost)
+        {
+            constexpr unsigned long long P4 = nibs({ 2, 4, 5, 7 }), P8 = nibs({ 2, 1, 3, 4, 5, 6, 8, 7 });
+            constexpr unsigned long long X8 = nibs({ 0, -1, 1, -2, 2, -1, 1, 0 });
+            const int p = key & 63, r = p < 4 ? 0 : (p < 12 ? 1 : 2), i = p < 4 ? p : (p - 4) & 7;
+            int dx, dy;
+            star_point(p, dx, dy);
+            bcost = key >> 6; bmx = as_i16(ox + dx); bmy = as_i16(oy + dy);
+            pt = r == 0 ? nib(P4, i) : nib(P8, i);
+            dist = (r >= 1 && (nib(X8, i) & 1)) ? (1 << r) >> 1 : 1 << r;
+            rounds = 0;
+        }
+        else
+            rounds++;
+    }
+    /* the record star_resume_kernel continues from (Searcher::resume_star) */
+    __device__ __forceinline__ void store(int *st, int bprecost, int bpx, int bpy, unsigned nsad, unsigned nsub) const
+    {
+        st[0] = (ox & 0xffff) | (oy << 16); st[1] = (bmx & 0xffff) | (bmy << 16); st[2] = bcost;
+        st[3] = pt | (dist << 8) | (rounds << 16);
+        st[4] = bprecost; st[5] = (bpx & 0xffff) | (bpy << 16); st[6] = (int)nsad; st[7] = (int)nsub;
+    }
+};
+
 template<int S, typename P>
 __global__ __launch_bounds__(64) void star_small_kernel(SearchArgs a)
 {
@@ -738,7 +820,7 @@ __global__ __launch_bounds__(64) void star_small_kernel(SearchArgs a)
 #pragma unroll
     for (int i = 0; i < 10; i++) d[i] = job[i];
     const bool sized = (d[1] & 0xffff) == G::SIZE_CODE;
-    if (valid && !sized && l == 0) a.results[j].sad_calls = SMALL_REDO;
+    if (valid && !sized && l == 0) { a.results[j].sad_calls = SMALL_REDO; a.mark[j] = 1; }
     const bool act = valid && sized;
     if (__ballot(act) == 0) return;
 
@@ -904,9 +986,7 @@ __global__ __launch_bounds__(64) void star_small_kernel(SearchArgs a)
     }
     /* ---- the first three star rounds around (bmx, bmy): 4 + 8 + 8 points (motion.cpp:330-452), does any beat bcost?
      * A lane per (point, tile), four points per pass ---- */
-    constexpr unsigned long long X4 = nibs({ 0, -1, 1, 0 }), Y4 = nibs({ -1, 0, 0, 1 });
-    constexpr unsigned long long X8 = nibs({ 0, -1, 1, -2, 2, -1, 1, 0 }), Y8 = nibs({ -2, -1, -1, 0, 0, 1, 1, 2 });
-    bool improve = false;
+    int rkey0 = 0x7fffffff, rkey1 = 0x7fffffff, rkey2 = 0x7fffffff;     /* per round: min of cost << 6 | point in visit order */
     unsigned npts = 0;
 #ifndef X265AMD_STAR_GLOBAL_LOADS
     /* the (S + 8)^2 samples the 20 points can touch, staged once per PU into the LDS of the start-up planes (dead by
@@ -931,9 +1011,8 @@ __global__ __launch_bounds__(64) void star_small_kernel(SearchArgs a)
     for (int pass = 0; pass < 5; pass++)
     {
         const int p = pass * 4 + (l >> G::LT);
-        const int r = p < 4 ? 0 : (p < 12 ? 1 : 2), i = p < 4 ? p : (p - 4) & 7;
-        const int unit = r == 2 ? 2 : 1;
-        const int dx = nib(r == 0 ? X4 : X8, i) * unit, dy = nib(r == 0 ? Y4 : Y8, i) * unit;
+        int dx, dy;
+        star_point(p, dx, dy);
         const int x = as_i16(bmx + dx), y = as_i16(bmy + dy);
         /* the reference tests only the bounds a point can cross */
         const bool ok = act && (dy >= 0 || y >= mny) && (dy <= 0 || y <= mxy) && (dx >= 0 || x >= mnx) && (dx <= 0 || x <= mxx);
@@ -952,22 +1031,283 @@ __global__ __launch_bounds__(64) void star_small_kernel(SearchArgs a)
             cost = ((int)ctab[as_i16(x << 2) - mvpx] + (int)ctab[as_i16(y << 2) - mvpy]) & 0xffff;
         }
         v = seg_sum(v, G::LT);      /* the tiles of a point are adjacent lanes */
-        improve = improve || (ok && v + cost < bcost);
+        const int km = grp_min<G::LG>(ok && tile == 0 ? ((v + cost) << 6) | p : 0x7fffffff);
+        if (pass == 0) rkey0 = km;
+        else if (pass < 3) rkey1 = km < rkey1 ? km : rkey1;
+        else rkey2 = km < rkey2 ? km : rkey2;
         npts += (unsigned)grp_count<G::LG>(ok && tile == 0);
     }
-    const bool anyImprove = grp_any<G::LG>(improve);
     if (!act || l != 0) return;
-    if (anyImprove)
+    /* the bookkeeping of StarPatternSearch over these rounds (motion.cpp:323-452): strict '<' in visit order, a
+     * counter of rounds without improvement */
+    StarFold F;
+    F.start(bmx, bmy, bcost);
+    F.round(rkey0); F.round(rkey1); F.round(rkey2);
+    nsad += npts;
+    int *res = (int*)(a.results + j);
+    a.mark[j] = F.rounds < 3;
+    if (F.rounds < 3)
     {
-        a.results[j].sad_calls = SMALL_REDO;
+        /* a point improved: the pattern goes on to larger distances, which star_resume_kernel measures */
+        F.store(a.state + 8 * (long)j, bprecost, bpx, bpy, nsad, nsub);
+        res[2] = (int)SMALL_RESUME;
         return;
     }
     /* three rounds without improvement end the pattern with the start point standing; motion.cpp:1063-1069 */
-    nsad += npts;
     int qx, qy;
     if (bprecost < bcost) { qx = bpx; qy = bpy; bcost = bprecost; }
     else { qx = as_i16(bmx << 2); qy = as_i16(bmy << 2); }
+    res[0] = (qx & 0xffff) | (qy << 16);
+    res[1] = bcost;
+    res[2] = (int)nsad;
+    res[3] = (int)nsub;
+}
+
+/* four samples at byte offset base + coff of the LDS array, base a multiple of four and coff a compile-time constant
+ * once the caller's loops are unrolled: the realignment disappears where coff is a multiple of four itself */
+template<typename P> __device__ __forceinline__ typename Px<P>::quad lds_quad_const(int base, int coff);
+template<> __device__ __forceinline__ uint32_t lds_quad_const<uint8_t>(int base, int coff)
+{
+    const uint32_t *q = (const uint32_t*)(x265amd_smem + base + (coff & ~3));
+    return (coff & 3) ? __builtin_amdgcn_alignbyte(q[1], q[0], (uint32_t)(coff & 3)) : q[0];
+}
+template<> __device__ __forceinline__ uint2 lds_quad_const<uint16_t>(int base, int coff)
+{
+    const uint32_t *q = (const uint32_t*)(x265amd_smem + base + (coff & ~3));
+    if (!(coff & 2)) return make_uint2(q[0], q[1]);
+    return make_uint2(__builtin_amdgcn_alignbit(q[1], q[0], 16), __builtin_amdgcn_alignbit(q[2], q[1], 16));
+}
+
+/* ---------------------------------------------------------------- the same for 32x32 and 64x64 PUs
+ *
+ * A workgroup of one / two waves per PU (StarBigGeo), everything about the PU uniform across it. The start-up candidates go
+ * one after the other: a whole-sample one is a plain SAD of the reference block, every thread taking the quad rows of its
+ * tile; a fractional one fills a plane of luma_hps intermediates (all threads), then every thread runs the vertical
+ * pass + SAD of its (tile, column) pairs -- two plane buffers in turn, so a fill never waits for the pass before it.
+ * The sums meet in LDS cells. The 20 points of the first three rounds are SADs from the (S + 8)^2 window staged over
+ * the dead planes, every thread a strip four samples wide, the sums of sixteen lanes at a time added to the point's cell. The
+ * fold over the rounds and the hand-over to star_resume_kernel are star_small_kernel's. */
+template<int S> struct StarBigLds
+{
+    typedef SmallGeo<S> G;
+    static constexpr int CELLS = SM_FIXED;                          /* 8 cells of the start-up slots, then 20 of the star points */
+    static constexpr int PLANES = CELLS + 128;
+    static_assert((S + 8) * (S + 12) * 2 + 8 <= 2 * G::PLANE, "the window of the star points (16-bit samples) fits the two planes");
+    static constexpr int TOTAL = PLANES + 2 * G::PLANE + 32;
+};
+
+/* Small workgroups on purpose: next to launches of one-wave workgroups a workgroup of four waves waits long for a
+ * compute unit with four free places at once (measured: the launch of the 32x32 PUs took 2.3 ms in the step against
+ * 0.4 ms alone). */
+template<int S> struct StarBigGeo
+{
+    static constexpr int WAVES = S == 32 ? 1 : 2;
+    static constexpr int THREADS = WAVES * 64;
+    static constexpr int ITEMS = SmallGeo<S>::LPP / THREADS;        /* (tile, column) pairs per thread */
+    static constexpr int NQ = S * S / (4 * THREADS);                /* quad rows per thread: a strip four samples wide */
+};
+
+template<int S, typename P>
+__global__ __launch_bounds__(StarBigGeo<S>::THREADS) void star_big_kernel(SearchArgs a)
+{
+    const int depth = sizeof(P) == 1 ? 8 : a.depth;
+    typedef SmallGeo<S> G;
+    typedef StarBigLds<S> L;
+    constexpr int THREADS = StarBigGeo<S>::THREADS, ITEMS = StarBigGeo<S>::ITEMS, NQ = StarBigGeo<S>::NQ, BPS = (int)sizeof(P);
+    const int j = xcd_remap((int)blockIdx.x, a.njobs);
+    if (j >= a.njobs) return;
+    const int tid = (int)threadIdx.x, lane = tid & 63;
+    const int *job = (const int*)(a.jobs + j);
+    int d[10];
+    d[1] = uni(job[1]);
+    if ((d[1] & 0xffff) != G::SIZE_CODE)
+    {
+        /* the launch for the list's largest size hands every PU that no fixed-shape launch takes to the one-wave search */
+        if (S == a.staged && (d[1] & 0xffff) != (a.staged2 | (a.staged2 << 8)) && tid == 0) { a.results[j].sad_calls = SMALL_REDO; a.mark[j] = 1; }
+        return;
+    }
+#pragma unroll
+    for (int i = 0; i < 10; i++) d[i] = uni(job[i]);
+    const int pux = as_i16(d[0]), puy = d[0] >> 16, numc = (d[1] >> 16) & 0xff;
+    const int mnx = as_i16(d[2]), mny = d[2] >> 16, mxx = as_i16(d[3]), mxy = d[3] >> 16;
+    const int mvpx = as_i16(d[4]), mvpy = d[4] >> 16;
+    const P AS1 *fenc0, *ref0;
+    int fstride, rstride;
+    small_planes<P>(a, d[1], fenc0, fstride, ref0, rstride);
+    const int roff = puy * rstride + pux;
+    const uint16_t AS1 *ctab = (const uint16_t AS1*)a.ctab;
+    small_load_taps<P>(tid, depth);
+    int *cells = (int*)(x265amd_smem + L::CELLS);
+    if (tid < 32) cells[tid] = 0;
+
+    /* ---- start-up candidates, motion.cpp:575-621 ---- */
+    const int qmnx = as_i16(mnx << 2), qmny = as_i16(mny << 2), qmxx = as_i16(mxx << 2), qmxy = as_i16(mxy << 2);
+#define SM_CLIPX(v) ((v) > qmxx ? qmxx : ((v) < qmnx ? qmnx : (v)))
+#define SM_CLIPY(v) ((v) > qmxy ? qmxy : ((v) < qmny ? qmny : (v)))
+    const int pmx = SM_CLIPX(mvpx), pmy = SM_CLIPY(mvpy);
+    int bmx = as_i16((pmx + 2) >> 2), bmy = as_i16((pmy + 2) >> 2);
+    const bool fpOn = ((pmx | pmy) & 3) != 0, zeroOn = (pmx | pmy) != 0;
+    int ccx[4], ccy[4];
+    bool cOn[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+    {
+        ccx[i] = SM_CLIPX(as_i16(d[5 + i])); ccy[i] = SM_CLIPY(d[5 + i] >> 16);
+        cOn[i] = i < numc && (ccx[i] | ccy[i]) != 0 && !(ccx[i] == pmx && ccy[i] == pmy);
+    }
+#undef SM_CLIPX
+#undef SM_CLIPY
+    /* lane l < 7 of every wave looks after candidate slot l, as in star_small_kernel */
+    int sx = pmx, sy = pmy;
+    bool on = lane == 0;
+    if (lane == 1) { sx = as_i16(bmx << 2); sy = as_i16(bmy << 2); on = fpOn; }
+    if (lane == 2) { sx = 0; sy = 0; on = zeroOn; }
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+        if (lane == 3 + i) { sx = ccx[i]; sy = ccy[i]; on = cOn[i]; }
+    on = on && lane < SM_SLOTS;
+    int mvc = 0;
+    if (on && lane != 0) mvc = ((int)ctab[sx - mvpx] + (int)ctab[sy - mvpy]) & 0xffff;
+
+    /* the thread's part of the source block: its (tile, column) pairs for the vertical passes, its quad rows for the SADs */
+    ColSrc ct[ITEMS];
+#pragma unroll
+    for (int u = 0; u < ITEMS; u++) small_source_column<S>(fenc0, fstride, pux, puy, tid + u * THREADS, ct[u]);
+    const int tlx = (tid & (G::TW - 1)) * 4, tly = (tid >> G::LTW) * NQ;
+    typename Px<P>::quad fq[NQ];
+    {
+        const P AS1 *src = fenc0 + (long)(puy + tly) * fstride + pux + tlx;
+#pragma unroll
+        for (int y = 0; y < NQ; y++) fq[y] = Px<P>::load_g(src + (long)y * fstride);
+    }
+    __syncthreads();
+    int pb = 0;
+#pragma unroll 1
+    for (int k = 0; k < SM_SLOTS; k++)
+    {
+        if (!__builtin_amdgcn_readlane((int)on, k)) continue;
+        const int kx = __builtin_amdgcn_readlane(sx, k), ky = __builtin_amdgcn_readlane(sy, k);
+        int v = 0;
+        if (((kx | ky) & 3) == 0)
+        {
+            const P AS1 *rp = ref0 + roff + (long)__mul24((ky >> 2) + tly, rstride) + (kx >> 2) + tlx;
+#pragma unroll
+            for (int y = 0; y < NQ; y++) v = Px<P>::sad(fq[y], Px<P>::load_g(rp + (long)y * rstride), v);
+        }
+        else
+        {
+            const int poff = L::PLANES + pb * G::PLANE;
+            const P AS1 *src = ref0 + (roff + __mul24((ky >> 2) - 3, rstride) + (kx >> 2) - 3);
+            const int *tp = (const int*)(x265amd_smem + SM_TAPS) + (kx & 3) * 12;
+            for (int item = tid; item < G::IPP; item += THREADS)
+            {
+                const int r = item >> G::LTW, q = item & (G::TW - 1);
+                hps_quad(src + (__mul24(r, rstride) + 4 * q), tp, (int16_t*)(x265amd_smem + poff) + (4 * q) * G::PROW + r, G::PROW, depth);
+            }
+            __syncthreads();
+#pragma unroll
+            for (int u = 0; u < ITEMS; u++) v += small_column_cost<S>(poff, 0, ky & 3, false, ct[u], tid & 3, depth);
+            pb ^= 1;
+        }
+        v = seg_sum(v, 6);
+        if (lane == 0) atomicAdd(cells + k, v);
+    }
+    __syncthreads();
+    /* the reference's sequence of tests on the measured costs (motion.cpp:579-621) */
+    int cst[SM_SLOTS];
+#pragma unroll
+    for (int k = 0; k < SM_SLOTS; k++) cst[k] = uni(cells[k]) + __builtin_amdgcn_readlane(mvc, k);
+    int bprecost = cst[0], bcost = bprecost;
+    unsigned nsad = 0, nsub = 1;
+    if (fpOn) { bcost = cst[1]; nsad++; }
+    if (zeroOn)
+    {
+        nsad++;
+        if (cst[2] < bcost) { bcost = cst[2]; bmx = 0; bmy = 0; }
+    }
+    int bpx = pmx, bpy = pmy;
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+        if (cOn[i] && !(ccx[i] == bpx && ccy[i] == bpy))
+        {
+            nsub++;
+            if (cst[3 + i] < bprecost) { bprecost = cst[3 + i]; bpx = ccx[i]; bpy = ccy[i]; }
+        }
+    /* ---- the window of the 20 points over the planes (every thread is past its last vertical pass) ---- */
+    constexpr int WP = (S + 12) * BPS;
+    const int woff = L::PLANES;
+    {
+        typedef uint32_t __attribute__((aligned(1))) u32u;
+        const char AS1 *w0 = (const char AS1*)(ref0 + roff + (long)__mul24(bmy - 4, rstride) + bmx - 4);
+        for (int i = tid; i < (S + 8) * (WP / 4); i += THREADS)
+        {
+            const int r = i / (WP / 4), q = i - r * (WP / 4);
+            *(uint32_t*)(x265amd_smem + woff + r * WP + 4 * q) = *(const u32u AS1*)(w0 + (long)r * rstride * BPS + 4 * q);
+        }
+    }
+    __syncthreads();
+    /* every point's SAD over the thread's quad rows: the loops are unrolled, so a point's offset in the window is a
+     * constant next to the thread's own (dword-aligned) corner -- reads shared between points are made once, and a
+     * point a multiple of four samples away needs no realignment */
+    unsigned npts = 0;
+    {
+        constexpr int DX[20] = { 0, -1, 1, 0, 0, -1, 1, -2, 2, -1, 1, 0, 0, -2, 2, -4, 4, -2, 2, 0 };
+        constexpr int DY[20] = { -1, 0, 0, 1, -2, -1, -1, 0, 0, 1, 1, 2, -4, -2, -2, 0, 0, 2, 2, 4 };
+        const int room_l = bmx - mnx, room_r = mxx - bmx, room_u = bmy - mny, room_d = mxy - bmy;
+        const int wbase = woff + tly * WP + tlx * BPS;
+        int pv[20];
+#pragma unroll
+        for (int p = 0; p < 20; p++)
+        {
+            int v = 0;
+#pragma unroll
+            for (int y2 = 0; y2 < NQ; y2++)
+                v = Px<P>::sad(fq[y2], lds_quad_const<P>(wbase, (4 + DY[p] + y2) * WP + (4 + DX[p]) * BPS), v);
+            pv[p] = v;
+        }
+#pragma unroll
+        for (int p = 0; p < 20; p++)
+        {
+            /* the reference tests only the bounds a point can cross (motion.cpp:330-452) */
+            const bool okx = DX[p] == 0 || (DX[p] < 0 ? room_l >= -DX[p] : room_r >= DX[p]);
+            const bool oky = DY[p] == 0 || (DY[p] < 0 ? room_u >= -DY[p] : room_d >= DY[p]);
+            if (okx && oky)
+            {
+                npts++;
+                const int v = seg_sum(pv[p], 4);
+                if ((lane & 15) == 0) atomicAdd(cells + 8 + p, v);
+            }
+        }
+    }
+    __syncthreads();
+    if (tid >= 64) return;
+    int key = 0x7fffffff;
+    if (lane < 20)
+    {
+        int dx, dy;
+        star_point(lane, dx, dy);
+        const int x = as_i16(bmx + dx), y = as_i16(bmy + dy);
+        if ((dy >= 0 || y >= mny) && (dy <= 0 || y <= mxy) && (dx >= 0 || x >= mnx) && (dx <= 0 || x <= mxx))
+            key = ((cells[8 + lane] + (((int)ctab[as_i16(x << 2) - mvpx] + (int)ctab[as_i16(y << 2) - mvpy]) & 0xffff)) << 6) | lane;
+    }
+    const int rkey0 = wave_min(lane < 4 ? key : 0x7fffffff), rkey1 = wave_min(lane >= 4 && lane < 12 ? key : 0x7fffffff),
+              rkey2 = wave_min(lane >= 12 ? key : 0x7fffffff);
+    if (tid != 0) return;
+    StarFold F;
+    F.start(bmx, bmy, bcost);
+    F.round(rkey0); F.round(rkey1); F.round(rkey2);
+    nsad += npts;
     int *res = (int*)(a.results + j);
+    a.mark[j] = F.rounds < 3;
+    if (F.rounds < 3)
+    {
+        F.store(a.state + 8 * (long)j, bprecost, bpx, bpy, nsad, nsub);
+        res[2] = (int)SMALL_RESUME;
+        return;
+    }
+    int qx, qy;
+    if (bprecost < bcost) { qx = bpx; qy = bpy; bcost = bprecost; }
+    else { qx = as_i16(bmx << 2); qy = as_i16(bmy << 2); }
     res[0] = (qx & 0xffff) | (qy << 16);
     res[1] = bcost;
     res[2] = (int)nsad;

@@ -19,6 +19,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("X265AMD_LIB") or os.path.join(HERE, "libx265_amd_me.so")
 
 DIA, HEX, UMH, STAR, FULL = 0, 1, 2, 3, 4
+SQUARE_ONLY = 0x100      # x265amd_search_batch*_dev: max_pu_dim | SQUARE_ONLY (the list holds only squares of that size)
 METHODS = {"dia": DIA, "hex": HEX, "umh": UMH, "star": STAR, "full": FULL}
 
 PARTITIONS = [(4, 4), (8, 8), (8, 4), (4, 8), (16, 16), (16, 8), (8, 16), (16, 12), (12, 16), (16, 4), (4, 16),
@@ -239,6 +240,12 @@ class Engine:
     # ---- device-resident variants (pointers are raw device addresses, e.g. torch tensor.data_ptr())
     def stream(self):
         return self.L.x265amd_stream(self.ctx)
+
+    def marked_count(self):
+        """PUs of the last STAR launch that the fixed-shape kernels did not finish (x265amd_marked_count)."""
+        n = C.c_int(0)
+        self._chk(self.L.x265amd_marked_count(self.ctx, C.byref(n)))
+        return n.value
 
     def sync(self):
         self._chk(self.L.x265amd_sync(self.ctx))

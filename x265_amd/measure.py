@@ -293,3 +293,48 @@ def bipred_picture(e, dev, width=3840, height=2160, reps=10, seed=6):
     jw, jh = jobs["w"].astype(np.int64), jobs["h"].astype(np.int64)
     return {"ms": ms, "pus": len(jobs), "algorithmic_bytes": int((bpp * (jw * jh + 2 * (jw + 7) * (jh + 7)) + 8).sum())}
 
+
+
+def pattern_search_clip(e, dev, kind, pairs=8, width=1920, height=1080, method="star", subme=5, merange=57, reps=3, seed=1234, qp=32):
+    """The headline's searches on another kind of clip (synth.make_clip: "noise" = no two frames alike, the worst case of
+    a pattern search; "static" = every frame the same, the best case; "texture" = the headline's translated texture):
+    every square 64/32/16/8 PU of `pairs` frame pairs, predictors from the lookahead field of each pair, one launch per
+    PU class over all pairs (the 64x64 PUs with their 32x32 children behind them), the classes one after the other on one
+    stream. Per class: ms, pixel-SADs, and the share of its PUs the fixed-shape kernels did not finish (marked).
+    Returns the classes and, for checking, the jobs and results of pair 0."""
+    import torch
+    from .engine import HEX, SQUARE_ONLY
+    from .synth import lowres_dims
+    M = 128
+    clip = make_clip(width, height, pairs + 1, seed=seed, kind=kind)
+    planes = []
+    for f in clip:
+        buf, org, stride = pad_plane(f, M)
+        planes.append(e.upload_plane(buf, width, height, M, M, stride))
+    low = [e.lowres_init(p) for p in planes]
+    lw, lh, wcu, hcu = lowres_dims(width, height)
+    la_mvs, _, _ = e.lookahead_fields([(low[i + 1][0], low[i]) for i in range(pairs)], wcu, hcu, 12, HEX, 1, 16)
+    host_jobs = [workload.square_pu_jobs(width, height, la_mvs[i], wcu, hcu, merange) for i in range(pairs)]
+    d_pairs = e.pairs_upload([(planes[i + 1], planes[i]) for i in range(pairs)])
+    out, keep = {}, []
+    for name, sizes, dim in (("64+32", (64, 32), 64), ("16", (16,), 16), ("8", (8,), 8)):
+        cj, index = workload.class_job_list(host_jobs, sizes, families=dim == 64)
+        n = len(cj)
+        d_jobs = torch.from_numpy(cj.view(np.uint8).reshape(n, -1).copy()).to(dev)
+        d_res = torch.zeros((n, RESULT_DTYPE.itemsize), dtype=torch.uint8, device=dev)
+        torch.cuda.synchronize()
+        launch = lambda: e.search_batch_pairs_dev(d_pairs, pairs, d_jobs.data_ptr(), n, d_res.data_ptr(), qp, METHODS[method], subme,
+                                                  max_pu_dim=dim | SQUARE_ONLY)
+        ms = _timed(torch, e, dev, launch, reps)
+        marked = e.marked_count()
+        res = d_res.cpu().numpy().view(RESULT_DTYPE).reshape(-1)
+        out[name] = {"pus": n, "ms": ms, "marked_frac": marked / n, "pixel_sads": workload.pixel_sads(cj, res)}
+        sel = index[:, 0] == 0
+        keep.append((cj[sel], res[sel]))
+    e.device_free(d_pairs)
+    for l in low:
+        for p in l:
+            e.free_plane(p)
+    for p in planes:
+        e.free_plane(p)
+    return out, (clip[0], clip[1], np.concatenate([k[0] for k in keep]), np.concatenate([k[1] for k in keep]))

@@ -45,6 +45,44 @@ def square_pu_jobs(width, height, lowres_mvs, wcu, hcu, merange, sizes=(64, 32, 
     return np.concatenate(out)
 
 
+def family_order(jobs):
+    """Quadtree order of a job list of 64x64 and 32x32 PUs of one picture: every 64x64 PU followed by its four 32x32
+    children in raster order (the library then refines them together with it where all five start from one MV); the 32x32
+    PUs without a parent (a picture whose height is no multiple of 64) at the end. Returns the permutation."""
+    pos = {(int(j["pu_x"]), int(j["pu_y"]), int(j["w"])): k for k, j in enumerate(jobs)}
+    fam, used = [], set()
+    for k, j in enumerate(jobs):
+        if j["w"] != 64:
+            continue
+        kids = [pos.get((int(j["pu_x"]) + 32 * (q & 1), int(j["pu_y"]) + 32 * (q >> 1), 32)) for q in range(4)]
+        fam.append(k)
+        if all(c is not None for c in kids):
+            fam += kids
+            used.update(kids)
+    fam += [k for k, j in enumerate(jobs) if j["w"] == 32 and k not in used]
+    fam = np.array(fam)
+    assert len(fam) == len(jobs) and len(set(fam.tolist())) == len(jobs)
+    return fam
+
+
+def class_job_list(host_jobs, sizes, families=False):
+    """One job list over several frame pairs for a launch of x265amd_search_batch_pairs_dev: the PUs of the given square
+    sizes of every pair's list (host_jobs[i], as square_pu_jobs makes it), pair-major, job.reserved naming the pair;
+    `families`: every pair's part in quadtree order (family_order). Returns (jobs, index) with index[k] = (pair, position
+    in host_jobs[pair]) of job k."""
+    parts, index = [], []
+    for i, jobs in enumerate(host_jobs):
+        idx = np.flatnonzero(np.isin(jobs["w"], sizes) & (jobs["w"] == jobs["h"]))
+        j = jobs[idx].copy()
+        j["reserved"] = i
+        if families:
+            order = family_order(j)
+            j, idx = j[order], idx[order]
+        parts.append(j)
+        index.append(np.stack([np.full(len(idx), i), idx], axis=1))
+    return np.concatenate(parts), np.concatenate(index)
+
+
 def algorithmic_bytes(jobs, bytes_per_pixel=1):
     w = jobs["w"].astype(np.int64)
     h = jobs["h"].astype(np.int64)
