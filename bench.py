@@ -454,31 +454,10 @@ def main():
         cls_jobs, cls_res, cls_index = [], [], []
         res_first = 0
         for (first, cnt, dim, eng) in segs:
-            parts, index = [], []
-            for i in range(B):
-                j = host_jobs[i][first:first + cnt].copy()
-                j["reserved"] = i
-                parts.append(j)
-                index.append(np.stack([np.full(cnt, i), np.arange(first, first + cnt)], axis=1))
-            if dim == 64 and args.launch == "families":
-                # quadtree order inside every pair's part: a 64x64 PU, then its four 32x32 children in raster order;
-                # the 32x32 PUs without a parent (the picture's height is no multiple of 64) at the end
-                j0 = host_jobs[0][first:first + cnt]
-                pos = {(int(j["pu_x"]), int(j["pu_y"]), int(j["w"])): k for k, j in enumerate(j0)}
-                fam, used = [], set()
-                for k, j in enumerate(j0):
-                    if j["w"] != 64:
-                        continue
-                    kids = [pos.get((int(j["pu_x"]) + 32 * (q & 1), int(j["pu_y"]) + 32 * (q >> 1), 32)) for q in range(4)]
-                    fam.append(k)
-                    if all(c is not None for c in kids):
-                        fam += kids
-                        used.update(kids)
-                fam += [k for k, j in enumerate(j0) if j["w"] == 32 and k not in used]
-                fam = np.array(fam)
-                assert len(fam) == cnt and len(set(fam.tolist())) == cnt
-                parts, index = [p_[fam] for p_ in parts], [x_[fam] for x_ in index]
-            cj, ci = np.concatenate(parts), np.concatenate(index)
+            sizes = sorted(set(int(w_) for w_ in host_jobs[0]["w"][first:first + cnt]))
+            # workload.class_job_list: pair-major, job.reserved = pair; the 64 + 32 class of `families` in quadtree order
+            cj, ci = workload.class_job_list(host_jobs, sizes, families=dim == 64 and args.launch == "families")
+            assert len(cj) == cnt * B
             if dim == 64 and args.launch != "families":
                 order = np.argsort(-cj["w"].astype(np.int64), kind="stable")
                 cj, ci = cj[order], ci[order]
@@ -799,6 +778,28 @@ def main():
                         "ms_intra_bidir_choice": m["ms_costs"],
                         "frame_costs_per_s": m["frames"] / (m["ms_search"] + m["ms_costs"]) * 1e3,
                         "searched_cus_per_s": m["fields"] * m["cus"] / (m["ms_search"] * 1e-3)}
+                progress("other paths: the headline's searches on a noise clip and on a static clip")
+                kinds = {}
+                for kind in ("noise", "static"):
+                    cls, (f0, f1, kj, kr) = measure.pattern_search_clip(es, dev, kind, pairs=8)
+                    # parity gate: a seeded sample of pair 0's PUs of every size through the oracle
+                    pick = np.concatenate([np.random.default_rng(3).choice(np.flatnonzero(kj["w"] == s_), n_, replace=False)
+                                           for s_, n_ in ((64, 24), (32, 48), (16, 96), (8, 192))])
+                    cur_, org_, st_ = pad_plane(f1, 128)
+                    ref_, _, _ = pad_plane(f0, 128)
+                    exp = orc.me_search_batch(orc.make_ctx(8, cur_, org_, st_, [ref_], org_, st_, False, 32, METHODS["star"], 5), kj[pick])
+                    if not all(np.array_equal(exp[k_], kr[pick][k_]) for k_ in ("mv", "cost", "sad_calls", "subpel_calls")):
+                        print("PARITY FAILURE: %s clip: GPU results differ from the oracle" % kind, file=sys.stderr)
+                        sys.exit(2)
+                    ms_ = sum(v["ms"] for v in cls.values())
+                    px_ = sum(v["pixel_sads"] for v in cls.values())
+                    kinds[kind] = {"ms_per_8_frame_pairs": ms_, "value": px_ / ms_ / 1e6, "unit": "Gpixel-SAD/s",
+                                   "pu_searches": sum(v["pus"] for v in cls.values()),
+                                   "per_class": {k_: {"pus": v["pus"], "ms": v["ms"], "marked_frac": v["marked_frac"],
+                                                      "ns_per_pu": v["ms"] * 1e6 / v["pus"],
+                                                      "Gpixel_SAD_per_s": v["pixel_sads"] / v["ms"] / 1e6} for k_, v in cls.items()},
+                                   "parity": "360 PUs of the first frame pair (24 / 48 / 96 / 192 of 64 / 32 / 16 / 8 samples, seeded) "
+                                             "compared with the oracle: MVs, costs, visit counts"}
                 progress("other paths: motion compensation, bi-prediction")
                 mc = measure.mc_picture(es, dev)
                 bp = measure.bipred_picture(es, dev)
@@ -811,6 +812,12 @@ def main():
                 rk10 = measure.rk_picture(e10, dev, qp=42)
                 e10.close()
                 out["other_paths"] = {
+                    "me1080p_noise": dict(kinds["noise"], workload="the headline's searches (1080p 8-bit, --me star --merange 57 --subme 5, every square "
+                                          "64/32/16/8 PU, predictors from the lookahead field) on a clip of independent uniform noise frames: the "
+                                          "pattern search's worst case, most PUs run on past the first three rounds (marked_frac) through raster "
+                                          "and re-centred patterns; 8 frame pairs, the three launch classes one after the other on one stream"),
+                    "me1080p_static": dict(kinds["static"], workload="the same on a clip whose frames are all alike: the best case, every search "
+                                           "ends at its start"),
                     "main10_4k": {"workload": "3840x2160 10-bit, --me star --merange 57 --subme 5, all 64/32/16/8 square PUs of one "
                                               "picture against one reference (BASELINE configs[3], per reference)",
                                   "ms_per_picture_reference": m10["ms"], "pu_searches": m10["pus"],

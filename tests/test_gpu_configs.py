@@ -78,11 +78,15 @@ def test_4k_exhaustive_search_three_refs(engine8, oracle):
     wcu, hcu = (W // 2 + 7) // 8, (H // 2 + 7) // 8
     la = rng.integers(-16, 17, (wcu * hcu, 2)).astype(np.int16)
     jobs64 = workload.square_pu_jobs(W, H, la, wcu, hcu, MR, sizes=(64,))
+    jobs32 = workload.square_pu_jobs(W, H, la, wcu, hcu, MR, sizes=(32,))
     jobs16 = workload.square_pu_jobs(W, H, la, wcu, hcu, MR, sizes=(16,))
+    jobs8 = workload.square_pu_jobs(W, H, la, wcu, hcu, MR, sizes=(8,))
     for r in range(3):   # 3 reference pictures, one search batch each
         ref, _, _ = pad_plane(clip[r], M)
         pr = engine8.upload_plane(ref, W, H, M, M, stride)
-        for jobs, n in ((jobs64, 6), (jobs16, 24)):
+        # the first reference with all four PU sizes (the 8x8 and 16x16 scans have routines of their own, and a 185 x 185
+        # range is scanned in strips at every size), the others with two
+        for jobs, n in ((jobs64, 6), (jobs16, 24)) + (((jobs32, 12), (jobs8, 24)) if r == 0 else ()):
             res = engine8.search_batch(pc, pr, jobs, 32, METHODS["full"], 5)
             idx, sub = _sample(jobs, n, 100 + r)
             mv, cost, sc, qc = oracle_search(oracle, 8, cur, [ref], org, stride, sub, 32, METHODS["full"], 5)
@@ -163,3 +167,64 @@ def test_8k_lookahead_field(engine8, oracle):
     mvs, costs, stats = engine8.lookahead_fields([(la[0], lb)], wcu, hcu, 12, 1, 1, 16, want_stats=True)
     assert np.array_equal(mvs[0], mv) and np.array_equal(costs[0], cost)
     assert int(stats["sad_calls"].sum()) == st.sad_calls and int(stats["subpel_calls"].sum()) == st.subpel_calls
+
+
+def test_1080p_headline_launch_lists(engine8, oracle):
+    """The launches of the benchmark's step as bench.py builds them (workload.class_job_list): per PU class one job list
+    over several frame pairs for x265amd_search_batch_pairs_dev -- the 64x64 PUs each followed by their four 32x32 children,
+    the 16x16 PUs, the 8x8 PUs -- with the statement that the lists hold only squares. Two frame pairs: one of steady
+    motion, where nearly every search ends with its first three pattern rounds, and one across the clip's wrap-around
+    (a jump of 29 samples the lookahead cannot follow), where many PUs are handed on to the resumed search. A sample
+    of more than 200 PUs, marked ones among them, against the oracle."""
+    from x265_amd.engine import RESULT_DTYPE, SQUARE_ONLY
+    W, H, M, MR, QP = 1920, 1080, 128, 57, 32
+    clip = make_clip(W, H, 12, seed=1234)
+    frames = [(1, 0), (11, 10)]
+    up = {}
+    for f in {f for pr_ in frames for f in pr_}:
+        buf, org, stride = pad_plane(clip[f], M)
+        up[f] = (engine8.upload_plane(buf, W, H, M, M, stride), buf)
+    low = {f: engine8.lowres_init(up[f][0]) for f in up}
+    wcu, hcu = 120, 68
+    mvs, _, _ = engine8.lookahead_fields([(low[a][0], low[b]) for a, b in frames], wcu, hcu, 12, METHODS["hex"], 1, 16)
+    host_jobs = [workload.square_pu_jobs(W, H, mvs[i], wcu, hcu, MR) for i in range(2)]
+    d_pairs = engine8.pairs_upload([(up[a][0], up[b][0]) for a, b in frames])
+    res = [np.zeros(len(host_jobs[0]), RESULT_DTYPE) for _ in range(2)]
+    marked = {}
+    for sizes, dim in (((64, 32), 64), ((16,), 16), ((8,), 8)):
+        cj, ci = workload.class_job_list(host_jobs, sizes, families=dim == 64)
+        if dim == 64:       # quadtree order: every 64x64 PU with all four children inside the picture is followed by them
+            k = int(np.flatnonzero(cj["w"] == 64)[0])
+            assert list(cj["w"][k:k + 5]) == [64, 32, 32, 32, 32] and (cj["pu_x"][k + 1:k + 5] - cj["pu_x"][k]).tolist() == [0, 32, 0, 32]
+        d_jobs, d_res = engine8.device_alloc(cj.nbytes), engine8.device_alloc(len(cj) * RESULT_DTYPE.itemsize)
+        engine8.upload(d_jobs, cj)
+        engine8.search_batch_pairs_dev(d_pairs, 2, d_jobs, len(cj), d_res, QP, METHODS["star"], 5, max_pu_dim=dim | SQUARE_ONLY)
+        marked[dim] = engine8.marked_count()
+        got = engine8.download(d_res, (len(cj),), RESULT_DTYPE)
+        for i in range(2):
+            sel = ci[:, 0] == i
+            res[i][ci[sel, 1]] = got[sel]
+        engine8.device_free(d_jobs)
+        engine8.device_free(d_res)
+    assert all(m > 0 for m in marked.values()), marked          # the wrap-around pair hands PUs of every class on
+    total = 0
+    for i, (a, b) in enumerate(frames):
+        jobs = host_jobs[i]
+        long_ = np.flatnonzero(res[i]["sad_calls"] > 22)        # went on past the first three rounds
+        rng = np.random.default_rng(5 + i)
+        pick = [rng.choice(np.flatnonzero(jobs["w"] == s), 20, replace=False) for s in (64, 32, 16, 8)]
+        for s in (64, 32, 16, 8):
+            of = long_[jobs["w"][long_] == s]
+            if len(of):
+                pick.append(rng.choice(of, min(12, len(of)), replace=False))
+        idx = np.unique(np.concatenate(pick))
+        total += len(idx)
+        org = M * (W + 2 * M) + M
+        mv, cost, sc, qc = oracle_search(oracle, 8, up[a][1], [up[b][1]], org, W + 2 * M, jobs[idx], QP, METHODS["star"], 5)
+        assert np.array_equal(res[i]["mv"][idx], mv) and np.array_equal(res[i]["cost"][idx], cost), i
+        assert np.array_equal(res[i]["sad_calls"][idx], sc) and np.array_equal(res[i]["subpel_calls"][idx], qc), i
+    assert total >= 200
+    engine8.device_free(d_pairs)
+    for f in up:
+        for p in [up[f][0]] + low[f]:
+            engine8.free_plane(p)

@@ -1078,6 +1078,19 @@ template<> __device__ __forceinline__ uint2 lds_quad_const<uint16_t>(int base, i
     return make_uint2(__builtin_amdgcn_alignbit(q[1], q[0], 16), __builtin_amdgcn_alignbit(q[2], q[1], 16));
 }
 
+/* sum over the wave as a scalar: four steps inside the rows of sixteen lanes, then the rows' sums handed up by the
+ * row broadcasts (lane 15 of a row into the next row, lane 31 into the upper half); the total arrives in lane 63 */
+__device__ __forceinline__ int wave_total(int v)
+{
+    v += dpp_all<0xB1>(v);
+    v += dpp_all<0x4E>(v);
+    v += dpp_all<0x141>(v);
+    v += dpp_all<0x140>(v);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);      /* row_bcast:15 into rows 1 and 3 */
+    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);      /* row_bcast:31 into rows 2 and 3 */
+    return __builtin_amdgcn_readlane(v, 63);
+}
+
 /* ---------------------------------------------------------------- the same for 32x32 and 64x64 PUs
  *
  * A workgroup of one / two waves per PU (StarBigGeo), everything about the PU uniform across it. The start-up candidates go
@@ -1087,15 +1100,6 @@ template<> __device__ __forceinline__ uint2 lds_quad_const<uint16_t>(int base, i
  * The sums meet in LDS cells. The 20 points of the first three rounds are SADs from the (S + 8)^2 window staged over
  * the dead planes, every thread a strip four samples wide, the sums of sixteen lanes at a time added to the point's cell. The
  * fold over the rounds and the hand-over to star_resume_kernel are star_small_kernel's. */
-template<int S> struct StarBigLds
-{
-    typedef SmallGeo<S> G;
-    static constexpr int CELLS = SM_FIXED;                          /* 8 cells of the start-up slots, then 20 of the star points */
-    static constexpr int PLANES = CELLS + 128;
-    static_assert((S + 8) * (S + 12) * 2 + 8 <= 2 * G::PLANE, "the window of the star points (16-bit samples) fits the two planes");
-    static constexpr int TOTAL = PLANES + 2 * G::PLANE + 32;
-};
-
 /* Small workgroups on purpose: next to launches of one-wave workgroups a workgroup of four waves waits long for a
  * compute unit with four free places at once (measured: the launch of the 32x32 PUs took 2.3 ms in the step against
  * 0.4 ms alone). */
@@ -1105,6 +1109,15 @@ template<int S> struct StarBigGeo
     static constexpr int THREADS = WAVES * 64;
     static constexpr int ITEMS = SmallGeo<S>::LPP / THREADS;        /* (tile, column) pairs per thread */
     static constexpr int NQ = S * S / (4 * THREADS);                /* quad rows per thread: a strip four samples wide */
+};
+
+template<int S> struct StarBigLds
+{
+    typedef SmallGeo<S> G;
+    static constexpr int CELLS = SM_FIXED;                          /* per wave: 8 cells of the start-up slots, then 20 of the star points */
+    static constexpr int PLANES = CELLS + 128 * StarBigGeo<S>::WAVES;
+    static_assert((S + 8) * (S + 12) * 2 + 8 <= 2 * G::PLANE, "the window of the star points (16-bit samples) fits the two planes");
+    static constexpr int TOTAL = PLANES + 2 * G::PLANE + 32;
 };
 
 template<int S, typename P>
@@ -1137,8 +1150,9 @@ __global__ __launch_bounds__(StarBigGeo<S>::THREADS) void star_big_kernel(Search
     const int roff = puy * rstride + pux;
     const uint16_t AS1 *ctab = (const uint16_t AS1*)a.ctab;
     small_load_taps<P>(tid, depth);
-    int *cells = (int*)(x265amd_smem + L::CELLS);
-    if (tid < 32) cells[tid] = 0;
+    constexpr int WAVES = StarBigGeo<S>::WAVES;
+    int *cells = (int*)(x265amd_smem + L::CELLS);                   /* [wave][32]: every wave's sums; a slot that is off stays unread */
+    const int wave = tid >> 6;
 
     /* ---- start-up candidates, motion.cpp:575-621 ---- */
     const int qmnx = as_i16(mnx << 2), qmny = as_i16(mny << 2), qmxx = as_i16(mxx << 2), qmxy = as_i16(mxy << 2);
@@ -1209,14 +1223,20 @@ __global__ __launch_bounds__(StarBigGeo<S>::THREADS) void star_big_kernel(Search
             for (int u = 0; u < ITEMS; u++) v += small_column_cost<S>(poff, 0, ky & 3, false, ct[u], tid & 3, depth);
             pb ^= 1;
         }
-        v = seg_sum(v, 6);
-        if (lane == 0) atomicAdd(cells + k, v);
+        v = wave_total(v);
+        if (lane == 0) cells[wave * 32 + k] = v;
     }
     __syncthreads();
     /* the reference's sequence of tests on the measured costs (motion.cpp:579-621) */
     int cst[SM_SLOTS];
 #pragma unroll
-    for (int k = 0; k < SM_SLOTS; k++) cst[k] = uni(cells[k]) + __builtin_amdgcn_readlane(mvc, k);
+    for (int k = 0; k < SM_SLOTS; k++)
+    {
+        int v = __builtin_amdgcn_readlane(mvc, k);
+#pragma unroll
+        for (int w = 0; w < WAVES; w++) v += uni(cells[w * 32 + k]);
+        cst[k] = v;
+    }
     int bprecost = cst[0], bcost = bprecost;
     unsigned nsad = 0, nsub = 1;
     if (fpOn) { bcost = cst[1]; nsad++; }
@@ -1274,8 +1294,8 @@ __global__ __launch_bounds__(StarBigGeo<S>::THREADS) void star_big_kernel(Search
             if (okx && oky)
             {
                 npts++;
-                const int v = seg_sum(pv[p], 4);
-                if ((lane & 15) == 0) atomicAdd(cells + 8 + p, v);
+                const int v = wave_total(pv[p]);
+                if (lane == 0) cells[wave * 32 + 8 + p] = v;
             }
         }
     }
@@ -1288,7 +1308,12 @@ __global__ __launch_bounds__(StarBigGeo<S>::THREADS) void star_big_kernel(Search
         star_point(lane, dx, dy);
         const int x = as_i16(bmx + dx), y = as_i16(bmy + dy);
         if ((dy >= 0 || y >= mny) && (dy <= 0 || y <= mxy) && (dx >= 0 || x >= mnx) && (dx <= 0 || x <= mxx))
-            key = ((cells[8 + lane] + (((int)ctab[as_i16(x << 2) - mvpx] + (int)ctab[as_i16(y << 2) - mvpy]) & 0xffff)) << 6) | lane;
+        {
+            int v = 0;
+#pragma unroll
+            for (int w = 0; w < WAVES; w++) v += cells[w * 32 + 8 + lane];
+            key = ((v + (((int)ctab[as_i16(x << 2) - mvpx] + (int)ctab[as_i16(y << 2) - mvpy]) & 0xffff)) << 6) | lane;
+        }
     }
     const int rkey0 = wave_min(lane < 4 ? key : 0x7fffffff), rkey1 = wave_min(lane >= 4 && lane < 12 ? key : 0x7fffffff),
               rkey2 = wave_min(lane >= 12 ? key : 0x7fffffff);
