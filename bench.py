@@ -404,7 +404,7 @@ def main():
     split = args.launch in ("split", "split3", "pairs3", "pairs4", "families")
     eb = Engine(local_rank, 8, high_priority=args.prio == "big") if split else es   # stream of the 64/32 class
     ebs = [eb] + [Engine(local_rank, 8) for _ in range(args.big_streams - 1)] if split else [es]
-    em = Engine(local_rank, 8) if args.launch in ("split3", "pairs3", "pairs4", "families") else es   # stream of the 16x16 class
+    em = Engine(local_rank, 8) if args.launch in ("split3", "pairs3", "pairs4") else es   # stream of the 16x16 class
     e32 = {"big": eb, "mid": em, "la": el, "own": None}[args.s32] or Engine(local_rank, 8)     # stream of the 32x32 class (pairs4)
     B = args.pairs
     clip = make_clip(W, H, B + 1, seed=1234 + rank)
@@ -436,7 +436,9 @@ def main():
                 return (int(idx[0]), len(idx), dim, eng)
             if args.launch == "split":
                 segs = [seg(jobs["w"] <= 16, 16, es), seg(jobs["w"] >= 32, 64, eb)]
-            elif args.launch in ("split3", "pairs3", "families"):
+            elif args.launch == "families":
+                segs = [seg(jobs["w"] <= 16, 16, es), seg(jobs["w"] >= 32, 64, eb)]
+            elif args.launch in ("split3", "pairs3"):
                 segs = [seg(jobs["w"] == 8, 8, es), seg(jobs["w"] == 16, 16, em), seg(jobs["w"] >= 32, 64, eb)]
             elif args.launch == "pairs4":
                 segs = [seg(jobs["w"] == 8, 8, es), seg(jobs["w"] == 16, 16, em), seg(jobs["w"] == 32, 32, e32),
@@ -456,7 +458,13 @@ def main():
         for (first, cnt, dim, eng) in segs:
             sizes = sorted(set(int(w_) for w_ in host_jobs[0]["w"][first:first + cnt]))
             # workload.class_job_list: pair-major, job.reserved = pair; the 64 + 32 class of `families` in quadtree order
-            cj, ci = workload.class_job_list(host_jobs, sizes, families=dim == 64 and args.launch == "families")
+            if dim == 16 and args.launch == "families":
+                # the 16x16 PUs and, as a list of its own, their 8x8 children (4 k + q = quadrant q of parent k): one launch
+                pj_, pi_, kj_, ki_ = workload.family_lists(host_jobs, 16)
+                cj, ci = np.concatenate([pj_, kj_]), np.concatenate([pi_, ki_])
+                fam_parents = len(pj_)
+            else:
+                cj, ci = workload.class_job_list(host_jobs, sizes, families=args.launch == "families")
             assert len(cj) == cnt * B
             if dim == 64 and args.launch != "families":
                 order = np.argsort(-cj["w"].astype(np.int64), kind="stable")
@@ -513,8 +521,13 @@ def main():
                 if c == 0 and k is not None:
                     ev1[k].record(s_search)
                 continue
-            eng.search_batch_pairs_dev(d_pairs, B, cls_jobs[c].data_ptr(), cls_jobs[c].shape[0], cls_res[c].data_ptr(),
-                                       QP, method, SUBME, max_pu_dim=dim | SQUARE_ONLY)      # every list holds squares only
+            if dim == 16 and args.launch == "families":
+                eng.search_batch_pairs_family_dev(d_pairs, B, cls_jobs[c].data_ptr(), fam_parents, cls_res[c].data_ptr(),
+                                                  cls_jobs[c].data_ptr() + 40 * fam_parents, cls_jobs[c].shape[0] - fam_parents,
+                                                  cls_res[c].data_ptr() + 16 * fam_parents, QP, SUBME)
+            else:
+                eng.search_batch_pairs_dev(d_pairs, B, cls_jobs[c].data_ptr(), cls_jobs[c].shape[0], cls_res[c].data_ptr(),
+                                           QP, method, SUBME, max_pu_dim=dim | SQUARE_ONLY)      # every list holds squares only
             if c == 0 and k is not None:
                 ev1[k].record(s_search)
         if not sync_steps:

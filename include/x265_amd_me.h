@@ -160,6 +160,19 @@ int x265amd_search_batch_pairs(x265amd_ctx *ctx, const x265amd_pair *pairs, int 
 int x265amd_search_batch_pairs_dev(x265amd_ctx *ctx, const void *d_pairs, int npairs, int qp, int method, int subme,
                                    const x265amd_job *d_jobs, int njobs, x265amd_result *d_results, int max_pu_dim);
 
+/* An X265_STAR_SEARCH launch of the 16x16 PUs and of the 8x8 PUs of the pictures in flight as one: two calls of
+ * x265amd_search_batch_pairs_dev (max_pu_dim 16 | X265AMD_SQUARE_ONLY, then 8 | X265AMD_SQUARE_ONLY) give the same results.
+ * The lists hold only squares of their size. Where PU 4 k + q (q = 0 .. 3) of the children's list is quadrant q
+ * (raster order) of PU k of the parents' list, searches the same pictures and starts its sub-pel rounds from the parent's
+ * MV, the parent takes it through those rounds: SAD and SATD are sums over 4x4 tiles, so the child's candidates cost a few
+ * instructions beside the parent's instead of a refinement of their own (encoder/motion.cpp:1071-1141 for both; the
+ * quadtree of TEncCu::xCompressCU, Lib/TLibEncoder/TEncCu.cpp:2352, is why the callers have both). Children anywhere
+ * else in their list, or whose decisions leave the parent's, are refined on their own: the order of the lists changes no
+ * result. marked_count afterwards counts the parents' list. Samples of at most 10 bits. */
+int x265amd_search_batch_pairs_family_dev(x265amd_ctx *ctx, const void *d_pairs, int npairs, int qp, int subme,
+                                          const x265amd_job *d_parents, int nparents, x265amd_result *d_parent_results,
+                                          const x265amd_job *d_children, int nchildren, x265amd_result *d_child_results);
+
 /* The checks x265amd_search_batch makes on host job arrays (partition of motion.cpp:119, numc, range, PU inside the
  * source plane, search window + 8-tap apron inside the padded reference: what xSetSearchRange, TEncSearch.cpp:4188-4215,
  * and the caller's margins guarantee in the reference), for a DEVICE-resident job list, which the *_dev entry points run

@@ -171,8 +171,9 @@ def test_8k_lookahead_field(engine8, oracle):
 
 def test_1080p_headline_launch_lists(engine8, oracle):
     """The launches of the benchmark's step as bench.py builds them (workload.class_job_list): per PU class one job list
-    over several frame pairs for x265amd_search_batch_pairs_dev -- the 64x64 PUs each followed by their four 32x32 children,
-    the 16x16 PUs, the 8x8 PUs -- with the statement that the lists hold only squares. Two frame pairs: one of steady
+    over several frame pairs -- the 64x64 PUs each followed by their four 32x32 children (x265amd_search_batch_pairs_dev with the
+    statement that the list holds only squares), the 16x16 PUs and the list of their 8x8 children
+    (x265amd_search_batch_pairs_family_dev). Two frame pairs: one of steady
     motion, where nearly every search ends with its first three pattern rounds, and one across the clip's wrap-around
     (a jump of 29 samples the lookahead cannot follow), where many PUs are handed on to the resumed search. A sample
     of more than 200 PUs, marked ones among them, against the oracle."""
@@ -191,19 +192,38 @@ def test_1080p_headline_launch_lists(engine8, oracle):
     d_pairs = engine8.pairs_upload([(up[a][0], up[b][0]) for a, b in frames])
     res = [np.zeros(len(host_jobs[0]), RESULT_DTYPE) for _ in range(2)]
     marked = {}
-    for sizes, dim in (((64, 32), 64), ((16,), 16), ((8,), 8)):
-        cj, ci = workload.class_job_list(host_jobs, sizes, families=dim == 64)
-        if dim == 64:       # quadtree order: every 64x64 PU with all four children inside the picture is followed by them
+    for dim in (64, 16):
+        if dim == 64:
+            cj, ci = workload.class_job_list(host_jobs, (64, 32), families=True)
+            # quadtree order: every 64x64 PU with all four children inside the picture is followed by them
             k = int(np.flatnonzero(cj["w"] == 64)[0])
             assert list(cj["w"][k:k + 5]) == [64, 32, 32, 32, 32] and (cj["pu_x"][k + 1:k + 5] - cj["pu_x"][k]).tolist() == [0, 32, 0, 32]
+            npar = 0
+        else:
+            # the 16x16 PUs and the list of their 8x8 children: 4 k + q = quadrant q of parent k
+            pj, pi, kj, ki = workload.family_lists(host_jobs, 16)
+            k = len(pj) - 7
+            assert (kj["pu_x"][4 * k:4 * k + 4] - pj["pu_x"][k]).tolist() == [0, 8, 0, 8] and (kj["reserved"][4 * k:4 * k + 4] == pj["reserved"][k]).all()
+            cj, ci, npar = np.concatenate([pj, kj]), np.concatenate([pi, ki]), len(pj)
         d_jobs, d_res = engine8.device_alloc(cj.nbytes), engine8.device_alloc(len(cj) * RESULT_DTYPE.itemsize)
         engine8.upload(d_jobs, cj)
-        engine8.search_batch_pairs_dev(d_pairs, 2, d_jobs, len(cj), d_res, QP, METHODS["star"], 5, max_pu_dim=dim | SQUARE_ONLY)
+        if dim == 64:
+            engine8.search_batch_pairs_dev(d_pairs, 2, d_jobs, len(cj), d_res, QP, METHODS["star"], 5, max_pu_dim=dim | SQUARE_ONLY)
+        else:
+            engine8.search_batch_pairs_family_dev(d_pairs, 2, d_jobs, npar, d_res, d_jobs + 40 * npar, len(cj) - npar,
+                                                  d_res + 16 * npar, QP, 5)
         marked[dim] = engine8.marked_count()
         got = engine8.download(d_res, (len(cj),), RESULT_DTYPE)
         for i in range(2):
             sel = ci[:, 0] == i
             res[i][ci[sel, 1]] = got[sel]
+        if dim == 16:
+            # the same two lists as launches of their own: identical records
+            for off, n_, d_ in ((0, npar, 16), (npar, len(cj) - npar, 8)):
+                engine8.search_batch_pairs_dev(d_pairs, 2, d_jobs + 40 * off, n_, d_res + 16 * off, QP, METHODS["star"], 5,
+                                               max_pu_dim=d_ | SQUARE_ONLY)
+            again = engine8.download(d_res, (len(cj),), RESULT_DTYPE)
+            assert np.array_equal(again, got)
         engine8.device_free(d_jobs)
         engine8.device_free(d_res)
     assert all(m > 0 for m in marked.values()), marked          # the wrap-around pair hands PUs of every class on

@@ -63,6 +63,12 @@ struct SearchArgs
                       the list has them behind one (refine_big_kernel<64>), by refine_big_kernel<32> otherwise; else 0 */
     unsigned char *done;   /* null, or per job: refined already (set by refine_big_kernel<64> for the children it took along) */
     int *state;            /* per job 8 ints: where a STAR search stands that a fixed-shape kernel began (StarFold::store) */
+    /* null, or the list of 8x8 PUs launched with this list of 16x16 PUs: PU 4 k + q of it is taken along by PU k of this
+     * list through the sub-pel rounds where it is that PU's quadrant q and starts from the same MV */
+    const x265amd_job *cjobs;
+    x265amd_result *cresults;
+    int ncjobs;
+    unsigned char *cmark, *cdone;
     unsigned char *mark;   /* null, or per job: 1 = a STAR kernel handed this PU on (it is in the redo list), 0 = it did not */
     int list;              /* refinement kernels: 1 = refine the PUs of the redo list instead of those of the job list */
 };
@@ -91,36 +97,33 @@ __device__ __forceinline__ void job_planes(const SearchArgs &a, const x265amd_jo
  * launch behind it costs what the marked PUs cost and not a wave per PU of the launch. `redo` (ints): [0] the number
  * of marked PUs (star_small_kernel zeroes it), [REDO_LIST ..) their job indices, a block's entries together and in job
  * order, the blocks in the order their reservations arrive (the searches do not depend on each other). */
-#define REDO_CHUNK 2048                /* jobs per block: one atomic reservation per block */
+#define REDO_CHUNK 1024                /* jobs per block (one wave: a block of several waves waits long for room next to
+                                          launches of one-wave blocks): one atomic reservation per block */
 #define REDO_LIST 64                   /* ints in front of the list */
 #define REDO_GRID 8192                 /* waves of the search launch that walks the list */
 
-__global__ __launch_bounds__(256) void redo_list_kernel(const x265amd_result *results, int njobs, int *redo)
+__global__ __launch_bounds__(64) void redo_list_kernel(const x265amd_result *results, int njobs, int *redo)
 {
-    __shared__ int part[REDO_CHUNK / 64];
-    __shared__ int first;
-    const int base = blockIdx.x * REDO_CHUNK, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    bool m[REDO_CHUNK / 256];
-    unsigned long long bal[REDO_CHUNK / 256];
+    const int base = blockIdx.x * REDO_CHUNK, lane = threadIdx.x;
+    unsigned long long bal[REDO_CHUNK / 64];
+    int n = 0;
 #pragma unroll
-    for (int k = 0; k < REDO_CHUNK / 256; k++)
+    for (int k = 0; k < REDO_CHUNK / 64; k++)
     {
-        const int j = base + k * 256 + (int)threadIdx.x;
-        m[k] = j < njobs && results[j].sad_calls >= SMALL_RESUME;
-        bal[k] = __ballot(m[k]);
-        if (lane == 0) part[k * 4 + wave] = __popcll(bal[k]);
+        const int j = base + k * 64 + lane;
+        bal[k] = __ballot(j < njobs && results[j].sad_calls >= SMALL_RESUME);
+        n += __popcll(bal[k]);
     }
-    __syncthreads();
-    if (threadIdx.x == 0)
-    {
-        int n = 0;
-        for (int i = 0; i < REDO_CHUNK / 64; i++) { const int c = part[i]; part[i] = n; n += c; }
-        first = n ? atomicAdd(redo, n) : 0;
-    }
-    __syncthreads();
+    if (!n) return;
+    int first = 0;
+    if (lane == 0) first = atomicAdd(redo, n);
+    first = __builtin_amdgcn_readfirstlane(first);
 #pragma unroll
-    for (int k = 0; k < REDO_CHUNK / 256; k++)
-        if (m[k]) redo[REDO_LIST + first + part[k * 4 + wave] + __popcll(bal[k] & ((1ull << lane) - 1))] = base + k * 256 + (int)threadIdx.x;
+    for (int k = 0; k < REDO_CHUNK / 64; k++)
+    {
+        if ((bal[k] >> lane) & 1) redo[REDO_LIST + first + __popcll(bal[k] & ((1ull << lane) - 1))] = base + k * 64 + lane;
+        first += __popcll(bal[k]);
+    }
 }
 
 template<typename P, bool LOWRES>
@@ -847,12 +850,19 @@ struct x265amd_ctx
     void *d_stage; size_t stage_cap;   /* staging for the per-call primitives */
     int probe_khz;                     /* constant-rate clock of the last x265amd_clock_probe_start, kHz */
     long long *d_probe;                /* the probe wave's two counters (a buffer of its own: other calls may run meanwhile) */
-    void *d_done; size_t done_cap;     /* per job of a launch: refined with its parent (refine_big_kernel<64>) */
-    void *d_redo; size_t redo_cap;     /* list of the PUs a fixed-shape kernel left to the one-wave search (redo_list_kernel) */
-    void *d_state; size_t state_cap;   /* per job of a launch: where the STAR search of a marked PU stands (StarFold::store) */
-    void *d_mark; size_t mark_cap;     /* per job of a launch: handed on by the STAR kernels */
-    hipStream_t aux;                   /* second stream of STAR launches: the marked PUs' searches run beside the others' refinement */
-    hipEvent_t ev_fork, ev_join;
+    /* Working arrays of a search launch, per job of its list; two sets, the second for the children's list of a
+     * launch of parents and children (x265amd_search_batch_pairs_family_dev) */
+    struct LaunchBufs
+    {
+        void *d_done; size_t done_cap;     /* refined with its parent already */
+        void *d_redo; size_t redo_cap;     /* list of the PUs a fixed-shape kernel handed on (redo_list_kernel) */
+        void *d_state; size_t state_cap;   /* where the STAR search of a handed-on PU stands (StarFold::store) */
+        void *d_mark; size_t mark_cap;     /* handed on by the STAR kernels */
+    } bufs[2];
+    hipStream_t aux;                   /* second stream of STAR launches: the marked PUs' searches run beside the others' refinement;
+                                          made by the first such launch (a context that never searches this way holds no queue for it) */
+    int prio;
+    hipEvent_t ev_fork, ev_join, ev_a, ev_b;
     bool redo_valid;                   /* d_redo[0] holds the marked-PU count of this context's last search launch */
     int32_t *d_out;
     int *d_ticket;                     /* row hand-out counter of the row-parallel lookahead kernel */
@@ -946,7 +956,8 @@ static void launch_refine(const SearchArgs &b, hipStream_t st, int list_grid)
 {
     const int n = b.njobs;
     if (b.staged == 8)
-        hipLaunchKernelGGL((refine_small_kernel<8, P>), dim3(list_grid ? list_grid : (n + 3) / 4), dim3(64), RefineLds<8>::TOTAL, st, b);
+        hipLaunchKernelGGL((refine_small_kernel<8, P>), dim3(list_grid ? list_grid : b.done ? (n + 63) / 64 : (n + 3) / 4), dim3(64),
+                           RefineLds<8>::TOTAL, st, b);
     else if (b.staged == 16)
         hipLaunchKernelGGL((refine_small_kernel<16, P>), dim3(list_grid ? list_grid : (n + RefineGeo<16>::NPU - 1) / RefineGeo<16>::NPU), dim3(64),
                            RefineLds<16>::TOTAL, st, b);
@@ -963,96 +974,187 @@ static void launch_refine(const SearchArgs &b, hipStream_t st, int list_grid)
 /* waves of a launch of search_kernel: a wave per PU up to this many, then every wave walks the list */
 #define SEARCH_GRID 8192
 
+/* A full-resolution search launch in phases. prepare: which sizes take the fixed-shape kernels, working arrays.
+ * STAR launches of those sizes then run star (start-up candidates + first three pattern rounds of every PU, on the
+ * context's stream), side (the PUs handed on: list, rest of their searches, their refinement, on the stream given)
+ * and refine (everything else, on the context's stream); other launches run the one-wave search and refine. */
+struct SearchLaunch
+{
+    SearchArgs b;
+    bool star, square_only;
+    int set;
+};
+
+template<typename P>
+static int search_prepare(x265amd_ctx *c, const SearchArgs &a, bool square_only, int set, SearchLaunch &sl)
+{
+    static const bool no_staged = getenv("X265AMD_NO_STAGED") != 0;                            /* measurements only */
+    static const bool no_star = getenv("X265AMD_NO_STAR8") != 0;
+    static const bool no_big = getenv("X265AMD_NO_STAGED_BIG") != 0;
+    static const bool no_star_big = getenv("X265AMD_NO_STAR_BIG") != 0;
+    static const bool no_quad = getenv("X265AMD_NO_QUAD") != 0;
+    x265amd_ctx::LaunchBufs &B = c->bufs[set];
+    SearchArgs &b = sl.b;
+    b = a;
+    sl.square_only = square_only; sl.set = set;
+    /* launches of PUs up to 8x8, 16x16, 32x32 or 64x64 (samples of at most 10 bits): the square PUs of that size are
+     * refined by a second kernel (four 8x8 PUs or two 16x16 PUs per wave; two waves per 32x32 PU, four per 64x64 PU) */
+    b.staged = (sizeof(P) == 1 || c->depth <= 10) && !no_staged &&
+               (a.max_dim == 8 || a.max_dim == 16 || ((a.max_dim == 32 || a.max_dim == 64) && !no_big)) ? a.max_dim : 0;
+    if (b.staged == 64 && !no_quad)
+    {
+        /* a launch for 64x64 PUs takes the 32x32 PUs of its list through the fixed-shape kernels as well; they are
+         * refined together with their parent where the list has the four children right behind it */
+        if (ensure(c, &B.d_done, &B.done_cap, (size_t)a.njobs)) return X265AMD_EHIP;      /* cleared by the STAR kernels */
+        b.staged2 = 32;
+        b.done = (unsigned char*)B.d_done;
+    }
+    sl.star = b.staged && a.method == X265AMD_STAR && !no_star && (b.staged <= 16 || !no_star_big);
+    if (sl.star)
+    {
+        if (ensure(c, &B.d_redo, &B.redo_cap, sizeof(int) * ((size_t)REDO_LIST + a.njobs))) return X265AMD_EHIP;
+        if (ensure(c, &B.d_state, &B.state_cap, 32 * (size_t)a.njobs)) return X265AMD_EHIP;
+        if (ensure(c, &B.d_mark, &B.mark_cap, (size_t)a.njobs)) return X265AMD_EHIP;
+        b.redo = (int*)B.d_redo;
+        b.state = (int*)B.d_state;
+        b.mark = (unsigned char*)B.d_mark;
+    }
+    return X265AMD_OK;
+}
+
+static int aux_stream(x265amd_ctx *c)
+{
+    if (!c->aux) HIPCHK(c, hipStreamCreateWithPriority(&c->aux, hipStreamNonBlocking, c->prio));
+    return X265AMD_OK;
+}
+
+/* STAR: start-up candidates and the first three pattern rounds of every PU in fixed-shape kernels. Most PUs end
+ * there; the others are marked and listed. */
+template<typename P>
+static int search_star(x265amd_ctx *c, SearchLaunch &sl, hipStream_t st)
+{
+    const SearchArgs &b = sl.b;
+    if (b.staged == 8)
+        hipLaunchKernelGGL((star_small_kernel<8, P>), dim3((b.njobs + 3) / 4), dim3(64), StarLds<8>::TOTAL, st, b);
+    else if (b.staged == 16)
+        hipLaunchKernelGGL((star_small_kernel<16, P>), dim3(b.njobs), dim3(64), StarLds<16>::TOTAL, st, b);
+    else
+    {
+        if (b.staged == 64)
+            hipLaunchKernelGGL((star_big_kernel<64, P>), dim3(b.njobs), dim3(StarBigGeo<64>::THREADS), StarBigLds<64>::TOTAL, st, b);
+        if (b.staged == 32 || b.staged2 == 32)
+            hipLaunchKernelGGL((star_big_kernel<32, P>), dim3(b.njobs), dim3(StarBigGeo<32>::THREADS), StarBigLds<32>::TOTAL, st, b);
+    }
+    return X265AMD_OK;
+}
+
+/* the PUs the STAR kernels handed on: star_resume_kernel takes their searches to the end, the PUs that are no
+ * fixed-shape kernel's (other shapes in the list) go through the one-wave search from the start, and the list-driven
+ * refinement finishes them */
+template<typename P>
+static void search_side(x265amd_ctx *c, SearchLaunch &sl, hipStream_t side)
+{
+    static const int pad = getenv("X265AMD_LDS_PAD") ? atoi(getenv("X265AMD_LDS_PAD")) : 0;   /* occupancy experiments */
+    const SearchArgs &b = sl.b;
+    const int blocks = (b.njobs + REDO_CHUNK - 1) / REDO_CHUNK, lgrid = b.njobs < REDO_GRID ? b.njobs : REDO_GRID;
+    hipLaunchKernelGGL(redo_list_kernel, dim3(blocks), dim3(64), 0, side, b.results, b.njobs, b.redo);
+    hipLaunchKernelGGL((star_resume_kernel<P>), dim3(lgrid), dim3(64), wave_lds_bytes<P>(b.max_dim), side, b);
+    /* a caller that states its list holds only the squares these kernels take saves the launch that looks for others */
+    if (!sl.square_only)
+        hipLaunchKernelGGL((search_kernel<P, false>), dim3(lgrid), dim3(64), wave_lds_bytes<P>(b.max_dim, true) + pad, side, b);
+    SearchArgs l = b;
+    l.list = 1;
+    launch_refine<P>(l, side, lgrid);
+}
+
 template<typename P>
 static int launch_search(x265amd_ctx *c, const SearchArgs &a, int is_lowres, bool square_only)
 {
     c->redo_valid = false;
     if (is_lowres)
+    {
         hipLaunchKernelGGL((search_kernel<P, true>), dim3(a.njobs < SEARCH_GRID ? a.njobs : SEARCH_GRID), dim3(64), wave_lds_bytes<P>(8), c->stream, a);
+        HIPCHK(c, hipGetLastError());
+        return X265AMD_OK;
+    }
+    SearchLaunch sl;
+    int rc = search_prepare<P>(c, a, square_only, 0, sl);
+    if (rc) return rc;
+    if (sl.star)
+    {
+        if ((rc = search_star<P>(c, sl, c->stream))) return rc;
+        /* The PUs handed on are few as a rule and each a long chain of dependent steps in one wave: their
+         * searches and refinement run on the context's second stream while this one refines all the others. */
+        static const bool no_fork = getenv("X265AMD_NO_FORK") != 0;                              /* measurements only */
+        if (!no_fork)
+        {
+            if ((rc = aux_stream(c))) return rc;
+            HIPCHK(c, hipEventRecord(c->ev_fork, c->stream));
+            HIPCHK(c, hipStreamWaitEvent(c->aux, c->ev_fork, 0));
+        }
+        search_side<P>(c, sl, no_fork ? c->stream : c->aux);
+        if (!no_fork) HIPCHK(c, hipEventRecord(c->ev_join, c->aux));
+        launch_refine<P>(sl.b, c->stream, 0);
+        if (!no_fork) HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_join, 0));
+        c->redo_valid = true;
+    }
     else
     {
         static const int pad = getenv("X265AMD_LDS_PAD") ? atoi(getenv("X265AMD_LDS_PAD")) : 0;   /* occupancy experiments */
-        static const bool no_staged = getenv("X265AMD_NO_STAGED") != 0;                            /* measurements only */
-        static const bool no_star = getenv("X265AMD_NO_STAR8") != 0;
-        static const bool no_big = getenv("X265AMD_NO_STAGED_BIG") != 0;
-        static const bool no_star_big = getenv("X265AMD_NO_STAR_BIG") != 0;
-        SearchArgs b = a;
-        /* launches of PUs up to 8x8, 16x16, 32x32 or 64x64 (samples of at most 10 bits): the square PUs of that size are
-         * refined by a second kernel (four 8x8 PUs or two 16x16 PUs per wave; two waves per 32x32 PU, four per 64x64 PU) */
-        b.staged = (sizeof(P) == 1 || c->depth <= 10) && !no_staged &&
-                   (a.max_dim == 8 || a.max_dim == 16 || ((a.max_dim == 32 || a.max_dim == 64) && !no_big)) ? a.max_dim : 0;
-        if (b.staged == 64 && !getenv("X265AMD_NO_QUAD"))
+        /* a launch of large PUs that refines elsewhere interpolates only its quarter-pel start-up candidates: room
+         * for one plane instead of two lets a compute unit hold a third more of its waves */
+        static const bool lean = getenv("X265AMD_NO_LEAN") == 0;
+        int lds = wave_lds_bytes<P>(a.max_dim, true);
+        if (sl.b.staged >= 32 && lean)
         {
-            /* a launch for 64x64 PUs takes the 32x32 PUs of its list through the fixed-shape kernels as well; they are
-             * refined together with their parent where the list has the four children right behind it */
-            if (ensure(c, &c->d_done, &c->done_cap, (size_t)a.njobs)) return X265AMD_EHIP;
-            HIPCHK(c, hipMemsetAsync(c->d_done, 0, (size_t)a.njobs, c->stream));
-            b.staged2 = 32;
-            b.done = (unsigned char*)c->d_done;
+            sl.b.plane_lds = plane_budget(a.max_dim, (int)sizeof(P)) / 2;
+            lds -= sl.b.plane_lds;
         }
-        const int grid = a.njobs < SEARCH_GRID ? a.njobs : SEARCH_GRID;
-        const bool star = b.staged && a.method == X265AMD_STAR && !no_star && (b.staged <= 16 || !no_star_big);
-        if (star)
-        {
-            /* STAR: start-up candidates and the first three pattern rounds of every PU in fixed-shape kernels. Most PUs
-             * end there; the others are listed, star_resume_kernel takes their searches to the end, and the PUs that are
-             * no fixed-shape kernel's (other shapes in the list) go through the one-wave search from the start. */
-            if (ensure(c, &c->d_redo, &c->redo_cap, sizeof(int) * ((size_t)REDO_LIST + a.njobs))) return X265AMD_EHIP;
-            if (ensure(c, &c->d_state, &c->state_cap, 32 * (size_t)a.njobs)) return X265AMD_EHIP;
-            if (ensure(c, &c->d_mark, &c->mark_cap, (size_t)a.njobs)) return X265AMD_EHIP;
-            b.redo = (int*)c->d_redo;
-            b.state = (int*)c->d_state;
-            b.mark = (unsigned char*)c->d_mark;
-            if (b.staged == 8)
-                hipLaunchKernelGGL((star_small_kernel<8, P>), dim3((a.njobs + 3) / 4), dim3(64), StarLds<8>::TOTAL, c->stream, b);
-            else if (b.staged == 16)
-                hipLaunchKernelGGL((star_small_kernel<16, P>), dim3(a.njobs), dim3(64), StarLds<16>::TOTAL, c->stream, b);
-            else
-            {
-                HIPCHK(c, hipMemsetAsync(c->d_redo, 0, sizeof(int), c->stream));
-                if (b.staged == 64)
-                    hipLaunchKernelGGL((star_big_kernel<64, P>), dim3(a.njobs), dim3(StarBigGeo<64>::THREADS), StarBigLds<64>::TOTAL, c->stream, b);
-                if (b.staged == 32 || b.staged2 == 32)
-                    hipLaunchKernelGGL((star_big_kernel<32, P>), dim3(a.njobs), dim3(StarBigGeo<32>::THREADS), StarBigLds<32>::TOTAL, c->stream, b);
-            }
-            /* The PUs handed on are few as a rule and each a long chain of dependent steps in one wave: their
-             * searches and refinement run on the context's second stream while this one refines all the others. */
-            static const bool no_fork = getenv("X265AMD_NO_FORK") != 0;                              /* measurements only */
-            hipStream_t side = no_fork ? c->stream : c->aux;
-            if (!no_fork)
-            {
-                HIPCHK(c, hipEventRecord(c->ev_fork, c->stream));
-                HIPCHK(c, hipStreamWaitEvent(c->aux, c->ev_fork, 0));
-            }
-            const int blocks = (a.njobs + REDO_CHUNK - 1) / REDO_CHUNK, lgrid = a.njobs < REDO_GRID ? a.njobs : REDO_GRID;
-            hipLaunchKernelGGL(redo_list_kernel, dim3(blocks), dim3(256), 0, side, a.results, a.njobs, (int*)c->d_redo);
-            hipLaunchKernelGGL((star_resume_kernel<P>), dim3(lgrid), dim3(64), wave_lds_bytes<P>(a.max_dim), side, b);
-            /* a caller that states its list holds only the squares these kernels take saves the launch that looks for others */
-            if (!square_only)
-                hipLaunchKernelGGL((search_kernel<P, false>), dim3(lgrid), dim3(64), wave_lds_bytes<P>(a.max_dim, true) + pad, side, b);
-            SearchArgs l = b;
-            l.list = 1;
-            launch_refine<P>(l, side, lgrid);
-            if (!no_fork) HIPCHK(c, hipEventRecord(c->ev_join, c->aux));
-            launch_refine<P>(b, c->stream, 0);
-            if (!no_fork) HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_join, 0));
-            c->redo_valid = true;
-        }
-        else
-        {
-            /* a launch of large PUs that refines elsewhere interpolates only its quarter-pel start-up candidates: room
-             * for one plane instead of two lets a compute unit hold a third more of its waves */
-            static const bool lean = getenv("X265AMD_NO_LEAN") == 0;
-            int lds = wave_lds_bytes<P>(a.max_dim, true);
-            if (b.staged >= 32 && lean)
-            {
-                b.plane_lds = plane_budget(a.max_dim, (int)sizeof(P)) / 2;
-                lds -= b.plane_lds;
-            }
-            hipLaunchKernelGGL((search_kernel<P, false>), dim3(grid), dim3(64), lds + pad, c->stream, b);
-            launch_refine<P>(b, c->stream, 0);
-        }
+        hipLaunchKernelGGL((search_kernel<P, false>), dim3(a.njobs < SEARCH_GRID ? a.njobs : SEARCH_GRID), dim3(64), lds + pad, c->stream, sl.b);
+        launch_refine<P>(sl.b, c->stream, 0);
     }
+    HIPCHK(c, hipGetLastError());
+    return X265AMD_OK;
+}
+
+/* A list of 16x16 PUs and the list of their 8x8 children as one launch: both lists' STAR kernels, then both lists'
+ * handed-on PUs on the second stream while the 16x16 PUs are refined with the children they can take along, then the
+ * remaining 8x8 PUs. Results are those of two launches of their own. */
+template<typename P>
+static int launch_family(x265amd_ctx *c, const SearchArgs &parents, const SearchArgs &children)
+{
+    c->redo_valid = false;
+    SearchLaunch pa, ch;
+    int rc = search_prepare<P>(c, parents, true, 0, pa);
+    if (!rc) rc = search_prepare<P>(c, children, true, 1, ch);
+    if (rc) return rc;
+    if (!pa.star || !ch.star || pa.b.staged != 16 || ch.b.staged != 8) return fail(c, X265AMD_EINVAL, "family launch: STAR search of 16x16 and 8x8 PUs, samples of at most 10 bits");
+    static const bool no_quad = getenv("X265AMD_NO_QUAD") != 0;                                  /* measurements only */
+    if (!no_quad)
+    {
+        /* which children their parents have refined */
+        x265amd_ctx::LaunchBufs &B = c->bufs[1];
+        if (ensure(c, &B.d_done, &B.done_cap, (size_t)children.njobs)) return X265AMD_EHIP;    /* cleared by the STAR kernel */
+        ch.b.done = (unsigned char*)B.d_done;
+        pa.b.cjobs = ch.b.jobs; pa.b.cresults = ch.b.results; pa.b.ncjobs = ch.b.njobs;
+        pa.b.cmark = ch.b.mark; pa.b.cdone = ch.b.done;
+    }
+    /* the two lists' STAR kernels side by side on the two streams; then the handed-on PUs of both on the second stream */
+    if ((rc = aux_stream(c))) return rc;
+    HIPCHK(c, hipEventRecord(c->ev_fork, c->stream));
+    HIPCHK(c, hipStreamWaitEvent(c->aux, c->ev_fork, 0));
+    if ((rc = search_star<P>(c, pa, c->stream)) || (rc = search_star<P>(c, ch, c->aux))) return rc;
+    HIPCHK(c, hipEventRecord(c->ev_a, c->stream));
+    HIPCHK(c, hipEventRecord(c->ev_b, c->aux));
+    search_side<P>(c, ch, c->aux);                          /* needs the children's STAR kernel only */
+    HIPCHK(c, hipStreamWaitEvent(c->aux, c->ev_a, 0));
+    HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_b, 0));
+    search_side<P>(c, pa, c->aux);
+    HIPCHK(c, hipEventRecord(c->ev_join, c->aux));
+    launch_refine<P>(pa.b, c->stream, 0);
+    launch_refine<P>(ch.b, c->stream, 0);
+    HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_join, 0));
+    c->redo_valid = true;
     HIPCHK(c, hipGetLastError());
     return X265AMD_OK;
 }
@@ -1148,9 +1250,9 @@ static int create_ctx(int device, int bit_depth, int high_priority, x265amd_ctx 
     if (hipGetDeviceCount(&n) != hipSuccess || device < 0 || device >= n) return X265AMD_EHIP;
     x265amd_ctx *c = new x265amd_ctx();
     c->device = device; c->depth = bit_depth;
-    c->d_done = 0; c->done_cap = 0; c->d_state = 0; c->state_cap = 0; c->redo_valid = false; c->d_mark = 0; c->mark_cap = 0;
-    c->d_jobs = c->d_results = c->d_stage = c->d_redo = 0; c->d_ticket = 0; c->d_probe = 0;
-    c->jobs_cap = c->results_cap = c->stage_cap = c->redo_cap = 0; c->d_out = 0;
+    memset(c->bufs, 0, sizeof(c->bufs)); c->redo_valid = false;
+    c->d_jobs = c->d_results = c->d_stage = 0; c->d_ticket = 0; c->d_probe = 0;
+    c->jobs_cap = c->results_cap = c->stage_cap = 0; c->d_out = 0;
     c->esa_window_bytes = 0;
     c->probe_khz = 0;
     c->esa_lds_raised = c->rime_lds_raised = false;
@@ -1161,10 +1263,12 @@ static int create_ctx(int device, int bit_depth, int high_priority, x265amd_ctx 
         return X265AMD_EHIP;
     }
     const int prio = high_priority > 0 ? prio_greatest : high_priority < 0 ? prio_least : prio_least + (prio_greatest - prio_least) / 2;
+    c->aux = 0; c->prio = prio;
     if (hipStreamCreateWithPriority(&c->stream, hipStreamDefault, prio) != hipSuccess ||
-        hipStreamCreateWithPriority(&c->aux, hipStreamNonBlocking, prio) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev_a, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev_b, hipEventDisableTiming) != hipSuccess ||
         hipMalloc((void**)&c->d_out, 64) != hipSuccess || hipMalloc((void**)&c->d_ticket, 256) != hipSuccess)
     {
         delete c;
@@ -1179,8 +1283,8 @@ static int create_ctx(int device, int bit_depth, int high_priority, x265amd_ctx 
             void *ptr = 0;
             if (hipGetSymbolAddress(&ptr, HIP_SYMBOL(scratch)) != hipSuccess || !ptr)
             {
-                (void)hipFree(c->d_out); (void)hipFree(c->d_ticket); (void)hipStreamDestroy(c->stream); (void)hipStreamDestroy(c->aux);
-                (void)hipEventDestroy(c->ev_fork); (void)hipEventDestroy(c->ev_join);
+                (void)hipFree(c->d_out); (void)hipFree(c->d_ticket); (void)hipStreamDestroy(c->stream);
+                (void)hipEventDestroy(c->ev_fork); (void)hipEventDestroy(c->ev_join); (void)hipEventDestroy(c->ev_a); (void)hipEventDestroy(c->ev_b);
                 delete c;
                 return X265AMD_EHIP;
             }
@@ -1202,14 +1306,22 @@ void x265amd_destroy(x265amd_ctx *c)
     if (c->d_jobs) (void)hipFree(c->d_jobs);
     if (c->d_results) (void)hipFree(c->d_results);
     if (c->d_stage) (void)hipFree(c->d_stage);
-    if (c->d_redo) (void)hipFree(c->d_redo);
-    if (c->d_done) (void)hipFree(c->d_done);
-    if (c->d_state) (void)hipFree(c->d_state);
-    if (c->d_mark) (void)hipFree(c->d_mark);
-    (void)hipStreamSynchronize(c->aux);
-    (void)hipStreamDestroy(c->aux);
+    for (int i = 0; i < 2; i++)
+    {
+        if (c->bufs[i].d_redo) (void)hipFree(c->bufs[i].d_redo);
+        if (c->bufs[i].d_done) (void)hipFree(c->bufs[i].d_done);
+        if (c->bufs[i].d_state) (void)hipFree(c->bufs[i].d_state);
+        if (c->bufs[i].d_mark) (void)hipFree(c->bufs[i].d_mark);
+    }
+    if (c->aux)
+    {
+        (void)hipStreamSynchronize(c->aux);
+        (void)hipStreamDestroy(c->aux);
+    }
     (void)hipEventDestroy(c->ev_fork);
     (void)hipEventDestroy(c->ev_join);
+    (void)hipEventDestroy(c->ev_a);
+    (void)hipEventDestroy(c->ev_b);
     if (c->d_probe) (void)hipFree(c->d_probe);
     if (c->d_out) (void)hipFree(c->d_out);
     if (c->d_ticket) (void)hipFree(c->d_ticket);
@@ -1473,7 +1585,7 @@ static void fill_args(x265amd_ctx *c, SearchArgs &a, const x265amd_plane *fenc, 
         a.ref[i].origin = r->origin; a.ref[i].stride = r->stride;
     }
     a.lowres = is_lowres; a.depth = c->depth; a.method = method; a.subme = subme; a.max_dim = is_lowres ? 8 : 64;
-    a.staged = 0; a.staged2 = 0; a.done = 0; a.redo = 0; a.pairs = 0; a.npairs = 0; a.plane_lds = 0; a.state = 0; a.mark = 0; a.list = 0;
+    a.staged = 0; a.staged2 = 0; a.done = 0; a.redo = 0; a.pairs = 0; a.npairs = 0; a.plane_lds = 0; a.state = 0; a.mark = 0; a.list = 0; a.cjobs = 0; a.cresults = 0; a.ncjobs = 0; a.cmark = 0; a.cdone = 0;
     a.ctab = c->tables[qp] + 32768;
 }
 
@@ -1559,6 +1671,29 @@ int x265amd_pairs_upload(x265amd_ctx *c, const x265amd_pair *pairs, int npairs, 
     HIPCHK(c, hipMalloc(d_pairs, npairs * sizeof(PairDev)));
     HIPCHK(c, hipMemcpy(*d_pairs, hp.data(), npairs * sizeof(PairDev), hipMemcpyHostToDevice));
     return X265AMD_OK;
+}
+
+int x265amd_search_batch_pairs_family_dev(x265amd_ctx *c, const void *d_pairs, int npairs, int qp, int subme,
+                                          const x265amd_job *d_parents, int nparents, x265amd_result *d_parent_results,
+                                          const x265amd_job *d_children, int nchildren, x265amd_result *d_child_results)
+{
+    if (!c || !d_pairs || npairs <= 0 || npairs > 256) return fail(c, X265AMD_EINVAL, "1 .. 256 pairs");
+    if (!d_parents || !d_parent_results || !d_children || !d_child_results || nparents <= 0 || nchildren <= 0)
+        return fail(c, X265AMD_EINVAL, "null argument");
+    if (subme < 0 || subme > 7) return fail(c, X265AMD_EINVAL, "bad subme");
+    if (c->depth > 10) return fail(c, X265AMD_EINVAL, "family launch: samples of at most 10 bits");
+    int rc = x265amd_set_qp(c, qp);
+    if (rc) return rc;
+    HIPCHK(c, hipSetDevice(c->device));
+    SearchArgs pa, ch;
+    x265amd_plane none;
+    memset(&none, 0, sizeof(none));
+    fill_args(c, pa, &none, &none, 0, qp, X265AMD_STAR, subme);
+    pa.pairs = (const PairDev*)d_pairs; pa.npairs = npairs;
+    ch = pa;
+    pa.jobs = d_parents; pa.results = d_parent_results; pa.njobs = nparents; pa.max_dim = 16;
+    ch.jobs = d_children; ch.results = d_child_results; ch.njobs = nchildren; ch.max_dim = 8;
+    return c->depth <= 8 ? launch_family<uint8_t>(c, pa, ch) : launch_family<uint16_t>(c, pa, ch);
 }
 
 int x265amd_search_batch_pairs_dev(x265amd_ctx *c, const void *d_pairs, int npairs, int qp, int method, int subme,
@@ -1672,7 +1807,7 @@ int x265amd_marked_count(x265amd_ctx *c, int *marked)
     if (!c->redo_valid) return X265AMD_OK;
     HIPCHK(c, hipSetDevice(c->device));
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    HIPCHK(c, hipMemcpy(marked, c->d_redo, sizeof(int), hipMemcpyDeviceToHost));
+    HIPCHK(c, hipMemcpy(marked, c->bufs[0].d_redo, sizeof(int), hipMemcpyDeviceToHost));
     return X265AMD_OK;
 }
 

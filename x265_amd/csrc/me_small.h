@@ -287,7 +287,11 @@ template<int S> struct RefineLds
     typedef SmallGeo<S> G;
     static constexpr int PLANES = SM_FIXED;
     static constexpr int PU_BYTES = 3 * G::PLANE + 4;               /* the odd dword staggers the PUs over the LDS banks */
-    static constexpr int TOTAL = PLANES + RefineGeo<S>::NPU * PU_BYTES + 32;
+    /* a 16x16 PU that takes its four 8x8 children along: per candidate of a round the sums of the four quadrants
+     * (9 x 4 ints), then the children's predictors (4 x, 4 y) */
+    static constexpr int FAM = PLANES + RefineGeo<S>::NPU * PU_BYTES + 32;
+    static constexpr int FAM_BYTES = 192;
+    static constexpr int TOTAL = FAM + (S == 16 ? RefineGeo<S>::NPU * FAM_BYTES : 0);
 };
 
 template<int S, typename P> struct RefineSmall
@@ -306,22 +310,46 @@ template<int S, typename P> struct RefineSmall
     int lane, grp, l;
     ColSrc ct[RG::ITEMS];
     const uint16_t AS1 *ctab;
+    /* a 16x16 PU launched together with the list of the 8x8 PUs (its four children at 4 k .. 4 k + 3 of that list), all
+     * five starting from one MV: SAD and SATD are
+     * sums over 4x4 tiles, so a candidate's distortion for a child is the sum over the child's quadrant. The lanes of
+     * the PU keep the sums of its upper and lower tiles apart and the quadrants' sums go to LDS; lanes 0 .. K - 1 then
+     * take every child's decisions beside the parent's with the child's own lambda * bits. The children stay while every
+     * decision moves all five to one MV; if one differs they are left to refine_small_kernel<8>. */
+    bool quad;                  /* per PU */
+    int cb[4];                  /* the children's best costs */
+    unsigned cadd;              /* candidates measured while the children were taken along */
+
+    /* the quadrants' sums and the PU's total of one candidate from the lanes' sums over their upper (vT) and lower (vB)
+     * tiles: blocks of eight lanes hold two tiles side by side, lanes 16 apart the same columns one tile row down */
+    __device__ __forceinline__ int fam_sums(int vT, int vB, int c)
+    {
+        vT += dpp_all<0xB1>(vT); vB += dpp_all<0xB1>(vB);
+        vT += dpp_all<0x4E>(vT); vB += dpp_all<0x4E>(vB);
+        vT += dpp_all<0x141>(vT); vB += dpp_all<0x141>(vB);
+        vT += __shfl_xor(vT, 16); vB += __shfl_xor(vB, 16);
+        int *cell = (int*)(x265amd_smem + L::FAM + grp * L::FAM_BYTES);
+        if ((l & 23) == 0) { cell[c * 4 + (l >> 3)] = vT; cell[c * 4 + 2 + (l >> 3)] = vB; }
+        int tot = vT + vB;
+        tot += dpp_all<0x140>(tot);
+        return tot;
+    }
 
     /* One refinement round for every PU of the wave: DIRS neighbours of (qx, qy) at distance `step`, plus the
      * centre itself first when CENTRE (the SATD re-measure of motion.cpp:1086, :1117, whose cost replaces
      * bcost). DIRS = 0 with CENTRE measures the centre alone (the closing SATD of subme 0). The candidate loop is
      * unrolled, so which plane and which of the three first rows / phases a candidate reads is fixed at compile time. */
-    template<int DIRS, bool CENTRE, bool HPEL>
+    template<int DIRS, bool CENTRE, bool HPEL, bool FAM = false>
     __device__ __forceinline__ void round_t(bool satd)
     {
         constexpr int step = HPEL ? 2 : 1;
         constexpr unsigned long long SQX = nibs({ 0, 0, 0, -1, 1, -1, -1, 1, 1 }), SQY = nibs({ 0, -1, 1, 0, 0, -1, 1, -1, 1 });
         constexpr int k0 = CENTRE ? 1 : 0, K = k0 + DIRS;
         /* lambda * bits of the candidate this lane folds (bitcost.h:46: the sum wraps at 16 bits) */
-        int mvc = 0;
+        int mvc = 0, tx, ty;
         {
             const int i = l < K ? l + 1 - k0 : 0;
-            const int tx = as_i16(qx + nib(SQX, i) * step), ty = as_i16(qy + nib(SQY, i) * step);
+            tx = as_i16(qx + nib(SQX, i) * step); ty = as_i16(qy + nib(SQY, i) * step);
             if (l < K && active) mvc = ((int)ctab[tx - mvpx] + (int)ctab[ty - mvpy]) & 0xffff;
         }
         /* rows of the planes: the candidates' first rows are ymin or ymin + 1 */
@@ -366,19 +394,35 @@ template<int S, typename P> struct RefineSmall
             if (HPEL && i >= 1 && dy == -1 && c + 1 < K && nib(SQY, i + 1) == 1 && nib(SQX, i + 1) == dx)
             {
                 int va = 0, vb = 0;
+                if constexpr (FAM)
+                {
+                    int vaB = 0, vbB = 0;
+                    small_column_cost_pair<S>(pbase + (dx + 1) * G::PLANE, r0y[0], phy[0], satd, ct[0], l & 3, depth, va, vb);
+                    small_column_cost_pair<S>(pbase + (dx + 1) * G::PLANE, r0y[0], phy[0], satd, ct[RG::ITEMS - 1], l & 3, depth, vaB, vbB);
+                    va = fam_sums(va, vaB, c); vb = fam_sums(vb, vbB, c + 1);
+                }
+                else
+                {
 #pragma unroll
-                for (int u = 0; u < RG::ITEMS; u++)
-                    small_column_cost_pair<S>(pbase + (dx + 1) * G::PLANE, r0y[0], phy[0], satd, ct[u], l & 3, depth, va, vb);
-                va = seg_sum(va, RG::LG); vb = seg_sum(vb, RG::LG);
+                    for (int u = 0; u < RG::ITEMS; u++)
+                        small_column_cost_pair<S>(pbase + (dx + 1) * G::PLANE, r0y[0], phy[0], satd, ct[u], l & 3, depth, va, vb);
+                    va = seg_sum(va, RG::LG); vb = seg_sum(vb, RG::LG);
+                }
                 if (l == c) mycost = (satd ? va >> 1 : va) + mvc;
                 if (l == c + 1) mycost = (satd ? vb >> 1 : vb) + mvc;
                 continue;
             }
             int v = 0;
+            if constexpr (FAM)
+                v = fam_sums(small_column_cost<S>(pbase + (dx + 1) * G::PLANE, r0y[dy + 1], phy[dy + 1], satd, ct[0], l & 3, depth),
+                             small_column_cost<S>(pbase + (dx + 1) * G::PLANE, r0y[dy + 1], phy[dy + 1], satd, ct[RG::ITEMS - 1], l & 3, depth), c);
+            else
+            {
 #pragma unroll
-            for (int u = 0; u < RG::ITEMS; u++)
-                v += small_column_cost<S>(pbase + (dx + 1) * G::PLANE, r0y[dy + 1], phy[dy + 1], satd, ct[u], l & 3, depth);
-            v = seg_sum(v, RG::LG);
+                for (int u = 0; u < RG::ITEMS; u++)
+                    v += small_column_cost<S>(pbase + (dx + 1) * G::PLANE, r0y[dy + 1], phy[dy + 1], satd, ct[u], l & 3, depth);
+                v = seg_sum(v, RG::LG);
+            }
             if (l == c) mycost = (satd ? v >> 1 : v) + mvc;   /* every 4x4 abs-sum is even: halving the total = halving per tile */
         }
         /* the reference's strict '<' over the candidates in table order */
@@ -391,6 +435,36 @@ template<int S, typename P> struct RefineSmall
             key = grp_min<RG::LG>(key);
             if (active && (key >> 6) < bcost) { bcost = key >> 6; bdir = (key & 63) - k0 + 1; }
         }
+        if constexpr (FAM)
+        {
+            /* the children: the same sequence on their quadrants' sums and their own lambda * bits */
+            wave_sync();
+            const int *cell = (const int*)(x265amd_smem + L::FAM + grp * L::FAM_BYTES);
+            bool agree = true;
+#pragma unroll
+            for (int q = 0; q < 4; q++)
+            {
+                int cc = 0;
+                if (l < K && quad)
+                {
+                    const int sum = cell[l * 4 + q];
+                    cc = (satd ? sum >> 1 : sum) + (((int)ctab[tx - cell[36 + q]] + (int)ctab[ty - cell[40 + q]]) & 0xffff);
+                }
+                if (CENTRE && quad) cb[q] = grp_lane<RG::LG>(cc, 0);
+                int cdir = 0;
+                if (DIRS)
+                {
+                    int key = 0x7fffffff;
+                    if (l >= k0 && l < K) key = (cc << 6) | l;
+                    key = grp_min<RG::LG>(key);
+                    if (quad && (key >> 6) < cb[q]) { cb[q] = key >> 6; cdir = (key & 63) - k0 + 1; }
+                }
+                agree = agree && cdir == bdir;
+            }
+            quad = quad && agree;
+            if (quad) cadd += (unsigned)K;
+            wave_sync();        /* the cells are the next round's */
+        }
         qx = as_i16(qx + nib(SQX, bdir) * step); qy = as_i16(qy + nib(SQY, bdir) * step);
         if (active) nsub += (unsigned)K;
     }
@@ -398,6 +472,14 @@ template<int S, typename P> struct RefineSmall
     /* the rounds the workload table can ask for (motion.cpp:53-63: four or eight directions) */
     __device__ __forceinline__ void round(int step, int dirs, bool satd, bool centre)
     {
+        if constexpr (S == 16)
+            if (__ballot(quad) != 0)
+            {
+                /* a wave with children in tow: the rounds of the levels that matter for throughput (eight directions) */
+                if (step == 2 && dirs == 8) { if (centre) round_t<8, true, true, true>(satd); else round_t<8, false, true, true>(satd); return; }
+                if (step == 1 && dirs == 8) { if (centre) round_t<8, true, false, true>(satd); else round_t<8, false, false, true>(satd); return; }
+                quad = false;       /* other workloads: the children are refined on their own */
+            }
         if (step == 2)
         {
             if (dirs == 8) { if (centre) round_t<8, true, true>(satd); else round_t<8, false, true>(satd); }
@@ -409,30 +491,17 @@ template<int S, typename P> struct RefineSmall
     }
 };
 
-/* one wave's group of PUs: group g of the launch's jobs, or of the launch's list of marked PUs (a.list) */
+/* one wave's PUs: the lanes of group `grp` refine job j (valid: there is one; j must be a readable index either way) */
 template<int S, typename P>
-__device__ __forceinline__ void refine_small_group(const SearchArgs &a, int g)
+__device__ __forceinline__ void refine_small_group(const SearchArgs &a, int j, bool valid)
 {
     typedef SmallGeo<S> G;
     typedef RefineGeo<S> RG;
     RefineSmall<S, P> R;
     R.depth = sizeof(P) == 1 ? 8 : a.depth;
     R.lane = (int)threadIdx.x; R.grp = R.lane >> RG::LG; R.l = R.lane & (RG::LPP - 1);
-    int j = g * RG::NPU + R.grp;
-    bool valid;
-    if (a.list)
-    {
-        const int total = uni(a.redo[0]);
-        valid = j < total;
-        j = a.redo[REDO_LIST + (valid ? j : total - 1)];
-    }
-    else
-    {
-        valid = j < a.njobs;
-        if (!valid) j = a.njobs - 1;
-        /* a PU the STAR kernels handed on is refined by the list-driven launch that follows its search */
-        if (a.mark && a.mark[j]) valid = false;
-    }
+    /* a PU the STAR kernels handed on is refined by the list-driven launch that follows its search */
+    if (!a.list && a.mark && a.mark[j]) valid = false;
     const int *job = (const int*)(a.jobs + j);
     const int d0 = job[0], d1 = job[1], d4 = job[4];
     const int pux = as_i16(d0), puy = d0 >> 16;
@@ -443,6 +512,32 @@ __device__ __forceinline__ void refine_small_group(const SearchArgs &a, int g)
     /* a PU whose full-pel cost is 0 is not refined (motion.cpp:1073-1076); PUs of other sizes are final already */
     R.active = valid && (d1 & 0xffff) == G::SIZE_CODE && R.bcost > 0;      /* a negative cost marks a job that was refused */
     if (__ballot(R.active) == 0) return;
+    R.quad = false; R.cadd = 0;
+    if constexpr (S == 16)
+    {
+        if (!a.list && a.cjobs)
+        {
+            /* lane q < 4 looks at child q: PU 4 j + q of the children's list, if it is the 8x8 PU of the same pictures
+             * at that place in the quadtree, not handed on by the STAR kernels, starting from the parent's MV, cost above 0 */
+            const int q = R.l & 3;
+            bool ok = R.active && 4 * j + 3 < a.ncjobs;
+            int bc = 0, c4 = 0;
+            if (ok)
+            {
+                const int *cj = (const int*)(a.cjobs + 4 * j + q);
+                const int *cr = (const int*)(a.cresults + 4 * j + q);
+                const int c0 = cj[0], c1 = cj[1];
+                c4 = cj[4]; bc = cr[1];
+                ok = (c1 & 0xffff) == SmallGeo<8>::SIZE_CODE && (c1 >> 24) == (d1 >> 24) && as_i16(c0) == pux + 8 * (q & 1) &&
+                     (c0 >> 16) == puy + 8 * (q >> 1) && cr[0] == r0 && bc > 0 && !a.cmark[4 * j + q];
+            }
+            R.quad = (grp_bits16<RG::LG>(ok) & 0xf) == 0xf;
+            int *cell = (int*)(x265amd_smem + RefineLds<S>::FAM + R.grp * RefineLds<S>::FAM_BYTES);
+            if (R.l < 4) { cell[36 + q] = as_i16(c4); cell[40 + q] = c4 >> 16; }
+#pragma unroll
+            for (int k = 0; k < 4; k++) R.cb[k] = grp_lane<RG::LG>(bc, k);
+        }
+    }
     const P AS1 *fenc0;
     int fstride;
     small_planes<P>(a, d1, fenc0, fstride, R.ref0, R.rstride);
@@ -472,20 +567,62 @@ __device__ __forceinline__ void refine_small_group(const SearchArgs &a, int g)
         res[1] = R.bcost;
         res[3] = (int)R.nsub;
     }
+    if constexpr (S == 16)
+        if (R.quad && R.l < 4)
+        {
+            int *cr = (int*)(a.cresults + 4 * j + R.l);
+            cr[0] = (R.qx & 0xffff) | (R.qy << 16);
+            cr[1] = R.l == 0 ? R.cb[0] : (R.l == 1 ? R.cb[1] : (R.l == 2 ? R.cb[2] : R.cb[3]));
+            cr[3] += (int)R.cadd;
+            a.cdone[4 * j + R.l] = 1;
+        }
 }
 
 template<int S, typename P>
 __global__ __launch_bounds__(64) void refine_small_kernel(SearchArgs a)
 {
     typedef RefineGeo<S> RG;
-    small_load_taps<P>((int)threadIdx.x, sizeof(P) == 1 ? 8 : a.depth);
-    /* every PU of the launch, a group per wave; or (a.list) the launch's list of marked PUs, every wave walking it */
-    const int n = a.list ? uni(a.redo[0]) : a.njobs, ngroups = (n + RG::NPU - 1) / RG::NPU;
-    for (int k = (int)blockIdx.x; k < ngroups; k += a.list ? (int)gridDim.x : ngroups)
+    const int lane = (int)threadIdx.x, grp = lane >> RG::LG;
+    small_load_taps<P>(lane, sizeof(P) == 1 ? 8 : a.depth);
+    if (a.list)
     {
-        wave_sync();
-        refine_small_group<S, P>(a, a.list ? k : xcd_remap(k, ngroups));
+        /* the launch's list of marked PUs, every wave walking it */
+        const int total = uni(a.redo[0]), ngroups = (total + RG::NPU - 1) / RG::NPU;
+        for (int k = (int)blockIdx.x; k < ngroups; k += (int)gridDim.x)
+        {
+            wave_sync();
+            const int i = k * RG::NPU + grp;
+            refine_small_group<S, P>(a, a.redo[REDO_LIST + (i < total ? i : total - 1)], i < total);
+        }
+        return;
     }
+    if (a.done)
+    {
+        /* the children of a family launch: most are refined already. A wave looks at 64 consecutive PUs and refines
+         * those left over, a group of lanes each at a time */
+        const int base = (int)blockIdx.x * 64, jl = base + lane;
+        unsigned long long m = __ballot(jl < a.njobs && !a.done[jl]);
+        while (m)
+        {
+            int j = base;
+            bool valid = false;
+#pragma unroll
+            for (int g = 0; g < RG::NPU; g++)
+                if (m)
+                {
+                    if (g == grp) { j = base + (int)__builtin_ctzll(m); valid = true; }
+                    m &= m - 1;
+                }
+            wave_sync();
+            refine_small_group<S, P>(a, j, valid);
+        }
+        return;
+    }
+    /* every PU of the launch, a group per wave */
+    const int ngroups = (a.njobs + RG::NPU - 1) / RG::NPU, g = xcd_remap((int)blockIdx.x, ngroups);
+    if (g >= ngroups) return;
+    const int j = g * RG::NPU + grp;
+    refine_small_group<S, P>(a, j < a.njobs ? j : a.njobs - 1, j < a.njobs);
 }
 
 /* ---------------------------------------------------------------- sub-pel refinement of 32x32 and 64x64 PUs
@@ -820,8 +957,14 @@ __global__ __launch_bounds__(64) void star_small_kernel(SearchArgs a)
 #pragma unroll
     for (int i = 0; i < 10; i++) d[i] = job[i];
     const bool sized = (d[1] & 0xffff) == G::SIZE_CODE;
-    if (valid && !sized && l == 0) { a.results[j].sad_calls = SMALL_REDO; a.mark[j] = 1; }
+    /* the launch for the list's largest size hands every PU that no fixed-shape launch takes to the one-wave search */
+    if (valid && !sized && l == 0 && S == a.staged && (d[1] & 0xffff) != (a.staged2 | (a.staged2 << 8)))
+    {
+        a.results[j].sad_calls = SMALL_REDO;
+        a.mark[j] = 1;
+    }
     const bool act = valid && sized;
+    if (act && l == 0 && a.done) a.done[j] = 0;        /* "refined with its parent": set by the parent's refinement, if at all */
     if (__ballot(act) == 0) return;
 
     const int pux = as_i16(d[0]), puy = d[0] >> 16, numc = (d[1] >> 16) & 0xff;
@@ -1127,9 +1270,11 @@ __global__ __launch_bounds__(StarBigGeo<S>::THREADS) void star_big_kernel(Search
     typedef SmallGeo<S> G;
     typedef StarBigLds<S> L;
     constexpr int THREADS = StarBigGeo<S>::THREADS, ITEMS = StarBigGeo<S>::ITEMS, NQ = StarBigGeo<S>::NQ, BPS = (int)sizeof(P);
+    if (blockIdx.x == 0 && threadIdx.x == 0 && S == a.staged) a.redo[0] = 0;   /* the list of marked PUs starts empty (redo_list_kernel) */
     const int j = xcd_remap((int)blockIdx.x, a.njobs);
     if (j >= a.njobs) return;
     const int tid = (int)threadIdx.x, lane = tid & 63;
+    if (tid == 0 && a.done && S == a.staged) a.done[j] = 0;     /* "refined with its parent": set by the parent's refinement, if at all */
     const int *job = (const int*)(a.jobs + j);
     int d[10];
     d[1] = uni(job[1]);

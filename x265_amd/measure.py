@@ -299,8 +299,8 @@ def pattern_search_clip(e, dev, kind, pairs=8, width=1920, height=1080, method="
     """The headline's searches on another kind of clip (synth.make_clip: "noise" = no two frames alike, the worst case of
     a pattern search; "static" = every frame the same, the best case; "texture" = the headline's translated texture):
     every square 64/32/16/8 PU of `pairs` frame pairs, predictors from the lookahead field of each pair, one launch per
-    PU class over all pairs (the 64x64 PUs with their 32x32 children behind them), the classes one after the other on one
-    stream. Per class: ms, pixel-SADs, and the share of its PUs the fixed-shape kernels did not finish (marked).
+    PU class over all pairs (the 64x64 PUs with their 32x32 children behind them, the 16x16 PUs with their 8x8 children), the
+    classes one after the other on one stream. Per class: ms, pixel-SADs, and the share of its PUs the fixed-shape kernels did not finish (marked).
     Returns the classes and, for checking, the jobs and results of pair 0."""
     import torch
     from .engine import HEX, SQUARE_ONLY
@@ -317,18 +317,28 @@ def pattern_search_clip(e, dev, kind, pairs=8, width=1920, height=1080, method="
     host_jobs = [workload.square_pu_jobs(width, height, la_mvs[i], wcu, hcu, merange) for i in range(pairs)]
     d_pairs = e.pairs_upload([(planes[i + 1], planes[i]) for i in range(pairs)])
     out, keep = {}, []
-    for name, sizes, dim in (("64+32", (64, 32), 64), ("16", (16,), 16), ("8", (8,), 8)):
-        cj, index = workload.class_job_list(host_jobs, sizes, families=dim == 64)
+    for name, sizes, dim in (("64+32", (64, 32), 64), ("16+8", (16, 8), 16)):
+        if dim == 64:
+            cj, index = workload.class_job_list(host_jobs, sizes, families=True)
+            nparents = 0
+        else:
+            pj, pi, kj, ki = workload.family_lists(host_jobs, 16)
+            cj, index, nparents = np.concatenate([pj, kj]), np.concatenate([pi, ki]), len(pj)
         n = len(cj)
         d_jobs = torch.from_numpy(cj.view(np.uint8).reshape(n, -1).copy()).to(dev)
         d_res = torch.zeros((n, RESULT_DTYPE.itemsize), dtype=torch.uint8, device=dev)
         torch.cuda.synchronize()
-        launch = lambda: e.search_batch_pairs_dev(d_pairs, pairs, d_jobs.data_ptr(), n, d_res.data_ptr(), qp, METHODS[method], subme,
-                                                  max_pu_dim=dim | SQUARE_ONLY)
+        if dim == 64:
+            launch = lambda: e.search_batch_pairs_dev(d_pairs, pairs, d_jobs.data_ptr(), n, d_res.data_ptr(), qp, METHODS[method], subme,
+                                                      max_pu_dim=dim | SQUARE_ONLY)
+        else:
+            launch = lambda: e.search_batch_pairs_family_dev(d_pairs, pairs, d_jobs.data_ptr(), nparents, d_res.data_ptr(),
+                                                             d_jobs.data_ptr() + 40 * nparents, n - nparents,
+                                                             d_res.data_ptr() + 16 * nparents, qp, subme)
         ms = _timed(torch, e, dev, launch, reps)
         marked = e.marked_count()
         res = d_res.cpu().numpy().view(RESULT_DTYPE).reshape(-1)
-        out[name] = {"pus": n, "ms": ms, "marked_frac": marked / n, "pixel_sads": workload.pixel_sads(cj, res)}
+        out[name] = {"pus": n, "ms": ms, "marked_frac": marked / (nparents or n), "pixel_sads": workload.pixel_sads(cj, res)}
         sel = index[:, 0] == 0
         keep.append((cj[sel], res[sel]))
     e.device_free(d_pairs)

@@ -45,21 +45,23 @@ def square_pu_jobs(width, height, lowres_mvs, wcu, hcu, merange, sizes=(64, 32, 
     return np.concatenate(out)
 
 
-def family_order(jobs):
-    """Quadtree order of a job list of 64x64 and 32x32 PUs of one picture: every 64x64 PU followed by its four 32x32
-    children in raster order (the library then refines them together with it where all five start from one MV); the 32x32
-    PUs without a parent (a picture whose height is no multiple of 64) at the end. Returns the permutation."""
+def family_order(jobs, parent=64):
+    """Quadtree order of a job list of the square PUs of two adjacent sizes of one picture (64x64 with 32x32, or 16x16 with
+    8x8): every parent followed by its four children in raster order (the library then refines them together with it
+    where all five start from one MV); the children without a parent (a picture whose height is no multiple of the
+    parent's size) at the end. Returns the permutation."""
+    child = parent // 2
     pos = {(int(j["pu_x"]), int(j["pu_y"]), int(j["w"])): k for k, j in enumerate(jobs)}
     fam, used = [], set()
     for k, j in enumerate(jobs):
-        if j["w"] != 64:
+        if j["w"] != parent:
             continue
-        kids = [pos.get((int(j["pu_x"]) + 32 * (q & 1), int(j["pu_y"]) + 32 * (q >> 1), 32)) for q in range(4)]
+        kids = [pos.get((int(j["pu_x"]) + child * (q & 1), int(j["pu_y"]) + child * (q >> 1), child)) for q in range(4)]
         fam.append(k)
         if all(c is not None for c in kids):
             fam += kids
             used.update(kids)
-    fam += [k for k, j in enumerate(jobs) if j["w"] == 32 and k not in used]
+    fam += [k for k, j in enumerate(jobs) if j["w"] == child and k not in used]
     fam = np.array(fam)
     assert len(fam) == len(jobs) and len(set(fam.tolist())) == len(jobs)
     return fam
@@ -76,11 +78,54 @@ def class_job_list(host_jobs, sizes, families=False):
         j = jobs[idx].copy()
         j["reserved"] = i
         if families:
-            order = family_order(j)
+            order = family_order(j, max(sizes))
             j, idx = j[order], idx[order]
         parts.append(j)
         index.append(np.stack([np.full(len(idx), i), idx], axis=1))
     return np.concatenate(parts), np.concatenate(index)
+
+
+def family_lists(host_jobs, parent=16):
+    """The two job lists of x265amd_search_batch_pairs_family_dev over several frame pairs: the parents (square PUs of
+    `parent` samples, pair-major, job.reserved naming the pair) and their children (half the size) with PU 4 k + q = quadrant q
+    (raster order) of parent k; a parent whose children are not all in the list gets four placeholders' worth of nothing --
+    its slots are filled with the list's first children that have no parent (so the lists stay dense), and what is left of
+    those follows at the end. Returns (parents, parent index, children, child index), index[k] = (pair, position in
+    host_jobs[pair]) of job k."""
+    child = parent // 2
+    pj, pi, fam_c, fam_i, orphans, orph_i = [], [], [], [], [], []
+    for i, jobs in enumerate(host_jobs):
+        sq = jobs["w"] == jobs["h"]
+        pidx = np.flatnonzero(sq & (jobs["w"] == parent))
+        cidx = np.flatnonzero(sq & (jobs["w"] == child))
+        pos = {(int(jobs["pu_x"][k]), int(jobs["pu_y"][k])): int(k) for k in cidx}
+        used = set()
+        kids_of = []
+        for k in pidx:
+            x, y = int(jobs["pu_x"][k]), int(jobs["pu_y"][k])
+            kids = [pos.get((x + child * (q & 1), y + child * (q >> 1))) for q in range(4)]
+            kids_of.append(kids if all(c is not None for c in kids) else None)
+            if kids_of[-1]:
+                used.update(kids)
+        free = [int(k) for k in cidx if int(k) not in used]
+        for kids in kids_of:
+            if kids is None:        # keep the 4 k + q correspondence of the parents behind: any four children without a parent
+                kids, free = free[:4], free[4:]
+                assert len(kids) == 4, "a parent without children and no spare children to fill its slots"
+            fam_i.append(np.stack([np.full(4, i), np.array(kids)], axis=1))
+            c = jobs[kids].copy()
+            c["reserved"] = i
+            fam_c.append(c)
+        p = jobs[pidx].copy()
+        p["reserved"] = i
+        pj.append(p)
+        pi.append(np.stack([np.full(len(pidx), i), pidx], axis=1))
+        if free:
+            o = jobs[free].copy()
+            o["reserved"] = i
+            orphans.append(o)
+            orph_i.append(np.stack([np.full(len(free), i), np.array(free)], axis=1))
+    return (np.concatenate(pj), np.concatenate(pi), np.concatenate(fam_c + orphans), np.concatenate(fam_i + orph_i))
 
 
 def algorithmic_bytes(jobs, bytes_per_pixel=1):
