@@ -142,7 +142,10 @@ def headline_roofline(vb, pus, launch_ms, alg_gbs, alg_bytes, traffic, compulsor
             "valu": vb, "hbm": hbm, "hbm_per_job": per_job, "compulsory": compulsory,
             "note": "achieved = essential VALU wave instructions per PU x PUs of the launch / launch duration (HIP events on the "
                     "launch's stream while the other classes run beside it); busy_frac = the instructions actually issued, same "
-                    "denominator; step_busy_frac = all kernels of a step over the step. The launch reads %s of HBM peak"
+                    "denominator; step_busy_frac = all kernels of a step over the step. The launch reads %s of HBM peak. The "
+                    "instruction counts come from a counter run of a 2-pair step and are scaled by PUs: that assumes a PU's "
+                    "instructions do not depend on how many pairs a step holds (same kernels, same lists per pair; the share of "
+                    "handed-on PUs differs from pair to pair by a few per cent of the PUs)"
                     % ("%.1f %%" % (100 * hbm["frac"]) if hbm else "an unmeasured share")}
 
 
@@ -342,9 +345,10 @@ def main():
                          "the 64x64 and 32x32 PUs in one launch; the others launch per frame pair: split3 = the "
                          "same three classes, split = 16/8 and 64/32 on two streams (LDS per PU sized per class), single = one "
                          "launch, per-size = four launches on one stream")
-    ap.add_argument("--prio", choices=("small", "big", "la", "flat"), default="small",
-                    help="which search stream gets the device's highest priority: small = the 8x8 class, whose launch is a chain of "
-                         "dependent kernels (measured: 3 % over flat); big = the 64x64 class; la = the lookahead's stream; flat = none")
+    ap.add_argument("--prio", choices=("small", "big", "la", "flat"), default="flat",
+                    help="which search stream gets the device's highest priority: small = the 16x16 + 8x8 class; big = the 64x64 + "
+                         "32x32 class; la = the lookahead's stream; flat = none (measured on the family launches: flat 3.55 ms, "
+                         "small 3.82, big 3.79 -- a favoured stream holds the others' dependent kernels back)")
     ap.add_argument("--s32", choices=("big", "mid", "la", "own"), default="la",
                     help="pairs4: the stream of the 32x32 launch: behind the 64x64 launch, behind the 16x16 launch, behind the "
                          "lookahead field, or one of its own")
@@ -633,7 +637,7 @@ def main():
     tpath = os.path.join(ROOT, "profiles", "traffic.json")
     if os.path.exists(tpath):
         traffic = json.load(open(tpath)).get("search_kernel_hbm_bytes_per_launch", {}).get(
-            "pairs3" if args.launch in ("pairs4", "families") else args.launch)     # the 8x8 launch is the same in all three
+            "pairs3" if args.launch == "pairs4" else args.launch)     # (the 8x8 launch of pairs4 is that of pairs3)
         if traffic is not None and multi:
             traffic *= B      # kept per frame pair (the counters were collected on a 2-pair step)
     # the floor of a step's HBM bytes: every plane of the frame pairs read once (padded as uploaded), job records in,
@@ -645,7 +649,8 @@ def main():
                   "frac": comp_bytes / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS,
                   "what": "whole step: each full-resolution and lowres plane once, job records in, result records and MV fields out"}
     vpath = os.path.join(ROOT, "profiles", "valu.json")
-    vprof = json.load(open(vpath)) if os.path.exists(vpath) and multi and method == METHODS["star"] and SUBME == 5 else None
+    # (the instruction profile is that of the family launches)
+    vprof = json.load(open(vpath)) if os.path.exists(vpath) and args.launch == "families" and method == METHODS["star"] and SUBME == 5 else None
 
     if rank == 0:
         # parity gate + CPU baseline: the oracle re-runs every PU search of the first frame pairs
@@ -736,11 +741,13 @@ def main():
                                   "thread, frame pairs dealt out in turn), %.1f s, %s; MVs and costs compared with the GPU's"
                                   % (njobs * B, B, nthr, mt_s, "the reference's own code (oracle/_ref)" if use_ref
                                      else "oracle/me_oracle.c -O3")})
-        kernel = {"families": "the launch over the %d 8x8 PUs of all %d frame pairs of a step: star_small_kernel<8> (start-up and the "
-                              "common case of the integer stage, four PUs per wave), search_kernel<uint8_t,false> (the PUs the first "
-                              "kernel marked: one PU per wave) and refine_small_kernel<8> (sub-pel rounds, four PUs per wave); the "
-                              "16x16 launch and the launch of the 64x64 PUs with their 32x32 children run concurrently on two more "
-                              "streams" % (timed_cnt * B, B),
+        kernel = {"families": "the family launch over the %d 16x16 PUs and their 8x8 children (%d PUs in all) of all %d frame pairs of a "
+                              "step, on the context's two streams: star_small_kernel<16> and <8> (start-up candidates and the first "
+                              "three pattern rounds: one and four PUs per wave), star_resume_kernel (the PUs those handed on: one per "
+                              "wave), refine_small_kernel<16> (sub-pel rounds, two PUs per wave, each taking its four children along "
+                              "while they decide alike) and refine_small_kernel<8> (the remaining 8x8 PUs, four per wave); the launch "
+                              "of the 64x64 PUs with their 32x32 children and the lookahead fields run beside it on streams of their "
+                              "own" % (int((host_jobs[0]["w"] == 16).sum()) * B, timed_cnt * B, B),
                   "pairs4": "the launch over the %d 8x8 PUs of all %d frame pairs of a step: star_small_kernel<8> (start-up and the "
                             "common case of the integer stage, four PUs per wave), search_kernel<uint8_t,false> (the PUs the first "
                             "kernel marked: one PU per wave) and refine_small_kernel<8> (sub-pel rounds, four PUs per wave); the "

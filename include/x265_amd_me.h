@@ -23,6 +23,13 @@ extern "C" {
 #define X265AMD_EINVAL     -1   /* bad argument */
 #define X265AMD_EHIP       -2   /* HIP runtime error */
 #define X265AMD_ENOMEM     -3
+#define X265AMD_EBUSY      -4   /* a resource that serves one call at a time is in use */
+
+/* Incremented whenever an entry point that exists changes its arguments (2: x265amd_fields_upload takes the CU grid,
+ * method and merange it checks the planes for). A binding compares x265amd_abi_version() with the header it was written
+ * against before its first call: a stale binding would pass arguments in the wrong slots, which no linker notices. */
+#define X265AMD_ABI_VERSION 2
+int x265amd_abi_version(void);
 
 /* search methods: X265_DIA_SEARCH .. X265_FULL_SEARCH, x265.h (searchMethod) */
 enum { X265AMD_DIA = 0, X265AMD_HEX = 1, X265AMD_UMH = 2, X265AMD_STAR = 3, X265AMD_FULL = 4 };
@@ -229,9 +236,10 @@ int x265amd_lookahead_fields(x265amd_ctx *ctx, const x265amd_field *fields, int 
 /* Device-resident variant: `d_fields` comes from x265amd_fields_upload (release it with
  * x265amd_device_free), outputs are DEVICE arrays of the sizes above; asynchronous on
  * the engine's stream. Same reference path as x265amd_lookahead_fields. x265amd_fields_upload makes the
- * geometry checks above for the grid, method and merange it is given; x265amd_lookahead_fields_dev cannot
- * see the planes and must be called with that grid, that method (or any other than UMH) and a merange no
- * larger. */
+ * geometry checks above for the grid, method and merange it is given and the context remembers them with the
+ * array: x265amd_lookahead_fields_dev takes such an array of the same context (or a run of its fields: d_fields
+ * + k * 80 bytes) and returns X265AMD_EINVAL for any other pointer, another grid, a larger merange, or UMH on an
+ * array that was not checked for UMH. */
 int x265amd_fields_upload(x265amd_ctx *ctx, const x265amd_field *fields, int nfields,
                           int width_in_cu, int height_in_cu, int method, int merange, void **d_fields);
 int x265amd_device_free(x265amd_ctx *ctx, void *d_ptr);
@@ -239,16 +247,19 @@ int x265amd_lookahead_fields_dev(x265amd_ctx *ctx, const void *d_fields, int nfi
                                  int width_in_cu, int height_in_cu, int qp, int method, int subme, int merange,
                                  int16_t *d_mvs, int32_t *d_costs, x265amd_result *d_stats /* or NULL */);
 
-/* x265amd_lookahead_fields for callers that cannot allocate device memory (code running under HIP graph capture,
- * tight serving loops, harnesses that forbid hipMalloc). It has no counterpart in the reference. Same arguments and
- * results as x265amd_lookahead_fields, but the call makes no allocation of any kind: the field descriptors, the MV /
- * cost / statistics arrays the kernel writes and the row ticket of the kernel sit in a static device array of
- * X265AMD_STATIC_SCRATCH_BYTES that every GPU the library runs on holds until the process ends. Limits, refused with
+/* x265amd_lookahead_fields for callers that cannot allocate device memory (tight serving loops, harnesses that forbid
+ * hipMalloc). It has no counterpart in the reference. Same arguments and results as x265amd_lookahead_fields, but the
+ * call allocates and frees no device memory (no hipMalloc / hipFree, here or in a library it calls): the field
+ * descriptors, the MV / cost / statistics arrays the kernel writes and the row ticket of the kernel sit in a static device
+ * array of X265AMD_STATIC_SCRATCH_BYTES that every GPU the library runs on holds until the process ends. It is a
+ * synchronous host call like its twin -- it copies from and to the caller's host arrays and waits for its stream -- so it
+ * is not for use under stream capture; error paths build their message on the host heap. Limits, refused with
  * X265AMD_EINVAL: at most X265AMD_STATIC_MAX_FIELDS fields, and
  *   256 + 80 * nfields (rounded up to 256) + nfields * width_in_cu * height_in_cu * (8, or 24 with out_stats)
  * bytes must fit the array (e.g. 120 fields of a 1080p frame, 7 of an 8K frame). The cost table of `qp` must have been
  * built before by x265amd_set_qp (that call allocates; this one returns X265AMD_EINVAL if the table is missing).
- * All calls on one GPU share that GPU's array: calls that overlap in time on one GPU (two contexts, two threads) race. */
+ * All calls on one GPU share that GPU's array, one at a time: a call that finds another one (of any context or thread of
+ * the process) still running on the same GPU returns X265AMD_EBUSY and touches nothing. */
 #define X265AMD_STATIC_SCRATCH_BYTES (8 << 20)
 #define X265AMD_STATIC_MAX_FIELDS 256
 int x265amd_lookahead_fields_static(x265amd_ctx *ctx, const x265amd_field *fields, int nfields,

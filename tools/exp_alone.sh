@@ -1,9 +1,8 @@
-# kernel durations of one launch class of the headline step running alone on the chip (EXP_ONLY = 8 | 8,16 | 8,64 ...;
-# the 8x8 class always runs: it carries the timing events)
+# kernel durations of launch classes of the headline step running alone on the chip (EXP_ONLY = 16 | 64 | la | 16,64 ...)
 set -e
 OUT=$GRAFT_REPO_ROOT/gpurun_out
 cd /tmp && export TMPDIR=/tmp
-for only in ${EXP_ONLY:-8 8,16 8,64 8,la}; do
+for only in ${EXP_ONLY:-16 64 la}; do
   rm -rf $OUT/exp_alone
   timeout -k 10 300 rocprofv3 --kernel-trace --output-format csv -d $OUT/exp_alone -- python3 $GRAFT_REPO_ROOT/bench.py --steps 5 --warmup 2 --cpu-pairs 0 --no-other-paths --no-clock-probe --only $only > $OUT/exp_alone.log 2>&1
   echo "== only $only"

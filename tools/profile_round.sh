@@ -2,7 +2,7 @@
 #   bash tools/profile_round.sh <tag>      -> gpurun_out/<tag>_{trace,sq,fetch,write}/...
 # Summaries for profiles/ are made afterwards with tools/profile_summary.py.
 set -e
-TAG=${1:-r02}
+TAG=${1:-r03}
 OUT=$GRAFT_REPO_ROOT/gpurun_out
 B=$GRAFT_REPO_ROOT/bench.py
 cd /tmp && export TMPDIR=/tmp

@@ -5,10 +5,11 @@
 
   profiles/<tag>_bench_kernel_trace.txt   per (kernel, grid): calls, average / median / min / max duration; per stream
                                           of a step (= launch class), the span from the start of its first kernel to
-                                          the end of its last one (what bench.py's HIP events bracket for the 8x8 class)
+                                          the end of its last one (a launch class uses two streams: bench.py's HIP events bracket
+                                          the 16x16 + 8x8 class's launch on its first)
   profiles/<tag>_search_sq_counters.txt   SQ counters per (kernel, grid), totals and per wave
   profiles/valu.json                      the same per frame pair, read by bench.py for roofline.valu
-  profiles/traffic.json                   HBM bytes per frame pair of the 8x8 launch class (FETCH_SIZE doubled for the
+  profiles/traffic.json                   HBM bytes per frame pair of the 16x16 + 8x8 launch class (FETCH_SIZE doubled for the
                                           128-byte requests gfx950 counts as 64, plus WRITE_SIZE)
 """
 import collections
@@ -44,12 +45,12 @@ def class_of(kernels):
     if "lookahead_band_kernel" in names:
         parts.append("lookahead")
     for s in ("8", "16"):
-        if re.search(r"star_small_kernel<%s[,>]" % s, names):
+        if re.search(r"(star_small_kernel|refine_small_kernel)<%s[,>]" % s, names):
             parts.append("%sx%s" % (s, s))
     for s in ("32", "64"):
         if re.search(r"refine_big_kernel<%s[,>]" % s, names):
             parts.append("%sx%s" % (s, s))
-    return " + ".join(parts) or "other"
+    return " + ".join(parts) or "handed-on PUs only"
 
 
 # ---- kernel trace
@@ -76,18 +77,33 @@ for i in range(STEPS):
     for e in ev:
         if bounds[i] <= e[0] < bounds[i + 1] and not e[2].startswith("__amd_rocclr") and "elementwise" not in e[2]:
             by_q[e[4]].append(e)
+    by_c = collections.defaultdict(list)
     for q, es in by_q.items():
-        per_class[class_of([e[2] for e in es])].append(es)
-lines += ["", "launch classes of the %d timed steps (one stream each): span = end of the class's last kernel - start of its first, "
-          "per step; then the kernels in launch order with their average durations" % STEPS]
+        by_c[class_of([e[2] for e in es])] += es
+    for cname, es in by_c.items():
+        per_class[cname].append(sorted(es))
+lines += ["", "launch classes of the %d timed steps (a context's two streams each): span = end of the class's last kernel - start of "
+          "its first, per step; then the kernels in start order (of the first of these steps) with start, end and duration "
+          "relative to the step's first kernel, averaged over the steps" % STEPS]
 for cname, steps in sorted(per_class.items()):
     sp = [(max(e[1] for e in es) - min(e[0] for e in es)) / 1e6 for es in steps]
     ks = [sum(e[1] - e[0] for e in es) / 1e6 for es in steps]
     lines.append("%-18s span avg %.3f ms (min %.3f max %.3f); sum of its kernels' durations avg %.3f ms" %
                  (cname, sum(sp) / len(sp), min(sp), max(sp), sum(ks) / len(ks)))
-    n = min(len(es) for es in steps)
-    for j in range(n):
-        lines.append("    %-44s grid %9d  avg %.3f ms" % (steps[0][j][2], steps[0][j][3], sum(es[j][1] - es[j][0] for es in steps) / len(steps) / 1e6))
+    # the same launch sequence every step: match kernels by (name, grid, occurrence)
+    def keyed(es):
+        seen, out = collections.Counter(), {}
+        for e in es:
+            seen[(e[2], e[3])] += 1
+            out[(e[2], e[3], seen[(e[2], e[3])])] = e
+        return out
+    ks_ = [keyed(es) for es in steps]
+    for key, e0 in sorted(ks_[0].items(), key=lambda kv: kv[1][0]):
+        have = [(k_[key], bounds[i]) for i, k_ in enumerate(ks_) if key in k_]
+        n_ = len(have)
+        lines.append("    %-44s grid %9d  %6.3f -> %6.3f  (%.3f ms)" % (
+            key[0], key[1], sum(e[0] - b for e, b in have) / n_ / 1e6, sum(e[1] - b for e, b in have) / n_ / 1e6,
+            sum(e[1] - e[0] for e, b in have) / n_ / 1e6))
 period = [(starts[i + 1] - starts[i]) / 1e6 for i in range(STEPS - 1)]
 lines.append("step period (start of one step's first kernel to the next one's) avg %.3f ms" % (sum(period) / len(period)))
 open(os.path.join(PROF, "%s_bench_kernel_trace.txt" % tag), "w").write("\n".join(lines) + "\n")
@@ -115,29 +131,36 @@ def per_pair(v):
             "waves": v["SQ_WAVES"] / PAIRS_PMC, "wave_cycles": v["SQ_WAVE_CYCLES"] / PAIRS_PMC}
 
 
-# the stream of a size class is the one its fixed-shape kernels ran on; the one-wave search launches (marked PUs of the
-# small classes, the integer stage of the large ones) are told apart by that stream
-q_of = {}
+# A launch class runs on a context's two streams: the queues that ran a fixed-shape kernel of the small PUs belong to the
+# 16x16 + 8x8 family launch (the timed class), those that ran one of the large PUs to the 64x64 + 32x32 launch. A context's
+# second stream may hold nothing but the compact search of handed-on PUs and its list kernel: those go by their grids
+# (the counter run's lists are shorter than the cap of 8192 waves only for the large PUs).
+FAMILY, BIG = "16x16 + 8x8", "64x64 + 32x32"
+q_class = {}
 for (k, g, q) in cnt:
-    for s in ("8", "16"):
-        if re.match(r"star_small_kernel<%s[,>]" % s, k):
-            q_of[q] = q_of.get(q, []) + [s]
-    for s in ("32", "64"):
-        if re.match(r"refine_big_kernel<%s[,>]" % s, k):
-            q_of[q] = q_of.get(q, []) + [s]
+    if k.startswith(("star_small_kernel", "refine_small_kernel")):
+        q_class[q] = FAMILY
+    elif k.startswith(("star_big_kernel", "refine_big_kernel")):
+        q_class.setdefault(q, BIG)
+BIG_PUS = (480 + 1980) * PAIRS_PMC      # 64x64 + 32x32 PUs of the counter run's step
+
+
+def class_of_launch(k, g, q):
+    if q in q_class:
+        return q_class[q]
+    if k.startswith(("star_resume_kernel", "search_kernel")):
+        return BIG if g < 8192 * 64 else FAMILY
+    if k == "redo_list_kernel":
+        return BIG if g <= 64 * ((BIG_PUS + 1023) // 1024) else FAMILY
+    return "?"
+
+
 kern, timed = {}, []
 for (k, g, q), v in cnt.items():
-    if k.startswith(("star_small_kernel", "refine_small_kernel", "refine_big_kernel", "redo_list_kernel", "lookahead_band_kernel")):
-        name = k + (" (%s)" % "/".join(q_of.get(q, ["?"])) if k == "redo_list_kernel" else "")
-    elif k.startswith("search_kernel"):
-        waves = v["SQ_WAVES"]
-        sizes = q_of.get(q, ["?"])
-        # the integer stage of the 32x32 / 64x64 PUs has a wave per PU; the launches over marked PUs have at most 8192 waves
-        big = [s for s in sizes if s in ("32", "64") and abs(waves - {"32": 1980, "64": 480}[s] * PAIRS_PMC) < 1]
-        both = "32" in sizes and "64" in sizes and abs(waves - (1980 + 480) * PAIRS_PMC) < 1    # one launch for parents and children
-        name = "search_kernel (%s)" % ("integer stage of the 64x64 and 32x32 PUs" if both else
-                                       "integer stage of the %sx%s PUs" % (big[0], big[0]) if big else
-                                       "PUs star_small_kernel marked, %s" % "/".join(s for s in sizes if s in ("8", "16")))
+    if k.startswith(("star_small_kernel", "refine_small_kernel", "star_big_kernel", "refine_big_kernel", "lookahead_band_kernel")):
+        name = k
+    elif k.startswith(("redo_list_kernel", "star_resume_kernel", "search_kernel")):
+        name = "%s (%s)" % (k, class_of_launch(k, g, q))
     else:
         continue
     if name in kern:
@@ -145,19 +168,37 @@ for (k, g, q), v in cnt.items():
             kern[name][c] += x
     else:
         kern[name] = per_pair(v)
-    if "8" in q_of.get(q, []) and not k.startswith(("lookahead", "refine_big")) and name not in timed:
+    if (k.startswith(("star_small", "refine_small")) or name.endswith("(%s)" % FAMILY)) and name not in timed:
         timed.append(name)
+PUS_16 = 8040            # 120 x 67 whole 16x16 PUs (the 240 8x8 PUs of the last half row have no parent)
+# Essential wave64 VALU instructions of a STAR / subme 5 search of an SxS PU, counted from the algorithm and the
+# instruction set alone: a full-pel candidate is S*S/256 v_sad_u8 wave instructions (64 lanes x 4 samples) + 1 for the MV
+# cost and the comparison; an interpolated SATD candidate costs per sample 8/3 multiply-adds of the horizontal pass (a
+# filtered plane serves the three candidates of a column of the square), 4 two-sample dot products of the vertical pass, 1
+# difference, 2 packed butterflies of the 4x4 Hadamard transform and 1 absolute-value add: 10.7 lane instructions.
+FULLPEL, SUBPEL, LANE_PER_SAMPLE = 21, 18, 8 / 3 + 4 + 1 + 2 + 1
+
+
+def essential(S, fullpel=True, subpel=True):
+    return (FULLPEL * (S * S / 256 + 1) if fullpel else 0) + (SUBPEL * S * S * LANE_PER_SAMPLE / 64 if subpel else 0)
+
+
+ess_family = (PUS_16 * essential(16) + PUS_8 * essential(8, subpel=False)) / (PUS_16 + PUS_8)
 json.dump({"source": "profiles/%s_search_sq_counters.txt (rocprofv3 --pmc SQ_*, bench.py --pairs 2 --steps 1 --warmup 0)" % tag,
-           "simds": 1024, "clock_hz": 2.4e9, "pus_per_pair": PUS_8, "timed_kernels": timed,
-           "essential_wave_instr_per_pu": {"value": 175, "how": "an 8x8 STAR / subme 5 search visits about 21 full-pel and 18 sub-pel "
-                                           "candidates; at four PUs per wave (16 lanes x 4 pixels per PU) a SAD of 64 pixels is 1 "
-                                           "v_sad_u8 + 4 cross-lane adds, an interpolated candidate about 8 multiply-adds per "
-                                           "filter pass and a packed Hadamard of about 20: 150-200 wave instructions per PU "
-                                           "before any control flow"},
+           "simds": 1024, "clock_hz": 2.4e9, "pus_per_pair": PUS_16 + PUS_8, "timed_kernels": timed,
+           "essential_wave_instr_per_pu": {
+               "value": ess_family,
+               "per_pu_size": {str(S): essential(S) for S in (8, 16, 32, 64)},
+               "how": "per SxS PU: %d full-pel candidates x (S*S/256 v_sad_u8 wave instructions + 1) + %d interpolated SATD candidates x "
+                      "S*S x %.1f lane instructions per sample / 64 lanes (horizontal 8-tap pass shared by three candidates 8/3, vertical "
+                      "pass as two-sample dot products 4, difference 1, packed 4x4 Hadamard 2, absolute sum 1); no start-up "
+                      "interpolation, staging, reduction or control flow. The timed class holds a 16x16 PU per four 8x8 PUs, and a "
+                      "candidate's SATD of a 16x16 PU is the sum of its children's: value = (essential(16) + 4 x the full-pel part "
+                      "of essential(8)) / 5 PUs" % (FULLPEL, SUBPEL, LANE_PER_SAMPLE)},
            "valu_wave_instr_per_pair_all_kernels": sum(v["valu"] for v in kern.values()),
            "kernels_per_pair": kern}, open(os.path.join(PROF, "valu.json"), "w"), indent=1)
 
-# ---- HBM traffic of the 8x8 launch class
+# ---- HBM traffic of the timed launch class
 tr = {}
 for what, counter in (("fetch", "FETCH_SIZE"), ("write", "WRITE_SIZE")):
     rows = list(csv.DictReader(open(one("%s_%s/**/*counter_collection.csv" % (tag, what)))))
@@ -166,27 +207,27 @@ for what, counter in (("fetch", "FETCH_SIZE"), ("write", "WRITE_SIZE")):
         if r["Counter_Name"] == counter:
             tr.setdefault(key, {}).setdefault(counter, 0.0)
             tr[key][counter] += float(r["Counter_Value"])
+            if r["Queue_Id"] in q_class:
+                tr[key]["class"] = q_class[r["Queue_Id"]]       # (queue ids of one run; the classes' grids differ anyway)
 tpath = os.path.join(PROF, "traffic.json")
 t = json.load(open(tpath))
 detail = {}
 total = 0.0
 for (k, g), v in tr.items():
-    if not k.startswith(("star_small", "refine_small", "refine_big", "search_kernel", "lookahead_band", "redo_list")):
+    if not k.startswith(("star_small", "refine_small", "star_big", "refine_big", "star_resume", "search_kernel", "lookahead_band", "redo_list")):
         continue
     b = (2 * v.get("FETCH_SIZE", 0) + v.get("WRITE_SIZE", 0)) * 1024 / PAIRS_PMC
+    cls = FAMILY if k.startswith(("star_small", "refine_small")) else class_of_launch(k, g, None) if not k.startswith(("star_big", "refine_big", "lookahead")) else ""
     detail["%s grid %d" % (k, g)] = {"FETCH_SIZE_KB": v.get("FETCH_SIZE", 0) / PAIRS_PMC, "WRITE_SIZE_KB": v.get("WRITE_SIZE", 0) / PAIRS_PMC,
-                                      "hbm_bytes_per_pair": b}
-    if re.match(r"(star_small_kernel|refine_small_kernel)<8[,>]", k) or k == "redo_list_kernel" and g == (PUS_8 * PAIRS_PMC + 2047) // 2048 * 256:
+                                      "hbm_bytes_per_pair": b, "class": cls}
+    if cls == FAMILY:
         total += b
-# the one-wave search over the marked 8x8 PUs shares its grid with the 16x16 class's: half of the pair is charged
-red = tr.get(("search_kernel<unsigned char, false>", 8192 * 64))
-if red:
-    total += (2 * red.get("FETCH_SIZE", 0) + red.get("WRITE_SIZE", 0)) * 1024 / PAIRS_PMC / 2
-t["search_kernel_hbm_bytes_per_launch"]["pairs3"] = total
-t["pairs3_detail"] = {"unit": "per frame pair (the step of the counter run held 2 pairs; bench.py multiplies by its pairs per step)",
-                      "correction": "HBM bytes = 2 x FETCH_SIZE KB (gfx950 counts a 128-byte request as 64 bytes) + WRITE_SIZE KB, "
-                                    "separate --pmc passes (tools/profile_round.sh)",
-                      "timed_class": "star_small_kernel<8> + redo_list_kernel + half of the two search launches over marked PUs + "
-                                     "refine_small_kernel<8>", "kernels": detail}
+t["search_kernel_hbm_bytes_per_launch"]["families"] = total
+t["families_detail"] = {"unit": "per frame pair (the step of the counter run held 2 pairs; bench.py multiplies by its pairs per step)",
+                        "correction": "HBM bytes = 2 x FETCH_SIZE KB (gfx950 counts a 128-byte request as 64 bytes) + WRITE_SIZE KB, "
+                                      "separate --pmc passes (tools/profile_round.sh)",
+                        "timed_class": "the family launch: star_small_kernel<16> and <8>, the list kernels and compact searches of "
+                                       "their handed-on PUs, refine_small_kernel<16> (with the 8x8 children it takes along) and <8>",
+                        "kernels": detail}
 json.dump(t, open(tpath, "w"), indent=1)
 print("\n".join(open(os.path.join(PROF, "%s_bench_kernel_trace.txt" % tag)).read().splitlines()))

@@ -6,7 +6,9 @@
 #include <stdlib.h>
 #include <string.h>
 #include <math.h>
+#include <atomic>
 #include <map>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -870,6 +872,8 @@ struct x265amd_ctx
     unsigned char *scratch;            /* this device's copy of the static scratch array (x265amd_lookahead_fields_static) */
     bool esa_lds_raised, rime_lds_raised; /* dynamic-LDS limits raised on this context's device (the attribute is per device) */
     std::map<const void*, void*> plane_base; /* plane origin -> start of its allocation, whatever the sample size */
+    struct FieldsInfo { int nfields, wcu, hcu, method, merange; };
+    std::map<const void*, FieldsInfo> uploads; /* descriptor arrays of x265amd_fields_upload and what they were checked for */
 };
 
 static x265amd_ctx *g_prim_ctx = 0;    /* context behind the per-call primitives table (me_primitives.inc) */
@@ -884,6 +888,8 @@ static x265amd_ctx *g_prim_ctx = 0;    /* context behind the per-call primitives
 #define SCRATCH_MAX_DEVICES 64
 static __device__ __align__(256) unsigned char scratch[SCRATCH_BYTES];
 static void *g_scratch_ptr[SCRATCH_MAX_DEVICES];   /* per device: address of its copy of `scratch`, 0 = not asked yet */
+static std::mutex g_scratch_mu;                    /* guards g_scratch_ptr (contexts may be created from several threads) */
+static std::atomic<int> g_scratch_busy[SCRATCH_MAX_DEVICES];   /* 1 while a call uses the device's array: a second one is refused */
 
 #define ESA_WINDOW_DEFAULT 36864
 #define ESA_WINDOW_MIN 8192
@@ -996,7 +1002,7 @@ static int search_prepare(x265amd_ctx *c, const SearchArgs &a, bool square_only,
     x265amd_ctx::LaunchBufs &B = c->bufs[set];
     SearchArgs &b = sl.b;
     b = a;
-    sl.square_only = square_only; sl.set = set;
+    sl.square_only = square_only && !(no_quad && a.max_dim == 64); sl.set = set;     /* (without the quad path the 32x32 PUs are the one-wave search's) */
     /* launches of PUs up to 8x8, 16x16, 32x32 or 64x64 (samples of at most 10 bits): the square PUs of that size are
      * refined by a second kernel (four 8x8 PUs or two 16x16 PUs per wave; two waves per 32x32 PU, four per 64x64 PU) */
     b.staged = (sizeof(P) == 1 || c->depth <= 10) && !no_staged &&
@@ -1278,6 +1284,7 @@ static int create_ctx(int device, int bit_depth, int high_priority, x265amd_ctx 
     c->scratch = 0;
     if (device < SCRATCH_MAX_DEVICES)
     {
+        std::lock_guard<std::mutex> lock(g_scratch_mu);
         if (!g_scratch_ptr[device])
         {
             void *ptr = 0;
@@ -1988,12 +1995,17 @@ int x265amd_fields_upload(x265amd_ctx *c, const x265amd_field *fields, int nfiel
     HIPCHK(c, hipSetDevice(c->device));
     HIPCHK(c, hipMalloc(d_fields, nfields * sizeof(FieldDev)));
     HIPCHK(c, hipMemcpy(*d_fields, hf.data(), nfields * sizeof(FieldDev), hipMemcpyHostToDevice));
+    const x265amd_ctx::FieldsInfo info = { nfields, wcu, hcu, method, merange };
+    c->uploads[*d_fields] = info;
     return X265AMD_OK;
 }
+
+int x265amd_abi_version(void) { return X265AMD_ABI_VERSION; }
 
 int x265amd_device_free(x265amd_ctx *c, void *d_ptr)
 {
     if (!c) return X265AMD_EINVAL;
+    c->uploads.erase(d_ptr);
     HIPCHK(c, hipSetDevice(c->device));
     HIPCHK(c, hipFree(d_ptr));
     return X265AMD_OK;
@@ -2007,6 +2019,18 @@ int x265amd_lookahead_fields_dev(x265amd_ctx *c, const void *d_fields, int nfiel
         return fail(c, X265AMD_EINVAL, "null argument");
     if (method < 0 || method > X265AMD_FULL || subme < 0 || subme > 7)
         return fail(c, X265AMD_EINVAL, "bad method / subme");
+    /* the descriptors were checked against the planes for one grid, method and range: nothing else may run on them */
+    {
+        std::map<const void*, x265amd_ctx::FieldsInfo>::const_iterator it = c->uploads.upper_bound(d_fields);
+        if (it == c->uploads.begin()) return fail(c, X265AMD_EINVAL, "d_fields is no array of x265amd_fields_upload on this context");
+        --it;
+        const size_t off = (size_t)((const char*)d_fields - (const char*)it->first);
+        const x265amd_ctx::FieldsInfo &u = it->second;
+        if (off % sizeof(FieldDev) || off / sizeof(FieldDev) + (size_t)nfields > (size_t)u.nfields)
+            return fail(c, X265AMD_EINVAL, "d_fields is no array of x265amd_fields_upload on this context, or holds fewer fields");
+        if (wcu != u.wcu || hcu != u.hcu || merange > u.merange || (method == X265AMD_UMH && u.method != X265AMD_UMH))
+            return fail(c, X265AMD_EINVAL, "d_fields was uploaded for another CU grid, a smaller merange or without the margins of UMH");
+    }
     int rc = x265amd_set_qp(c, qp);
     if (rc) return rc;
     if (!nfields) return X265AMD_OK;
@@ -2047,6 +2071,14 @@ int x265amd_lookahead_fields_static(x265amd_ctx *c, const x265amd_field *fields,
     int rc = lookahead_fields_check(c, fields, nfields, wcu, hcu, method, merange, hf);
     if (rc) return rc;
     HIPCHK(c, hipSetDevice(c->device));
+    /* one call at a time per GPU: a second one (another context, another thread) is refused, not left to race */
+    struct Busy
+    {
+        std::atomic<int> &f; bool mine;
+        Busy(std::atomic<int> &f_) : f(f_) { int z = 0; mine = f.compare_exchange_strong(z, 1); }
+        ~Busy() { if (mine) f.store(0); }
+    } busy(g_scratch_busy[c->device]);
+    if (!busy.mine) return fail(c, X265AMD_EBUSY, "another x265amd_lookahead_fields_static call is using this GPU's static scratch array");
     unsigned char *base = c->scratch;
     LookaheadArgs a;
     a.fields = (const FieldDev*)(base + SCRATCH_HEAD);

@@ -24,6 +24,34 @@
 #ifndef X265AMD_ME_SMALL_H
 #define X265AMD_ME_SMALL_H
 
+/* Waves per SIMD the register allocator is asked to leave room for (512 registers per lane and SIMD; overrides for
+ * measurements: -DOCC_...). Measured on the 1080p step (32 frame pairs, all launch classes side by side): the 16x16
+ * refinement at 169 registers (two waves) 3.55 ms, at 164 (three) 3.40, at 128 with 16 spilled dwords (four) 3.29, at
+ * 96 with 63 spilled (five) 3.53; the other kernels' settings are within +-0.5 % of their neighbours'. */
+#ifndef OCC_R16
+#define OCC_R16 4
+#endif
+#ifndef OCC_R8
+#define OCC_R8 5
+#endif
+#ifndef OCC_RB64
+#define OCC_RB64 5
+#endif
+#ifndef OCC_RB32
+#define OCC_RB32 6
+#endif
+#ifndef OCC_S16
+#define OCC_S16 6
+#endif
+#ifndef OCC_S8
+#define OCC_S8 6
+#endif
+#ifndef OCC_SB64
+#define OCC_SB64 5
+#endif
+#ifndef OCC_SB32
+#define OCC_SB32 8
+#endif
 namespace x265amd {
 
 template<int S> struct SmallGeo
@@ -579,7 +607,7 @@ __device__ __forceinline__ void refine_small_group(const SearchArgs &a, int j, b
 }
 
 template<int S, typename P>
-__global__ __launch_bounds__(64) void refine_small_kernel(SearchArgs a)
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(S == 16 ? OCC_R16 : OCC_R8))) void refine_small_kernel(SearchArgs a)
 {
     typedef RefineGeo<S> RG;
     const int lane = (int)threadIdx.x, grp = lane >> RG::LG;
@@ -629,8 +657,8 @@ __global__ __launch_bounds__(64) void refine_small_kernel(SearchArgs a)
  *
  * The same rounds for the large PUs: a workgroup of two waves per 32x32 PU and of four waves per 64x64 PU, every lane
  * looking after two or four (tile, column) pairs, one tile row band apart, where the one-wave search walks the PU's 64 or 256 tiles through
- * its general candidate machinery. The three planes of a round are filled by all waves together; every wave measures
- * its tiles of every candidate and adds the wave's sum to the candidate's cell in LDS (one cell array per round,
+ * its general candidate machinery. The planes of a round are filled by all waves together, one after the other
+ * through one buffer; every wave measures its tiles of every candidate and adds the wave's sum to the candidate's cell in LDS (one cell array per round,
  * zeroed at the start, so no round has to wait for cells to be cleared); after the barrier every wave reads the same
  * totals and takes the same decisions on its own copy of the PU's values. Workgroups stay small on purpose: a
  * sixteen-wave workgroup per 64x64 PU waits for a compute unit with that much room while launches of small PUs share
@@ -651,7 +679,7 @@ template<int S> struct BigLds
     static constexpr int ROUNDS = 5;                                /* motion.cpp:53-63: at most 2 + 2 rounds, or the closing re-measure */
     static constexpr int VOTES = CELLS + ROUNDS * 256;              /* per round the four children's decisions */
     static constexpr int PLANES = VOTES + ROUNDS * 16;
-    static constexpr int TOTAL = PLANES + 3 * G::PLANE + 32;
+    static constexpr int TOTAL = PLANES + G::PLANE + 32;          /* one plane at a time */
 };
 
 template<int S, typename P>
@@ -731,57 +759,65 @@ __device__ __forceinline__ void refine_big_pu(const SearchArgs &a, int j)
         const int ya = as_i16(qy - step) >> 2, yb = qy >> 2, yc = as_i16(qy + step) >> 2;
         int ymin = ya < yb ? ya : yb;
         ymin = yc < ymin ? yc : ymin;
-        /* horizontal pass: all waves, plane by plane (every wave is past the vertical pass of the round before: it
-         * has read that round's totals behind a barrier) */
+        /* plane by plane through one buffer: all waves filter the plane (horizontal pass), then every wave measures its
+         * tiles of the candidates in that column of the square (vertical pass + cost). One plane instead of three keeps
+         * the workgroup's LDS small enough to find room on a compute unit shared with the small PUs' kernels. A lane's
+         * first half of its pairs lies in the upper half of the PU and the second in the lower (tile rows wave + 4 u),
+         * lanes 0-31 in the left half and 32-63 in the right: the sums of the four quadrants stay apart (lane c: left,
+         * lane c + 32: right) */
+        int partT = 0, partB = 0;
+        bool filled = false;
 #pragma unroll
         for (int p = 0; p < 3; p++)
         {
-            const int xp = as_i16(qx + (p - 1) * step);
-            const P AS1 *src = ref0 + (roff + __mul24(ymin - 3, rstride) + (xp >> 2) - 3);
-            const int *tp = (const int*)(x265amd_smem + SM_TAPS) + (xp & 3) * 12;
-            int16_t *plane = (int16_t*)(x265amd_smem + L::PLANES + p * G::PLANE);
-            for (int item = tid; item < G::IPP; item += THREADS)
+            if (p != 1 && dirs < 4) continue;           /* the closing re-measure has the centre only */
+            if (filled) __syncthreads();                /* every wave is done with the plane before */
+            filled = true;
             {
-                const int r = item >> G::LTW, q = item & (G::TW - 1);
-                hps_quad(src + (__mul24(r, rstride) + 4 * q), tp, plane + (4 * q) * G::PROW + r, G::PROW, depth);
+                const int xp = as_i16(qx + (p - 1) * step);
+                const P AS1 *src = ref0 + (roff + __mul24(ymin - 3, rstride) + (xp >> 2) - 3);
+                const int *tp = (const int*)(x265amd_smem + SM_TAPS) + (xp & 3) * 12;
+                int16_t *plane = (int16_t*)(x265amd_smem + L::PLANES);
+                for (int item = tid; item < G::IPP; item += THREADS)
+                {
+                    const int r = item >> G::LTW, q = item & (G::TW - 1);
+                    hps_quad(src + (__mul24(r, rstride) + 4 * q), tp, plane + (4 * q) * G::PROW + r, G::PROW, depth);
+                }
             }
-        }
-        __syncthreads();
-        /* vertical pass + cost: a candidate per pass, the wave's tiles of it. A lane's first half of its pairs lies in
-         * the upper half of the PU and the second in the lower (tile rows wave + 4 u), lanes 0-31 in the left half and
-         * 32-63 in the right: the sums of the four quadrants stay apart (lane c: left, lane c + 32: right) */
-        int partT = 0, partB = 0;
-        for (int c = 0; c < K; c++)
-        {
-            const int i = c + 1 - k0;
-            const int ty = as_i16(qy + nib(SQY, i) * step);
-            const int poff = L::PLANES + (nib(SQX, i) + 1) * G::PLANE, rr = (ty >> 2) - ymin;
-            /* half-pel rounds: (dx, -1) and (dx, +1) follow each other in the table and are one row apart in the same
-             * plane and phase -- measured together */
-            if (step == 2 && i >= 1 && nib(SQY, i) == -1 && c + 1 < K && nib(SQY, i + 1) == 1 && nib(SQX, i + 1) == nib(SQX, i))
+            __syncthreads();
+            for (int c = 0; c < K; c++)
             {
-                int vaT = 0, vbT = 0, vaB = 0, vbB = 0;
+                const int i = c + 1 - k0;
+                if (nib(SQX, i) != p - 1) continue;
+                const int ty = as_i16(qy + nib(SQY, i) * step);
+                const int poff = L::PLANES, rr = (ty >> 2) - ymin;
+                /* half-pel rounds: (dx, -1) and (dx, +1) follow each other in the table and are one row apart in the
+                 * same plane and phase -- measured together */
+                if (step == 2 && i >= 1 && nib(SQY, i) == -1 && c + 1 < K && nib(SQY, i + 1) == 1 && nib(SQX, i + 1) == nib(SQX, i))
+                {
+                    int vaT = 0, vbT = 0, vaB = 0, vbB = 0;
+#pragma unroll
+                    for (int u = 0; u < ITEMS; u++)
+                    {
+                        if (u < ITEMS / 2) small_column_cost_pair<S>(poff, rr, ty & 3, satd, ct[u], tid & 3, depth, vaT, vbT);
+                        else small_column_cost_pair<S>(poff, rr, ty & 3, satd, ct[u], tid & 3, depth, vaB, vbB);
+                    }
+                    vaT = seg_sum(vaT, 5); vbT = seg_sum(vbT, 5); vaB = seg_sum(vaB, 5); vbB = seg_sum(vbB, 5);
+                    if ((lane & 31) == c) { partT = vaT; partB = vaB; }
+                    if ((lane & 31) == c + 1) { partT = vbT; partB = vbB; }
+                    c++;
+                    continue;
+                }
+                int vT = 0, vB = 0;
 #pragma unroll
                 for (int u = 0; u < ITEMS; u++)
                 {
-                    if (u < ITEMS / 2) small_column_cost_pair<S>(poff, rr, ty & 3, satd, ct[u], tid & 3, depth, vaT, vbT);
-                    else small_column_cost_pair<S>(poff, rr, ty & 3, satd, ct[u], tid & 3, depth, vaB, vbB);
+                    const int v = small_column_cost<S>(poff, rr, ty & 3, satd, ct[u], tid & 3, depth);
+                    if (u < ITEMS / 2) vT += v; else vB += v;
                 }
-                vaT = seg_sum(vaT, 5); vbT = seg_sum(vbT, 5); vaB = seg_sum(vaB, 5); vbB = seg_sum(vbB, 5);
-                if ((lane & 31) == c) { partT = vaT; partB = vaB; }
-                if ((lane & 31) == c + 1) { partT = vbT; partB = vbB; }
-                c++;
-                continue;
+                vT = seg_sum(vT, 5); vB = seg_sum(vB, 5);
+                if ((lane & 31) == c) { partT = vT; partB = vB; }
             }
-            int vT = 0, vB = 0;
-#pragma unroll
-            for (int u = 0; u < ITEMS; u++)
-            {
-                const int v = small_column_cost<S>(poff, rr, ty & 3, satd, ct[u], tid & 3, depth);
-                if (u < ITEMS / 2) vT += v; else vB += v;
-            }
-            vT = seg_sum(vT, 5); vB = seg_sum(vB, 5);
-            if ((lane & 31) == c) { partT = vT; partB = vB; }
         }
         int *cells = (int*)(x265amd_smem + L::CELLS) + rnd * 64;           /* [candidate][TL, TR, BL, BR] */
         if ((lane & 31) < K)
@@ -857,7 +893,7 @@ __device__ __forceinline__ void refine_big_pu(const SearchArgs &a, int j)
 }
 
 template<int S, typename P>
-__global__ __launch_bounds__(BigGeo<S>::THREADS) void refine_big_kernel(SearchArgs a)
+__global__ __launch_bounds__(BigGeo<S>::THREADS) __attribute__((amdgpu_waves_per_eu(S == 64 ? OCC_RB64 : OCC_RB32))) void refine_big_kernel(SearchArgs a)
 {
     small_load_taps<P>((int)threadIdx.x, sizeof(P) == 1 ? 8 : a.depth);
     /* a workgroup per PU of the launch; or (a.list) the launch's list of marked PUs, every workgroup walking it */
@@ -939,7 +975,7 @@ struct StarFold
 };
 
 template<int S, typename P>
-__global__ __launch_bounds__(64) void star_small_kernel(SearchArgs a)
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(S == 16 ? OCC_S16 : OCC_S8))) void star_small_kernel(SearchArgs a)
 {
     const int depth = sizeof(P) == 1 ? 8 : a.depth;
     typedef SmallGeo<S> G;
@@ -1264,7 +1300,7 @@ template<int S> struct StarBigLds
 };
 
 template<int S, typename P>
-__global__ __launch_bounds__(StarBigGeo<S>::THREADS) void star_big_kernel(SearchArgs a)
+__global__ __launch_bounds__(StarBigGeo<S>::THREADS) __attribute__((amdgpu_waves_per_eu(S == 64 ? OCC_SB64 : OCC_SB32))) void star_big_kernel(SearchArgs a)
 {
     const int depth = sizeof(P) == 1 ? 8 : a.depth;
     typedef SmallGeo<S> G;
