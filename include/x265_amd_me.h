@@ -243,6 +243,9 @@ int x265amd_lookahead_fields(x265amd_ctx *ctx, const x265amd_field *fields, int 
 int x265amd_fields_upload(x265amd_ctx *ctx, const x265amd_field *fields, int nfields,
                           int width_in_cu, int height_in_cu, int method, int merange, void **d_fields);
 int x265amd_device_free(x265amd_ctx *ctx, void *d_ptr);
+/* Free and total memory of the context's GPU as the driver reports them (hipMemGetInfo); no reference counterpart: for
+ * callers that size their resident picture sets, and for the test that x265amd_lookahead_fields_static takes none. */
+int x265amd_device_mem_info(x265amd_ctx *ctx, size_t *free_bytes, size_t *total_bytes);
 int x265amd_lookahead_fields_dev(x265amd_ctx *ctx, const void *d_fields, int nfields,
                                  int width_in_cu, int height_in_cu, int qp, int method, int subme, int merange,
                                  int16_t *d_mvs, int32_t *d_costs, x265amd_result *d_stats /* or NULL */);

@@ -65,6 +65,26 @@ def test_field_geometry_is_checked(engine8):
         engine8.lookahead_fields([(la[0], mixed)], 26, 15, 12, 1, 1, 16)          # one half-pel plane with another stride
     with pytest.raises(EngineError):
         engine8.lookahead_fields([(Plane(), lb)], 26, 15, 12, 1, 1, 16)           # null source plane
+    # the device-resident form runs only on what an upload was checked for
+    d = engine8.fields_upload([(la[0], lb), (la[0], lb)], 26, 15, 1, 16)
+    ncu = 26 * 15
+    mv, cost = engine8.device_alloc(2 * ncu * 4), engine8.device_alloc(2 * ncu * 4)
+    engine8.lookahead_fields_dev(d, 2, 26, 15, 12, 1, 1, 16, mv, cost)
+    engine8.sync()
+    got = engine8.download(mv, (2, ncu, 2), np.int16)
+    want = engine8.lookahead_fields([(la[0], lb)], 26, 15, 12, 1, 1, 16)[0]
+    assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[0])
+    engine8.lookahead_fields_dev(d.value + 80, 1, 26, 15, 12, 1, 1, 8, mv, cost)     # a run of its fields, a smaller range
+    for bad in (dict(n=3), dict(wcu=25), dict(merange=17), dict(method=2), dict(ptr=d.value + 40), dict(ptr=mv)):
+        with pytest.raises(EngineError):
+            engine8.lookahead_fields_dev(bad.get("ptr", d), bad.get("n", 2), bad.get("wcu", 26), 15, 12, bad.get("method", 1), 1,
+                                         bad.get("merange", 16), mv, cost)
+    engine8.sync()
+    engine8.device_free(d)
+    with pytest.raises(EngineError):
+        engine8.lookahead_fields_dev(d, 2, 26, 15, 12, 1, 1, 16, mv, cost)          # freed
+    engine8.device_free(mv)
+    engine8.device_free(cost)
 
 
 @pytest.mark.parametrize("rows", [2, 4])

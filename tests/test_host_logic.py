@@ -68,8 +68,6 @@ def test_shard_range_partitions_everything():
                 lo, hi = sharding.shard_range(n, r, world)
                 got += list(range(lo, hi))
             assert got == list(range(n))
-    lo, hi, y0, y1 = sharding.shard_rows(34, 1, 8, 92)
-    assert (lo, hi) == (5, 10) and y0 == 5 * 64 - 100 and y1 == 10 * 64 + 100
 
 
 def _random_field_jobs(width, height, merange, seed, nrefs=3):

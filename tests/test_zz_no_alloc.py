@@ -45,10 +45,37 @@ def test_static_lookahead_matches_allocating_entry_point():
         assert _same(e.lookahead_fields_static(big, 26, 15, 12, 1, 1, 16, want_stats=True), want_big)
         mv, cost, none = e.lookahead_fields_static(small, 13, 8, 12, 1, 1, 16)
         assert none is None and np.array_equal(mv, want_small[0]) and np.array_equal(cost, want_small[1])
+        # the defining property: the calls take no device memory. Everything is warm by now (kernels loaded, cost table
+        # built); the free memory the driver reports must not move over a run of calls, larger after smaller included
+        e.sync()
+        free0 = e.mem_info()[0]
+        for _ in range(3):
+            e.lookahead_fields_static(small, 13, 8, 12, 1, 1, 16, want_stats=True)
+            e.lookahead_fields_static(big, 26, 15, 12, 1, 1, 16, want_stats=True)
+            e.lookahead_fields_static(small, 13, 8, 12, 3, 2, 16)
+        assert e.mem_info()[0] == free0
         # a second context on the same GPU uses the same array (one call at a time)
         e2 = Engine(0, 8)
         e2.set_qp(12)
         assert _same(e2.lookahead_fields_static(small, 13, 8, 12, 1, 1, 16, want_stats=True), want_small)
+        # ... and a call that finds the array in use is refused (X265AMD_EBUSY), whatever context it comes from
+        import threading
+        refused, done = [], []
+
+        def hammer(eng, fields, w, h):
+            for _ in range(40):
+                try:
+                    got = eng.lookahead_fields_static(fields, w, h, 12, 1, 1, 16, want_stats=True)
+                    done.append(_same(got, want_big if fields is big else want_small))
+                except EngineError as ex:
+                    refused.append(str(ex))
+        th = [threading.Thread(target=hammer, args=(e, big, 26, 15)), threading.Thread(target=hammer, args=(e2, small, 13, 8))]
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
+        assert all(done) and len(done) + len(refused) == 80      # every call either ran alone and is right, or was refused
+        assert all("in use" in r or "using" in r for r in refused)
         e2.close()
         # limits: more fields than the entry point takes, and fields that do not fit the array
         with pytest.raises(EngineError):

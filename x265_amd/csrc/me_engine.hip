@@ -2002,6 +2002,14 @@ int x265amd_fields_upload(x265amd_ctx *c, const x265amd_field *fields, int nfiel
 
 int x265amd_abi_version(void) { return X265AMD_ABI_VERSION; }
 
+int x265amd_device_mem_info(x265amd_ctx *c, size_t *free_bytes, size_t *total_bytes)
+{
+    if (!c || !free_bytes || !total_bytes) return fail(c, X265AMD_EINVAL, "null argument");
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipMemGetInfo(free_bytes, total_bytes));
+    return X265AMD_OK;
+}
+
 int x265amd_device_free(x265amd_ctx *c, void *d_ptr)
 {
     if (!c) return X265AMD_EINVAL;

@@ -89,6 +89,9 @@ class Weight(C.Structure):
                 ("orig_score", C.c_uint32), ("min_score", C.c_uint32)]
 
 
+ABI_VERSION = 2
+
+
 class EngineError(RuntimeError):
     pass
 
@@ -96,7 +99,13 @@ class EngineError(RuntimeError):
 def load_library():
     if not os.path.exists(LIB_PATH):
         raise EngineError("HIP engine library %s is missing: build it with __graft_entry__.build()" % LIB_PATH)
-    return C.CDLL(LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    # this binding is written against X265AMD_ABI_VERSION 2 of include/x265_amd_me.h: a library with other argument
+    # lists must not be called through it
+    if not hasattr(lib, "x265amd_abi_version") or lib.x265amd_abi_version() != ABI_VERSION:
+        raise EngineError("HIP engine library %s has another ABI version than this binding (%d): rebuild it with "
+                          "__graft_entry__.build()" % (LIB_PATH, ABI_VERSION))
+    return lib
 
 
 _FN_TYPES = {
@@ -340,6 +349,7 @@ class Engine:
         self._chk(self.L.x265amd_device_free(self.ctx, C.c_void_p(d) if isinstance(d, int) else d))
 
     def lookahead_fields_dev(self, d_fields, nfields, wcu, hcu, qp, method, subme, merange, d_mvs, d_costs, d_stats=None):
+        d_fields = C.c_void_p(d_fields) if isinstance(d_fields, int) else d_fields
         self._chk(self.L.x265amd_lookahead_fields_dev(self.ctx, d_fields, nfields, wcu, hcu, qp, method, subme, merange,
                                                       C.c_void_p(d_mvs), C.c_void_p(d_costs),
                                                       C.c_void_p(d_stats) if d_stats else None))
@@ -349,6 +359,12 @@ class Engine:
         d = C.c_void_p()
         self._chk(self.L.x265amd_device_alloc(self.ctx, C.c_size_t(nbytes), C.byref(d)))
         return d.value
+
+    def mem_info(self):
+        """(free, total) bytes of the context's GPU."""
+        f, t = C.c_size_t(), C.c_size_t()
+        self._chk(self.L.x265amd_device_mem_info(self.ctx, C.byref(f), C.byref(t)))
+        return f.value, t.value
 
     def upload(self, d_dst, arr):
         arr = np.ascontiguousarray(arr)

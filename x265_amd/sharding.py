@@ -15,12 +15,6 @@ def shard_range(n_units, rank, world):
     return lo, lo + q + (1 if rank < r else 0)
 
 
-def shard_rows(n_ctu_rows, rank, world, merange, ctu=64, apron=8):
-    """CTU-row band of `rank` plus the reference rows it needs: band +- (merange + apron) pixels."""
-    lo, hi = shard_range(n_ctu_rows, rank, world)
-    return lo, hi, lo * ctu - merange - apron, hi * ctu + merange + apron
-
-
 def gather_records(local, dist=None, dst=0, bufs=None, async_op=False):
     """Gather equally-shaped record tensors to `dst`. `local` is a torch tensor (uint8 view of the
     records); returns the list of per-rank tensors on dst, None elsewhere. `bufs`: dst's receive tensors to use again
