@@ -210,6 +210,9 @@ struct LookaheadArgs
     x265amd_result *stats; /* nfields * ncu or null */
     int nfields;
     int *ticket;         /* row hand-out counter of lookahead_rows_kernel, zero at launch */
+#ifdef X265AMD_PHASE_PROFILE
+    long long *phase;    /* measurement build: 16 counters per wave of lookahead_band_kernel, or null */
+#endif
 };
 
 __device__ __forceinline__ int median3(int a, int b, int c)
@@ -1171,8 +1174,18 @@ static int launch_family(x265amd_ctx *c, const SearchArgs &parents, const Search
  * fill the chip. LA_ROWS_MAX_FIELDS is where a launch switches over. */
 #define LA_ROWS_MAX_FIELDS 512
 #define LB_LATENCY_WAVES 1024      /* band waves up to which a lookahead launch trades lane work for latency */
+#ifdef X265AMD_PHASE_PROFILE
+static long long *g_phase_buffer = 0;
+/* measurement build only: where the next lookahead_band_kernel launches write their per-wave phase counters
+ * (8192 waves x 16 counters of 8 bytes, zeroed by the caller), or null */
+extern "C" void x265amd_debug_phase_buffer(void *d_buffer) { g_phase_buffer = (long long*)d_buffer; }
+#endif
+
 static int launch_lookahead(x265amd_ctx *c, LookaheadArgs &a, int nfields, int *d_ticket)
 {
+#ifdef X265AMD_PHASE_PROFILE
+    a.phase = g_phase_buffer;
+#endif
     const char *force = getenv("X265AMD_LOOKAHEAD_KERNEL");   /* "field", "rows" or "band": measurements only */
     /* the hexagon search -- the only method the reference's lookahead uses -- has a kernel of its own (four CU rows per
      * wave, any number of fields) */

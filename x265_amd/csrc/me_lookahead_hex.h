@@ -230,9 +230,24 @@ template<typename P, int LG> struct BandCu
 
 __device__ __forceinline__ int mv_word(int x, int y) { return (x & 0xffff) | (y << 16); }
 
+/* Measurement build (-DX265AMD_PHASE_PROFILE): a wave adds up, in registers, the shader-clock cycles it spends between
+ * the marks of a CU step and writes the sums once, with plain vector stores from lane 0, when it has no band left:
+ * phase[wave][0..LB_NPHASE-1] cycles, [LB_NPHASE] steps, [LB_NPHASE + 1] hexagon-walk iterations. The product build
+ * has none of it. */
+#ifdef X265AMD_PHASE_PROFILE
+#define LB_NPHASE 10
+#define LB_MARK(i) do { const long long t_ = (long long)__builtin_readcyclecounter(); ph[i] += t_ - tlast; tlast = t_; } while (0)
+#else
+#define LB_MARK(i) do { } while (0)
+#endif
+
 template<typename P, int LG>
 __global__ __launch_bounds__(64) void lookahead_band_kernel(LookaheadArgs a)
 {
+#ifdef X265AMD_PHASE_PROFILE
+    long long ph[LB_NPHASE + 2] = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
+    long long tlast = (long long)__builtin_readcyclecounter();
+#endif
     constexpr int ROWS = 64 >> LG;                  /* CU rows of a band */
     /* passes of the integer stage's evaluations: start-up (at most 7 candidates), hexagon (6), closing square (8) */
     constexpr int CPP = BandCu<P, LG>::CPP, NP7 = (7 + CPP - 1) / CPP, NP6 = (6 + CPP - 1) / CPP, NP8 = (8 + CPP - 1) / CPP;
@@ -267,6 +282,10 @@ __global__ __launch_bounds__(64) void lookahead_band_kernel(LookaheadArgs a)
         for (int s = 0; s < W + 2 * (ROWS - 1); s++)
         {
             const int cux = W - 1 - (s - 2 * g);
+            LB_MARK(9);                                     /* between steps: ticket, loop, wave_sync */
+#ifdef X265AMD_PHASE_PROFILE
+            ph[LB_NPHASE]++;
+#endif
             if (cuy >= 0 && cux >= 0 && cux < W)
             {
                 const int cuXY = cux + cuy * W;
@@ -298,6 +317,7 @@ __global__ __launch_bounds__(64) void lookahead_band_kernel(LookaheadArgs a)
                         if (cux < W - 1) bright = rb[(cux + 1) & 3];
                     }
                 }
+                LB_MARK(0);                                 /* the neighbours' MVs: polling the band below, or LDS */
                 int cx[4] = { 0, 0, 0, 0 }, cy[4] = { 0, 0, 0, 0 }, numc = 0;
 #define LB_PUSH(word) do { const int w_ = (word); if (numc == 0) { cx[0] = as_i16(w_); cy[0] = w_ >> 16; } else if (numc == 1) { cx[1] = as_i16(w_); cy[1] = w_ >> 16; } \
                            else if (numc == 2) { cx[2] = as_i16(w_); cy[2] = w_ >> 16; } else { cx[3] = as_i16(w_); cy[3] = w_ >> 16; } numc++; } while (0)
@@ -342,6 +362,7 @@ __global__ __launch_bounds__(64) void lookahead_band_kernel(LookaheadArgs a)
 #undef LB_CLIPX
 #undef LB_CLIPY
                 int bcost, bprecost, bpx = pmx, bpy = pmy;
+                LB_MARK(1);                                 /* predictor, bounds, source tile loads issued, candidate clipping */
                 {
                     const int fx = as_i16(bmx << 2), fy = as_i16(bmy << 2);
                     /* slots: 0 clipped predictor (no lambda * bits of its own, :579-582), 1 its full-pel rounding, 2 MV 0, 3.. candidates */
@@ -380,6 +401,7 @@ __global__ __launch_bounds__(64) void lookahead_band_kernel(LookaheadArgs a)
                         }
                     }
                 }
+                LB_MARK(2);                                 /* start-up candidates and their tests */
                 /* ---- hexagon search, motion.cpp:651-723 ---- */
                 {
                     const int ox = bmx, oy = bmy;
@@ -387,6 +409,7 @@ __global__ __launch_bounds__(64) void lookahead_band_kernel(LookaheadArgs a)
                                             [](int) { return true; });
                     C.nsad += 6;
                     int dir = C.fold(mine, 0, 6, bcost);
+                    LB_MARK(3);                             /* the hexagon's six points */
                     if (dir >= 0)
                     {
                         bmx = as_i16(bmx + nib(H2X, dir + 1)); bmy = as_i16(bmy + nib(H2Y, dir + 1));
@@ -397,12 +420,16 @@ __global__ __launch_bounds__(64) void lookahead_band_kernel(LookaheadArgs a)
                                                   [](int) { return true; });
                             C.nsad += 3;
                             const int step = C.fold(m3, 0, 3, bcost) + 1;
+#ifdef X265AMD_PHASE_PROFILE
+                            ph[LB_NPHASE + 1]++;
+#endif
                             if (!step) break;
                             dir += step - 2;
                             dir = nib(MOD6M1, dir + 1);
                             bmx = as_i16(bmx + nib(H2X, dir + 1)); bmy = as_i16(bmy + nib(H2Y, dir + 1));
                         }
                     }
+                    LB_MARK(4);                             /* the walk: three points per iteration */
                     const int sx = bmx, sy = bmy;
                     const int m8 = C.template eval_sad<NP8, true>(8, [&](int k, int &x, int &y) { x = as_i16(as_i16(sx + nib(SQX, k + 1)) << 2); y = as_i16(as_i16(sy + nib(SQY, k + 1)) << 2); },
                                           [](int) { return true; });
@@ -410,6 +437,7 @@ __global__ __launch_bounds__(64) void lookahead_band_kernel(LookaheadArgs a)
                     const int sq = C.fold(m8, 0, 8, bcost) + 1;
                     bmx = as_i16(bmx + nib(SQX, sq)); bmy = as_i16(bmy + nib(SQY, sq));
                 }
+                LB_MARK(5);                                 /* the closing square */
                 /* ---- motion.cpp:1063-1069, then the lowres sub-pel rounds, :1077-1099 ---- */
                 int qx, qy;
                 if (bprecost < bcost) { qx = bpx; qy = bpy; bcost = bprecost; }
@@ -418,6 +446,7 @@ __global__ __launch_bounds__(64) void lookahead_band_kernel(LookaheadArgs a)
                 {
                     C.stage_window(qx, qy, (W - cux) * 8, (H - cuy) * 8 + 12 - LB_WIN_H);
                     wave_sync();
+                    LB_MARK(6);                             /* the sub-pel window staged in LDS */
                     {
                         const int ox = qx, oy = qy;
                         const int mine = C.template eval<true>(hpel_dirs, false, [&](int k, int &x, int &y) { x = as_i16(ox + nib(SQX, k + 1) * 2); y = as_i16(oy + nib(SQY, k + 1) * 2); },
@@ -427,6 +456,7 @@ __global__ __launch_bounds__(64) void lookahead_band_kernel(LookaheadArgs a)
                         const int bdir = k < 0 ? 0 : k + 1;
                         qx = as_i16(qx + nib(SQX, bdir) * 2); qy = as_i16(qy + nib(SQY, bdir) * 2);
                     }
+                    LB_MARK(7);                             /* half-pel round */
                     {
                         const int ox = qx, oy = qy;
                         const int mine = C.template eval<true>(1 + qpel_dirs, true, [&](int k, int &x, int &y) { x = as_i16(ox + nib(SQX, k)); y = as_i16(oy + nib(SQY, k)); },
@@ -438,6 +468,7 @@ __global__ __launch_bounds__(64) void lookahead_band_kernel(LookaheadArgs a)
                         qx = as_i16(qx + nib(SQX, bdir)); qy = as_i16(qy + nib(SQY, bdir));
                     }
                 }
+                LB_MARK(8);                                 /* quarter-pel round */
                 right = mv_word(qx, qy);
                 rowmv[g * 4 + (cux & 3)] = right;
                 if (l == 0)
@@ -455,6 +486,10 @@ __global__ __launch_bounds__(64) void lookahead_band_kernel(LookaheadArgs a)
             wave_sync();
         }
     }
+#ifdef X265AMD_PHASE_PROFILE
+    if (a.phase && lane == 0)
+        for (int i = 0; i < LB_NPHASE + 2; i++) a.phase[(size_t)blockIdx.x * 16 + i] = ph[i];
+#endif
 }
 
 } // namespace x265amd
