@@ -201,6 +201,25 @@ int x265amd_check_jobs_pairs_dev(x265amd_ctx *ctx, const x265amd_pair *pairs, in
  * not depend on it. */
 int x265amd_set_esa_window_bytes(x265amd_ctx *ctx, int bytes);
 
+/* X265_FULL_SEARCH (encoder/motion.cpp:1021-1056) of every square PU of whole 64x64 CTUs: the quadtree of
+ * TEncCu::xCompressCU (Lib/TLibEncoder/TEncCu.cpp:2352) has the encoder search the 64x64 PU, its four 32x32, sixteen
+ * 16x16 and sixty-four 8x8 PUs, and the SAD of a PU at a displacement is the sum of its 8x8 blocks' -- the reference's
+ * hardware model shares them the same way (hardwareC/inter.cpp:2521-2624). With 8-bit samples one scan per CTU measures
+ * the 8x8 level over the bounding box of the PUs' ranges and adds the sums up the quadtree, every PU keeping the first
+ * minimum of its own range with its own predictor's lambda * bits; results equal x265amd_search_batch with X265_FULL_SEARCH
+ * job for job (deeper samples, or a QP whose cost table can wrap, run the per-size scans). It pays where the
+ * predictors of a CTU's PUs lie close together (the scan covers the box around all ranges); a caller sends CTUs whose
+ * ranges lie far apart through x265amd_search_batch_dev per size instead.
+ * jobs / results: 85 nctu records -- the 64 nctu 8x8 PUs (CTU-major; inside a CTU in Morton order: bit 0 of the index
+ * = bit 0 of the block column, bit 1 = bit 0 of the block row, and so on), then the 16 nctu 16x16 PUs (likewise), the
+ * 4 nctu 32x32 PUs (raster order inside a CTU), the nctu 64x64 PUs. A slot with w = h = 0 holds no PU (CTUs the picture's
+ * edge cuts) and gets cost -1; its pu_x / pu_y still name its place, and slot 0 of a CTU's 8x8 PUs is the CTU's origin.
+ * The host form checks every slot (place, size, and what x265amd_search_batch checks); the device-resident form does not. */
+int x265amd_esa_ctu_batch(x265amd_ctx *ctx, const x265amd_plane *fenc, const x265amd_plane *ref, int qp, int subme,
+                          const x265amd_job *jobs, int nctu, x265amd_result *results);
+int x265amd_esa_ctu_batch_dev(x265amd_ctx *ctx, const x265amd_plane *fenc, const x265amd_plane *ref, int qp, int subme,
+                              const x265amd_job *d_jobs, int nctu, x265amd_result *d_results);
+
 /* MotionEstimate::subpelCompare (encoder/motion.cpp:1651-1689) for njobs PUs:
  * job.qmvp is the qpel MV to evaluate, cmp 0 = sad, 1 = satd; results[i].cost. */
 int x265amd_subpel_compare_batch(x265amd_ctx *ctx, const x265amd_plane *fenc, const x265amd_plane *ref,

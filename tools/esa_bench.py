@@ -28,6 +28,9 @@ def main():
     ap.add_argument("--window", type=int, default=0, help="LDS window bytes (0 = library default)")
     ap.add_argument("--check", type=int, default=0, help="PUs per size to compare with the CPU oracle")
     ap.add_argument("--lib", default="", help="engine library to load instead of the in-tree build (experiments)")
+    ap.add_argument("--ctu", action="store_true", help="also time the CTU scan (all four sizes in one launch, 8x8 SADs shared) "
+                                                       "and compare its records with the per-size launches'")
+    ap.add_argument("--spread", type=int, default=12, help="the stand-in lookahead field's MVs lie in +-spread (lowres quarter-pels)")
     args = ap.parse_args()
 
     import torch
@@ -64,6 +67,12 @@ def main():
         print(line, flush=True)
     print("all     %8.3f ms  %7.2f T pixel-SAD/s  %5.1f %% of SAD issue peak" % (
         total_ms, total_px / total_ms / 1e9, 100.0 * total_px / (total_ms * 1e-3) / peak))
+    if args.ctu:
+        for spread in sorted({args.spread, 0}):
+            r = measure.esa_ctu_picture(e, dev, args.width, args.height, args.merange, args.subme, args.reps, spread=spread, compare=True)
+            # the SADs the scan measures are the 8x8 level's; the count every PU is credited with is four times that
+            print("CTU scan, field +-%-2d  %6d PUs in %d CTUs  %8.3f ms  %7.2f T pixel-SAD/s credited  records %s the per-size launches'" % (
+                spread, r["pus"], r["ctus"], r["ms"], r["pixel_sads"] / r["ms"] / 1e9, "equal" if r["equal"] else "DIFFER FROM"), flush=True)
 
 
 if __name__ == "__main__":

@@ -164,6 +164,7 @@ __global__ __launch_bounds__(64) void search_kernel(SearchArgs a)
 }
 
 #include "me_esa.h"   /* esa_scan_kernel, esa_finish_kernel: use SearchArgs and xcd_remap */
+#include "me_esa_ctu.h"   /* esa_ctu_kernel: the scan of all 85 square PUs of a CTU at once */
 #include "me_small.h"   /* star_small_kernel, refine_small_kernel: 8x8 / 16x16 PUs in fixed-shape kernels, four / one per wave */
 #include "me_lookahead_cost.h"
 
@@ -917,6 +918,22 @@ static int ensure(x265amd_ctx *c, void **p, size_t *cap, size_t need)
     return 0;
 }
 
+/* the stages around an exhaustive scan (esa_finish_kernel) and the sub-pel refinement of the launch's fixed-shape size */
+template<typename P>
+static void esa_finish(x265amd_ctx *c, const SearchArgs &b, int window_bytes, hipStream_t st)
+{
+    const int n = b.njobs;
+    hipLaunchKernelGGL(esa_finish_kernel<P>, dim3(n), dim3(64), wave_lds_bytes<P>(b.max_dim, true), st, b, window_bytes);
+    if (b.staged == 8)
+        hipLaunchKernelGGL((refine_small_kernel<8, P>), dim3((n + 3) / 4), dim3(64), RefineLds<8>::TOTAL, st, b);
+    else if (b.staged == 16)
+        hipLaunchKernelGGL((refine_small_kernel<16, P>), dim3((n + RefineGeo<16>::NPU - 1) / RefineGeo<16>::NPU), dim3(64), RefineLds<16>::TOTAL, st, b);
+    else if (b.staged == 32)
+        hipLaunchKernelGGL((refine_big_kernel<32, P>), dim3(n), dim3(BigGeo<32>::THREADS), BigLds<32>::TOTAL, st, b);
+    else if (b.staged == 64)
+        hipLaunchKernelGGL((refine_big_kernel<64, P>), dim3(n), dim3(BigGeo<64>::THREADS), BigLds<64>::TOTAL, st, b);
+}
+
 /* X265_FULL_SEARCH: workgroup-per-PU scan through an LDS window, then the one-wave stages around it */
 template<typename P>
 static int launch_esa(x265amd_ctx *c, const SearchArgs &a, int window_bytes, int nowrap)
@@ -944,16 +961,33 @@ static int launch_esa(x265amd_ctx *c, const SearchArgs &a, int window_bytes, int
         hipLaunchKernelGGL((esa_scan_kernel<P, 16>), dim3(a.njobs), dim3(ESA_THREADS), scan_lds, c->stream, b, window_bytes, nowrap);
     else
         hipLaunchKernelGGL((esa_scan_kernel<P, 0>), dim3(a.njobs), dim3(ESA_THREADS), scan_lds, c->stream, b, window_bytes, nowrap);
-    hipLaunchKernelGGL(esa_finish_kernel<P>, dim3(a.njobs), dim3(64), wave_lds_bytes<P>(a.max_dim, true),
-                       c->stream, b, window_bytes);
-    if (b.staged == 8)
-        hipLaunchKernelGGL((refine_small_kernel<8, P>), dim3((a.njobs + 3) / 4), dim3(64), RefineLds<8>::TOTAL, c->stream, b);
-    else if (b.staged == 16)
-        hipLaunchKernelGGL((refine_small_kernel<16, P>), dim3((a.njobs + RefineGeo<16>::NPU - 1) / RefineGeo<16>::NPU), dim3(64), RefineLds<16>::TOTAL, c->stream, b);
-    else if (b.staged == 32)
-        hipLaunchKernelGGL((refine_big_kernel<32, P>), dim3(a.njobs), dim3(BigGeo<32>::THREADS), BigLds<32>::TOTAL, c->stream, b);
-    else if (b.staged == 64)
-        hipLaunchKernelGGL((refine_big_kernel<64, P>), dim3(a.njobs), dim3(BigGeo<64>::THREADS), BigLds<64>::TOTAL, c->stream, b);
+    esa_finish<P>(c, b, window_bytes, c->stream);
+    HIPCHK(c, hipGetLastError());
+    return X265AMD_OK;
+}
+
+/* X265_FULL_SEARCH of whole CTUs (8-bit samples): one scan over all of a CTU's PUs, then the stages around it per PU
+ * size. a.jobs: 85 slots per CTU in the order me_esa_ctu.h describes. */
+static int launch_esa_ctu(x265amd_ctx *c, const SearchArgs &a, int nctu)
+{
+    static bool raised[SCRATCH_MAX_DEVICES];
+    if (!raised[c->device])
+    {
+        HIPCHK(c, hipFuncSetAttribute((const void*)esa_ctu_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, ECTU_L_TOTAL));
+        raised[c->device] = true;
+    }
+    static const bool no_staged = getenv("X265AMD_NO_STAGED") != 0;      /* measurements only */
+    hipLaunchKernelGGL(esa_ctu_kernel, dim3(nctu), dim3(ECTU_THREADS), ECTU_L_TOTAL, c->stream, a, nctu);
+    static const int first[5] = { 0, 64, 80, 84, 85 };
+    for (int k = 0; k < 4; k++)
+    {
+        SearchArgs b = a;
+        b.jobs = a.jobs + (size_t)first[k] * nctu; b.results = a.results + (size_t)first[k] * nctu;
+        b.njobs = (first[k + 1] - first[k]) * nctu;
+        b.max_dim = 8 << k;
+        b.staged = no_staged ? 0 : b.max_dim;
+        esa_finish<uint8_t>(c, b, ESA_WINDOW_DEFAULT, c->stream);
+    }
     HIPCHK(c, hipGetLastError());
     return X265AMD_OK;
 }
@@ -1868,6 +1902,85 @@ int x265amd_search_batch(x265amd_ctx *c, const x265amd_plane *fenc, const x265am
                     (x265amd_result*)c->d_results, dim | (squares ? X265AMD_SQUARE_ONLY : 0), window);
     if (rc) return rc;
     HIPCHK(c, hipMemcpyAsync(results, c->d_results, (size_t)njobs * sizeof(x265amd_result), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return X265AMD_OK;
+}
+
+/* ---- exhaustive search of whole CTUs ---- */
+
+/* the launch for a checked or device-resident CTU list: the shared scan where the engine has it (8-bit samples, a cost
+ * table whose entries never wrap when added), the per-size scans otherwise -- same results either way */
+static int esa_ctu_dev(x265amd_ctx *c, const x265amd_plane *fenc, const x265amd_plane *ref, int qp, int subme,
+                       const x265amd_job *d_jobs, int nctu, x265amd_result *d_results)
+{
+    if (!c || !fenc || !ref || !d_jobs || !d_results || nctu < 0) return fail(c, X265AMD_EINVAL, "null argument");
+    if (subme < 0 || subme > 7) return fail(c, X265AMD_EINVAL, "bad subme");
+    if (nctu > (1 << 24) / ECTU_PUS) return fail(c, X265AMD_EINVAL, "too many CTUs in one launch");
+    int rc = x265amd_set_qp(c, qp);
+    if (rc) return rc;
+    if (!nctu) return X265AMD_OK;
+    HIPCHK(c, hipSetDevice(c->device));
+    SearchArgs a;
+    fill_args(c, a, fenc, ref, 0, qp, X265AMD_FULL, subme);
+    a.jobs = d_jobs; a.results = d_results; a.njobs = ECTU_PUS * nctu;
+    static const bool no_share = getenv("X265AMD_NO_ESA_CTU") != 0;      /* measurements only */
+    if (c->depth <= 8 && c->table_nowrap[qp] && !no_share) return launch_esa_ctu(c, a, nctu);
+    static const int first[5] = { 0, 64, 80, 84, 85 };
+    for (int k = 0; k < 4; k++)
+    {
+        SearchArgs b = a;
+        b.jobs = d_jobs + (size_t)first[k] * nctu; b.results = d_results + (size_t)first[k] * nctu;
+        b.njobs = (first[k + 1] - first[k]) * nctu;
+        b.max_dim = 8 << k;
+        rc = c->depth <= 8 ? launch_esa<uint8_t>(c, b, esa_window_for(c, b.max_dim), c->table_nowrap[qp])
+                           : launch_esa<uint16_t>(c, b, esa_window_for(c, b.max_dim), c->table_nowrap[qp]);
+        if (rc) return rc;
+    }
+    return X265AMD_OK;
+}
+
+int x265amd_esa_ctu_batch_dev(x265amd_ctx *c, const x265amd_plane *fenc, const x265amd_plane *ref, int qp, int subme,
+                              const x265amd_job *d_jobs, int nctu, x265amd_result *d_results)
+{
+    return esa_ctu_dev(c, fenc, ref, qp, subme, d_jobs, nctu, d_results);
+}
+
+int x265amd_esa_ctu_batch(x265amd_ctx *c, const x265amd_plane *fenc, const x265amd_plane *ref, int qp, int subme,
+                          const x265amd_job *jobs, int nctu, x265amd_result *results)
+{
+    if (!c || !fenc || !ref || !jobs || !results || nctu < 0) return fail(c, X265AMD_EINVAL, "null argument");
+    if (nctu > (1 << 24) / ECTU_PUS) return fail(c, X265AMD_EINVAL, "too many CTUs in one launch");
+    /* every slot: empty (w = h = 0), or the square of its size at its place in the CTU, a job x265amd_search_batch would take */
+    for (int k = 0; k < nctu; k++)
+    {
+        const x265amd_job &o = jobs[ectu_job(0, k, nctu)];
+        int lox = 0x7fffffff, hix = -0x7fffffff, loy = 0x7fffffff, hiy = -0x7fffffff;
+        for (int p = 0; p < ECTU_PUS; p++)
+        {
+            const x265amd_job &j = jobs[ectu_job(p, k, nctu)];
+            if (!j.w && !j.h) continue;
+            int ox, oy, s;
+            ectu_slot(p, ox, oy, s);
+            if (j.w != s || j.h != s || j.pu_x != o.pu_x + ox || j.pu_y != o.pu_y + oy)
+                return fail(c, X265AMD_EINVAL, "CTU list: a slot holds neither nothing nor the square PU of its place and size");
+            int rc = validate_jobs(c, fenc, ref, 0, X265AMD_FULL, subme, &j, 1);
+            if (rc) return rc;
+            lox = j.mvmin[0] < lox ? j.mvmin[0] : lox; hix = j.mvmax[0] > hix ? j.mvmax[0] : hix;
+            loy = j.mvmin[1] < loy ? j.mvmin[1] : loy; hiy = j.mvmax[1] > hiy ? j.mvmax[1] : hiy;
+        }
+        if (hix >= lox && (hix - lox >= ECTU_MAX_SPAN || hiy - loy >= ECTU_MAX_SPAN))
+            return fail(c, X265AMD_EINVAL, "CTU list: the search ranges of a CTU's PUs span more than 1024 positions");
+    }
+    if (!nctu) return X265AMD_OK;
+    HIPCHK(c, hipSetDevice(c->device));
+    const size_t n = (size_t)ECTU_PUS * nctu;
+    int rc;
+    if ((rc = ensure(c, &c->d_jobs, &c->jobs_cap, n * sizeof(x265amd_job)))) return rc;
+    if ((rc = ensure(c, &c->d_results, &c->results_cap, n * sizeof(x265amd_result)))) return rc;
+    HIPCHK(c, hipMemcpyAsync(c->d_jobs, jobs, n * sizeof(x265amd_job), hipMemcpyHostToDevice, c->stream));
+    rc = esa_ctu_dev(c, fenc, ref, qp, subme, (const x265amd_job*)c->d_jobs, nctu, (x265amd_result*)c->d_results);
+    if (rc) return rc;
+    HIPCHK(c, hipMemcpyAsync(results, c->d_results, n * sizeof(x265amd_result), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return X265AMD_OK;
 }

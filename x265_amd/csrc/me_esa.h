@@ -538,7 +538,9 @@ __global__ __launch_bounds__(64) void esa_finish_kernel(SearchArgs a, int win_bu
     J.load(job);
     const int w = uni(job->w), h = uni(job->h);
     EsaGeo g;
-    if (!esa_job_ok(J, w, h, a.max_dim, win_budget, g, EsaLane<P>::CX, EsaLane<P>::BPS))
+    const uint32_t bc = (uint32_t)uni(a.results[j].cost), bi = (uint32_t)uni((int)a.results[j].sad_calls);
+    /* refused: a job the scan cannot take, a slot of a CTU launch that holds no PU (w = 0), or one the scan marked */
+    if (w == 0 || bc == 0xffffffffu || !esa_job_ok(J, w, h, a.max_dim, win_budget, g, EsaLane<P>::CX, EsaLane<P>::BPS))
     {
         if (threadIdx.x == 0)
         {
@@ -547,7 +549,6 @@ __global__ __launch_bounds__(64) void esa_finish_kernel(SearchArgs a, int win_bu
         }
         return;
     }
-    const uint32_t bc = (uint32_t)uni(a.results[j].cost), bi = (uint32_t)uni((int)a.results[j].sad_calls);
     Searcher<P, 64> S;
     SearchState st;
     PlaneDev pfenc, pref[4];

@@ -1,0 +1,399 @@
+/* Exhaustive integer search (X265_FULL_SEARCH, source/encoder/motion.cpp:1021-1056) of all 85 square PUs of a 64x64
+ * CTU at once (8-bit samples).
+ *
+ * The SAD of a PU at a displacement is the sum of the SADs of its 8x8 blocks at that displacement, so the four quadtree
+ * depths of a CTU (TEncCu::xCompressCU, Lib/TLibEncoder/TEncCu.cpp:2352, searches every one of them) need the 8x8 level
+ * measured once: the reference's own hardware model does the same for its refinement windows
+ * (source/hardwareC/inter.cpp:2521-2624). One workgroup takes a CTU. It scans the bounding box of the PUs' search
+ * ranges in absolute displacements (the ranges of the PUs of a CTU differ where their predictors do): strips of the
+ * box's reference window go through LDS, and per task a wave measures a patch of 4 x 8 displacements with a lane per
+ * 8x8 block (v_qsad_pk_u16_u8 as in esa_patch, the block's source samples in registers). The lanes are in Morton
+ * order, so a 16x16 PU is a quad of lanes and a 32x32 PU a row of sixteen: the packed 16-bit sums go up to 16x16 by
+ * two DPP adds per dword (16 x 16 x 255 still fits 16 bits), then every lane of a quad keeps a quarter of the patch,
+ * widens it, and two row rotations give the 32x32 sums; of those every lane keeps a pair of displacements and two
+ * lane-swap adds give the 64x64 sums. Every level folds its sums with its own PU's lambda * bits -- per-PU tables of
+ * (cost << 5 | index in the patch) per column and per row of the strip, a sentinel outside the PU's own range -- into
+ * the lane's running minimum of (cost, row, column), which is the position the reference's strict-'<' raster scan of
+ * that PU keeps. esa_finish_kernel and the refinement kernels then run per PU size as after esa_scan_kernel.
+ *
+ * Job order of a launch of n CTUs: the 64 n 8x8 PUs (CTU-major, Morton order inside a CTU), then the 16 n 16x16 PUs
+ * (likewise), the 4 n 32x32 PUs (raster order inside a CTU = Morton order), the n 64x64 PUs. A slot whose w is 0 is a
+ * PU that is not searched (CTUs cut by the picture's edge); slot 0 of a CTU's 8x8 PUs always carries the CTU's origin.
+ */
+#ifndef X265AMD_ME_ESA_CTU_H
+#define X265AMD_ME_ESA_CTU_H
+
+#include "me_esa.h"
+
+namespace x265amd {
+
+#define ECTU_THREADS 512
+#define ECTU_WAVES (ECTU_THREADS / 64)
+#define ECTU_PUS 85
+#define ECTU_XG 24                              /* groups of 4 columns per strip at most */
+#define ECTU_YG 4                               /* groups of 8 rows per strip at most */
+/* dwords per PU of the column / row tables: a multiple of 4 that is no multiple of 8, so that the 64 lanes of a
+ * 16-byte read, one PU each, spread over all banks */
+#define ECTU_KXP (ECTU_XG * 4 + 4)
+#define ECTU_KYP (ECTU_YG * 8 + 4)
+/* bytes per window row: 96 columns + 64 of the CTU, and eight rows (one block row) a multiple of 16 dwords that is
+ * no multiple of 32: lanes 0 .. 31 (block rows 0 .. 3, two dwords per block column) then hit every bank once */
+#define ECTU_PITCH 168
+#define ECTU_WROWS (ECTU_YG * 8 + 63)
+#define ECTU_L_HDR 0
+#define ECTU_L_PU 64                            /* per PU 8 ints: mnx, mxx, mny, mxy, qmx, qmy, present, job index */
+#define ECTU_L_KX (ECTU_L_PU + ECTU_PUS * 32)
+#define ECTU_L_KY (ECTU_L_KX + ECTU_PUS * ECTU_KXP * 4)
+#define ECTU_L_WIN (ECTU_L_KY + ECTU_PUS * ECTU_KYP * 4)
+#define ECTU_L_TOTAL (ECTU_L_WIN + ECTU_WROWS * ECTU_PITCH)
+#define ECTU_L_RED ECTU_L_KX                    /* the waves' minima, over the column tables once the scan is over */
+#define ECTU_SENT 0x1000000u                    /* added to the cost of a position outside a PU's range (EsaLane<uint8_t>::SENT) */
+#define ECTU_MAX_SPAN 1024                      /* columns / rows of the bounding box at most (10 bits each in a lane's index) */
+
+enum { EH_BX0 = 0, EH_BX1, EH_BY0, EH_BY1, EH_GX0, EH_GX1, EH_GY0, EH_GY1, EH_SX1, EH_SY1, EH_ANY };
+
+/* where PU slot p of a CTU lies in it and how large it is */
+__host__ __device__ inline void ectu_slot(int p, int &ox, int &oy, int &s)
+{
+    int k = p, sh = 3;
+    s = 8;
+    if (p >= 84) { k = 0; s = 64; sh = 6; }
+    else if (p >= 80) { k = p - 80; s = 32; sh = 5; }
+    else if (p >= 64) { k = p - 64; s = 16; sh = 4; }
+    const int mx = (k & 1) | ((k >> 1) & 2) | ((k >> 2) & 4), my = ((k >> 1) & 1) | ((k >> 2) & 2) | ((k >> 3) & 4);
+    ox = mx << sh; oy = my << sh;
+}
+
+/* index of slot p of CTU c in the job list of a launch of n CTUs */
+__host__ __device__ inline int ectu_job(int p, int c, int n)
+{
+    if (p < 64) return c * 64 + p;
+    if (p < 80) return 64 * n + c * 16 + (p - 64);
+    if (p < 84) return 80 * n + c * 4 + (p - 80);
+    return 84 * n + c;
+}
+
+__device__ __forceinline__ uint32_t ectu_mad_lo(uint32_t a, uint32_t k)
+{
+    uint32_t r;
+    asm("v_mad_u32_u16 %0, %1, 32, %2" : "=v"(r) : "v"(a), "v"(k));
+    return r;
+}
+__device__ __forceinline__ uint32_t ectu_mad_hi(uint32_t a, uint32_t k)
+{
+    uint32_t r;
+    asm("v_mad_u32_u16 %0, %1, 32, %2 op_sel:[1,0,0,0]" : "=v"(r) : "v"(a), "v"(k));
+    return r;
+}
+__device__ __forceinline__ uint32_t ectu_min(uint32_t a, uint32_t b) { return a < b ? a : b; }
+
+/* a level's best key of one patch into the lane's running minimum: key = cost << 5 | index in the patch (row * 4 +
+ * column); base = first row of the patch << 10 | its first column */
+__device__ __forceinline__ void ectu_update(uint32_t &bc, uint32_t &bi, uint32_t key, uint32_t base)
+{
+    const uint32_t cost = key >> 5, ri = base + ((key & 28u) << 8) + (key & 3u);
+    const bool better = cost < bc || (cost == bc && ri < bi);
+    bc = better ? cost : bc; bi = better ? ri : bi;
+}
+
+/* minimum of (cost, index) over the lanes whose numbers differ in the bits of `mask` */
+__device__ __forceinline__ void ectu_lane_min(uint32_t &bc, uint32_t &bi, int mask)
+{
+    for (int o = 1; o < 64; o <<= 1)
+    {
+        if (!(o & mask)) continue;
+        const uint32_t oc = (uint32_t)__shfl_xor((int)bc, o), oi = (uint32_t)__shfl_xor((int)bi, o);
+        if (oc < bc || (oc == bc && oi < bi)) { bc = oc; bi = oi; }
+    }
+}
+
+__global__ __launch_bounds__(ECTU_THREADS) __attribute__((amdgpu_waves_per_eu(4))) void esa_ctu_kernel(SearchArgs a, int nctu)
+{
+    const int c = xcd_remap(blockIdx.x, nctu);
+    if (c >= nctu) return;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    int *hdr = lds_i(0, ECTU_L_HDR);
+    if (tid == 0)
+    {
+        hdr[EH_BX0] = hdr[EH_BY0] = hdr[EH_GX0] = hdr[EH_GY0] = 0x7fffffff;
+        hdr[EH_BX1] = hdr[EH_BY1] = hdr[EH_GX1] = hdr[EH_GY1] = hdr[EH_SX1] = hdr[EH_SY1] = -0x7fffffff;
+        hdr[EH_ANY] = 0;
+    }
+    /* the CTU's origin: slot 0 carries it whether or not its PU is searched */
+    const int o0 = uni(((const int*)(a.jobs + ectu_job(0, c, nctu)))[0]);
+    const int ctx = as_i16(o0), cty = o0 >> 16;
+    __syncthreads();
+    if (tid < ECTU_PUS)
+    {
+        const int j = ectu_job(tid, c, nctu);
+        const int *p = (const int*)(a.jobs + j);
+        const int d0 = p[0], d1 = p[1], d2 = p[2], d3 = p[3], d4 = p[4];
+        int ox, oy, s;
+        ectu_slot(tid, ox, oy, s);
+        const int mnx = as_i16(d2), mny = d2 >> 16, mxx = as_i16(d3), mxy = d3 >> 16;
+        /* searched: a square of the slot's size at the slot's place with a range that is not empty */
+        const bool present = (d1 & 0xffff) == (s | (s << 8)) && as_i16(d0) == ctx + ox && (d0 >> 16) == cty + oy &&
+                             mnx <= mxx && mny <= mxy;
+        int *q = lds_i(0, ECTU_L_PU) + tid * 8;
+        q[0] = mnx; q[1] = mxx; q[2] = mny; q[3] = mxy; q[4] = as_i16(d4); q[5] = d4 >> 16; q[6] = present; q[7] = j;
+        if (present)
+        {
+            atomicMin(hdr + EH_BX0, mnx); atomicMax(hdr + EH_BX1, mxx);
+            atomicMin(hdr + EH_BY0, mny); atomicMax(hdr + EH_BY1, mxy);
+            /* what the PUs may read of the reference (their windows) and of the source, relative to the CTU */
+            atomicMin(hdr + EH_GX0, ox + mnx); atomicMax(hdr + EH_GX1, ox + s - 1 + mxx);
+            atomicMin(hdr + EH_GY0, oy + mny); atomicMax(hdr + EH_GY1, oy + s - 1 + mxy);
+            atomicMax(hdr + EH_SX1, ox + s - 1); atomicMax(hdr + EH_SY1, oy + s - 1);
+            hdr[EH_ANY] = 1;
+        }
+        else if ((d1 & 0xffff) != 0)
+        {
+            /* not what the slot holds: refused (esa_finish_kernel passes the mark on) */
+            a.results[j].cost = -1; a.results[j].sad_calls = 0;
+        }
+    }
+    __syncthreads();
+    if (!hdr[EH_ANY]) return;
+    const int bx0 = hdr[EH_BX0], by0 = hdr[EH_BY0];
+    const int nxb = hdr[EH_BX1] - bx0 + 1, nyb = hdr[EH_BY1] - by0 + 1;
+    const int gx0 = hdr[EH_GX0], gx1 = hdr[EH_GX1], gy0 = hdr[EH_GY0], gy1 = hdr[EH_GY1];
+    if (nxb > ECTU_MAX_SPAN || nyb > ECTU_MAX_SPAN)
+    {
+        if (tid < ECTU_PUS && lds_i(0, ECTU_L_PU)[tid * 8 + 6]) { const int j = lds_i(0, ECTU_L_PU)[tid * 8 + 7]; a.results[j].cost = -1; a.results[j].sad_calls = 0; }
+        return;
+    }
+    const uint16_t AS1 *ctab = (const uint16_t AS1*)a.ctab;
+    const uint8_t AS1 *ref = (const uint8_t AS1*)a.ref[0].origin + (long)cty * a.ref[0].stride + ctx;
+    const long rstride = a.ref[0].stride;
+
+    /* the lane's 8x8 block (Morton order) and its source samples: 8 rows of two dwords */
+    const int bx8 = (lane & 1) | ((lane >> 1) & 2) | ((lane >> 2) & 4), by8 = ((lane >> 1) & 1) | ((lane >> 2) & 2) | ((lane >> 3) & 4);
+    uint32_t f[16];
+    {
+        /* blocks of PUs that are not searched read the last searched block's samples instead of running off the plane */
+        const int sbx = bx8 < (hdr[EH_SX1] >> 3) ? bx8 : hdr[EH_SX1] >> 3, sby = by8 < (hdr[EH_SY1] >> 3) ? by8 : hdr[EH_SY1] >> 3;
+        const uint8_t AS1 *src = (const uint8_t AS1*)a.fenc.origin + (long)(cty + sby * 8) * a.fenc.stride + ctx + sbx * 8;
+        typedef uint32_t __attribute__((aligned(1))) u32u;
+#pragma unroll
+        for (int y = 0; y < 8; y++)
+        {
+            f[2 * y] = *(const u32u AS1*)(src + (long)y * a.fenc.stride);
+            f[2 * y + 1] = *(const u32u AS1*)(src + (long)y * a.fenc.stride + 4);
+        }
+    }
+    const int q = lane & 3, Q = (lane >> 2) & 3;
+    uint32_t bc8 = 0xffffffffu, bi8 = 0xffffffffu, bc16 = 0xffffffffu, bi16 = 0xffffffffu;
+    uint32_t bc32 = 0xffffffffu, bi32 = 0xffffffffu, bc64 = 0xffffffffu, bi64 = 0xffffffffu;
+
+    const int nxg = (nxb + 3) >> 2, nyg = (nyb + 7) >> 3;
+    const int nxs = (nxg + ECTU_XG - 1) / ECTU_XG, xgs = (nxg + nxs - 1) / nxs;       /* strips evened out */
+    const int nys = (nyg + ECTU_YG - 1) / ECTU_YG, ygs = (nyg + nys - 1) / nys;
+    for (int xs0 = 0; xs0 < nxg; xs0 += xgs)
+    {
+        const int xgc = nxg - xs0 < xgs ? nxg - xs0 : xgs;
+        if (xs0) __syncthreads();               /* every wave is done with the tables of the strip before */
+        /* lambda * bits of the strip's columns per PU (bitcost.h:46), as (cost << 5 | column in its group) */
+        for (int p = wave; p < ECTU_PUS; p += ECTU_WAVES)
+        {
+            const int *pq = lds_i(0, ECTU_L_PU) + p * 8;
+            const int mnx = uni(pq[0]), mxx = uni(pq[1]), qmx = uni(pq[4]), present = uni(pq[6]);
+            for (int i = lane; i < xgc * 4; i += 64)
+            {
+                const int mvx = bx0 + xs0 * 4 + i;
+                uint32_t v = ECTU_SENT;
+                if (present && mvx >= mnx && mvx <= mxx) v = ctab[as_i16(mvx << 2) - qmx];
+                ((uint32_t*)(x265amd_smem + ECTU_L_KX))[p * ECTU_KXP + i] = (v << 5) | (uint32_t)(i & 3);
+            }
+        }
+        for (int ys0 = 0; ys0 < nyg; ys0 += ygs)
+        {
+            const int ygc = nyg - ys0 < ygs ? nyg - ys0 : ygs;
+            if (ys0) __syncthreads();
+            for (int p = wave; p < ECTU_PUS; p += ECTU_WAVES)
+            {
+                const int *pq = lds_i(0, ECTU_L_PU) + p * 8;
+                const int mny = uni(pq[2]), mxy = uni(pq[3]), qmy = uni(pq[5]), present = uni(pq[6]);
+                const int i = lane;
+                if (i < ygc * 8)
+                {
+                    const int mvy = by0 + ys0 * 8 + i;
+                    uint32_t v = ECTU_SENT;
+                    if (present && mvy >= mny && mvy <= mxy) v = ctab[as_i16(mvy << 2) - qmy];
+                    ((uint32_t*)(x265amd_smem + ECTU_L_KY))[p * ECTU_KYP + i] = (v << 5) | (uint32_t)((i & 7) << 2);
+                }
+            }
+            {
+                /* the window of the strip: a wave copies whole rows (lane = dword). Rows and dwords are held inside
+                 * what the searched PUs' own windows (with their 8-sample apron) cover: positions that read beyond
+                 * that are in no PU's range */
+                const int W0 = bx0 + xs0 * 4, Y0 = by0 + ys0 * 8;      /* relative to the CTU */
+                const int rows = ygc * 8 + 63, nd = xgc + 16;
+                int dlo = (gx0 - 8 - W0 + 3) >> 2, dhi = (gx1 + 5 - W0) >> 2;
+                dlo = dlo < 0 ? 0 : dlo;
+                int d = lane < dhi ? lane : dhi;
+                d = d > dlo ? d : dlo;
+                const uint8_t AS1 *src0 = ref + W0 + 4 * d;
+                typedef uint32_t __attribute__((aligned(1))) u32u;
+                for (int r0 = wave; r0 < rows; r0 += 4 * ECTU_WAVES)
+                {
+                    uint32_t v[4];
+#pragma unroll
+                    for (int u = 0; u < 4; u++)
+                    {
+                        int y = Y0 + r0 + u * ECTU_WAVES;
+                        y = y < gy0 ? gy0 : (y > gy1 ? gy1 : y);
+                        v[u] = *(const u32u AS1*)(src0 + (long)y * rstride);
+                    }
+#pragma unroll
+                    for (int u = 0; u < 4; u++)
+                    {
+                        const int r = r0 + u * ECTU_WAVES;
+                        if (r < rows && lane < nd) *(uint32_t*)(x265amd_smem + ECTU_L_WIN + r * ECTU_PITCH + 4 * lane) = v[u];
+                    }
+                }
+            }
+            __syncthreads();
+
+            const int ntask = xgc * ygc;
+            for (int t = wave; t < ntask; t += ECTU_WAVES)
+            {
+                const int yg = t / xgc, xg = t - yg * xgc;
+                const int org = ECTU_L_WIN + (by8 * 8 + yg * 8) * ECTU_PITCH + bx8 * 8 + xg * 4;
+                uint64_t a16[8];
+#pragma unroll
+                for (int k = 0; k < 8; k++) a16[k] = 0;
+#pragma unroll
+                for (int j = 0; j < 2; j++)
+                {
+                    uint64_t rw[15];
+#pragma unroll
+                    for (int k = 0; k < 15; k++) rw[k] = lds_pair(org + 4 * j + k * ECTU_PITCH);
+#pragma unroll
+                    for (int yy = 0; yy < 8; yy++)
+#pragma unroll
+                        for (int k = 0; k < 8; k++)
+                            a16[k] = __builtin_amdgcn_qsad_pk_u16_u8(rw[yy + k], f[2 * yy + j], a16[k]);
+                }
+                const uint32_t base = (uint32_t)(((ys0 + yg) * 8) << 10) | (uint32_t)((xs0 + xg) * 4);
+                /* 8x8: the lane's own PU */
+                {
+                    const uint4 kx = *(const uint4*)(x265amd_smem + ECTU_L_KX + (lane * ECTU_KXP + xg * 4) * 4);
+                    const uint4 k0 = *(const uint4*)(x265amd_smem + ECTU_L_KY + (lane * ECTU_KYP + yg * 8) * 4);
+                    const uint4 k1 = *(const uint4*)(x265amd_smem + ECTU_L_KY + (lane * ECTU_KYP + yg * 8 + 4) * 4);
+                    const uint32_t ky[8] = { k0.x, k0.y, k0.z, k0.w, k1.x, k1.y, k1.z, k1.w };
+                    uint32_t best = 0xffffffffu;
+#pragma unroll
+                    for (int k = 0; k < 8; k++)
+                    {
+                        const uint32_t lo = (uint32_t)a16[k], hi = (uint32_t)(a16[k] >> 32);
+                        uint32_t m = ectu_min(ectu_min(ectu_mad_lo(lo, kx.x), ectu_mad_hi(lo, kx.y)),
+                                              ectu_min(ectu_mad_lo(hi, kx.z), ectu_mad_hi(hi, kx.w)));
+                        best = ectu_min(best, m + ky[k]);
+                    }
+                    ectu_update(bc8, bi8, best, base);
+                }
+                /* 16x16: the quad's sums, still packed; lane q of the quad keeps rows 2q and 2q + 1 of the patch */
+                uint32_t sel[4];
+                {
+                    uint32_t s[16];
+#pragma unroll
+                    for (int k = 0; k < 8; k++) { s[2 * k] = (uint32_t)a16[k]; s[2 * k + 1] = (uint32_t)(a16[k] >> 32); }
+#pragma unroll
+                    for (int k = 0; k < 16; k++)
+                    {
+                        s[k] += (uint32_t)dpp_all<0xB1>((int)s[k]);
+                        s[k] += (uint32_t)dpp_all<0x4E>((int)s[k]);
+                    }
+#pragma unroll
+                    for (int k = 0; k < 4; k++)
+                    {
+                        const uint32_t t0 = (q & 1) ? s[4 + k] : s[k], t1 = (q & 1) ? s[12 + k] : s[8 + k];
+                        sel[k] = (q & 2) ? t1 : t0;
+                    }
+                    const int p = 64 + (lane >> 2);
+                    const uint4 kx = *(const uint4*)(x265amd_smem + ECTU_L_KX + (p * ECTU_KXP + xg * 4) * 4);
+                    const uint2 ky = *(const uint2*)(x265amd_smem + ECTU_L_KY + (p * ECTU_KYP + yg * 8 + 2 * q) * 4);
+                    const uint32_t mA = ectu_min(ectu_min(ectu_mad_lo(sel[0], kx.x), ectu_mad_hi(sel[0], kx.y)),
+                                                 ectu_min(ectu_mad_lo(sel[1], kx.z), ectu_mad_hi(sel[1], kx.w))) + ky.x;
+                    const uint32_t mB = ectu_min(ectu_min(ectu_mad_lo(sel[2], kx.x), ectu_mad_hi(sel[2], kx.y)),
+                                                 ectu_min(ectu_mad_lo(sel[3], kx.z), ectu_mad_hi(sel[3], kx.w))) + ky.y;
+                    ectu_update(bc16, bi16, ectu_min(mA, mB), base);
+                }
+                /* 32x32: the sums of the four quads of a row of sixteen lanes, 32 bits wide */
+                uint32_t w[8];
+                {
+#pragma unroll
+                    for (int k = 0; k < 4; k++) { w[2 * k] = sel[k] & 0xffffu; w[2 * k + 1] = sel[k] >> 16; }
+#pragma unroll
+                    for (int k = 0; k < 8; k++)
+                    {
+                        w[k] += (uint32_t)dpp_all<0x124>((int)w[k]);     /* row_ror:4 */
+                        w[k] += (uint32_t)dpp_all<0x128>((int)w[k]);     /* row_ror:8 */
+                    }
+                    const int p = 80 + (lane >> 4);
+                    const uint4 kx = *(const uint4*)(x265amd_smem + ECTU_L_KX + (p * ECTU_KXP + xg * 4) * 4);
+                    const uint2 ky = *(const uint2*)(x265amd_smem + ECTU_L_KY + (p * ECTU_KYP + yg * 8 + 2 * q) * 4);
+                    const uint32_t mA = ectu_min(ectu_min((w[0] << 5) + kx.x, (w[1] << 5) + kx.y),
+                                                 ectu_min((w[2] << 5) + kx.z, (w[3] << 5) + kx.w)) + ky.x;
+                    const uint32_t mB = ectu_min(ectu_min((w[4] << 5) + kx.x, (w[5] << 5) + kx.y),
+                                                 ectu_min((w[6] << 5) + kx.z, (w[7] << 5) + kx.w)) + ky.y;
+                    ectu_update(bc32, bi32, ectu_min(mA, mB), base);
+                }
+                /* 64x64: lane (Q, q) of a row keeps columns 2 (Q & 1), + 1 of patch row 2q + (Q >> 1); the four rows of
+                 * sixteen lanes are added up by the two lane swaps */
+                {
+                    const uint32_t t0 = (Q & 1) ? w[2] : w[0], t1 = (Q & 1) ? w[6] : w[4];
+                    const uint32_t v0 = (Q & 1) ? w[3] : w[1], v1 = (Q & 1) ? w[7] : w[5];
+                    uint32_t u0 = (Q & 2) ? t1 : t0, u1 = (Q & 2) ? v1 : v0;
+                    auto r0 = __builtin_amdgcn_permlane16_swap(u0, u0, false, false);
+                    u0 = r0[0] + r0[1];
+                    auto r1 = __builtin_amdgcn_permlane16_swap(u1, u1, false, false);
+                    u1 = r1[0] + r1[1];
+                    r0 = __builtin_amdgcn_permlane32_swap(u0, u0, false, false);
+                    u0 = r0[0] + r0[1];
+                    r1 = __builtin_amdgcn_permlane32_swap(u1, u1, false, false);
+                    u1 = r1[0] + r1[1];
+                    const uint2 kx = *(const uint2*)(x265amd_smem + ECTU_L_KX + (84 * ECTU_KXP + xg * 4 + 2 * (Q & 1)) * 4);
+                    const uint32_t ky = *(const uint32_t*)(x265amd_smem + ECTU_L_KY + (84 * ECTU_KYP + yg * 8 + 2 * q + (Q >> 1)) * 4);
+                    ectu_update(bc64, bi64, ectu_min((u0 << 5) + kx.x, (u1 << 5) + kx.y) + ky, base);
+                }
+            }
+        }
+    }
+
+    /* the PUs' minima: over the lanes that share a PU, then over the waves */
+    ectu_lane_min(bc16, bi16, 3);
+    ectu_lane_min(bc32, bi32, 15);
+    ectu_lane_min(bc64, bi64, 63);
+    __syncthreads();
+    {
+        uint32_t *red = (uint32_t*)(x265amd_smem + ECTU_L_RED) + wave * ECTU_PUS * 2;
+        red[lane * 2] = bc8; red[lane * 2 + 1] = bi8;
+        if (q == 0) { red[(64 + (lane >> 2)) * 2] = bc16; red[(64 + (lane >> 2)) * 2 + 1] = bi16; }
+        if ((lane & 15) == 0) { red[(80 + (lane >> 4)) * 2] = bc32; red[(80 + (lane >> 4)) * 2 + 1] = bi32; }
+        if (lane == 0) { red[84 * 2] = bc64; red[84 * 2 + 1] = bi64; }
+    }
+    __syncthreads();
+    if (tid < ECTU_PUS)
+    {
+        const int *pq = lds_i(0, ECTU_L_PU) + tid * 8;
+        if (pq[6])
+        {
+            uint32_t bc = 0xffffffffu, bi = 0xffffffffu;
+            for (int k = 0; k < ECTU_WAVES; k++)
+            {
+                const uint32_t *red = (const uint32_t*)(x265amd_smem + ECTU_L_RED) + (k * ECTU_PUS + tid) * 2;
+                const uint32_t oc = red[0], oi = red[1];
+                if (oc < bc || (oc == bc && oi < bi)) { bc = oc; bi = oi; }
+            }
+            /* as esa_scan_kernel leaves it: cost and the raster index inside the PU's own range */
+            const int mvx = bx0 + (int)(bi & 1023u), mvy = by0 + (int)(bi >> 10);
+            const int j = pq[7];
+            a.results[j].cost = (int)bc;
+            a.results[j].sad_calls = (uint32_t)((mvy - pq[2]) * (pq[1] - pq[0] + 1) + (mvx - pq[0]));
+        }
+    }
+}
+
+} // namespace x265amd
+#endif

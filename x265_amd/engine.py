@@ -202,6 +202,20 @@ class Engine:
                                               C.c_void_p(jobs.ctypes.data), len(jobs), C.c_void_p(res.ctypes.data)))
         return res
 
+    def esa_ctu_batch(self, fenc, ref, jobs, nctu, qp, subme):
+        """X265_FULL_SEARCH of whole CTUs through the scan that shares the 8x8 SADs between the quadtree depths:
+        jobs = 85 * nctu records in the order workload.esa_ctu_jobs makes."""
+        jobs = np.ascontiguousarray(jobs, JOB_DTYPE)
+        assert len(jobs) == 85 * nctu
+        res = np.zeros(len(jobs), RESULT_DTYPE)
+        self._chk(self.L.x265amd_esa_ctu_batch(self.ctx, C.byref(fenc), C.byref(ref), qp, subme,
+                                               C.c_void_p(jobs.ctypes.data), nctu, C.c_void_p(res.ctypes.data)))
+        return res
+
+    def esa_ctu_batch_dev(self, fenc, ref, d_jobs, nctu, d_results, qp, subme):
+        self._chk(self.L.x265amd_esa_ctu_batch_dev(self.ctx, C.byref(fenc), C.byref(ref), qp, subme,
+                                                   C.c_void_p(d_jobs), nctu, C.c_void_p(d_results)))
+
     def subpel_compare_batch(self, fenc, ref, jobs, cmp):
         jobs = np.ascontiguousarray(jobs, JOB_DTYPE)
         res = np.zeros(len(jobs), RESULT_DTYPE)

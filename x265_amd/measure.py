@@ -53,6 +53,49 @@ def esa_per_size(e, dev, width=3840, height=2160, merange=92, sizes=(64, 32, 16,
     return rows, (cur, ref, org, stride)
 
 
+def esa_ctu_picture(e, dev, width=3840, height=2160, merange=92, subme=5, reps=3, seed=99, qp=32, spread=12, compare=False):
+    """--me full over every square PU of one picture against one reference through the CTU scan (x265amd_esa_ctu_batch_dev:
+    the 8x8 SADs measured once per CTU and summed up the quadtree), the same picture, stand-in lookahead field
+    (`spread`: its MVs lie in +-spread lowres quarter-pels) and jobs as esa_per_size.
+    Returns {ms, pus, ctus, pixel_sads, jobs, results[, equal]}; compare: the per-size launches' records are compared too."""
+    import torch
+    M = 128
+    clip = make_clip(width, height, 2, seed=seed, depth=e.depth)
+    cur, org, stride = pad_plane(clip[1], M)
+    ref, _, _ = pad_plane(clip[0], M)
+    pc = e.upload_plane(cur, width, height, M, M, stride)
+    pr = e.upload_plane(ref, width, height, M, M, stride)
+    rng = np.random.default_rng(5)
+    wcu, hcu = (width // 2 + 7) // 8, (height // 2 + 7) // 8
+    la = rng.integers(-spread, spread + 1, (wcu * hcu, 2)).astype(np.int16)
+    jobs = workload.square_pu_jobs(width, height, la, wcu, hcu, merange)
+    cj, index, nctu = workload.esa_ctu_jobs(jobs, width, height)
+    n = len(cj)
+    d_jobs = torch.from_numpy(cj.view(np.uint8).reshape(n, -1).copy()).to(dev)
+    d_res = torch.zeros((n, RESULT_DTYPE.itemsize), dtype=torch.uint8, device=dev)
+    torch.cuda.synchronize()
+    ms = _timed(torch, e, dev, lambda: e.esa_ctu_batch_dev(pc, pr, d_jobs.data_ptr(), nctu, d_res.data_ptr(), qp, subme), reps)
+    res = d_res.cpu().numpy().view(RESULT_DTYPE).reshape(-1)
+    have = index >= 0
+    out = {"ms": ms, "pus": int(have.sum()), "ctus": nctu, "pixel_sads": workload.pixel_sads(cj[have], res[have]),
+           "jobs": cj[have], "results": res[have], "planes": (cur, ref, org, stride)}
+    if compare:
+        m = len(jobs)
+        dj = torch.from_numpy(jobs.view(np.uint8).reshape(m, -1).copy()).to(dev)
+        dr = torch.zeros((m, RESULT_DTYPE.itemsize), dtype=torch.uint8, device=dev)
+        first = 0
+        for s in (64, 32, 16, 8):
+            cnt = int((jobs["w"] == s).sum())
+            e.search_batch_dev(pc, pr, dj.data_ptr() + 40 * first, cnt, dr.data_ptr() + 16 * first, qp, METHODS["full"], subme, max_pu_dim=s)
+            first += cnt
+        e.sync()
+        per = dr.cpu().numpy().view(RESULT_DTYPE).reshape(-1)
+        out["equal"] = bool(np.array_equal(res[have], per[index[have]]))
+    e.free_plane(pc)
+    e.free_plane(pr)
+    return out
+
+
 def rk_picture(e, dev, width=1920, height=1080, reps=5, seed=5, qp=30):
     """CIME + RIME + FME of every CTU of one picture against one reference, default RK search range.
     Returns a dict with ms, ctus, pixel_sads and the inputs / results for checking."""

@@ -128,6 +128,47 @@ def family_lists(host_jobs, parent=16):
     return (np.concatenate(pj), np.concatenate(pi), np.concatenate(fam_c + orphans), np.concatenate(fam_i + orph_i))
 
 
+def ctu_slot(p):
+    """(x offset, y offset, size) of slot p of the 85 square PUs of a 64x64 CTU as x265amd_esa_ctu_batch orders them:
+    0-63 the 8x8 PUs in Morton order, 64-79 the 16x16 PUs in Morton order, 80-83 the 32x32 PUs, 84 the 64x64 PU."""
+    if p >= 84:
+        k, s = 0, 64
+    elif p >= 80:
+        k, s = p - 80, 32
+    elif p >= 64:
+        k, s = p - 64, 16
+    else:
+        k, s = p, 8
+    mx = (k & 1) | ((k >> 1) & 2) | ((k >> 2) & 4)
+    my = ((k >> 1) & 1) | ((k >> 2) & 2) | ((k >> 3) & 4)
+    return mx * s, my * s, s
+
+
+def esa_ctu_jobs(jobs, width, height):
+    """The job list of x265amd_esa_ctu_batch for a picture: `jobs` holds square PUs of 64 / 32 / 16 / 8 samples (as
+    square_pu_jobs makes them); every 64x64 CTU that holds at least one of them gets its 85 slots, size-major (all
+    CTUs' 8x8 slots, then the 16x16, 32x32, 64x64 ones), a slot without a PU in `jobs` with w = h = 0.
+    Returns (list, index) with index[k] = position in `jobs` of slot k, or -1."""
+    pos = {(int(j["pu_x"]), int(j["pu_y"]), int(j["w"])): k for k, j in enumerate(jobs) if j["w"] == j["h"]}
+    ctus = sorted({(y // 64, x // 64) for (x, y, s) in pos})
+    n = len(ctus)
+    first = (0, 64 * n, 80 * n, 84 * n)
+    out = np.zeros(85 * n, JOB_DTYPE)
+    index = np.full(85 * n, -1, np.int64)
+    for c, (cy, cx) in enumerate(ctus):
+        for p in range(85):
+            ox, oy, s = ctu_slot(p)
+            lvl = 0 if p < 64 else 1 if p < 80 else 2 if p < 84 else 3
+            slot = first[lvl] + c * (64, 16, 4, 1)[lvl] + (p - (0, 64, 80, 84)[lvl])
+            k = pos.get((cx * 64 + ox, cy * 64 + oy, s))
+            if k is None:
+                out[slot]["pu_x"], out[slot]["pu_y"] = cx * 64 + ox, cy * 64 + oy
+            else:
+                out[slot] = jobs[k]
+                index[slot] = k
+    return out, index, n
+
+
 def algorithmic_bytes(jobs, bytes_per_pixel=1):
     w = jobs["w"].astype(np.int64)
     h = jobs["h"].astype(np.int64)
