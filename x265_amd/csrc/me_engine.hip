@@ -968,6 +968,7 @@ static int launch_esa(x265amd_ctx *c, const SearchArgs &a, int window_bytes, int
 
 /* X265_FULL_SEARCH of whole CTUs (8-bit samples): one scan over all of a CTU's PUs, then the stages around it per PU
  * size. a.jobs: 85 slots per CTU in the order me_esa_ctu.h describes. */
+static int aux_stream(x265amd_ctx *c);
 static int launch_esa_ctu(x265amd_ctx *c, const SearchArgs &a, int nctu)
 {
     static bool raised[SCRATCH_MAX_DEVICES];
@@ -978,6 +979,12 @@ static int launch_esa_ctu(x265amd_ctx *c, const SearchArgs &a, int nctu)
     }
     static const bool no_staged = getenv("X265AMD_NO_STAGED") != 0;      /* measurements only */
     hipLaunchKernelGGL(esa_ctu_kernel, dim3(nctu), dim3(ECTU_THREADS), ECTU_L_TOTAL, c->stream, a, nctu);
+    /* the stages around the scan are short launches that depend on the scan alone: the two small sizes on the
+     * context's stream, the two large ones beside them on its second stream */
+    int rc = aux_stream(c);
+    if (rc) return rc;
+    HIPCHK(c, hipEventRecord(c->ev_fork, c->stream));
+    HIPCHK(c, hipStreamWaitEvent(c->aux, c->ev_fork, 0));
     static const int first[5] = { 0, 64, 80, 84, 85 };
     for (int k = 0; k < 4; k++)
     {
@@ -986,8 +993,10 @@ static int launch_esa_ctu(x265amd_ctx *c, const SearchArgs &a, int nctu)
         b.njobs = (first[k + 1] - first[k]) * nctu;
         b.max_dim = 8 << k;
         b.staged = no_staged ? 0 : b.max_dim;
-        esa_finish<uint8_t>(c, b, ESA_WINDOW_DEFAULT, c->stream);
+        esa_finish<uint8_t>(c, b, ESA_WINDOW_DEFAULT, k < 2 ? c->stream : c->aux);
     }
+    HIPCHK(c, hipEventRecord(c->ev_join, c->aux));
+    HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_join, 0));
     HIPCHK(c, hipGetLastError());
     return X265AMD_OK;
 }
@@ -1153,6 +1162,8 @@ static int launch_search(x265amd_ctx *c, const SearchArgs &a, int is_lowres, boo
             sl.b.plane_lds = plane_budget(a.max_dim, (int)sizeof(P)) / 2;
             lds -= sl.b.plane_lds;
         }
+        /* "refined with its parent": the STAR kernels clear these marks for their launches; here nothing else does */
+        if (sl.b.done) HIPCHK(c, hipMemsetAsync(sl.b.done, 0, (size_t)a.njobs, c->stream));
         hipLaunchKernelGGL((search_kernel<P, false>), dim3(a.njobs < SEARCH_GRID ? a.njobs : SEARCH_GRID), dim3(64), lds + pad, c->stream, sl.b);
         launch_refine<P>(sl.b, c->stream, 0);
     }

@@ -86,13 +86,17 @@ __device__ __forceinline__ uint32_t ectu_mad_hi(uint32_t a, uint32_t k)
     return r;
 }
 __device__ __forceinline__ uint32_t ectu_min(uint32_t a, uint32_t b) { return a < b ? a : b; }
+/* b where the mask is all ones, a where it is zero: one v_bfi_b32 (written as a choice between array elements by a
+ * lane-dependent condition the compiler puts the array into scratch memory and indexes it) */
+__device__ __forceinline__ uint32_t ectu_pick(uint32_t m, uint32_t a, uint32_t b) { return (b & m) | (a & ~m); }
 
 /* a level's best key of one patch into the lane's running minimum: key = cost << 5 | index in the patch (row * 4 +
  * column); base = first row of the patch << 10 | its first column */
 __device__ __forceinline__ void ectu_update(uint32_t &bc, uint32_t &bi, uint32_t key, uint32_t base)
 {
     const uint32_t cost = key >> 5, ri = base + ((key & 28u) << 8) + (key & 3u);
-    const bool better = cost < bc || (cost == bc && ri < bi);
+    const unsigned long long k = ((unsigned long long)cost << 32) | ri, b = ((unsigned long long)bc << 32) | bi;
+    const bool better = k < b;
     bc = better ? cost : bc; bi = better ? ri : bi;
 }
 
@@ -182,6 +186,7 @@ __global__ __launch_bounds__(ECTU_THREADS) __attribute__((amdgpu_waves_per_eu(4)
         }
     }
     const int q = lane & 3, Q = (lane >> 2) & 3;
+    const uint32_t qm1 = 0u - (uint32_t)(q & 1), qm2 = 0u - (uint32_t)(q >> 1), Qm1 = 0u - (uint32_t)(Q & 1), Qm2 = 0u - (uint32_t)(Q >> 1);
     uint32_t bc8 = 0xffffffffu, bi8 = 0xffffffffu, bc16 = 0xffffffffu, bi16 = 0xffffffffu;
     uint32_t bc32 = 0xffffffffu, bi32 = 0xffffffffu, bc64 = 0xffffffffu, bi64 = 0xffffffffu;
 
@@ -307,8 +312,8 @@ __global__ __launch_bounds__(ECTU_THREADS) __attribute__((amdgpu_waves_per_eu(4)
 #pragma unroll
                     for (int k = 0; k < 4; k++)
                     {
-                        const uint32_t t0 = (q & 1) ? s[4 + k] : s[k], t1 = (q & 1) ? s[12 + k] : s[8 + k];
-                        sel[k] = (q & 2) ? t1 : t0;
+                        const uint32_t t0 = ectu_pick(qm1, s[k], s[4 + k]), t1 = ectu_pick(qm1, s[8 + k], s[12 + k]);
+                        sel[k] = ectu_pick(qm2, t0, t1);
                     }
                     const int p = 64 + (lane >> 2);
                     const uint4 kx = *(const uint4*)(x265amd_smem + ECTU_L_KX + (p * ECTU_KXP + xg * 4) * 4);
@@ -342,9 +347,9 @@ __global__ __launch_bounds__(ECTU_THREADS) __attribute__((amdgpu_waves_per_eu(4)
                 /* 64x64: lane (Q, q) of a row keeps columns 2 (Q & 1), + 1 of patch row 2q + (Q >> 1); the four rows of
                  * sixteen lanes are added up by the two lane swaps */
                 {
-                    const uint32_t t0 = (Q & 1) ? w[2] : w[0], t1 = (Q & 1) ? w[6] : w[4];
-                    const uint32_t v0 = (Q & 1) ? w[3] : w[1], v1 = (Q & 1) ? w[7] : w[5];
-                    uint32_t u0 = (Q & 2) ? t1 : t0, u1 = (Q & 2) ? v1 : v0;
+                    const uint32_t t0 = ectu_pick(Qm1, w[0], w[2]), t1 = ectu_pick(Qm1, w[4], w[6]);
+                    const uint32_t v0 = ectu_pick(Qm1, w[1], w[3]), v1 = ectu_pick(Qm1, w[5], w[7]);
+                    uint32_t u0 = ectu_pick(Qm2, t0, t1), u1 = ectu_pick(Qm2, v0, v1);
                     auto r0 = __builtin_amdgcn_permlane16_swap(u0, u0, false, false);
                     u0 = r0[0] + r0[1];
                     auto r1 = __builtin_amdgcn_permlane16_swap(u1, u1, false, false);
