@@ -788,6 +788,17 @@ def main():
                 rows, _ = measure.esa_per_size(es, dev)
                 ms = sum(r["ms"] for r in rows)
                 px = sum(r["pixel_sads"] for r in rows)
+                progress("other paths: exhaustive search 4K, one scan per CTU")
+                ctu = measure.esa_ctu_picture(es, dev, compare=True)
+                ctu0 = measure.esa_ctu_picture(es, dev, spread=0)
+                # parity gate: PUs of every size through the oracle, and every record against the per-size launches'
+                cjobs, cres = ctu["jobs"], ctu["results"]
+                pick = np.concatenate([np.random.default_rng(4).choice(np.flatnonzero(cjobs["w"] == s_), 3, replace=False) for s_ in (64, 32, 16, 8)])
+                cur_, ref_, org_, st_ = ctu["planes"]
+                exp = orc.me_search_batch(orc.make_ctx(8, cur_, org_, st_, [ref_], org_, st_, False, 32, METHODS["full"], 5), cjobs[pick])
+                if not ctu["equal"] or not all(np.array_equal(exp[k_], cres[pick][k_]) for k_ in ("mv", "cost", "sad_calls", "subpel_calls")):
+                    print("PARITY FAILURE: exhaustive search per CTU: GPU results differ from the oracle or the per-size scans", file=sys.stderr)
+                    sys.exit(2)
                 progress("other paths: Rockchip path, lookahead frame costs")
                 rk = measure.rk_picture(es, dev)
                 la = {}
@@ -851,6 +862,17 @@ def main():
                                "bound": "valu", "peak": measure.SAD_ISSUE_PEAK / 1e9,
                                "frac": px / (ms * 1e-3) / measure.SAD_ISSUE_PEAK,
                                "per_pu_size_ms": {str(r["size"]): r["ms"] for r in rows}},
+                    "esa_4k_ctu": {"workload": "the same searches as esa_4k through x265amd_esa_ctu_batch_dev: one scan per 64x64 CTU measures its "
+                                               "64 8x8 blocks over the bounding box of the PUs' ranges and sums them up the quadtree for all 85 PUs "
+                                               "(the predictors of the stand-in field lie up to 6 samples apart; `smooth_field`: one predictor for all)",
+                                   "ms_per_picture_reference": ctu["ms"], "value": ctu["pixel_sads"] / ctu["ms"] / 1e6,
+                                   "unit": "Gpixel-SAD/s credited (every PU its own range; the scan measures a quarter of them)",
+                                   "smooth_field": {"ms_per_picture_reference": ctu0["ms"], "value": ctu0["pixel_sads"] / ctu0["ms"] / 1e6},
+                                   "bound": "valu", "peak": measure.SAD_ISSUE_PEAK / 1e9,
+                                   "frac": ctu0["pixel_sads"] / 4 / (ctu0["ms"] * 1e-3) / measure.SAD_ISSUE_PEAK,
+                                   "frac_note": "SADs the scan measures (the 8x8 level: a quarter of the credited count) against the byte-SAD "
+                                                "issue peak, smooth field, finishing stages and sub-pel refinement inside the time",
+                                   "parity": "every record equal to the per-size launches'; 12 PUs (3 per size, seeded) through the oracle"},
                     "esa_4k_main10": {"workload": "the same exhaustive search on 10-bit samples (v_sad_u16: two samples per lane "
                                                   "and instruction, half the byte-SAD peak)",
                                       "ms_per_picture_reference": ms10, "value": px10 / ms10 / 1e6, "unit": "Gpixel-SAD/s",

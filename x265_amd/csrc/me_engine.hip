@@ -186,7 +186,7 @@ __global__ __launch_bounds__(64) void star_resume_kernel(SearchArgs a)
         PlaneDev fenc, ref[4];
         job_planes(a, job, fenc, ref);
         S.bind(0, fenc, ref, 1, a.ctab, a.depth, job->pu_x, job->pu_y, job->w, job->h, a.max_dim, 0);
-        S.resume_star(job, a.state + 8 * (long)j, a.results + j);
+        S.resume_pattern(job, a.state + 8 * (long)j, a.method, a.results + j);
     }
 }
 
@@ -1061,7 +1061,9 @@ static int search_prepare(x265amd_ctx *c, const SearchArgs &a, bool square_only,
         b.staged2 = 32;
         b.done = (unsigned char*)B.d_done;
     }
-    sl.star = b.staged && a.method == X265AMD_STAR && !no_star && (b.staged <= 16 || !no_star_big);
+    static const bool no_pat = getenv("X265AMD_NO_PATTERN_FIXED") != 0;        /* HEX / DIA through the one-wave search, as before */
+    sl.star = b.staged && (a.method == X265AMD_STAR || ((a.method == X265AMD_HEX || a.method == X265AMD_DIA) && !no_pat)) &&
+              !no_star && (b.staged <= 16 || !no_star_big);
     if (sl.star)
     {
         if (ensure(c, &B.d_redo, &B.redo_cap, sizeof(int) * ((size_t)REDO_LIST + a.njobs))) return X265AMD_EHIP;
@@ -1082,21 +1084,29 @@ static int aux_stream(x265amd_ctx *c)
 
 /* STAR: start-up candidates and the first three pattern rounds of every PU in fixed-shape kernels. Most PUs end
  * there; the others are marked and listed. */
+template<typename P, int M>
+static void search_star_m(const SearchArgs &b, hipStream_t st)
+{
+    if (b.staged == 8)
+        hipLaunchKernelGGL((star_small_kernel<8, P, M>), dim3((b.njobs + 3) / 4), dim3(64), StarLds<8>::TOTAL, st, b);
+    else if (b.staged == 16)
+        hipLaunchKernelGGL((star_small_kernel<16, P, M>), dim3(b.njobs), dim3(64), StarLds<16>::TOTAL, st, b);
+    else
+    {
+        if (b.staged == 64)
+            hipLaunchKernelGGL((star_big_kernel<64, P, M>), dim3(b.njobs), dim3(StarBigGeo<64>::THREADS), StarBigLds<64>::TOTAL, st, b);
+        if (b.staged == 32 || b.staged2 == 32)
+            hipLaunchKernelGGL((star_big_kernel<32, P, M>), dim3(b.njobs), dim3(StarBigGeo<32>::THREADS), StarBigLds<32>::TOTAL, st, b);
+    }
+}
+
 template<typename P>
 static int search_star(x265amd_ctx *c, SearchLaunch &sl, hipStream_t st)
 {
     const SearchArgs &b = sl.b;
-    if (b.staged == 8)
-        hipLaunchKernelGGL((star_small_kernel<8, P>), dim3((b.njobs + 3) / 4), dim3(64), StarLds<8>::TOTAL, st, b);
-    else if (b.staged == 16)
-        hipLaunchKernelGGL((star_small_kernel<16, P>), dim3(b.njobs), dim3(64), StarLds<16>::TOTAL, st, b);
-    else
-    {
-        if (b.staged == 64)
-            hipLaunchKernelGGL((star_big_kernel<64, P>), dim3(b.njobs), dim3(StarBigGeo<64>::THREADS), StarBigLds<64>::TOTAL, st, b);
-        if (b.staged == 32 || b.staged2 == 32)
-            hipLaunchKernelGGL((star_big_kernel<32, P>), dim3(b.njobs), dim3(StarBigGeo<32>::THREADS), StarBigLds<32>::TOTAL, st, b);
-    }
+    if (b.method == X265AMD_HEX) search_star_m<P, X265AMD_HEX>(b, st);
+    else if (b.method == X265AMD_DIA) search_star_m<P, X265AMD_DIA>(b, st);
+    else search_star_m<P, X265AMD_STAR>(b, st);
     return X265AMD_OK;
 }
 

@@ -1176,6 +1176,87 @@ struct Searcher
         }
     }
 
+    /* X265_DIA_SEARCH, motion.cpp:628-649: rounds of four points (N, S, W, E; the packed (cost << 4) + dir compare is
+     * a strict '<' scan in that order) until none improves, the count runs out or the centre leaves the range.
+     * first = false: the first round has been measured and has moved the centre already. */
+    __device__ __forceinline__ void dia_rest(int mnx, int mny, int mxx, int mxy, int merange, bool first, int &bmx, int &bmy, int &bcost)
+    {
+        constexpr unsigned long long SQX = nibs({ 0, 0, 0, -1, 1, -1, -1, 1, 1 }), SQY = nibs({ 0, -1, 1, 0, 0, -1, 1, -1, 1 });
+        int i = merange;
+        if (!first && !(--i && in_range(bmx, bmy, mnx, mny, mxx, mxy))) return;
+        do
+        {
+            put_lanes(lane < 4, bmx + nib(SQX, lane + 1), bmy + nib(SQY, lane + 1),
+                      as_i16(bmx + nib(SQX, lane + 1)), as_i16(bmy + nib(SQY, lane + 1)), 2, 0);
+            eval(4, 0, true);
+            const int dir = fold_min(4, bcost);
+            if (dir < 0) break;
+            bmx = mvx_of(dir); bmy = mvy_of(dir);
+        }
+        while (--i && in_range(bmx, bmy, mnx, mny, mxx, mxy));
+    }
+
+    /* the half hexagons of X265_HEX_SEARCH after the first ring has moved the centre in direction `dir`
+     * (motion.cpp:687-707); points are measured without a range check, as in the reference */
+    __device__ __forceinline__ void hex_walk(int mnx, int mny, int mxx, int mxy, int merange, int dir, int &bmx, int &bmy, int &bcost)
+    {
+        constexpr unsigned long long H2X = nibs({ -1, -2, -1, 1, 2, 1, -1, -2 }), H2Y = nibs({ -2, 0, 2, 2, 0, -2, -2, 0 });
+        for (int i = (merange >> 1) - 1; i > 0 && in_range(bmx, bmy, mnx, mny, mxx, mxy); i--)
+        {
+            put_lanes(lane < 3, bmx + nib(H2X, dir + lane), bmy + nib(H2Y, dir + lane),
+                      as_i16(bmx + nib(H2X, dir + lane)), as_i16(bmy + nib(H2Y, dir + lane)), 2, 0);
+            eval(3, 0, true);
+            const int step = fold_min(3, bcost) + 1;
+            if (!step) break;
+            dir += step - 2;
+            dir = kMod6m1[dir + 1];
+            bmx = as_i16(bmx + kHex2[dir + 1][0]); bmy = as_i16(bmy + kHex2[dir + 1][1]);
+        }
+    }
+
+    /* the closing square of X265_HEX_SEARCH, motion.cpp:710-722 */
+    __device__ __forceinline__ void hex_square(int &bmx, int &bmy, int &bcost)
+    {
+        constexpr unsigned long long SQX = nibs({ 0, 0, 0, -1, 1, -1, -1, 1, 1 }), SQY = nibs({ 0, -1, 1, 0, 0, -1, 1, -1, 1 });
+        put_lanes(lane < 8, bmx + nib(SQX, lane + 1), bmy + nib(SQY, lane + 1),
+                  as_i16(bmx + nib(SQX, lane + 1)), as_i16(bmy + nib(SQY, lane + 1)), 2, 0);
+        eval(8, 0, true);
+        const int dir = fold_min(8, bcost) + 1;
+        bmx = as_i16(bmx + kSquare1[dir][0]); bmy = as_i16(bmy + kSquare1[dir][1]);
+    }
+
+    /* The rest of a DIA or HEX search whose start-up candidates and first round / ring a fixed-shape kernel has measured
+     * (me_small.h) and which moved the centre: `state` as resume_star reads it, with the centre after the move, its
+     * cost and -- HEX -- the direction of the move. Leaves the record as search_staged does. */
+    __device__ __forceinline__ void resume_pattern(const x265amd_job *job, const int *state, int method, x265amd_result *res)
+    {
+        if (method == X265AMD_STAR) { resume_star(job, state, res); return; }
+        JobRegs J;
+        J.load(job);
+        set_mvp(J.qmx, J.qmy);
+        const int s1 = uni(state[1]), s3 = uni(state[3]), s5 = uni(state[5]);
+        SearchState st;
+        int bmx = as_i16(s1), bmy = s1 >> 16, bcost = uni(state[2]);
+        st.bprecost = uni(state[4]); st.bpx = as_i16(s5); st.bpy = s5 >> 16;
+        nsad = (unsigned)uni(state[6]); nsub = (unsigned)uni(state[7]);
+        if (method == X265AMD_HEX)
+        {
+            hex_walk(J.mnx, J.mny, J.mxx, J.mxy, J.merange, s3 & 0xff, bmx, bmy, bcost);
+            hex_square(bmx, bmy, bcost);
+        }
+        else
+            dia_rest(J.mnx, J.mny, J.mxx, J.mxy, J.merange, false, bmx, bmy, bcost);
+        st.bmx = bmx; st.bmy = bmy; st.bcost = bcost;
+        int qx, qy, c;
+        choose(st, qx, qy, c);
+        if (lane == 0)
+        {
+            res->mv[0] = (int16_t)qx; res->mv[1] = (int16_t)qy;
+            res->cost = c;
+            res->sad_calls = nsad; res->subpel_calls = nsub;
+        }
+    }
+
     /* The rest of a STAR search whose start-up candidates and first three pattern rounds a fixed-shape kernel has
      * measured and folded (me_small.h): `state` holds what the reference has in hand at that point. Leaves the
      * choice of motion.cpp:1063-1069 and the counters in the result record, as search_staged does. */
@@ -1488,17 +1569,7 @@ struct Searcher
         {
             /* motion.cpp:628-649; the packed (cost << 4) + dir compare is a strict
              * '<' scan in the order N, S, W, E */
-            int i = merange;
-            do
-            {
-                put_lanes(lane < 4, bmx + nib(SQX, lane + 1), bmy + nib(SQY, lane + 1),
-                          as_i16(bmx + nib(SQX, lane + 1)), as_i16(bmy + nib(SQY, lane + 1)), 2, 0);
-                eval(4, 0, true);
-                const int dir = fold_min(4, bcost);
-                if (dir < 0) break;
-                bmx = mvx_of(dir); bmy = mvy_of(dir);
-            }
-            while (--i && in_range(bmx, bmy, mnx, mny, mxx, mxy));
+            dia_rest(mnx, mny, mxx, mxy, merange, true, bmx, bmy, bcost);
             break;
         }
         case X265AMD_HEX:
@@ -1552,26 +1623,11 @@ struct Searcher
             const int code = fold_min(6, bcost) + 2;
             if (code > 1)
             {
-                int dir = code - 2;
+                const int dir = code - 2;
                 bmx = as_i16(bmx + kHex2[dir + 1][0]); bmy = as_i16(bmy + kHex2[dir + 1][1]);
-                for (int i = (merange >> 1) - 1; i > 0 && in_range(bmx, bmy, mnx, mny, mxx, mxy); i--)
-                {
-                    put_lanes(lane < 3, bmx + nib(H2X, dir + lane), bmy + nib(H2Y, dir + lane),
-                              as_i16(bmx + nib(H2X, dir + lane)), as_i16(bmy + nib(H2Y, dir + lane)), 2, 0);
-                    eval(3, 0, true);
-                    const int step = fold_min(3, bcost) + 1;
-                    if (!step) break;
-                    dir += step - 2;
-                    dir = kMod6m1[dir + 1];
-                    bmx = as_i16(bmx + kHex2[dir + 1][0]); bmy = as_i16(bmy + kHex2[dir + 1][1]);
-                }
+                hex_walk(mnx, mny, mxx, mxy, merange, dir, bmx, bmy, bcost);
             }
-            /* square refine */
-            put_lanes(lane < 8, bmx + nib(SQX, lane + 1), bmy + nib(SQY, lane + 1),
-                      as_i16(bmx + nib(SQX, lane + 1)), as_i16(bmy + nib(SQY, lane + 1)), 2, 0);
-            eval(8, 0, true);
-            const int dir = fold_min(8, bcost) + 1;
-            bmx = as_i16(bmx + kSquare1[dir][0]); bmy = as_i16(bmy + kSquare1[dir][1]);
+            hex_square(bmx, bmy, bcost);
         }
 
         st.bmx = bmx; st.bmy = bmy; st.bcost = bcost;

@@ -941,6 +941,55 @@ __device__ __forceinline__ void star_point(int p, int &dx, int &dy)
     dx = nib(r == 0 ? X4 : X8, i) * unit; dy = nib(r == 0 ? Y4 : Y8, i) * unit;
 }
 
+/* The points a fixed-shape kernel measures around the start of method M in visit order, and how many: STAR the 20 of
+ * star_point; HEX the six of the first hexagon ring (motion.cpp:673-686) and then the eight of the closing square
+ * (:710-722), which is what the search measures when the ring does not move the centre; DIA the four of its first
+ * round (:628-649). */
+template<int M> struct PatPoints { static constexpr int N = M == X265AMD_STAR ? 20 : (M == X265AMD_HEX ? 14 : 4); };
+template<int M> __device__ __forceinline__ void pat_point(int p, int &dx, int &dy)
+{
+    if constexpr (M == X265AMD_STAR) star_point(p, dx, dy);
+    else
+    {
+        constexpr unsigned long long SQX = nibs({ 0, 0, 0, -1, 1, -1, -1, 1, 1 }), SQY = nibs({ 0, -1, 1, 0, 0, -1, 1, -1, 1 });
+        constexpr unsigned long long HRX = nibs({ -2, -1, 1, 2, 1, -1 }), HRY = nibs({ 0, 2, 2, 0, -2, -2 });
+        if (M == X265AMD_HEX && p < 6) { dx = nib(HRX, p); dy = nib(HRY, p); }
+        else
+        {
+            const int i = (M == X265AMD_HEX ? p - 6 : p) + 1;
+            dx = nib(SQX, i & 15); dy = nib(SQY, i & 15);
+        }
+    }
+}
+
+/* How a HEX or DIA search stands after the points above, given the first minimum (cost << 6 | point) of the ring /
+ * round (k0) and -- HEX -- of the square (k1): true when the search is over (centre and cost updated to the final
+ * full-pel choice, `counted` = points the reference has measured), false when the ring / round moved the centre: the
+ * centre is then the new one, `dir` the direction of the move, and the rest is Searcher::resume_pattern's. */
+template<int M> __device__ __forceinline__ bool pat_fold(int k0, int k1, int &bmx, int &bmy, int &bcost, int &dir, unsigned &counted)
+{
+    int dx, dy;
+    counted = M == X265AMD_HEX ? 6 : 4;
+    dir = 0;
+    if ((k0 >> 6) < bcost)
+    {
+        dir = k0 & 63;
+        pat_point<M>(dir, dx, dy);
+        bcost = k0 >> 6; bmx = as_i16(bmx + dx); bmy = as_i16(bmy + dy);
+        return false;
+    }
+    if constexpr (M == X265AMD_HEX)
+    {
+        counted += 8;
+        if ((k1 >> 6) < bcost)
+        {
+            pat_point<M>(k1 & 63, dx, dy);
+            bcost = k1 >> 6; bmx = as_i16(bmx + dx); bmy = as_i16(bmy + dy);
+        }
+    }
+    return true;
+}
+
 /* What StarPatternSearch has in hand after its first three rounds, given each round's first minimum
  * (cost << 6 | point, 0x7fffffff for a round without points): best MV and cost, bPointNr / bDistance of the winner
  * (COST_MV_PT_DIST, motion.cpp:182-194) and the count of rounds without improvement (:443-446). */
@@ -974,7 +1023,7 @@ struct StarFold
     }
 };
 
-template<int S, typename P>
+template<int S, typename P, int M = X265AMD_STAR>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(S == 16 ? OCC_S16 : OCC_S8))) void star_small_kernel(SearchArgs a)
 {
     const int depth = sizeof(P) == 1 ? 8 : a.depth;
@@ -1187,14 +1236,16 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(S == 16 ? OC
     wave_sync();
 #endif
 #pragma unroll 1
-    for (int pass = 0; pass < 5; pass++)
+    for (int pass = 0; pass < (PatPoints<M>::N + 3) / 4; pass++)
     {
         const int p = pass * 4 + (l >> G::LT);
         int dx, dy;
-        star_point(p, dx, dy);
+        pat_point<M>(p < PatPoints<M>::N ? p : 0, dx, dy);
         const int x = as_i16(bmx + dx), y = as_i16(bmy + dy);
-        /* the reference tests only the bounds a point can cross */
-        const bool ok = act && (dy >= 0 || y >= mny) && (dy <= 0 || y <= mxy) && (dx >= 0 || x >= mnx) && (dx <= 0 || x <= mxx);
+        /* STAR: the reference tests only the bounds a point can cross; the hexagon, square and diamond points are
+         * measured unchecked */
+        const bool ok = act && p < PatPoints<M>::N &&
+                        (M != X265AMD_STAR || ((dy >= 0 || y >= mny) && (dy <= 0 || y <= mxy) && (dx >= 0 || x >= mnx) && (dx <= 0 || x <= mxx)));
         int v = 0, cost = 0;
         if (ok)
         {
@@ -1210,13 +1261,49 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(S == 16 ? OC
             cost = ((int)ctab[as_i16(x << 2) - mvpx] + (int)ctab[as_i16(y << 2) - mvpy]) & 0xffff;
         }
         v = seg_sum(v, G::LT);      /* the tiles of a point are adjacent lanes */
-        const int km = grp_min<G::LG>(ok && tile == 0 ? ((v + cost) << 6) | p : 0x7fffffff);
-        if (pass == 0) rkey0 = km;
-        else if (pass < 3) rkey1 = km < rkey1 ? km : rkey1;
-        else rkey2 = km < rkey2 ? km : rkey2;
+        const int key = ok && tile == 0 ? ((v + cost) << 6) | p : 0x7fffffff;
+        if constexpr (M == X265AMD_HEX)
+        {
+            /* rkey0: the ring (points 0 .. 5), rkey1: the square */
+            const int kr = grp_min<G::LG>(p < 6 ? key : 0x7fffffff), ks = grp_min<G::LG>(p >= 6 ? key : 0x7fffffff);
+            rkey0 = kr < rkey0 ? kr : rkey0; rkey1 = ks < rkey1 ? ks : rkey1;
+        }
+        else
+        {
+            const int km = grp_min<G::LG>(key);
+            if (pass == 0) rkey0 = km;
+            else if (pass < 3) rkey1 = km < rkey1 ? km : rkey1;
+            else rkey2 = km < rkey2 ? km : rkey2;
+        }
         npts += (unsigned)grp_count<G::LG>(ok && tile == 0);
     }
     if (!act || l != 0) return;
+    if constexpr (M != X265AMD_STAR)
+    {
+        int dir;
+        unsigned counted;
+        const bool over = pat_fold<M>(rkey0, rkey1, bmx, bmy, bcost, dir, counted);
+        nsad += counted;
+        int *res = (int*)(a.results + j);
+        a.mark[j] = !over;
+        if (!over)
+        {
+            StarFold F;
+            F.start(bmx, bmy, bcost);
+            F.pt = dir;
+            F.store(a.state + 8 * (long)j, bprecost, bpx, bpy, nsad, nsub);
+            res[2] = (int)SMALL_RESUME;
+            return;
+        }
+        int qx, qy;
+        if (bprecost < bcost) { qx = bpx; qy = bpy; bcost = bprecost; }
+        else { qx = as_i16(bmx << 2); qy = as_i16(bmy << 2); }
+        res[0] = (qx & 0xffff) | (qy << 16);
+        res[1] = bcost;
+        res[2] = (int)nsad;
+        res[3] = (int)nsub;
+        return;
+    }
     /* the bookkeeping of StarPatternSearch over these rounds (motion.cpp:323-452): strict '<' in visit order, a
      * counter of rounds without improvement */
     StarFold F;
@@ -1299,7 +1386,26 @@ template<int S> struct StarBigLds
     static constexpr int TOTAL = PLANES + 2 * G::PLANE + 32;
 };
 
-template<int S, typename P>
+/* offsets of the pattern points as compile-time tables (the big kernel unrolls over them) */
+template<int M> struct PatTable
+{
+    int dx[20], dy[20];
+    constexpr PatTable() : dx(), dy()
+    {
+        const int sx[20] = { 0, -1, 1, 0, 0, -1, 1, -2, 2, -1, 1, 0, 0, -2, 2, -4, 4, -2, 2, 0 };
+        const int sy[20] = { -1, 0, 0, 1, -2, -1, -1, 0, 0, 1, 1, 2, -4, -2, -2, 0, 0, 2, 2, 4 };
+        const int hx[14] = { -2, -1, 1, 2, 1, -1, 0, 0, -1, 1, -1, -1, 1, 1 };
+        const int hy[14] = { 0, 2, 2, 0, -2, -2, -1, 1, 0, 0, -1, 1, -1, 1 };
+        for (int p = 0; p < 20; p++)
+        {
+            if (M == X265AMD_STAR) { dx[p] = sx[p]; dy[p] = sy[p]; }
+            else if (M == X265AMD_HEX) { dx[p] = p < 14 ? hx[p] : 0; dy[p] = p < 14 ? hy[p] : 0; }
+            else { dx[p] = p < 4 ? hx[6 + p] : 0; dy[p] = p < 4 ? hy[6 + p] : 0; }
+        }
+    }
+};
+
+template<int S, typename P, int M = X265AMD_STAR>
 __global__ __launch_bounds__(StarBigGeo<S>::THREADS) __attribute__((amdgpu_waves_per_eu(S == 64 ? OCC_SB64 : OCC_SB32))) void star_big_kernel(SearchArgs a)
 {
     const int depth = sizeof(P) == 1 ? 8 : a.depth;
@@ -1452,26 +1558,27 @@ __global__ __launch_bounds__(StarBigGeo<S>::THREADS) __attribute__((amdgpu_waves
      * point a multiple of four samples away needs no realignment */
     unsigned npts = 0;
     {
-        constexpr int DX[20] = { 0, -1, 1, 0, 0, -1, 1, -2, 2, -1, 1, 0, 0, -2, 2, -4, 4, -2, 2, 0 };
-        constexpr int DY[20] = { -1, 0, 0, 1, -2, -1, -1, 0, 0, 1, 1, 2, -4, -2, -2, 0, 0, 2, 2, 4 };
+        constexpr PatTable<M> T = PatTable<M>();
+        constexpr int NP = PatPoints<M>::N;
         const int room_l = bmx - mnx, room_r = mxx - bmx, room_u = bmy - mny, room_d = mxy - bmy;
         const int wbase = woff + tly * WP + tlx * BPS;
-        int pv[20];
+        int pv[NP];
 #pragma unroll
-        for (int p = 0; p < 20; p++)
+        for (int p = 0; p < NP; p++)
         {
             int v = 0;
 #pragma unroll
             for (int y2 = 0; y2 < NQ; y2++)
-                v = Px<P>::sad(fq[y2], lds_quad_const<P>(wbase, (4 + DY[p] + y2) * WP + (4 + DX[p]) * BPS), v);
+                v = Px<P>::sad(fq[y2], lds_quad_const<P>(wbase, (4 + T.dy[p] + y2) * WP + (4 + T.dx[p]) * BPS), v);
             pv[p] = v;
         }
 #pragma unroll
-        for (int p = 0; p < 20; p++)
+        for (int p = 0; p < NP; p++)
         {
-            /* the reference tests only the bounds a point can cross (motion.cpp:330-452) */
-            const bool okx = DX[p] == 0 || (DX[p] < 0 ? room_l >= -DX[p] : room_r >= DX[p]);
-            const bool oky = DY[p] == 0 || (DY[p] < 0 ? room_u >= -DY[p] : room_d >= DY[p]);
+            /* STAR: the reference tests only the bounds a point can cross (motion.cpp:330-452); the other patterns'
+             * points are measured unchecked */
+            const bool okx = M != X265AMD_STAR || T.dx[p] == 0 || (T.dx[p] < 0 ? room_l >= -T.dx[p] : room_r >= T.dx[p]);
+            const bool oky = M != X265AMD_STAR || T.dy[p] == 0 || (T.dy[p] < 0 ? room_u >= -T.dy[p] : room_d >= T.dy[p]);
             if (okx && oky)
             {
                 npts++;
@@ -1483,18 +1590,46 @@ __global__ __launch_bounds__(StarBigGeo<S>::THREADS) __attribute__((amdgpu_waves
     __syncthreads();
     if (tid >= 64) return;
     int key = 0x7fffffff;
-    if (lane < 20)
+    if (lane < PatPoints<M>::N)
     {
         int dx, dy;
-        star_point(lane, dx, dy);
+        pat_point<M>(lane, dx, dy);
         const int x = as_i16(bmx + dx), y = as_i16(bmy + dy);
-        if ((dy >= 0 || y >= mny) && (dy <= 0 || y <= mxy) && (dx >= 0 || x >= mnx) && (dx <= 0 || x <= mxx))
+        if (M != X265AMD_STAR || ((dy >= 0 || y >= mny) && (dy <= 0 || y <= mxy) && (dx >= 0 || x >= mnx) && (dx <= 0 || x <= mxx)))
         {
             int v = 0;
 #pragma unroll
             for (int w = 0; w < WAVES; w++) v += cells[w * 32 + 8 + lane];
             key = ((v + (((int)ctab[as_i16(x << 2) - mvpx] + (int)ctab[as_i16(y << 2) - mvpy]) & 0xffff)) << 6) | lane;
         }
+    }
+    if constexpr (M != X265AMD_STAR)
+    {
+        const int k0 = wave_min(lane < (M == X265AMD_HEX ? 6 : 4) ? key : 0x7fffffff), k1 = wave_min(lane >= 6 ? key : 0x7fffffff);
+        if (tid != 0) return;
+        int dir;
+        unsigned counted;
+        const bool over = pat_fold<M>(k0, k1, bmx, bmy, bcost, dir, counted);
+        nsad += counted;
+        int *res = (int*)(a.results + j);
+        a.mark[j] = !over;
+        if (!over)
+        {
+            StarFold F;
+            F.start(bmx, bmy, bcost);
+            F.pt = dir;
+            F.store(a.state + 8 * (long)j, bprecost, bpx, bpy, nsad, nsub);
+            res[2] = (int)SMALL_RESUME;
+            return;
+        }
+        int qx, qy;
+        if (bprecost < bcost) { qx = bpx; qy = bpy; bcost = bprecost; }
+        else { qx = as_i16(bmx << 2); qy = as_i16(bmy << 2); }
+        res[0] = (qx & 0xffff) | (qy << 16);
+        res[1] = bcost;
+        res[2] = (int)nsad;
+        res[3] = (int)nsub;
+        return;
     }
     const int rkey0 = wave_min(lane < 4 ? key : 0x7fffffff), rkey1 = wave_min(lane >= 4 && lane < 12 ? key : 0x7fffffff),
               rkey2 = wave_min(lane >= 12 ? key : 0x7fffffff);
