@@ -811,14 +811,15 @@ def main():
                         "searched_cus_per_s": m["fields"] * m["cus"] / (m["ms_search"] * 1e-3)}
                 progress("other paths: the headline's searches on a noise clip and on a static clip")
                 kinds = {}
-                for kind in ("noise", "static"):
-                    cls, (f0, f1, kj, kr) = measure.pattern_search_clip(es, dev, kind, pairs=8)
+                for kind in ("noise", "static", "hex"):
+                    mname_ = "hex" if kind == "hex" else "star"
+                    cls, (f0, f1, kj, kr) = measure.pattern_search_clip(es, dev, "texture" if kind == "hex" else kind, pairs=8, method=mname_)
                     # parity gate: a seeded sample of pair 0's PUs of every size through the oracle
                     pick = np.concatenate([np.random.default_rng(3).choice(np.flatnonzero(kj["w"] == s_), n_, replace=False)
                                            for s_, n_ in ((64, 24), (32, 48), (16, 96), (8, 192))])
                     cur_, org_, st_ = pad_plane(f1, 128)
                     ref_, _, _ = pad_plane(f0, 128)
-                    exp = orc.me_search_batch(orc.make_ctx(8, cur_, org_, st_, [ref_], org_, st_, False, 32, METHODS["star"], 5), kj[pick])
+                    exp = orc.me_search_batch(orc.make_ctx(8, cur_, org_, st_, [ref_], org_, st_, False, 32, METHODS[mname_], 5), kj[pick])
                     if not all(np.array_equal(exp[k_], kr[pick][k_]) for k_ in ("mv", "cost", "sad_calls", "subpel_calls")):
                         print("PARITY FAILURE: %s clip: GPU results differ from the oracle" % kind, file=sys.stderr)
                         sys.exit(2)
@@ -849,6 +850,9 @@ def main():
                                           "and re-centred patterns; 8 frame pairs, the three launch classes one after the other on one stream"),
                     "me1080p_static": dict(kinds["static"], workload="the same on a clip whose frames are all alike: the best case, every search "
                                            "ends at its start"),
+                    "me1080p_hex": dict(kinds["hex"], workload="the headline's PUs and textured clip searched with --me hex (the reference's default "
+                                        "method, BASELINE configs[0]): first hexagon ring + closing square in the fixed-shape kernels, PUs whose ring "
+                                        "moves (marked_frac) walk on one per wave; 8 frame pairs, classes one after the other on one stream"),
                     "main10_4k": {"workload": "3840x2160 10-bit, --me star --merange 57 --subme 5, all 64/32/16/8 square PUs of one "
                                               "picture against one reference (BASELINE configs[3], per reference)",
                                   "ms_per_picture_reference": m10["ms"], "pu_searches": m10["pus"],

@@ -179,6 +179,12 @@ int x265amd_search_batch_pairs_dev(x265amd_ctx *ctx, const void *d_pairs, int np
 int x265amd_search_batch_pairs_family_dev(x265amd_ctx *ctx, const void *d_pairs, int npairs, int qp, int subme,
                                           const x265amd_job *d_parents, int nparents, x265amd_result *d_parent_results,
                                           const x265amd_job *d_children, int nchildren, x265amd_result *d_child_results);
+/* The same launch for X265_HEX_SEARCH and X265_DIA_SEARCH as well (`method`; encoder/motion.cpp:628-723): their first
+ * hexagon ring + closing square, or first diamond round, are measured by the fixed-shape kernels like the first three
+ * rounds of the star pattern, and the PUs whose ring / round moves the centre finish their walk one per wave. */
+int x265amd_search_batch_pairs_family_method_dev(x265amd_ctx *ctx, const void *d_pairs, int npairs, int qp, int method, int subme,
+                                                 const x265amd_job *d_parents, int nparents, x265amd_result *d_parent_results,
+                                                 const x265amd_job *d_children, int nchildren, x265amd_result *d_child_results);
 
 /* The checks x265amd_search_batch makes on host job arrays (partition of motion.cpp:119, numc, range, PU inside the
  * source plane, search window + 8-tap apron inside the padded reference: what xSetSearchRange, TEncSearch.cpp:4188-4215,

@@ -169,15 +169,18 @@ def test_8k_lookahead_field(engine8, oracle):
     assert int(stats["sad_calls"].sum()) == st.sad_calls and int(stats["subpel_calls"].sum()) == st.subpel_calls
 
 
-def test_1080p_headline_launch_lists(engine8, oracle):
+@pytest.mark.parametrize("mname", ["star", "hex", "dia"])
+def test_1080p_headline_launch_lists(engine8, oracle, mname):
     """The launches of the benchmark's step as bench.py builds them (workload.class_job_list): per PU class one job list
     over several frame pairs -- the 64x64 PUs each followed by their four 32x32 children (x265amd_search_batch_pairs_dev with the
     statement that the list holds only squares), the 16x16 PUs and the list of their 8x8 children
     (x265amd_search_batch_pairs_family_dev). Two frame pairs: one of steady
     motion, where nearly every search ends with its first three pattern rounds, and one across the clip's wrap-around
     (a jump of 29 samples the lookahead cannot follow), where many PUs are handed on to the resumed search. A sample
-    of more than 200 PUs, marked ones among them, against the oracle."""
+    of more than 200 PUs, marked ones among them, against the oracle. The same lists with the hexagon and the diamond
+    search, whose first ring + square / first round the same kernels measure (x265amd_search_batch_pairs_family_method_dev)."""
     from x265_amd.engine import RESULT_DTYPE, SQUARE_ONLY
+    method = METHODS[mname]
     W, H, M, MR, QP = 1920, 1080, 128, 57, 32
     clip = make_clip(W, H, 12, seed=1234)
     frames = [(1, 0), (11, 10)]
@@ -208,10 +211,10 @@ def test_1080p_headline_launch_lists(engine8, oracle):
         d_jobs, d_res = engine8.device_alloc(cj.nbytes), engine8.device_alloc(len(cj) * RESULT_DTYPE.itemsize)
         engine8.upload(d_jobs, cj)
         if dim == 64:
-            engine8.search_batch_pairs_dev(d_pairs, 2, d_jobs, len(cj), d_res, QP, METHODS["star"], 5, max_pu_dim=dim | SQUARE_ONLY)
+            engine8.search_batch_pairs_dev(d_pairs, 2, d_jobs, len(cj), d_res, QP, method, 5, max_pu_dim=dim | SQUARE_ONLY)
         else:
             engine8.search_batch_pairs_family_dev(d_pairs, 2, d_jobs, npar, d_res, d_jobs + 40 * npar, len(cj) - npar,
-                                                  d_res + 16 * npar, QP, 5)
+                                                  d_res + 16 * npar, QP, 5, method)
         marked[dim] = engine8.marked_count()
         got = engine8.download(d_res, (len(cj),), RESULT_DTYPE)
         for i in range(2):
@@ -220,7 +223,7 @@ def test_1080p_headline_launch_lists(engine8, oracle):
         if dim == 16:
             # the same two lists as launches of their own: identical records
             for off, n_, d_ in ((0, npar, 16), (npar, len(cj) - npar, 8)):
-                engine8.search_batch_pairs_dev(d_pairs, 2, d_jobs + 40 * off, n_, d_res + 16 * off, QP, METHODS["star"], 5,
+                engine8.search_batch_pairs_dev(d_pairs, 2, d_jobs + 40 * off, n_, d_res + 16 * off, QP, method, 5,
                                                max_pu_dim=d_ | SQUARE_ONLY)
             again = engine8.download(d_res, (len(cj),), RESULT_DTYPE)
             assert np.array_equal(again, got)
@@ -230,7 +233,7 @@ def test_1080p_headline_launch_lists(engine8, oracle):
     total = 0
     for i, (a, b) in enumerate(frames):
         jobs = host_jobs[i]
-        long_ = np.flatnonzero(res[i]["sad_calls"] > 22)        # went on past the first three rounds
+        long_ = np.flatnonzero(res[i]["sad_calls"] > {"star": 22, "hex": 16, "dia": 6}[mname])      # went on past what the fixed-shape kernels measure
         rng = np.random.default_rng(5 + i)
         pick = [rng.choice(np.flatnonzero(jobs["w"] == s), 20, replace=False) for s in (64, 32, 16, 8)]
         for s in (64, 32, 16, 8):
@@ -240,7 +243,7 @@ def test_1080p_headline_launch_lists(engine8, oracle):
         idx = np.unique(np.concatenate(pick))
         total += len(idx)
         org = M * (W + 2 * M) + M
-        mv, cost, sc, qc = oracle_search(oracle, 8, up[a][1], [up[b][1]], org, W + 2 * M, jobs[idx], QP, METHODS["star"], 5)
+        mv, cost, sc, qc = oracle_search(oracle, 8, up[a][1], [up[b][1]], org, W + 2 * M, jobs[idx], QP, method, 5)
         assert np.array_equal(res[i]["mv"][idx], mv) and np.array_equal(res[i]["cost"][idx], cost), i
         assert np.array_equal(res[i]["sad_calls"][idx], sc) and np.array_equal(res[i]["subpel_calls"][idx], qc), i
     assert total >= 200

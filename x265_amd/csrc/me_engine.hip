@@ -1192,7 +1192,7 @@ static int launch_family(x265amd_ctx *c, const SearchArgs &parents, const Search
     int rc = search_prepare<P>(c, parents, true, 0, pa);
     if (!rc) rc = search_prepare<P>(c, children, true, 1, ch);
     if (rc) return rc;
-    if (!pa.star || !ch.star || pa.b.staged != 16 || ch.b.staged != 8) return fail(c, X265AMD_EINVAL, "family launch: STAR search of 16x16 and 8x8 PUs, samples of at most 10 bits");
+    if (!pa.star || !ch.star || pa.b.staged != 16 || ch.b.staged != 8) return fail(c, X265AMD_EINVAL, "family launch: STAR, HEX or DIA search of 16x16 and 8x8 PUs, samples of at most 10 bits");
     static const bool no_quad = getenv("X265AMD_NO_QUAD") != 0;                                  /* measurements only */
     if (!no_quad)
     {
@@ -1752,7 +1752,17 @@ int x265amd_search_batch_pairs_family_dev(x265amd_ctx *c, const void *d_pairs, i
                                           const x265amd_job *d_parents, int nparents, x265amd_result *d_parent_results,
                                           const x265amd_job *d_children, int nchildren, x265amd_result *d_child_results)
 {
+    return x265amd_search_batch_pairs_family_method_dev(c, d_pairs, npairs, qp, X265AMD_STAR, subme, d_parents, nparents, d_parent_results,
+                                                        d_children, nchildren, d_child_results);
+}
+
+int x265amd_search_batch_pairs_family_method_dev(x265amd_ctx *c, const void *d_pairs, int npairs, int qp, int method, int subme,
+                                                 const x265amd_job *d_parents, int nparents, x265amd_result *d_parent_results,
+                                                 const x265amd_job *d_children, int nchildren, x265amd_result *d_child_results)
+{
     if (!c || !d_pairs || npairs <= 0 || npairs > 256) return fail(c, X265AMD_EINVAL, "1 .. 256 pairs");
+    if (method != X265AMD_STAR && method != X265AMD_HEX && method != X265AMD_DIA)
+        return fail(c, X265AMD_EINVAL, "family launch: X265_STAR_SEARCH, X265_HEX_SEARCH or X265_DIA_SEARCH");
     if (!d_parents || !d_parent_results || !d_children || !d_child_results || nparents <= 0 || nchildren <= 0)
         return fail(c, X265AMD_EINVAL, "null argument");
     if (subme < 0 || subme > 7) return fail(c, X265AMD_EINVAL, "bad subme");
@@ -1763,7 +1773,7 @@ int x265amd_search_batch_pairs_family_dev(x265amd_ctx *c, const void *d_pairs, i
     SearchArgs pa, ch;
     x265amd_plane none;
     memset(&none, 0, sizeof(none));
-    fill_args(c, pa, &none, &none, 0, qp, X265AMD_STAR, subme);
+    fill_args(c, pa, &none, &none, 0, qp, method, subme);
     pa.pairs = (const PairDev*)d_pairs; pa.npairs = npairs;
     ch = pa;
     pa.jobs = d_parents; pa.results = d_parent_results; pa.njobs = nparents; pa.max_dim = 16;

@@ -337,11 +337,17 @@ class Engine:
                                                         C.c_void_p(d_jobs), njobs, C.c_void_p(d_results), max_pu_dim))
 
     def search_batch_pairs_family_dev(self, d_pairs, npairs, d_parents, nparents, d_parent_results, d_children, nchildren,
-                                      d_child_results, qp, subme):
-        """STAR search of a list of 16x16 PUs and the list of their 8x8 children (4 k + q = quadrant q of parent k) as one launch."""
-        self._chk(self.L.x265amd_search_batch_pairs_family_dev(self.ctx, d_pairs, npairs, qp, subme,
-                                                               C.c_void_p(d_parents), nparents, C.c_void_p(d_parent_results),
-                                                               C.c_void_p(d_children), nchildren, C.c_void_p(d_child_results)))
+                                      d_child_results, qp, subme, method=STAR):
+        """STAR (or HEX / DIA) search of a list of 16x16 PUs and the list of their 8x8 children (4 k + q = quadrant q of
+        parent k) as one launch."""
+        if method == STAR:
+            self._chk(self.L.x265amd_search_batch_pairs_family_dev(self.ctx, d_pairs, npairs, qp, subme,
+                                                                   C.c_void_p(d_parents), nparents, C.c_void_p(d_parent_results),
+                                                                   C.c_void_p(d_children), nchildren, C.c_void_p(d_child_results)))
+        else:
+            self._chk(self.L.x265amd_search_batch_pairs_family_method_dev(self.ctx, d_pairs, npairs, qp, method, subme,
+                                                                          C.c_void_p(d_parents), nparents, C.c_void_p(d_parent_results),
+                                                                          C.c_void_p(d_children), nchildren, C.c_void_p(d_child_results)))
 
     def fields_upload(self, fields, wcu, hcu, method=HEX, merange=16):
         """Checks the planes against the CU grid / method / merange and puts the descriptors on the device."""

@@ -377,7 +377,7 @@ def pattern_search_clip(e, dev, kind, pairs=8, width=1920, height=1080, method="
         else:
             launch = lambda: e.search_batch_pairs_family_dev(d_pairs, pairs, d_jobs.data_ptr(), nparents, d_res.data_ptr(),
                                                              d_jobs.data_ptr() + 40 * nparents, n - nparents,
-                                                             d_res.data_ptr() + 16 * nparents, qp, subme)
+                                                             d_res.data_ptr() + 16 * nparents, qp, subme, METHODS[method])
         ms = _timed(torch, e, dev, launch, reps)
         marked = e.marked_count()
         res = d_res.cpu().numpy().view(RESULT_DTYPE).reshape(-1)
