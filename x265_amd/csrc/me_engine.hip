@@ -73,6 +73,8 @@ struct SearchArgs
     unsigned char *cmark, *cdone;
     unsigned char *mark;   /* null, or per job: 1 = a STAR kernel handed this PU on (it is in the redo list), 0 = it did not */
     int list;              /* refinement kernels: 1 = refine the PUs of the redo list instead of those of the job list */
+    int stage_all;         /* 1: the one-wave search stops every PU before the sub-pel refinement; the PUs that are not squares of
+                              the fixed-shape sizes are refined by refine_any_kernel */
 };
 
 /* the planes job `job` searches: the launch's own, or its entry of the launch's pair table. Device-resident jobs
@@ -158,7 +160,7 @@ __global__ __launch_bounds__(64) void search_kernel(SearchArgs a)
         job_planes(a, job, fenc, ref);
         S.bind(0, fenc, ref, a.nref, a.ctab, a.depth, job->pu_x, job->pu_y, w, h, a.max_dim,
                a.plane_lds ? a.plane_lds : plane_budget(a.max_dim, (int)sizeof(P)));
-        if (a.staged && w == h && (w == a.staged || w == a.staged2)) S.search_staged(job, a.method, a.results + j);
+        if (a.staged && ((a.stage_all && any_refines(w, h)) || (w == h && (w == a.staged || w == a.staged2)))) S.search_staged(job, a.method, a.results + j);
         else S.search(job, a.method, a.subme, a.results + j);
     }
 }
@@ -1023,6 +1025,20 @@ static void launch_refine(const SearchArgs &b, hipStream_t st, int list_grid)
     }
 }
 
+/* the sub-pel refinement of the PUs no fixed-shape kernel takes (other partitions, squares of other sizes): every PU of
+ * the job list, or of the redo list walked by list_grid waves */
+template<typename P>
+static void launch_any(const SearchArgs &b, hipStream_t st, int list_grid)
+{
+    const int grid = list_grid ? list_grid : b.njobs;
+    if (b.max_dim <= 16)
+        hipLaunchKernelGGL((refine_any_kernel<P, 1>), dim3(grid), dim3(64), AnyLds<1>::TOTAL, st, b);
+    else if (b.max_dim == 32)
+        hipLaunchKernelGGL((refine_any_kernel<P, 4>), dim3(grid), dim3(64), AnyLds<4>::TOTAL, st, b);
+    else
+        hipLaunchKernelGGL((refine_any_kernel<P, 12>), dim3(grid), dim3(64), AnyLds<12>::TOTAL, st, b);
+}
+
 /* waves of a launch of search_kernel: a wave per PU up to this many, then every wave walks the list */
 #define SEARCH_GRID 8192
 
@@ -1062,6 +1078,8 @@ static int search_prepare(x265amd_ctx *c, const SearchArgs &a, bool square_only,
         b.done = (unsigned char*)B.d_done;
     }
     static const bool no_pat = getenv("X265AMD_NO_PATTERN_FIXED") != 0;        /* HEX / DIA through the one-wave search, as before */
+    static const bool no_any = getenv("X265AMD_NO_REFINE_ANY") != 0;           /* other partitions refined by the one-wave search, as before */
+    b.stage_all = b.staged && !sl.square_only && !no_any;
     sl.star = b.staged && (a.method == X265AMD_STAR || ((a.method == X265AMD_HEX || a.method == X265AMD_DIA) && !no_pat)) &&
               !no_star && (b.staged <= 16 || !no_star_big);
     if (sl.star)
@@ -1127,6 +1145,7 @@ static void search_side(x265amd_ctx *c, SearchLaunch &sl, hipStream_t side)
     SearchArgs l = b;
     l.list = 1;
     launch_refine<P>(l, side, lgrid);
+    if (b.stage_all) launch_any<P>(l, side, lgrid);
 }
 
 template<typename P>
@@ -1176,6 +1195,7 @@ static int launch_search(x265amd_ctx *c, const SearchArgs &a, int is_lowres, boo
         if (sl.b.done) HIPCHK(c, hipMemsetAsync(sl.b.done, 0, (size_t)a.njobs, c->stream));
         hipLaunchKernelGGL((search_kernel<P, false>), dim3(a.njobs < SEARCH_GRID ? a.njobs : SEARCH_GRID), dim3(64), lds + pad, c->stream, sl.b);
         launch_refine<P>(sl.b, c->stream, 0);
+        if (sl.b.stage_all) launch_any<P>(sl.b, c->stream, 0);
     }
     HIPCHK(c, hipGetLastError());
     return X265AMD_OK;
@@ -1660,7 +1680,7 @@ static void fill_args(x265amd_ctx *c, SearchArgs &a, const x265amd_plane *fenc, 
         a.ref[i].origin = r->origin; a.ref[i].stride = r->stride;
     }
     a.lowres = is_lowres; a.depth = c->depth; a.method = method; a.subme = subme; a.max_dim = is_lowres ? 8 : 64;
-    a.staged = 0; a.staged2 = 0; a.done = 0; a.redo = 0; a.pairs = 0; a.npairs = 0; a.plane_lds = 0; a.state = 0; a.mark = 0; a.list = 0; a.cjobs = 0; a.cresults = 0; a.ncjobs = 0; a.cmark = 0; a.cdone = 0;
+    a.staged = 0; a.staged2 = 0; a.done = 0; a.redo = 0; a.pairs = 0; a.npairs = 0; a.plane_lds = 0; a.state = 0; a.mark = 0; a.list = 0; a.stage_all = 0; a.cjobs = 0; a.cresults = 0; a.ncjobs = 0; a.cmark = 0; a.cdone = 0;
     a.ctab = c->tables[qp] + 32768;
 }
 

@@ -143,6 +143,11 @@ __device__ __forceinline__ int inv_tiles(int wt)
          : wt == 12 ? 5462 : wt == 16 ? 4096 : (65536 + wt - 1) / wt;
 }
 
+/* the partitions refine_any_kernel (me_small.h) is given: from 128 samples up. A wave per PU does not pay below that
+ * (8x4, 4x8, 16x4, 4x16: a quarter of the lanes or fewer would have a (tile, column) pair); the one-wave search refines
+ * those itself. */
+__device__ __forceinline__ bool any_refines(int w, int h) { return w * h >= 128; }
+
 /* sum over each group of 2^l adjacent lanes, left in every lane of the group */
 __device__ __forceinline__ int seg_sum(int v, int l)
 {

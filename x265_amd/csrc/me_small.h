@@ -194,11 +194,19 @@ __device__ __forceinline__ void hps_quad(const uint8_t AS1 *s, const int *tp, in
  * abs-sum of its four coefficients and the caller halves the total (every tile's abs-sum is even, pixel.cpp:226). */
 /* N (4 or 5) consecutive output rows of the vertical pass for the lane's column: sums whose high halves are
  * (int16_t)(sum >> (20 - depth)), luma_vsp's result before the clip (ipfilter.cpp:372-389) */
+template<int N>
+__device__ __forceinline__ void column_rows(int poff, int prow, int r0, int yf, const ColSrc &ct, int depth, int o[N]);
 template<int S, int N>
 __device__ __forceinline__ void small_column_rows(int poff, int r0, int yf, const ColSrc &ct, int depth, int o[N])
 {
+    column_rows<N>(poff, SmallGeo<S>::PROW, r0, yf, ct, depth, o);
+}
+/* prow: int16 rows per plane column (even) */
+template<int N>
+__device__ __forceinline__ void column_rows(int poff, int prow, int r0, int yf, const ColSrc &ct, int depth, int o[N])
+{
     const int R = r0 + 4 * ct.ty;
-    const uint32_t *col = (const uint32_t*)(x265amd_smem + poff + (__mul24(ct.col, SmallGeo<S>::PROW) + (R & ~1)) * 2);
+    const uint32_t *col = (const uint32_t*)(x265amd_smem + poff + (__mul24(ct.col, prow) + (R & ~1)) * 2);
     const uint32_t *tp = (const uint32_t*)(x265amd_smem + SM_VTAPS) + ((yf << 1) | (r0 & 1)) * 10;
     uint32_t E[N + 2], P[5], Q[5];
 #pragma unroll
@@ -903,6 +911,186 @@ __global__ __launch_bounds__(BigGeo<S>::THREADS) __attribute__((amdgpu_waves_per
         __syncthreads();        /* the workgroup's LDS belongs to the PU before until here */
         const int j = a.list ? uni(a.redo[REDO_LIST + k]) : xcd_remap(k, a.njobs);
         if (j < a.njobs) refine_big_pu<S, P>(a, j);
+    }
+}
+
+/* ---------------------------------------------------------------- sub-pel refinement of every other partition
+ *
+ * The rounds of motion.cpp:1071-1141 for a PU of any luma partition (primitives.h:65-73: 2NxN, Nx2N, the asymmetric
+ * pairs, and squares that are not the size the launch's fixed-shape kernels take), one wave per PU with the PU's width
+ * and height as values: the same planes of luma_hps intermediates (one buffer, a column of candidates at a time, as in
+ * refine_big_kernel) and the same vertical pass per (tile, column) pair -- a lane takes every 64th pair of the PU, up to
+ * MAXI of them (the launch's largest PU decides MAXI: 1 up to 16 samples, 4 up to 32, 12 up to 64). The one-wave search
+ * measures these candidates through its general machinery at about three times the instructions per sample. Measured on
+ * 1080p lists of one shape, 16 pictures per launch, STAR: 64x48 0.56 -> 0.38 ms, 64x32 0.83 -> 0.63, 32x24 0.68 -> 0.52,
+ * 16x12 1.31 -> 1.09, 16x8 2.06 -> 1.91; the integer stage of these PUs stays a wave per PU and is what is left. */
+__device__ __forceinline__ int wave_total(int v);
+template<int MAXI> struct AnyLds
+{
+    static constexpr int DIM = MAXI == 1 ? 16 : (MAXI == 4 ? 32 : 64);
+    static constexpr int PLANES = SM_FIXED;
+    static constexpr int TOTAL = PLANES + DIM * (DIM + 10) * 2 + 32;
+};
+
+template<typename P, int MAXI>
+__device__ __forceinline__ void refine_any_pu(const SearchArgs &a, int j)
+{
+    const int depth = sizeof(P) == 1 ? 8 : a.depth;
+    typedef AnyLds<MAXI> L;
+    const int lane = (int)threadIdx.x;
+    const int *job = (const int*)(a.jobs + j);
+    const int d0 = uni(job[0]), d1 = uni(job[1]), d4 = uni(job[4]);
+    const int pux = as_i16(d0), puy = d0 >> 16, w = d1 & 0xff, h = (d1 >> 8) & 0xff;
+    /* the squares of the launch's fixed-shape sizes have kernels of their own; a PU larger than the launch reserved
+     * LDS for was refused by the search */
+    if (w == h && (w == a.staged || w == a.staged2)) return;
+    if (w > L::DIM || h > L::DIM || !any_refines(w, h) || ((w | h) & 3)) return;
+    if (!a.list && a.mark && a.mark[j]) return;         /* handed on by the STAR kernels: the list-driven launch's */
+    int *res = (int*)(a.results + j);
+    const int r0 = uni(res[0]);
+    int qx = as_i16(r0), qy = r0 >> 16, bcost = uni(res[1]);
+    unsigned nsub = (unsigned)uni(res[3]);
+    /* a PU whose full-pel cost is 0 is not refined (motion.cpp:1073-1076), a negative cost marks a job that was refused */
+    if (bcost <= 0) return;
+    const int mvpx = as_i16(d4), mvpy = d4 >> 16;
+    const P AS1 *fenc0, *ref0;
+    int fstride, rstride;
+    small_planes<P>(a, d1, fenc0, fstride, ref0, rstride);
+    const int roff = puy * rstride + pux;
+    const uint16_t AS1 *ctab = (const uint16_t AS1*)a.ctab;
+    const int tw = w >> 2, inv = (65536 + tw - 1) / tw;     /* tiles in a row; item / tw = item * inv >> 16 (items < 4096) */
+    const int npairs = (w * h) >> 2, prow = h + 10, rows = h + 8, nitems = rows * tw;
+    ColSrc ct[MAXI];
+#pragma unroll
+    for (int u = 0; u < MAXI; u++)
+    {
+        int l = lane + 64 * u;
+        if (l >= npairs) l = npairs - 4 + (lane & 3);       /* the pair of the last tile with the lane's column: never summed */
+        const int t = l >> 2, ty = (t * inv) >> 16, tx = t - ty * tw;
+        ct[u].ty = ty; ct[u].col = tx * 4 + (l & 3);
+        const P AS1 *src = fenc0 + (long)(puy + ty * 4) * fstride + pux + ct[u].col;
+        uint32_t f[4];
+#pragma unroll
+        for (int y = 0; y < 4; y++) f[y] = (uint32_t)src[(long)y * fstride];
+        ct[u].f01 = f[0] | (f[1] << 16); ct[u].f23 = f[2] | (f[3] << 16);
+    }
+
+    auto round = [&](int step, int dirs, bool satd, bool centre)
+    {
+        constexpr unsigned long long SQX = nibs({ 0, 0, 0, -1, 1, -1, -1, 1, 1 }), SQY = nibs({ 0, -1, 1, 0, 0, -1, 1, -1, 1 });
+        const int k0 = centre ? 1 : 0, K = k0 + dirs;
+        int mvc = 0;
+        {
+            const int i = lane < K ? lane + 1 - k0 : 0;
+            const int tx = as_i16(qx + nib(SQX, i) * step), ty = as_i16(qy + nib(SQY, i) * step);
+            if (lane < K) mvc = ((int)ctab[tx - mvpx] + (int)ctab[ty - mvpy]) & 0xffff;
+        }
+        const int ya = as_i16(qy - step) >> 2, yb = qy >> 2, yc = as_i16(qy + step) >> 2;
+        int ymin = ya < yb ? ya : yb;
+        ymin = yc < ymin ? yc : ymin;
+        int mycost = 0;
+#pragma unroll 1
+        for (int p = 0; p < 3; p++)
+        {
+            if (p != 1 && dirs < 4) continue;           /* the closing re-measure has the centre only */
+            wave_sync();                                /* the plane before has been read */
+            {
+                const int xp = as_i16(qx + (p - 1) * step);
+                const P AS1 *src = ref0 + (roff + __mul24(ymin - 3, rstride) + (xp >> 2) - 3);
+                const int *tp = (const int*)(x265amd_smem + SM_TAPS) + (xp & 3) * 12;
+                int16_t *plane = (int16_t*)(x265amd_smem + L::PLANES);
+                for (int item = lane; item < nitems; item += 64)
+                {
+                    const int r = (item * inv) >> 16, q = item - r * tw;
+                    hps_quad(src + (__mul24(r, rstride) + 4 * q), tp, plane + (4 * q) * prow + r, prow, depth);
+                }
+            }
+            wave_sync();
+            for (int c = 0; c < K; c++)
+            {
+                const int i = c + 1 - k0;
+                if (nib(SQX, i) != p - 1) continue;
+                const int ty = as_i16(qy + nib(SQY, i) * step);
+                const int rr = (ty >> 2) - ymin;
+                /* half-pel rounds: (dx, -1) and (dx, +1) follow each other in the table and are one row apart in the
+                 * same plane and phase -- measured together */
+                if (step == 2 && i >= 1 && nib(SQY, i) == -1 && c + 1 < K && nib(SQY, i + 1) == 1 && nib(SQX, i + 1) == nib(SQX, i))
+                {
+                    int va = 0, vb = 0;
+#pragma unroll
+                    for (int u = 0; u < MAXI; u++)
+                    {
+                        if (64 * u >= npairs) break;        /* (the same for every lane) */
+                        int o[5];
+                        column_rows<5>(L::PLANES, prow, rr, ty & 3, ct[u], depth, o);
+                        const int ca = small_rows_cost(o[0], o[1], o[2], o[3], satd, ct[u], lane & 3, depth);
+                        const int cb = small_rows_cost(o[1], o[2], o[3], o[4], satd, ct[u], lane & 3, depth);
+                        if (lane + 64 * u < npairs) { va += ca; vb += cb; }
+                    }
+                    va = wave_total(va); vb = wave_total(vb);
+                    if (lane == c) mycost = (satd ? va >> 1 : va) + mvc;
+                    if (lane == c + 1) mycost = (satd ? vb >> 1 : vb) + mvc;
+                    c++;
+                    continue;
+                }
+                int v = 0;
+#pragma unroll
+                for (int u = 0; u < MAXI; u++)
+                {
+                    if (64 * u >= npairs) break;
+                    int o[4];
+                    column_rows<4>(L::PLANES, prow, rr, ty & 3, ct[u], depth, o);
+                    const int cv = small_rows_cost(o[0], o[1], o[2], o[3], satd, ct[u], lane & 3, depth);
+                    if (lane + 64 * u < npairs) v += cv;
+                }
+                v = wave_total(v);
+                if (lane == c) mycost = (satd ? v >> 1 : v) + mvc;      /* every 4x4 abs-sum is even: halving the total = halving per tile */
+            }
+        }
+        if (centre) bcost = __shfl(mycost, 0);
+        int key = 0x7fffffff;
+        if (lane >= k0 && lane < K) key = (mycost << 6) | lane;
+        key = wave_min(key);
+        int bdir = 0;
+        if ((key >> 6) < bcost) { bcost = key >> 6; bdir = (key & 63) - k0 + 1; }
+        qx = as_i16(qx + nib(SQX, bdir) * step); qy = as_i16(qy + nib(SQY, bdir) * step);
+        nsub += (unsigned)K;
+    };
+
+    const int hpel_iters = kWorkload[a.subme][0], hpel_dirs = kWorkload[a.subme][1];
+    const int qpel_iters = kWorkload[a.subme][2], qpel_dirs = kWorkload[a.subme][3], hpel_satd = kWorkload[a.subme][4];
+    bool centre = hpel_satd != 0;
+    for (int it = 0; it < hpel_iters; it++)
+    {
+        round(2, hpel_dirs, hpel_satd != 0, centre);
+        centre = false;
+    }
+    centre = !hpel_satd;
+    if (centre && !qpel_iters) round(1, 0, true, true);
+    for (int it = 0; it < qpel_iters; it++)
+    {
+        round(1, qpel_dirs, true, centre);
+        centre = false;
+    }
+    if (lane == 0)
+    {
+        res[0] = (qx & 0xffff) | (qy << 16);
+        res[1] = bcost;
+        res[3] = (int)nsub;
+    }
+}
+
+template<typename P, int MAXI>
+__global__ __launch_bounds__(64) void refine_any_kernel(SearchArgs a)
+{
+    small_load_taps<P>((int)threadIdx.x, sizeof(P) == 1 ? 8 : a.depth);
+    /* a wave per PU of the launch, or (a.list) the waves walk the launch's list of PUs the one-wave search has staged */
+    const int n = a.list ? uni(a.redo[0]) : a.njobs;
+    for (int k = (int)blockIdx.x; k < n; k += (int)gridDim.x)
+    {
+        wave_sync();
+        const int j = a.list ? uni(a.redo[REDO_LIST + k]) : xcd_remap(k, a.njobs);
+        if (j < a.njobs) refine_any_pu<P, MAXI>(a, j);
     }
 }
 
