@@ -1030,13 +1030,17 @@ static void launch_refine(const SearchArgs &b, hipStream_t st, int list_grid)
 template<typename P>
 static void launch_any(const SearchArgs &b, hipStream_t st, int list_grid)
 {
-    const int grid = list_grid ? list_grid : b.njobs;
+    /* a wave looks at `chunk` PUs of the job list at once: as many as leave a few thousand waves */
+    int chunk = 64;
+    while (chunk > 1 && b.njobs / chunk < 4096) chunk >>= 1;
+    int grid = list_grid ? list_grid : (b.njobs + chunk - 1) / chunk;
+    if (grid > 65536) grid = 65536;
     if (b.max_dim <= 16)
-        hipLaunchKernelGGL((refine_any_kernel<P, 1>), dim3(grid), dim3(64), AnyLds<1>::TOTAL, st, b);
+        hipLaunchKernelGGL((refine_any_kernel<P, 1>), dim3(grid), dim3(64), AnyLds<1>::TOTAL, st, b, chunk);
     else if (b.max_dim == 32)
-        hipLaunchKernelGGL((refine_any_kernel<P, 4>), dim3(grid), dim3(64), AnyLds<4>::TOTAL, st, b);
+        hipLaunchKernelGGL((refine_any_kernel<P, 4>), dim3(grid), dim3(64), AnyLds<4>::TOTAL, st, b, chunk);
     else
-        hipLaunchKernelGGL((refine_any_kernel<P, 12>), dim3(grid), dim3(64), AnyLds<12>::TOTAL, st, b);
+        hipLaunchKernelGGL((refine_any_kernel<P, 12>), dim3(grid), dim3(64), AnyLds<12>::TOTAL, st, b, chunk);
 }
 
 /* waves of a launch of search_kernel: a wave per PU up to this many, then every wave walks the list */

@@ -1080,17 +1080,42 @@ __device__ __forceinline__ void refine_any_pu(const SearchArgs &a, int j)
     }
 }
 
+/* chunk: PUs of the job list a wave looks at together (a power of two up to 64, a lane each) before it refines those
+ * that are this kernel's one after the other: a list of squares of the fixed-shape sizes then costs a wave per `chunk`
+ * PUs and not a wave per PU. The host picks it so that a short list still spreads over the chip. */
 template<typename P, int MAXI>
-__global__ __launch_bounds__(64) void refine_any_kernel(SearchArgs a)
+__global__ __launch_bounds__(64) void refine_any_kernel(SearchArgs a, int chunk)
 {
     small_load_taps<P>((int)threadIdx.x, sizeof(P) == 1 ? 8 : a.depth);
-    /* a wave per PU of the launch, or (a.list) the waves walk the launch's list of PUs the one-wave search has staged */
-    const int n = a.list ? uni(a.redo[0]) : a.njobs;
-    for (int k = (int)blockIdx.x; k < n; k += (int)gridDim.x)
+    if (a.list)
     {
-        wave_sync();
-        const int j = a.list ? uni(a.redo[REDO_LIST + k]) : xcd_remap(k, a.njobs);
-        if (j < a.njobs) refine_any_pu<P, MAXI>(a, j);
+        /* the launch's list of PUs the STAR kernels left to others, every wave walking it */
+        const int n = uni(a.redo[0]);
+        for (int k = (int)blockIdx.x; k < n; k += (int)gridDim.x)
+        {
+            wave_sync();
+            const int j = uni(a.redo[REDO_LIST + k]);
+            if (j < a.njobs) refine_any_pu<P, MAXI>(a, j);
+        }
+        return;
+    }
+    const int lane = (int)threadIdx.x;
+    for (int base = (int)blockIdx.x * chunk; base < a.njobs; base += (int)gridDim.x * chunk)
+    {
+        const int j = base + lane;
+        bool mine = false;
+        if (lane < chunk && j < a.njobs)
+        {
+            const int d1 = ((const int*)(a.jobs + j))[1], w = d1 & 0xff, h = (d1 >> 8) & 0xff;
+            mine = !(w == h && (w == a.staged || w == a.staged2)) && any_refines(w, h) && a.results[j].cost > 0;
+        }
+        unsigned long long m = __ballot(mine);
+        while (m)
+        {
+            wave_sync();
+            refine_any_pu<P, MAXI>(a, base + (int)__builtin_ctzll(m));
+            m &= m - 1;
+        }
     }
 }
 
