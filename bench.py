@@ -841,6 +841,14 @@ def main():
                 rows10, _ = measure.esa_per_size(e10, dev)
                 ms10 = sum(r["ms"] for r in rows10)
                 px10 = sum(r["pixel_sads"] for r in rows10)
+                ctu10 = measure.esa_ctu_picture(e10, dev, compare=True)
+                cj10, cr10 = ctu10["jobs"], ctu10["results"]
+                pick = np.concatenate([np.random.default_rng(6).choice(np.flatnonzero(cj10["w"] == s_), 2, replace=False) for s_ in (64, 32, 16, 8)])
+                cur_, ref_, org_, st_ = ctu10["planes"]
+                exp = orc.me_search_batch(orc.make_ctx(10, cur_, org_, st_, [ref_], org_, st_, False, 32, METHODS["full"], 5), cj10[pick])
+                if not ctu10["equal"] or not all(np.array_equal(exp[k_], cr10[pick][k_]) for k_ in ("mv", "cost", "sad_calls", "subpel_calls")):
+                    print("PARITY FAILURE: exhaustive search per CTU, 10-bit: GPU results differ from the oracle or the per-size scans", file=sys.stderr)
+                    sys.exit(2)
                 rk10 = measure.rk_picture(e10, dev, qp=42)
                 e10.close()
                 out["other_paths"] = {
@@ -883,6 +891,10 @@ def main():
                                       "bound": "valu", "peak": measure.SAD_ISSUE_PEAK / 2e9,
                                       "frac": px10 / (ms10 * 1e-3) / (measure.SAD_ISSUE_PEAK / 2),
                                       "per_pu_size_ms": {str(r["size"]): r["ms"] for r in rows10}},
+                    "esa_4k_main10_ctu": {"workload": "the 10-bit searches through the scan per CTU (v_sad_u16, 2 x 8 displacements per lane and task)",
+                                          "ms_per_picture_reference": ctu10["ms"], "value": ctu10["pixel_sads"] / ctu10["ms"] / 1e6,
+                                          "unit": "Gpixel-SAD/s credited",
+                                          "parity": "every record equal to the per-size launches'; 8 PUs (2 per size, seeded) through the oracle"},
                     "mc_4k": {"workload": "3840x2160 8-bit TComPrediction::motionCompensation of every PU of a picture (mixed quadtree "
                                           "partitioning, luma + 4:2:0 chroma, random quarter-pel MVs), device-resident job list",
                               "bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s",

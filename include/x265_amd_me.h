@@ -210,10 +210,10 @@ int x265amd_set_esa_window_bytes(x265amd_ctx *ctx, int bytes);
 /* X265_FULL_SEARCH (encoder/motion.cpp:1021-1056) of every square PU of whole 64x64 CTUs: the quadtree of
  * TEncCu::xCompressCU (Lib/TLibEncoder/TEncCu.cpp:2352) has the encoder search the 64x64 PU, its four 32x32, sixteen
  * 16x16 and sixty-four 8x8 PUs, and the SAD of a PU at a displacement is the sum of its 8x8 blocks' -- the reference's
- * hardware model shares them the same way (hardwareC/inter.cpp:2521-2624). With 8-bit samples one scan per CTU measures
+ * hardware model shares them the same way (hardwareC/inter.cpp:2521-2624). One scan per CTU measures
  * the 8x8 level over the bounding box of the PUs' ranges and adds the sums up the quadtree, every PU keeping the first
  * minimum of its own range with its own predictor's lambda * bits; results equal x265amd_search_batch with X265_FULL_SEARCH
- * job for job (deeper samples, or a QP whose cost table can wrap, run the per-size scans). It pays where the
+ * job for job (a QP whose cost table can wrap runs the per-size scans). It pays where the
  * predictors of a CTU's PUs lie close together (the scan covers the box around all ranges); a caller sends CTUs whose
  * ranges lie far apart through x265amd_search_batch_dev per size instead.
  * jobs / results: 85 nctu records -- the 64 nctu 8x8 PUs (CTU-major; inside a CTU in Morton order: bit 0 of the index

@@ -26,22 +26,27 @@ def _picture_jobs(W, H, rng, merange, spread, margin, own_ranges=False):
     return jobs
 
 
+@pytest.mark.parametrize("depth", [8, 10, 12])
 @pytest.mark.parametrize("kind,W,H,merange,spread,own", [
     ("texture", 256, 192, 20, 3, False),        # whole CTUs, predictors a few samples apart
     ("texture", 192, 160, 33, 0, False),        # the last CTU row is cut: 64x64 and lower 32x32 slots are empty
     ("static", 128, 128, 13, 2, True),          # every position the same SAD: table costs and raster order decide
     ("noise", 192, 128, 57, 6, True),           # ranges of their own per PU inside a wide box: several strips each way
 ])
-def test_ctu_scan_vs_oracle_and_per_pu_scans(engine8, oracle, kind, W, H, merange, spread, own):
+def test_ctu_scan_vs_oracle_and_per_pu_scans(request, oracle, kind, W, H, merange, spread, own, depth):
+    """8-bit samples: packed quad-SADs, 4 x 8 displacements per lane and task; deeper samples: v_sad_u16, 2 x 8."""
+    from x265_amd.engine import Engine
+    own_engine = Engine(0, depth) if depth == 12 else None
+    engine8 = own_engine or request.getfixturevalue("engine8" if depth == 8 else "engine10")      # the engine of this depth
     m = 96
-    fenc, ref, org, stride = clip_planes(W, H, 8, kind, seed=5, margin=m)
+    fenc, ref, org, stride = clip_planes(W, H, depth, kind, seed=5, margin=m)
     pf = engine8.upload_plane(fenc, W, H, m, m, stride)
     pr = engine8.upload_plane(ref, W, H, m, m, stride)
     rng = np.random.default_rng(W + H + merange)
     jobs = _picture_jobs(W, H, rng, merange, spread, m, own)
     cj, index, nctu = workload.esa_ctu_jobs(jobs, W, H)
     assert nctu == ((W + 63) // 64) * ((H + 63) // 64) and (index >= 0).sum() == len(jobs)
-    for qp, subme in ((30, 5), (12, 2)):
+    for qp, subme in ((30 + 6 * (depth - 8), 5), (12 + 6 * (depth - 8), 2)):
         res = engine8.esa_ctu_batch(pf, pr, cj, nctu, qp, subme)
         have = index >= 0
         assert (res["cost"][~have] == -1).all()
@@ -53,11 +58,13 @@ def test_ctu_scan_vs_oracle_and_per_pu_scans(engine8, oracle, kind, W, H, merang
             assert np.array_equal(got[k], exp[k]), (k, qp)
         # and the oracle itself on a sample of every size
         pick = np.concatenate([np.flatnonzero(have & (cj["w"] == s))[:: max(1, (have & (cj["w"] == s)).sum() // 6)] for s in (8, 16, 32, 64)])
-        mv, cost, sc, qc = oracle_search(oracle, 8, fenc, [ref], org, stride, cj[pick], qp, METHODS["full"], subme)
+        mv, cost, sc, qc = oracle_search(oracle, depth, fenc, [ref], org, stride, cj[pick], qp, METHODS["full"], subme)
         assert np.array_equal(res["mv"][pick], mv) and np.array_equal(res["cost"][pick], cost)
         assert np.array_equal(res["sad_calls"][pick], sc) and np.array_equal(res["subpel_calls"][pick], qc)
     engine8.free_plane(pf)
     engine8.free_plane(pr)
+    if own_engine:
+        own_engine.close()
 
 
 def test_ctu_list_checks(engine8):

@@ -52,6 +52,7 @@ def main():
     ap.add_argument("--subme", type=int, default=5)
     ap.add_argument("--merange", type=int, default=57)
     ap.add_argument("--check", type=int, default=0, help="PUs per shape to compare with the CPU oracle")
+    ap.add_argument("--shapes", default="", help="only these shapes, e.g. 16x8,8x16")
     ap.add_argument("--pairs", type=int, default=1, help="launch the picture's PUs this many times over in one launch (throughput instead of latency)")
     args = ap.parse_args()
     import torch
@@ -73,6 +74,9 @@ def main():
     d_pairs = e.pairs_upload([(planes[1], planes[0])] * args.pairs) if args.pairs > 1 else None
     shapes = [(64, 64, 64), (64, 32, 64), (32, 64, 64), (64, 16, 64), (64, 48, 64), (32, 32, 32), (32, 16, 32), (16, 32, 32), (32, 8, 32), (32, 24, 32),
               (16, 16, 16), (16, 8, 16), (8, 16, 16), (16, 4, 16), (16, 12, 16), (8, 8, 8), (8, 4, 8), (4, 8, 8)]
+    if args.shapes:
+        want = {tuple(int(v) for v in t.split("x")) for t in args.shapes.split(",")}
+        shapes = [t for t in shapes if (t[0], t[1]) in want]
     for (w, h, cu) in shapes:
         jobs = shape_jobs(W, H, w, h, la[0], wcu, hcu, args.merange, cu)
         if args.pairs > 1:

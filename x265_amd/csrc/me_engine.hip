@@ -968,19 +968,20 @@ static int launch_esa(x265amd_ctx *c, const SearchArgs &a, int window_bytes, int
     return X265AMD_OK;
 }
 
-/* X265_FULL_SEARCH of whole CTUs (8-bit samples): one scan over all of a CTU's PUs, then the stages around it per PU
+/* X265_FULL_SEARCH of whole CTUs: one scan over all of a CTU's PUs, then the stages around it per PU
  * size. a.jobs: 85 slots per CTU in the order me_esa_ctu.h describes. */
 static int aux_stream(x265amd_ctx *c);
+template<typename P>
 static int launch_esa_ctu(x265amd_ctx *c, const SearchArgs &a, int nctu)
 {
     static bool raised[SCRATCH_MAX_DEVICES];
     if (!raised[c->device])
     {
-        HIPCHK(c, hipFuncSetAttribute((const void*)esa_ctu_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, ECTU_L_TOTAL));
+        HIPCHK(c, hipFuncSetAttribute((const void*)esa_ctu_kernel<P>, hipFuncAttributeMaxDynamicSharedMemorySize, Ectu<P>::L_TOTAL));
         raised[c->device] = true;
     }
     static const bool no_staged = getenv("X265AMD_NO_STAGED") != 0;      /* measurements only */
-    hipLaunchKernelGGL(esa_ctu_kernel, dim3(nctu), dim3(ECTU_THREADS), ECTU_L_TOTAL, c->stream, a, nctu);
+    hipLaunchKernelGGL(esa_ctu_kernel<P>, dim3(nctu), dim3(ECTU_THREADS), Ectu<P>::L_TOTAL, c->stream, a, nctu);
     /* the stages around the scan are short launches that depend on the scan alone: the two small sizes on the
      * context's stream, the two large ones beside them on its second stream */
     int rc = aux_stream(c);
@@ -994,8 +995,8 @@ static int launch_esa_ctu(x265amd_ctx *c, const SearchArgs &a, int nctu)
         b.jobs = a.jobs + (size_t)first[k] * nctu; b.results = a.results + (size_t)first[k] * nctu;
         b.njobs = (first[k + 1] - first[k]) * nctu;
         b.max_dim = 8 << k;
-        b.staged = no_staged ? 0 : b.max_dim;
-        esa_finish<uint8_t>(c, b, ESA_WINDOW_DEFAULT, k < 2 ? c->stream : c->aux);
+        b.staged = no_staged || c->depth > 10 ? 0 : b.max_dim;
+        esa_finish<P>(c, b, ESA_WINDOW_DEFAULT, k < 2 ? c->stream : c->aux);
     }
     HIPCHK(c, hipEventRecord(c->ev_join, c->aux));
     HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_join, 0));
@@ -1963,8 +1964,8 @@ int x265amd_search_batch(x265amd_ctx *c, const x265amd_plane *fenc, const x265am
 
 /* ---- exhaustive search of whole CTUs ---- */
 
-/* the launch for a checked or device-resident CTU list: the shared scan where the engine has it (8-bit samples, a cost
- * table whose entries never wrap when added), the per-size scans otherwise -- same results either way */
+/* the launch for a checked or device-resident CTU list: the shared scan where the cost table's entries never wrap when
+ * added, the per-size scans otherwise -- same results either way */
 static int esa_ctu_dev(x265amd_ctx *c, const x265amd_plane *fenc, const x265amd_plane *ref, int qp, int subme,
                        const x265amd_job *d_jobs, int nctu, x265amd_result *d_results)
 {
@@ -1979,7 +1980,7 @@ static int esa_ctu_dev(x265amd_ctx *c, const x265amd_plane *fenc, const x265amd_
     fill_args(c, a, fenc, ref, 0, qp, X265AMD_FULL, subme);
     a.jobs = d_jobs; a.results = d_results; a.njobs = ECTU_PUS * nctu;
     static const bool no_share = getenv("X265AMD_NO_ESA_CTU") != 0;      /* measurements only */
-    if (c->depth <= 8 && c->table_nowrap[qp] && !no_share) return launch_esa_ctu(c, a, nctu);
+    if (c->table_nowrap[qp] && !no_share) return c->depth <= 8 ? launch_esa_ctu<uint8_t>(c, a, nctu) : launch_esa_ctu<uint16_t>(c, a, nctu);
     static const int first[5] = { 0, 64, 80, 84, 85 };
     for (int k = 0; k < 4; k++)
     {
