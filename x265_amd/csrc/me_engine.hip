@@ -73,6 +73,15 @@ struct SearchArgs
     unsigned char *cmark, *cdone;
     unsigned char *mark;   /* null, or per job: 1 = a STAR kernel handed this PU on (it is in the redo list), 0 = it did not */
     int list;              /* refinement kernels: 1 = refine the PUs of the redo list instead of those of the job list */
+    /* family launches, STAR: the list of 8x8 PUs carries the parents' list (pjobs ...), whose PU k a wave of
+     * star_small_kernel<8> searches along with its children 4 k .. 4 k + 3 where it can; handled[k] says so to both lists'
+     * launches (in the children's arguments: written; in the parents': read) */
+    const x265amd_job *pjobs;
+    x265amd_result *presults;
+    int npjobs;
+    unsigned char *pmark;
+    int *pstate;
+    unsigned char *handled;
     int stage_all;         /* 1: the one-wave search stops every PU before the sub-pel refinement; the PUs that are not squares of
                               the fixed-shape sizes are refined by refine_any_kernel */
 };
@@ -866,6 +875,7 @@ struct x265amd_ctx
         void *d_redo; size_t redo_cap;     /* list of the PUs a fixed-shape kernel handed on (redo_list_kernel) */
         void *d_state; size_t state_cap;   /* where the STAR search of a handed-on PU stands (StarFold::store) */
         void *d_mark; size_t mark_cap;     /* handed on by the STAR kernels */
+        void *d_handled; size_t handled_cap; /* parents of a family launch: searched along with their children */
     } bufs[2];
     hipStream_t aux;                   /* second stream of STAR launches: the marked PUs' searches run beside the others' refinement;
                                           made by the first such launch (a context that never searches this way holds no queue for it) */
@@ -1228,16 +1238,38 @@ static int launch_family(x265amd_ctx *c, const SearchArgs &parents, const Search
         pa.b.cjobs = ch.b.jobs; pa.b.cresults = ch.b.results; pa.b.ncjobs = ch.b.njobs;
         pa.b.cmark = ch.b.mark; pa.b.cdone = ch.b.done;
     }
-    /* the two lists' STAR kernels side by side on the two streams; then the handed-on PUs of both on the second stream */
+    static const bool no_share = getenv("X265AMD_NO_STAR_SHARE") != 0;                           /* measurements only */
+    const bool share = pa.b.method == X265AMD_STAR && !no_share;
     if ((rc = aux_stream(c))) return rc;
     HIPCHK(c, hipEventRecord(c->ev_fork, c->stream));
     HIPCHK(c, hipStreamWaitEvent(c->aux, c->ev_fork, 0));
-    if ((rc = search_star<P>(c, pa, c->stream)) || (rc = search_star<P>(c, ch, c->aux))) return rc;
-    HIPCHK(c, hipEventRecord(c->ev_a, c->stream));
-    HIPCHK(c, hipEventRecord(c->ev_b, c->aux));
+    if (share)
+    {
+        /* STAR: the children's kernel searches the parents along where the five jobs ask the same (their SADs are the
+         * children's sums); the parents' kernel then takes the parents left over */
+        x265amd_ctx::LaunchBufs &B = c->bufs[0];
+        if (ensure(c, &B.d_handled, &B.handled_cap, (size_t)parents.njobs)) return X265AMD_EHIP;
+        HIPCHK(c, hipMemsetAsync(B.d_handled, 0, (size_t)parents.njobs, c->aux));
+        ch.b.pjobs = pa.b.jobs; ch.b.presults = pa.b.results; ch.b.npjobs = pa.b.njobs;
+        ch.b.pmark = pa.b.mark; ch.b.pstate = pa.b.state;
+        ch.b.handled = pa.b.handled = (unsigned char*)B.d_handled;
+        if ((rc = search_star<P>(c, ch, c->aux))) return rc;
+        HIPCHK(c, hipEventRecord(c->ev_b, c->aux));
+        HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_b, 0));
+        if ((rc = search_star<P>(c, pa, c->stream))) return rc;
+        HIPCHK(c, hipEventRecord(c->ev_a, c->stream));
+    }
+    else
+    {
+        /* the two lists' STAR kernels side by side on the two streams */
+        if ((rc = search_star<P>(c, pa, c->stream)) || (rc = search_star<P>(c, ch, c->aux))) return rc;
+        HIPCHK(c, hipEventRecord(c->ev_a, c->stream));
+        HIPCHK(c, hipEventRecord(c->ev_b, c->aux));
+    }
+    /* then the handed-on PUs of both lists on the second stream */
     search_side<P>(c, ch, c->aux);                          /* needs the children's STAR kernel only */
     HIPCHK(c, hipStreamWaitEvent(c->aux, c->ev_a, 0));
-    HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_b, 0));
+    if (!share) HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_b, 0));
     search_side<P>(c, pa, c->aux);
     HIPCHK(c, hipEventRecord(c->ev_join, c->aux));
     launch_refine<P>(pa.b, c->stream, 0);
@@ -1412,6 +1444,7 @@ void x265amd_destroy(x265amd_ctx *c)
         if (c->bufs[i].d_done) (void)hipFree(c->bufs[i].d_done);
         if (c->bufs[i].d_state) (void)hipFree(c->bufs[i].d_state);
         if (c->bufs[i].d_mark) (void)hipFree(c->bufs[i].d_mark);
+        if (c->bufs[i].d_handled) (void)hipFree(c->bufs[i].d_handled);
     }
     if (c->aux)
     {
@@ -1685,7 +1718,7 @@ static void fill_args(x265amd_ctx *c, SearchArgs &a, const x265amd_plane *fenc, 
         a.ref[i].origin = r->origin; a.ref[i].stride = r->stride;
     }
     a.lowres = is_lowres; a.depth = c->depth; a.method = method; a.subme = subme; a.max_dim = is_lowres ? 8 : 64;
-    a.staged = 0; a.staged2 = 0; a.done = 0; a.redo = 0; a.pairs = 0; a.npairs = 0; a.plane_lds = 0; a.state = 0; a.mark = 0; a.list = 0; a.stage_all = 0; a.cjobs = 0; a.cresults = 0; a.ncjobs = 0; a.cmark = 0; a.cdone = 0;
+    a.staged = 0; a.staged2 = 0; a.done = 0; a.redo = 0; a.pairs = 0; a.npairs = 0; a.plane_lds = 0; a.state = 0; a.mark = 0; a.list = 0; a.stage_all = 0; a.pjobs = 0; a.presults = 0; a.npjobs = 0; a.pmark = 0; a.pstate = 0; a.handled = 0; a.cjobs = 0; a.cresults = 0; a.ncjobs = 0; a.cmark = 0; a.cdone = 0;
     a.ctab = c->tables[qp] + 32768;
 }
 

@@ -1236,6 +1236,21 @@ struct StarFold
     }
 };
 
+/* v of the four rows of sixteen lanes of a wave added up, lane by lane (two lane-swap adds) */
+__device__ __forceinline__ int rows4_sum(int v)
+{
+    auto r = __builtin_amdgcn_permlane16_swap((unsigned)v, (unsigned)v, false, false);
+    v = (int)(r[0] + r[1]);
+    r = __builtin_amdgcn_permlane32_swap((unsigned)v, (unsigned)v, false, false);
+    return (int)(r[0] + r[1]);
+}
+
+/* S = 8 in a family launch (a.pjobs: the list of 16x16 PUs launched with this list, PU k of it the parent of this
+ * list's PUs 4 k .. 4 k + 3): a wave holds the four children of one parent. Where the five jobs name the same
+ * predictor, candidates and range, every start-up candidate's SAD for the parent is the sum of the children's, the
+ * parent's own sequence of tests runs on those sums, and if the children all start their pattern where the parent does
+ * its 20 points are the children's sums too: the parent's whole integer stage costs a few lane swaps here and
+ * star_small_kernel<16> skips it (a.handled). */
 template<int S, typename P, int M = X265AMD_STAR>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(S == 16 ? OCC_S16 : OCC_S8))) void star_small_kernel(SearchArgs a)
 {
@@ -1262,8 +1277,22 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(S == 16 ? OC
         a.mark[j] = 1;
     }
     const bool act = valid && sized;
+    if constexpr (S == 16)
+        if (a.handled && valid && a.handled[j]) return;        /* searched with its children (one PU per wave: all lanes agree) */
     if (act && l == 0 && a.done) a.done[j] = 0;        /* "refined with its parent": set by the parent's refinement, if at all */
     if (__ballot(act) == 0) return;
+    bool fam = false;
+    if constexpr (S == 8 && M == X265AMD_STAR)
+        if (a.pjobs && g < a.npjobs)
+        {
+            const int *pjob = (const int*)(a.pjobs + g);
+            const int p0 = pjob[0], p1 = pjob[1];
+            bool same = act && (p1 & 0xffff) == SmallGeo<16>::SIZE_CODE && ((p1 ^ d[1]) >> 16) == 0 &&
+                        as_i16(d[0]) == as_i16(p0) + 8 * (grp & 1) && (d[0] >> 16) == (p0 >> 16) + 8 * (grp >> 1);
+#pragma unroll
+            for (int i = 2; i < 10; i++) same = same && pjob[i] == d[i];
+            fam = __ballot(same) == ~0ull;
+        }
 
     const int pux = as_i16(d[0]), puy = d[0] >> 16, numc = (d[1] >> 16) & 0xff;
     const int mnx = as_i16(d[2]), mny = d[2] >> 16, mxx = as_i16(d[3]), mxy = d[3] >> 16;
@@ -1425,6 +1454,37 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(S == 16 ? OC
             if (c < bprecost) { bprecost = c; bpx = ccx[i]; bpy = ccy[i]; }
         }
     }
+    /* the parent's start-up: the same slots with the children's SADs added up, its own sequence of tests */
+    int Pbmx = 0, Pbmy = 0, Pbcost = 0, Pbprecost = 0, Pbpx = pmx, Pbpy = pmy;
+    unsigned Pnsad = 0, Pnsub = 1;
+    int prkey0 = 0x7fffffff, prkey1 = 0x7fffffff, prkey2 = 0x7fffffff;
+    if constexpr (S == 8 && M == X265AMD_STAR)
+        if (fam)
+        {
+            const int pcost = rows4_sum(mycost - mvc) + mvc, pdir = rows4_sum(vdir);
+            Pbprecost = grp_lane<G::LG>(pcost, 0); Pbcost = Pbprecost;
+            Pbmx = as_i16((pmx + 2) >> 2); Pbmy = as_i16((pmy + 2) >> 2);
+            const int cFp = grp_lane<G::LG>(pdir, 0) + grp_lane<G::LG>(mvc, 1);
+            const int cZero = grp_lane<G::LG>(pdir, 1 << G::LT) + grp_lane<G::LG>(mvc, 2);
+            if (fpOn) { Pbcost = cFp; Pnsad++; }
+            if (zeroOn)
+            {
+                Pnsad++;
+                if (cZero < Pbcost) { Pbcost = cZero; Pbmx = 0; Pbmy = 0; }
+            }
+#pragma unroll
+            for (int i = 0; i < 4; i++)
+            {
+                const int c = grp_lane<G::LG>(pcost, 3 + i);
+                if (cOn[i] && !(ccx[i] == Pbpx && ccy[i] == Pbpy))
+                {
+                    Pnsub++;
+                    if (c < Pbprecost) { Pbprecost = c; Pbpx = ccx[i]; Pbpy = ccy[i]; }
+                }
+            }
+            /* the parent's points are the children's only where all five patterns have one centre */
+            fam = __ballot(bmx == Pbmx && bmy == Pbmy) == ~0ull;
+        }
     /* ---- the first three star rounds around (bmx, bmy): 4 + 8 + 8 points (motion.cpp:330-452), does any beat bcost?
      * A lane per (point, tile), four points per pass ---- */
     int rkey0 = 0x7fffffff, rkey1 = 0x7fffffff, rkey2 = 0x7fffffff;     /* per round: min of cost << 6 | point in visit order */
@@ -1487,9 +1547,48 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(S == 16 ? OC
             if (pass == 0) rkey0 = km;
             else if (pass < 3) rkey1 = km < rkey1 ? km : rkey1;
             else rkey2 = km < rkey2 ? km : rkey2;
+            if constexpr (S == 8 && M == X265AMD_STAR)
+                if (fam)
+                {
+                    /* same centre, range and predictor: the same points pass the bounds tests and carry the same lambda * bits */
+                    const int pv = rows4_sum(v);
+                    const int pkm = grp_min<G::LG>(ok && tile == 0 ? ((pv + cost) << 6) | p : 0x7fffffff);
+                    if (pass == 0) prkey0 = pkm;
+                    else if (pass < 3) prkey1 = pkm < prkey1 ? pkm : prkey1;
+                    else prkey2 = pkm < prkey2 ? pkm : prkey2;
+                }
         }
         npts += (unsigned)grp_count<G::LG>(ok && tile == 0);
     }
+    if constexpr (S == 8 && M == X265AMD_STAR)
+        if (a.pjobs && lane == 0 && g < a.npjobs)
+        {
+            a.handled[g] = fam;
+            if (fam)
+            {
+                StarFold F;
+                F.start(Pbmx, Pbmy, Pbcost);
+                F.round(prkey0); F.round(prkey1); F.round(prkey2);
+                Pnsad += npts;
+                int *pres = (int*)(a.presults + g);
+                a.pmark[g] = F.rounds < 3;
+                if (F.rounds < 3)
+                {
+                    F.store(a.pstate + 8 * (long)g, Pbprecost, Pbpx, Pbpy, Pnsad, Pnsub);
+                    pres[2] = (int)SMALL_RESUME;
+                }
+                else
+                {
+                    int qx, qy, c = Pbcost;
+                    if (Pbprecost < c) { qx = Pbpx; qy = Pbpy; c = Pbprecost; }
+                    else { qx = as_i16(Pbmx << 2); qy = as_i16(Pbmy << 2); }
+                    pres[0] = (qx & 0xffff) | (qy << 16);
+                    pres[1] = c;
+                    pres[2] = (int)Pnsad;
+                    pres[3] = (int)Pnsub;
+                }
+            }
+        }
     if (!act || l != 0) return;
     if constexpr (M != X265AMD_STAR)
     {
