@@ -73,7 +73,7 @@ struct SearchArgs
     unsigned char *cmark, *cdone;
     unsigned char *mark;   /* null, or per job: 1 = a STAR kernel handed this PU on (it is in the redo list), 0 = it did not */
     int list;              /* refinement kernels: 1 = refine the PUs of the redo list instead of those of the job list */
-    /* family launches, STAR: the list of 8x8 PUs carries the parents' list (pjobs ...), whose PU k a wave of
+    /* family launches: the list of 8x8 PUs carries the parents' list (pjobs ...), whose PU k a wave of
      * star_small_kernel<8> searches along with its children 4 k .. 4 k + 3 where it can; handled[k] says so to both lists'
      * launches (in the children's arguments: written; in the parents': read) */
     const x265amd_job *pjobs;
@@ -1239,13 +1239,13 @@ static int launch_family(x265amd_ctx *c, const SearchArgs &parents, const Search
         pa.b.cmark = ch.b.mark; pa.b.cdone = ch.b.done;
     }
     static const bool no_share = getenv("X265AMD_NO_STAR_SHARE") != 0;                           /* measurements only */
-    const bool share = pa.b.method == X265AMD_STAR && !no_share;
+    const bool share = !no_share;
     if ((rc = aux_stream(c))) return rc;
     HIPCHK(c, hipEventRecord(c->ev_fork, c->stream));
     HIPCHK(c, hipStreamWaitEvent(c->aux, c->ev_fork, 0));
     if (share)
     {
-        /* STAR: the children's kernel searches the parents along where the five jobs ask the same (their SADs are the
+        /* the children's kernel searches the parents along where the five jobs ask the same (their SADs are the
          * children's sums); the parents' kernel then takes the parents left over */
         x265amd_ctx::LaunchBufs &B = c->bufs[0];
         if (ensure(c, &B.d_handled, &B.handled_cap, (size_t)parents.njobs)) return X265AMD_EHIP;

@@ -1282,7 +1282,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(S == 16 ? OC
     if (act && l == 0 && a.done) a.done[j] = 0;        /* "refined with its parent": set by the parent's refinement, if at all */
     if (__ballot(act) == 0) return;
     bool fam = false;
-    if constexpr (S == 8 && M == X265AMD_STAR)
+    if constexpr (S == 8)
         if (a.pjobs && g < a.npjobs)
         {
             const int *pjob = (const int*)(a.pjobs + g);
@@ -1458,7 +1458,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(S == 16 ? OC
     int Pbmx = 0, Pbmy = 0, Pbcost = 0, Pbprecost = 0, Pbpx = pmx, Pbpy = pmy;
     unsigned Pnsad = 0, Pnsub = 1;
     int prkey0 = 0x7fffffff, prkey1 = 0x7fffffff, prkey2 = 0x7fffffff;
-    if constexpr (S == 8 && M == X265AMD_STAR)
+    if constexpr (S == 8)
         if (fam)
         {
             const int pcost = rows4_sum(mycost - mvc) + mvc, pdir = rows4_sum(vdir);
@@ -1535,11 +1535,25 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(S == 16 ? OC
         }
         v = seg_sum(v, G::LT);      /* the tiles of a point are adjacent lanes */
         const int key = ok && tile == 0 ? ((v + cost) << 6) | p : 0x7fffffff;
+        /* the parent's key of the point: same centre, range and predictor, so the same points pass the bounds tests and
+         * carry the same lambda * bits */
+        int pkey = 0x7fffffff;
+        if constexpr (S == 8)
+            if (fam)
+            {
+                const int pv = rows4_sum(v);
+                pkey = ok && tile == 0 ? ((pv + cost) << 6) | p : 0x7fffffff;
+            }
         if constexpr (M == X265AMD_HEX)
         {
             /* rkey0: the ring (points 0 .. 5), rkey1: the square */
             const int kr = grp_min<G::LG>(p < 6 ? key : 0x7fffffff), ks = grp_min<G::LG>(p >= 6 ? key : 0x7fffffff);
             rkey0 = kr < rkey0 ? kr : rkey0; rkey1 = ks < rkey1 ? ks : rkey1;
+            if (S == 8 && fam)
+            {
+                const int pr = grp_min<G::LG>(p < 6 ? pkey : 0x7fffffff), ps = grp_min<G::LG>(p >= 6 ? pkey : 0x7fffffff);
+                prkey0 = pr < prkey0 ? pr : prkey0; prkey1 = ps < prkey1 ? ps : prkey1;
+            }
         }
         else
         {
@@ -1547,20 +1561,17 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(S == 16 ? OC
             if (pass == 0) rkey0 = km;
             else if (pass < 3) rkey1 = km < rkey1 ? km : rkey1;
             else rkey2 = km < rkey2 ? km : rkey2;
-            if constexpr (S == 8 && M == X265AMD_STAR)
-                if (fam)
-                {
-                    /* same centre, range and predictor: the same points pass the bounds tests and carry the same lambda * bits */
-                    const int pv = rows4_sum(v);
-                    const int pkm = grp_min<G::LG>(ok && tile == 0 ? ((pv + cost) << 6) | p : 0x7fffffff);
-                    if (pass == 0) prkey0 = pkm;
-                    else if (pass < 3) prkey1 = pkm < prkey1 ? pkm : prkey1;
-                    else prkey2 = pkm < prkey2 ? pkm : prkey2;
-                }
+            if (S == 8 && fam)
+            {
+                const int pkm = grp_min<G::LG>(pkey);
+                if (pass == 0) prkey0 = pkm;
+                else if (pass < 3) prkey1 = pkm < prkey1 ? pkm : prkey1;
+                else prkey2 = pkm < prkey2 ? pkm : prkey2;
+            }
         }
         npts += (unsigned)grp_count<G::LG>(ok && tile == 0);
     }
-    if constexpr (S == 8 && M == X265AMD_STAR)
+    if constexpr (S == 8)
         if (a.pjobs && lane == 0 && g < a.npjobs)
         {
             a.handled[g] = fam;
@@ -1568,11 +1579,25 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(S == 16 ? OC
             {
                 StarFold F;
                 F.start(Pbmx, Pbmy, Pbcost);
-                F.round(prkey0); F.round(prkey1); F.round(prkey2);
-                Pnsad += npts;
+                bool over;
+                if constexpr (M == X265AMD_STAR)
+                {
+                    F.round(prkey0); F.round(prkey1); F.round(prkey2);
+                    Pnsad += npts;
+                    over = F.rounds >= 3;
+                }
+                else
+                {
+                    int dir;
+                    unsigned counted;
+                    over = pat_fold<M>(prkey0, prkey1, Pbmx, Pbmy, Pbcost, dir, counted);
+                    Pnsad += counted;
+                    F.start(Pbmx, Pbmy, Pbcost);
+                    F.pt = dir;
+                }
                 int *pres = (int*)(a.presults + g);
-                a.pmark[g] = F.rounds < 3;
-                if (F.rounds < 3)
+                a.pmark[g] = !over;
+                if (!over)
                 {
                     F.store(a.pstate + 8 * (long)g, Pbprecost, Pbpx, Pbpy, Pnsad, Pnsub);
                     pres[2] = (int)SMALL_RESUME;
