@@ -742,8 +742,9 @@ def main():
                                   % (njobs * B, B, nthr, mt_s, "the reference's own code (oracle/_ref)" if use_ref
                                      else "oracle/me_oracle.c -O3")})
         kernel = {"families": "the family launch over the %d 16x16 PUs and their 8x8 children (%d PUs in all) of all %d frame pairs of a "
-                              "step, on the context's two streams: star_small_kernel<16> and <8> (start-up candidates and the first "
-                              "three pattern rounds: one and four PUs per wave), star_resume_kernel (the PUs those handed on: one per "
+                              "step, on the context's two streams: star_small_kernel<8> (start-up candidates and the first three "
+                              "pattern rounds of four 8x8 PUs per wave, and of their 16x16 parent from the children's sums where the "
+                              "five jobs ask the same), star_small_kernel<16> (the parents left over), star_resume_kernel (the PUs those handed on: one per "
                               "wave), refine_small_kernel<16> (sub-pel rounds, two PUs per wave, each taking its four children along "
                               "while they decide alike) and refine_small_kernel<8> (the remaining 8x8 PUs, four per wave); the launch "
                               "of the 64x64 PUs with their 32x32 children and the lookahead fields run beside it on streams of their "
