@@ -177,7 +177,7 @@ def valu_bound(profile, kernels, pus, launch_s, step_pairs=0, step_s=0.0, clock_
             "source": profile["source"]}
 
 
-def split_roofline(workload_name, value_gpx, alg_gbs, alg_bytes, world):
+def split_roofline(workload_name, value_gpx, alg_gbs, alg_bytes, world, measured_gpx=None):
     """Roofline entry of the split workloads (whole step: all launches + the gather, not one kernel). The exhaustive
     search is bound by the issue rate of the byte-SAD instructions; the lookahead window by the dependency chain of its
     wavefront (its HBM and VALU shares are both small), for which the HBM entry prices the compulsory bytes only."""
@@ -186,9 +186,12 @@ def split_roofline(workload_name, value_gpx, alg_gbs, alg_bytes, world):
                "formula": "compulsory bytes with no reuse between units; not measured traffic"}
     if workload_name == "esa4k":
         peak = SAD_ISSUE_PEAK * world / 1e9
-        return {"bound": "valu", "achieved": value_gpx, "peak": peak, "unit": "Gpixel-SAD/s (v_sad_u8 / v_qsad_pk_u16_u8 issue rate)",
-                "frac": value_gpx / peak, "traffic": None, "hbm_per_job": per_job,
-                "note": "whole step (all launches + gather); 10^3 - 10^4 pixel-SADs per byte of window: HBM does not bind"}
+        measured = value_gpx if measured_gpx is None else measured_gpx
+        return {"bound": "valu", "achieved": measured, "peak": peak, "unit": "Gpixel-SAD/s (v_sad_u8 / v_qsad_pk_u16_u8 issue rate)",
+                "frac": measured / peak, "credited": value_gpx, "traffic": None, "hbm_per_job": per_job,
+                "note": "whole step (all launches + gather); achieved = the SADs the launches measure (the scan per CTU measures the "
+                        "8x8 level once over the box around a CTU's ranges; `credited` = `value` counts every PU's own range at "
+                        "its own size); 10^3 - 10^4 pixel-SADs per byte of window: HBM does not bind"}
     return {"bound": "hbm", "achieved": alg_gbs, "peak": HBM_PEAK_GBS * world, "unit": "GB/s", "frac": alg_gbs / (HBM_PEAK_GBS * world),
             "traffic": None, "hbm_per_job": per_job,
             "note": "whole step; the launch is bound by the dependency chain of the lookahead wavefront (width + 2 x height CU "
@@ -208,7 +211,8 @@ def run_split_workload(args, torch, dist, dev, cdev, rank, local_rank, world):
         wl = sharded.EsaPicture(e, rank, world)
         wl.validate()
         name = ("3840x2160 8-bit, --me full --merange 92 --subme 5, every square 64/32/16/8 PU of one picture against 3 references; "
-                "%d (reference, CTU row) units split contiguously over %d GPU(s), each rank holds only its bands' rows + halo"
+                "%d (reference, CTU row) units split contiguously over %d GPU(s), each rank holds only its bands' rows + halo; "
+                "one launch per rank: the scan per CTU over all of its bands (x265amd_esa_ctu_batch_pairs_dev)"
                 % (wl.nrefs * wl.nrows, world))
     else:
         wl = sharded.LookaheadWindow(e, rank, world)
@@ -241,7 +245,8 @@ def run_split_workload(args, torch, dist, dev, cdev, rank, local_rank, world):
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    tot = torch.tensor([float(wl.pixel_sads()), float(wl.algorithmic_bytes())], dtype=torch.float64, device=cdev)
+    measured = float(wl.measured_pixel_sads()) if hasattr(wl, "measured_pixel_sads") else 0.0
+    tot = torch.tensor([float(wl.pixel_sads()), float(wl.algorithmic_bytes()), measured], dtype=torch.float64, device=cdev)
     t = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
     if world > 1:
         dist.all_reduce(tot, op=dist.ReduceOp.SUM)
@@ -310,7 +315,8 @@ def run_split_workload(args, torch, dist, dev, cdev, rank, local_rank, world):
                "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "strong",
                "vs_baseline": None, "dtype": "u8", "data": "synthetic",
                "config": {"workload": name, "parallelism": "units split over %d GPU(s), gather of MV records to rank 0" % world},
-               "roofline": split_roofline(args.workload, value, alg * args.steps / elapsed / 1e9, alg, world),
+               "roofline": split_roofline(args.workload, value, alg * args.steps / elapsed / 1e9, alg, world,
+                                          float(tot[2].item()) * args.steps / elapsed / 1e9 if float(tot[2].item()) else None),
                "cpu_baseline": {"value": cpu_px / cpu_s / 1e9, "unit": "Gpixel-SAD/s", "cores": 1, "kind": "port",
                                 "sample": sample + ", %.1f s; compared with the gathered GPU records" % cpu_s} if cpu_s else None}
         print(json.dumps(out))

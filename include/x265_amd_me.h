@@ -225,6 +225,10 @@ int x265amd_esa_ctu_batch(x265amd_ctx *ctx, const x265amd_plane *fenc, const x26
                           const x265amd_job *jobs, int nctu, x265amd_result *results);
 int x265amd_esa_ctu_batch_dev(x265amd_ctx *ctx, const x265amd_plane *fenc, const x265amd_plane *ref, int qp, int subme,
                               const x265amd_job *d_jobs, int nctu, x265amd_result *d_results);
+/* The same over several (source, reference) pairs in one launch (x265amd_pairs_upload): slot 0 of a CTU's 8x8 PUs names
+ * the CTU's pair in job.reserved, and so does every slot that holds a PU. */
+int x265amd_esa_ctu_batch_pairs_dev(x265amd_ctx *ctx, const void *d_pairs, int npairs, int qp, int subme,
+                                    const x265amd_job *d_jobs, int nctu, x265amd_result *d_results);
 
 /* MotionEstimate::subpelCompare (encoder/motion.cpp:1651-1689) for njobs PUs:
  * job.qmvp is the qpel MV to evaluate, cmp 0 = sad, 1 = satd; results[i].cost. */
@@ -353,6 +357,9 @@ int x265amd_upload(x265amd_ctx *ctx, void *d_dst, const void *src, size_t bytes)
  * copy to the host or the gather to the rank that feeds the encoder. Device pointers; asynchronous on the engine's
  * stream, after the searches launched before it. */
 int x265amd_pack_mv_cost(x265amd_ctx *ctx, const void *d_results, int n, void *d_out);
+/* The same with the records picked by index: out[i] = the MV + cost half of record d_index[i] (a launch whose list order
+ * is not the order the host wants the records in, e.g. the CTU order of x265amd_esa_ctu_batch_dev). */
+int x265amd_pack_mv_cost_indexed(x265amd_ctx *ctx, const void *d_results, const int32_t *d_index, int n, void *d_out);
 
 /* Measurement aid, no counterpart in the reference: the shader clock while the chip is busy. _start queues one wave on
  * the engine's stream that sleeps for `ms` milliseconds of the device's constant-rate clock and counts shader cycles

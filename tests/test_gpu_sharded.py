@@ -11,13 +11,15 @@ from util import host_lowres_planes
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("world", [1, 3, 4])
-def test_esa_bands_equal_the_unsharded_picture(engine8, oracle, world):
+@pytest.mark.parametrize("world,ctu", [(1, True), (3, True), (4, True), (3, False)])
+def test_esa_bands_equal_the_unsharded_picture(engine8, oracle, world, ctu):
+    """ctu: the bands' PUs through the scan per CTU (one launch over all of a rank's bands, records picked into the rank's
+    record order on the device), or through one launch per PU size."""
     W, H, merange, subme, qp = 640, 384, 20, 5, 30
     gathered, first = [], None
     for rank in range(world):
         wl = sharded.EsaPicture(engine8, rank, world, width=W, height=H, merange=merange, subme=subme, qp=qp,
-                                seed=17, margin=160)
+                                seed=17, margin=160, ctu=ctu)
         wl.validate()
         wl.step()
         assert wl.records_bytes == 8 * max(len(wl.rank_index(q)) for q in range(world))

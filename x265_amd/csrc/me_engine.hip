@@ -886,7 +886,8 @@ struct x265amd_ctx
     int *d_ticket;                     /* row hand-out counter of the row-parallel lookahead kernel */
     int esa_window_bytes;              /* LDS the exhaustive search may use per PU for its window; 0 = the library's choice */
     unsigned char *scratch;            /* this device's copy of the static scratch array (x265amd_lookahead_fields_static) */
-    bool esa_lds_raised, rime_lds_raised; /* dynamic-LDS limits raised on this context's device (the attribute is per device) */
+    bool esa_lds_raised, rime_lds_raised, ctu_lds_raised; /* dynamic-LDS limits raised on this context's device (the attribute is per device;
+                                                             a context has one sample size, so one instance of esa_ctu_kernel) */
     std::map<const void*, void*> plane_base; /* plane origin -> start of its allocation, whatever the sample size */
     struct FieldsInfo { int nfields, wcu, hcu, method, merange; };
     std::map<const void*, FieldsInfo> uploads; /* descriptor arrays of x265amd_fields_upload and what they were checked for */
@@ -984,11 +985,10 @@ static int aux_stream(x265amd_ctx *c);
 template<typename P>
 static int launch_esa_ctu(x265amd_ctx *c, const SearchArgs &a, int nctu)
 {
-    static bool raised[SCRATCH_MAX_DEVICES];
-    if (!raised[c->device])
+    if (!c->ctu_lds_raised)
     {
         HIPCHK(c, hipFuncSetAttribute((const void*)esa_ctu_kernel<P>, hipFuncAttributeMaxDynamicSharedMemorySize, Ectu<P>::L_TOTAL));
-        raised[c->device] = true;
+        c->ctu_lds_raised = true;
     }
     static const bool no_staged = getenv("X265AMD_NO_STAGED") != 0;      /* measurements only */
     hipLaunchKernelGGL(esa_ctu_kernel<P>, dim3(nctu), dim3(ECTU_THREADS), Ectu<P>::L_TOTAL, c->stream, a, nctu);
@@ -1386,7 +1386,7 @@ static int create_ctx(int device, int bit_depth, int high_priority, x265amd_ctx 
     c->jobs_cap = c->results_cap = c->stage_cap = 0; c->d_out = 0;
     c->esa_window_bytes = 0;
     c->probe_khz = 0;
-    c->esa_lds_raised = c->rime_lds_raised = false;
+    c->esa_lds_raised = c->rime_lds_raised = c->ctu_lds_raised = false;
     int prio_least = 0, prio_greatest = 0;
     if (hipSetDevice(device) != hipSuccess || hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest) != hipSuccess)
     {
@@ -2000,9 +2000,9 @@ int x265amd_search_batch(x265amd_ctx *c, const x265amd_plane *fenc, const x265am
 /* the launch for a checked or device-resident CTU list: the shared scan where the cost table's entries never wrap when
  * added, the per-size scans otherwise -- same results either way */
 static int esa_ctu_dev(x265amd_ctx *c, const x265amd_plane *fenc, const x265amd_plane *ref, int qp, int subme,
-                       const x265amd_job *d_jobs, int nctu, x265amd_result *d_results)
+                       const x265amd_job *d_jobs, int nctu, x265amd_result *d_results, const PairDev *d_pairs = 0, int npairs = 0)
 {
-    if (!c || !fenc || !ref || !d_jobs || !d_results || nctu < 0) return fail(c, X265AMD_EINVAL, "null argument");
+    if (!c || (!d_pairs && (!fenc || !ref)) || !d_jobs || !d_results || nctu < 0) return fail(c, X265AMD_EINVAL, "null argument");
     if (subme < 0 || subme > 7) return fail(c, X265AMD_EINVAL, "bad subme");
     if (nctu > (1 << 24) / ECTU_PUS) return fail(c, X265AMD_EINVAL, "too many CTUs in one launch");
     int rc = x265amd_set_qp(c, qp);
@@ -2010,7 +2010,10 @@ static int esa_ctu_dev(x265amd_ctx *c, const x265amd_plane *fenc, const x265amd_
     if (!nctu) return X265AMD_OK;
     HIPCHK(c, hipSetDevice(c->device));
     SearchArgs a;
-    fill_args(c, a, fenc, ref, 0, qp, X265AMD_FULL, subme);
+    x265amd_plane none;
+    memset(&none, 0, sizeof(none));
+    fill_args(c, a, d_pairs ? &none : fenc, d_pairs ? &none : ref, 0, qp, X265AMD_FULL, subme);
+    a.pairs = d_pairs; a.npairs = npairs;
     a.jobs = d_jobs; a.results = d_results; a.njobs = ECTU_PUS * nctu;
     static const bool no_share = getenv("X265AMD_NO_ESA_CTU") != 0;      /* measurements only */
     if (c->table_nowrap[qp] && !no_share) return c->depth <= 8 ? launch_esa_ctu<uint8_t>(c, a, nctu) : launch_esa_ctu<uint16_t>(c, a, nctu);
@@ -2032,6 +2035,13 @@ int x265amd_esa_ctu_batch_dev(x265amd_ctx *c, const x265amd_plane *fenc, const x
                               const x265amd_job *d_jobs, int nctu, x265amd_result *d_results)
 {
     return esa_ctu_dev(c, fenc, ref, qp, subme, d_jobs, nctu, d_results);
+}
+
+int x265amd_esa_ctu_batch_pairs_dev(x265amd_ctx *c, const void *d_pairs, int npairs, int qp, int subme,
+                                    const x265amd_job *d_jobs, int nctu, x265amd_result *d_results)
+{
+    if (!c || !d_pairs || npairs <= 0 || npairs > 256) return fail(c, X265AMD_EINVAL, "1 .. 256 pairs");
+    return esa_ctu_dev(c, 0, 0, qp, subme, d_jobs, nctu, d_results, (const PairDev*)d_pairs, npairs);
 }
 
 int x265amd_esa_ctu_batch(x265amd_ctx *c, const x265amd_plane *fenc, const x265amd_plane *ref, int qp, int subme,
@@ -2460,6 +2470,22 @@ __global__ __launch_bounds__(256) void pack_mv_cost_kernel(const uint2 *records,
 {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i < n) out[i] = records[2 * i];
+}
+
+__global__ __launch_bounds__(256) void pack_mv_cost_indexed_kernel(const uint2 *records, const int *index, uint2 *out, int n)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) out[i] = records[2 * index[i]];
+}
+
+int x265amd_pack_mv_cost_indexed(x265amd_ctx *c, const void *d_results, const int32_t *d_index, int n, void *d_out)
+{
+    if (!c || n < 0 || (n && (!d_results || !d_index || !d_out))) return fail(c, X265AMD_EINVAL, "null argument");
+    if (!n) return X265AMD_OK;
+    HIPCHK(c, hipSetDevice(c->device));
+    hipLaunchKernelGGL(pack_mv_cost_indexed_kernel, dim3((n + 255) / 256), dim3(256), 0, c->stream, (const uint2*)d_results, d_index, (uint2*)d_out, n);
+    HIPCHK(c, hipGetLastError());
+    return X265AMD_OK;
 }
 
 int x265amd_pack_mv_cost(x265amd_ctx *c, const void *d_results, int n, void *d_out)

@@ -19,7 +19,8 @@
  *
  * Job order of a launch of n CTUs: the 64 n 8x8 PUs (CTU-major, Morton order inside a CTU), then the 16 n 16x16 PUs
  * (likewise), the 4 n 32x32 PUs (raster order inside a CTU = Morton order), the n 64x64 PUs. A slot whose w is 0 is a
- * PU that is not searched (CTUs cut by the picture's edge); slot 0 of a CTU's 8x8 PUs always carries the CTU's origin.
+ * PU that is not searched (CTUs cut by the picture's edge); slot 0 of a CTU's 8x8 PUs always carries the CTU's origin
+ * and, in a launch over several (source, reference) pairs, the CTU's pair (job.reserved).
  */
 #ifndef X265AMD_ME_ESA_CTU_H
 #define X265AMD_ME_ESA_CTU_H
@@ -186,8 +187,11 @@ __global__ __launch_bounds__(ECTU_THREADS) __attribute__((amdgpu_waves_per_eu(4)
         return;
     }
     const uint16_t AS1 *ctab = (const uint16_t AS1*)a.ctab;
-    const char AS1 *ref = (const char AS1*)((const P AS1*)a.ref[0].origin + (long)cty * a.ref[0].stride + ctx);
-    const long rstride = (long)a.ref[0].stride * BPS;           /* bytes */
+    /* the CTU's pictures: the launch's own, or the entry of the launch's pair table that slot 0 names */
+    PlaneDev pfenc, pref[4];
+    job_planes(a, a.jobs + ectu_job(0, c, nctu), pfenc, pref);
+    const char AS1 *ref = (const char AS1*)((const P AS1*)pref[0].origin + (long)cty * pref[0].stride + ctx);
+    const long rstride = (long)pref[0].stride * BPS;           /* bytes */
 
     /* the lane's 8x8 block (Morton order) */
     const int bx8 = (lane & 1) | ((lane >> 1) & 2) | ((lane >> 2) & 4), by8 = ((lane >> 1) & 1) | ((lane >> 2) & 2) | ((lane >> 3) & 4);
@@ -198,8 +202,8 @@ __global__ __launch_bounds__(ECTU_THREADS) __attribute__((amdgpu_waves_per_eu(4)
          * off the plane. 8-bit: the lane's own block into registers, 8 rows of two dwords. 16-bit: the CTU into LDS, a
          * thread per row and run of eight samples. */
         const int sx8 = hdr[EH_SX1] >> 3, sy8 = hdr[EH_SY1] >> 3;
-        const long fstride = (long)a.fenc.stride * BPS;
-        const char AS1 *src = (const char AS1*)((const P AS1*)a.fenc.origin + (long)cty * a.fenc.stride + ctx);
+        const long fstride = (long)pfenc.stride * BPS;
+        const char AS1 *src = (const char AS1*)((const P AS1*)pfenc.origin + (long)cty * pfenc.stride + ctx);
         if constexpr (BPS == 1)
         {
             const int sbx = bx8 < sx8 ? bx8 : sx8, sby = by8 < sy8 ? by8 : sy8;

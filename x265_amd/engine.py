@@ -361,6 +361,14 @@ class Engine:
         self._chk(self.L.x265amd_fields_upload(self.ctx, arr, n, wcu, hcu, method, merange, C.byref(d)))
         return d
 
+    def esa_ctu_batch_pairs_dev(self, d_pairs, npairs, d_jobs, nctu, d_results, qp, subme):
+        self._chk(self.L.x265amd_esa_ctu_batch_pairs_dev(self.ctx, d_pairs, npairs, qp, subme,
+                                                         C.c_void_p(d_jobs), nctu, C.c_void_p(d_results)))
+
+    def pack_mv_cost_indexed(self, d_results, d_index, n, d_out):
+        """out[i] = the MV + cost half of record d_index[i] (int32 indices on the device)."""
+        self._chk(self.L.x265amd_pack_mv_cost_indexed(self.ctx, C.c_void_p(d_results), C.c_void_p(d_index), n, C.c_void_p(d_out)))
+
     def pack_mv_cost(self, d_results, n, d_out):
         """The MV + cost halves of n result records, packed (device pointers, asynchronous on the engine's stream)."""
         self._chk(self.L.x265amd_pack_mv_cost(self.ctx, C.c_void_p(d_results), n, C.c_void_p(d_out)))

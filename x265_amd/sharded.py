@@ -19,12 +19,14 @@ class EsaPicture:
     """--me full --merange 92 --subme 5 over every square 64/32/16/8 PU of one picture against `nrefs` references.
     Units: (reference, CTU row); a rank owns a contiguous run of them (sharding.row_units) and uploads, per run of rows
     of one reference, the source rows of the band and the reference rows the band's search windows reach (band_jobs).
-    One launch per PU size over all of the rank's bands (x265amd_search_batch_pairs_dev)."""
+    One launch over all of the rank's bands: the scan per CTU (x265amd_esa_ctu_batch_pairs_dev; a band starts on a CTU
+    row, so its PUs form whole CTUs), its records picked into the rank's record order on the device; ctu=False: one
+    launch per PU size (x265amd_search_batch_pairs_dev)."""
 
     SIZES = (64, 32, 16, 8)
 
     def __init__(self, e, rank, world, width=3840, height=2160, merange=92, nrefs=3, subme=5, qp=32,
-                 seed=99, margin=256, sizes=SIZES, records_ptr=None):
+                 seed=99, margin=256, sizes=SIZES, records_ptr=None, ctu=True):
         self.e, self.rank, self.world = e, rank, world
         self.W, self.H, self.merange, self.nrefs, self.subme, self.qp, self.M = width, height, merange, nrefs, subme, qp, margin
         self.sizes = sizes
@@ -87,6 +89,19 @@ class EsaPicture:
         self.own_records = None if records_ptr else e.device_alloc(self.records_bytes)
         self.records_ptr = records_ptr or self.own_records
         self.pairs = pairs
+        # the scan per CTU: the same jobs in CTU order, and where each of the rank's records is found in that list
+        self.ctu = bool(ctu) and self.n > 0
+        self.d_ctu_jobs = self.d_ctu_res = self.d_ctu_index = None
+        if self.ctu:
+            cj, index, self.nctu = workload.esa_ctu_jobs(self.my_jobs)
+            slot_of = np.zeros(self.n, np.int32)
+            slot_of[index[index >= 0]] = np.flatnonzero(index >= 0)
+            self.d_ctu_jobs = e.device_alloc(len(cj) * JOB_DTYPE.itemsize)
+            e.upload(self.d_ctu_jobs, cj.view(np.uint8))
+            self.d_ctu_res = e.device_alloc(len(cj) * RESULT_DTYPE.itemsize)
+            self.d_ctu_index = e.device_alloc(self.n * 4)
+            e.upload(self.d_ctu_index, slot_of.view(np.uint8))
+            self.ctu_slot_of = slot_of
 
     def validate(self):
         """The rank's whole job list once through the entry point that checks every job against its planes."""
@@ -95,6 +110,11 @@ class EsaPicture:
         return np.zeros(0, RESULT_DTYPE)
 
     def step(self):
+        if self.ctu:
+            self.e.esa_ctu_batch_pairs_dev(self.d_pairs, self.npairs, self.d_ctu_jobs, self.nctu, self.d_ctu_res, self.qp, self.subme)
+            self.e.pack_mv_cost_indexed(self.d_ctu_res, self.d_ctu_index, self.n, self.records_ptr)
+            self.e.sync()
+            return
         for (first, cnt, s) in self.classes:
             self.e.search_batch_pairs_dev(self.d_pairs, self.npairs, self.d_jobs + first * JOB_DTYPE.itemsize, cnt,
                                           self.d_res + first * RESULT_DTYPE.itemsize, self.qp, FULL, self.subme, max_pu_dim=s)
@@ -106,10 +126,31 @@ class EsaPicture:
         return self.e.download(self.records_ptr, self.records_bytes, np.uint8)
 
     def results(self):
-        return self.e.download(self.d_res, self.n, RESULT_DTYPE) if self.n else np.zeros(0, RESULT_DTYPE)
+        if not self.n:
+            return np.zeros(0, RESULT_DTYPE)
+        if self.ctu:
+            return self.e.download(self.d_ctu_res, 85 * self.nctu, RESULT_DTYPE)[self.ctu_slot_of]
+        return self.e.download(self.d_res, self.n, RESULT_DTYPE)
 
     def pixel_sads(self):
         return workload.pixel_sads(self.my_jobs, self.results())
+
+    def measured_pixel_sads(self):
+        """The SADs the launches measure. Per-size launches: every PU's own range (= pixel_sads of the full-pel stage);
+        the scan per CTU: the 8x8 level over the box around the ranges of a CTU's PUs, once for all four depths."""
+        if not self.ctu:
+            return self.pixel_sads()
+        j = self.my_jobs
+        key = (j["reserved"].astype(np.int64) << 32) | ((j["pu_y"].astype(np.int64) // 64) << 16) | (j["pu_x"].astype(np.int64) // 64)
+        total = 0
+        order = np.argsort(key, kind="stable")
+        ks, first = np.unique(key[order], return_index=True)
+        for a, b in zip(first, list(first[1:]) + [len(order)]):
+            g = j[order[a:b]]
+            nx = int(g["mvmax"][:, 0].max()) - int(g["mvmin"][:, 0].min()) + 1
+            ny = int(g["mvmax"][:, 1].max()) - int(g["mvmin"][:, 1].min()) + 1
+            total += nx * ny * 4096
+        return total
 
     def algorithmic_bytes(self):
         return workload.algorithmic_bytes(self.my_jobs)
@@ -124,7 +165,7 @@ class EsaPicture:
     def close(self):
         for p in self.planes:
             self.e.free_plane(p)
-        for d in (self.d_pairs, self.d_jobs, self.d_res, self.own_records):
+        for d in (self.d_pairs, self.d_jobs, self.d_res, self.own_records, self.d_ctu_jobs, self.d_ctu_res, self.d_ctu_index):
             if d:
                 self.e.device_free(d)
 

@@ -144,25 +144,26 @@ def ctu_slot(p):
     return mx * s, my * s, s
 
 
-def esa_ctu_jobs(jobs, width, height):
+def esa_ctu_jobs(jobs, width=0, height=0):
     """The job list of x265amd_esa_ctu_batch for a picture: `jobs` holds square PUs of 64 / 32 / 16 / 8 samples (as
     square_pu_jobs makes them); every 64x64 CTU that holds at least one of them gets its 85 slots, size-major (all
     CTUs' 8x8 slots, then the 16x16, 32x32, 64x64 ones), a slot without a PU in `jobs` with w = h = 0.
-    Returns (list, index) with index[k] = position in `jobs` of slot k, or -1."""
-    pos = {(int(j["pu_x"]), int(j["pu_y"]), int(j["w"])): k for k, j in enumerate(jobs) if j["w"] == j["h"]}
-    ctus = sorted({(y // 64, x // 64) for (x, y, s) in pos})
+    Jobs of several (source, reference) pairs (job.reserved, x265amd_esa_ctu_batch_pairs_dev) form CTUs per pair.
+    Returns (list, index, nctu) with index[k] = position in `jobs` of slot k, or -1."""
+    pos = {(int(j["reserved"]), int(j["pu_x"]), int(j["pu_y"]), int(j["w"])): k for k, j in enumerate(jobs) if j["w"] == j["h"]}
+    ctus = sorted({(g, y // 64, x // 64) for (g, x, y, s) in pos})
     n = len(ctus)
     first = (0, 64 * n, 80 * n, 84 * n)
     out = np.zeros(85 * n, JOB_DTYPE)
     index = np.full(85 * n, -1, np.int64)
-    for c, (cy, cx) in enumerate(ctus):
+    for c, (g, cy, cx) in enumerate(ctus):
         for p in range(85):
             ox, oy, s = ctu_slot(p)
             lvl = 0 if p < 64 else 1 if p < 80 else 2 if p < 84 else 3
             slot = first[lvl] + c * (64, 16, 4, 1)[lvl] + (p - (0, 64, 80, 84)[lvl])
-            k = pos.get((cx * 64 + ox, cy * 64 + oy, s))
+            k = pos.get((g, cx * 64 + ox, cy * 64 + oy, s))
             if k is None:
-                out[slot]["pu_x"], out[slot]["pu_y"] = cx * 64 + ox, cy * 64 + oy
+                out[slot]["pu_x"], out[slot]["pu_y"], out[slot]["reserved"] = cx * 64 + ox, cy * 64 + oy, g
             else:
                 out[slot] = jobs[k]
                 index[slot] = k
