@@ -256,3 +256,43 @@ def test_two_rank_band_records_over_gloo(tmp_path):
     outs = [p.communicate(timeout=240)[0] for p in procs]
     assert all(p.returncode == 0 for p in procs), outs
     assert "BANDS_OK" in outs[0]
+
+
+def test_ctu_job_lists_for_the_exhaustive_scan():
+    """workload.esa_ctu_jobs: 85 slots per 64x64 CTU, size-major; inside a CTU the 8x8 and 16x16 slots in Morton order
+    (a 16x16 PU's four 8x8 blocks are consecutive, a 32x32 PU's sixteen likewise); slots the picture's edge cuts off are
+    empty but still name their place; jobs of several pairs form CTUs per pair."""
+    W, H = 192, 160                                 # the third CTU row is cut: 32 of its 64 rows
+    wcu, hcu = (W // 2 + 7) // 8, (H // 2 + 7) // 8
+    la = np.zeros((wcu * hcu, 2), np.int16)
+    jobs = workload.square_pu_jobs(W, H, la, wcu, hcu, 16)
+    cj, index, n = workload.esa_ctu_jobs(jobs)
+    assert n == 9 and len(cj) == 85 * n and (index >= 0).sum() == len(jobs)
+    have = index >= 0
+    assert np.array_equal(cj[have], jobs[index[have]])
+    assert (cj["w"][~have] == 0).all() and (cj["h"][~have] == 0).all()
+    first = (0, 64 * n, 80 * n, 84 * n, 85 * n)
+    for lvl, (s, per) in enumerate(((8, 64), (16, 16), (32, 4), (64, 1))):
+        part = cj[first[lvl]:first[lvl + 1]].reshape(n, per)
+        for c in range(n):
+            ox0, oy0 = int(part[c, 0]["pu_x"]), int(part[c, 0]["pu_y"])
+            assert ox0 % 64 == 0 and oy0 % 64 == 0
+            for p in range(per):
+                ox, oy, ss = workload.ctu_slot(p + (0, 64, 80, 84)[lvl])
+                assert ss == s and int(part[c, p]["pu_x"]) == ox0 + ox and int(part[c, p]["pu_y"]) == oy0 + oy
+                inside = ox0 + ox + s <= W and oy0 + oy + s <= H
+                assert (part[c, p]["w"] == s) == inside
+    # Morton order: the children of 16x16 slot k are the 8x8 slots 4 k .. 4 k + 3, of 32x32 slot k the 16x16 slots 4 k .. 4 k + 3
+    for k in range(16):
+        x, y, _ = workload.ctu_slot(64 + k)
+        assert sorted(workload.ctu_slot(4 * k + q)[:2] for q in range(4)) == sorted((x + dx, y + dy) for dy in (0, 8) for dx in (0, 8))
+    for k in range(4):
+        x, y, _ = workload.ctu_slot(80 + k)
+        assert sorted(workload.ctu_slot(64 + 4 * k + q)[:2] for q in range(4)) == sorted((x + dx, y + dy) for dy in (0, 16) for dx in (0, 16))
+    # two pairs: CTUs per pair, every slot carrying its pair
+    two = np.concatenate([jobs, jobs])
+    two["reserved"][len(jobs):] = 1
+    cj2, index2, n2 = workload.esa_ctu_jobs(two)
+    assert n2 == 2 * n
+    eight = cj2[:64 * n2].reshape(n2, 64)
+    assert (eight["reserved"][:n] == 0).all() and (eight["reserved"][n:] == 1).all()
