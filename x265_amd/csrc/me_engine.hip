@@ -927,6 +927,9 @@ static int ensure(x265amd_ctx *c, void **p, size_t *cap, size_t need)
     if (*p) { HIPCHK(c, hipFree(*p)); *p = 0; *cap = 0; }
     size_t n = need + need / 2 + 4096;
     HIPCHK(c, hipMalloc(p, n));
+    /* tests only: working arrays start out as garbage, so a kernel that reads one before a launch has written it shows */
+    static const bool poison = getenv("X265AMD_POISON") != 0;
+    if (poison) HIPCHK(c, hipMemset(*p, 0xA5, n));
     *cap = n;
     return 0;
 }
