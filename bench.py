@@ -845,6 +845,19 @@ def main():
                 progress("other paths: Main10")
                 e10 = Engine(local_rank, 10)
                 m10 = measure.pattern_search_picture(e10, dev)
+                e10b = Engine(local_rank, 10)
+                m10f = measure.pattern_search_picture_families(e10, e10b, dev)
+                e10b.close()
+                j10 = m10f["jobs"]
+                pick = np.concatenate([np.random.default_rng(8).choice(np.flatnonzero(j10["w"] == s_), n_, replace=False)
+                                       for s_, n_ in ((64, 6), (32, 12), (16, 24), (8, 48))])
+                cur_, org_, st_ = pad_plane(m10f["planes"][1], 128)
+                ref_, _, _ = pad_plane(m10f["planes"][0], 128)
+                exp = orc.me_search_batch(orc.make_ctx(10, cur_, org_, st_, [ref_], org_, st_, False, 38, METHODS["star"], 5), j10[pick])
+                if not all(np.array_equal(m10f["results"][k_], m10["results"][k_]) and np.array_equal(exp[k_], m10f["results"][pick][k_])
+                           for k_ in ("mv", "cost", "sad_calls", "subpel_calls")):
+                    print("PARITY FAILURE: Main10 4K: GPU records differ between the launch forms or from the oracle", file=sys.stderr)
+                    sys.exit(2)
                 rows10, _ = measure.esa_per_size(e10, dev)
                 ms10 = sum(r["ms"] for r in rows10)
                 px10 = sum(r["pixel_sads"] for r in rows10)
@@ -870,8 +883,13 @@ def main():
                                         "moves (marked_frac) walk on one per wave; 8 frame pairs, classes one after the other on one stream"),
                     "main10_4k": {"workload": "3840x2160 10-bit, --me star --merange 57 --subme 5, all 64/32/16/8 square PUs of one "
                                               "picture against one reference (BASELINE configs[3], per reference)",
-                                  "ms_per_picture_reference": m10["ms"], "pu_searches": m10["pus"],
-                                  "value": m10["pixel_sads"] / m10["ms"] / 1e6, "unit": "Gpixel-SAD/s"},
+                                  "ms_per_picture_reference": m10f["ms"], "pu_searches": m10f["pus"],
+                                  "value": m10f["pixel_sads"] / m10f["ms"] / 1e6, "unit": "Gpixel-SAD/s",
+                                  "launch": "two launches side by side, as the headline's: the 16x16 PUs with the list of their 8x8 "
+                                            "children on one context, the 64x64 PUs each followed by their 32x32 children on another; "
+                                            "host clock from the first launch to the end of both, every picture waited for",
+                                  "one_launch_per_size": {"ms_per_picture_reference": m10["ms"], "value": m10["pixel_sads"] / m10["ms"] / 1e6},
+                                  "parity": "records equal between the two launch forms; 90 PUs (6 / 12 / 24 / 48 per size, seeded) through the oracle"},
                     "lookahead_frame_cost": dict(la, workload="estimateFrameCost of B-frame triples (b-1, b, b+1): two lowres HEX "
                                                  "subme-1 merange-16 MV fields each, then 35-mode intra, bidirectional candidates, "
                                                  "list choice and row / frame sums (BASELINE configs[4] at 7680x4320)"),

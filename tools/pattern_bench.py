@@ -9,6 +9,8 @@ import argparse
 import os
 import sys
 
+import numpy as np
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
@@ -29,6 +31,14 @@ def main():
         m = measure.pattern_search_picture(e, dev, args.width, args.height, depth=depth, method=args.method, subme=args.subme, qp=qp)
         print("%2d-bit %dx%d %s subme %d: %d PU searches, %.3f ms per picture-reference, %.1f Gpixel-SAD/s" %
               (depth, args.width, args.height, args.method, args.subme, m["pus"], m["ms"], m["pixel_sads"] / m["ms"] / 1e6))
+        if args.method in ("star", "hex", "dia"):
+            e2 = Engine(0, depth)
+            f = measure.pattern_search_picture_families(e, e2, dev, args.width, args.height, depth=depth, method=args.method, subme=args.subme, qp=qp)
+            same = all(np.array_equal(f["results"][k], m["results"][k]) for k in ("mv", "cost", "sad_calls", "subpel_calls"))
+            print("       the same as two launches side by side (16x16 with their 8x8 children; 64x64 with their 32x32 children): "
+                  "%.3f ms per picture-reference, %.1f Gpixel-SAD/s, records %s" %
+                  (f["ms"], f["pixel_sads"] / f["ms"] / 1e6, "equal" if same else "DIFFER"))
+            e2.close()
         e.close()
 
 

@@ -237,6 +237,59 @@ def pattern_search_picture(e, dev, width=3840, height=2160, depth=10, method="st
     return {"ms": ms, "pus": n, "pixel_sads": workload.pixel_sads(jobs, res), "jobs": jobs, "results": res}
 
 
+def pattern_search_picture_families(e, e2, dev, width=3840, height=2160, depth=10, method="star", subme=5, merange=57, reps=5, seed=31, qp=38):
+    """The searches of pattern_search_picture launched the way the headline launches them: the 16x16 PUs with the list of
+    their 8x8 children as one family launch on engine `e`, the 64x64 PUs each followed by their 32x32 children on engine
+    `e2` beside it (two contexts, so the two launches share the chip). Times a picture from the first launch to the end
+    of both (host clock around `reps` pictures, every picture waited for). Returns ms, pixel-SADs, jobs / results."""
+    import time
+    import torch
+    from .engine import HEX, SQUARE_ONLY
+    from .synth import lowres_dims
+    M = 128
+    clip = make_clip(width, height, 2, seed=seed, depth=depth)
+    planes = []
+    for f in clip:
+        buf, org, stride = pad_plane(f, M)
+        planes.append(e.upload_plane(buf, width, height, M, M, stride))
+    low = [e.lowres_init(p) for p in planes]
+    lw, lh, wcu, hcu = lowres_dims(width, height)
+    la_mvs, _, _ = e.lookahead_fields([(low[1][0], low[0])], wcu, hcu, 12 + 6 * (depth - 8), HEX, 1, 16)
+    host_jobs = [workload.square_pu_jobs(width, height, la_mvs[0], wcu, hcu, merange)]
+    d_pairs = e.pairs_upload([(planes[1], planes[0])])
+    bj, bi = workload.class_job_list(host_jobs, (64, 32), families=True)
+    pj, pi, kj, ki = workload.family_lists(host_jobs, 16)
+    sj, si, npar = np.concatenate([pj, kj]), np.concatenate([pi, ki]), len(pj)
+    up = lambda j: torch.from_numpy(j.view(np.uint8).reshape(len(j), -1).copy()).to(dev)
+    d_bj, d_sj = up(bj), up(sj)
+    d_br = torch.zeros((len(bj), RESULT_DTYPE.itemsize), dtype=torch.uint8, device=dev)
+    d_sr = torch.zeros((len(sj), RESULT_DTYPE.itemsize), dtype=torch.uint8, device=dev)
+    torch.cuda.synchronize()
+
+    def picture():
+        e2.search_batch_pairs_dev(d_pairs, 1, d_bj.data_ptr(), len(bj), d_br.data_ptr(), qp, METHODS[method], subme, max_pu_dim=64 | SQUARE_ONLY)
+        e.search_batch_pairs_family_dev(d_pairs, 1, d_sj.data_ptr(), npar, d_sr.data_ptr(), d_sj.data_ptr() + 40 * npar, len(sj) - npar,
+                                        d_sr.data_ptr() + 16 * npar, qp, subme, METHODS[method])
+        e.sync()
+        e2.sync()
+    picture()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        picture()
+    ms = (time.perf_counter() - t0) / reps * 1e3
+    res = np.zeros(len(host_jobs[0]), RESULT_DTYPE)
+    res[bi[:, 1]] = d_br.cpu().numpy().view(RESULT_DTYPE).reshape(-1)
+    res[si[:, 1]] = d_sr.cpu().numpy().view(RESULT_DTYPE).reshape(-1)
+    e.device_free(d_pairs)
+    for l in low:
+        for p in l:
+            e.free_plane(p)
+    for p in planes:
+        e.free_plane(p)
+    return {"ms": ms, "pus": len(res), "pixel_sads": workload.pixel_sads(host_jobs[0], res), "jobs": host_jobs[0], "results": res,
+            "planes": clip}
+
+
 def mixed_partition(rng, W, H, dtype):
     """A frame's final partitioning as mode decision leaves it: every 64x64 CTU split at random down the quadtree, leaf CUs
     as 2Nx2N, 2NxN, Nx2N or an asymmetric pair."""
