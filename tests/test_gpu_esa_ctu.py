@@ -46,7 +46,8 @@ def test_ctu_scan_vs_oracle_and_per_pu_scans(request, oracle, kind, W, H, merang
     jobs = _picture_jobs(W, H, rng, merange, spread, m, own)
     cj, index, nctu = workload.esa_ctu_jobs(jobs, W, H)
     assert nctu == ((W + 63) // 64) * ((H + 63) // 64) and (index >= 0).sum() == len(jobs)
-    for qp, subme in ((30 + 6 * (depth - 8), 5), (12 + 6 * (depth - 8), 2)):
+    # (the last QP is the largest one: the largest lambda * bits entries, 27 050 -- two of them still add up below 2^16)
+    for qp, subme in ((30 + 6 * (depth - 8), 5), (12 + 6 * (depth - 8), 2), (69, 1)):
         res = engine8.esa_ctu_batch(pf, pr, cj, nctu, qp, subme)
         have = index >= 0
         assert (res["cost"][~have] == -1).all()
