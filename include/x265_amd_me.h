@@ -132,7 +132,9 @@ int x265amd_search_batch(x265amd_ctx *ctx, const x265amd_plane *fenc, const x265
  * size, so batches of small PUs keep more PUs resident per CU; a larger job in the batch gets
  * cost -1 and is not searched. With 8-bit samples the square PUs of exactly that size take the
  * fixed-shape kernels (several PUs per wave, or several waves per PU), so a caller after
- * throughput launches one batch per PU size; results do not depend on it. A batch for 64x64 PUs (samples of at most
+ * throughput launches one batch per PU size; results do not depend on it. Other partitions in the batch (2NxN, Nx2N, the
+ * asymmetric pairs, squares of other sizes) take the one-wave search for their integer stage and, from 128 samples up, a
+ * kernel of their own for the sub-pel rounds. A batch for 64x64 PUs (samples of at most
  * 10 bits) takes its 32x32 PUs through the fixed-shape kernels as well, and a 64x64 PU that is directly followed in the list by
  * its four 32x32 children (raster order, same pictures) refines them together with itself where all five start the sub-pel
  * rounds from one MV -- a quarter of the children's work; the list order changes no result.
@@ -146,10 +148,12 @@ int x265amd_search_batch_dev(x265amd_ctx *ctx, const x265amd_plane *fenc, const 
                              int qp, int method, int subme,
                              const x265amd_job *d_jobs, int njobs, x265amd_result *d_results, int max_pu_dim);
 int x265amd_sync(x265amd_ctx *ctx);
-/* Measurement aid, no counterpart in the reference: how many PUs of this context's last X265_STAR_SEARCH launch through the
- * fixed-shape kernels did not end with their first three pattern rounds (StarPatternSearch, encoder/motion.cpp:307-547:
- * a point improved, so larger distances, the two-point or raster refinement and re-centred patterns followed) or were of
- * a shape those kernels do not take; 0 for any other launch. Waits for the engine's stream. */
+/* Measurement aid, no counterpart in the reference: how many PUs of this context's last launch through the fixed-shape
+ * integer kernels (X265_STAR_SEARCH, X265_HEX_SEARCH, X265_DIA_SEARCH) did not end with what those kernels measure -- the
+ * first three rounds of the star pattern (StarPatternSearch, encoder/motion.cpp:307-547: a point improved, so larger
+ * distances, the two-point or raster refinement and re-centred patterns followed), the first hexagon ring (:673-707: it
+ * moved the centre) or the first diamond round (:628-649) -- or were of a shape those kernels do not take; 0 for any other
+ * launch. Waits for the engine's stream. */
 int x265amd_marked_count(x265amd_ctx *ctx, int *marked);
 
 /* The same searches over several (source, reference) pairs in ONE launch: job.reserved (0 .. npairs - 1) names the pair
