@@ -135,7 +135,7 @@ __global__ __launch_bounds__(ECTU_THREADS) __attribute__((amdgpu_waves_per_eu(4)
     constexpr int CX = E::CX, CXL = E::CXL, BPS = E::BPS, KSH = E::KSH, KXP = E::KXP, PITCH = E::PITCH;
     const int c = xcd_remap(blockIdx.x, nctu);
     if (c >= nctu) return;
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int tid = threadIdx.x, wave = uni(tid >> 6), lane = tid & 63;     /* the wave's number as a scalar: so are its tasks' places */
     int *hdr = lds_i(0, ECTU_L_HDR);
     if (tid == 0)
     {
