@@ -169,7 +169,7 @@ __global__ __launch_bounds__(64) void search_kernel(SearchArgs a)
         job_planes(a, job, fenc, ref);
         S.bind(0, fenc, ref, a.nref, a.ctab, a.depth, job->pu_x, job->pu_y, w, h, a.max_dim,
                a.plane_lds ? a.plane_lds : plane_budget(a.max_dim, (int)sizeof(P)));
-        if (a.staged && ((a.stage_all && any_refines(w, h)) || (w == h && (w == a.staged || w == a.staged2)))) S.search_staged(job, a.method, a.results + j);
+        if (a.staged && ((a.stage_all && (any_refines(w, h) || tiny_class(w, h))) || (w == h && (w == a.staged || w == a.staged2)))) S.search_staged(job, a.method, a.results + j);
         else S.search(job, a.method, a.subme, a.results + j);
     }
 }
@@ -1055,6 +1055,11 @@ static void launch_any(const SearchArgs &b, hipStream_t st, int list_grid)
         hipLaunchKernelGGL((refine_any_kernel<P, 4>), dim3(grid), dim3(64), AnyLds<4>::TOTAL, st, b, chunk);
     else
         hipLaunchKernelGGL((refine_any_kernel<P, 12>), dim3(grid), dim3(64), AnyLds<12>::TOTAL, st, b, chunk);
+    /* the small shapes, several PUs per wave: a wave per 64 PUs of the list */
+    static const bool no_tiny = getenv("X265AMD_NO_REFINE_TINY") != 0;     /* measurements only: then they are nobody's */
+    int tgrid = list_grid ? list_grid : (b.njobs + 63) / 64;
+    if (tgrid > 65536) tgrid = 65536;
+    if (!no_tiny) hipLaunchKernelGGL((refine_tiny_kernel<P>), dim3(tgrid), dim3(64), TINY_LDS_MAX, st, b);
 }
 
 /* waves of a launch of search_kernel: a wave per PU up to this many, then every wave walks the list */

@@ -143,10 +143,17 @@ __device__ __forceinline__ int inv_tiles(int wt)
          : wt == 12 ? 5462 : wt == 16 ? 4096 : (65536 + wt - 1) / wt;
 }
 
-/* the partitions refine_any_kernel (me_small.h) is given: from 128 samples up. A wave per PU does not pay below that
- * (8x4, 4x8, 16x4, 4x16: a quarter of the lanes or fewer would have a (tile, column) pair); the one-wave search refines
- * those itself. */
-__device__ __forceinline__ bool any_refines(int w, int h) { return w * h >= 128; }
+/* The sub-pel rounds of the partitions no fixed-shape kernel takes (me_small.h): refine_any_kernel, a wave per PU,
+ * above 128 samples; refine_tiny_kernel, several PUs per wave, for the shapes whose (tile, column) pairs fill 8, 16 or
+ * 32 lanes exactly: 8x4, 4x8 | 16x4, 4x16, 8x8 | 16x8, 8x16. tiny_class: log2 of the lanes such a PU takes, 0 for any
+ * other shape. */
+__device__ __forceinline__ int tiny_class(int w, int h)
+{
+    const int a = w * h;
+    if ((w | h) & 3 || w > 16 || h > 16 || (w == 12 || h == 12)) return 0;
+    return a == 32 ? 3 : (a == 64 ? 4 : (a == 128 ? 5 : 0));
+}
+__device__ __forceinline__ bool any_refines(int w, int h) { return w * h >= 128 && !tiny_class(w, h); }
 
 /* sum over each group of 2^l adjacent lanes, left in every lane of the group */
 __device__ __forceinline__ int seg_sum(int v, int l)

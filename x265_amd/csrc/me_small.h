@@ -1119,6 +1119,172 @@ __global__ __launch_bounds__(64) void refine_any_kernel(SearchArgs a, int chunk)
     }
 }
 
+/* ---------------------------------------------------------------- sub-pel refinement of the small other partitions
+ *
+ * The same rounds for the shapes of tiny_class, several PUs per wave: 2^LG lanes per PU (a lane per (tile, column) pair),
+ * 64 >> LG PUs side by side, each with planes of its own in LDS. The PUs of a wave may differ in shape inside their
+ * class; everything about a PU is a value its lanes hold. A candidate's cost is a segmented sum; the reference's strict
+ * '<' over the candidates in table order is kept as a running (cost, direction) per PU. */
+template<int LG> struct TinyLds
+{
+    static constexpr int LPP = 1 << LG, NPU = 64 / LPP;
+    static constexpr int PLANE = LG == 3 ? 256 : (LG == 4 ? 512 : 640);        /* the largest plane of the class: (h + 10) w int16 */
+    static constexpr int PLANES = SM_FIXED;
+    static constexpr int TOTAL = PLANES + NPU * 3 * PLANE + 32;
+};
+#define TINY_LDS_MAX (SM_FIXED + 8 * 3 * 256 + 32)
+
+/* the PUs of class LG among jobs[base + 0 .. 63] (or among the redo list's entries there), NPU at a time */
+template<typename P, int LG>
+__device__ __forceinline__ void refine_tiny_pass(const SearchArgs &a, int jmine, bool mine)
+{
+    typedef TinyLds<LG> L;
+    constexpr int LPP = L::LPP, NPU = L::NPU;
+    const int depth = sizeof(P) == 1 ? 8 : a.depth;
+    const int lane = (int)threadIdx.x, grp = lane >> LG, l = lane & (LPP - 1);
+    unsigned long long m = __ballot(mine);
+    while (m)
+    {
+        /* group g takes the g-th PU that is left; a group without one goes along with the first (and writes nothing) */
+        int src_lane = (int)__builtin_ctzll(m);
+        bool valid = false;
+#pragma unroll
+        for (int g = 0; g < NPU; g++)
+            if (m)
+            {
+                if (g == grp) { src_lane = (int)__builtin_ctzll(m); valid = true; }
+                m &= m - 1;
+            }
+        const int j = __shfl(jmine, src_lane);
+        wave_sync();
+        const int *job = (const int*)(a.jobs + j);
+        const int d0 = job[0], d1 = job[1], d4 = job[4];
+        const int pux = as_i16(d0), puy = d0 >> 16, w = d1 & 0xff, h = (d1 >> 8) & 0xff;
+        int *res = (int*)(a.results + j);
+        const int r0 = res[0];
+        int qx = as_i16(r0), qy = r0 >> 16, bcost = res[1];
+        unsigned nsub = (unsigned)res[3];
+        const int mvpx = as_i16(d4), mvpy = d4 >> 16;
+        const bool active = valid;
+        const P AS1 *fenc0, *ref0;
+        int fstride, rstride;
+        small_planes<P>(a, d1, fenc0, fstride, ref0, rstride);
+        const int roff = puy * rstride + pux;
+        const uint16_t AS1 *ctab = (const uint16_t AS1*)a.ctab;
+        const int ltw = w == 16 ? 2 : (w == 8 ? 1 : 0), tw = 1 << ltw;
+        const int prow = h + 10, nitems = (h + 8) << ltw;
+        ColSrc ct;
+        {
+            const int t = l >> 2;
+            ct.ty = t >> ltw; ct.col = (t & (tw - 1)) * 4 + (l & 3);
+            const P AS1 *src = fenc0 + (long)(puy + ct.ty * 4) * fstride + pux + ct.col;
+            uint32_t f[4];
+#pragma unroll
+            for (int y = 0; y < 4; y++) f[y] = (uint32_t)src[(long)y * fstride];
+            ct.f01 = f[0] | (f[1] << 16); ct.f23 = f[2] | (f[3] << 16);
+        }
+        const int pbase = L::PLANES + grp * 3 * L::PLANE;
+
+        auto round = [&](int step, int dirs, bool satd, bool centre)
+        {
+            constexpr unsigned long long SQX = nibs({ 0, 0, 0, -1, 1, -1, -1, 1, 1 }), SQY = nibs({ 0, -1, 1, 0, 0, -1, 1, -1, 1 });
+            const int k0 = centre ? 1 : 0, K = k0 + dirs;
+            const int ya = as_i16(qy - step) >> 2, yb = qy >> 2, yc = as_i16(qy + step) >> 2;
+            int ymin = ya < yb ? ya : yb;
+            ymin = yc < ymin ? yc : ymin;
+            wave_sync();
+            /* horizontal pass: the lanes of a PU fill its own planes (the closing re-measure has the centre plane only) */
+            for (int p = 0; p < 3; p++)
+            {
+                if (p != 1 && dirs < 4) continue;
+                const int xp = as_i16(qx + (p - 1) * step);
+                const P AS1 *src = ref0 + (roff + __mul24(ymin - 3, rstride) + (xp >> 2) - 3);
+                const int *tp = (const int*)(x265amd_smem + SM_TAPS) + (xp & 3) * 12;
+                int16_t *plane = (int16_t*)(x265amd_smem + pbase + p * L::PLANE);
+#pragma unroll
+                for (int it = 0; it < (LG == 5 ? 2 : 3); it++)
+                {
+                    const int item = it * LPP + l;
+                    if (item < nitems)
+                    {
+                        const int r = item >> ltw, q = item & (tw - 1);
+                        hps_quad(src + (__mul24(r, rstride) + 4 * q), tp, plane + (4 * q) * prow + r, prow, depth);
+                    }
+                }
+            }
+            wave_sync();
+            int best = 0x7fffffff, bdir = 0;
+            for (int c = 0; c < K; c++)
+            {
+                const int i = c + 1 - k0, dx = nib(SQX, i), dy = nib(SQY, i);
+                const int tx = as_i16(qx + dx * step), ty = as_i16(qy + dy * step);
+                int mvc = 0;
+                if (active) mvc = ((int)ctab[tx - mvpx] + (int)ctab[ty - mvpy]) & 0xffff;
+                int o[4];
+                column_rows<4>(pbase + (dx + 1) * L::PLANE, prow, (ty >> 2) - ymin, ty & 3, ct, depth, o);
+                int v = small_rows_cost(o[0], o[1], o[2], o[3], satd, ct, l & 3, depth);
+                v = seg_sum(v, LG);
+                const int cost = (satd ? v >> 1 : v) + mvc;         /* every 4x4 abs-sum is even: halving the total = halving per tile */
+                if (centre && c == 0) { if (active) bcost = cost; }
+                else if (cost < best) { best = cost; bdir = i; }
+            }
+            if (active && best < bcost) { bcost = best; } else bdir = 0;
+            qx = as_i16(qx + nib(SQX, bdir) * step); qy = as_i16(qy + nib(SQY, bdir) * step);
+            if (active) nsub += (unsigned)K;
+        };
+
+        const int hpel_iters = kWorkload[a.subme][0], hpel_dirs = kWorkload[a.subme][1];
+        const int qpel_iters = kWorkload[a.subme][2], qpel_dirs = kWorkload[a.subme][3], hpel_satd = kWorkload[a.subme][4];
+        bool centre = hpel_satd != 0;
+        for (int it = 0; it < hpel_iters; it++)
+        {
+            round(2, hpel_dirs, hpel_satd != 0, centre);
+            centre = false;
+        }
+        centre = !hpel_satd;
+        if (centre && !qpel_iters) round(1, 0, true, true);
+        for (int it = 0; it < qpel_iters; it++)
+        {
+            round(1, qpel_dirs, true, centre);
+            centre = false;
+        }
+        if (l == 0 && active)
+        {
+            res[0] = (qx & 0xffff) | (qy << 16);
+            res[1] = bcost;
+            res[3] = (int)nsub;
+        }
+    }
+}
+
+template<typename P>
+__global__ __launch_bounds__(64) void refine_tiny_kernel(SearchArgs a)
+{
+    const int lane = (int)threadIdx.x;
+    small_load_taps<P>(lane, sizeof(P) == 1 ? 8 : a.depth);
+    /* a wave looks at 64 PUs of the job list at once (a.list: 64 entries of the launch's list of PUs the STAR kernels left
+     * to others), a lane each, and takes those of each class in turn */
+    const int n = a.list ? uni(a.redo[0]) : a.njobs;
+    for (int base = (int)blockIdx.x * 64; base < n; base += (int)gridDim.x * 64)
+    {
+        int j = 0, cls = 0;
+        if (base + lane < n)
+        {
+            j = a.list ? a.redo[REDO_LIST + base + lane] : base + lane;
+            if (j < a.njobs)
+            {
+                const int d1 = ((const int*)(a.jobs + j))[1], w = d1 & 0xff, h = (d1 >> 8) & 0xff;
+                /* a PU whose full-pel cost is 0 is not refined (motion.cpp:1073-1076), a negative cost marks a job that was refused */
+                if (!(w == h && (w == a.staged || w == a.staged2)) && !(!a.list && a.mark && a.mark[j]) && a.results[j].cost > 0) cls = tiny_class(w, h);
+            }
+        }
+        if (__ballot(cls != 0) == 0) continue;
+        refine_tiny_pass<P, 3>(a, j, cls == 3);
+        refine_tiny_pass<P, 4>(a, j, cls == 4);
+        refine_tiny_pass<P, 5>(a, j, cls == 5);
+    }
+}
+
 /* ---------------------------------------------------------------- the common case of a STAR search
  *
  * Most PUs of a picture end their integer search where it began: the start-up candidates (motion.cpp:562-621)
