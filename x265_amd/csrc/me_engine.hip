@@ -82,6 +82,8 @@ struct SearchArgs
     unsigned char *pmark;
     int *pstate;
     unsigned char *handled;
+    int tiny;              /* 1: the launch has star_tiny_kernel for the small other partitions (tiny_class): the square
+                              kernels do not hand those to the one-wave search */
     int stage_all;         /* 1: the one-wave search stops every PU before the sub-pel refinement; the PUs that are not squares of
                               the fixed-shape sizes are refined by refine_any_kernel */
 };
@@ -1039,6 +1041,17 @@ static void launch_refine(const SearchArgs &b, hipStream_t st, int list_grid)
     }
 }
 
+/* the sub-pel refinement of the small other partitions, several PUs per wave: a wave per 64 PUs of the job list or of
+ * the redo list */
+template<typename P>
+static void launch_tiny(const SearchArgs &b, hipStream_t st, int list_grid)
+{
+    static const bool no_tiny = getenv("X265AMD_NO_REFINE_TINY") != 0;     /* measurements only: then they are nobody's */
+    int tgrid = list_grid ? list_grid : (b.njobs + 63) / 64;
+    if (tgrid > 65536) tgrid = 65536;
+    if (!no_tiny) hipLaunchKernelGGL((refine_tiny_kernel<P>), dim3(tgrid), dim3(64), TINY_LDS_MAX, st, b);
+}
+
 /* the sub-pel refinement of the PUs no fixed-shape kernel takes (other partitions, squares of other sizes): every PU of
  * the job list, or of the redo list walked by list_grid waves */
 template<typename P>
@@ -1055,11 +1068,7 @@ static void launch_any(const SearchArgs &b, hipStream_t st, int list_grid)
         hipLaunchKernelGGL((refine_any_kernel<P, 4>), dim3(grid), dim3(64), AnyLds<4>::TOTAL, st, b, chunk);
     else
         hipLaunchKernelGGL((refine_any_kernel<P, 12>), dim3(grid), dim3(64), AnyLds<12>::TOTAL, st, b, chunk);
-    /* the small shapes, several PUs per wave: a wave per 64 PUs of the list */
-    static const bool no_tiny = getenv("X265AMD_NO_REFINE_TINY") != 0;     /* measurements only: then they are nobody's */
-    int tgrid = list_grid ? list_grid : (b.njobs + 63) / 64;
-    if (tgrid > 65536) tgrid = 65536;
-    if (!no_tiny) hipLaunchKernelGGL((refine_tiny_kernel<P>), dim3(tgrid), dim3(64), TINY_LDS_MAX, st, b);
+    launch_tiny<P>(b, st, list_grid);
 }
 
 /* waves of a launch of search_kernel: a wave per PU up to this many, then every wave walks the list */
@@ -1186,7 +1195,18 @@ static int launch_search(x265amd_ctx *c, const SearchArgs &a, int is_lowres, boo
     if (rc) return rc;
     if (sl.star)
     {
+        /* the small other partitions of the list through a fixed-shape stage of their own */
+        static const bool no_star_tiny = getenv("X265AMD_NO_STAR_TINY") != 0;                    /* measurements only */
+        sl.b.tiny = sl.b.stage_all && !no_star_tiny;
         if ((rc = search_star<P>(c, sl, c->stream))) return rc;
+        if (sl.b.tiny)
+        {
+            int tgrid = (a.njobs + 63) / 64;
+            if (tgrid > 65536) tgrid = 65536;
+            if (a.method == X265AMD_HEX) hipLaunchKernelGGL((star_tiny_kernel<P, X265AMD_HEX>), dim3(tgrid), dim3(64), STAR_TINY_LDS_MAX, c->stream, sl.b);
+            else if (a.method == X265AMD_DIA) hipLaunchKernelGGL((star_tiny_kernel<P, X265AMD_DIA>), dim3(tgrid), dim3(64), STAR_TINY_LDS_MAX, c->stream, sl.b);
+            else hipLaunchKernelGGL((star_tiny_kernel<P, X265AMD_STAR>), dim3(tgrid), dim3(64), STAR_TINY_LDS_MAX, c->stream, sl.b);
+        }
         /* The PUs handed on are few as a rule and each a long chain of dependent steps in one wave: their
          * searches and refinement run on the context's second stream while this one refines all the others. */
         static const bool no_fork = getenv("X265AMD_NO_FORK") != 0;                              /* measurements only */
@@ -1199,6 +1219,7 @@ static int launch_search(x265amd_ctx *c, const SearchArgs &a, int is_lowres, boo
         search_side<P>(c, sl, no_fork ? c->stream : c->aux);
         if (!no_fork) HIPCHK(c, hipEventRecord(c->ev_join, c->aux));
         launch_refine<P>(sl.b, c->stream, 0);
+        if (sl.b.tiny) launch_tiny<P>(sl.b, c->stream, 0);         /* (the PUs star_tiny_kernel ended; the others are in the list) */
         if (!no_fork) HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_join, 0));
         c->redo_valid = true;
     }
@@ -1726,7 +1747,7 @@ static void fill_args(x265amd_ctx *c, SearchArgs &a, const x265amd_plane *fenc, 
         a.ref[i].origin = r->origin; a.ref[i].stride = r->stride;
     }
     a.lowres = is_lowres; a.depth = c->depth; a.method = method; a.subme = subme; a.max_dim = is_lowres ? 8 : 64;
-    a.staged = 0; a.staged2 = 0; a.done = 0; a.redo = 0; a.pairs = 0; a.npairs = 0; a.plane_lds = 0; a.state = 0; a.mark = 0; a.list = 0; a.stage_all = 0; a.pjobs = 0; a.presults = 0; a.npjobs = 0; a.pmark = 0; a.pstate = 0; a.handled = 0; a.cjobs = 0; a.cresults = 0; a.ncjobs = 0; a.cmark = 0; a.cdone = 0;
+    a.staged = 0; a.staged2 = 0; a.done = 0; a.redo = 0; a.pairs = 0; a.npairs = 0; a.plane_lds = 0; a.state = 0; a.mark = 0; a.list = 0; a.stage_all = 0; a.tiny = 0; a.pjobs = 0; a.presults = 0; a.npjobs = 0; a.pmark = 0; a.pstate = 0; a.handled = 0; a.cjobs = 0; a.cresults = 0; a.ncjobs = 0; a.cmark = 0; a.cdone = 0;
     a.ctab = c->tables[qp] + 32768;
 }
 

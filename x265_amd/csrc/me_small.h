@@ -134,6 +134,14 @@ struct ColSrc
 template<int LG> __device__ __forceinline__ int grp_lane(int v, int k) { return __shfl(v, (int)(threadIdx.x & 63 & ~((1 << LG) - 1)) + k); }
 template<int LG> __device__ __forceinline__ int grp_min(int v)
 {
+    if (LG == 3)
+    {
+        int o;
+        o = dpp_all<0xB1>(v); v = o < v ? o : v;
+        o = dpp_all<0x4E>(v); v = o < v ? o : v;
+        o = dpp_all<0x141>(v); v = o < v ? o : v;
+        return v;
+    }
     if (LG == 4) return row_min16(v);
     if (LG == 5)
     {
@@ -152,6 +160,12 @@ template<int LG> __device__ __forceinline__ int grp_count(bool p)
 {
     const unsigned long long b = __ballot(p);
     return LG == 6 ? (int)__builtin_popcountll(b) : (int)__builtin_popcount((unsigned)((b >> (threadIdx.x & 48)) & 0xffff));
+}
+/* the same for groups of any size */
+template<int LG> __device__ __forceinline__ int grp_count_any(bool p)
+{
+    const unsigned long long b = __ballot(p);
+    return (int)__builtin_popcountll((b >> (threadIdx.x & 63 & ~((1 << LG) - 1))) & ((1ull << (1 << LG)) - 1));
 }
 template<int LG> __device__ __forceinline__ bool grp_any(bool p)
 {
@@ -1437,7 +1451,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(S == 16 ? OC
     for (int i = 0; i < 10; i++) d[i] = job[i];
     const bool sized = (d[1] & 0xffff) == G::SIZE_CODE;
     /* the launch for the list's largest size hands every PU that no fixed-shape launch takes to the one-wave search */
-    if (valid && !sized && l == 0 && S == a.staged && (d[1] & 0xffff) != (a.staged2 | (a.staged2 << 8)))
+    if (valid && !sized && l == 0 && S == a.staged && (d[1] & 0xffff) != (a.staged2 | (a.staged2 << 8)) &&
+        !(a.tiny && tiny_class(d[1] & 0xff, (d[1] >> 8) & 0xff)))
     {
         a.results[j].sad_calls = SMALL_REDO;
         a.mark[j] = 1;
@@ -1832,6 +1847,306 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(S == 16 ? OC
     res[3] = (int)nsub;
 }
 
+/* ---------------------------------------------------------------- the same stage for the small other partitions
+ *
+ * star_small_kernel's stage for the shapes of tiny_class, 2, 4 or 8 PUs per wave: start-up candidates, the points of the
+ * method's first rounds from a window in LDS, the record or the hand-over state. A wave looks at 64 PUs of the job list
+ * and takes those of each class in turn (as refine_tiny_kernel does); width and height of a PU are values its lanes
+ * hold, only the lanes per PU are fixed per class. */
+template<int LG> struct StarTinyLds
+{
+    static constexpr int LPP = 1 << LG, NPU = 64 / LPP;
+    static constexpr int PLANE = LG == 3 ? 224 : (LG == 4 ? 448 : 576);        /* the largest plane of the class: (h + 10) w int16 */
+    static constexpr int PU_BYTES = SM_PLANES * PLANE + 4;                      /* the planes, later the window of the points */
+    static constexpr int TOTAL = SM_FIXED + NPU * PU_BYTES + 32;
+};
+#define STAR_TINY_LDS_MAX (SM_FIXED + 8 * (SM_PLANES * 224 + 4) + 32)
+static_assert(StarTinyLds<3>::TOTAL <= STAR_TINY_LDS_MAX && StarTinyLds<4>::TOTAL <= STAR_TINY_LDS_MAX && StarTinyLds<5>::TOTAL <= STAR_TINY_LDS_MAX, "one LDS size for the three classes");
+
+template<typename P, int M, int LG>
+__device__ __forceinline__ void star_tiny_pass(const SearchArgs &a, int jmine, bool mine)
+{
+    typedef StarTinyLds<LG> L;
+    constexpr int LPP = L::LPP, NPU = L::NPU, LT = LG - 2, BPS = (int)sizeof(P);
+    const int depth = sizeof(P) == 1 ? 8 : a.depth;
+    const int lane = (int)threadIdx.x, grp = lane >> LG, l = lane & (LPP - 1);
+    unsigned long long m = __ballot(mine);
+    while (m)
+    {
+        /* group g takes the g-th PU that is left; a group without one goes along with the first (and writes nothing) */
+        int src_lane = (int)__builtin_ctzll(m);
+        bool act = false;
+#pragma unroll
+        for (int g = 0; g < NPU; g++)
+            if (m)
+            {
+                if (g == grp) { src_lane = (int)__builtin_ctzll(m); act = true; }
+                m &= m - 1;
+            }
+        const int j = __shfl(jmine, src_lane);
+        wave_sync();
+        const int *job = (const int*)(a.jobs + j);
+        int d[10];
+#pragma unroll
+        for (int i = 0; i < 10; i++) d[i] = job[i];
+        const int pux = as_i16(d[0]), puy = d[0] >> 16, w = d[1] & 0xff, h = (d[1] >> 8) & 0xff, numc = (d[1] >> 16) & 0xff;
+        const int ltw = w == 16 ? 2 : (w == 8 ? 1 : 0), tw = 1 << ltw, prow = h + 10, nitems = (h + 8) << ltw;
+        const int mnx = as_i16(d[2]), mny = d[2] >> 16, mxx = as_i16(d[3]), mxy = d[3] >> 16;
+        const int mvpx = as_i16(d[4]), mvpy = d[4] >> 16;
+        const P AS1 *fenc0, *ref0;
+        int fstride, rstride;
+        small_planes<P>(a, d[1], fenc0, fstride, ref0, rstride);
+        const int roff = puy * rstride + pux;
+        const uint16_t AS1 *ctab = (const uint16_t AS1*)a.ctab;
+
+        /* ---- start-up candidates, motion.cpp:575-621 (values every lane of the group holds) ---- */
+        const int qmnx = as_i16(mnx << 2), qmny = as_i16(mny << 2), qmxx = as_i16(mxx << 2), qmxy = as_i16(mxy << 2);
+#define SM_CLIPX(v) ((v) > qmxx ? qmxx : ((v) < qmnx ? qmnx : (v)))
+#define SM_CLIPY(v) ((v) > qmxy ? qmxy : ((v) < qmny ? qmny : (v)))
+        const int pmx = SM_CLIPX(mvpx), pmy = SM_CLIPY(mvpy);
+        int bmx = as_i16((pmx + 2) >> 2), bmy = as_i16((pmy + 2) >> 2);
+        const bool fpOn = ((pmx | pmy) & 3) != 0, zeroOn = (pmx | pmy) != 0;
+        int ccx[4], ccy[4];
+        bool cOn[4];
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+        {
+            ccx[i] = SM_CLIPX(as_i16(d[5 + i])); ccy[i] = SM_CLIPY(d[5 + i] >> 16);
+            cOn[i] = i < numc && (ccx[i] | ccy[i]) != 0 && !(ccx[i] == pmx && ccy[i] == pmy);
+        }
+#undef SM_CLIPX
+#undef SM_CLIPY
+        /* lane l < 7 of a group looks after candidate slot l: where it is measured (quarter-pel) and whether it is in use */
+        int sx = pmx, sy = pmy;
+        bool on = l == 0;
+        if (l == 1) { sx = as_i16(bmx << 2); sy = as_i16(bmy << 2); on = fpOn; }
+        if (l == 2) { sx = 0; sy = 0; on = zeroOn; }
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+            if (l == 3 + i) { sx = ccx[i]; sy = ccy[i]; on = cOn[i]; }
+        on = l < SM_SLOTS && on;
+        /* slots 1 and 2 are whole-sample positions and measured as plain SADs; the others get a plane each */
+        const int planebits = (int)((__ballot(on) >> (lane & ~(LPP - 1))) & 0x79);
+        const int nplanes = __builtin_popcount(planebits);
+        int kmax = 1;
+        while (__ballot(nplanes > kmax)) kmax++;
+        int mvc = 0;
+        if (on && l != 0) mvc = ((int)ctab[sx - mvpx] + (int)ctab[sy - mvpy]) & 0xffff;
+        const int slot_off = roff + __mul24((sy >> 2) - 3, rstride) + (sx >> 2) - 3, slot_ph = sx & 3;
+
+        /* the lane's tile of the source block, for the plain SADs: a lane per (point, tile) */
+        const int tile = l & ((1 << LT) - 1), tlx = (tile & (tw - 1)) * 4, tly = (tile >> ltw) * 4;
+        typename Px<P>::quad fq[4];
+        {
+            const P AS1 *src = fenc0 + (long)(puy + tly) * fstride + pux + tlx;
+#pragma unroll
+            for (int y = 0; y < 4; y++) fq[y] = Px<P>::load_g(src + (long)y * fstride);
+        }
+        /* slots 1 and 2: point 0 = the rounded predictor, point 1 = MV 0 */
+        int vdir = 0;
+        {
+            const int pnt = l >> LT;
+            if (pnt < 2)
+            {
+                const P AS1 *rp = ref0 + roff + (long)__mul24((pnt ? 0 : bmy) + tly, rstride) + (pnt ? 0 : bmx) + tlx;
+#pragma unroll
+                for (int yy = 0; yy < 4; yy++) vdir = Px<P>::sad(fq[yy], Px<P>::load_g(rp + (long)yy * rstride), vdir);
+            }
+            vdir = seg_sum(vdir, LT);
+        }
+        /* horizontal pass: the lanes of a PU fill the planes of its own slots, kmax per PU (a PU with fewer repeats its last) */
+        const int pbase = SM_FIXED + grp * L::PU_BYTES;
+        {
+            int rem = planebits, sk = 0;
+            for (int k = 0; k < kmax; k++)
+            {
+                if (rem) { sk = __builtin_ctz(rem); rem &= rem - 1; }
+                const int so = grp_lane<LG>(slot_off, sk), ph = grp_lane<LG>(slot_ph, sk);
+                const int kk = k < nplanes ? k : nplanes - 1;
+                const int *tp = (const int*)(x265amd_smem + SM_TAPS) + ph * 12;
+                int16_t *plane = (int16_t*)(x265amd_smem + pbase + kk * L::PLANE);
+#pragma unroll
+                for (int it = 0; it < (LG == 5 ? 2 : 3); it++)
+                {
+                    const int item = it * LPP + l;
+                    if (item < nitems)
+                    {
+                        const int r = item >> ltw, q = item & (tw - 1);
+                        hps_quad(ref0 + (so + __mul24(r, rstride) + 4 * q), tp, plane + (4 * q) * prow + r, prow, depth);
+                    }
+                }
+            }
+        }
+        wave_sync();
+        /* vertical pass + SAD: the k-th plane of every PU per pass */
+        ColSrc ct;
+        {
+            const int t = l >> 2;
+            ct.ty = t >> ltw; ct.col = (t & (tw - 1)) * 4 + (l & 3);
+            const P AS1 *src = fenc0 + (long)(puy + ct.ty * 4) * fstride + pux + ct.col;
+            uint32_t f[4];
+#pragma unroll
+            for (int y = 0; y < 4; y++) f[y] = (uint32_t)src[(long)y * fstride];
+            ct.f01 = f[0] | (f[1] << 16); ct.f23 = f[2] | (f[3] << 16);
+        }
+        int mycost = 0;
+        {
+            int rem = planebits, sk = 0;
+            for (int k = 0; k < kmax; k++)
+            {
+                if (rem) { sk = __builtin_ctz(rem); rem &= rem - 1; }
+                const int ysk = grp_lane<LG>(sy, sk);
+                int o[4];
+                column_rows<4>(pbase + (k < nplanes ? k : nplanes - 1) * L::PLANE, prow, 0, ysk & 3, ct, depth, o);
+                int v = small_rows_cost(o[0], o[1], o[2], o[3], false, ct, l & 3, depth);
+                v = seg_sum(v, LG);
+                if (l == sk) mycost = v + mvc;
+            }
+        }
+        /* the reference's sequence of tests on the measured costs (motion.cpp:579-621) */
+        int bprecost = grp_lane<LG>(mycost, 0), bcost = bprecost;
+        unsigned nsad = 0, nsub = 1;
+        {
+            const int cFp = grp_lane<LG>(vdir, 0) + grp_lane<LG>(mvc, 1);
+            const int cZero = grp_lane<LG>(vdir, 1 << LT) + grp_lane<LG>(mvc, 2);
+            if (fpOn) { bcost = cFp; nsad++; }
+            if (zeroOn)
+            {
+                nsad++;
+                if (cZero < bcost) { bcost = cZero; bmx = 0; bmy = 0; }
+            }
+        }
+        int bpx = pmx, bpy = pmy;
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+        {
+            const int c = grp_lane<LG>(mycost, 3 + i);
+            if (cOn[i] && !(ccx[i] == bpx && ccy[i] == bpy))
+            {
+                nsub++;
+                if (c < bprecost) { bprecost = c; bpx = ccx[i]; bpy = ccy[i]; }
+            }
+        }
+        /* ---- the points of the method's first rounds around (bmx, bmy), from the (w + 8) x (h + 8) samples they can
+         * touch, staged into the LDS of the start-up planes (dead by now). A lane per (point, tile), four points per pass ---- */
+        int rkey0 = 0x7fffffff, rkey1 = 0x7fffffff, rkey2 = 0x7fffffff;
+        unsigned npts = 0;
+        const int WQ = ((w + 12) * BPS) >> 2, WP = WQ * 4, nwin = (h + 8) * WQ;     /* window row pitch in dwords and bytes */
+        int inv = w == 4 ? 16384 : (w == 8 ? 13108 : 9363);                          /* i / WQ = i * inv >> 16 for i < nwin */
+        if (BPS == 2) inv = (inv + 1) >> 1;
+        wave_sync();
+        {
+            typedef uint32_t __attribute__((aligned(1))) u32u;      /* the window starts at any sample */
+            const char AS1 *w0 = (const char AS1*)(ref0 + roff + (long)__mul24(bmy - 4, rstride) + bmx - 4);
+            for (int i = l; __ballot(i < nwin) != 0; i += LPP)
+                if (i < nwin)
+                {
+                    const int r = (i * inv) >> 16, q = i - r * WQ;
+                    *(uint32_t*)(x265amd_smem + pbase + r * WP + 4 * q) = *(const u32u AS1*)(w0 + (long)r * rstride * BPS + 4 * q);
+                }
+        }
+        wave_sync();
+#pragma unroll 1
+        for (int pass = 0; pass < (PatPoints<M>::N + 3) / 4; pass++)
+        {
+            const int p = pass * 4 + (l >> LT);
+            int dx, dy;
+            pat_point<M>(p < PatPoints<M>::N ? p : 0, dx, dy);
+            const int x = as_i16(bmx + dx), y = as_i16(bmy + dy);
+            /* STAR: the reference tests only the bounds a point can cross; the hexagon, square and diamond points are
+             * measured unchecked */
+            const bool ok = p < PatPoints<M>::N &&
+                            (M != X265AMD_STAR || ((dy >= 0 || y >= mny) && (dy <= 0 || y <= mxy) && (dx >= 0 || x >= mnx) && (dx <= 0 || x <= mxx)));
+            int v = 0, cost = 0;
+            if (ok)
+            {
+                const int bo = pbase + (4 + dy + tly) * WP + (4 + dx + tlx) * BPS;
+#pragma unroll
+                for (int yy = 0; yy < 4; yy++) v = Px<P>::sad(fq[yy], Px<P>::load_lds(bo + yy * WP), v);
+                cost = ((int)ctab[as_i16(x << 2) - mvpx] + (int)ctab[as_i16(y << 2) - mvpy]) & 0xffff;
+            }
+            v = seg_sum(v, LT);         /* the tiles of a point are adjacent lanes */
+            const int key = ok && tile == 0 ? ((v + cost) << 6) | p : 0x7fffffff;
+            if constexpr (M == X265AMD_HEX)
+            {
+                /* rkey0: the ring (points 0 .. 5), rkey1: the square */
+                const int kr = grp_min<LG>(p < 6 ? key : 0x7fffffff), ks = grp_min<LG>(p >= 6 ? key : 0x7fffffff);
+                rkey0 = kr < rkey0 ? kr : rkey0; rkey1 = ks < rkey1 ? ks : rkey1;
+            }
+            else
+            {
+                const int km = grp_min<LG>(key);
+                if (pass == 0) rkey0 = km;
+                else if (pass < 3) rkey1 = km < rkey1 ? km : rkey1;
+                else rkey2 = km < rkey2 ? km : rkey2;
+            }
+            npts += (unsigned)grp_count_any<LG>(ok && tile == 0);
+        }
+        if (act && l == 0)
+        {
+            int *res = (int*)(a.results + j);
+            bool over;
+            StarFold F;
+            if constexpr (M != X265AMD_STAR)
+            {
+                int dir;
+                unsigned counted;
+                over = pat_fold<M>(rkey0, rkey1, bmx, bmy, bcost, dir, counted);
+                nsad += counted;
+                F.start(bmx, bmy, bcost);
+                F.pt = dir;
+            }
+            else
+            {
+                /* the bookkeeping of StarPatternSearch over these rounds (motion.cpp:323-452) */
+                F.start(bmx, bmy, bcost);
+                F.round(rkey0); F.round(rkey1); F.round(rkey2);
+                nsad += npts;
+                over = F.rounds >= 3;
+            }
+            a.mark[j] = !over;
+            if (!over)
+            {
+                /* the search goes on: star_resume_kernel's */
+                F.store(a.state + 8 * (long)j, bprecost, bpx, bpy, nsad, nsub);
+                res[2] = (int)SMALL_RESUME;
+            }
+            else
+            {
+                /* motion.cpp:1063-1069 */
+                int qx, qy;
+                if (bprecost < bcost) { qx = bpx; qy = bpy; bcost = bprecost; }
+                else { qx = as_i16(bmx << 2); qy = as_i16(bmy << 2); }
+                res[0] = (qx & 0xffff) | (qy << 16);
+                res[1] = bcost;
+                res[2] = (int)nsad;
+                res[3] = (int)nsub;
+            }
+        }
+    }
+}
+
+template<typename P, int M>
+__global__ __launch_bounds__(64) void star_tiny_kernel(SearchArgs a)
+{
+    const int lane = (int)threadIdx.x;
+    small_load_taps<P>(lane, sizeof(P) == 1 ? 8 : a.depth);
+    for (int base = (int)blockIdx.x * 64; base < a.njobs; base += (int)gridDim.x * 64)
+    {
+        const int j = base + lane;
+        int cls = 0;
+        if (j < a.njobs)
+        {
+            const int d1 = ((const int*)(a.jobs + j))[1], w = d1 & 0xff, h = (d1 >> 8) & 0xff;
+            if (!(w == h && (w == a.staged || w == a.staged2))) cls = tiny_class(w, h);
+        }
+        if (__ballot(cls != 0) == 0) continue;
+        star_tiny_pass<P, M, 3>(a, j, cls == 3);
+        star_tiny_pass<P, M, 4>(a, j, cls == 4);
+        star_tiny_pass<P, M, 5>(a, j, cls == 5);
+    }
+}
+
 /* four samples at byte offset base + coff of the LDS array, base a multiple of four and coff a compile-time constant
  * once the caller's loops are unrolled: the realignment disappears where coff is a multiple of four itself */
 template<typename P> __device__ __forceinline__ typename Px<P>::quad lds_quad_const(int base, int coff);
@@ -1926,7 +2241,8 @@ __global__ __launch_bounds__(StarBigGeo<S>::THREADS) __attribute__((amdgpu_waves
     if ((d[1] & 0xffff) != G::SIZE_CODE)
     {
         /* the launch for the list's largest size hands every PU that no fixed-shape launch takes to the one-wave search */
-        if (S == a.staged && (d[1] & 0xffff) != (a.staged2 | (a.staged2 << 8)) && tid == 0) { a.results[j].sad_calls = SMALL_REDO; a.mark[j] = 1; }
+        if (S == a.staged && (d[1] & 0xffff) != (a.staged2 | (a.staged2 << 8)) && tid == 0 &&
+            !(a.tiny && tiny_class(d[1] & 0xff, (d[1] >> 8) & 0xff))) { a.results[j].sad_calls = SMALL_REDO; a.mark[j] = 1; }
         return;
     }
 #pragma unroll
