@@ -119,6 +119,37 @@ def test_small_pu_batches_vs_oracle(request, oracle, mname, size, depth):
 
 
 @pytest.mark.parametrize("depth", [8, 10])
+@pytest.mark.parametrize("mname", ["star", "hex", "dia", "umh"])
+def test_small_other_partitions_packed_vs_oracle(request, oracle, mname, depth):
+    """The small other partitions (8x4, 4x8 | 16x4, 4x16, 8x8 beside 16x16 | 16x8, 8x16) have kernels that put 8, 4 or 2
+    PUs into one wave (star_tiny_kernel for the integer stage of star / hex / dia launches, refine_tiny_kernel for the
+    sub-pel rounds of every method): lists long enough for many waves with the shapes of a class mixed inside a wave, with
+    waves whose last groups are empty, with squares and larger partitions in between, and on noise, where most PUs are
+    handed on to the resumed search (motion.cpp:562-621, :307-547, :1071-1141)."""
+    e = _engine(request, depth)
+    method = METHODS[mname]
+    W, H = 320, 192
+    m = margin_for(method)
+    small = [(8, 4), (4, 8), (16, 4), (4, 16), (8, 8), (16, 8), (8, 16)]
+    for kind, parts, n, subme in (("texture", small, 333, 5), ("noise", small + [(16, 16), (12, 16)], 257, 2),
+                                  ("texture", [(8, 4)] * 7 + [(16, 16)], 150, 7), ("static", small, 130, 1),
+                                  ("texture", small + [(32, 32), (32, 16), (64, 64)], 201, 3)):
+        fenc, ref, org, stride = clip_planes(W, H, depth, kind, margin=m)
+        pf = e.upload_plane(fenc, W, H, m, m, stride)
+        pr = e.upload_plane(ref, W, H, m, m, stride)
+        rng = np.random.default_rng(4000 + method * 10 + subme + n)
+        jobs = random_jobs(rng, n, W, H, method, parts=parts)
+        qp = int(rng.integers(10, 45)) + 6 * (depth - 8)
+        r = e.search_batch(pf, pr, jobs, qp, method, subme)
+        mv, cost, sc, qc = oracle_search(oracle, depth, fenc, [ref], org, stride, jobs, qp, method, subme)
+        assert np.array_equal(r["mv"], mv), (kind, n)
+        assert np.array_equal(r["cost"], cost), (kind, n)
+        assert np.array_equal(r["sad_calls"], sc) and np.array_equal(r["subpel_calls"], qc), (kind, n)
+        e.free_plane(pf)
+        e.free_plane(pr)
+
+
+@pytest.mark.parametrize("depth", [8, 10])
 def test_pairs_in_one_launch_vs_oracle(request, oracle, depth):
     """x265amd_search_batch_pairs: jobs of three (source, reference) pairs of different sizes and strides in one launch,
     interleaved job by job (so the four 8x8 PUs one refinement wave takes belong to different pictures), every method,
