@@ -1041,15 +1041,26 @@ static void launch_refine(const SearchArgs &b, hipStream_t st, int list_grid)
     }
 }
 
-/* the sub-pel refinement of the small other partitions, several PUs per wave: a wave per 64 PUs of the job list or of
- * the redo list */
+/* PUs of the job list a wave of the small partitions' kernels looks at together: as many as leave several thousand waves
+ * (its groups take 2 to 8 PUs at a time) */
+static int tiny_chunk(int njobs)
+{
+    static const int fixed = getenv("X265AMD_TINY_CHUNK") ? atoi(getenv("X265AMD_TINY_CHUNK")) : 0;     /* measurements only */
+    if (fixed >= 8 && fixed <= 64 && !(fixed & (fixed - 1))) return fixed;
+    int chunk = 64;
+    while (chunk > 8 && njobs / chunk < 16384) chunk >>= 1;
+    return chunk;
+}
+
+/* the sub-pel refinement of the small other partitions, several PUs per wave: the job list or the redo list */
 template<typename P>
 static void launch_tiny(const SearchArgs &b, hipStream_t st, int list_grid)
 {
     static const bool no_tiny = getenv("X265AMD_NO_REFINE_TINY") != 0;     /* measurements only: then they are nobody's */
-    int tgrid = list_grid ? list_grid : (b.njobs + 63) / 64;
+    const int chunk = list_grid ? 8 : tiny_chunk(b.njobs);
+    int tgrid = list_grid ? list_grid : (b.njobs + chunk - 1) / chunk;
     if (tgrid > 65536) tgrid = 65536;
-    if (!no_tiny) hipLaunchKernelGGL((refine_tiny_kernel<P>), dim3(tgrid), dim3(64), TINY_LDS_MAX, st, b);
+    if (!no_tiny) hipLaunchKernelGGL((refine_tiny_kernel<P>), dim3(tgrid), dim3(64), TINY_LDS_MAX, st, b, chunk);
 }
 
 /* the sub-pel refinement of the PUs no fixed-shape kernel takes (other partitions, squares of other sizes): every PU of
@@ -1201,11 +1212,12 @@ static int launch_search(x265amd_ctx *c, const SearchArgs &a, int is_lowres, boo
         if ((rc = search_star<P>(c, sl, c->stream))) return rc;
         if (sl.b.tiny)
         {
-            int tgrid = (a.njobs + 63) / 64;
+            const int chunk = tiny_chunk(a.njobs);
+            int tgrid = (a.njobs + chunk - 1) / chunk;
             if (tgrid > 65536) tgrid = 65536;
-            if (a.method == X265AMD_HEX) hipLaunchKernelGGL((star_tiny_kernel<P, X265AMD_HEX>), dim3(tgrid), dim3(64), STAR_TINY_LDS_MAX, c->stream, sl.b);
-            else if (a.method == X265AMD_DIA) hipLaunchKernelGGL((star_tiny_kernel<P, X265AMD_DIA>), dim3(tgrid), dim3(64), STAR_TINY_LDS_MAX, c->stream, sl.b);
-            else hipLaunchKernelGGL((star_tiny_kernel<P, X265AMD_STAR>), dim3(tgrid), dim3(64), STAR_TINY_LDS_MAX, c->stream, sl.b);
+            if (a.method == X265AMD_HEX) hipLaunchKernelGGL((star_tiny_kernel<P, X265AMD_HEX>), dim3(tgrid), dim3(64), STAR_TINY_LDS_MAX, c->stream, sl.b, chunk);
+            else if (a.method == X265AMD_DIA) hipLaunchKernelGGL((star_tiny_kernel<P, X265AMD_DIA>), dim3(tgrid), dim3(64), STAR_TINY_LDS_MAX, c->stream, sl.b, chunk);
+            else hipLaunchKernelGGL((star_tiny_kernel<P, X265AMD_STAR>), dim3(tgrid), dim3(64), STAR_TINY_LDS_MAX, c->stream, sl.b, chunk);
         }
         /* The PUs handed on are few as a rule and each a long chain of dependent steps in one wave: their
          * searches and refinement run on the context's second stream while this one refines all the others. */

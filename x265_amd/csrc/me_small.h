@@ -1272,17 +1272,18 @@ __device__ __forceinline__ void refine_tiny_pass(const SearchArgs &a, int jmine,
 }
 
 template<typename P>
-__global__ __launch_bounds__(64) void refine_tiny_kernel(SearchArgs a)
+__global__ __launch_bounds__(64) void refine_tiny_kernel(SearchArgs a, int chunk)
 {
     const int lane = (int)threadIdx.x;
     small_load_taps<P>(lane, sizeof(P) == 1 ? 8 : a.depth);
-    /* a wave looks at 64 PUs of the job list at once (a.list: 64 entries of the launch's list of PUs the STAR kernels left
-     * to others), a lane each, and takes those of each class in turn */
+    /* a wave looks at `chunk` PUs of the job list at once (a.list: entries of the launch's list of PUs the STAR kernels
+     * left to others), a lane each, and takes those of each class in turn; chunk: a power of two from 8 to 64, picked by
+     * the host so that a short list still spreads over the chip */
     const int n = a.list ? uni(a.redo[0]) : a.njobs;
-    for (int base = (int)blockIdx.x * 64; base < n; base += (int)gridDim.x * 64)
+    for (int base = (int)blockIdx.x * chunk; base < n; base += (int)gridDim.x * chunk)
     {
         int j = 0, cls = 0;
-        if (base + lane < n)
+        if (lane < chunk && base + lane < n)
         {
             j = a.list ? a.redo[REDO_LIST + base + lane] : base + lane;
             if (j < a.njobs)
@@ -2127,15 +2128,15 @@ __device__ __forceinline__ void star_tiny_pass(const SearchArgs &a, int jmine, b
 }
 
 template<typename P, int M>
-__global__ __launch_bounds__(64) void star_tiny_kernel(SearchArgs a)
+__global__ __launch_bounds__(64) void star_tiny_kernel(SearchArgs a, int chunk)
 {
     const int lane = (int)threadIdx.x;
     small_load_taps<P>(lane, sizeof(P) == 1 ? 8 : a.depth);
-    for (int base = (int)blockIdx.x * 64; base < a.njobs; base += (int)gridDim.x * 64)
+    for (int base = (int)blockIdx.x * chunk; base < a.njobs; base += (int)gridDim.x * chunk)
     {
         const int j = base + lane;
         int cls = 0;
-        if (j < a.njobs)
+        if (lane < chunk && j < a.njobs)
         {
             const int d1 = ((const int*)(a.jobs + j))[1], w = d1 & 0xff, h = (d1 >> 8) & 0xff;
             if (!(w == h && (w == a.staged || w == a.staged2))) cls = tiny_class(w, h);
