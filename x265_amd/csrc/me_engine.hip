@@ -1215,9 +1215,9 @@ static int launch_search(x265amd_ctx *c, const SearchArgs &a, int is_lowres, boo
             const int chunk = tiny_chunk(a.njobs);
             int tgrid = (a.njobs + chunk - 1) / chunk;
             if (tgrid > 65536) tgrid = 65536;
-            if (a.method == X265AMD_HEX) hipLaunchKernelGGL((star_tiny_kernel<P, X265AMD_HEX>), dim3(tgrid), dim3(64), STAR_TINY_LDS_MAX, c->stream, sl.b, chunk);
-            else if (a.method == X265AMD_DIA) hipLaunchKernelGGL((star_tiny_kernel<P, X265AMD_DIA>), dim3(tgrid), dim3(64), STAR_TINY_LDS_MAX, c->stream, sl.b, chunk);
-            else hipLaunchKernelGGL((star_tiny_kernel<P, X265AMD_STAR>), dim3(tgrid), dim3(64), STAR_TINY_LDS_MAX, c->stream, sl.b, chunk);
+            if (a.method == X265AMD_HEX) hipLaunchKernelGGL((star_tiny_kernel<P, X265AMD_HEX>), dim3(tgrid), dim3(64), StarTinyMax<(int)sizeof(P)>::TOTAL, c->stream, sl.b, chunk);
+            else if (a.method == X265AMD_DIA) hipLaunchKernelGGL((star_tiny_kernel<P, X265AMD_DIA>), dim3(tgrid), dim3(64), StarTinyMax<(int)sizeof(P)>::TOTAL, c->stream, sl.b, chunk);
+            else hipLaunchKernelGGL((star_tiny_kernel<P, X265AMD_STAR>), dim3(tgrid), dim3(64), StarTinyMax<(int)sizeof(P)>::TOTAL, c->stream, sl.b, chunk);
         }
         /* The PUs handed on are few as a rule and each a long chain of dependent steps in one wave: their
          * searches and refinement run on the context's second stream while this one refines all the others. */

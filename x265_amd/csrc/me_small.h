@@ -1854,21 +1854,27 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(S == 16 ? OC
  * method's first rounds from a window in LDS, the record or the hand-over state. A wave looks at 64 PUs of the job list
  * and takes those of each class in turn (as refine_tiny_kernel does); width and height of a PU are values its lanes
  * hold, only the lanes per PU are fixed per class. */
-template<int LG> struct StarTinyLds
+template<int LG, int BPS> struct StarTinyLds
 {
     static constexpr int LPP = 1 << LG, NPU = 64 / LPP;
     static constexpr int PLANE = LG == 3 ? 224 : (LG == 4 ? 448 : 576);        /* the largest plane of the class: (h + 10) w int16 */
-    static constexpr int PU_BYTES = SM_PLANES * PLANE + 4;                      /* the planes, later the window of the points */
+    static constexpr int WINDOW = (LG == 3 ? 256 : (LG == 4 ? 384 : 480)) * BPS; /* its largest window: (h + 8) (w + 12) samples */
+    /* one plane at a time (filled, then measured), later the window of the points */
+    static constexpr int PU_BYTES = (PLANE > WINDOW ? PLANE : WINDOW) + 4;
     static constexpr int TOTAL = SM_FIXED + NPU * PU_BYTES + 32;
 };
-#define STAR_TINY_LDS_MAX (SM_FIXED + 8 * (SM_PLANES * 224 + 4) + 32)
-static_assert(StarTinyLds<3>::TOTAL <= STAR_TINY_LDS_MAX && StarTinyLds<4>::TOTAL <= STAR_TINY_LDS_MAX && StarTinyLds<5>::TOTAL <= STAR_TINY_LDS_MAX, "one LDS size for the three classes");
+template<int BPS> struct StarTinyMax
+{
+    static constexpr int A = StarTinyLds<3, BPS>::TOTAL, B = StarTinyLds<4, BPS>::TOTAL, C = StarTinyLds<5, BPS>::TOTAL;
+    static constexpr int TOTAL = A > B ? (A > C ? A : C) : (B > C ? B : C);     /* one LDS size for the three classes */
+};
 
 template<typename P, int M, int LG>
 __device__ __forceinline__ void star_tiny_pass(const SearchArgs &a, int jmine, bool mine)
 {
-    typedef StarTinyLds<LG> L;
-    constexpr int LPP = L::LPP, NPU = L::NPU, LT = LG - 2, BPS = (int)sizeof(P);
+    constexpr int BPS = (int)sizeof(P);
+    typedef StarTinyLds<LG, BPS> L;
+    constexpr int LPP = L::LPP, NPU = L::NPU, LT = LG - 2;
     const int depth = sizeof(P) == 1 ? 8 : a.depth;
     const int lane = (int)threadIdx.x, grp = lane >> LG, l = lane & (LPP - 1);
     unsigned long long m = __ballot(mine);
@@ -1955,31 +1961,7 @@ __device__ __forceinline__ void star_tiny_pass(const SearchArgs &a, int jmine, b
             }
             vdir = seg_sum(vdir, LT);
         }
-        /* horizontal pass: the lanes of a PU fill the planes of its own slots, kmax per PU (a PU with fewer repeats its last) */
         const int pbase = SM_FIXED + grp * L::PU_BYTES;
-        {
-            int rem = planebits, sk = 0;
-            for (int k = 0; k < kmax; k++)
-            {
-                if (rem) { sk = __builtin_ctz(rem); rem &= rem - 1; }
-                const int so = grp_lane<LG>(slot_off, sk), ph = grp_lane<LG>(slot_ph, sk);
-                const int kk = k < nplanes ? k : nplanes - 1;
-                const int *tp = (const int*)(x265amd_smem + SM_TAPS) + ph * 12;
-                int16_t *plane = (int16_t*)(x265amd_smem + pbase + kk * L::PLANE);
-#pragma unroll
-                for (int it = 0; it < (LG == 5 ? 2 : 3); it++)
-                {
-                    const int item = it * LPP + l;
-                    if (item < nitems)
-                    {
-                        const int r = item >> ltw, q = item & (tw - 1);
-                        hps_quad(ref0 + (so + __mul24(r, rstride) + 4 * q), tp, plane + (4 * q) * prow + r, prow, depth);
-                    }
-                }
-            }
-        }
-        wave_sync();
-        /* vertical pass + SAD: the k-th plane of every PU per pass */
         ColSrc ct;
         {
             const int t = l >> 2;
@@ -1990,15 +1972,31 @@ __device__ __forceinline__ void star_tiny_pass(const SearchArgs &a, int jmine, b
             for (int y = 0; y < 4; y++) f[y] = (uint32_t)src[(long)y * fstride];
             ct.f01 = f[0] | (f[1] << 16); ct.f23 = f[2] | (f[3] << 16);
         }
+        /* the k-th slot of every PU per pass (a PU with fewer repeats its last): horizontal pass by the lanes of the PU
+         * into its plane, then vertical pass + SAD, a lane per (tile, column) */
         int mycost = 0;
         {
             int rem = planebits, sk = 0;
             for (int k = 0; k < kmax; k++)
             {
                 if (rem) { sk = __builtin_ctz(rem); rem &= rem - 1; }
-                const int ysk = grp_lane<LG>(sy, sk);
+                const int so = grp_lane<LG>(slot_off, sk), ph = grp_lane<LG>(slot_ph, sk), ysk = grp_lane<LG>(sy, sk);
+                const int *tp = (const int*)(x265amd_smem + SM_TAPS) + ph * 12;
+                int16_t *plane = (int16_t*)(x265amd_smem + pbase);
+                wave_sync();                            /* the plane before has been read */
+#pragma unroll
+                for (int it = 0; it < (LG == 5 ? 2 : 3); it++)
+                {
+                    const int item = it * LPP + l;
+                    if (item < nitems)
+                    {
+                        const int r = item >> ltw, q = item & (tw - 1);
+                        hps_quad(ref0 + (so + __mul24(r, rstride) + 4 * q), tp, plane + (4 * q) * prow + r, prow, depth);
+                    }
+                }
+                wave_sync();
                 int o[4];
-                column_rows<4>(pbase + (k < nplanes ? k : nplanes - 1) * L::PLANE, prow, 0, ysk & 3, ct, depth, o);
+                column_rows<4>(pbase, prow, 0, ysk & 3, ct, depth, o);
                 int v = small_rows_cost(o[0], o[1], o[2], o[3], false, ct, l & 3, depth);
                 v = seg_sum(v, LG);
                 if (l == sk) mycost = v + mvc;
@@ -2029,7 +2027,7 @@ __device__ __forceinline__ void star_tiny_pass(const SearchArgs &a, int jmine, b
             }
         }
         /* ---- the points of the method's first rounds around (bmx, bmy), from the (w + 8) x (h + 8) samples they can
-         * touch, staged into the LDS of the start-up planes (dead by now). A lane per (point, tile), four points per pass ---- */
+         * touch, staged into the LDS of the start-up plane (dead by now). A lane per (point, tile), four points per pass ---- */
         int rkey0 = 0x7fffffff, rkey1 = 0x7fffffff, rkey2 = 0x7fffffff;
         unsigned npts = 0;
         const int WQ = ((w + 12) * BPS) >> 2, WP = WQ * 4, nwin = (h + 8) * WQ;     /* window row pitch in dwords and bytes */
