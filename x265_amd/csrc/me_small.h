@@ -2125,8 +2125,11 @@ __device__ __forceinline__ void star_tiny_pass(const SearchArgs &a, int jmine, b
     }
 }
 
+#ifndef OCC_ST
+#define OCC_ST 4
+#endif
 template<typename P, int M>
-__global__ __launch_bounds__(64) void star_tiny_kernel(SearchArgs a, int chunk)
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(OCC_ST))) void star_tiny_kernel(SearchArgs a, int chunk)
 {
     const int lane = (int)threadIdx.x;
     small_load_taps<P>(lane, sizeof(P) == 1 ? 8 : a.depth);
