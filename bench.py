@@ -839,6 +839,15 @@ def main():
                                                       "Gpixel_SAD_per_s": v["pixel_sads"] / v["ms"] / 1e6} for k_, v in cls.items()},
                                    "parity": "360 PUs of the first frame pair (24 / 48 / 96 / 192 of 64 / 32 / 16 / 8 samples, seeded) "
                                              "compared with the oracle: MVs, costs, visit counts"}
+                progress("other paths: the 2NxN / Nx2N partitions of the headline's clip")
+                rect_cls, (f0, f1, kj, kr) = measure.other_partitions_clip(es, dev, pairs=8)
+                pick = np.random.default_rng(9).choice(len(kj), 256, replace=False)
+                cur_, org_, st_ = pad_plane(f1, 128)
+                ref_, _, _ = pad_plane(f0, 128)
+                exp = orc.me_search_batch(orc.make_ctx(8, cur_, org_, st_, [ref_], org_, st_, False, 32, METHODS["star"], 5), kj[pick])
+                if not all(np.array_equal(exp[k_], kr[pick][k_]) for k_ in ("mv", "cost", "sad_calls", "subpel_calls")):
+                    print("PARITY FAILURE: 2NxN / Nx2N partitions: GPU results differ from the oracle", file=sys.stderr)
+                    sys.exit(2)
                 progress("other paths: motion compensation, bi-prediction")
                 mc = measure.mc_picture(es, dev)
                 bp = measure.bipred_picture(es, dev)
@@ -881,6 +890,17 @@ def main():
                     "me1080p_hex": dict(kinds["hex"], workload="the headline's PUs and textured clip searched with --me hex (the reference's default "
                                         "method, BASELINE configs[0]): first hexagon ring + closing square in the fixed-shape kernels, PUs whose ring "
                                         "moves (marked_frac) walk on one per wave; 8 frame pairs, classes one after the other on one stream"),
+                    "me1080p_rect": {"workload": "the 2NxN and Nx2N partitions of every CU of the headline's clip (1080p 8-bit, --me star "
+                                                 "--merange 57 --subme 5, 8 frame pairs): one launch per CU size with both shapes mixed; "
+                                                 "16x8 / 8x16 and 8x4 / 4x8 run two and eight PUs per wave (star_tiny_kernel, "
+                                                 "refine_tiny_kernel), the larger shapes a wave per PU",
+                                     "ms_per_8_frame_pairs": sum(v["ms"] for v in rect_cls.values()),
+                                     "pu_searches": sum(v["pus"] for v in rect_cls.values()),
+                                     "value": sum(v["pixel_sads"] for v in rect_cls.values()) / sum(v["ms"] for v in rect_cls.values()) / 1e6,
+                                     "unit": "Gpixel-SAD/s",
+                                     "per_class": {k_: {"pus": v["pus"], "ms": v["ms"], "ns_per_pu": v["ms"] * 1e6 / v["pus"],
+                                                        "Gpixel_SAD_per_s": v["pixel_sads"] / v["ms"] / 1e6} for k_, v in rect_cls.items()},
+                                     "parity": "256 PUs of the first frame pair (all shapes, seeded) compared with the oracle: MVs, costs, visit counts"},
                     "main10_4k": {"workload": "3840x2160 10-bit, --me star --merange 57 --subme 5, all 64/32/16/8 square PUs of one "
                                               "picture against one reference (BASELINE configs[3], per reference)",
                                   "ms_per_picture_reference": m10f["ms"], "pu_searches": m10f["pus"],

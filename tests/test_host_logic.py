@@ -296,3 +296,26 @@ def test_ctu_job_lists_for_the_exhaustive_scan():
     assert n2 == 2 * n
     eight = cj2[:64 * n2].reshape(n2, 64)
     assert (eight["reserved"][:n] == 0).all() and (eight["reserved"][n:] == 1).all()
+
+
+def test_partition_shape_job_lists():
+    """workload.shape_jobs: both PUs of every 2NxN / Nx2N split of a picture's CU grid, inside the picture, ranges around
+    the predictor of the lookahead CU under the PU's centre."""
+    import numpy as np
+    from x265_amd import workload
+    W, H, wcu, hcu = 416, 240, 26, 15
+    la = np.random.default_rng(2).integers(-20, 21, (wcu * hcu, 2)).astype(np.int16)
+    for cu in (64, 32, 16, 8):
+        ncu = (W // cu) * (H // cu)
+        for (w, h) in ((cu, cu // 2), (cu // 2, cu)):
+            jobs = workload.shape_jobs(W, H, w, h, la, wcu, hcu, 57, cu)
+            assert len(jobs) == 2 * ncu and (jobs["w"] == w).all() and (jobs["h"] == h).all()
+            assert (jobs["pu_x"] + w <= W).all() and (jobs["pu_y"] + h <= H).all()
+            # the two PUs of a CU tile it
+            first, second = jobs[:ncu], jobs[ncu:]
+            assert ((second["pu_x"] - first["pu_x"] == (0 if w == cu else w)) & (second["pu_y"] - first["pu_y"] == (0 if h == cu else h))).all()
+            fx, fy = jobs["qmvp"][:, 0] >> 2, jobs["qmvp"][:, 1] >> 2
+            assert (jobs["mvmin"][:, 0] <= fx).all() and (fx <= jobs["mvmax"][:, 0]).all()
+            assert (jobs["mvmin"][:, 1] <= fy).all() and (fy <= jobs["mvmax"][:, 1]).all()
+            assert (jobs["mvmax"][:, 0] - jobs["mvmin"][:, 0] <= 2 * 57).all()
+        assert len(workload.shape_jobs(W, H, cu, cu, la, wcu, hcu, 57, cu)) == ncu

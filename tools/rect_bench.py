@@ -16,34 +16,6 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 
-def shape_jobs(width, height, w, h, la, wcu, hcu, merange, cu):
-    """every PU of shape w x h of a CU grid of `cu` samples (all part indices of the partition mode the shape belongs to)"""
-    from x265_amd.engine import JOB_DTYPE
-    mv_full = la.astype(np.int32).reshape(hcu, wcu, 2) * 2
-    xs, ys = np.meshgrid(np.arange(0, width - cu + 1, cu), np.arange(0, height - cu + 1, cu))
-    xs, ys = xs.ravel(), ys.ravel()
-    offs = [(0, 0)] if (w, h) == (cu, cu) else ([(0, 0), (0, h)] if w == cu and 2 * h == cu else [(0, 0), (w, 0)] if h == cu and 2 * w == cu else [(0, 0)])
-    parts = []
-    for ox, oy in offs:
-        jobs = np.zeros(xs.size, JOB_DTYPE)
-        jobs["pu_x"], jobs["pu_y"], jobs["w"], jobs["h"] = xs + ox, ys + oy, w, h
-        cx = np.minimum((xs + ox + w // 2) // 16, wcu - 1)
-        cy = np.minimum((ys + oy + h // 2) // 16, hcu - 1)
-        mvp = mv_full[cy, cx]
-        jobs["qmvp"] = mvp
-        jobs["numc"] = 2
-        jobs["mvc"][:, 0] = mv_full[cy, np.maximum(cx - 1, 0)]
-        jobs["mvc"][:, 1] = mv_full[np.maximum(cy - 1, 0), cx]
-        fx, fy = mvp[:, 0] >> 2, mvp[:, 1] >> 2
-        jobs["mvmin"][:, 0] = np.maximum(fx - merange, -(xs + ox) - 100)
-        jobs["mvmin"][:, 1] = np.maximum(fy - merange, -(ys + oy) - 100)
-        jobs["mvmax"][:, 0] = np.minimum(fx + merange, width - (xs + ox) - w + 100)
-        jobs["mvmax"][:, 1] = np.minimum(fy + merange, height - (ys + oy) - h + 100)
-        jobs["merange"] = merange
-        parts.append(jobs)
-    return np.concatenate(parts)
-
-
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--width", type=int, default=1920)
@@ -57,7 +29,7 @@ def main():
     args = ap.parse_args()
     import torch
     from x265_amd.engine import Engine, METHODS, RESULT_DTYPE, HEX
-    from x265_amd import measure
+    from x265_amd import measure, workload
     from x265_amd.synth import make_clip, pad_plane, lowres_dims
     dev = torch.device("cuda", 0)
     e = Engine(0, 8)
@@ -78,7 +50,7 @@ def main():
         want = {tuple(int(v) for v in t.split("x")) for t in args.shapes.split(",")}
         shapes = [t for t in shapes if (t[0], t[1]) in want]
     for (w, h, cu) in shapes:
-        jobs = shape_jobs(W, H, w, h, la[0], wcu, hcu, args.merange, cu)
+        jobs = workload.shape_jobs(W, H, w, h, la[0], wcu, hcu, args.merange, cu)
         if args.pairs > 1:
             reps = []
             for i in range(args.pairs):

@@ -444,3 +444,51 @@ def pattern_search_clip(e, dev, kind, pairs=8, width=1920, height=1080, method="
     for p in planes:
         e.free_plane(p)
     return out, (clip[0], clip[1], np.concatenate([k[0] for k in keep]), np.concatenate([k[1] for k in keep]))
+
+
+def other_partitions_clip(e, dev, pairs=8, width=1920, height=1080, method="star", subme=5, merange=57, reps=3, seed=1234, qp=32):
+    """The 2NxN and Nx2N partitions of every CU size of `pairs` frame pairs of the headline's clip: per CU size one launch
+    over all pairs holding both shapes mixed (64x32 + 32x64 | 32x16 + 16x32 | 16x8 + 8x16 | 8x4 + 4x8), predictors from
+    the lookahead field of each pair. The two small classes run in the kernels that pack several PUs into a wave, the two
+    large ones a wave per PU. Returns per class PUs, ms and pixel-SADs and, for checking, the jobs and results of pair 0."""
+    import torch
+    from .engine import HEX
+    from .synth import lowres_dims
+    M = 128
+    clip = make_clip(width, height, pairs + 1, seed=seed)
+    planes = []
+    for f in clip:
+        buf, org, stride = pad_plane(f, M)
+        planes.append(e.upload_plane(buf, width, height, M, M, stride))
+    low = [e.lowres_init(p) for p in planes]
+    lw, lh, wcu, hcu = lowres_dims(width, height)
+    la_mvs, _, _ = e.lookahead_fields([(low[i + 1][0], low[i]) for i in range(pairs)], wcu, hcu, 12, HEX, 1, 16)
+    d_pairs = e.pairs_upload([(planes[i + 1], planes[i]) for i in range(pairs)])
+    out, keep = {}, []
+    for cu in (64, 32, 16, 8):
+        per_pair = []
+        for i in range(pairs):
+            # the CUs of a picture in raster order, both splits of a CU side by side as a caller deciding between them has them
+            a = workload.shape_jobs(width, height, cu, cu // 2, la_mvs[i], wcu, hcu, merange, cu)
+            b = workload.shape_jobs(width, height, cu // 2, cu, la_mvs[i], wcu, hcu, merange, cu)
+            n2 = len(a) // 2
+            mixed = np.stack([a[:n2], a[n2:], b[:n2], b[n2:]], axis=1).reshape(-1)
+            mixed["reserved"] = i
+            per_pair.append(mixed)
+        cj = np.concatenate(per_pair)
+        n = len(cj)
+        d_jobs = torch.from_numpy(cj.view(np.uint8).reshape(n, -1).copy()).to(dev)
+        d_res = torch.zeros((n, RESULT_DTYPE.itemsize), dtype=torch.uint8, device=dev)
+        torch.cuda.synchronize()
+        ms = _timed(torch, e, dev, lambda: e.search_batch_pairs_dev(d_pairs, pairs, d_jobs.data_ptr(), n, d_res.data_ptr(), qp, METHODS[method], subme,
+                                                                    max_pu_dim=cu), reps)
+        res = d_res.cpu().numpy().view(RESULT_DTYPE).reshape(-1)
+        out["%dx%d+%dx%d" % (cu, cu // 2, cu // 2, cu)] = {"pus": n, "ms": ms, "pixel_sads": workload.pixel_sads(cj, res)}
+        keep.append((per_pair[0], res[:len(per_pair[0])]))
+    e.device_free(d_pairs)
+    for l in low:
+        for p in l:
+            e.free_plane(p)
+    for p in planes:
+        e.free_plane(p)
+    return out, (clip[0], clip[1], np.concatenate([k[0] for k in keep]), np.concatenate([k[1] for k in keep]))

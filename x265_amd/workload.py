@@ -248,3 +248,33 @@ def rk_ctu_jobs(pic_w, pic_h, pmvs, mvps, have_mvd=True, me_range=(384, 320), dt
             j["mvp"] = mvps[cy * ncx + cx]
             j["have_mvd"] = int(have_mvd)
     return jobs
+
+
+def shape_jobs(width, height, w, h, la, wcu, hcu, merange, cu):
+    """Every PU of shape w x h of a picture's grid of `cu` x `cu` CUs (both PUs of a 2NxN / Nx2N split; the first PU of an
+    asymmetric one), predictor and two candidates from the lookahead MV field `la` (the CU under the PU's centre, its left
+    and upper neighbours), range `merange` around the predictor clipped 100 samples past the picture."""
+    from .engine import JOB_DTYPE
+    mv_full = la.astype(np.int32).reshape(hcu, wcu, 2) * 2
+    xs, ys = np.meshgrid(np.arange(0, width - cu + 1, cu), np.arange(0, height - cu + 1, cu))
+    xs, ys = xs.ravel(), ys.ravel()
+    offs = [(0, 0)] if (w, h) == (cu, cu) else ([(0, 0), (0, h)] if w == cu and 2 * h == cu else [(0, 0), (w, 0)] if h == cu and 2 * w == cu else [(0, 0)])
+    parts = []
+    for ox, oy in offs:
+        jobs = np.zeros(xs.size, JOB_DTYPE)
+        jobs["pu_x"], jobs["pu_y"], jobs["w"], jobs["h"] = xs + ox, ys + oy, w, h
+        cx = np.minimum((xs + ox + w // 2) // 16, wcu - 1)
+        cy = np.minimum((ys + oy + h // 2) // 16, hcu - 1)
+        mvp = mv_full[cy, cx]
+        jobs["qmvp"] = mvp
+        jobs["numc"] = 2
+        jobs["mvc"][:, 0] = mv_full[cy, np.maximum(cx - 1, 0)]
+        jobs["mvc"][:, 1] = mv_full[np.maximum(cy - 1, 0), cx]
+        fx, fy = mvp[:, 0] >> 2, mvp[:, 1] >> 2
+        jobs["mvmin"][:, 0] = np.maximum(fx - merange, -(xs + ox) - 100)
+        jobs["mvmin"][:, 1] = np.maximum(fy - merange, -(ys + oy) - 100)
+        jobs["mvmax"][:, 0] = np.minimum(fx + merange, width - (xs + ox) - w + 100)
+        jobs["mvmax"][:, 1] = np.minimum(fy + merange, height - (ys + oy) - h + 100)
+        jobs["merange"] = merange
+        parts.append(jobs)
+    return np.concatenate(parts)
