@@ -84,6 +84,7 @@ struct SearchArgs
     unsigned char *handled;
     int tiny;              /* 1: the launch has star_tiny_kernel for the small other partitions (tiny_class): the square
                               kernels do not hand those to the one-wave search */
+    int rect;              /* 1: the launch has star_rect_kernel for the larger other partitions (rect_class), likewise */
     int stage_all;         /* 1: the one-wave search stops every PU before the sub-pel refinement; the PUs that are not squares of
                               the fixed-shape sizes are refined by refine_any_kernel */
 };
@@ -1209,6 +1210,8 @@ static int launch_search(x265amd_ctx *c, const SearchArgs &a, int is_lowres, boo
         /* the small other partitions of the list through a fixed-shape stage of their own */
         static const bool no_star_tiny = getenv("X265AMD_NO_STAR_TINY") != 0;                    /* measurements only */
         sl.b.tiny = sl.b.stage_all && !no_star_tiny;
+        static const bool no_star_rect = getenv("X265AMD_NO_STAR_RECT") != 0;
+        sl.b.rect = sl.b.stage_all && a.max_dim >= 32 && !no_star_rect;
         if ((rc = search_star<P>(c, sl, c->stream))) return rc;
         if (sl.b.tiny)
         {
@@ -1218,6 +1221,13 @@ static int launch_search(x265amd_ctx *c, const SearchArgs &a, int is_lowres, boo
             if (a.method == X265AMD_HEX) hipLaunchKernelGGL((star_tiny_kernel<P, X265AMD_HEX>), dim3(tgrid), dim3(64), StarTinyMax<(int)sizeof(P)>::TOTAL, c->stream, sl.b, chunk);
             else if (a.method == X265AMD_DIA) hipLaunchKernelGGL((star_tiny_kernel<P, X265AMD_DIA>), dim3(tgrid), dim3(64), StarTinyMax<(int)sizeof(P)>::TOTAL, c->stream, sl.b, chunk);
             else hipLaunchKernelGGL((star_tiny_kernel<P, X265AMD_STAR>), dim3(tgrid), dim3(64), StarTinyMax<(int)sizeof(P)>::TOTAL, c->stream, sl.b, chunk);
+        }
+        if (sl.b.rect)
+        {
+            const int lds = star_rect_lds(a.max_dim, (int)sizeof(P));
+            if (a.method == X265AMD_HEX) hipLaunchKernelGGL((star_rect_kernel<P, X265AMD_HEX>), dim3(a.njobs), dim3(64), lds, c->stream, sl.b);
+            else if (a.method == X265AMD_DIA) hipLaunchKernelGGL((star_rect_kernel<P, X265AMD_DIA>), dim3(a.njobs), dim3(64), lds, c->stream, sl.b);
+            else hipLaunchKernelGGL((star_rect_kernel<P, X265AMD_STAR>), dim3(a.njobs), dim3(64), lds, c->stream, sl.b);
         }
         /* The PUs handed on are few as a rule and each a long chain of dependent steps in one wave: their
          * searches and refinement run on the context's second stream while this one refines all the others. */
@@ -1231,7 +1241,9 @@ static int launch_search(x265amd_ctx *c, const SearchArgs &a, int is_lowres, boo
         search_side<P>(c, sl, no_fork ? c->stream : c->aux);
         if (!no_fork) HIPCHK(c, hipEventRecord(c->ev_join, c->aux));
         launch_refine<P>(sl.b, c->stream, 0);
-        if (sl.b.tiny) launch_tiny<P>(sl.b, c->stream, 0);         /* (the PUs star_tiny_kernel ended; the others are in the list) */
+        /* (the PUs star_tiny_kernel / star_rect_kernel ended; the others are in the list) */
+        if (sl.b.rect) launch_any<P>(sl.b, c->stream, 0);
+        else if (sl.b.tiny) launch_tiny<P>(sl.b, c->stream, 0);
         if (!no_fork) HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_join, 0));
         c->redo_valid = true;
     }
@@ -1759,7 +1771,7 @@ static void fill_args(x265amd_ctx *c, SearchArgs &a, const x265amd_plane *fenc, 
         a.ref[i].origin = r->origin; a.ref[i].stride = r->stride;
     }
     a.lowres = is_lowres; a.depth = c->depth; a.method = method; a.subme = subme; a.max_dim = is_lowres ? 8 : 64;
-    a.staged = 0; a.staged2 = 0; a.done = 0; a.redo = 0; a.pairs = 0; a.npairs = 0; a.plane_lds = 0; a.state = 0; a.mark = 0; a.list = 0; a.stage_all = 0; a.tiny = 0; a.pjobs = 0; a.presults = 0; a.npjobs = 0; a.pmark = 0; a.pstate = 0; a.handled = 0; a.cjobs = 0; a.cresults = 0; a.ncjobs = 0; a.cmark = 0; a.cdone = 0;
+    a.staged = 0; a.staged2 = 0; a.done = 0; a.redo = 0; a.pairs = 0; a.npairs = 0; a.plane_lds = 0; a.state = 0; a.mark = 0; a.list = 0; a.stage_all = 0; a.tiny = 0; a.rect = 0; a.pjobs = 0; a.presults = 0; a.npjobs = 0; a.pmark = 0; a.pstate = 0; a.handled = 0; a.cjobs = 0; a.cresults = 0; a.ncjobs = 0; a.cmark = 0; a.cdone = 0;
     a.ctab = c->tables[qp] + 32768;
 }
 

@@ -1453,7 +1453,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(S == 16 ? OC
     const bool sized = (d[1] & 0xffff) == G::SIZE_CODE;
     /* the launch for the list's largest size hands every PU that no fixed-shape launch takes to the one-wave search */
     if (valid && !sized && l == 0 && S == a.staged && (d[1] & 0xffff) != (a.staged2 | (a.staged2 << 8)) &&
-        !(a.tiny && tiny_class(d[1] & 0xff, (d[1] >> 8) & 0xff)))
+        !(a.tiny && tiny_class(d[1] & 0xff, (d[1] >> 8) & 0xff)) && !(a.rect && rect_class(d[1] & 0xff, (d[1] >> 8) & 0xff)))
     {
         a.results[j].sad_calls = SMALL_REDO;
         a.mark[j] = 1;
@@ -2244,7 +2244,8 @@ __global__ __launch_bounds__(StarBigGeo<S>::THREADS) __attribute__((amdgpu_waves
     {
         /* the launch for the list's largest size hands every PU that no fixed-shape launch takes to the one-wave search */
         if (S == a.staged && (d[1] & 0xffff) != (a.staged2 | (a.staged2 << 8)) && tid == 0 &&
-            !(a.tiny && tiny_class(d[1] & 0xff, (d[1] >> 8) & 0xff))) { a.results[j].sad_calls = SMALL_REDO; a.mark[j] = 1; }
+            !(a.tiny && tiny_class(d[1] & 0xff, (d[1] >> 8) & 0xff)) && !(a.rect && rect_class(d[1] & 0xff, (d[1] >> 8) & 0xff)))
+        { a.results[j].sad_calls = SMALL_REDO; a.mark[j] = 1; }
         return;
     }
 #pragma unroll
@@ -2474,6 +2475,278 @@ __global__ __launch_bounds__(StarBigGeo<S>::THREADS) __attribute__((amdgpu_waves
     res[1] = bcost;
     res[2] = (int)nsad;
     res[3] = (int)nsub;
+}
+
+/* ---------------------------------------------------------------- the same stage for the larger 2NxN / Nx2N / pow-2 partitions
+ *
+ * star_big_kernel's stage for the other partitions of rect_class (64x32, 32x64, 64x16, 16x64, 32x16, 16x32, 32x8, 8x32),
+ * one wave per PU: a lane looks after W H / 256 (tile, column) pairs for the vertical passes and a strip of as many
+ * quad rows for the plain SADs. One kernel for all shapes -- the wave reads its PU's shape and takes that shape's
+ * straight-line code -- because the shapes of a device-resident list are not known to the host. */
+template<int W, int H> struct RectGeo
+{
+    static constexpr int LTW = W == 8 ? 1 : W == 16 ? 2 : W == 32 ? 3 : 4;
+    static constexpr int TW = W / 4;
+    static constexpr int ITEMS = W * H / 256;               /* (tile, column) pairs per lane = quad rows per lane */
+    static constexpr int PROW = H + 10;                     /* int16 rows of a plane column */
+    static constexpr int PLANE = W * PROW * 2;
+    static constexpr int IPP = (H + 8) * TW;                /* horizontal-pass items per plane */
+    static constexpr int SIZE_CODE = W | (H << 8);
+    static constexpr int CELLS = SM_FIXED;                  /* 8 cells of the start-up slots, then 20 of the points */
+    static constexpr int PLANES = CELLS + 128;
+    static constexpr int window(int bps) { return (H + 8) * (W + 12) * bps + 8; }
+    static constexpr int total(int bps) { return PLANES + (2 * PLANE > window(bps) ? 2 * PLANE : window(bps)) + 32; }
+};
+/* LDS of a launch for PUs up to max_dim samples (32 or 64): the largest of its shapes */
+static inline int star_rect_lds(int max_dim, int bps)
+{
+    int a = RectGeo<32, 16>::total(bps), b = RectGeo<16, 32>::total(bps), c = RectGeo<32, 8>::total(bps), d = RectGeo<8, 32>::total(bps);
+    int m = a > b ? a : b;
+    m = c > m ? c : m; m = d > m ? d : m;
+    if (max_dim > 32)
+    {
+        int e = RectGeo<64, 32>::total(bps), f = RectGeo<32, 64>::total(bps), g = RectGeo<64, 16>::total(bps), h = RectGeo<16, 64>::total(bps);
+        m = e > m ? e : m; m = f > m ? f : m; m = g > m ? g : m; m = h > m ? h : m;
+    }
+    return m;
+}
+
+template<int W, int H, typename P, int M>
+__device__ __forceinline__ void star_rect_pu(const SearchArgs &a, int j, const int *job)
+{
+    typedef RectGeo<W, H> G;
+    constexpr int ITEMS = G::ITEMS, NQ = G::ITEMS, BPS = (int)sizeof(P);
+    const int depth = sizeof(P) == 1 ? 8 : a.depth;
+    const int lane = (int)threadIdx.x;
+    int d[10];
+#pragma unroll
+    for (int i = 0; i < 10; i++) d[i] = uni(job[i]);
+    const int pux = as_i16(d[0]), puy = d[0] >> 16, numc = (d[1] >> 16) & 0xff;
+    const int mnx = as_i16(d[2]), mny = d[2] >> 16, mxx = as_i16(d[3]), mxy = d[3] >> 16;
+    const int mvpx = as_i16(d[4]), mvpy = d[4] >> 16;
+    const P AS1 *fenc0, *ref0;
+    int fstride, rstride;
+    small_planes<P>(a, d[1], fenc0, fstride, ref0, rstride);
+    const int roff = puy * rstride + pux;
+    const uint16_t AS1 *ctab = (const uint16_t AS1*)a.ctab;
+    int *cells = (int*)(x265amd_smem + G::CELLS);
+
+    /* ---- start-up candidates, motion.cpp:575-621 ---- */
+    const int qmnx = as_i16(mnx << 2), qmny = as_i16(mny << 2), qmxx = as_i16(mxx << 2), qmxy = as_i16(mxy << 2);
+#define SM_CLIPX(v) ((v) > qmxx ? qmxx : ((v) < qmnx ? qmnx : (v)))
+#define SM_CLIPY(v) ((v) > qmxy ? qmxy : ((v) < qmny ? qmny : (v)))
+    const int pmx = SM_CLIPX(mvpx), pmy = SM_CLIPY(mvpy);
+    int bmx = as_i16((pmx + 2) >> 2), bmy = as_i16((pmy + 2) >> 2);
+    const bool fpOn = ((pmx | pmy) & 3) != 0, zeroOn = (pmx | pmy) != 0;
+    int ccx[4], ccy[4];
+    bool cOn[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+    {
+        ccx[i] = SM_CLIPX(as_i16(d[5 + i])); ccy[i] = SM_CLIPY(d[5 + i] >> 16);
+        cOn[i] = i < numc && (ccx[i] | ccy[i]) != 0 && !(ccx[i] == pmx && ccy[i] == pmy);
+    }
+#undef SM_CLIPX
+#undef SM_CLIPY
+    /* lane l < 7 looks after candidate slot l, as in star_small_kernel */
+    int sx = pmx, sy = pmy;
+    bool on = lane == 0;
+    if (lane == 1) { sx = as_i16(bmx << 2); sy = as_i16(bmy << 2); on = fpOn; }
+    if (lane == 2) { sx = 0; sy = 0; on = zeroOn; }
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+        if (lane == 3 + i) { sx = ccx[i]; sy = ccy[i]; on = cOn[i]; }
+    on = on && lane < SM_SLOTS;
+    int mvc = 0;
+    if (on && lane != 0) mvc = ((int)ctab[sx - mvpx] + (int)ctab[sy - mvpy]) & 0xffff;
+
+    /* the lane's part of the source block: its (tile, column) pairs for the vertical passes, its quad rows for the SADs */
+    ColSrc ct[ITEMS];
+#pragma unroll
+    for (int u = 0; u < ITEMS; u++)
+    {
+        const int l = lane + 64 * u, t = l >> 2;
+        ct[u].ty = t >> G::LTW; ct[u].col = (t & (G::TW - 1)) * 4 + (l & 3);
+        const P AS1 *src = fenc0 + (long)(puy + ct[u].ty * 4) * fstride + pux + ct[u].col;
+        uint32_t f[4];
+#pragma unroll
+        for (int y = 0; y < 4; y++) f[y] = (uint32_t)src[(long)y * fstride];
+        ct[u].f01 = f[0] | (f[1] << 16); ct[u].f23 = f[2] | (f[3] << 16);
+    }
+    const int tlx = (lane & (G::TW - 1)) * 4, tly = (lane >> G::LTW) * NQ;
+    typename Px<P>::quad fq[NQ];
+    {
+        const P AS1 *src = fenc0 + (long)(puy + tly) * fstride + pux + tlx;
+#pragma unroll
+        for (int y = 0; y < NQ; y++) fq[y] = Px<P>::load_g(src + (long)y * fstride);
+    }
+    wave_sync();
+    int pb = 0;
+#pragma unroll 1
+    for (int k = 0; k < SM_SLOTS; k++)
+    {
+        if (!__builtin_amdgcn_readlane((int)on, k)) continue;
+        const int kx = __builtin_amdgcn_readlane(sx, k), ky = __builtin_amdgcn_readlane(sy, k);
+        int v = 0;
+        if (((kx | ky) & 3) == 0)
+        {
+            const P AS1 *rp = ref0 + roff + (long)__mul24((ky >> 2) + tly, rstride) + (kx >> 2) + tlx;
+#pragma unroll
+            for (int y = 0; y < NQ; y++) v = Px<P>::sad(fq[y], Px<P>::load_g(rp + (long)y * rstride), v);
+        }
+        else
+        {
+            const int poff = G::PLANES + pb * G::PLANE;
+            const P AS1 *src = ref0 + (roff + __mul24((ky >> 2) - 3, rstride) + (kx >> 2) - 3);
+            const int *tp = (const int*)(x265amd_smem + SM_TAPS) + (kx & 3) * 12;
+            for (int item = lane; item < G::IPP; item += 64)
+            {
+                const int r = item >> G::LTW, q = item & (G::TW - 1);
+                hps_quad(src + (__mul24(r, rstride) + 4 * q), tp, (int16_t*)(x265amd_smem + poff) + (4 * q) * G::PROW + r, G::PROW, depth);
+            }
+            wave_sync();
+#pragma unroll
+            for (int u = 0; u < ITEMS; u++)
+            {
+                int o[4];
+                column_rows<4>(poff, G::PROW, 0, ky & 3, ct[u], depth, o);
+                v += small_rows_cost(o[0], o[1], o[2], o[3], false, ct[u], lane & 3, depth);
+            }
+            pb ^= 1;
+        }
+        v = wave_total(v);
+        if (lane == 0) cells[k] = v;
+    }
+    wave_sync();
+    /* the reference's sequence of tests on the measured costs (motion.cpp:579-621) */
+    int cst[SM_SLOTS];
+#pragma unroll
+    for (int k = 0; k < SM_SLOTS; k++) cst[k] = __builtin_amdgcn_readlane(mvc, k) + uni(cells[k]);
+    int bprecost = cst[0], bcost = bprecost;
+    unsigned nsad = 0, nsub = 1;
+    if (fpOn) { bcost = cst[1]; nsad++; }
+    if (zeroOn)
+    {
+        nsad++;
+        if (cst[2] < bcost) { bcost = cst[2]; bmx = 0; bmy = 0; }
+    }
+    int bpx = pmx, bpy = pmy;
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+        if (cOn[i] && !(ccx[i] == bpx && ccy[i] == bpy))
+        {
+            nsub++;
+            if (cst[3 + i] < bprecost) { bprecost = cst[3 + i]; bpx = ccx[i]; bpy = ccy[i]; }
+        }
+    /* ---- the window of the points over the planes (every lane is past its last vertical pass) ---- */
+    constexpr int WP = (W + 12) * BPS;
+    const int woff = G::PLANES;
+    {
+        typedef uint32_t __attribute__((aligned(1))) u32u;
+        const char AS1 *w0 = (const char AS1*)(ref0 + roff + (long)__mul24(bmy - 4, rstride) + bmx - 4);
+        for (int i = lane; i < (H + 8) * (WP / 4); i += 64)
+        {
+            const int r = i / (WP / 4), q = i - r * (WP / 4);
+            *(uint32_t*)(x265amd_smem + woff + r * WP + 4 * q) = *(const u32u AS1*)(w0 + (long)r * rstride * BPS + 4 * q);
+        }
+    }
+    wave_sync();
+    /* every point's SAD over the lane's quad rows, unrolled: a point's offset in the window is a constant next to the
+     * lane's own (dword-aligned) corner */
+    unsigned npts = 0;
+    {
+        constexpr PatTable<M> T = PatTable<M>();
+        constexpr int NP = PatPoints<M>::N;
+        const int room_l = bmx - mnx, room_r = mxx - bmx, room_u = bmy - mny, room_d = mxy - bmy;
+        const int wbase = woff + tly * WP + tlx * BPS;
+#pragma unroll
+        for (int p = 0; p < NP; p++)
+        {
+            int v = 0;
+#pragma unroll
+            for (int y2 = 0; y2 < NQ; y2++)
+                v = Px<P>::sad(fq[y2], lds_quad_const<P>(wbase, (4 + T.dy[p] + y2) * WP + (4 + T.dx[p]) * BPS), v);
+            /* STAR: the reference tests only the bounds a point can cross (motion.cpp:330-452); the other patterns'
+             * points are measured unchecked */
+            const bool okx = M != X265AMD_STAR || T.dx[p] == 0 || (T.dx[p] < 0 ? room_l >= -T.dx[p] : room_r >= T.dx[p]);
+            const bool oky = M != X265AMD_STAR || T.dy[p] == 0 || (T.dy[p] < 0 ? room_u >= -T.dy[p] : room_d >= T.dy[p]);
+            if (okx && oky)
+            {
+                npts++;
+                v = wave_total(v);
+                if (lane == 0) cells[8 + p] = v;
+            }
+        }
+    }
+    wave_sync();
+    int key = 0x7fffffff;
+    if (lane < PatPoints<M>::N)
+    {
+        int dx, dy;
+        pat_point<M>(lane, dx, dy);
+        const int x = as_i16(bmx + dx), y = as_i16(bmy + dy);
+        if (M != X265AMD_STAR || ((dy >= 0 || y >= mny) && (dy <= 0 || y <= mxy) && (dx >= 0 || x >= mnx) && (dx <= 0 || x <= mxx)))
+            key = ((cells[8 + lane] + (((int)ctab[as_i16(x << 2) - mvpx] + (int)ctab[as_i16(y << 2) - mvpy]) & 0xffff)) << 6) | lane;
+    }
+    StarFold F;
+    bool over;
+    if constexpr (M != X265AMD_STAR)
+    {
+        const int k0 = wave_min(lane < (M == X265AMD_HEX ? 6 : 4) ? key : 0x7fffffff), k1 = wave_min(lane >= 6 ? key : 0x7fffffff);
+        int dir;
+        unsigned counted;
+        over = pat_fold<M>(k0, k1, bmx, bmy, bcost, dir, counted);
+        nsad += counted;
+        F.start(bmx, bmy, bcost);
+        F.pt = dir;
+    }
+    else
+    {
+        const int rkey0 = wave_min(lane < 4 ? key : 0x7fffffff), rkey1 = wave_min(lane >= 4 && lane < 12 ? key : 0x7fffffff),
+                  rkey2 = wave_min(lane >= 12 ? key : 0x7fffffff);
+        F.start(bmx, bmy, bcost);
+        F.round(rkey0); F.round(rkey1); F.round(rkey2);
+        nsad += npts;
+        over = F.rounds >= 3;
+    }
+    if (lane != 0) return;
+    int *res = (int*)(a.results + j);
+    a.mark[j] = !over;
+    if (!over)
+    {
+        F.store(a.state + 8 * (long)j, bprecost, bpx, bpy, nsad, nsub);
+        res[2] = (int)SMALL_RESUME;
+        return;
+    }
+    int qx, qy;
+    if (bprecost < bcost) { qx = bpx; qy = bpy; bcost = bprecost; }
+    else { qx = as_i16(bmx << 2); qy = as_i16(bmy << 2); }
+    res[0] = (qx & 0xffff) | (qy << 16);
+    res[1] = bcost;
+    res[2] = (int)nsad;
+    res[3] = (int)nsub;
+}
+
+template<typename P, int M>
+__global__ __launch_bounds__(64) void star_rect_kernel(SearchArgs a)
+{
+    const int j = xcd_remap((int)blockIdx.x, a.njobs);
+    if (j >= a.njobs) return;
+    const int *job = (const int*)(a.jobs + j);
+    const int code = uni(job[1]) & 0xffff, w = code & 0xff, h = code >> 8;
+    if (!rect_class(w, h) || (w > h ? w : h) > a.max_dim) return;
+    small_load_taps<P>((int)threadIdx.x, sizeof(P) == 1 ? 8 : a.depth);
+    switch (code)
+    {
+    case RectGeo<32, 16>::SIZE_CODE: star_rect_pu<32, 16, P, M>(a, j, job); break;
+    case RectGeo<16, 32>::SIZE_CODE: star_rect_pu<16, 32, P, M>(a, j, job); break;
+    case RectGeo<32, 8>::SIZE_CODE: star_rect_pu<32, 8, P, M>(a, j, job); break;
+    case RectGeo<8, 32>::SIZE_CODE: star_rect_pu<8, 32, P, M>(a, j, job); break;
+    case RectGeo<64, 32>::SIZE_CODE: star_rect_pu<64, 32, P, M>(a, j, job); break;
+    case RectGeo<32, 64>::SIZE_CODE: star_rect_pu<32, 64, P, M>(a, j, job); break;
+    case RectGeo<64, 16>::SIZE_CODE: star_rect_pu<64, 16, P, M>(a, j, job); break;
+    case RectGeo<16, 64>::SIZE_CODE: star_rect_pu<16, 64, P, M>(a, j, job); break;
+    }
 }
 
 } // namespace x265amd
