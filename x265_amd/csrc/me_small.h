@@ -2479,14 +2479,15 @@ __global__ __launch_bounds__(StarBigGeo<S>::THREADS) __attribute__((amdgpu_waves
 
 /* ---------------------------------------------------------------- the same stage for the larger 2NxN / Nx2N / pow-2 partitions
  *
- * star_big_kernel's stage for the other partitions of rect_class (64x32, 32x64, 64x16, 16x64, 32x16, 16x32, 32x8, 8x32),
- * one wave per PU: a lane looks after W H / 256 (tile, column) pairs for the vertical passes and a strip of as many
+ * star_big_kernel's stage for the other partitions of rect_class (64x32, 32x64, 64x16, 16x64, 32x16, 16x32, 32x8, 8x32,
+ * 32x24, 64x48), one wave per PU: a lane looks after W H / 256 (tile, column) pairs for the vertical passes and a strip of as many
  * quad rows for the plain SADs. One kernel for all shapes -- the wave reads its PU's shape and takes that shape's
  * straight-line code -- because the shapes of a device-resident list are not known to the host. */
 template<int W, int H> struct RectGeo
 {
     static constexpr int LTW = W == 8 ? 1 : W == 16 ? 2 : W == 32 ? 3 : 4;
     static constexpr int TW = W / 4;
+    static_assert(W * H % 256 == 0 && (W == 8 || W == 16 || W == 32 || W == 64), "whole pairs per lane, a power of two of tiles per row");
     static constexpr int ITEMS = W * H / 256;               /* (tile, column) pairs per lane = quad rows per lane */
     static constexpr int PROW = H + 10;                     /* int16 rows of a plane column */
     static constexpr int PLANE = W * PROW * 2;
@@ -2503,10 +2504,14 @@ static inline int star_rect_lds(int max_dim, int bps)
     int a = RectGeo<32, 16>::total(bps), b = RectGeo<16, 32>::total(bps), c = RectGeo<32, 8>::total(bps), d = RectGeo<8, 32>::total(bps);
     int m = a > b ? a : b;
     m = c > m ? c : m; m = d > m ? d : m;
+    const int i = RectGeo<32, 24>::total(bps);
+    m = i > m ? i : m;
     if (max_dim > 32)
     {
         int e = RectGeo<64, 32>::total(bps), f = RectGeo<32, 64>::total(bps), g = RectGeo<64, 16>::total(bps), h = RectGeo<16, 64>::total(bps);
         m = e > m ? e : m; m = f > m ? f : m; m = g > m ? g : m; m = h > m ? h : m;
+        const int k = RectGeo<64, 48>::total(bps);
+        m = k > m ? k : m;
     }
     return m;
 }
@@ -2746,6 +2751,8 @@ __global__ __launch_bounds__(64) void star_rect_kernel(SearchArgs a)
     case RectGeo<32, 64>::SIZE_CODE: star_rect_pu<32, 64, P, M>(a, j, job); break;
     case RectGeo<64, 16>::SIZE_CODE: star_rect_pu<64, 16, P, M>(a, j, job); break;
     case RectGeo<16, 64>::SIZE_CODE: star_rect_pu<16, 64, P, M>(a, j, job); break;
+    case RectGeo<32, 24>::SIZE_CODE: star_rect_pu<32, 24, P, M>(a, j, job); break;
+    case RectGeo<64, 48>::SIZE_CODE: star_rect_pu<64, 48, P, M>(a, j, job); break;
     }
 }
 
