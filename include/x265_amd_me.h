@@ -133,9 +133,9 @@ int x265amd_search_batch(x265amd_ctx *ctx, const x265amd_plane *fenc, const x265
  * cost -1 and is not searched. With 8-bit samples the square PUs of exactly that size take the
  * fixed-shape kernels (several PUs per wave, or several waves per PU), so a caller after
  * throughput launches one batch per PU size; results do not depend on it. Other partitions in the batch (2NxN, Nx2N, the
- * asymmetric pairs, squares of other sizes): the small ones (8x4, 4x8, 16x4, 4x16, 8x8, 16x8, 8x16) have fixed-shape kernels
- * of their own for both stages, two to eight PUs per wave whatever the mix of shapes; the larger ones take the one-wave
- * search for their integer stage and a kernel of their own for the sub-pel rounds. A batch for 64x64 PUs (samples of at most
+ * asymmetric pairs, squares of other sizes) have fixed-shape kernels of their own for both stages: the small ones (8x4, 4x8,
+ * 16x4, 4x16, 8x8, 16x8, 8x16) two to eight PUs per wave whatever the mix of shapes, the larger ones (16x12 .. 64x48) a
+ * wave per PU; only squares of sizes the launch is not made for take the one-wave search. A batch for 64x64 PUs (samples of at most
  * 10 bits) takes its 32x32 PUs through the fixed-shape kernels as well, and a 64x64 PU that is directly followed in the list by
  * its four 32x32 children (raster order, same pictures) refines them together with itself where all five start the sub-pel
  * rounds from one MV -- a quarter of the children's work; the list order changes no result.

@@ -150,6 +150,39 @@ def test_small_other_partitions_packed_vs_oracle(request, oracle, mname, depth):
 
 
 @pytest.mark.parametrize("depth", [8, 10])
+@pytest.mark.parametrize("mname", ["star", "hex", "dia"])
+def test_larger_other_partitions_fixed_shape_vs_oracle(request, oracle, mname, depth):
+    """The other partitions from 16x12 up have a fixed-shape integer stage of a wave per PU (star_rect_kernel; 16x12 and
+    12x16 inside star_tiny_kernel): every one of the fourteen shapes -- strips of quad rows per lane for the power-of-two
+    widths, scattered quad rows for 12, 24 and 48 samples, idle lanes for the 48 pairs of 16x12 -- mixed with squares, on
+    texture (most PUs end in the kernel), noise (most are handed on to the resumed search) and a static clip
+    (motion.cpp:562-621, :307-547)."""
+    e = _engine(request, depth)
+    method = METHODS[mname]
+    W, H = 320, 192
+    m = margin_for(method)
+    s16 = [(16, 12), (12, 16)]
+    s32 = [(32, 16), (16, 32), (32, 8), (8, 32), (32, 24), (24, 32)]
+    s64 = [(64, 32), (32, 64), (64, 16), (16, 64), (64, 48), (48, 64)]
+    for kind, parts, n, subme in (("texture", s16 + [(16, 16), (16, 8)], 140, 5), ("noise", s16 + s32 + [(32, 32)], 120, 2),
+                                  ("texture", s16 + s32 + s64 + [(64, 64), (32, 32), (8, 8)], 170, 6), ("noise", s64 + s32, 60, 1),
+                                  ("static", s16 + s32 + s64, 90, 3)):
+        fenc, ref, org, stride = clip_planes(W, H, depth, kind, margin=m)
+        pf = e.upload_plane(fenc, W, H, m, m, stride)
+        pr = e.upload_plane(ref, W, H, m, m, stride)
+        rng = np.random.default_rng(5000 + method * 10 + subme + n)
+        jobs = random_jobs(rng, n, W, H, method, parts=parts)
+        qp = int(rng.integers(10, 45)) + 6 * (depth - 8)
+        r = e.search_batch(pf, pr, jobs, qp, method, subme)
+        mv, cost, sc, qc = oracle_search(oracle, depth, fenc, [ref], org, stride, jobs, qp, method, subme)
+        assert np.array_equal(r["mv"], mv), (kind, n)
+        assert np.array_equal(r["cost"], cost), (kind, n)
+        assert np.array_equal(r["sad_calls"], sc) and np.array_equal(r["subpel_calls"], qc), (kind, n)
+        e.free_plane(pf)
+        e.free_plane(pr)
+
+
+@pytest.mark.parametrize("depth", [8, 10])
 def test_pairs_in_one_launch_vs_oracle(request, oracle, depth):
     """x265amd_search_batch_pairs: jobs of three (source, reference) pairs of different sizes and strides in one launch,
     interleaved job by job (so the four 8x8 PUs one refinement wave takes belong to different pictures), every method,

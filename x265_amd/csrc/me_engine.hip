@@ -1162,6 +1162,16 @@ static void search_star_m(const SearchArgs &b, hipStream_t st)
     }
 }
 
+/* the larger other partitions: a kernel per class of shapes (longer side 32, 64) the list can hold; 16x12 / 12x16 are
+ * star_tiny_kernel's */
+template<typename P, int M>
+static void search_rect_m(const SearchArgs &b, hipStream_t st)
+{
+    const int bps = (int)sizeof(P);
+    if (b.max_dim >= 32) hipLaunchKernelGGL((star_rect_kernel<P, M, 32>), dim3(b.njobs), dim3(64), star_rect_lds(32, bps), st, b);
+    if (b.max_dim >= 64) hipLaunchKernelGGL((star_rect_kernel<P, M, 64>), dim3(b.njobs), dim3(64), star_rect_lds(64, bps), st, b);
+}
+
 template<typename P>
 static int search_star(x265amd_ctx *c, SearchLaunch &sl, hipStream_t st)
 {
@@ -1211,23 +1221,24 @@ static int launch_search(x265amd_ctx *c, const SearchArgs &a, int is_lowres, boo
         static const bool no_star_tiny = getenv("X265AMD_NO_STAR_TINY") != 0;                    /* measurements only */
         sl.b.tiny = sl.b.stage_all && !no_star_tiny;
         static const bool no_star_rect = getenv("X265AMD_NO_STAR_RECT") != 0;
-        sl.b.rect = sl.b.stage_all && a.max_dim >= 32 && !no_star_rect;
+        sl.b.rect = sl.b.tiny && a.max_dim >= 16 && !no_star_rect;
         if ((rc = search_star<P>(c, sl, c->stream))) return rc;
         if (sl.b.tiny)
         {
             const int chunk = tiny_chunk(a.njobs);
+            const int rect_lds = star_rect_lds(16, (int)sizeof(P));
+            const int tiny_lds = StarTinyMax<(int)sizeof(P)>::TOTAL > rect_lds ? StarTinyMax<(int)sizeof(P)>::TOTAL : rect_lds;
             int tgrid = (a.njobs + chunk - 1) / chunk;
             if (tgrid > 65536) tgrid = 65536;
-            if (a.method == X265AMD_HEX) hipLaunchKernelGGL((star_tiny_kernel<P, X265AMD_HEX>), dim3(tgrid), dim3(64), StarTinyMax<(int)sizeof(P)>::TOTAL, c->stream, sl.b, chunk);
-            else if (a.method == X265AMD_DIA) hipLaunchKernelGGL((star_tiny_kernel<P, X265AMD_DIA>), dim3(tgrid), dim3(64), StarTinyMax<(int)sizeof(P)>::TOTAL, c->stream, sl.b, chunk);
-            else hipLaunchKernelGGL((star_tiny_kernel<P, X265AMD_STAR>), dim3(tgrid), dim3(64), StarTinyMax<(int)sizeof(P)>::TOTAL, c->stream, sl.b, chunk);
+            if (a.method == X265AMD_HEX) hipLaunchKernelGGL((star_tiny_kernel<P, X265AMD_HEX>), dim3(tgrid), dim3(64), tiny_lds, c->stream, sl.b, chunk);
+            else if (a.method == X265AMD_DIA) hipLaunchKernelGGL((star_tiny_kernel<P, X265AMD_DIA>), dim3(tgrid), dim3(64), tiny_lds, c->stream, sl.b, chunk);
+            else hipLaunchKernelGGL((star_tiny_kernel<P, X265AMD_STAR>), dim3(tgrid), dim3(64), tiny_lds, c->stream, sl.b, chunk);
         }
         if (sl.b.rect)
         {
-            const int lds = star_rect_lds(a.max_dim, (int)sizeof(P));
-            if (a.method == X265AMD_HEX) hipLaunchKernelGGL((star_rect_kernel<P, X265AMD_HEX>), dim3(a.njobs), dim3(64), lds, c->stream, sl.b);
-            else if (a.method == X265AMD_DIA) hipLaunchKernelGGL((star_rect_kernel<P, X265AMD_DIA>), dim3(a.njobs), dim3(64), lds, c->stream, sl.b);
-            else hipLaunchKernelGGL((star_rect_kernel<P, X265AMD_STAR>), dim3(a.njobs), dim3(64), lds, c->stream, sl.b);
+            if (a.method == X265AMD_HEX) search_rect_m<P, X265AMD_HEX>(sl.b, c->stream);
+            else if (a.method == X265AMD_DIA) search_rect_m<P, X265AMD_DIA>(sl.b, c->stream);
+            else search_rect_m<P, X265AMD_STAR>(sl.b, c->stream);
         }
         /* The PUs handed on are few as a rule and each a long chain of dependent steps in one wave: their
          * searches and refinement run on the context's second stream while this one refines all the others. */

@@ -1280,7 +1280,7 @@ __global__ __launch_bounds__(64) void refine_tiny_kernel(SearchArgs a, int chunk
      * left to others), a lane each, and takes those of each class in turn; chunk: a power of two from 8 to 64, picked by
      * the host so that a short list still spreads over the chip */
     const int n = a.list ? uni(a.redo[0]) : a.njobs;
-    for (int base = (int)blockIdx.x * chunk; base < n; base += (int)gridDim.x * chunk)
+    for (int base = xcd_remap((int)blockIdx.x, (int)gridDim.x) * chunk; base < n; base += (int)gridDim.x * chunk)
     {
         int j = 0, cls = 0;
         if (lane < chunk && base + lane < n)
@@ -2128,12 +2128,14 @@ __device__ __forceinline__ void star_tiny_pass(const SearchArgs &a, int jmine, b
 #ifndef OCC_ST
 #define OCC_ST 4
 #endif
+template<int D, typename P, int M>
+__device__ __forceinline__ void star_rect_shape(const SearchArgs &a, int j, const int *job, int code);   /* (below) */
 template<typename P, int M>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(OCC_ST))) void star_tiny_kernel(SearchArgs a, int chunk)
 {
     const int lane = (int)threadIdx.x;
     small_load_taps<P>(lane, sizeof(P) == 1 ? 8 : a.depth);
-    for (int base = (int)blockIdx.x * chunk; base < a.njobs; base += (int)gridDim.x * chunk)
+    for (int base = xcd_remap((int)blockIdx.x, (int)gridDim.x) * chunk; base < a.njobs; base += (int)gridDim.x * chunk)
     {
         const int j = base + lane;
         int cls = 0;
@@ -2141,11 +2143,22 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(OCC_ST))) vo
         {
             const int d1 = ((const int*)(a.jobs + j))[1], w = d1 & 0xff, h = (d1 >> 8) & 0xff;
             if (!(w == h && (w == a.staged || w == a.staged2))) cls = tiny_class(w, h);
+            /* 16x12 and 12x16, a wave per PU: star_rect_kernel's shapes whose list this kernel screens anyway */
+            if (a.rect && rect_class(w, h) && (w > h ? w : h) == 16) cls = 6;
         }
         if (__ballot(cls != 0) == 0) continue;
         star_tiny_pass<P, M, 3>(a, j, cls == 3);
         star_tiny_pass<P, M, 4>(a, j, cls == 4);
         star_tiny_pass<P, M, 5>(a, j, cls == 5);
+        unsigned long long m = __ballot(cls == 6);
+        while (m)
+        {
+            const int jj = base + (int)__builtin_ctzll(m);
+            m &= m - 1;
+            const int *job = (const int*)(a.jobs + jj);
+            wave_sync();
+            star_rect_shape<16, P, M>(a, jj, job, uni(job[1]) & 0xffff);
+        }
     }
 }
 
@@ -2479,16 +2492,19 @@ __global__ __launch_bounds__(StarBigGeo<S>::THREADS) __attribute__((amdgpu_waves
 
 /* ---------------------------------------------------------------- the same stage for the larger 2NxN / Nx2N / pow-2 partitions
  *
- * star_big_kernel's stage for the other partitions of rect_class (64x32, 32x64, 64x16, 16x64, 32x16, 16x32, 32x8, 8x32,
- * 32x24, 64x48), one wave per PU: a lane looks after W H / 256 (tile, column) pairs for the vertical passes and a strip of as many
+ * star_big_kernel's stage for the other partitions of rect_class (2NxN / Nx2N from 32x16 up, every asymmetric shape from
+ * 16x12 up), one wave per PU: a lane looks after W H / 256 (tile, column) pairs for the vertical passes and as many
  * quad rows for the plain SADs. One kernel for all shapes -- the wave reads its PU's shape and takes that shape's
  * straight-line code -- because the shapes of a device-resident list are not known to the host. */
 template<int W, int H> struct RectGeo
 {
     static constexpr int LTW = W == 8 ? 1 : W == 16 ? 2 : W == 32 ? 3 : 4;
     static constexpr int TW = W / 4;
-    static_assert(W * H % 256 == 0 && (W == 8 || W == 16 || W == 32 || W == 64), "whole pairs per lane, a power of two of tiles per row");
-    static constexpr int ITEMS = W * H / 256;               /* (tile, column) pairs per lane = quad rows per lane */
+    static constexpr int PAIRS = W * H / 4;                 /* (tile, column) pairs = quad rows of the PU */
+    static constexpr int ITEMS = (PAIRS + 63) / 64;         /* of either, per lane */
+    /* a power of two of tiles per row and whole items per lane: a lane's quad rows are a strip, one below the other;
+     * otherwise (12, 24, 48 samples wide, or 16x12) they are every 64th quad row of the PU in raster order */
+    static constexpr bool STRIP = (W == 8 || W == 16 || W == 32 || W == 64) && PAIRS % 64 == 0;
     static constexpr int PROW = H + 10;                     /* int16 rows of a plane column */
     static constexpr int PLANE = W * PROW * 2;
     static constexpr int IPP = (H + 8) * TW;                /* horizontal-pass items per plane */
@@ -2498,20 +2514,26 @@ template<int W, int H> struct RectGeo
     static constexpr int window(int bps) { return (H + 8) * (W + 12) * bps + 8; }
     static constexpr int total(int bps) { return PLANES + (2 * PLANE > window(bps) ? 2 * PLANE : window(bps)) + 32; }
 };
-/* LDS of a launch for PUs up to max_dim samples (32 or 64): the largest of its shapes */
-static inline int star_rect_lds(int max_dim, int bps)
+/* LDS of the kernel for the shapes whose longer side is d samples (16, 32, 64): the largest of them */
+static inline int star_rect_lds(int d, int bps)
 {
-    int a = RectGeo<32, 16>::total(bps), b = RectGeo<16, 32>::total(bps), c = RectGeo<32, 8>::total(bps), d = RectGeo<8, 32>::total(bps);
-    int m = a > b ? a : b;
-    m = c > m ? c : m; m = d > m ? d : m;
-    const int i = RectGeo<32, 24>::total(bps);
-    m = i > m ? i : m;
-    if (max_dim > 32)
+    int m = 0;
+    if (d == 16)
     {
-        int e = RectGeo<64, 32>::total(bps), f = RectGeo<32, 64>::total(bps), g = RectGeo<64, 16>::total(bps), h = RectGeo<16, 64>::total(bps);
-        m = e > m ? e : m; m = f > m ? f : m; m = g > m ? g : m; m = h > m ? h : m;
-        const int k = RectGeo<64, 48>::total(bps);
-        m = k > m ? k : m;
+        const int t[2] = { RectGeo<16, 12>::total(bps), RectGeo<12, 16>::total(bps) };
+        for (int i = 0; i < 2; i++) m = t[i] > m ? t[i] : m;
+    }
+    else if (d == 32)
+    {
+        const int t[6] = { RectGeo<32, 16>::total(bps), RectGeo<16, 32>::total(bps), RectGeo<32, 8>::total(bps), RectGeo<8, 32>::total(bps),
+                           RectGeo<32, 24>::total(bps), RectGeo<24, 32>::total(bps) };
+        for (int i = 0; i < 6; i++) m = t[i] > m ? t[i] : m;
+    }
+    else
+    {
+        const int t[6] = { RectGeo<64, 32>::total(bps), RectGeo<32, 64>::total(bps), RectGeo<64, 16>::total(bps), RectGeo<16, 64>::total(bps),
+                           RectGeo<64, 48>::total(bps), RectGeo<48, 64>::total(bps) };
+        for (int i = 0; i < 6; i++) m = t[i] > m ? t[i] : m;
     }
     return m;
 }
@@ -2567,24 +2589,34 @@ __device__ __forceinline__ void star_rect_pu(const SearchArgs &a, int j, const i
 
     /* the lane's part of the source block: its (tile, column) pairs for the vertical passes, its quad rows for the SADs */
     ColSrc ct[ITEMS];
+    /* a lane beyond the PU's last pair (16x12, 12x16: 48 pairs) measures a pair of the first tile and adds nothing */
+    const bool mine = G::PAIRS % 64 == 0 || lane < G::PAIRS % 64;
 #pragma unroll
     for (int u = 0; u < ITEMS; u++)
     {
-        const int l = lane + 64 * u, t = l >> 2;
-        ct[u].ty = t >> G::LTW; ct[u].col = (t & (G::TW - 1)) * 4 + (l & 3);
+        const int l = (u < ITEMS - 1 || mine) ? lane + 64 * u : (lane & 3), t = l >> 2;
+        ct[u].ty = t / G::TW; ct[u].col = (t % G::TW) * 4 + (l & 3);
         const P AS1 *src = fenc0 + (long)(puy + ct[u].ty * 4) * fstride + pux + ct[u].col;
         uint32_t f[4];
 #pragma unroll
         for (int y = 0; y < 4; y++) f[y] = (uint32_t)src[(long)y * fstride];
         ct[u].f01 = f[0] | (f[1] << 16); ct[u].f23 = f[2] | (f[3] << 16);
     }
-    const int tlx = (lane & (G::TW - 1)) * 4, tly = (lane >> G::LTW) * NQ;
-    typename Px<P>::quad fq[NQ];
-    {
-        const P AS1 *src = fenc0 + (long)(puy + tly) * fstride + pux + tlx;
+    /* the lane's quad rows: row sqy[u] of the PU, samples sqx[u] .. sqx[u] + 3 */
+    int sqx[NQ], sqy[NQ];
 #pragma unroll
-        for (int y = 0; y < NQ; y++) fq[y] = Px<P>::load_g(src + (long)y * fstride);
+    for (int u = 0; u < NQ; u++)
+    {
+        if constexpr (G::STRIP) { sqx[u] = (lane % G::TW) * 4; sqy[u] = (lane / G::TW) * NQ + u; }
+        else
+        {
+            const int q = (u < NQ - 1 || mine) ? lane + 64 * u : 0;
+            sqx[u] = (q % G::TW) * 4; sqy[u] = q / G::TW;
+        }
     }
+    typename Px<P>::quad fq[NQ];
+#pragma unroll
+    for (int y = 0; y < NQ; y++) fq[y] = Px<P>::load_g(fenc0 + (long)(puy + sqy[y]) * fstride + pux + sqx[y]);
     wave_sync();
     int pb = 0;
 #pragma unroll 1
@@ -2595,9 +2627,13 @@ __device__ __forceinline__ void star_rect_pu(const SearchArgs &a, int j, const i
         int v = 0;
         if (((kx | ky) & 3) == 0)
         {
-            const P AS1 *rp = ref0 + roff + (long)__mul24((ky >> 2) + tly, rstride) + (kx >> 2) + tlx;
+            const P AS1 *rp = ref0 + roff + (long)__mul24(ky >> 2, rstride) + (kx >> 2);
 #pragma unroll
-            for (int y = 0; y < NQ; y++) v = Px<P>::sad(fq[y], Px<P>::load_g(rp + (long)y * rstride), v);
+            for (int y = 0; y < NQ; y++)
+            {
+                const int c = Px<P>::sad(fq[y], Px<P>::load_g(rp + (long)__mul24(sqy[y], rstride) + sqx[y]), 0);
+                v += (y < NQ - 1 || mine) ? c : 0;
+            }
         }
         else
         {
@@ -2606,7 +2642,7 @@ __device__ __forceinline__ void star_rect_pu(const SearchArgs &a, int j, const i
             const int *tp = (const int*)(x265amd_smem + SM_TAPS) + (kx & 3) * 12;
             for (int item = lane; item < G::IPP; item += 64)
             {
-                const int r = item >> G::LTW, q = item & (G::TW - 1);
+                const int r = item / G::TW, q = item % G::TW;
                 hps_quad(src + (__mul24(r, rstride) + 4 * q), tp, (int16_t*)(x265amd_smem + poff) + (4 * q) * G::PROW + r, G::PROW, depth);
             }
             wave_sync();
@@ -2615,7 +2651,8 @@ __device__ __forceinline__ void star_rect_pu(const SearchArgs &a, int j, const i
             {
                 int o[4];
                 column_rows<4>(poff, G::PROW, 0, ky & 3, ct[u], depth, o);
-                v += small_rows_cost(o[0], o[1], o[2], o[3], false, ct[u], lane & 3, depth);
+                const int c = small_rows_cost(o[0], o[1], o[2], o[3], false, ct[u], lane & 3, depth);
+                v += (u < ITEMS - 1 || mine) ? c : 0;
             }
             pb ^= 1;
         }
@@ -2663,14 +2700,20 @@ __device__ __forceinline__ void star_rect_pu(const SearchArgs &a, int j, const i
         constexpr PatTable<M> T = PatTable<M>();
         constexpr int NP = PatPoints<M>::N;
         const int room_l = bmx - mnx, room_r = mxx - bmx, room_u = bmy - mny, room_d = mxy - bmy;
-        const int wbase = woff + tly * WP + tlx * BPS;
+        /* (a strip's rows are the first row's address plus a constant: reads shared between points are made once) */
+        int wbase[NQ];
+#pragma unroll
+        for (int y2 = 0; y2 < NQ; y2++) wbase[y2] = woff + (G::STRIP ? sqy[0] : sqy[y2]) * WP + sqx[y2] * BPS;
 #pragma unroll
         for (int p = 0; p < NP; p++)
         {
             int v = 0;
 #pragma unroll
             for (int y2 = 0; y2 < NQ; y2++)
-                v = Px<P>::sad(fq[y2], lds_quad_const<P>(wbase, (4 + T.dy[p] + y2) * WP + (4 + T.dx[p]) * BPS), v);
+            {
+                const int c = Px<P>::sad(fq[y2], lds_quad_const<P>(wbase[y2], (4 + T.dy[p] + (G::STRIP ? y2 : 0)) * WP + (4 + T.dx[p]) * BPS), 0);
+                v += (y2 < NQ - 1 || mine) ? c : 0;
+            }
             /* STAR: the reference tests only the bounds a point can cross (motion.cpp:330-452); the other patterns'
              * points are measured unchecked */
             const bool okx = M != X265AMD_STAR || T.dx[p] == 0 || (T.dx[p] < 0 ? room_l >= -T.dx[p] : room_r >= T.dx[p]);
@@ -2714,46 +2757,75 @@ __device__ __forceinline__ void star_rect_pu(const SearchArgs &a, int j, const i
         nsad += npts;
         over = F.rounds >= 3;
     }
-    if (lane != 0) return;
-    int *res = (int*)(a.results + j);
-    a.mark[j] = !over;
-    if (!over)
+    if (lane == 0)
     {
-        F.store(a.state + 8 * (long)j, bprecost, bpx, bpy, nsad, nsub);
-        res[2] = (int)SMALL_RESUME;
-        return;
+        int *res = (int*)(a.results + j);
+        a.mark[j] = !over;
+        if (!over)
+        {
+            F.store(a.state + 8 * (long)j, bprecost, bpx, bpy, nsad, nsub);
+            res[2] = (int)SMALL_RESUME;
+        }
+        else
+        {
+            int qx, qy;
+            if (bprecost < bcost) { qx = bpx; qy = bpy; bcost = bprecost; }
+            else { qx = as_i16(bmx << 2); qy = as_i16(bmy << 2); }
+            res[0] = (qx & 0xffff) | (qy << 16);
+            res[1] = bcost;
+            res[2] = (int)nsad;
+            res[3] = (int)nsub;
+        }
     }
-    int qx, qy;
-    if (bprecost < bcost) { qx = bpx; qy = bpy; bcost = bprecost; }
-    else { qx = as_i16(bmx << 2); qy = as_i16(bmy << 2); }
-    res[0] = (qx & 0xffff) | (qy << 16);
-    res[1] = bcost;
-    res[2] = (int)nsad;
-    res[3] = (int)nsub;
 }
 
-template<typename P, int M>
+/* D: the longer side of the shapes this instance takes (32 or 64) -- a kernel per class, so that the smaller shapes do not
+ * run at the register count of 48x64's twelve pairs per lane. The two shapes with a longer side of 16 are taken by
+ * star_tiny_kernel, which screens a max_dim-16 list anyway. */
+template<int D, typename P, int M>
+__device__ __forceinline__ void star_rect_shape(const SearchArgs &a, int j, const int *job, int code);
+
+template<typename P, int M, int D>
 __global__ __launch_bounds__(64) void star_rect_kernel(SearchArgs a)
 {
     const int j = xcd_remap((int)blockIdx.x, a.njobs);
     if (j >= a.njobs) return;
     const int *job = (const int*)(a.jobs + j);
     const int code = uni(job[1]) & 0xffff, w = code & 0xff, h = code >> 8;
-    if (!rect_class(w, h) || (w > h ? w : h) > a.max_dim) return;
+    if (!rect_class(w, h) || (w > h ? w : h) != D) return;
     small_load_taps<P>((int)threadIdx.x, sizeof(P) == 1 ? 8 : a.depth);
-    switch (code)
-    {
-    case RectGeo<32, 16>::SIZE_CODE: star_rect_pu<32, 16, P, M>(a, j, job); break;
-    case RectGeo<16, 32>::SIZE_CODE: star_rect_pu<16, 32, P, M>(a, j, job); break;
-    case RectGeo<32, 8>::SIZE_CODE: star_rect_pu<32, 8, P, M>(a, j, job); break;
-    case RectGeo<8, 32>::SIZE_CODE: star_rect_pu<8, 32, P, M>(a, j, job); break;
-    case RectGeo<64, 32>::SIZE_CODE: star_rect_pu<64, 32, P, M>(a, j, job); break;
-    case RectGeo<32, 64>::SIZE_CODE: star_rect_pu<32, 64, P, M>(a, j, job); break;
-    case RectGeo<64, 16>::SIZE_CODE: star_rect_pu<64, 16, P, M>(a, j, job); break;
-    case RectGeo<16, 64>::SIZE_CODE: star_rect_pu<16, 64, P, M>(a, j, job); break;
-    case RectGeo<32, 24>::SIZE_CODE: star_rect_pu<32, 24, P, M>(a, j, job); break;
-    case RectGeo<64, 48>::SIZE_CODE: star_rect_pu<64, 48, P, M>(a, j, job); break;
-    }
+    star_rect_shape<D, P, M>(a, j, job, code);
+}
+
+template<int D, typename P, int M>
+__device__ __forceinline__ void star_rect_shape(const SearchArgs &a, int j, const int *job, int code)
+{
+    if constexpr (D == 16)
+        switch (code)
+        {
+        case RectGeo<16, 12>::SIZE_CODE: star_rect_pu<16, 12, P, M>(a, j, job); break;
+        case RectGeo<12, 16>::SIZE_CODE: star_rect_pu<12, 16, P, M>(a, j, job); break;
+        }
+    else if constexpr (D == 32)
+        switch (code)
+        {
+        case RectGeo<32, 16>::SIZE_CODE: star_rect_pu<32, 16, P, M>(a, j, job); break;
+        case RectGeo<16, 32>::SIZE_CODE: star_rect_pu<16, 32, P, M>(a, j, job); break;
+        case RectGeo<32, 8>::SIZE_CODE: star_rect_pu<32, 8, P, M>(a, j, job); break;
+        case RectGeo<8, 32>::SIZE_CODE: star_rect_pu<8, 32, P, M>(a, j, job); break;
+        case RectGeo<32, 24>::SIZE_CODE: star_rect_pu<32, 24, P, M>(a, j, job); break;
+        case RectGeo<24, 32>::SIZE_CODE: star_rect_pu<24, 32, P, M>(a, j, job); break;
+        }
+    else
+        switch (code)
+        {
+        case RectGeo<64, 32>::SIZE_CODE: star_rect_pu<64, 32, P, M>(a, j, job); break;
+        case RectGeo<32, 64>::SIZE_CODE: star_rect_pu<32, 64, P, M>(a, j, job); break;
+        case RectGeo<64, 16>::SIZE_CODE: star_rect_pu<64, 16, P, M>(a, j, job); break;
+        case RectGeo<16, 64>::SIZE_CODE: star_rect_pu<16, 64, P, M>(a, j, job); break;
+        case RectGeo<64, 48>::SIZE_CODE: star_rect_pu<64, 48, P, M>(a, j, job); break;
+        case RectGeo<48, 64>::SIZE_CODE: star_rect_pu<48, 64, P, M>(a, j, job); break;
+        }
 }
 
 } // namespace x265amd
