@@ -1234,6 +1234,24 @@ __device__ __forceinline__ void refine_tiny_pass(const SearchArgs &a, int jmine,
                 const int tx = as_i16(qx + dx * step), ty = as_i16(qy + dy * step);
                 int mvc = 0;
                 if (active) mvc = ((int)ctab[tx - mvpx] + (int)ctab[ty - mvpy]) & 0xffff;
+                /* half-pel rounds: (dx, -1) and (dx, +1) follow each other in the table and are one row apart in the same
+                 * plane and phase -- measured together, five vertical sums instead of eight */
+                if (step == 2 && i >= 1 && dy == -1 && c + 1 < K && nib(SQY, i + 1) == 1 && nib(SQX, i + 1) == dx)
+                {
+                    const int ty2 = as_i16(qy + step);
+                    int mvc2 = 0;
+                    if (active) mvc2 = ((int)ctab[tx - mvpx] + (int)ctab[ty2 - mvpy]) & 0xffff;
+                    int o[5];
+                    column_rows<5>(pbase + (dx + 1) * L::PLANE, prow, (ty >> 2) - ymin, ty & 3, ct, depth, o);
+                    int va = small_rows_cost(o[0], o[1], o[2], o[3], satd, ct, l & 3, depth);
+                    int vb = small_rows_cost(o[1], o[2], o[3], o[4], satd, ct, l & 3, depth);
+                    va = seg_sum(va, LG); vb = seg_sum(vb, LG);
+                    const int ca = (satd ? va >> 1 : va) + mvc, cb = (satd ? vb >> 1 : vb) + mvc2;
+                    if (ca < best) { best = ca; bdir = i; }
+                    if (cb < best) { best = cb; bdir = i + 1; }
+                    c++;
+                    continue;
+                }
                 int o[4];
                 column_rows<4>(pbase + (dx + 1) * L::PLANE, prow, (ty >> 2) - ymin, ty & 3, ct, depth, o);
                 int v = small_rows_cost(o[0], o[1], o[2], o[3], satd, ct, l & 3, depth);
