@@ -202,7 +202,7 @@ def pattern_search_picture(e, dev, width=3840, height=2160, depth=10, method="st
     one launch per PU size (as the headline does), for an engine of `depth` bits. Predictors come from
     the lookahead field of the same pair. Returns ms per picture-reference, the pixel-SAD count and jobs / results."""
     import torch
-    from .engine import HEX
+    from .engine import HEX, SQUARE_ONLY
     from .synth import lowres_dims
     M = 128
     clip = make_clip(width, height, 2, seed=seed, depth=depth)
@@ -226,7 +226,7 @@ def pattern_search_picture(e, dev, width=3840, height=2160, depth=10, method="st
     def launch():
         for (first, cnt, dim) in classes:
             e.search_batch_dev(planes[1], planes[0], d_jobs.data_ptr() + first * 40, cnt, d_res.data_ptr() + first * 16, qp,
-                               METHODS[method], subme, max_pu_dim=dim)
+                               METHODS[method], subme, max_pu_dim=dim | SQUARE_ONLY)      # (a list per size: nothing but its squares)
     ms = _timed(torch, e, dev, launch, reps)
     res = d_res.cpu().numpy().view(RESULT_DTYPE).reshape(-1)
     for l in low:
