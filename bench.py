@@ -780,6 +780,10 @@ def main():
                        "pu_searches_per_step_per_gpu": njobs * B, "lookahead_cus_per_step_per_gpu": ncu * B,
                        "qp": QP, "launch": args.launch,
                        "steps_synchronised": bool(sync_steps),
+                       "job_independence": "the PU jobs of a step are searched as mutually independent: predictors and candidates come "
+                                           "from the lookahead field, not from neighbours' final MVs as in predInterSearch "
+                                           "(TEncSearch.cpp:4268-4292), where a legal batch is (reference x CTU row x frame) wide at "
+                                           "most -- the figure is the engine's ceiling, not an encode-shaped rate (encode_fps is that)",
                        "parallelism": "frame pairs sharded over %d GPU(s), gather of MV records" % world},
             "roofline": headline_roofline(vb, timed_cnt * B, launch_ms, achieved, alg_bytes, traffic, compulsory, kernel),
             "cpu_baseline": cpu,
