@@ -182,6 +182,37 @@ def test_larger_other_partitions_fixed_shape_vs_oracle(request, oracle, mname, d
         e.free_plane(pr)
 
 
+@pytest.mark.parametrize("mname", ["star", "hex", "umh"])
+def test_pu_larger_than_the_launch_is_refused(engine8, oracle, mname):
+    """x265amd_search_batch_dev with max_pu_dim below some PUs of a device-resident list: those PUs get cost -1 (whatever
+    kernel their shape would take in a launch made for them) and every other PU its record."""
+    from x265_amd.engine import RESULT_DTYPE
+    method = METHODS[mname]
+    W, H = 320, 192
+    m = margin_for(method)
+    fenc, ref, org, stride = clip_planes(W, H, 8, "texture", margin=m)
+    pf = engine8.upload_plane(fenc, W, H, m, m, stride)
+    pr = engine8.upload_plane(ref, W, H, m, m, stride)
+    for dim, parts in ((16, [(16, 16), (16, 8), (8, 16), (8, 8), (16, 12), (12, 16), (8, 4), (32, 16), (16, 32), (32, 32), (24, 32), (32, 8), (64, 32)]),
+                       (8, [(8, 8), (8, 4), (4, 8), (16, 8), (8, 16), (16, 16), (16, 4), (4, 16), (16, 12)]),
+                       (32, [(32, 32), (32, 16), (16, 16), (8, 8), (24, 32), (64, 32), (32, 64), (64, 16), (48, 64), (64, 64)])):
+        jobs = random_jobs(np.random.default_rng(700 + dim + method), 150, W, H, method, parts=parts)
+        d_jobs, d_res = engine8.device_alloc(jobs.nbytes), engine8.device_alloc(len(jobs) * RESULT_DTYPE.itemsize)
+        engine8.upload(d_jobs, jobs)
+        engine8.search_batch_dev(pf, pr, d_jobs, len(jobs), d_res, 30, method, 5, max_pu_dim=dim)
+        got = engine8.download(d_res, (len(jobs),), RESULT_DTYPE)
+        engine8.device_free(d_jobs)
+        engine8.device_free(d_res)
+        big = (jobs["w"] > dim) | (jobs["h"] > dim)
+        assert big.any() and (~big).any()
+        assert (got["cost"][big] == -1).all(), (dim, jobs[big][got["cost"][big] != -1][["w", "h"]])
+        mv, cost, sc, qc = oracle_search(oracle, 8, fenc, [ref], org, stride, jobs[~big], 30, method, 5)
+        assert np.array_equal(got["mv"][~big], mv) and np.array_equal(got["cost"][~big], cost), dim
+        assert np.array_equal(got["sad_calls"][~big], sc) and np.array_equal(got["subpel_calls"][~big], qc), dim
+    engine8.free_plane(pf)
+    engine8.free_plane(pr)
+
+
 @pytest.mark.parametrize("depth", [8, 10])
 def test_pairs_in_one_launch_vs_oracle(request, oracle, depth):
     """x265amd_search_batch_pairs: jobs of three (source, reference) pairs of different sizes and strides in one launch,

@@ -154,13 +154,14 @@ __device__ __forceinline__ int tiny_class(int w, int h)
     return a == 32 ? 3 : (a == 64 ? 4 : (a == 128 ? 5 : 0));
 }
 __device__ __forceinline__ bool any_refines(int w, int h) { return w * h >= 128 && !tiny_class(w, h); }
-/* the other partitions star_rect_kernel (me_small.h) takes through a fixed-shape integer stage, a wave per PU: sides of
- * 8 to 64 samples, 64 to 512 (tile, column) pairs, not square; and the large parts of the asymmetric splits */
+/* the PUs star_rect_kernel (me_small.h) takes through a fixed-shape integer stage, a wave per PU: sides of 8 to 64
+ * samples, 64 to 512 (tile, column) pairs; the large parts of the asymmetric splits; and 16x16 / 32x32 PUs, for the lists
+ * of launches made for another size (the callers test that first) */
 __device__ __forceinline__ bool rect_class(int w, int h)
 {
     const bool pw = w == 8 || w == 16 || w == 32 || w == 64, ph = h == 8 || h == 16 || h == 32 || h == 64;
     const int lo = w < h ? w : h, hi = w < h ? h : w;
-    return (pw && ph && w != h && w * h >= 256 && w * h <= 2048) || (4 * lo == 3 * hi && (hi == 16 || hi == 32 || hi == 64));
+    return (pw && ph && w * h >= 256 && w * h <= 2048) || (4 * lo == 3 * hi && (hi == 16 || hi == 32 || hi == 64));
 }
 
 /* sum over each group of 2^l adjacent lanes, left in every lane of the group */

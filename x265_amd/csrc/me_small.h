@@ -54,6 +54,19 @@
 #endif
 namespace x265amd {
 
+/* whether the launch's star_rect_kernel (or, for shapes up to 16 samples, star_tiny_kernel's pass for them) takes a w x h
+ * PU: a shape of rect_class that fits the launch and is not a square of the launch's own fixed-shape sizes */
+__device__ __forceinline__ bool rect_takes(const SearchArgs &a, int w, int h)
+{
+    return a.rect && rect_class(w, h) && (w > h ? w : h) <= a.max_dim && !(w == h && (w == a.staged || w == a.staged2));
+}
+
+/* likewise for star_tiny_kernel's own shapes (a PU larger than the launch's size is refused by the one-wave search) */
+__device__ __forceinline__ bool tiny_takes(const SearchArgs &a, int w, int h)
+{
+    return a.tiny && tiny_class(w, h) && (w > h ? w : h) <= a.max_dim && !(w == h && (w == a.staged || w == a.staged2));
+}
+
 template<int S> struct SmallGeo
 {
     static_assert(S == 8 || S == 16 || S == 32 || S == 64, "square PUs of 8 to 64 samples");
@@ -1471,7 +1484,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(S == 16 ? OC
     const bool sized = (d[1] & 0xffff) == G::SIZE_CODE;
     /* the launch for the list's largest size hands every PU that no fixed-shape launch takes to the one-wave search */
     if (valid && !sized && l == 0 && S == a.staged && (d[1] & 0xffff) != (a.staged2 | (a.staged2 << 8)) &&
-        !(a.tiny && tiny_class(d[1] & 0xff, (d[1] >> 8) & 0xff)) && !(a.rect && rect_class(d[1] & 0xff, (d[1] >> 8) & 0xff)))
+        !tiny_takes(a, d[1] & 0xff, (d[1] >> 8) & 0xff) && !rect_takes(a, d[1] & 0xff, (d[1] >> 8) & 0xff))
     {
         a.results[j].sad_calls = SMALL_REDO;
         a.mark[j] = 1;
@@ -2160,9 +2173,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(OCC_ST))) vo
         if (lane < chunk && j < a.njobs)
         {
             const int d1 = ((const int*)(a.jobs + j))[1], w = d1 & 0xff, h = (d1 >> 8) & 0xff;
-            if (!(w == h && (w == a.staged || w == a.staged2))) cls = tiny_class(w, h);
-            /* 16x12 and 12x16, a wave per PU: star_rect_kernel's shapes whose list this kernel screens anyway */
-            if (a.rect && rect_class(w, h) && (w > h ? w : h) == 16) cls = 6;
+            if (tiny_takes(a, w, h)) cls = tiny_class(w, h);
+            /* 16x12, 12x16 and 16x16, a wave per PU: star_rect_kernel's shapes whose list this kernel screens anyway */
+            if (rect_takes(a, w, h) && (w > h ? w : h) == 16) cls = 6;
         }
         if (__ballot(cls != 0) == 0) continue;
         star_tiny_pass<P, M, 3>(a, j, cls == 3);
@@ -2275,7 +2288,7 @@ __global__ __launch_bounds__(StarBigGeo<S>::THREADS) __attribute__((amdgpu_waves
     {
         /* the launch for the list's largest size hands every PU that no fixed-shape launch takes to the one-wave search */
         if (S == a.staged && (d[1] & 0xffff) != (a.staged2 | (a.staged2 << 8)) && tid == 0 &&
-            !(a.tiny && tiny_class(d[1] & 0xff, (d[1] >> 8) & 0xff)) && !(a.rect && rect_class(d[1] & 0xff, (d[1] >> 8) & 0xff)))
+            !tiny_takes(a, d[1] & 0xff, (d[1] >> 8) & 0xff) && !rect_takes(a, d[1] & 0xff, (d[1] >> 8) & 0xff))
         { a.results[j].sad_calls = SMALL_REDO; a.mark[j] = 1; }
         return;
     }
@@ -2538,14 +2551,14 @@ static inline int star_rect_lds(int d, int bps)
     int m = 0;
     if (d == 16)
     {
-        const int t[2] = { RectGeo<16, 12>::total(bps), RectGeo<12, 16>::total(bps) };
-        for (int i = 0; i < 2; i++) m = t[i] > m ? t[i] : m;
+        const int t[3] = { RectGeo<16, 12>::total(bps), RectGeo<12, 16>::total(bps), RectGeo<16, 16>::total(bps) };
+        for (int i = 0; i < 3; i++) m = t[i] > m ? t[i] : m;
     }
     else if (d == 32)
     {
-        const int t[6] = { RectGeo<32, 16>::total(bps), RectGeo<16, 32>::total(bps), RectGeo<32, 8>::total(bps), RectGeo<8, 32>::total(bps),
-                           RectGeo<32, 24>::total(bps), RectGeo<24, 32>::total(bps) };
-        for (int i = 0; i < 6; i++) m = t[i] > m ? t[i] : m;
+        const int t[7] = { RectGeo<32, 16>::total(bps), RectGeo<16, 32>::total(bps), RectGeo<32, 8>::total(bps), RectGeo<8, 32>::total(bps),
+                           RectGeo<32, 24>::total(bps), RectGeo<24, 32>::total(bps), RectGeo<32, 32>::total(bps) };
+        for (int i = 0; i < 7; i++) m = t[i] > m ? t[i] : m;
     }
     else
     {
@@ -2810,7 +2823,7 @@ __global__ __launch_bounds__(64) void star_rect_kernel(SearchArgs a)
     if (j >= a.njobs) return;
     const int *job = (const int*)(a.jobs + j);
     const int code = uni(job[1]) & 0xffff, w = code & 0xff, h = code >> 8;
-    if (!rect_class(w, h) || (w > h ? w : h) != D) return;
+    if (!rect_takes(a, w, h) || (w > h ? w : h) != D) return;
     small_load_taps<P>((int)threadIdx.x, sizeof(P) == 1 ? 8 : a.depth);
     star_rect_shape<D, P, M>(a, j, job, code);
 }
@@ -2823,6 +2836,7 @@ __device__ __forceinline__ void star_rect_shape(const SearchArgs &a, int j, cons
         {
         case RectGeo<16, 12>::SIZE_CODE: star_rect_pu<16, 12, P, M>(a, j, job); break;
         case RectGeo<12, 16>::SIZE_CODE: star_rect_pu<12, 16, P, M>(a, j, job); break;
+        case RectGeo<16, 16>::SIZE_CODE: star_rect_pu<16, 16, P, M>(a, j, job); break;
         }
     else if constexpr (D == 32)
         switch (code)
@@ -2833,6 +2847,7 @@ __device__ __forceinline__ void star_rect_shape(const SearchArgs &a, int j, cons
         case RectGeo<8, 32>::SIZE_CODE: star_rect_pu<8, 32, P, M>(a, j, job); break;
         case RectGeo<32, 24>::SIZE_CODE: star_rect_pu<32, 24, P, M>(a, j, job); break;
         case RectGeo<24, 32>::SIZE_CODE: star_rect_pu<24, 32, P, M>(a, j, job); break;
+        case RectGeo<32, 32>::SIZE_CODE: star_rect_pu<32, 32, P, M>(a, j, job); break;
         }
     else
         switch (code)
