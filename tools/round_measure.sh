@@ -14,4 +14,5 @@ timeout -k 10 300 python -u tools/rk_bench.py > gpurun_out/${TAG}_rk_bench.txt 2
 timeout -k 10 300 python -u tools/la_bench.py > gpurun_out/${TAG}_la_bench.txt 2>&1
 for m in star hex dia umh; do timeout -k 10 200 python -u tools/pattern_bench.py --method $m >> gpurun_out/${TAG}_pattern_4k.txt 2>&1; done
 timeout -k 10 300 python -u tools/rect_bench.py --pairs 16 --check 6 > gpurun_out/${TAG}_rect_bench.txt 2>&1
+for d in 8 10; do timeout -k 10 100 python -u tools/mixed_bench.py --depth $d >> gpurun_out/${TAG}_mixed_bench.txt 2>&1; done
 bash tools/profile_round.sh $TAG
