@@ -72,7 +72,8 @@ struct SearchArgs
     int ncjobs;
     unsigned char *cmark, *cdone;
     unsigned char *mark;   /* null, or per job: 1 = a STAR kernel handed this PU on (it is in the redo list), 0 = it did not */
-    int list;              /* refinement kernels: 1 = refine the PUs of the redo list instead of those of the job list */
+    int list;              /* refinement kernels: 1 = refine the PUs of the redo list instead of those of the job list;
+                              refine_big_kernel: 2 = `redo` lists the PUs the job-list launch would refine (square_list_kernel) */
     /* family launches: the list of 8x8 PUs carries the parents' list (pjobs ...), whose PU k a wave of
      * star_small_kernel<8> searches along with its children 4 k .. 4 k + 3 where it can; handled[k] says so to both lists'
      * launches (in the children's arguments: written; in the parents': read) */
@@ -138,6 +139,40 @@ __global__ __launch_bounds__(64) void redo_list_kernel(const x265amd_result *res
     for (int k = 0; k < REDO_CHUNK / 64; k++)
     {
         if ((bal[k] >> lane) & 1) redo[REDO_LIST + first + __popcll(bal[k] & ((1ull << lane) - 1))] = base + k * 64 + lane;
+        first += __popcll(bal[k]);
+    }
+}
+
+/* The square PUs of the launch's fixed-shape sizes (w | h << 8 == code1 or code2) that no STAR kernel handed on, as a list
+ * of the redo list's form: for the refinement of a list that may hold few of them, where a workgroup of several waves per
+ * job that leaves at once costs more than the PUs themselves (a 4K picture's 172 020 square PUs of all sizes in one launch:
+ * refine_big_kernel<64> 0.26 ms for 1 980 PUs of its own). */
+__global__ __launch_bounds__(64) void square_list_kernel(const x265amd_job *jobs, const unsigned char *mark, int njobs, int code1, int code2, int *list)
+{
+    const int base = blockIdx.x * REDO_CHUNK, lane = threadIdx.x;
+    unsigned long long bal[REDO_CHUNK / 64];
+    int n = 0;
+#pragma unroll
+    for (int k = 0; k < REDO_CHUNK / 64; k++)
+    {
+        const int j = base + k * 64 + lane;
+        bool take = false;
+        if (j < njobs)
+        {
+            const int code = ((const int*)(jobs + j))[1] & 0xffff;
+            take = (code == code1 || code == code2) && !mark[j];
+        }
+        bal[k] = __ballot(take);
+        n += __popcll(bal[k]);
+    }
+    if (!n) return;
+    int first = 0;
+    if (lane == 0) first = atomicAdd(list, n);
+    first = __builtin_amdgcn_readfirstlane(first);
+#pragma unroll
+    for (int k = 0; k < REDO_CHUNK / 64; k++)
+    {
+        if ((bal[k] >> lane) & 1) list[REDO_LIST + first + __popcll(bal[k] & ((1ull << lane) - 1))] = base + k * 64 + lane;
         first += __popcll(bal[k]);
     }
 }
@@ -879,6 +914,7 @@ struct x265amd_ctx
         void *d_state; size_t state_cap;   /* where the STAR search of a handed-on PU stands (StarFold::store) */
         void *d_mark; size_t mark_cap;     /* handed on by the STAR kernels */
         void *d_handled; size_t handled_cap; /* parents of a family launch: searched along with their children */
+        void *d_squares; size_t squares_cap; /* square_list_kernel's list */
     } bufs[2];
     hipStream_t aux;                   /* second stream of STAR launches: the marked PUs' searches run beside the others' refinement;
                                           made by the first such launch (a context that never searches this way holds no queue for it) */
@@ -1253,6 +1289,23 @@ static int launch_search(x265amd_ctx *c, const SearchArgs &a, int is_lowres, boo
         }
         search_side<P>(c, sl, no_fork ? c->stream : c->aux);
         if (!no_fork) HIPCHK(c, hipEventRecord(c->ev_join, c->aux));
+        /* the squares of a 32 / 64 launch whose list may hold anything: through a list of them (the order of the list is
+         * the blocks' arrival, so a 64x64 PU still finds its children behind it in the job list) */
+        static const bool no_square_list = getenv("X265AMD_NO_SQUARE_LIST") != 0;                /* measurements only */
+        if (sl.b.staged >= 32 && !sl.square_only && !no_square_list)
+        {
+            x265amd_ctx::LaunchBufs &B = c->bufs[0];
+            if (ensure(c, &B.d_squares, &B.squares_cap, sizeof(int) * ((size_t)REDO_LIST + a.njobs))) return X265AMD_EHIP;
+            HIPCHK(c, hipMemsetAsync(B.d_squares, 0, sizeof(int), c->stream));
+            const int code1 = sl.b.staged | (sl.b.staged << 8), code2 = sl.b.staged2 ? sl.b.staged2 | (sl.b.staged2 << 8) : code1;
+            hipLaunchKernelGGL(square_list_kernel, dim3((a.njobs + REDO_CHUNK - 1) / REDO_CHUNK), dim3(64), 0, c->stream,
+                               sl.b.jobs, sl.b.mark, a.njobs, code1, code2, (int*)B.d_squares);
+            SearchArgs l2 = sl.b;
+            l2.list = 2;
+            l2.redo = (int*)B.d_squares;
+            launch_refine<P>(l2, c->stream, a.njobs < 32768 ? a.njobs : 32768);     /* (a workgroup per PU up to there) */
+        }
+        else
         launch_refine<P>(sl.b, c->stream, 0);
         /* (the PUs star_tiny_kernel / star_rect_kernel ended; the others are in the list) */
         if (sl.b.rect) launch_any<P>(sl.b, c->stream, 0);
@@ -1511,6 +1564,7 @@ void x265amd_destroy(x265amd_ctx *c)
         if (c->bufs[i].d_state) (void)hipFree(c->bufs[i].d_state);
         if (c->bufs[i].d_mark) (void)hipFree(c->bufs[i].d_mark);
         if (c->bufs[i].d_handled) (void)hipFree(c->bufs[i].d_handled);
+        if (c->bufs[i].d_squares) (void)hipFree(c->bufs[i].d_squares);
     }
     if (c->aux)
     {

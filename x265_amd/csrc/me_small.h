@@ -736,9 +736,9 @@ __device__ __forceinline__ void refine_big_pu(const SearchArgs &a, int j)
     /* a PU whose full-pel cost is 0 is not refined (motion.cpp:1073-1076), a negative cost marks a job that was
      * refused; PUs of other sizes are final already */
     if ((d1 & 0xffff) != G::SIZE_CODE || bcost <= 0) return;
-    if (!a.list && a.done && a.done[j]) return;     /* refined together with its parent already */
+    if (a.list != 1 && a.done && a.done[j]) return;     /* refined together with its parent already */
     /* a PU the STAR kernels handed on is refined by the list-driven launch that follows its search */
-    if (!a.list && a.mark && a.mark[j]) return;
+    if (a.list != 1 && a.mark && a.mark[j]) return;
     const P AS1 *fenc0, *ref0;
     int fstride, rstride;
     small_planes<P>(a, d1, fenc0, fstride, ref0, rstride);
@@ -757,7 +757,7 @@ __device__ __forceinline__ void refine_big_pu(const SearchArgs &a, int j)
     if constexpr (S == 64)
     {
         /* (the list-driven launch refines PU by PU: the children of a marked parent were refined on their own) */
-        if (!a.list && a.done && j + 4 < a.njobs)
+        if (a.list != 1 && a.done && j + 4 < a.njobs)
         {
             quad = true;
 #pragma unroll
@@ -931,7 +931,8 @@ template<int S, typename P>
 __global__ __launch_bounds__(BigGeo<S>::THREADS) __attribute__((amdgpu_waves_per_eu(S == 64 ? OCC_RB64 : OCC_RB32))) void refine_big_kernel(SearchArgs a)
 {
     small_load_taps<P>((int)threadIdx.x, sizeof(P) == 1 ? 8 : a.depth);
-    /* a workgroup per PU of the launch; or (a.list) the launch's list of marked PUs, every workgroup walking it */
+    /* a workgroup per PU of the launch; or (a.list) a list of its PUs, every workgroup walking it: the marked PUs (1), or
+     * the unmarked squares of the launch's sizes of a list that may hold few of them (2: otherwise as without a list) */
     const int n = a.list ? uni(a.redo[0]) : a.njobs;
     for (int k = (int)blockIdx.x; k < n; k += a.list ? (int)gridDim.x : n)
     {
