@@ -852,6 +852,17 @@ def main():
                 if not all(np.array_equal(exp[k_], kr[pick][k_]) for k_ in ("mv", "cost", "sad_calls", "subpel_calls")):
                     print("PARITY FAILURE: 2NxN / Nx2N partitions: GPU results differ from the oracle", file=sys.stderr)
                     sys.exit(2)
+                progress("other paths: the headline's searches CTU row by CTU row")
+                e_row = Engine(local_rank, 8)
+                wf = measure.ctu_row_wavefront(es, e_row, dev, pairs=32)
+                e_row.close()
+                pick = np.random.default_rng(10).choice(len(wf["jobs"]), 256, replace=False)
+                cur_, org_, st_ = pad_plane(wf["frames"][1], 128)
+                ref_, _, _ = pad_plane(wf["frames"][0], 128)
+                exp = orc.me_search_batch(orc.make_ctx(8, cur_, org_, st_, [ref_], org_, st_, False, 32, METHODS["star"], 5), wf["jobs"][pick])
+                if not all(np.array_equal(exp[k_], wf["results"][pick][k_]) for k_ in ("mv", "cost", "sad_calls", "subpel_calls")):
+                    print("PARITY FAILURE: CTU-row launches: GPU results differ from the oracle", file=sys.stderr)
+                    sys.exit(2)
                 progress("other paths: motion compensation, bi-prediction")
                 mc = measure.mc_picture(es, dev)
                 bp = measure.bipred_picture(es, dev)
@@ -894,6 +905,15 @@ def main():
                     "me1080p_hex": dict(kinds["hex"], workload="the headline's PUs and textured clip searched with --me hex (the reference's default "
                                         "method, BASELINE configs[0]): first hexagon ring + closing square in the fixed-shape kernels, PUs whose ring "
                                         "moves (marked_frac) walk on one per wave; 8 frame pairs, classes one after the other on one stream"),
+                    "me1080p_ctu_rows": {"workload": "the headline's searches (same clip, same 32 frame pairs, same PUs) in the shape an encode "
+                                                     "can batch them: one CTU row of every frame pair per dependent step (predInterSearch needs "
+                                                     "the row above's final MVs for its predictors, TEncSearch.cpp:4268-4292), two launches side "
+                                                     "by side per row as in the headline, both waited for on the host before the next row; no "
+                                                     "lookahead launch beside them",
+                                         "ctu_rows": wf["rows"], "ms_per_32_frame_pairs": wf["ms"], "pu_searches": wf["pus"],
+                                         "ms_per_row_step": wf["ms"] / wf["rows"],
+                                         "value": wf["pixel_sads"] / wf["ms"] / 1e6, "unit": "Gpixel-SAD/s",
+                                         "parity": "256 PUs of the first frame pair (seeded) compared with the oracle"},
                     "me1080p_rect": {"workload": "the 2NxN and Nx2N partitions of every CU of the headline's clip (1080p 8-bit, --me star "
                                                  "--merange 57 --subme 5, 8 frame pairs): one launch per CU size with both shapes mixed; "
                                                  "16x8 / 8x16 and 8x4 / 4x8 run two and eight PUs per wave (star_tiny_kernel, "

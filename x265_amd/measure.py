@@ -492,3 +492,78 @@ def other_partitions_clip(e, dev, pairs=8, width=1920, height=1080, method="star
     for p in planes:
         e.free_plane(p)
     return out, (clip[0], clip[1], np.concatenate([k[0] for k in keep]), np.concatenate([k[1] for k in keep]))
+
+
+def ctu_row_wavefront(e, e2, dev, pairs=32, width=1920, height=1080, method="star", subme=5, merange=57, reps=3, seed=1234, qp=32):
+    """The headline's searches in the shape an encoder can batch them: a CTU row needs the MVs of the row above before its
+    predictors are known (predInterSearch takes them from the neighbours' final MVs, TEncSearch.cpp:4268-4292), so the
+    legal batch is one CTU row of every frame pair in flight. Per row two launches side by side, as the headline's (the
+    64x64 PUs with their 32x32 children on `e`, the 16x16 PUs with the list of their 8x8 children on `e2`), both waited
+    for before the next row starts; the predictors still come from the lookahead field (the dependency is kept as a
+    barrier, not as data). Returns ms for all rows of all pairs, the PU and pixel-SAD counts and the jobs / results of pair 0."""
+    import torch
+    from .engine import HEX, SQUARE_ONLY
+    from .synth import lowres_dims
+    M = 128
+    clip = make_clip(width, height, pairs + 1, seed=seed)
+    planes = []
+    for f in clip:
+        buf, org, stride = pad_plane(f, M)
+        planes.append(e.upload_plane(buf, width, height, M, M, stride))
+    low = [e.lowres_init(p) for p in planes]
+    lw, lh, wcu, hcu = lowres_dims(width, height)
+    la_mvs, _, _ = e.lookahead_fields([(low[i + 1][0], low[i]) for i in range(pairs)], wcu, hcu, 12, HEX, 1, 16)
+    host_jobs = [workload.square_pu_jobs(width, height, la_mvs[i], wcu, hcu, merange) for i in range(pairs)]
+    d_pairs = e.pairs_upload([(planes[i + 1], planes[i]) for i in range(pairs)])
+    rows = []
+    nrows = (height + 63) // 64
+    for r in range(nrows):
+        sel = [np.flatnonzero(j["pu_y"] // 64 == r) for j in host_jobs]
+        row_jobs = [j[s_] for j, s_ in zip(host_jobs, sel)]
+        big, big_index = workload.class_job_list(row_jobs, (64, 32), families=True)
+        pj, pi, kj, ki = workload.family_lists(row_jobs, 16)
+        fam, fam_index, npar = np.concatenate([pj, kj]), np.concatenate([pi, ki]), len(pj)
+        dev_lists = []
+        for cj in (big, fam):
+            n = len(cj)
+            dev_lists.append((torch.from_numpy(cj.view(np.uint8).reshape(n, -1).copy()).to(dev),
+                              torch.zeros((n, RESULT_DTYPE.itemsize), dtype=torch.uint8, device=dev), n))
+        rows.append((dev_lists, npar, big, big_index, fam, fam_index, sel))
+    torch.cuda.synchronize()
+
+    def step():
+        for (dev_lists, npar, *_rest) in rows:
+            (bj, br, bn), (fj, fr, fn) = dev_lists
+            if bn:
+                e.search_batch_pairs_dev(d_pairs, pairs, bj.data_ptr(), bn, br.data_ptr(), qp, METHODS[method], subme, max_pu_dim=64 | SQUARE_ONLY)
+            e2.search_batch_pairs_family_dev(d_pairs, pairs, fj.data_ptr(), npar, fr.data_ptr(), fj.data_ptr() + 40 * npar, fn - npar,
+                                             fr.data_ptr() + 16 * npar, qp, subme, METHODS[method])
+            e.sync()
+            e2.sync()
+
+    import time
+    step()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        step()
+    ms = (time.perf_counter() - t0) / reps * 1e3
+    pus = sads = 0
+    keep_j, keep_r = [], []
+    for (dev_lists, npar, big, big_index, fam, fam_index, sel) in rows:
+        for (dj, dr, n), cj, index in zip(dev_lists, (big, fam), (big_index, fam_index)):
+            if not n:
+                continue
+            res = dr.cpu().numpy().view(RESULT_DTYPE).reshape(-1)
+            pus += n
+            sads += workload.pixel_sads(cj, res)
+            first = index[:, 0] == 0
+            keep_j.append(cj[first])
+            keep_r.append(res[first])
+    e.device_free(d_pairs)
+    for l in low:
+        for p in l:
+            e.free_plane(p)
+    for p in planes:
+        e.free_plane(p)
+    return {"ms": ms, "rows": nrows, "pus": pus, "pixel_sads": sads, "frames": (clip[0], clip[1]),
+            "jobs": np.concatenate(keep_j), "results": np.concatenate(keep_r)}
