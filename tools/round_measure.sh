@@ -15,4 +15,5 @@ timeout -k 10 300 python -u tools/la_bench.py > gpurun_out/${TAG}_la_bench.txt 2
 for m in star hex dia umh; do timeout -k 10 200 python -u tools/pattern_bench.py --method $m >> gpurun_out/${TAG}_pattern_4k.txt 2>&1; done
 timeout -k 10 300 python -u tools/rect_bench.py --pairs 16 --check 6 > gpurun_out/${TAG}_rect_bench.txt 2>&1
 for d in 8 10; do timeout -k 10 100 python -u tools/mixed_bench.py --depth $d >> gpurun_out/${TAG}_mixed_bench.txt 2>&1; done
+for p in 32 8 1; do GPU_MAX_HW_QUEUES=8 timeout -k 10 100 python -u tools/rows_bench.py --pairs $p >> gpurun_out/${TAG}_rows_bench.txt 2>&1; done
 bash tools/profile_round.sh $TAG

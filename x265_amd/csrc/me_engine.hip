@@ -1281,10 +1281,10 @@ static int launch_search(x265amd_ctx *c, const SearchArgs &a, int is_lowres, boo
         /* The PUs handed on are few as a rule and each a long chain of dependent steps in one wave: their
          * searches and refinement run on the context's second stream while this one refines all the others. */
         static const bool never_fork = getenv("X265AMD_NO_FORK") != 0;                           /* measurements only */
-        static const int fork_min = getenv("X265AMD_FORK_MIN") ? atoi(getenv("X265AMD_FORK_MIN")) : 6144;
+        static const int fork_min = getenv("X265AMD_FORK_MIN") ? atoi(getenv("X265AMD_FORK_MIN")) : 2048;
         /* a short list is a chain of short kernels either way, and the two waits between the streams cost more than the
-         * overlap gives (the 1 200 large PUs of a CTU row of 8 frame pairs: 0.23 ms per row forked, 0.17 in a row; from
-         * some ten thousand PUs on the fork pays) */
+         * overlap gives (the 1 200 large PUs of a CTU row of 8 frame pairs: 0.23 ms per row forked, 0.17 in a row; at
+         * 4 800 PUs the two forms measure alike, from some ten thousand on the fork pays) */
         const bool no_fork = never_fork || a.njobs < fork_min;
         if (!no_fork)
         {
